@@ -1,0 +1,260 @@
+/*
+ * ig_detmath.h -- the arithmetic contract of the instaGRAAL likelihood path.
+ *
+ * Everything the per-contact Rippe/Poisson term needs (powf, expf, log10, the
+ * fixed-point quantiser and the exact limb accumulator) written ONLY with
+ * operations that IEEE-754 defines bit-for-bit: + - * / fma, integer ops and
+ * int<->float conversions.  The same header is compiled by gcc (CPU oracle,
+ * -mfma -ffp-contract=off) and by hipcc for gfx950 (-ffp-contract=off), so a
+ * term evaluated on the host and on an MI355X is the same 64-bit pattern and
+ * sums of quantised terms are order-independent integers.  That is what makes
+ * "identical argmax / identical fragment order" a provable property instead of
+ * a hope (SURVEY.md section 7 "Hard parts": libm differences, atomics order).
+ *
+ * Reference arithmetic being restated (file:line under /root/reference/src/instagraal):
+ *   kernels/kernel_sparse_adapt.cu:111-124  factorial()
+ *   kernels/kernel_sparse_adapt.cu:153-163  rippe_contacts()
+ *   kernels/kernel_sparse_adapt.cu:200-225  rippe_contacts_circ()
+ *   kernels/kernel_sparse_adapt.cu:251-270  evaluate_likelihood_pxl_double()
+ *   kernels/kernel_sparse_adapt.cu:4172-4208, 4315-4353, 4426-4462  per-contact term
+ *   kernels/kernel_sparse_adapt.cu:3882-3899, 3955-3972           zero-pixel term
+ * The reference calls CUDA's powf/expf/log10; those are replaced here by
+ * double-precision range-reduction + polynomial evaluations whose result,
+ * rounded to the reference's precision class (float for P(s), double for the
+ * Poisson term), is within 1 ulp of the correctly rounded value.
+ */
+#ifndef IG_DETMATH_H
+#define IG_DETMATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define IG_HD __host__ __device__ __forceinline__
+#else
+#define IG_HD static inline
+#endif
+
+#ifdef __cplusplus
+#define IG_BITCAST_FN 1
+#endif
+
+/* ---- bit casts ------------------------------------------------------- */
+IG_HD uint64_t ig_d2u(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
+IG_HD double ig_u2d(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
+IG_HD uint32_t ig_f2u(float x) { uint32_t u; __builtin_memcpy(&u, &x, 4); return u; }
+IG_HD float ig_u2f(uint32_t u) { float x; __builtin_memcpy(&x, &u, 4); return x; }
+
+IG_HD double ig_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+#define IG_INF (ig_u2d(0x7ff0000000000000ULL))
+#define IG_NAN (ig_u2d(0x7ff8000000000000ULL))
+#define IG_INFF (ig_u2f(0x7f800000u))
+#define IG_NANF (ig_u2f(0x7fc00000u))
+
+IG_HD int ig_isnan(double x) { return (ig_d2u(x) & 0x7fffffffffffffffULL) > 0x7ff0000000000000ULL; }
+IG_HD int ig_isinf(double x) { return (ig_d2u(x) & 0x7fffffffffffffffULL) == 0x7ff0000000000000ULL; }
+IG_HD int ig_isnanf(float x) { return (ig_f2u(x) & 0x7fffffffu) > 0x7f800000u; }
+IG_HD int ig_isinff(float x) { return (ig_f2u(x) & 0x7fffffffu) == 0x7f800000u; }
+
+/* fmaxf semantics of CUDA's max(float,float): a NaN operand loses. */
+IG_HD float ig_fmaxf(float a, float b)
+{
+    if (ig_isnanf(a)) return b;
+    if (ig_isnanf(b)) return a;
+    return a > b ? a : b;
+}
+
+/* ---- log2 of a positive, finite, normal double ------------------------
+ * x = 2^e * m, m in (sqrt(1/2), sqrt(2)];  ln m = 2 atanh(f), f=(m-1)/(m+1),
+ * |f| <= 0.1716; odd series to f^23 (truncation < 2e-19 relative). */
+IG_HD double ig_log2_pos(double x)
+{
+    uint64_t b = ig_d2u(x);
+    int e = (int)((b >> 52) & 0x7ffu) - 1023;
+    double m = ig_u2d((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+    if (m > 1.4142135623730951) {
+        m = m * 0.5;
+        e += 1;
+    }
+    double f = (m - 1.0) / (m + 1.0);
+    double f2 = f * f;
+    double p = 1.0 / 23.0;
+    p = ig_fma(p, f2, 1.0 / 21.0);
+    p = ig_fma(p, f2, 1.0 / 19.0);
+    p = ig_fma(p, f2, 1.0 / 17.0);
+    p = ig_fma(p, f2, 1.0 / 15.0);
+    p = ig_fma(p, f2, 1.0 / 13.0);
+    p = ig_fma(p, f2, 1.0 / 11.0);
+    p = ig_fma(p, f2, 1.0 / 9.0);
+    p = ig_fma(p, f2, 1.0 / 7.0);
+    p = ig_fma(p, f2, 1.0 / 5.0);
+    p = ig_fma(p, f2, 1.0 / 3.0);
+    p = ig_fma(p, f2, 1.0);
+    double lnm = (2.0 * f) * p;
+    /* 1/ln2 split: hi part has 32 significant bits so lnm*hi is nearly exact */
+    return ig_fma(lnm, 1.4426950408889634, (double)e);
+}
+
+/* ---- 2^y for |y| <= 1022 (clamped outside) ---------------------------- */
+IG_HD double ig_exp2(double y)
+{
+    if (ig_isnan(y)) return IG_NAN; /* canonical NaN: payloads differ between targets */
+    if (y > 1000.0) return IG_INF;
+    if (y < -1000.0) return 0.0;
+    double k = __builtin_rint(y); /* round-half-even, exact */
+    double r = y - k;             /* exact, |r| <= 0.5 */
+    double t = r * 0.6931471805599453;
+    double p = 1.0 / 6227020800.0; /* 1/13! */
+    p = ig_fma(p, t, 1.0 / 479001600.0);
+    p = ig_fma(p, t, 1.0 / 39916800.0);
+    p = ig_fma(p, t, 1.0 / 3628800.0);
+    p = ig_fma(p, t, 1.0 / 362880.0);
+    p = ig_fma(p, t, 1.0 / 40320.0);
+    p = ig_fma(p, t, 1.0 / 5040.0);
+    p = ig_fma(p, t, 1.0 / 720.0);
+    p = ig_fma(p, t, 1.0 / 120.0);
+    p = ig_fma(p, t, 1.0 / 24.0);
+    p = ig_fma(p, t, 1.0 / 6.0);
+    p = ig_fma(p, t, 0.5);
+    p = ig_fma(p, t, 1.0);
+    p = ig_fma(p, t, 1.0);
+    int ki = (int)k;
+    double sc = ig_u2d((uint64_t)(ki + 1023) << 52);
+    return p * sc;
+}
+
+/* ---- the three libm calls of the reference kernels --------------------- */
+
+/* powf(x, y) as used by KA:159, 217 (x = distance or n, y = slope / 2.0f / -3.0f / n). */
+IG_HD float ig_powf(float x, float y)
+{
+    if (ig_isnanf(x) || ig_isnanf(y)) return IG_NANF;
+    if (y == 0.0f) return 1.0f;
+    if (y == 2.0f) return x * x;
+    if (x < 0.0f) return IG_NANF; /* non-integer exponents only on this path */
+    if (x == 0.0f) return y < 0.0f ? IG_INFF : 0.0f;
+    if (ig_isinff(x)) return y < 0.0f ? 0.0f : IG_INFF;
+    return (float)ig_exp2((double)y * ig_log2_pos((double)x));
+}
+
+/* expf(x) as used by KA:121, 159, 217. */
+IG_HD float ig_expf(float x)
+{
+    if (ig_isnanf(x)) return IG_NANF;
+    return (float)ig_exp2((double)x * 1.4426950408889634);
+}
+
+/* log10(x), double, as used by KA:259-262. */
+IG_HD double ig_log10(double x)
+{
+    if (ig_isnan(x)) return IG_NAN;
+    if (x < 0.0) return IG_NAN;
+    if (x == 0.0) return -IG_INF;
+    if (ig_isinf(x)) return x;
+    return ig_log2_pos(x) * 0.30102999566398120;
+}
+
+/* ---- model ------------------------------------------------------------- */
+typedef struct ig_params {
+    float kuhn, lm, c1, slope, d, d_max, fact, v_inter; /* KA:91-100, same order */
+} ig_params;
+
+/* KA:153-163 */
+IG_HD float ig_rippe(float s, const ig_params p)
+{
+    float result = 0.0f;
+    if ((s > 0.0f) && (s < p.d_max)) {
+        float pw = ig_powf(s, p.slope);
+        float t = s * p.lm / p.kuhn;
+        float e = ig_expf((p.d - 2.0f) / (ig_powf(t, 2.0f) + p.d));
+        result = (p.c1 * pw * e) * p.fact;
+    }
+    return ig_fmaxf(result, p.v_inter);
+}
+
+/* KA:200-225 (note the clamp with d_max, quirk Q6) */
+IG_HD float ig_rippe_circ(float s, float s_tot, const ig_params p)
+{
+    float result = 0.0f;
+    if ((s > 0.0f) && (s < p.d_max)) {
+        float K = p.lm / p.kuhn;
+        float n = K * s * (s_tot - s) / s_tot;
+        result = (ig_powf(p.kuhn, -3.0f) * ig_powf(n, p.slope) *
+                  ig_expf((p.d - 2.0f) / (ig_powf(n, 2.0f) + p.d))) *
+                 p.fact;
+    }
+    return ig_fmaxf(result, p.d_max);
+}
+
+/* log10(ob!) part of KA:251-270; ob >= 1. `lgf_small` = table of
+ * log10((double)factorial_f32(ob)) for ob = 0..14 (KA:111-124), built once on
+ * the host by ig_build_lgf_table(). */
+IG_HD double ig_lgfact(int ob, const double* lgf_small)
+{
+    if (ob < 15) return lgf_small[ob];
+    double o = (double)ob;
+    /* ob*log10(ob) - ob + log10(sqrt(2*pi*ob)); the sqrt is folded into the log */
+    return (o * ig_log10(o) - o) + 0.5 * ig_log10(o * 2.0 * 3.14159265358979323846);
+}
+
+/* The float literal 0.43429448190325182f of KA:4019, 4208, 4353, 4462. */
+#define IG_LOG_E_F ((double)0.43429448190325182f)
+
+/* One non-zero pixel: KA:4207-4208 / 4352-4353 / 4462.
+ * ex, ex_z : expected contacts (float, already clamped), ob : observed count,
+ * lgf = ig_lgfact(ob).  Evaluation order follows the reference expression. */
+IG_HD double ig_pixel_term(float ex, float ex_z, int ob, double lgf)
+{
+    double e = (double)ex;
+    double res = 0.0;
+    if (e != 0.0) {
+        double o = (double)ob;
+        if (ob > 0) res = o * ig_log10(e) - e - lgf;
+        else res = -e;
+    }
+    return res + (double)ex_z * IG_LOG_E_F;
+}
+
+/* ---- exact accumulation -------------------------------------------------
+ * A term is quantised to a multiple of 2^-32 (round-half-even) and added as
+ * a 64-bit integer; integer addition is associative, so any thread/wave/
+ * block/GPU decomposition gives the same sum.  Terms are clamped to
+ * |t| < 2^20 and NaN -> 0 so the conversion is defined on every target. */
+#define IG_QSCALE 4294967296.0
+#define IG_QCLAMP 1048576.0
+
+IG_HD int64_t ig_quantize(double t)
+{
+    if (ig_isnan(t)) return 0;
+    if (t > IG_QCLAMP) t = IG_QCLAMP;
+    if (t < -IG_QCLAMP) t = -IG_QCLAMP;
+    return (int64_t)__builtin_rint(t * IG_QSCALE);
+}
+
+/* A sum is carried as two int64 limbs: value = hi * 2^32 + lo (lo >= 0). */
+typedef struct ig_acc {
+    int64_t hi, lo;
+} ig_acc;
+
+IG_HD void ig_acc_add(ig_acc* a, int64_t q)
+{
+    a->hi += q >> 32; /* arithmetic shift: floor(q / 2^32) */
+    a->lo += (int64_t)(uint32_t)q;
+}
+
+/* limbs -> double, one rounding: value / 2^32 */
+IG_HD double ig_acc_to_double(int64_t hi, int64_t lo)
+{
+    int64_t H = hi + (lo >> 32);
+    int64_t L = lo & 0xffffffffLL;
+    return (double)H + (double)L * (1.0 / 4294967296.0);
+}
+
+/* normalise limbs so that 0 <= lo < 2^32 (unique representation) */
+IG_HD void ig_acc_normalize(int64_t* hi, int64_t* lo)
+{
+    *hi += (*lo >> 32);
+    *lo &= 0xffffffffLL;
+}
+
+#endif /* IG_DETMATH_H */
