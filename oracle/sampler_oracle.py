@@ -25,6 +25,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import oracle_lib as ol
+from . import rippe_fit as opti
 from .oracle_lib import FragStruct, f32, i32, ptr
 
 N_TMP = 24
@@ -481,3 +482,49 @@ class OracleSampler:
                        valid_after=self.gpu_list_valid_insert.copy())
             self.trace.append(rec)
         return (o, dist, op_sampled, id_f_sampled, self.mean_length_contigs, self.n_contigs)
+
+    # -------------------------------------------------------------- nuisance
+    def step_nuisance_parameters(self, dt, t, n_step):  # CL:2961-3051
+        curr_param = np.copy(self.param_simu)
+        kuhn, lm, c1, slope, d, d_max, fact, d_nuc = curr_param[0]
+        self.sigma_fact = 10 ** (np.log10(fact) - 2)
+        self.sigma_slope = 0.005
+        self.sigma_d_max = 100
+        self.sigma_d_nuc = 10 ** (np.log10(d_nuc) - 2)
+        id_modif = np.random.choice(4)
+        if id_modif == 0:
+            new_fact = fact + np.random.normal(loc=0.0, scale=self.sigma_fact)
+            new_d_max = opti.estimate_max_dist_intra_nuis([kuhn, lm, slope, d, new_fact], d_nuc, d_max)
+            c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+            out = [(kuhn, lm, c1, slope, d, new_d_max, new_fact, d_nuc)]
+        elif id_modif == 1:
+            new_slope = slope + np.random.normal(loc=0.0, scale=self.sigma_slope)
+            new_d_max = opti.estimate_max_dist_intra_nuis([kuhn, lm, new_slope, d, fact], d_nuc, d_max)
+            c1 = np.float32((0.53 * np.power(lm / kuhn, new_slope)) * np.power(kuhn, -3))
+            out = [(kuhn, lm, c1, new_slope, d, new_d_max, fact, d_nuc)]
+        elif id_modif == 2:
+            new_d_max = d_max + np.random.normal(loc=0.0, scale=self.sigma_d_max)
+            new_d_nuc = opti.peval(new_d_max, [kuhn, lm, slope, d, fact])  # 5 params where 4 are read: quirk Q12
+            c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+            out = [(kuhn, lm, c1, slope, d, new_d_max, fact, new_d_nuc)]
+        else:
+            if self.sigma_d_nuc <= 0:
+                new_d_nuc = d_nuc
+            else:
+                new_d_nuc = d_nuc + np.random.normal(loc=0.0, scale=self.sigma_d_nuc)
+            new_d_max = opti.estimate_max_dist_intra_nuis([kuhn, lm, slope, d, fact], new_d_nuc, d_max)
+            c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+            out = [(kuhn, lm, c1, slope, d, new_d_max, fact, new_d_nuc)]
+        out = np.array(out, dtype=ol.PARAM_DTYPE)
+        self.param_simu_test = out
+        self.likelihood_nuis = self.eval_likelihood_4_nuisance()
+        ratio = np.exp((self.likelihood_nuis - self.likelihood_t) / 1.0)
+        u = np.random.rand()
+        success = 0
+        if ratio >= u:
+            success = 1
+            self.param_simu = out
+            self.likelihood_t = self.likelihood_nuis
+        kuhn, lm, c1, slope, d, d_max, fact, d_nuc = self.param_simu[0]
+        y_rippe = opti.peval(self.bins, [kuhn, lm, slope, d, fact]) if hasattr(self, "bins") else None
+        return (fact, d, d_max, d_nuc, slope, self.likelihood_t, success, y_rippe)

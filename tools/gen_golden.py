@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own sampler Python.
+
+Runs only in the authoring container (needs /root/reference).  The reference's
+``instagraal.cuda_lib_gl_single.sampler`` is imported unmodified; ``pycuda`` is
+the functional fake in tools/fake_pycuda whose kernels are oracle/ig_oracle_*.c.
+What this pins: everything the reference does on the HOST for the hot path --
+neighbour draw and RNG consumption (CL:3103-3141), call order and stale buffers
+(CL:1401-1465, 1918-1923), slice + sort (CL:1009-1069), argmax (CL:1435-1446),
+apply + renumbering (CL:2094-2151, 2715-2881), genome distance (CL:665-716),
+nuisance step (CL:2961-3051) -- for both arithmetic modes of the oracle kernels.
+
+Only numeric inputs/outputs are stored; no reference source enters the repo.
+
+usage:  python tools/gen_golden.py [--out tests/golden]
+"""
+import argparse
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "tools", "fake_pycuda"))
+sys.path.insert(0, ROOT)
+sys.path.insert(1, "/root/reference/src")
+
+CASES = {
+    # name: (config, seed, n_moves, bomb, n_nuisance_from)
+    "tiny_plain": ("tiny", 11, 80, False, None),
+    "tiny_bomb": ("tiny", 12, 60, True, None),
+    "tiny_nuis": ("tiny", 13, 30, False, 10),
+}
+
+
+def run_case(name, mode, outdir):
+    from instagraal_amd import synth
+    from oracle import oracle_lib as ol
+    import pycuda.driver as cuda
+    from pycuda import compiler as fake_compiler
+    from instagraal.cuda_lib_gl_single import sampler as ref_sampler
+
+    cfg, seed, n_moves, bomb, nuis_from = CASES[name]
+    ol.set_mode(mode)
+    prob = synth.make_problem(*synth.CONFIGS[cfg])
+    kw = prob.sampler_kwargs()
+    np.random.seed(seed)
+    s = ref_sampler(*[kw[k] for k in kw])
+    # what estimate_parameters_rippe does after the fit (CL:2343-2349), with fixed parameters
+    p = prob.params
+    par = np.array([(p["kuhn"], p["lm"], p["c1"], p["slope"], p["d"], p["d_max"], p["fact"], p["v_inter"])],
+                   dtype=s.param_simu_rippe)
+    s.param_simu = par
+    s.param_simu_test = s.param_simu
+    s.gpu_param_simu = cuda.mem_alloc(s.param_simu.nbytes)
+    s.gpu_param_simu_test = cuda.mem_alloc(s.param_simu.nbytes)
+    cuda.memcpy_htod(s.gpu_param_simu, s.param_simu)
+    cuda.memcpy_htod(s.gpu_param_simu_test, s.param_simu_test)
+    s.bins = np.arange(1.0, 60.0, 1.0)  # normally set by estimate_parameters_rippe (CL:2247)
+    s.eval_likelihood_init()
+    init_nz = float(s.gpu_curr_likelihood_nz.get()[0])
+
+    if bomb:
+        s.bomb_the_genome()
+    list_frags = np.arange(0, s.n_new_frags)
+    np.random.shuffle(list_frags)  # IG:213
+    rec = dict(frag=[], cands=[], scores=[], ret=[], valid=[], state_every=[], states=[], nuis=[])
+    fake_compiler.CALL_LOG.clear()
+    for t, id_frag in enumerate(list_frags[:n_moves]):
+        r = s.step_sampler(id_frag, 5, s.dt)
+        c = list(s.candidates) + [-1] * (5 - len(s.candidates))
+        sc = np.full(5 * 24, np.nan)
+        sc[: len(s.all_scores)] = s.all_scores
+        rec["frag"].append(int(id_frag))
+        rec["cands"].append(c)
+        rec["scores"].append(sc)
+        rec["ret"].append([float(r[0]), float(r[1]), float(r[2]), float(r[3]), float(r[4]), float(r[5])])
+        rec["valid"].append(s.gpu_list_valid_insert.get())
+        if nuis_from is not None and t >= nuis_from:
+            q = s.step_nuisance_parameters(s.dt, t, n_moves)
+            rec["nuis"].append([float(q[0]), float(q[1]), float(q[2]), float(q[3]), float(q[4]),
+                                float(np.ravel(q[5])[0]), float(q[6])])
+        if t % 10 == 9 or t == n_moves - 1:
+            s.gpu_vect_frags.copy_from_gpu()
+            g = s.gpu_vect_frags
+            rec["state_every"].append(t)
+            rec["states"].append(np.stack([getattr(g, k) if k != "next" else g.next for k in ol.FRAG_FIELDS]).astype(np.int32))
+    launches = len(fake_compiler.CALL_LOG) / float(n_moves)
+    out = os.path.join(outdir, "%s_mode%d.npz" % (name, mode))
+    np.savez_compressed(
+        out, config=cfg, seed=seed, bomb=bomb, mode=mode, init_nz=init_nz, frag=np.array(rec["frag"], np.int32),
+        cands=np.array(rec["cands"], np.int32), scores=np.array(rec["scores"]), ret=np.array(rec["ret"]),
+        valid=np.array(rec["valid"], np.int32), state_every=np.array(rec["state_every"], np.int32),
+        states=np.array(rec["states"], np.int32), nuis=np.array(rec["nuis"]), launches_per_move=launches,
+        nuis_from=-1 if nuis_from is None else nuis_from,
+        params=np.array([p[k] for k in ("kuhn", "lm", "c1", "slope", "d", "d_max", "fact", "v_inter")], np.float64),
+        rng_after=np.array(np.random.get_state()[1][:8], np.uint32))
+    print("wrote", out, "launches/move %.0f" % launches, "last ret", rec["ret"][-1])
+
+
+def host_helper_goldens(outdir):
+    """Reference host helpers that need no kernels ('importable-and-runnable pieces')."""
+    from instagraal import optim_rippe_curve_update as opti
+
+    x = np.array([1.0, 2.5, 7.0, 20.0, 55.0, 160.0, 400.0, 900.0])
+    p = [50.0, 9.6, -1.5, 3.0e5]
+    y = opti.peval(x, p)
+    dmax = opti.estimate_max_dist_intra([50.0, 9.6, -1.5, 2.0, 3.0e5], 5e-3)
+    dmax_n = opti.estimate_max_dist_intra_nuis([50.0, 9.6, -1.45, 2.0, 3.0e5], 5e-3, dmax)
+    fit, y_est = opti.estimate_param_rippe(opti.peval(x, p) * 1.0, x)
+    np.savez(os.path.join(outdir, "host_helpers.npz"), x=x, p=np.array(p), peval=y, dmax=dmax, dmax_nuis=dmax_n,
+             fit=np.array(fit, dtype=np.float64), y_est=y_est)
+    print("wrote host_helpers.npz", dmax, dmax_n, fit)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--cases", default=",".join(CASES))
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    os.chdir(tempfile.mkdtemp())  # the reference's log.py drops a log file in the CWD
+    for name in a.cases.split(","):
+        for mode in (0, 1):
+            run_case(name, mode, a.out)
+    host_helper_goldens(a.out)
+
+
+if __name__ == "__main__":
+    main()
