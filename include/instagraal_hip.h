@@ -1,0 +1,130 @@
+/*
+ * instagraal_hip.h -- C ABI of the MI355X-native per-move scoring path of instaGRAAL.
+ *
+ * The reference has no FFI of its own for this path: its Python reaches the GPU only
+ * through pycuda (cuda_lib_gl_single.py, "CL").  This library replaces that layer --
+ *   pycuda.compiler.SourceModule(...).get_function(name)   CL:1521-1600
+ *   gpuarray / mem_alloc / memcpy_htod / memcpy_dtoh         CL:321-424, 551-646
+ *   GPUStruct (struct of 17 int*)                            gpustruct.py:8-186
+ * -- with a flat C ABI: one opaque handle per sampler, library-owned device memory,
+ * caller-owned host memory, int return codes (0 = ok, <0 = error; text via
+ * ig_last_error()).  No exceptions, callbacks or torch types cross the boundary.
+ * A handle is not thread-safe; distinct handles are independent.
+ * Unless stated otherwise a call returns after its work is complete (synchronous).
+ *
+ * Fragment state is exchanged as int32 soa[17][N] in the member order of
+ * kernel_sparse_adapt.cu:40-58 ("KA"):
+ *   pos sub_pos id_c start_bp len_bp sub_len circ id prev next l_cont sub_l_cont
+ *   l_cont_bp ori rep activ id_d
+ */
+#ifndef INSTAGRAAL_HIP_H
+#define INSTAGRAAL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IG_N_TMP_STRUCT 24 /* candidate mutation slots per (frag, candidate) pair, CL:192-194 */
+#define IG_MAX_CANDIDATES 16
+#define IG_N_INSERT_BLOCKS 6 /* CL:192 */
+
+typedef struct ig_ctx ig_ctx;
+
+/* outcome of one move: the 6-tuple of sampler.step_sampler (CL:1458-1465) + diagnostics */
+typedef struct ig_move_result {
+    double o;            /* score of the applied candidate = new likelihood_t (CL:1454-1457) */
+    double dist;         /* dist_inter_genome (CL:665-716) */
+    double mean_len;     /* mean_length_contigs (CL:2742), float32 value widened */
+    int32_t op_sampled;  /* 0..23 */
+    int32_t id_f_sampled;/* partner fragment of the applied candidate */
+    int32_t n_contigs;
+    int32_t n_candidates;
+    int64_t n_slice;     /* sum over candidates of sliced contacts S_c (CL:1043) */
+    int64_t n_evals;     /* sum over candidates of S_c * (n_uniq + 1) term evaluations */
+    int64_t bytes_min;   /* compulsory-traffic model B_min of this move */
+    int32_t error;       /* 0, or a device-side consistency failure code */
+    int32_t pad;
+} ig_move_result;
+
+/* ---- lifetime --------------------------------------------------------- */
+int ig_create(int device_id, ig_ctx** out);
+void ig_destroy(ig_ctx* ctx);
+const char* ig_last_error(void);
+int ig_sync(ig_ctx* ctx);
+/* use an existing hipStream_t (e.g. torch's current stream); NULL = library-owned stream */
+int ig_set_stream(ig_ctx* ctx, void* hip_stream);
+
+/* ---- problem upload (replaces sparse_data_2_gpu CL:551-646, create_gpu_struct CL:429-549) */
+/* level-(L-1) contacts: strict upper triangle COO, row-major sorted, as CL:592-615 uploads them.
+ * rank/world: contact shard of this handle (rows r with r % world == rank); (0,1) = all. */
+int ig_upload_contacts(ig_ctx* ctx, const int32_t* row, const int32_t* col, const int32_t* cnt, int64_t Z, int32_t M,
+                       int32_t rank, int32_t world);
+/* np_sub_frags_2_frags: M x float4 (parent bin, watson kb, crick kb, index in bin), simu_single.py:701-717 */
+int ig_upload_subfrag_table(ig_ctx* ctx, const float* xyzw, int32_t M);
+int ig_upload_state(ig_ctx* ctx, const int32_t* soa17, int32_t N);
+/* contig ids are returned renumbered exactly as modify_gl_cuda_buffer leaves them (CL:2715-2881) */
+int ig_download_state(ig_ctx* ctx, int32_t* soa17);
+/* which: 0 = param_simu, 1 = param_simu_test (CL:2343-2349, 3019-3023); p in KA:91-100 order */
+int ig_set_params(ig_ctx* ctx, const float p[8], float mean_subfrag_kb, int which);
+/* list_bounds (CL:417-422) and max_bounds_insert (CL:418-420) */
+int ig_set_insert_config(ig_ctx* ctx, const int32_t list_bounds[IG_N_INSERT_BLOCKS], int32_t max_bounds_insert);
+/* initial prev/next/orientable for the genome distance (CL:269-276); blacklist may be NULL */
+int ig_set_initial_genome(ig_ctx* ctx, const int32_t* init_prev, const int32_t* init_next, const int32_t* orientable,
+                          const int32_t* blacklisted, int32_t n_blacklisted);
+
+/* ---- likelihood (evaluate_likelihood_sparse KA:4374-4488, eval_likelihood_on_zero KA:3850-3917) */
+/* nz, z: the two scalars eval_likelihood()/approx_single_likelihood_on_zeros() leave behind
+ * (CL:1245-1292, 718-760).  which_params as ig_set_params.  use_prev_tables != 0 evaluates on the
+ * coordinates of the state BEFORE the last applied move (what eval_likelihood_4_nuisance sees,
+ * CL:1296-1344, quirk Q12).  limbs (may be NULL): exact sums {nz_hi, nz_lo, z_hi, z_lo, n_intra}. */
+int ig_full_likelihood(ig_ctx* ctx, int which_params, int use_prev_tables, double* nz, double* z, int64_t* limbs5);
+
+/* ---- the move (step_sampler CL:1401-1465) ------------------------------ */
+/* scores: C x 24 doubles laid out as all_scores (CL:1414, 1431); slots that are not scored are 0. */
+int ig_score_move(ig_ctx* ctx, int32_t frag_a, const int32_t* cands, int32_t C, double* scores);
+/* re-materialise (frag_a, frag_b, op) into the live state (test_copy_struct CL:2094-2151) */
+int ig_apply(ig_ctx* ctx, int32_t frag_a, int32_t frag_b, int32_t op);
+/* score + device argmax (CL:1435-1446) + apply + bookkeeping, one small D2H */
+int ig_step(ig_ctx* ctx, int32_t frag_a, const int32_t* cands, int32_t C, ig_move_result* out, double* scores_or_null);
+/* n_moves consecutive moves enqueued back to back without host round trips.
+ * cands: n_moves x max_c, -1 padded.  results: n_moves entries. */
+int ig_step_batch(ig_ctx* ctx, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c,
+                  ig_move_result* results);
+
+/* ---- bookkeeping -------------------------------------------------------- */
+int ig_renumber_contigs(ig_ctx* ctx, int32_t* n_contigs, float* mean_len, int32_t* max_id); /* CL:2715-2881 */
+int ig_bomb(ig_ctx* ctx, const int32_t* shuffle);                                            /* CL:1925-1948 */
+int ig_genome_distance(ig_ctx* ctx, double* d);                                              /* CL:665-716 */
+int ig_get_valid_insert(ig_ctx* ctx, int32_t out12[12]); /* gpu_list_valid_insert, stale-flag state (Q4) */
+
+/* ---- multi-GPU (contact shards) -------------------------- */
+/* Two-phase move: partial sums over this handle's contact shard are left in a device buffer of
+ * ig_partials_count() int64 values; the caller all-reduces (SUM) it across ranks, then finishes. */
+int64_t ig_partials_count(ig_ctx* ctx);
+void* ig_partials_device_ptr(ig_ctx* ctx);
+int ig_step_begin(ig_ctx* ctx, int32_t frag_a, const int32_t* cands, int32_t C);
+int ig_step_finish(ig_ctx* ctx, ig_move_result* out, double* scores_or_null);
+
+/* ---- timing / roofline -------------------------------------------------- */
+/* average duration (ms) of the named kernel over the launches since the last reset, measured
+ * with hipEvents on the library's stream; name in {"score","mutate","gather","finalize","apply","post"} */
+int ig_kernel_time_ms(ig_ctx* ctx, const char* name, double* avg_ms, int64_t* n_launches);
+int ig_reset_timers(ig_ctx* ctx, int enable);
+
+/* ---- debug ABI (kernel-granularity parity tests) ------------------------ */
+/* evaluate the model on arrays: ex = rippe(s), exc = rippe_circ(s, s_tot), term, quantised term */
+int ig_debug_eval_terms(ig_ctx* ctx, const float* s, const float* s_tot, const int32_t* ob, int64_t n, float* ex, float* exc,
+                        double* term, int64_t* q);
+/* candidate genome (cand index c, slot) of the last ig_score_move, as soa17 (ids internal) */
+int ig_debug_candidate_state(ig_ctx* ctx, int32_t c, int32_t slot, int32_t* soa17);
+/* per-(candidate, slot) exact sums of the last scored move: nz limbs, z limbs, n_intra, extract limbs, S_c */
+int ig_debug_last_sums(ig_ctx* ctx, int64_t* nz_hi, int64_t* nz_lo, int64_t* z_hi, int64_t* z_lo, int64_t* n_intra,
+                       int64_t* ext_hi, int64_t* ext_lo, int64_t* n_slice, int32_t* n_uniq, int32_t* uniq);
+int ig_debug_tables(ig_ctx* ctx, float* dist, int32_t* id_c, float* s_tot, int32_t* pos, int32_t* len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

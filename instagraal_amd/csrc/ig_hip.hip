@@ -1,0 +1,1995 @@
+/*
+ * ig_hip.hip -- MI355X (gfx950) implementation of instaGRAAL's per-move scoring path behind the
+ * C ABI of include/instagraal_hip.h.  Design notes: DESIGN.md.  Reference being replaced:
+ *   /root/reference/src/instagraal/kernels/kernel_sparse_adapt.cu  ("KA", 38 CUDA kernels)
+ *   /root/reference/src/instagraal/cuda_lib_gl_single.py           ("CL", pycuda host code)
+ *
+ * One move (CL:1401-1465) is eight launches on one stream, no host round trip in between:
+ *   k_gather   O(N)        local fragment lists of the touched contigs, uniq-mutation lists, flags
+ *   k_mutate   C x 25 WGs  one candidate genome per workgroup, operators applied in place on the
+ *                          local window, coordinate columns + zero-pixel sums emitted
+ *   k_score    C x G WGs   CSR rows of the touched contigs streamed once per column, Rippe P(s),
+ *                          Poisson term, exact fixed-point sums (wave shuffles + 64-bit atomics)
+ *   k_finalize 1 WG        tail quirk (Q5), scores, argmax
+ *   k_delta    G WGs       exact update of the full likelihood when the slice was windowed
+ *   k_apply    WGs         winner scattered into the live state + coordinate tables
+ *   k_post     O(N)        genome distance credits
+ *   k_commit   1 lane      result record
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/ig_detmath.h"
+#include "../../include/instagraal_hip.h"
+#include "ig_ops.cuh"
+
+#define NSLOT 25          /* 24 mutation slots + the current genome */
+#define NCODE 8           /* contig codes inside a candidate: A, B, fresh0..fresh3 (+spare) */
+#define NFRESH 4
+#define LGF_TAB 1024
+#define SCORE_BLOCKS 64   /* workgroups per candidate in k_score */
+#define SCORE_THREADS 256
+
+static thread_local std::string g_err;
+static int fail(const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+#define HIPCK(x)                                                                                     \
+    do {                                                                                             \
+        hipError_t e_ = (x);                                                                         \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+/* ------------------------------------------------------------------ device data */
+
+struct SubTab {
+    int parent;
+    float wat, cri;
+    int w;
+};
+
+struct State { /* N-length arrays */
+    int *pos, *spos, *cid, *sbp, *circ, *prev, *next, *L, *SL, *LB, *ori; /* dynamic, order = Loc */
+    int *lb, *sl, *sub_first, *rep, *activ, *id_d;                        /* constant */
+};
+#define NDYN 11
+
+struct Tables { /* M-length current coordinates (uni_fill_vect_dist, KA:3763-3822) */
+    float* dist;
+    int* cid;
+    float* stot;
+    int* pos;
+    int* len;
+};
+
+struct CandMeta {
+    int B, ctgA, ctgB, same, windowed;
+    int LA, LB, SLA, SLB, n_loc, m_loc;
+    int lA, lB; /* local indices of A and B */
+    int n_uniq, uniq[24], kidx[NSLOT];
+    int flags[12], pos_up[6], pos_down[6];
+    /* slice windows (KA:530-548) */
+    int pos_fa, pos_fb, up_fa, down_fa, up_fb, down_fb;
+};
+
+struct ColMeta {
+    float stot;
+    int len;
+};
+
+struct Glob {
+    ig_params par[2];
+    float mean_kb;
+    int slice_nb;
+    int list_bounds[6];
+    long long nz_hi, nz_lo, z_hi, z_lo, n_intra;
+    long long d_hi, d_lo; /* k_delta accumulator */
+    long long credit2, credit2_acc;
+    double n_tot_pxl;
+    double lgf[15];
+    int n_contigs, next_cid, n_black, N, M;
+    int valid_insert[12];
+    int error;
+    /* move in flight */
+    int A, C, force_slot;
+    int ch_c, ch_k, ch_slot, ch_windowed;
+    double ch_score;
+    long long n_slice_tot, n_eval_tot, bytes_min;
+};
+
+struct MoveBuf {
+    int* Lloc;      /* [capC][N] global ids of local fragments */
+    int* lbloc;     /* [capC][N] */
+    int* slloc;     /* [capC][N] */
+    int* subs;      /* [capC][M] global sub-frag id of local sub index */
+    uint2* coords;  /* [capC][M][NSLOT] {dist bits, pos | code<<28} column k */
+    int* loc;       /* [capC][NSLOT][NDYN][N] candidate genomes on the local window */
+    CandMeta* meta; /* [capC] */
+    ColMeta* cmeta; /* [capC][NSLOT][NCODE] */
+    long long* part;/* partial sums, see P_* offsets */
+    double* scores; /* [capC][24] */
+    int N, M, capC;
+};
+/* layout of MoveBuf.part per candidate (int64 units) */
+#define P_NZ 0                 /* [NSLOT][2] slice sums per column k (k=0: current = "extract") */
+#define P_CNT (NSLOT * 2)      /* [1] kept entries S_c */
+#define P_STRIDE (NSLOT * 2 + 2)
+/* not all-reduced (computed redundantly on every rank) */
+#define Q_Z 0                  /* [NSLOT][2] zero-pixel sums on the local window, per column k */
+#define Q_NI (NSLOT * 2)       /* [NSLOT] intra pair counts */
+#define Q_NZFULL (NSLOT * 3)   /* [NSLOT][2] slice sums before the tail correction */
+#define Q_STRIDE (NSLOT * 5)
+
+struct ig_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    int N, M;
+    long long Z;
+    int rank, world;
+    State st;
+    int* st_block; /* one allocation for all state arrays */
+    Tables tab, tab_prev;
+    SubTab* sub_tab;
+    long long* rowptr;
+    int2* cc; /* (col, count) */
+    int* init_prev;
+    int* init_next;
+    int* orientable;
+    unsigned char* black;
+    double* lgf_tab;
+    Glob* glob;
+    MoveBuf mb;
+    long long* q_part; /* [capC][Q_STRIDE] */
+    ig_move_result* d_results;
+    int results_cap;
+    int* d_frags;
+    int* d_cands;
+    int cands_cap;
+    /* timers */
+    bool timing;
+    struct Timer {
+        const char* name;
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+        double total_ms;
+        long long n;
+    } timers[8];
+    bool have_contacts, have_sub, have_state, have_init, have_params;
+};
+
+/* ------------------------------------------------------------------ device helpers */
+
+__device__ __forceinline__ long long wave_sum_ll(long long v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ void atomic_add_ll(long long* p, long long v)
+{
+    atomicAdd((unsigned long long*)p, (unsigned long long)v);
+}
+
+/* expected contacts of one pair: KA:4430-4459 (== 4182-4206, 4327-4351) */
+__device__ __forceinline__ void expected_pair(const ig_params& p, bool cis, float s, float s_z, float s_tot, float s_tot_z,
+                                              float& ex, float& ex_z)
+{
+    if (cis) {
+        if (s_tot == 0) {
+            ex = ig_rippe(s, p);
+            ex_z = (s_z < p.d_max) ? ig_rippe(s_z, p) : p.v_inter;
+        } else {
+            ex = ig_rippe_circ(s, s_tot, p);
+            ex_z = (s_z < p.d_max) ? ig_rippe_circ(s_z, s_tot_z, p) : p.v_inter;
+        }
+    } else {
+        ex = p.v_inter;
+        ex_z = p.v_inter;
+    }
+}
+
+__device__ __forceinline__ double lgfact_dev(int ob, const double* __restrict__ lgf_tab)
+{
+    if (ob <= 0) return 0.0;
+    if (ob < LGF_TAB) return lgf_tab[ob];
+    double o = (double)ob;
+    return (o * ig_log10(o) - o) + 0.5 * ig_log10(o * 2.0 * 3.14159265358979323846);
+}
+
+/* quantised likelihood term of one contact under one coordinate column */
+__device__ __forceinline__ long long eval_q(const ig_params& p, float mean_kb, uint2 a, uint2 b, const ColMeta* __restrict__ cm,
+                                            int ob, double lgf)
+{
+    const float di = __uint_as_float(a.x), dj = __uint_as_float(b.x);
+    const int pi = (int)(a.y & 0x0fffffffu), pj = (int)(b.y & 0x0fffffffu);
+    const int ci = (int)(a.y >> 28), cj = (int)(b.y >> 28);
+    const float s = fabsf(di - dj);
+    const float s_z = fabsf((float)pi - (float)pj) * mean_kb;
+    const float s_tot = cm[ci].stot;
+    const float s_tot_z = (float)cm[cj].len * mean_kb;
+    float ex, ex_z;
+    expected_pair(p, ci == cj, s, s_z, s_tot, s_tot_z, ex, ex_z);
+    return ig_quantize(ig_pixel_term(ex, ex_z, ob, lgf));
+}
+
+/* one sub-fragment's zero-pixel term: KA:3882-3899 */
+__device__ __forceinline__ long long zero_q(const ig_params& p, int pos, int len_cont, float s_tot, float mean_kb)
+{
+    const float s = (float)pos * mean_kb;
+    const float s_tot_z = (float)len_cont * mean_kb;
+    double ve;
+    if (s < p.d_max) {
+        if (s_tot == 0) ve = (double)ig_rippe(s, p);
+        else ve = (double)ig_rippe_circ(s, s_tot_z, p);
+    } else {
+        ve = (double)p.v_inter;
+    }
+    return ig_quantize(0.0 - (ve * (double)(len_cont - pos)));
+}
+
+/* cut positions + validity flags of get_bounds (KA:2124-2252), scalar part */
+__device__ inline void bounds_scalar(const State& st, const Glob* g, int P, int I, int* pos_up, int* pos_down, int* valid)
+{
+    const int cP = st.cid[P], cI = st.cid[I];
+    const int same = (cP == cI);
+    const int pP = st.pos[P], pI = st.pos[I];
+    const int LP = st.L[P], LI = st.L[I];
+    const int ins_is_ext = (pI == 0) || (pI == (LI - 1));
+    const int nb = IG_N_INSERT_BLOCKS;
+    for (int i = 0; i < nb; i++) {
+        int up, down;
+        if (i == 0) {
+            if (same && (pI < pP - 1)) {
+                up = pI + 1;
+                down = pP;
+            } else if (same && (pI > pP + 1)) {
+                down = pI - 1;
+                up = pP;
+            } else {
+                up = pP;
+                down = pP;
+            }
+        } else if (i < nb - 1) {
+            up = max(0, pP - g->list_bounds[i - 1]);
+            down = min(LP - 1, pP + g->list_bounds[i - 1]);
+        } else {
+            up = 0;
+            down = LP - 1;
+        }
+        if (same && (pI <= pP) && (pI >= up)) {
+            pos_up[i] = -1;
+            valid[i * 2] = -1;
+        } else {
+            pos_up[i] = up;
+            valid[i * 2] = 1;
+            if (up == 0 && (((pP - up) == 1) || ins_is_ext)) {
+                valid[i * 2] = -1;
+                pos_up[i] = -1;
+            }
+        }
+        if (same && (((pI >= pP) && (pI <= down)) || (pI == (pP - 1)))) {
+            pos_down[i] = -1;
+            valid[i * 2 + 1] = -1;
+        } else {
+            pos_down[i] = down;
+            valid[i * 2 + 1] = 1;
+            if (down == LP - 1 && (((down - pP) == 1) || ins_is_ext)) {
+                valid[i * 2 + 1] = -1;
+                pos_down[i] = -1;
+            }
+        }
+    }
+}
+
+/* slice predicate of slice_sp_mat (KA:557-593) for a contact whose row lies in a touched contig */
+__device__ __forceinline__ bool slice_keep(const CandMeta& m, int c1, int c2, int p1, int p2, int ob, bool unwindowed)
+{
+    if (ob <= 0) return false;
+    if ((c2 == c1) && m.same && m.windowed && !unwindowed) {
+        const int px = min(p1, p2), py = max(p1, p2);
+        const bool ca = (px <= m.down_fa) && (py >= m.up_fa);
+        const bool cb = (py >= m.up_fb) && (px <= m.down_fb);
+        return ca || cb;
+    }
+    if (m.same) return c2 == m.ctgB; /* ctgA == ctgB */
+    return (c2 == m.ctgA) || (c2 == m.ctgB);
+}
+
+/* ------------------------------------------------------------------ set-up kernels */
+
+__global__ void k_lgf_table(double* tab, const double* small15)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < LGF_TAB) tab[i] = ig_lgfact(i < 1 ? 1 : i, small15);
+    if (i == 0) tab[0] = 0.0;
+}
+
+/* KA:3763-3822 for every sub-fragment */
+__global__ void k_fill_tables(State st, const SubTab* __restrict__ sub, Tables t, int M)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= M) return;
+    const SubTab b = sub[s];
+    const int f = b.parent;
+    const int ori = st.ori[f];
+    const int sp = st.spos[f], sl = st.sl[f];
+    const int stot_i = (int)((float)(st.circ[f] == 1) * (float)st.LB[f] / 1000.0f);
+    const float dfi = (ori == 1) ? b.wat : b.cri;
+    t.dist[s] = (float)st.sbp[f] / 1000.0f + dfi;
+    t.cid[s] = st.cid[f];
+    t.stot[s] = (float)stot_i;
+    t.pos[s] = (ori == 1) ? sp + b.w : sp + (sl - 1) - b.w;
+    t.len[s] = st.SL[f];
+}
+
+/* evaluate_likelihood_sparse (KA:4374-4488) over the whole CSR, exact sums -> out[0..1] */
+__global__ void k_full_nz(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables t, const Glob* g, int which,
+                          const double* __restrict__ lgf_tab, int M, int rank, int world, long long* out)
+{
+    const ig_params p = g->par[which];
+    const float mean = g->mean_kb;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    long long hi = 0, lo = 0;
+    for (int i = wave; i < M; i += nwaves) {
+        if (world > 1 && (i % world) != rank) continue;
+        const long long b = rowptr[i], e = rowptr[i + 1];
+        if (b == e) continue;
+        const float di = t.dist[i], sti = t.stot[i];
+        const int ci = t.cid[i], pi = t.pos[i], li = t.len[i];
+        for (long long k = b + lane; k < e; k += 64) {
+            const int2 v = cc[k];
+            const int j = v.x;
+            const float s = fabsf(di - t.dist[j]);
+            const int dp = pi - t.pos[j];
+            const float s_z = (float)(dp < 0 ? -dp : dp) * mean;
+            float ex, ex_z;
+            expected_pair(p, ci == t.cid[j], s, s_z, sti, (float)li * mean, ex, ex_z);
+            const long long q = ig_quantize(ig_pixel_term(ex, ex_z, v.y, lgfact_dev(v.y, lgf_tab)));
+            hi += q >> 32;
+            lo += (long long)(unsigned int)q;
+        }
+    }
+    hi = wave_sum_ll(hi);
+    lo = wave_sum_ll(lo);
+    if (lane == 0) {
+        atomic_add_ll(&out[0], hi);
+        atomic_add_ll(&out[1], lo);
+    }
+}
+
+/* eval_likelihood_on_zero (KA:3850-3917) over all sub-fragments -> out[0..2] = hi, lo, n_intra */
+__global__ void k_full_zero(Tables t, const Glob* g, int which, int M, long long* out)
+{
+    const ig_params p = g->par[which];
+    const float mean = g->mean_kb;
+    long long hi = 0, lo = 0, ni = 0;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < M; s += gridDim.x * blockDim.x) {
+        const int pos = t.pos[s], len = t.len[s];
+        if (pos == 0) ni += ((long long)len * (long long)(len - 1)) / 2;
+        if (pos > 0) {
+            const long long q = zero_q(p, pos, len, t.stot[s], mean);
+            hi += q >> 32;
+            lo += (long long)(unsigned int)q;
+        }
+    }
+    hi = wave_sum_ll(hi);
+    lo = wave_sum_ll(lo);
+    ni = wave_sum_ll(ni);
+    if ((threadIdx.x & 63) == 0) {
+        atomic_add_ll(&out[0], hi);
+        atomic_add_ll(&out[1], lo);
+        atomic_add_ll(&out[2], ni);
+    }
+}
+
+__global__ void k_count_heads(State st, int N, int* out)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    int h = (f < N && st.pos[f] == 0) ? 1 : 0;
+    h = wave_sum_i(h);
+    if ((threadIdx.x & 63) == 0 && h) atomicAdd(out, h);
+}
+
+/* explode_genome (KA:409-426); internal contig id = fragment index (ori is NOT reset) */
+__global__ void k_explode(State st, int N)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= N) return;
+    st.pos[f] = 0;
+    st.sbp[f] = 0;
+    st.spos[f] = 0;
+    st.cid[f] = f;
+    st.prev[f] = -1;
+    st.next[f] = -1;
+    st.L[f] = 1;
+    st.LB[f] = st.lb[f];
+    st.SL[f] = st.sl[f];
+}
+
+/* dist_inter_genome (CL:665-716): credits in half units, summed exactly */
+__device__ __forceinline__ int credit2_of(const State& st, const int* ip, const int* in, const int* orientable, int f)
+{
+    const int p0 = ip[f], n0 = in[f];
+    int p1 = st.prev[f], n1 = st.next[f];
+    const int o1 = st.ori[f];
+    int c2 = 0;
+    if (((p1 == p0) && (n1 == n0)) || ((p1 == n0) && (n1 == p0))) c2 += 2;
+    if (orientable[f]) {
+        int swap = 1;
+        if (1 != o1) { /* init ori is +1 (CL:276) */
+            int t = p1;
+            p1 = n1;
+            n1 = t;
+            swap = -1;
+        }
+        if (p0 == p1) {
+            if (p0 == -1) c2 += 2;
+            else if (!orientable[p1]) c2 += 2;
+            else c2 += 1 + ((1 == swap * st.ori[p1]) ? 1 : 0);
+        }
+        if (n0 == n1) {
+            if (n0 == -1) c2 += 2;
+            else if (!orientable[n1]) c2 += 2;
+            else c2 += 1 + ((1 == swap * st.ori[n1]) ? 1 : 0);
+        }
+    } else {
+        if ((p1 == p0) || (p1 == n0)) c2 += 2;
+        if ((n1 == n0) || (n1 == p0)) c2 += 2;
+    }
+    return c2;
+}
+
+__global__ void k_post(State st, const int* __restrict__ ip, const int* __restrict__ in, const int* __restrict__ orientable,
+                       const unsigned char* __restrict__ black, Glob* g, int N)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    int c2 = 0;
+    if (f < N && !black[f]) c2 = credit2_of(st, ip, in, orientable, f);
+    c2 = wave_sum_i(c2);
+    if ((threadIdx.x & 63) == 0 && c2) atomic_add_ll(&g->credit2_acc, (long long)c2);
+}
+
+/* ------------------------------------------------------------------ the move */
+
+/* k_gather: every fragment of a touched contig drops itself at its rank (no compaction needed);
+ * block 0 also derives per-candidate metadata, get_bounds flags and the uniq-mutation lists
+ * (extract_uniq_mutations KA:4492-4553, with the STALE flags of quirk Q4). */
+__global__ void k_gather(State st, Glob* g, MoveBuf mb, const int* __restrict__ cands_all, const int* __restrict__ frags_all,
+                         int move, int max_c, long long* q_part)
+{
+    __shared__ int sh_flags[IG_MAX_CANDIDATES][12];
+    const int A = frags_all[move];
+    const int* cands = cands_all + (size_t)move * max_c;
+    int C = 0;
+    for (int i = 0; i < max_c; i++) C += (cands[i] >= 0);
+    const int N = mb.N;
+    const int cA = st.cid[A], LA = st.L[A];
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < N) {
+        const int cf = st.cid[f], pf = st.pos[f];
+        const int lb = st.lb[f], sl = st.sl[f];
+        for (int c = 0; c < C; c++) {
+            const int cB = st.cid[cands[c]];
+            int slot = -1;
+            if (cf == cA) slot = pf;
+            else if (cf == cB) slot = LA + pf;
+            if (slot >= 0) {
+                const size_t o = (size_t)c * N + slot;
+                mb.Lloc[o] = f;
+                mb.lbloc[o] = lb;
+                mb.slloc[o] = sl;
+            }
+        }
+    }
+    if (blockIdx.x != 0) return;
+    const int t = threadIdx.x;
+    if (t == 0) {
+        g->A = A;
+        g->C = C;
+        g->d_hi = 0;
+        g->d_lo = 0;
+    }
+    for (int i = t; i < C * P_STRIDE; i += blockDim.x) mb.part[i] = 0;
+    for (int i = t; i < C * Q_STRIDE; i += blockDim.x) q_part[i] = 0;
+    for (int i = t; i < C * IG_N_TMP_STRUCT; i += blockDim.x) mb.scores[i] = 0.0;
+    if (t < C) {
+        CandMeta m;
+        const int B = cands[t];
+        m.B = B;
+        m.ctgA = cA;
+        m.ctgB = st.cid[B];
+        m.same = (m.ctgA == m.ctgB);
+        m.LA = LA;
+        m.LB = st.L[B];
+        m.SLA = st.SL[A];
+        m.SLB = st.SL[B];
+        m.n_loc = m.same ? m.LA : m.LA + m.LB;
+        m.m_loc = m.same ? m.SLA : m.SLA + m.SLB;
+        m.lA = st.pos[A];
+        m.lB = (m.same ? 0 : m.LA) + st.pos[B];
+        /* slice windows, KA:530-548 */
+        const int sa = st.spos[A], sb = st.spos[B], oa = st.ori[A], ob = st.ori[B];
+        const int sla = st.sl[A], slb = st.sl[B];
+        m.pos_fa = max(0, sa * (oa == 1) + (sa - sla) * (oa == -1));
+        m.pos_fb = max(0, sb * (ob == 1) + (sb - slb) * (ob == -1));
+        m.up_fa = max(0, m.pos_fa - g->slice_nb - sla);
+        m.down_fa = min(m.SLA - 1, m.pos_fa + g->slice_nb + sla);
+        m.up_fb = max(0, m.pos_fb - slb);
+        m.down_fb = min(m.SLB - 1, m.pos_fb + slb);
+        m.windowed = m.same && (st.circ[A] == 0);
+        bounds_scalar(st, g, A, B, m.pos_up, m.pos_down, m.flags);
+        for (int i = 0; i < 12; i++) sh_flags[t][i] = m.flags[i];
+        mb.meta[t] = m;
+    }
+    __syncthreads();
+    if (t < C) {
+        CandMeta* m = &mb.meta[t];
+        const int* vf = (t == 0) ? g->valid_insert : sh_flags[t - 1];
+        int n = 0;
+        int* u = m->uniq;
+        for (int k = 0; k < NSLOT; k++) m->kidx[k] = -1;
+        if (g->force_slot >= 0) {
+            u[n++] = g->force_slot;
+        } else {
+            if (t == 0) {
+                u[n++] = 0;
+                u[n++] = 1;
+            }
+            u[n++] = 2;
+            u[n++] = 3;
+            if (m->LB != 1)
+                for (int k = 4; k < 8; k++) u[n++] = k;
+            if (m->LA != 1)
+                for (int k = 8; k < 12; k++) u[n++] = k;
+            for (int k = 12; k < IG_N_TMP_STRUCT; k++)
+                if (vf[k - 12] != -1) u[n++] = k;
+        }
+        m->n_uniq = n;
+        m->kidx[IG_N_TMP_STRUCT] = 0; /* current genome = column 0 */
+        for (int k = 0; k < n; k++) m->kidx[u[k]] = k + 1;
+    }
+}
+
+/* k_mutate: one workgroup = one candidate genome on the local window. */
+__global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubTab* __restrict__ sub, Glob* g, MoveBuf mb,
+                                                long long* q_part)
+{
+    const int slot = blockIdx.x, c = blockIdx.y;
+    if (c >= g->C) return;
+    const CandMeta& m = mb.meta[c];
+    const int k = m.kidx[slot];
+    if (k < 0) return;
+    const int N = mb.N, M = mb.M, n = m.n_loc;
+    int* base = mb.loc + ((size_t)(c * NSLOT + slot) * NDYN) * N;
+    igd::Loc S;
+    S.pos = base;
+    S.spos = base + (size_t)N;
+    S.cid = base + (size_t)2 * N;
+    S.sbp = base + (size_t)3 * N;
+    S.circ = base + (size_t)4 * N;
+    S.prev = base + (size_t)5 * N;
+    S.next = base + (size_t)6 * N;
+    S.L = base + (size_t)7 * N;
+    S.SL = base + (size_t)8 * N;
+    S.LB = base + (size_t)9 * N;
+    S.ori = base + (size_t)10 * N;
+    S.gid = mb.Lloc + (size_t)c * N;
+    S.lb = mb.lbloc + (size_t)c * N;
+    S.sl = mb.slloc + (size_t)c * N;
+    S.n = n;
+    for (int x = threadIdx.x; x < n; x += blockDim.x) {
+        const int f = S.gid[x];
+        S.pos[x] = st.pos[f];
+        S.spos[x] = st.spos[f];
+        S.cid[x] = st.cid[f];
+        S.sbp[x] = st.sbp[f];
+        S.circ[x] = st.circ[f];
+        S.prev[x] = st.prev[f];
+        S.next[x] = st.next[f];
+        S.L[x] = st.L[f];
+        S.SL[x] = st.SL[f];
+        S.LB[x] = st.LB[f];
+        S.ori[x] = st.ori[f];
+    }
+    __syncthreads();
+    const int A = m.lA, B = m.lB;
+    const int fresh = g->next_cid;
+    if (slot == 0) { /* CL:1672 */
+        igd::op_pop_out(S, A, fresh);
+    } else if (slot == 1) { /* CL:1680 */
+        igd::op_flip(S, A);
+    } else if (slot < 8) { /* CL:1689-1760 */
+        igd::op_pop_out(S, A, fresh);
+        const int ori = (slot & 1) ? -1 : 1;
+        if (slot < 4) igd::op_pop_in_1(S, A, B, fresh + 1, ori);
+        else if (slot < 6) igd::op_pop_in_2(S, A, B, fresh + 1, ori);
+        else igd::op_pop_in_3(S, A, B, ori);
+    } else if (slot < 12) { /* CL:1780-1841: (upA, upB) = (0,0),(0,1),(1,0),(1,1) */
+        igd::op_split(S, A, (slot - 8) >> 1, fresh);
+        igd::op_split(S, B, (slot - 8) & 1, fresh + 1);
+        igd::op_paste(S, A, B);
+    } else if (slot < IG_N_TMP_STRUCT) { /* CL:1843-1916: slot = 12 + 2 i + (j == 1 ? 0 : 1) */
+        const int i = (slot - 12) >> 1;
+        const int up = ((slot - 12) & 1) ? 0 : 1;
+        const int cutpos = up ? m.pos_up[i] : m.pos_down[i];
+        const int g_ext = cutpos >= 0 ? S.gid[cutpos] : -1;
+        igd::op_extract_block(S, A, cutpos, up, fresh);
+        igd::op_insert_block(S, A, B, g_ext, m.flags[slot - 12], up);
+    }
+    /* ---- coordinate column k (fill_vect_dist, KA:3699-3760) + zero-pixel sums on the window */
+    const ig_params p = g->par[0];
+    const float mean = g->mean_kb;
+    uint2* col = mb.coords + (size_t)c * M * NSLOT;
+    ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
+    int* subs = mb.subs + (size_t)c * M;
+    long long hi = 0, lo = 0, ni = 0;
+    for (int x = threadIdx.x; x < n; x += blockDim.x) {
+        const int f = S.gid[x];
+        const int cid = S.cid[x];
+        const int code = (cid == m.ctgA) ? 0 : ((cid == m.ctgB) ? 1 : 2 + (cid - fresh));
+        const int ori = S.ori[x], sp = S.spos[x], sl = S.sl[x], SLc = S.SL[x];
+        const float stot = (float)(int)((float)S.circ[x] * (float)S.LB[x] / 1000.0f);
+        if (S.pos[x] == 0) {
+            cm[code].stot = stot;
+            cm[code].len = SLc;
+        }
+        const float sbp_kb = (float)S.sbp[x] / 1000.0f;
+        const int sf = st.sub_first[f];
+        const int lbase = (x < m.LA) ? 0 : m.SLA;
+        for (int w = 0; w < sl; w++) {
+            const int s = sf + w;
+            const SubTab b = sub[s];
+            const float dist = sbp_kb + ((ori == 1) ? b.wat : b.cri);
+            const int npos = (ori == 1) ? sp + w : sp + sl - (w + 1);
+            const int ls = lbase + tab.pos[s];
+            uint2 v;
+            v.x = __float_as_uint(dist);
+            v.y = (unsigned)npos | ((unsigned)code << 28);
+            col[(size_t)ls * NSLOT + k] = v;
+            if (k == 0) subs[ls] = s;
+            if (npos == 0) ni += ((long long)SLc * (long long)(SLc - 1)) / 2;
+            if (npos > 0) {
+                const long long q = zero_q(p, npos, SLc, stot, mean);
+                hi += q >> 32;
+                lo += (long long)(unsigned int)q;
+            }
+        }
+    }
+    __shared__ long long red[3][4];
+    hi = wave_sum_ll(hi);
+    lo = wave_sum_ll(lo);
+    ni = wave_sum_ll(ni);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[0][wv] = hi;
+        red[1][wv] = lo;
+        red[2][wv] = ni;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long* q = q_part + (size_t)c * Q_STRIDE;
+        q[Q_Z + 2 * k] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        q[Q_Z + 2 * k + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        q[Q_NI + k] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    }
+}
+
+/* k_score: the hot kernel.  A wave owns a strided set of CSR rows of candidate c; for each
+ * coordinate column it streams those rows (coalesced int2 loads), evaluates the Rippe/Poisson
+ * term and adds it as a 64-bit integer; one wave reduction + two atomics per (wave, column). */
+template <bool UNWINDOWED>
+__global__ void __launch_bounds__(SCORE_THREADS)
+    k_score(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, const Glob* g, MoveBuf mb,
+            const double* __restrict__ lgf_tab, int rank, int world, int only_c)
+{
+    (void)only_c;
+    const int c = UNWINDOWED ? g->ch_c : (int)blockIdx.y;
+    if (c < 0 || c >= g->C) return;
+    if (UNWINDOWED && (!g->ch_windowed || g->error)) return; /* the slice was already the whole contig pair */
+    const CandMeta& m = mb.meta[c];
+    const int M = mb.M;
+    const ig_params p = g->par[0];
+    const float mean = g->mean_kb;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * SCORE_THREADS + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * SCORE_THREADS) >> 6;
+    const uint2* col = mb.coords + (size_t)c * M * NSLOT;
+    const int* subs = mb.subs + (size_t)c * M;
+    const int ncol = UNWINDOWED ? 2 : m.n_uniq + 1;
+    long long* part = UNWINDOWED ? nullptr : mb.part + (size_t)c * P_STRIDE;
+    const int ch_k = g->ch_k;
+    for (int kk = 0; kk < ncol; kk++) {
+        const int k = UNWINDOWED ? (kk == 0 ? 0 : ch_k) : kk;
+        const ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
+        long long hi = 0, lo = 0;
+        int cnt = 0;
+        for (int r = wave; r < m.m_loc; r += nwaves) {
+            if (world > 1 && (r % world) != rank) continue;
+            const int i = subs[r];
+            const long long b = rowptr[i], e = rowptr[i + 1];
+            if (b == e) continue;
+            const int c1 = tab.cid[i], p1 = tab.pos[i];
+            const uint2 ai = col[(size_t)r * NSLOT + k];
+            for (long long q0 = b + lane; q0 < e; q0 += 64) {
+                const int2 v = cc[q0];
+                const int j = v.x;
+                const int c2 = tab.cid[j], p2 = tab.pos[j];
+                if (!slice_keep(m, c1, c2, p1, p2, v.y, UNWINDOWED)) continue;
+                const int lj = ((m.same || c2 == m.ctgA) ? 0 : m.SLA) + p2;
+                const uint2 bj = col[(size_t)lj * NSLOT + k];
+                const long long q = eval_q(p, mean, ai, bj, cm, v.y, lgfact_dev(v.y, lgf_tab));
+                hi += q >> 32;
+                lo += (long long)(unsigned int)q;
+                cnt++;
+            }
+        }
+        hi = wave_sum_ll(hi);
+        lo = wave_sum_ll(lo);
+        if (UNWINDOWED) {
+            if (lane == 0 && (hi | lo)) {
+                Glob* gw = const_cast<Glob*>(g);
+                atomic_add_ll(&gw->d_hi, kk == 0 ? -hi : hi);
+                atomic_add_ll(&gw->d_lo, kk == 0 ? -lo : lo);
+            }
+        } else {
+            if (kk == 0) cnt = wave_sum_i(cnt);
+            if (lane == 0) {
+                if (hi | lo) {
+                    atomic_add_ll(&part[P_NZ + 2 * k], hi);
+                    atomic_add_ll(&part[P_NZ + 2 * k + 1], lo);
+                }
+                if (kk == 0 && cnt) atomic_add_ll(&part[P_CNT], (long long)cnt);
+            }
+        }
+    }
+}
+
+/* k_finalize: tail quirk, zero-pixel totals, scores (KA:4005-4046), host argmax (CL:1435-1446).
+ * One wave; everything here is O(C * 24) except the tail walk (< 64 contacts per candidate). */
+__device__ __forceinline__ int wave_max_i(int v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__global__ void __launch_bounds__(64) k_finalize(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
+                                                 Glob* g, MoveBuf mb, long long* q_part, const double* __restrict__ lgf_tab,
+                                                 int tail_quirk)
+{
+    __shared__ int t_li[64], t_lj[64], t_ob[64];
+    const int lane = threadIdx.x;
+    const int C = g->C, M = mb.M;
+    const ig_params p = g->par[0];
+    const float mean = g->mean_kb;
+    const double log_e = IG_LOG_E_F;
+    const double cur_nz = ig_acc_to_double(g->nz_hi, g->nz_lo);
+    long long tot_slice = 0, tot_eval = 0, bytes = 0;
+    for (int c = 0; c < C; c++) {
+        const CandMeta& m = mb.meta[c];
+        long long* part = mb.part + (size_t)c * P_STRIDE;
+        long long* qp = q_part + (size_t)c * Q_STRIDE;
+        const uint2* col = mb.coords + (size_t)c * M * NSLOT;
+        const int* subs = mb.subs + (size_t)c * M;
+        const int ncol = m.n_uniq + 1;
+        for (int k = lane; k < ncol; k += 64) { /* uncorrected sums: the exact full-likelihood update uses them */
+            qp[Q_NZFULL + 2 * k] = part[P_NZ + 2 * k];
+            qp[Q_NZFULL + 2 * k + 1] = part[P_NZ + 2 * k + 1];
+        }
+        __syncthreads();
+        const long long Sc = part[P_CNT];
+        tot_slice += Sc;
+        tot_eval += Sc * ncol;
+        bytes += 12 * Sc + 20LL * m.m_loc * m.n_uniq + 8LL * m.n_uniq;
+        /* quirk Q5 (KA:4362, block 64 CL:200): with r = S_c mod 64 > 0, the columns at list positions
+         * >= r never receive the last r sliced contacts (canonical order = COO order). */
+        const int r = (int)(Sc % 64);
+        if (tail_quirk && r > 0 && m.n_uniq > r) {
+            int remaining = r, bound = 0x7fffffff, n_tail = 0;
+            while (remaining > 0) {
+                int best = -1;
+                for (int ls = lane; ls < m.m_loc; ls += 64) {
+                    const int s = subs[ls];
+                    if (s < bound && rowptr[s + 1] > rowptr[s]) best = max(best, s);
+                }
+                best = wave_max_i(best);
+                if (best < 0) break;
+                bound = best;
+                const int i = best;
+                const int c1 = tab.cid[i], p1 = tab.pos[i];
+                const int li = ((m.same || c1 == m.ctgA) ? 0 : m.SLA) + p1;
+                const long long b = rowptr[i], e = rowptr[i + 1];
+                for (long long end = e; end > b && remaining > 0; end -= 64) {
+                    const long long q0 = end - 1 - lane;
+                    bool keep = false;
+                    int2 v = make_int2(0, 0);
+                    int lj = 0;
+                    if (q0 >= b) {
+                        v = cc[q0];
+                        const int c2 = tab.cid[v.x], p2 = tab.pos[v.x];
+                        keep = slice_keep(m, c1, c2, p1, p2, v.y, false);
+                        lj = ((m.same || c2 == m.ctgA) ? 0 : m.SLA) + p2;
+                    }
+                    const unsigned long long mask = __ballot(keep);
+                    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+                    if (keep && rank < remaining) {
+                        t_li[n_tail + rank] = li;
+                        t_lj[n_tail + rank] = lj;
+                        t_ob[n_tail + rank] = v.y;
+                    }
+                    const int took = min(__popcll(mask), remaining);
+                    n_tail += took;
+                    remaining -= took;
+                }
+            }
+            __syncthreads();
+            for (int kk = r; kk < m.n_uniq; kk++) {
+                const int k = kk + 1;
+                const ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
+                long long hi = 0, lo = 0;
+                if (lane < n_tail) {
+                    const long long q = eval_q(p, mean, col[(size_t)t_li[lane] * NSLOT + k], col[(size_t)t_lj[lane] * NSLOT + k],
+                                               cm, t_ob[lane], lgfact_dev(t_ob[lane], lgf_tab));
+                    hi = q >> 32;
+                    lo = (long long)(unsigned int)q;
+                }
+                hi = wave_sum_ll(hi);
+                lo = wave_sum_ll(lo);
+                if (lane == 0) {
+                    part[P_NZ + 2 * k] -= hi;
+                    part[P_NZ + 2 * k + 1] -= lo;
+                }
+            }
+            __syncthreads();
+        }
+        /* eval_all_likelihood_on_zero_2nd (KA:4005-4027) + eval_all_scores (KA:4029-4046) */
+        const double ext = ig_acc_to_double(part[P_NZ], part[P_NZ + 1]);
+        for (int k = 1 + lane; k < ncol; k += 64) {
+            const long long zhi = g->z_hi + qp[Q_Z + 2 * k] - qp[Q_Z];
+            const long long zlo = g->z_lo + qp[Q_Z + 2 * k + 1] - qp[Q_Z + 1];
+            const long long ni = g->n_intra + qp[Q_NI + k] - qp[Q_NI];
+            const double val_inter = -1.0 * log_e * (g->n_tot_pxl - (double)ni) * p.v_inter;
+            const double val_intra = ig_acc_to_double(zhi, zlo) * log_e;
+            const double z = val_intra + val_inter;
+            const double nz = ig_acc_to_double(part[P_NZ + 2 * k], part[P_NZ + 2 * k + 1]);
+            mb.scores[c * IG_N_TMP_STRUCT + m.uniq[k - 1]] = nz + z + cur_nz - ext;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) { /* CL:1435-1446 */
+        const int n = C * IG_N_TMP_STRUCT;
+        double mx = -IG_INF;
+        for (int i = 0; i < n; i++) {
+            const double s = mb.scores[i];
+            const double ok = (s == 0.0) ? -IG_INF : s;
+            if (ok > mx) mx = ok;
+        }
+        int best = 0;
+        double bestv = -IG_INF;
+        for (int i = 0; i < n; i++) {
+            const double s = mb.scores[i];
+            const double ok = (s == 0.0) ? -IG_INF : s;
+            double fs = ok - (mx - 30.0);
+            if (fs < 0) fs = 0;
+            if (i == 0 || fs > bestv) {
+                if (i == 0 || fs > bestv) {
+                    bestv = fs;
+                    best = i;
+                }
+            }
+        }
+        const int cc_ = best / IG_N_TMP_STRUCT, slot = best % IG_N_TMP_STRUCT;
+        g->ch_c = cc_;
+        g->ch_slot = slot;
+        g->ch_k = mb.meta[cc_].kidx[slot] < 0 ? 0 : mb.meta[cc_].kidx[slot];
+        g->ch_windowed = mb.meta[cc_].windowed;
+        g->ch_score = mb.scores[best];
+        g->n_slice_tot = tot_slice;
+        g->n_eval_tot = tot_eval;
+        g->bytes_min = bytes;
+        g->credit2_acc = 0;
+        if (mb.meta[cc_].kidx[slot] < 0) g->error = 3; /* an unscored slot won: cannot happen */
+    }
+}
+
+/* forced choice for ig_apply (test_copy_struct / apply_replay_simu, CL:2094-2151, 2546-2553) */
+__global__ void k_force_choice(Glob* g, MoveBuf mb, int slot)
+{
+    g->ch_c = 0;
+    g->ch_slot = slot;
+    g->ch_k = mb.meta[0].kidx[slot];
+    g->ch_windowed = 1; /* always take the exact-delta path */
+    g->ch_score = 0.0;
+    g->n_slice_tot = 0;
+    g->n_eval_tot = 0;
+    g->bytes_min = 0;
+    g->credit2_acc = 0;
+    if (g->ch_k < 0) g->error = 4;
+}
+
+/* k_apply: the winner becomes the live genome (copy_struct KA:4566-4591) and the coordinate
+ * tables of the touched sub-fragments are refreshed from its column. */
+__global__ void k_apply(State st, Tables tab, Glob* g, MoveBuf mb, long long* q_part, int forced)
+{
+    const int c = g->ch_c, slot = g->ch_slot, k = g->ch_k;
+    if (g->error) return;
+    const CandMeta& m = mb.meta[c];
+    const int N = mb.N, M = mb.M;
+    const int* base = mb.loc + ((size_t)(c * NSLOT + slot) * NDYN) * N;
+    const int* gid = mb.Lloc + (size_t)c * N;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    int heads = 0;
+    for (int x = tid; x < m.n_loc; x += nth) {
+        const int f = gid[x];
+        const int np_ = base[x];
+        st.pos[f] = np_;
+        st.spos[f] = base[(size_t)N + x];
+        st.cid[f] = base[(size_t)2 * N + x];
+        st.sbp[f] = base[(size_t)3 * N + x];
+        st.circ[f] = base[(size_t)4 * N + x];
+        st.prev[f] = base[(size_t)5 * N + x];
+        st.next[f] = base[(size_t)6 * N + x];
+        st.L[f] = base[(size_t)7 * N + x];
+        st.SL[f] = base[(size_t)8 * N + x];
+        st.LB[f] = base[(size_t)9 * N + x];
+        st.ori[f] = base[(size_t)10 * N + x];
+        heads += (np_ == 0);
+    }
+    heads = wave_sum_i(heads);
+    if ((threadIdx.x & 63) == 0 && heads) atomicAdd(&g->n_contigs, heads);
+    const uint2* col = mb.coords + (size_t)c * M * NSLOT;
+    const ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
+    const int* subs = mb.subs + (size_t)c * M;
+    const int fresh = g->next_cid;
+    for (int ls = tid; ls < m.m_loc; ls += nth) {
+        const int s = subs[ls];
+        const uint2 v = col[(size_t)ls * NSLOT + k];
+        const int code = (int)(v.y >> 28);
+        tab.dist[s] = __uint_as_float(v.x);
+        tab.pos[s] = (int)(v.y & 0x0fffffffu);
+        tab.cid[s] = code == 0 ? m.ctgA : (code == 1 ? m.ctgB : fresh + (code - 2));
+        tab.stot[s] = cm[code].stot;
+        tab.len[s] = cm[code].len;
+    }
+    if (tid == 0) {
+        const long long* qp = q_part + (size_t)c * Q_STRIDE;
+        atomicAdd(&g->n_contigs, m.same ? -1 : -2);
+        long long dh, dl;
+        if (g->ch_windowed) {
+            dh = g->d_hi;
+            dl = g->d_lo;
+        } else {
+            dh = qp[Q_NZFULL + 2 * k] - qp[Q_NZFULL];
+            dl = qp[Q_NZFULL + 2 * k + 1] - qp[Q_NZFULL + 1];
+        }
+        long long h = g->nz_hi + dh, l = g->nz_lo + dl;
+        ig_acc_normalize((int64_t*)&h, (int64_t*)&l);
+        g->nz_hi = h;
+        g->nz_lo = l;
+        h = g->z_hi + qp[Q_Z + 2 * k] - qp[Q_Z];
+        l = g->z_lo + qp[Q_Z + 2 * k + 1] - qp[Q_Z + 1];
+        ig_acc_normalize((int64_t*)&h, (int64_t*)&l);
+        g->z_hi = h;
+        g->z_lo = l;
+        g->n_intra += qp[Q_NI + k] - qp[Q_NI];
+        /* stale-flag state (quirk Q4): flags of the last candidate, or of the winner when its
+         * family re-ran get_bounds in test_copy_struct (op >= 12, CL:2125-2126) */
+        if (!forced || slot >= 12) {
+            const int* fl = (slot >= 12) ? m.flags : mb.meta[g->C - 1].flags;
+            for (int i = 0; i < 12; i++) g->valid_insert[i] = fl[i];
+        }
+    }
+}
+
+__global__ void k_commit(Glob* g, MoveBuf mb, ig_move_result* res, int move)
+{
+    g->next_cid += NFRESH;
+    g->credit2 = g->credit2_acc;
+    ig_move_result r;
+    const double norm = 3.0 * (double)(g->N - g->n_black);
+    r.o = g->ch_score;
+    r.dist = (norm - 0.5 * (double)g->credit2) / norm;
+    r.mean_len = (double)((float)g->N / (float)g->n_contigs);
+    r.op_sampled = g->ch_slot;
+    r.id_f_sampled = mb.meta[g->ch_c].B;
+    r.n_contigs = g->n_contigs;
+    r.n_candidates = g->C;
+    r.n_slice = g->n_slice_tot;
+    r.n_evals = g->n_eval_tot;
+    r.bytes_min = g->bytes_min + 68LL * mb.meta[g->ch_c].n_loc;
+    r.error = g->error;
+    r.pad = 0;
+    res[move] = r;
+}
+
+__global__ void k_debug_terms(const float* s, const float* stot, const int* ob, long long n, const Glob* g,
+                              const double* __restrict__ lgf_tab, float* ex, float* exc, double* term, long long* q)
+{
+    long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ig_params p = g->par[0];
+    ex[i] = ig_rippe(s[i], p);
+    exc[i] = ig_rippe_circ(s[i], stot[i], p);
+    term[i] = ig_pixel_term(ex[i], exc[i], ob[i], lgfact_dev(ob[i], lgf_tab));
+    q[i] = ig_quantize(term[i]);
+}
+
+/* ================================================================== host side */
+
+template <class T>
+static int dalloc(T** p, size_t n)
+{
+    *p = nullptr;
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+    if (e != hipSuccess) return fail("hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+    return 0;
+}
+#define DALLOC(p, n)                     \
+    do {                                 \
+        if (dalloc(&(p), (n))) return -1; \
+    } while (0)
+
+enum { T_GATHER = 0, T_MUTATE, T_SCORE, T_FINALIZE, T_DELTA, T_APPLY, T_POST, T_COMMIT };
+static const char* kTimerNames[8] = {"gather", "mutate", "score", "finalize", "delta", "apply", "post", "commit"};
+
+struct TimedLaunch {
+    ig_ctx* c;
+    int id;
+    hipEvent_t a, b;
+    TimedLaunch(ig_ctx* ctx, int which) : c(ctx), id(which), a(nullptr), b(nullptr)
+    {
+        if (c->timing) {
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            hipEventRecord(a, c->stream);
+        }
+    }
+    ~TimedLaunch()
+    {
+        if (c->timing) {
+            hipEventRecord(b, c->stream);
+            c->timers[id].ev.emplace_back(a, b);
+        }
+    }
+};
+
+static void drain_timers(ig_ctx* c)
+{
+    for (int i = 0; i < 8; i++) {
+        for (auto& pr : c->timers[i].ev) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                c->timers[i].total_ms += ms;
+                c->timers[i].n++;
+            }
+            hipEventDestroy(pr.first);
+            hipEventDestroy(pr.second);
+        }
+        c->timers[i].ev.clear();
+    }
+}
+
+extern "C" const char* ig_last_error(void) { return g_err.c_str(); }
+
+extern "C" int ig_create(int device_id, ig_ctx** out)
+{
+    if (!out) return fail("ig_create: out is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail("ig_create: no HIP device (the MI355X path has no CPU fallback)");
+    if (device_id < 0 || device_id >= n) return fail("ig_create: device %d out of range (%d devices)", device_id, n);
+    HIPCK(hipSetDevice(device_id));
+    ig_ctx* c = new ig_ctx();
+    memset((void*)&c->st, 0, sizeof c->st);
+    memset((void*)&c->tab, 0, sizeof c->tab);
+    memset((void*)&c->tab_prev, 0, sizeof c->tab_prev);
+    memset((void*)&c->mb, 0, sizeof c->mb);
+    c->device = device_id;
+    c->own_stream = true;
+    c->rank = 0;
+    c->world = 1;
+    c->N = c->M = 0;
+    c->Z = 0;
+    c->st_block = nullptr;
+    c->sub_tab = nullptr;
+    c->rowptr = nullptr;
+    c->cc = nullptr;
+    c->init_prev = c->init_next = c->orientable = nullptr;
+    c->black = nullptr;
+    c->q_part = nullptr;
+    c->d_results = nullptr;
+    c->results_cap = 0;
+    c->d_frags = c->d_cands = nullptr;
+    c->cands_cap = 0;
+    c->timing = false;
+    for (int i = 0; i < 8; i++) {
+        c->timers[i].name = kTimerNames[i];
+        c->timers[i].total_ms = 0;
+        c->timers[i].n = 0;
+    }
+    c->have_contacts = c->have_sub = c->have_state = c->have_init = c->have_params = false;
+    HIPCK(hipStreamCreate(&c->stream));
+    DALLOC(c->glob, 1);
+    HIPCK(hipMemset(c->glob, 0, sizeof(Glob)));
+    DALLOC(c->lgf_tab, LGF_TAB);
+    /* log10(ob!) table (KA:111-124, 251-270): the 15 float-factorial constants on the host, the rest on the device */
+    double small[15];
+    for (int k = 0; k < 15; k++) {
+        float r = 1;
+        if (k < 10) {
+            for (int q = 1; q <= k; q++) r = r * q;
+        } else {
+            r = ig_powf((float)k, (float)k) * ig_expf(-(float)k) * __builtin_sqrtf((float)(2 * 3.14159265358979323846 * (float)k));
+        }
+        small[k] = ig_log10((double)r);
+    }
+    Glob hg;
+    memset(&hg, 0, sizeof hg);
+    for (int k = 0; k < 15; k++) hg.lgf[k] = small[k];
+    hg.force_slot = -1;
+    const int lb[6] = {1, 3, 5, 10, 20, 50}; /* CL:417 */
+    for (int k = 0; k < 6; k++) hg.list_bounds[k] = lb[k];
+    hg.slice_nb = 50 * 4;
+    HIPCK(hipMemcpy(c->glob, &hg, sizeof hg, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_lgf_table, dim3((LGF_TAB + 255) / 256), dim3(256), 0, c->stream, c->lgf_tab, c->glob->lgf);
+    HIPCK(hipStreamSynchronize(c->stream));
+    *out = c;
+    return 0;
+}
+
+static void free_move_buffers(ig_ctx* c)
+{
+    MoveBuf& m = c->mb;
+    hipFree(m.Lloc);
+    hipFree(m.lbloc);
+    hipFree(m.slloc);
+    hipFree(m.subs);
+    hipFree(m.coords);
+    hipFree(m.loc);
+    hipFree(m.meta);
+    hipFree(m.cmeta);
+    hipFree(m.part);
+    hipFree(m.scores);
+    hipFree(c->q_part);
+    memset((void*)&m, 0, sizeof m);
+    c->q_part = nullptr;
+}
+
+extern "C" void ig_destroy(ig_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    drain_timers(c);
+    free_move_buffers(c);
+    hipFree(c->st_block);
+    hipFree(c->tab.dist);
+    hipFree(c->tab_prev.dist);
+    hipFree(c->sub_tab);
+    hipFree(c->rowptr);
+    hipFree(c->cc);
+    hipFree(c->init_prev);
+    hipFree(c->init_next);
+    hipFree(c->orientable);
+    hipFree(c->black);
+    hipFree(c->lgf_tab);
+    hipFree(c->glob);
+    hipFree(c->d_results);
+    hipFree(c->d_frags);
+    hipFree(c->d_cands);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int ig_sync(ig_ctx* c)
+{
+    HIPCK(hipSetDevice(c->device));
+    HIPCK(hipStreamSynchronize(c->stream));
+    drain_timers(c);
+    return 0;
+}
+
+extern "C" int ig_set_stream(ig_ctx* c, void* s)
+{
+    HIPCK(hipStreamSynchronize(c->stream));
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    if (s) {
+        c->stream = (hipStream_t)s;
+        c->own_stream = false;
+    } else {
+        HIPCK(hipStreamCreate(&c->stream));
+        c->own_stream = true;
+    }
+    return 0;
+}
+
+static int ensure_move_buffers(ig_ctx* c, int capC)
+{
+    if (c->mb.capC >= capC && c->mb.N == c->N && c->mb.M == c->M) return 0;
+    if (c->N == 0 || c->M == 0) return 0;
+    free_move_buffers(c);
+    MoveBuf& m = c->mb;
+    const size_t N = c->N, M = c->M, C = capC;
+    DALLOC(m.Lloc, C * N);
+    DALLOC(m.lbloc, C * N);
+    DALLOC(m.slloc, C * N);
+    DALLOC(m.subs, C * M);
+    DALLOC(m.coords, C * M * NSLOT);
+    DALLOC(m.loc, C * NSLOT * NDYN * N);
+    DALLOC(m.meta, C);
+    DALLOC(m.cmeta, C * NSLOT * NCODE);
+    DALLOC(m.part, C * P_STRIDE);
+    DALLOC(m.scores, C * IG_N_TMP_STRUCT);
+    DALLOC(c->q_part, C * Q_STRIDE);
+    HIPCK(hipMemset(m.cmeta, 0, C * NSLOT * NCODE * sizeof(ColMeta)));
+    m.N = c->N;
+    m.M = c->M;
+    m.capC = capC;
+    return 0;
+}
+
+extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* col, const int32_t* cnt, int64_t Z, int32_t M,
+                                  int32_t rank, int32_t world)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (Z < 0 || M <= 0) return fail("ig_upload_contacts: bad sizes");
+    if (world < 1 || rank < 0 || rank >= world) return fail("ig_upload_contacts: bad shard %d/%d", rank, world);
+    if (c->M && c->M != M) return fail("ig_upload_contacts: M=%d does not match the sub-fragment table (%d)", M, c->M);
+    std::vector<long long> rp((size_t)M + 1, 0);
+    std::vector<int2> cc((size_t)Z);
+    for (int64_t k = 0; k < Z; k++) {
+        const int r = row[k], q = col[k];
+        if (r < 0 || r >= M || q <= r || q >= M) return fail("ig_upload_contacts: entry %lld (%d,%d) is not strict upper triangle", (long long)k, r, q);
+        if (k > 0 && (row[k - 1] > r || (row[k - 1] == r && col[k - 1] >= q)))
+            return fail("ig_upload_contacts: entries must be row-major sorted and distinct (at %lld)", (long long)k);
+        rp[(size_t)r + 1]++;
+        cc[(size_t)k] = make_int2(q, cnt[k]);
+    }
+    for (int i = 0; i < M; i++) rp[(size_t)i + 1] += rp[(size_t)i];
+    hipFree(c->rowptr);
+    hipFree(c->cc);
+    DALLOC(c->rowptr, (size_t)M + 1);
+    DALLOC(c->cc, (size_t)Z);
+    HIPCK(hipMemcpy(c->rowptr, rp.data(), ((size_t)M + 1) * sizeof(long long), hipMemcpyHostToDevice));
+    if (Z) HIPCK(hipMemcpy(c->cc, cc.data(), (size_t)Z * sizeof(int2), hipMemcpyHostToDevice));
+    c->Z = Z;
+    c->M = M;
+    c->rank = rank;
+    c->world = world;
+    c->have_contacts = true;
+    return 0;
+}
+
+extern "C" int ig_upload_subfrag_table(ig_ctx* c, const float* xyzw, int32_t M)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (M <= 0) return fail("ig_upload_subfrag_table: M <= 0");
+    if (c->M && c->M != M) return fail("ig_upload_subfrag_table: M=%d does not match the contacts (%d)", M, c->M);
+    std::vector<SubTab> t((size_t)M);
+    for (int s = 0; s < M; s++) {
+        t[s].parent = (int)xyzw[4 * (size_t)s];
+        t[s].wat = xyzw[4 * (size_t)s + 1];
+        t[s].cri = xyzw[4 * (size_t)s + 2];
+        t[s].w = (int)xyzw[4 * (size_t)s + 3];
+        if (s > 0 && (t[s].parent < t[s - 1].parent || (t[s].parent == t[s - 1].parent && t[s].w != t[s - 1].w + 1)))
+            return fail("ig_upload_subfrag_table: sub-fragments of a bin must be contiguous and ordered (at %d)", s);
+    }
+    hipFree(c->sub_tab);
+    DALLOC(c->sub_tab, (size_t)M);
+    HIPCK(hipMemcpy(c->sub_tab, t.data(), (size_t)M * sizeof(SubTab), hipMemcpyHostToDevice));
+    hipFree(c->tab.dist);
+    hipFree(c->tab_prev.dist);
+    for (Tables* tb : {&c->tab, &c->tab_prev}) {
+        int* blk;
+        DALLOC(blk, 5 * (size_t)M);
+        tb->dist = (float*)blk;
+        tb->cid = blk + (size_t)M;
+        tb->stot = (float*)(blk + 2 * (size_t)M);
+        tb->pos = blk + 3 * (size_t)M;
+        tb->len = blk + 4 * (size_t)M;
+    }
+    c->M = M;
+    c->have_sub = true;
+    return 0;
+}
+
+static int launch_recompute(ig_ctx* c);
+
+extern "C" int ig_upload_state(ig_ctx* c, const int32_t* soa, int32_t N)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (N <= 0) return fail("ig_upload_state: N <= 0");
+    if (!c->have_sub) return fail("ig_upload_state: upload the sub-fragment table first");
+    const size_t n = N;
+    std::vector<int> host(17 * n);
+    /* soa member order (KA:40-58): 0 pos 1 sub_pos 2 id_c 3 start_bp 4 len_bp 5 sub_len 6 circ 7 id 8 prev 9 next
+     * 10 l_cont 11 sub_l_cont 12 l_cont_bp 13 ori 14 rep 15 activ 16 id_d */
+    static const int dyn_src[NDYN] = {0, 1, 2, 3, 6, 8, 9, 10, 11, 12, 13};
+    for (int k = 0; k < NDYN; k++) memcpy(&host[k * n], soa + dyn_src[k] * n, n * sizeof(int));
+    memcpy(&host[11 * n], soa + 4 * n, n * sizeof(int));  /* len_bp */
+    memcpy(&host[12 * n], soa + 5 * n, n * sizeof(int));  /* sub_len */
+    memcpy(&host[14 * n], soa + 14 * n, n * sizeof(int)); /* rep */
+    memcpy(&host[15 * n], soa + 15 * n, n * sizeof(int)); /* activ */
+    memcpy(&host[16 * n], soa + 16 * n, n * sizeof(int)); /* id_d */
+    /* first sub-fragment of each bin + consistency with the table */
+    std::vector<SubTab> t((size_t)c->M);
+    HIPCK(hipMemcpy(t.data(), c->sub_tab, (size_t)c->M * sizeof(SubTab), hipMemcpyDeviceToHost));
+    long long acc = 0;
+    for (size_t f = 0; f < n; f++) {
+        host[13 * n + f] = (int)acc;
+        const int sl = soa[5 * n + f];
+        if (sl < 1 || acc + sl > c->M) return fail("ig_upload_state: sub_len of bin %zu inconsistent with the sub-fragment table", f);
+        for (int w = 0; w < sl; w++)
+            if (t[(size_t)acc + w].parent != (int)f || t[(size_t)acc + w].w != w)
+                return fail("ig_upload_state: sub-fragment %lld is not (bin %zu, index %d)", acc + w, f, w);
+        acc += sl;
+        if (soa[15 * n + f] != 1) return fail("ig_upload_state: inactive fragments are not supported (dead in the reference)");
+    }
+    if (acc != c->M) return fail("ig_upload_state: bins cover %lld sub-fragments, table has %d", acc, c->M);
+    /* internal contig ids: any injective relabelling works; keep the caller's, they are >= 0 */
+    int max_c = 0;
+    for (size_t f = 0; f < n; f++) {
+        if (soa[2 * n + f] < 0) return fail("ig_upload_state: negative contig id");
+        max_c = std::max(max_c, soa[2 * n + f]);
+    }
+    hipFree(c->st_block);
+    DALLOC(c->st_block, 17 * n);
+    HIPCK(hipMemcpy(c->st_block, host.data(), 17 * n * sizeof(int), hipMemcpyHostToDevice));
+    int** sp = (int**)&c->st;
+    for (int k = 0; k < 17; k++) sp[k] = c->st_block + k * n;
+    const bool size_changed = (c->N != N);
+    c->N = N;
+    if (size_changed || !c->have_init) { /* default initial genome for the distance = this state (CL:269-276) */
+        hipFree(c->init_prev);
+        hipFree(c->init_next);
+        hipFree(c->orientable);
+        hipFree(c->black);
+        DALLOC(c->init_prev, n);
+        DALLOC(c->init_next, n);
+        DALLOC(c->orientable, n);
+        DALLOC(c->black, n);
+        std::vector<int> orient(n);
+        for (size_t f = 0; f < n; f++) orient[f] = soa[5 * n + f] > 1;
+        HIPCK(hipMemcpy(c->init_prev, soa + 8 * n, n * sizeof(int), hipMemcpyHostToDevice));
+        HIPCK(hipMemcpy(c->init_next, soa + 9 * n, n * sizeof(int), hipMemcpyHostToDevice));
+        HIPCK(hipMemcpy(c->orientable, orient.data(), n * sizeof(int), hipMemcpyHostToDevice));
+        HIPCK(hipMemset(c->black, 0, n));
+        c->have_init = true;
+    }
+    Glob hg;
+    HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));
+    hg.N = N;
+    hg.M = c->M;
+    hg.next_cid = max_c + 1;
+    hg.n_tot_pxl = (double)c->M * ((double)c->M - 1.0) / 2.0; /* CL:366 */
+    for (int i = 0; i < 12; i++) hg.valid_insert[i] = 0; /* CL:421 */
+    hg.error = 0;
+    HIPCK(hipMemcpy(c->glob, &hg, sizeof hg, hipMemcpyHostToDevice));
+    c->have_state = true;
+    if (ensure_move_buffers(c, 8)) return -1;
+    return launch_recompute(c);
+}
+
+/* tables, head count, genome-distance credits and (when parameters are known) the exact
+ * likelihood sums of the current state */
+static int launch_recompute(ig_ctx* c)
+{
+    if (!c->have_state || !c->have_sub) return 0;
+    const int N = c->N, M = c->M;
+    hipLaunchKernelGGL(k_fill_tables, dim3((M + 255) / 256), dim3(256), 0, c->stream, c->st, c->sub_tab, c->tab, M);
+    HIPCK(hipMemcpyAsync(c->tab_prev.dist, c->tab.dist, 5 * (size_t)M * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+    long long* scratch;
+    DALLOC(scratch, 8);
+    HIPCK(hipMemsetAsync(scratch, 0, 8 * sizeof(long long), c->stream));
+    int* heads = (int*)(scratch + 6);
+    hipLaunchKernelGGL(k_count_heads, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->st, N, heads);
+    HIPCK(hipMemsetAsync(&c->glob->credit2_acc, 0, sizeof(long long), c->stream));
+    hipLaunchKernelGGL(k_post, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->st, c->init_prev, c->init_next, c->orientable,
+                       c->black, c->glob, N);
+    if (c->have_params && c->have_contacts) {
+        hipLaunchKernelGGL(k_full_nz, dim3(1024), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, 0, c->lgf_tab, M, 0, 1,
+                           scratch);
+        hipLaunchKernelGGL(k_full_zero, dim3(256), dim3(256), 0, c->stream, c->tab, c->glob, 0, M, scratch + 2);
+    }
+    long long h[8];
+    HIPCK(hipMemcpyAsync(h, scratch, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    hipFree(scratch);
+    Glob hg;
+    HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));
+    ig_acc_normalize((int64_t*)&h[0], (int64_t*)&h[1]);
+    ig_acc_normalize((int64_t*)&h[2], (int64_t*)&h[3]);
+    hg.nz_hi = h[0];
+    hg.nz_lo = h[1];
+    hg.z_hi = h[2];
+    hg.z_lo = h[3];
+    hg.n_intra = h[4];
+    hg.n_contigs = ((int*)&h[6])[0];
+    hg.credit2 = hg.credit2_acc;
+    HIPCK(hipMemcpy(c->glob, &hg, sizeof hg, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int ig_set_params(ig_ctx* c, const float p[8], float mean_subfrag_kb, int which)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (which != 0 && which != 1) return fail("ig_set_params: which must be 0 or 1");
+    HIPCK(hipStreamSynchronize(c->stream));
+    ig_params hp = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]};
+    HIPCK(hipMemcpy(&c->glob->par[which], &hp, sizeof hp, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(&c->glob->mean_kb, &mean_subfrag_kb, sizeof(float), hipMemcpyHostToDevice));
+    if (which == 0) {
+        c->have_params = true;
+        return launch_recompute(c); /* the maintained exact sums depend on param_simu */
+    }
+    return 0;
+}
+
+extern "C" int ig_set_insert_config(ig_ctx* c, const int32_t list_bounds[IG_N_INSERT_BLOCKS], int32_t max_bounds_insert)
+{
+    HIPCK(hipSetDevice(c->device));
+    HIPCK(hipStreamSynchronize(c->stream));
+    HIPCK(hipMemcpy(c->glob->list_bounds, list_bounds, 6 * sizeof(int), hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(&c->glob->slice_nb, &max_bounds_insert, sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int ig_set_initial_genome(ig_ctx* c, const int32_t* ip, const int32_t* in, const int32_t* orientable,
+                                     const int32_t* blacklisted, int32_t nb)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (!c->have_state) return fail("ig_set_initial_genome: upload the state first");
+    const size_t n = c->N;
+    HIPCK(hipStreamSynchronize(c->stream));
+    HIPCK(hipMemcpy(c->init_prev, ip, n * sizeof(int), hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(c->init_next, in, n * sizeof(int), hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(c->orientable, orientable, n * sizeof(int), hipMemcpyHostToDevice));
+    std::vector<unsigned char> b(n, 0);
+    for (int i = 0; i < nb; i++) {
+        if (blacklisted[i] < 0 || (size_t)blacklisted[i] >= n) return fail("ig_set_initial_genome: blacklisted id out of range");
+        b[blacklisted[i]] = 1;
+    }
+    int cnt = 0;
+    for (size_t i = 0; i < n; i++) cnt += b[i];
+    HIPCK(hipMemcpy(c->black, b.data(), n, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(&c->glob->n_black, &cnt, sizeof(int), hipMemcpyHostToDevice));
+    return launch_recompute(c);
+}
+
+/* canonical contig numbering of modify_gl_cuda_buffer (CL:2715-2881): contigs enumerated by
+ * ascending index of their pos==0 fragment (the order an in-order select_uniq_id_c produces,
+ * KA:357-406), stable sort by length descending (CL:69-77), id = (n-1) - rank (KA:4689-4692). */
+static void canonical_ids(const int* pos, const int* cid, const int* L, size_t n, std::vector<int>& out, int* n_contigs)
+{
+    std::vector<int> heads;
+    for (size_t f = 0; f < n; f++)
+        if (pos[f] == 0) heads.push_back((int)f);
+    std::vector<int> order(heads.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return L[heads[a]] > L[heads[b]]; });
+    int max_c = 0;
+    for (size_t f = 0; f < n; f++) max_c = std::max(max_c, cid[f]);
+    std::vector<int> map((size_t)max_c + 1, -1);
+    const int nc = (int)heads.size();
+    for (int r = 0; r < nc; r++) map[cid[heads[order[r]]]] = (nc - 1) - r;
+    out.resize(n);
+    for (size_t f = 0; f < n; f++) out[f] = map[cid[f]];
+    *n_contigs = nc;
+}
+
+extern "C" int ig_download_state(ig_ctx* c, int32_t* soa)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (!c->have_state) return fail("ig_download_state: no state");
+    const size_t n = c->N;
+    HIPCK(hipStreamSynchronize(c->stream));
+    std::vector<int> host(17 * n);
+    HIPCK(hipMemcpy(host.data(), c->st_block, 17 * n * sizeof(int), hipMemcpyDeviceToHost));
+    static const int dyn_src[NDYN] = {0, 1, 2, 3, 6, 8, 9, 10, 11, 12, 13};
+    for (int k = 0; k < NDYN; k++) memcpy(soa + dyn_src[k] * n, &host[k * n], n * sizeof(int));
+    memcpy(soa + 4 * n, &host[11 * n], n * sizeof(int));
+    memcpy(soa + 5 * n, &host[12 * n], n * sizeof(int));
+    memcpy(soa + 14 * n, &host[14 * n], n * sizeof(int));
+    memcpy(soa + 15 * n, &host[15 * n], n * sizeof(int));
+    memcpy(soa + 16 * n, &host[16 * n], n * sizeof(int));
+    for (size_t f = 0; f < n; f++) soa[7 * n + f] = (int)f;
+    std::vector<int> ids;
+    int nc;
+    canonical_ids(&host[0], &host[2 * n], &host[7 * n], n, ids, &nc);
+    memcpy(soa + 2 * n, ids.data(), n * sizeof(int));
+    return 0;
+}
+
+extern "C" int ig_renumber_contigs(ig_ctx* c, int32_t* n_contigs, float* mean_len, int32_t* max_id)
+{
+    HIPCK(hipSetDevice(c->device));
+    HIPCK(hipStreamSynchronize(c->stream));
+    int nc;
+    HIPCK(hipMemcpy(&nc, &c->glob->n_contigs, sizeof(int), hipMemcpyDeviceToHost));
+    if (n_contigs) *n_contigs = nc;
+    if (mean_len) *mean_len = (float)c->N / (float)nc;
+    if (max_id) *max_id = nc - 1;
+    return 0;
+}
+
+extern "C" int ig_bomb(ig_ctx* c, const int32_t* shuffle)
+{
+    (void)shuffle; /* explode_genome writes id_c = shuffle[i] (KA:419); the renumbering that follows (CL:1948) erases it */
+    HIPCK(hipSetDevice(c->device));
+    if (!c->have_state) return fail("ig_bomb: no state");
+    hipLaunchKernelGGL(k_explode, dim3((c->N + 255) / 256), dim3(256), 0, c->stream, c->st, c->N);
+    int next = c->N;
+    HIPCK(hipMemcpyAsync(&c->glob->next_cid, &next, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    return launch_recompute(c);
+}
+
+extern "C" int ig_genome_distance(ig_ctx* c, double* d)
+{
+    HIPCK(hipSetDevice(c->device));
+    HIPCK(hipStreamSynchronize(c->stream));
+    Glob hg;
+    HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));
+    const double norm = 3.0 * (double)(hg.N - hg.n_black);
+    *d = (norm - 0.5 * (double)hg.credit2) / norm;
+    return 0;
+}
+
+extern "C" int ig_get_valid_insert(ig_ctx* c, int32_t out12[12])
+{
+    HIPCK(hipSetDevice(c->device));
+    HIPCK(hipStreamSynchronize(c->stream));
+    HIPCK(hipMemcpy(out12, c->glob->valid_insert, 12 * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int ig_full_likelihood(ig_ctx* c, int which, int use_prev, double* nz, double* z, int64_t* limbs5)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (!c->have_contacts || !c->have_state || !c->have_params) return fail("ig_full_likelihood: contacts, state and parameters are required");
+    if (which != 0 && which != 1) return fail("ig_full_likelihood: which must be 0 or 1");
+    long long* scratch;
+    DALLOC(scratch, 8);
+    HIPCK(hipMemsetAsync(scratch, 0, 8 * sizeof(long long), c->stream));
+    Tables& t = use_prev ? c->tab_prev : c->tab;
+    hipLaunchKernelGGL(k_full_nz, dim3(1024), dim3(256), 0, c->stream, c->rowptr, c->cc, t, c->glob, which, c->lgf_tab, c->M, 0, 1,
+                       scratch);
+    hipLaunchKernelGGL(k_full_zero, dim3(256), dim3(256), 0, c->stream, t, c->glob, which, c->M, scratch + 2);
+    long long h[8];
+    HIPCK(hipMemcpyAsync(h, scratch, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    hipFree(scratch);
+    Glob hg;
+    HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));
+    ig_acc_normalize((int64_t*)&h[0], (int64_t*)&h[1]);
+    ig_acc_normalize((int64_t*)&h[2], (int64_t*)&h[3]);
+    if (nz) *nz = ig_acc_to_double(h[0], h[1]);
+    if (z) { /* CL:755-759 with the float log_e of the kernels replaced by the host's double constant */
+        const double log_e = 0.43429448190325182;
+        const double val_intra = ig_acc_to_double(h[2], h[3]) * log_e;
+        const double val_inter = log_e * (hg.n_tot_pxl - (double)h[4]) * -1.0 * (double)hg.par[which].v_inter;
+        *z = val_intra + val_inter;
+    }
+    if (limbs5)
+        for (int i = 0; i < 5; i++) limbs5[i] = h[i];
+    return 0;
+}
+
+/* ------------------------------------------------------------------ move driver */
+
+static int ensure_io(ig_ctx* c, int n_moves, int max_c)
+{
+    if (c->results_cap < n_moves) {
+        hipFree(c->d_results);
+        hipFree(c->d_frags);
+        DALLOC(c->d_results, (size_t)n_moves);
+        DALLOC(c->d_frags, (size_t)n_moves);
+        c->results_cap = n_moves;
+    }
+    if (c->cands_cap < n_moves * max_c) {
+        hipFree(c->d_cands);
+        DALLOC(c->d_cands, (size_t)n_moves * max_c);
+        c->cands_cap = n_moves * max_c;
+    }
+    return 0;
+}
+
+static int check_ready(ig_ctx* c)
+{
+    if (!c->have_contacts || !c->have_sub || !c->have_state || !c->have_params)
+        return fail("contacts, sub-fragment table, state and parameters must be uploaded before a move");
+    return 0;
+}
+
+static int g_tail_quirk = 1;
+
+/* enqueue the launches of one move; phase 0 = up to k_score, phase 1 = the rest, 2 = both */
+static void enqueue_move(ig_ctx* c, int move, int max_c, int force_slot, int phase)
+{
+    const int N = c->N;
+    const int gN = (N + 255) / 256;
+    if (phase == 0 || phase == 2) {
+        if (force_slot != -1 || true) hipMemcpyAsync(&c->glob->force_slot, &force_slot, sizeof(int), hipMemcpyHostToDevice, c->stream);
+        {
+            TimedLaunch t(c, T_GATHER);
+            hipLaunchKernelGGL(k_gather, dim3(gN), dim3(256), 0, c->stream, c->st, c->glob, c->mb, c->d_cands, c->d_frags, move, max_c,
+                               c->q_part);
+        }
+        {
+            TimedLaunch t(c, T_MUTATE);
+            hipLaunchKernelGGL(k_mutate, dim3(NSLOT, max_c), dim3(256), 0, c->stream, c->st, c->tab, c->sub_tab, c->glob, c->mb,
+                               c->q_part);
+        }
+        if (force_slot < 0) {
+            TimedLaunch t(c, T_SCORE);
+            hipLaunchKernelGGL(k_score<false>, dim3(SCORE_BLOCKS, max_c), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab,
+                               c->glob, c->mb, c->lgf_tab, c->rank, c->world, -1);
+        }
+    }
+    if (phase == 1 || phase == 2) {
+        if (force_slot < 0) {
+            TimedLaunch t(c, T_FINALIZE);
+            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->q_part,
+                               c->lgf_tab, g_tail_quirk);
+        } else {
+            hipLaunchKernelGGL(k_force_choice, dim3(1), dim3(1), 0, c->stream, c->glob, c->mb, force_slot);
+        }
+    }
+}
+
+static void enqueue_apply(ig_ctx* c, int move, int forced)
+{
+    const int N = c->N;
+    {
+        TimedLaunch t(c, T_DELTA);
+        hipLaunchKernelGGL(k_score<true>, dim3(SCORE_BLOCKS), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob,
+                           c->mb, c->lgf_tab, 0, 1, -2);
+    }
+    {
+        TimedLaunch t(c, T_APPLY);
+        hipLaunchKernelGGL(k_apply, dim3(64), dim3(256), 0, c->stream, c->st, c->tab, c->glob, c->mb, c->q_part, forced);
+    }
+    {
+        TimedLaunch t(c, T_POST);
+        hipLaunchKernelGGL(k_post, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->st, c->init_prev, c->init_next, c->orientable,
+                           c->black, c->glob, N);
+    }
+    {
+        TimedLaunch t(c, T_COMMIT);
+        hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, c->stream, c->glob, c->mb, c->d_results, move);
+    }
+}
+
+static int validate_move(ig_ctx* c, int frag_a, const int32_t* cands, int C)
+{
+    if (C < 1 || C > IG_MAX_CANDIDATES) return fail("a move needs 1..%d candidates (got %d)", IG_MAX_CANDIDATES, C);
+    if (frag_a < 0 || frag_a >= c->N) return fail("fragment %d out of range", frag_a);
+    for (int i = 0; i < C; i++) {
+        if (cands[i] < 0 || cands[i] >= c->N) return fail("candidate %d out of range", cands[i]);
+        if (cands[i] == frag_a)
+            return fail("candidate == focal fragment (%d): the reference reads stale buffers here (quirk Q13), not supported", frag_a);
+    }
+    return 0;
+}
+
+extern "C" int ig_step_batch(ig_ctx* c, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c,
+                             ig_move_result* results)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (check_ready(c)) return -1;
+    if (n_moves <= 0) return 0;
+    if (max_c < 1 || max_c > IG_MAX_CANDIDATES) return fail("ig_step_batch: max_c out of range");
+    for (int i = 0; i < n_moves; i++) {
+        int C = 0;
+        while (C < max_c && cands[(size_t)i * max_c + C] >= 0) C++;
+        for (int k = C; k < max_c; k++)
+            if (cands[(size_t)i * max_c + k] >= 0) return fail("ig_step_batch: candidates must be packed before the -1 padding");
+        if (validate_move(c, frags[i], cands + (size_t)i * max_c, C)) return -1;
+    }
+    if (ensure_move_buffers(c, std::max(8, (int)max_c))) return -1;
+    if (ensure_io(c, n_moves, max_c)) return -1;
+    HIPCK(hipMemcpyAsync(c->d_frags, frags, (size_t)n_moves * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCK(hipMemcpyAsync(c->d_cands, cands, (size_t)n_moves * max_c * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    for (int i = 0; i < n_moves; i++) {
+        enqueue_move(c, i, max_c, -1, 2);
+        enqueue_apply(c, i, 0);
+    }
+    HIPCK(hipMemcpyAsync(results, c->d_results, (size_t)n_moves * sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    HIPCK(hipGetLastError());
+    drain_timers(c);
+    for (int i = 0; i < n_moves; i++)
+        if (results[i].error) return fail("device-side consistency failure %d at move %d", results[i].error, i);
+    return 0;
+}
+
+extern "C" int ig_step(ig_ctx* c, int32_t frag_a, const int32_t* cands, int32_t C, ig_move_result* out, double* scores)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (check_ready(c)) return -1;
+    if (validate_move(c, frag_a, cands, C)) return -1;
+    if (ensure_move_buffers(c, std::max(8, (int)C))) return -1;
+    if (ensure_io(c, 1, C)) return -1;
+    HIPCK(hipMemcpyAsync(c->d_frags, &frag_a, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCK(hipMemcpyAsync(c->d_cands, cands, (size_t)C * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    enqueue_move(c, 0, C, -1, 2);
+    if (scores) HIPCK(hipMemcpyAsync(scores, c->mb.scores, (size_t)C * IG_N_TMP_STRUCT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    enqueue_apply(c, 0, 0);
+    HIPCK(hipMemcpyAsync(out, c->d_results, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    HIPCK(hipGetLastError());
+    drain_timers(c);
+    if (out->error) return fail("device-side consistency failure %d", out->error);
+    return 0;
+}
+
+extern "C" int ig_score_move(ig_ctx* c, int32_t frag_a, const int32_t* cands, int32_t C, double* scores)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (check_ready(c)) return -1;
+    if (validate_move(c, frag_a, cands, C)) return -1;
+    if (ensure_move_buffers(c, std::max(8, (int)C))) return -1;
+    if (ensure_io(c, 1, C)) return -1;
+    HIPCK(hipMemcpyAsync(c->d_frags, &frag_a, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCK(hipMemcpyAsync(c->d_cands, cands, (size_t)C * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    enqueue_move(c, 0, C, -1, 2);
+    HIPCK(hipMemcpyAsync(scores, c->mb.scores, (size_t)C * IG_N_TMP_STRUCT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    HIPCK(hipGetLastError());
+    drain_timers(c);
+    return 0;
+}
+
+extern "C" int ig_apply(ig_ctx* c, int32_t frag_a, int32_t frag_b, int32_t op)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (check_ready(c)) return -1;
+    if (op < 0 || op >= IG_N_TMP_STRUCT) return fail("ig_apply: op out of range");
+    if (validate_move(c, frag_a, &frag_b, 1)) return -1;
+    if (ensure_move_buffers(c, 8)) return -1;
+    if (ensure_io(c, 1, 1)) return -1;
+    HIPCK(hipMemcpyAsync(c->d_frags, &frag_a, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCK(hipMemcpyAsync(c->d_cands, &frag_b, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    enqueue_move(c, 0, 1, op, 2);
+    enqueue_apply(c, 0, 1);
+    ig_move_result r;
+    HIPCK(hipMemcpyAsync(&r, c->d_results, sizeof r, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    HIPCK(hipGetLastError());
+    drain_timers(c);
+    if (r.error) return fail("device-side consistency failure %d", r.error);
+    return 0;
+}
+
+extern "C" int64_t ig_partials_count(ig_ctx* c) { return (int64_t)c->mb.capC * P_STRIDE; }
+extern "C" void* ig_partials_device_ptr(ig_ctx* c) { return c->mb.part; }
+
+extern "C" int ig_step_begin(ig_ctx* c, int32_t frag_a, const int32_t* cands, int32_t C)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (check_ready(c)) return -1;
+    if (validate_move(c, frag_a, cands, C)) return -1;
+    if (ensure_move_buffers(c, std::max(8, (int)C))) return -1;
+    if (ensure_io(c, 1, C)) return -1;
+    HIPCK(hipMemcpyAsync(c->d_frags, &frag_a, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCK(hipMemcpyAsync(c->d_cands, cands, (size_t)C * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    enqueue_move(c, 0, C, -1, 0);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ig_step_finish(ig_ctx* c, ig_move_result* out, double* scores)
+{
+    HIPCK(hipSetDevice(c->device));
+    int C = 0;
+    enqueue_move(c, 0, IG_MAX_CANDIDATES, -1, 1);
+    (void)C;
+    if (scores) {
+        Glob hg;
+        HIPCK(hipMemcpyAsync(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));
+        HIPCK(hipMemcpyAsync(scores, c->mb.scores, (size_t)hg.C * IG_N_TMP_STRUCT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    enqueue_apply(c, 0, 0);
+    HIPCK(hipMemcpyAsync(out, c->d_results, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    HIPCK(hipGetLastError());
+    drain_timers(c);
+    if (out->error) return fail("device-side consistency failure %d", out->error);
+    return 0;
+}
+
+extern "C" int ig_kernel_time_ms(ig_ctx* c, const char* name, double* avg_ms, int64_t* n)
+{
+    drain_timers(c);
+    for (int i = 0; i < 8; i++)
+        if (!strcmp(name, c->timers[i].name)) {
+            if (avg_ms) *avg_ms = c->timers[i].n ? c->timers[i].total_ms / (double)c->timers[i].n : 0.0;
+            if (n) *n = c->timers[i].n;
+            return 0;
+        }
+    return fail("ig_kernel_time_ms: unknown kernel '%s'", name);
+}
+
+extern "C" int ig_reset_timers(ig_ctx* c, int enable)
+{
+    HIPCK(hipStreamSynchronize(c->stream));
+    drain_timers(c);
+    for (int i = 0; i < 8; i++) {
+        c->timers[i].total_ms = 0;
+        c->timers[i].n = 0;
+    }
+    c->timing = enable != 0;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ debug ABI */
+
+extern "C" int ig_debug_eval_terms(ig_ctx* c, const float* s, const float* s_tot, const int32_t* ob, int64_t n, float* ex, float* exc,
+                                   double* term, int64_t* q)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (!c->have_params) return fail("ig_debug_eval_terms: set parameters first");
+    float *ds, *dst, *dex, *dexc;
+    int* dob;
+    double* dterm;
+    long long* dq;
+    DALLOC(ds, (size_t)n);
+    DALLOC(dst, (size_t)n);
+    DALLOC(dob, (size_t)n);
+    DALLOC(dex, (size_t)n);
+    DALLOC(dexc, (size_t)n);
+    DALLOC(dterm, (size_t)n);
+    DALLOC(dq, (size_t)n);
+    HIPCK(hipMemcpy(ds, s, n * sizeof(float), hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(dst, s_tot, n * sizeof(float), hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(dob, ob, n * sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_terms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, ds, dst, dob, (long long)n, c->glob,
+                       c->lgf_tab, dex, dexc, dterm, dq);
+    HIPCK(hipStreamSynchronize(c->stream));
+    HIPCK(hipMemcpy(ex, dex, n * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(exc, dexc, n * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(term, dterm, n * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(q, dq, n * sizeof(long long), hipMemcpyDeviceToHost));
+    hipFree(ds);
+    hipFree(dst);
+    hipFree(dob);
+    hipFree(dex);
+    hipFree(dexc);
+    hipFree(dterm);
+    hipFree(dq);
+    return 0;
+}
+
+extern "C" int ig_debug_candidate_state(ig_ctx* c, int32_t cand, int32_t slot, int32_t* soa)
+{
+    HIPCK(hipSetDevice(c->device));
+    HIPCK(hipStreamSynchronize(c->stream));
+    if (cand < 0 || cand >= c->mb.capC || slot < 0 || slot > IG_N_TMP_STRUCT) return fail("ig_debug_candidate_state: bad index");
+    const size_t n = c->N;
+    CandMeta m;
+    HIPCK(hipMemcpy(&m, c->mb.meta + cand, sizeof m, hipMemcpyDeviceToHost));
+    if (m.kidx[slot] < 0) return fail("ig_debug_candidate_state: slot %d was not materialised for candidate %d", slot, cand);
+    /* start from the live genome (internal ids), overlay the local window */
+    std::vector<int> host(17 * n);
+    HIPCK(hipMemcpy(host.data(), c->st_block, 17 * n * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<int> loc((size_t)NDYN * n), gid(n);
+    HIPCK(hipMemcpy(loc.data(), c->mb.loc + ((size_t)(cand * NSLOT + slot) * NDYN) * n, (size_t)NDYN * n * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(gid.data(), c->mb.Lloc + (size_t)cand * n, n * sizeof(int), hipMemcpyDeviceToHost));
+    for (int x = 0; x < m.n_loc; x++)
+        for (int k = 0; k < NDYN; k++) host[k * n + gid[x]] = loc[k * n + x];
+    static const int dyn_src[NDYN] = {0, 1, 2, 3, 6, 8, 9, 10, 11, 12, 13};
+    for (int k = 0; k < NDYN; k++) memcpy(soa + dyn_src[k] * n, &host[k * n], n * sizeof(int));
+    memcpy(soa + 4 * n, &host[11 * n], n * sizeof(int));
+    memcpy(soa + 5 * n, &host[12 * n], n * sizeof(int));
+    memcpy(soa + 14 * n, &host[14 * n], n * sizeof(int));
+    memcpy(soa + 15 * n, &host[15 * n], n * sizeof(int));
+    memcpy(soa + 16 * n, &host[16 * n], n * sizeof(int));
+    for (size_t f = 0; f < n; f++) soa[7 * n + f] = (int)f;
+    return 0;
+}
+
+extern "C" int ig_debug_last_sums(ig_ctx* c, int64_t* nz_hi, int64_t* nz_lo, int64_t* z_hi, int64_t* z_lo, int64_t* n_intra,
+                                  int64_t* ext_hi, int64_t* ext_lo, int64_t* n_slice, int32_t* n_uniq, int32_t* uniq)
+{
+    HIPCK(hipSetDevice(c->device));
+    HIPCK(hipStreamSynchronize(c->stream));
+    Glob hg;
+    HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));
+    const int C = hg.C;
+    std::vector<long long> part((size_t)C * P_STRIDE), qp((size_t)C * Q_STRIDE);
+    std::vector<CandMeta> meta(C);
+    HIPCK(hipMemcpy(part.data(), c->mb.part, part.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(qp.data(), c->q_part, qp.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(meta.data(), c->mb.meta, C * sizeof(CandMeta), hipMemcpyDeviceToHost));
+    for (int cc_ = 0; cc_ < C; cc_++) {
+        const long long* p = &part[(size_t)cc_ * P_STRIDE];
+        const long long* q = &qp[(size_t)cc_ * Q_STRIDE];
+        n_uniq[cc_] = meta[cc_].n_uniq;
+        n_slice[cc_] = p[P_CNT];
+        int64_t eh = p[P_NZ], el = p[P_NZ + 1];
+        ig_acc_normalize(&eh, &el);
+        ext_hi[cc_] = eh;
+        ext_lo[cc_] = el;
+        for (int s = 0; s < IG_N_TMP_STRUCT; s++) {
+            const int o = cc_ * IG_N_TMP_STRUCT + s;
+            uniq[o] = -1;
+            nz_hi[o] = nz_lo[o] = z_hi[o] = z_lo[o] = n_intra[o] = 0;
+        }
+        for (int k = 1; k <= meta[cc_].n_uniq; k++) {
+            const int s = meta[cc_].uniq[k - 1];
+            const int o = cc_ * IG_N_TMP_STRUCT + s;
+            uniq[cc_ * IG_N_TMP_STRUCT + (k - 1)] = s;
+            int64_t h = p[P_NZ + 2 * k], l = p[P_NZ + 2 * k + 1];
+            ig_acc_normalize(&h, &l);
+            nz_hi[o] = h;
+            nz_lo[o] = l;
+            h = hg.z_hi + q[Q_Z + 2 * k] - q[Q_Z];
+            l = hg.z_lo + q[Q_Z + 2 * k + 1] - q[Q_Z + 1];
+            ig_acc_normalize(&h, &l);
+            z_hi[o] = h;
+            z_lo[o] = l;
+            n_intra[o] = hg.n_intra + q[Q_NI + k] - q[Q_NI];
+        }
+    }
+    return 0;
+}
+
+extern "C" int ig_debug_tables(ig_ctx* c, float* dist, int32_t* id_c, float* s_tot, int32_t* pos, int32_t* len)
+{
+    HIPCK(hipSetDevice(c->device));
+    HIPCK(hipStreamSynchronize(c->stream));
+    const size_t m = c->M;
+    HIPCK(hipMemcpy(dist, c->tab.dist, m * 4, hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(id_c, c->tab.cid, m * 4, hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(s_tot, c->tab.stot, m * 4, hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(pos, c->tab.pos, m * 4, hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(len, c->tab.len, m * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int ig_debug_set_tail_quirk(int on)
+{
+    g_tail_quirk = on;
+    return 0;
+}
+
+/* maintained exact sums {nz_hi, nz_lo, z_hi, z_lo, n_intra} and {n_contigs, next_cid, ch_c, ch_k, ch_slot, ch_windowed} */
+extern "C" int ig_debug_globals(ig_ctx* c, int64_t* sums5, int32_t* ints6)
+{
+    HIPCK(hipSetDevice(c->device));
+    HIPCK(hipStreamSynchronize(c->stream));
+    Glob hg;
+    HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));
+    sums5[0] = hg.nz_hi;
+    sums5[1] = hg.nz_lo;
+    sums5[2] = hg.z_hi;
+    sums5[3] = hg.z_lo;
+    sums5[4] = hg.n_intra;
+    ints6[0] = hg.n_contigs;
+    ints6[1] = hg.next_cid;
+    ints6[2] = hg.ch_c;
+    ints6[3] = hg.ch_k;
+    ints6[4] = hg.ch_slot;
+    ints6[5] = hg.ch_windowed;
+    return 0;
+}

@@ -1,0 +1,282 @@
+"""ctypes binding of libinstagraal_hip.so (the C ABI of include/instagraal_hip.h).
+
+There is no CPU fallback: if the shared library or a HIP device is missing, every entry
+point raises.  The library is built in-tree by ``__graft_entry__.build()`` / ``build_lib()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "libinstagraal_hip.so")
+SRC = os.path.join(HERE, "csrc", "ig_hip.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "ig_ops.cuh"), os.path.join(ROOT, "include", "ig_detmath.h"),
+        os.path.join(ROOT, "include", "instagraal_hip.h")]
+
+N_TMP_STRUCT = 24
+MAX_CANDIDATES = 16
+
+FRAG_FIELDS = ("pos", "sub_pos", "id_c", "start_bp", "len_bp", "sub_len", "circ", "id", "prev", "next", "l_cont",
+               "sub_l_cont", "l_cont_bp", "ori", "rep", "activ", "id_d")  # kernel_sparse_adapt.cu:40-58
+
+
+class MoveResult(C.Structure):
+    _fields_ = [("o", C.c_double), ("dist", C.c_double), ("mean_len", C.c_double), ("op_sampled", C.c_int32),
+                ("id_f_sampled", C.c_int32), ("n_contigs", C.c_int32), ("n_candidates", C.c_int32),
+                ("n_slice", C.c_int64), ("n_evals", C.c_int64), ("bytes_min", C.c_int64), ("error", C.c_int32),
+                ("pad", C.c_int32)]
+
+
+MOVE_RESULT_DTYPE = np.dtype([("o", np.float64), ("dist", np.float64), ("mean_len", np.float64),
+                              ("op_sampled", np.int32), ("id_f_sampled", np.int32), ("n_contigs", np.int32),
+                              ("n_candidates", np.int32), ("n_slice", np.int64), ("n_evals", np.int64),
+                              ("bytes_min", np.int64), ("error", np.int32), ("pad", np.int32)])
+assert MOVE_RESULT_DTYPE.itemsize == C.sizeof(MoveResult)
+
+
+def build_lib(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in DEPS):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-Wno-unused-result", "-o", LIB_PATH, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libinstagraal_hip.so is missing (%s): run __graft_entry__.build(); "
+                               "the MI355X path has no CPU fallback" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.ig_last_error.restype = C.c_char_p
+        _lib.ig_partials_count.restype = C.c_int64
+        _lib.ig_partials_device_ptr.restype = C.c_void_p
+        _lib.ig_partials_count.argtypes = [C.c_void_p]
+        _lib.ig_partials_device_ptr.argtypes = [C.c_void_p]
+    return _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _ck(rc):
+    if rc != 0:
+        raise HipError(lib().ig_last_error().decode())
+
+
+def _p(a):
+    return C.c_void_p(0) if a is None else C.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """One handle per sampler (ig_create .. ig_destroy)."""
+
+    def __init__(self, device_id=0):
+        self._h = C.c_void_p()
+        _ck(lib().ig_create(C.c_int(device_id), C.byref(self._h)))
+        self.N = 0
+        self.M = 0
+
+    def close(self):
+        if self._h:
+            lib().ig_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- upload
+    def upload_contacts(self, row, col, cnt, M, rank=0, world=1):
+        row = np.ascontiguousarray(row, np.int32)
+        col = np.ascontiguousarray(col, np.int32)
+        cnt = np.ascontiguousarray(cnt, np.int32)
+        _ck(lib().ig_upload_contacts(self._h, _p(row), _p(col), _p(cnt), C.c_int64(row.size), C.c_int32(M), C.c_int32(rank),
+                                     C.c_int32(world)))
+        self.M = int(M)
+
+    def upload_subfrag_table(self, table):
+        """table: (M,) structured float4 or (M, 4) float32"""
+        t = np.ascontiguousarray(table)
+        if t.dtype.names:
+            t = np.stack([t["x"], t["y"], t["z"], t["w"]], axis=1)
+        t = np.ascontiguousarray(t, np.float32)
+        _ck(lib().ig_upload_subfrag_table(self._h, _p(t), C.c_int32(t.shape[0])))
+        self.M = int(t.shape[0])
+
+    def upload_state(self, soa17):
+        s = np.ascontiguousarray(soa17, np.int32)
+        assert s.ndim == 2 and s.shape[0] == 17
+        _ck(lib().ig_upload_state(self._h, _p(s), C.c_int32(s.shape[1])))
+        self.N = int(s.shape[1])
+
+    def download_state(self):
+        out = np.zeros((17, self.N), np.int32)
+        _ck(lib().ig_download_state(self._h, _p(out)))
+        return out
+
+    def set_params(self, p8, mean_subfrag_kb, which=0):
+        p = np.ascontiguousarray(p8, np.float32)
+        assert p.size == 8
+        _ck(lib().ig_set_params(self._h, _p(p), C.c_float(float(mean_subfrag_kb)), C.c_int(which)))
+
+    def set_insert_config(self, list_bounds6, max_bounds_insert):
+        b = np.ascontiguousarray(list_bounds6, np.int32)
+        assert b.size == 6
+        _ck(lib().ig_set_insert_config(self._h, _p(b), C.c_int32(int(max_bounds_insert))))
+
+    def set_initial_genome(self, init_prev, init_next, orientable, blacklisted=()):
+        ip = np.ascontiguousarray(init_prev, np.int32)
+        inn = np.ascontiguousarray(init_next, np.int32)
+        o = np.ascontiguousarray(orientable, np.int32)
+        b = np.ascontiguousarray(list(blacklisted), np.int32)
+        _ck(lib().ig_set_initial_genome(self._h, _p(ip), _p(inn), _p(o), _p(b) if b.size else C.c_void_p(0), C.c_int32(b.size)))
+
+    # ---- likelihood
+    def full_likelihood(self, which=0, use_prev_tables=False):
+        nz = C.c_double()
+        z = C.c_double()
+        limbs = np.zeros(5, np.int64)
+        _ck(lib().ig_full_likelihood(self._h, C.c_int(which), C.c_int(int(use_prev_tables)), C.byref(nz), C.byref(z), _p(limbs)))
+        return nz.value, z.value, limbs
+
+    # ---- moves
+    def score_move(self, frag_a, cands):
+        c = np.ascontiguousarray(cands, np.int32)
+        out = np.zeros(c.size * N_TMP_STRUCT, np.float64)
+        _ck(lib().ig_score_move(self._h, C.c_int32(int(frag_a)), _p(c), C.c_int32(c.size), _p(out)))
+        return out
+
+    def apply(self, frag_a, frag_b, op):
+        _ck(lib().ig_apply(self._h, C.c_int32(int(frag_a)), C.c_int32(int(frag_b)), C.c_int32(int(op))))
+
+    def step(self, frag_a, cands, want_scores=True):
+        c = np.ascontiguousarray(cands, np.int32)
+        res = MoveResult()
+        sc = np.zeros(c.size * N_TMP_STRUCT, np.float64) if want_scores else None
+        _ck(lib().ig_step(self._h, C.c_int32(int(frag_a)), _p(c), C.c_int32(c.size), C.byref(res), _p(sc)))
+        return res, sc
+
+    def step_batch(self, frags, cands):
+        """frags: (n,), cands: (n, max_c) -1 padded -> structured array of MOVE_RESULT_DTYPE"""
+        f = np.ascontiguousarray(frags, np.int32)
+        c = np.ascontiguousarray(cands, np.int32)
+        assert c.ndim == 2 and c.shape[0] == f.size
+        res = np.zeros(f.size, MOVE_RESULT_DTYPE)
+        _ck(lib().ig_step_batch(self._h, C.c_int32(f.size), _p(f), _p(c), C.c_int32(c.shape[1]), _p(res)))
+        return res
+
+    # ---- bookkeeping
+    def renumber_contigs(self):
+        n = C.c_int32()
+        m = C.c_float()
+        mx = C.c_int32()
+        _ck(lib().ig_renumber_contigs(self._h, C.byref(n), C.byref(m), C.byref(mx)))
+        return n.value, np.float32(m.value), mx.value
+
+    def bomb(self, shuffle):
+        s = np.ascontiguousarray(shuffle, np.int32)
+        _ck(lib().ig_bomb(self._h, _p(s)))
+
+    def genome_distance(self):
+        d = C.c_double()
+        _ck(lib().ig_genome_distance(self._h, C.byref(d)))
+        return d.value
+
+    def valid_insert(self):
+        out = np.zeros(12, np.int32)
+        _ck(lib().ig_get_valid_insert(self._h, _p(out)))
+        return out
+
+    def sync(self):
+        _ck(lib().ig_sync(self._h))
+
+    def set_stream(self, hip_stream_ptr):
+        _ck(lib().ig_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    # ---- timing
+    def reset_timers(self, enable=True):
+        _ck(lib().ig_reset_timers(self._h, C.c_int(int(enable))))
+
+    def kernel_time_ms(self, name):
+        avg = C.c_double()
+        n = C.c_int64()
+        _ck(lib().ig_kernel_time_ms(self._h, name.encode(), C.byref(avg), C.byref(n)))
+        return avg.value, n.value
+
+    # ---- multi-GPU two-phase move
+    def partials(self):
+        return lib().ig_partials_device_ptr(self._h), lib().ig_partials_count(self._h)
+
+    def step_begin(self, frag_a, cands):
+        c = np.ascontiguousarray(cands, np.int32)
+        _ck(lib().ig_step_begin(self._h, C.c_int32(int(frag_a)), _p(c), C.c_int32(c.size)))
+
+    def step_finish(self, n_cands, want_scores=False):
+        res = MoveResult()
+        sc = np.zeros(n_cands * N_TMP_STRUCT, np.float64) if want_scores else None
+        _ck(lib().ig_step_finish(self._h, C.byref(res), _p(sc)))
+        return res, sc
+
+    # ---- debug
+    def debug_eval_terms(self, s, s_tot, ob):
+        s = np.ascontiguousarray(s, np.float32)
+        st = np.ascontiguousarray(s_tot, np.float32)
+        ob = np.ascontiguousarray(ob, np.int32)
+        n = s.size
+        ex = np.zeros(n, np.float32)
+        exc = np.zeros(n, np.float32)
+        term = np.zeros(n, np.float64)
+        q = np.zeros(n, np.int64)
+        _ck(lib().ig_debug_eval_terms(self._h, _p(s), _p(st), _p(ob), C.c_int64(n), _p(ex), _p(exc), _p(term), _p(q)))
+        return ex, exc, term, q
+
+    def debug_candidate_state(self, cand, slot):
+        out = np.zeros((17, self.N), np.int32)
+        _ck(lib().ig_debug_candidate_state(self._h, C.c_int32(cand), C.c_int32(slot), _p(out)))
+        return out
+
+    def debug_last_sums(self, n_cands):
+        T = N_TMP_STRUCT
+        a = {k: np.zeros(n_cands * T, np.int64) for k in ("nz_hi", "nz_lo", "z_hi", "z_lo", "n_intra")}
+        ext_hi = np.zeros(n_cands, np.int64)
+        ext_lo = np.zeros(n_cands, np.int64)
+        n_slice = np.zeros(n_cands, np.int64)
+        n_uniq = np.zeros(n_cands, np.int32)
+        uniq = np.zeros(n_cands * T, np.int32)
+        _ck(lib().ig_debug_last_sums(self._h, _p(a["nz_hi"]), _p(a["nz_lo"]), _p(a["z_hi"]), _p(a["z_lo"]), _p(a["n_intra"]),
+                                     _p(ext_hi), _p(ext_lo), _p(n_slice), _p(n_uniq), _p(uniq)))
+        a.update(ext_hi=ext_hi, ext_lo=ext_lo, n_slice=n_slice, n_uniq=n_uniq, uniq=uniq.reshape(n_cands, T))
+        return a
+
+    def debug_globals(self):
+        sums = np.zeros(5, np.int64)
+        ints = np.zeros(6, np.int32)
+        _ck(lib().ig_debug_globals(self._h, _p(sums), _p(ints)))
+        return sums, ints
+
+    def debug_tables(self):
+        M = self.M
+        d = np.zeros(M, np.float32)
+        c = np.zeros(M, np.int32)
+        st = np.zeros(M, np.float32)
+        p = np.zeros(M, np.int32)
+        ln = np.zeros(M, np.int32)
+        _ck(lib().ig_debug_tables(self._h, _p(d), _p(c), _p(st), _p(p), _p(ln)))
+        return d, c, st, p, ln
