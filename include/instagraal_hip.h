@@ -102,6 +102,7 @@ int ig_get_valid_insert(ig_ctx* ctx, int32_t out12[12]); /* gpu_list_valid_inser
 /* ---- multi-GPU (contact shards) -------------------------- */
 /* Two-phase move: partial sums over this handle's contact shard are left in a device buffer of
  * ig_partials_count() int64 values; the caller all-reduces (SUM) it across ranks, then finishes. */
+int ig_set_shard(ig_ctx* ctx, int32_t rank, int32_t world); /* score rows r with r % world == rank */
 int64_t ig_partials_count(ig_ctx* ctx);
 void* ig_partials_device_ptr(ig_ctx* ctx);
 int ig_step_begin(ig_ctx* ctx, int32_t frag_a, const int32_t* cands, int32_t C);
@@ -123,6 +124,10 @@ int ig_debug_candidate_state(ig_ctx* ctx, int32_t c, int32_t slot, int32_t* soa1
 int ig_debug_last_sums(ig_ctx* ctx, int64_t* nz_hi, int64_t* nz_lo, int64_t* z_hi, int64_t* z_lo, int64_t* n_intra,
                        int64_t* ext_hi, int64_t* ext_lo, int64_t* n_slice, int32_t* n_uniq, int32_t* uniq);
 int ig_debug_tables(ig_ctx* ctx, float* dist, int32_t* id_c, float* s_tot, int32_t* pos, int32_t* len);
+/* maintained exact sums {nz_hi, nz_lo, z_hi, z_lo, n_intra}; {n_contigs, next_cid, chosen c, k, slot, windowed} */
+int ig_debug_globals(ig_ctx* ctx, int64_t* sums5, int32_t* ints6);
+/* 0 disables the reference's dropped-tail behaviour of eval_sub_likelihood (quirk Q5); default 1 */
+int ig_debug_set_tail_quirk(int on);
 
 #ifdef __cplusplus
 }

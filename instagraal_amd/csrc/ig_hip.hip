@@ -103,6 +103,7 @@ struct Glob {
     double n_tot_pxl;
     double lgf[15];
     int n_contigs, next_cid, n_black, N, M;
+    int n_prev_touched;
     int valid_insert[12];
     int error;
     /* move in flight */
@@ -161,6 +162,8 @@ struct ig_ctx {
     int* d_frags;
     int* d_cands;
     int cands_cap;
+    int* prev_touched;
+    unsigned timing_mask;
     /* timers */
     bool timing;
     struct Timer {
@@ -476,8 +479,19 @@ __global__ void k_post(State st, const int* __restrict__ ip, const int* __restri
  * block 0 also derives per-candidate metadata, get_bounds flags and the uniq-mutation lists
  * (extract_uniq_mutations KA:4492-4553, with the STALE flags of quirk Q4). */
 __global__ void k_gather(State st, Glob* g, MoveBuf mb, const int* __restrict__ cands_all, const int* __restrict__ frags_all,
-                         int move, int max_c, long long* q_part)
+                         int move, int max_c, long long* q_part, Tables tab, Tables tab_prev, const int* __restrict__ prev_touched,
+                         int force_slot)
 {
+    /* tab_prev := coordinates before the LAST applied move (eval_likelihood_4_nuisance reads tables that
+     * were filled before the move was applied, CL:1296-1344 / quirk Q12): catch up the entries that move touched */
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g->n_prev_touched; i += gridDim.x * blockDim.x) {
+        const int s = prev_touched[i];
+        tab_prev.dist[s] = tab.dist[s];
+        tab_prev.cid[s] = tab.cid[s];
+        tab_prev.stot[s] = tab.stot[s];
+        tab_prev.pos[s] = tab.pos[s];
+        tab_prev.len[s] = tab.len[s];
+    }
     __shared__ int sh_flags[IG_MAX_CANDIDATES][12];
     const int A = frags_all[move];
     const int* cands = cands_all + (size_t)move * max_c;
@@ -509,6 +523,7 @@ __global__ void k_gather(State st, Glob* g, MoveBuf mb, const int* __restrict__ 
         g->C = C;
         g->d_hi = 0;
         g->d_lo = 0;
+        g->force_slot = force_slot;
     }
     for (int i = t; i < C * P_STRIDE; i += blockDim.x) mb.part[i] = 0;
     for (int i = t; i < C * Q_STRIDE; i += blockDim.x) q_part[i] = 0;
@@ -549,8 +564,8 @@ __global__ void k_gather(State st, Glob* g, MoveBuf mb, const int* __restrict__ 
         int n = 0;
         int* u = m->uniq;
         for (int k = 0; k < NSLOT; k++) m->kidx[k] = -1;
-        if (g->force_slot >= 0) {
-            u[n++] = g->force_slot;
+        if (force_slot >= 0) {
+            u[n++] = force_slot;
         } else {
             if (t == 0) {
                 u[n++] = 0;
@@ -929,7 +944,7 @@ __global__ void k_force_choice(Glob* g, MoveBuf mb, int slot)
 
 /* k_apply: the winner becomes the live genome (copy_struct KA:4566-4591) and the coordinate
  * tables of the touched sub-fragments are refreshed from its column. */
-__global__ void k_apply(State st, Tables tab, Glob* g, MoveBuf mb, long long* q_part, int forced)
+__global__ void k_apply(State st, Tables tab, Glob* g, MoveBuf mb, long long* q_part, int forced, int* prev_touched)
 {
     const int c = g->ch_c, slot = g->ch_slot, k = g->ch_k;
     if (g->error) return;
@@ -970,9 +985,11 @@ __global__ void k_apply(State st, Tables tab, Glob* g, MoveBuf mb, long long* q_
         tab.cid[s] = code == 0 ? m.ctgA : (code == 1 ? m.ctgB : fresh + (code - 2));
         tab.stot[s] = cm[code].stot;
         tab.len[s] = cm[code].len;
+        prev_touched[ls] = s;
     }
     if (tid == 0) {
         const long long* qp = q_part + (size_t)c * Q_STRIDE;
+        g->n_prev_touched = m.m_loc;
         atomicAdd(&g->n_contigs, m.same ? -1 : -2);
         long long dh, dl;
         if (g->ch_windowed) {
@@ -1059,6 +1076,7 @@ struct TimedLaunch {
     hipEvent_t a, b;
     TimedLaunch(ig_ctx* ctx, int which) : c(ctx), id(which), a(nullptr), b(nullptr)
     {
+        if (c->timing && !((c->timing_mask >> id) & 1u)) return;
         if (c->timing) {
             hipEventCreate(&a);
             hipEventCreate(&b);
@@ -1067,7 +1085,7 @@ struct TimedLaunch {
     }
     ~TimedLaunch()
     {
-        if (c->timing) {
+        if (c->timing && a) {
             hipEventRecord(b, c->stream);
             c->timers[id].ev.emplace_back(a, b);
         }
@@ -1121,6 +1139,8 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->results_cap = 0;
     c->d_frags = c->d_cands = nullptr;
     c->cands_cap = 0;
+    c->prev_touched = nullptr;
+    c->timing_mask = 0xff;
     c->timing = false;
     for (int i = 0; i < 8; i++) {
         c->timers[i].name = kTimerNames[i];
@@ -1197,6 +1217,7 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipFree(c->d_results);
     hipFree(c->d_frags);
     hipFree(c->d_cands);
+    hipFree(c->prev_touched);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1308,6 +1329,8 @@ extern "C" int ig_upload_subfrag_table(ig_ctx* c, const float* xyzw, int32_t M)
         tb->pos = blk + 3 * (size_t)M;
         tb->len = blk + 4 * (size_t)M;
     }
+    hipFree(c->prev_touched);
+    DALLOC(c->prev_touched, (size_t)M);
     c->M = M;
     c->have_sub = true;
     return 0;
@@ -1426,6 +1449,7 @@ static int launch_recompute(ig_ctx* c)
     hg.n_intra = h[4];
     hg.n_contigs = ((int*)&h[6])[0];
     hg.credit2 = hg.credit2_acc;
+    hg.n_prev_touched = 0;
     HIPCK(hipMemcpy(c->glob, &hg, sizeof hg, hipMemcpyHostToDevice));
     return 0;
 }
@@ -1628,11 +1652,10 @@ static void enqueue_move(ig_ctx* c, int move, int max_c, int force_slot, int pha
     const int N = c->N;
     const int gN = (N + 255) / 256;
     if (phase == 0 || phase == 2) {
-        if (force_slot != -1 || true) hipMemcpyAsync(&c->glob->force_slot, &force_slot, sizeof(int), hipMemcpyHostToDevice, c->stream);
         {
             TimedLaunch t(c, T_GATHER);
             hipLaunchKernelGGL(k_gather, dim3(gN), dim3(256), 0, c->stream, c->st, c->glob, c->mb, c->d_cands, c->d_frags, move, max_c,
-                               c->q_part);
+                               c->q_part, c->tab, c->tab_prev, c->prev_touched, force_slot);
         }
         {
             TimedLaunch t(c, T_MUTATE);
@@ -1666,7 +1689,7 @@ static void enqueue_apply(ig_ctx* c, int move, int forced)
     }
     {
         TimedLaunch t(c, T_APPLY);
-        hipLaunchKernelGGL(k_apply, dim3(64), dim3(256), 0, c->stream, c->st, c->tab, c->glob, c->mb, c->q_part, forced);
+        hipLaunchKernelGGL(k_apply, dim3(64), dim3(256), 0, c->stream, c->st, c->tab, c->glob, c->mb, c->q_part, forced, c->prev_touched);
     }
     {
         TimedLaunch t(c, T_POST);
@@ -1780,6 +1803,15 @@ extern "C" int ig_apply(ig_ctx* c, int32_t frag_a, int32_t frag_b, int32_t op)
     return 0;
 }
 
+extern "C" int ig_set_shard(ig_ctx* c, int32_t rank, int32_t world)
+{
+    if (world < 1 || rank < 0 || rank >= world) return fail("ig_set_shard: bad shard %d/%d", rank, world);
+    HIPCK(hipStreamSynchronize(c->stream));
+    c->rank = rank;
+    c->world = world;
+    return 0;
+}
+
 extern "C" int64_t ig_partials_count(ig_ctx* c) { return (int64_t)c->mb.capC * P_STRIDE; }
 extern "C" void* ig_partials_device_ptr(ig_ctx* c) { return c->mb.part; }
 
@@ -1839,6 +1871,7 @@ extern "C" int ig_reset_timers(ig_ctx* c, int enable)
         c->timers[i].n = 0;
     }
     c->timing = enable != 0;
+    c->timing_mask = enable > 1 ? (unsigned)(enable >> 1) : 0xffu; /* enable = 1 | (mask << 1) */
     return 0;
 }
 

@@ -221,6 +221,9 @@ class Context:
         return avg.value, n.value
 
     # ---- multi-GPU two-phase move
+    def set_shard(self, rank, world):
+        _ck(lib().ig_set_shard(self._h, C.c_int32(rank), C.c_int32(world)))
+
     def partials(self):
         return lib().ig_partials_device_ptr(self._h), lib().ig_partials_count(self._h)
 

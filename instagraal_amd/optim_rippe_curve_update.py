@@ -1,0 +1,70 @@
+"""P(s) ("Rippe") curve fit used by the sampler's host side.
+
+Same public names and argument meaning as the reference module
+``/root/reference/src/instagraal/optim_rippe_curve_update.py``: ``peval`` (l.21-31),
+``log_residuals`` (l.34-49), ``estimate_param_rippe`` (l.64-106), ``estimate_max_dist_intra`` (l.120-134),
+``estimate_max_dist_intra_nuis`` (l.137-149).  Host-only scipy code in the reference as well -- this is
+set-up / nuisance bookkeeping, not part of the device path.
+"""
+import warnings
+
+import numpy as np
+from scipy.optimize import fsolve, leastsq
+
+d = 2  # the exponential cut-off parameter is pinned (reference l.8)
+
+
+def _rippe_shape(x, kuhn, lm, slope, dd):
+    u = lm * x / kuhn
+    return 0.53 * (kuhn ** -3.0) * np.power(u, slope) * np.exp((dd - 2) / (np.power(u, 2) + dd))
+
+
+def peval(x, param):
+    """param = (kuhn, lm, slope, A, ...): amplitude is param[3] whatever follows (callers rely on it)."""
+    return param[3] * _rippe_shape(x, param[0], param[1], param[2], d)
+
+
+def log_residuals(p, y, x):
+    kuhn, lm, slope, A = p
+    with np.errstate(invalid="ignore", divide="ignore"):
+        model = (np.log(A) + np.log(0.53) - 3 * np.log(kuhn) + slope * (np.log(lm * x / kuhn))
+                 + (d - 2) / (np.power((lm * x / kuhn), 2) + d))
+    return y - model
+
+
+def estimate_param_rippe(y_meas, x_bins):
+    kuhn, lm, slope = 50, 9.6, -1.5
+    A = np.max(y_meas)
+    lower_fact = 7.0
+    plsq = leastsq(log_residuals, [kuhn, lm, slope, A], args=(np.log(y_meas / lower_fact), x_bins))
+    y_estim = peval(x_bins, plsq[0])
+    kuhn_x, lm_x, slope_x, A_x = plsq[0]
+    out = [kuhn_x, lm_x, slope_x, d, A_x]
+    if np.any(np.isnan(np.array(out))) or slope_x >= 0:
+        test = peval(x_bins, [kuhn, lm, slope, A])
+        new_A = y_meas[0] * A / test.max()
+        out = [kuhn, lm, slope, d, A * new_A]
+        y_estim = peval(x_bins, [kuhn, lm, slope, new_A])
+    return out, y_estim
+
+
+def residual_4_max_dist(x, p):
+    kuhn, lm, slope, dd, A, y = p
+    x[np.isnan(x)] = 0
+    x = np.abs(x)
+    return np.abs(y - A * _rippe_shape(x, kuhn, lm, slope, dd))
+
+
+def _solve(p, val_inter, s0):
+    kuhn, lm, slope, dd, A = p
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        return fsolve(residual_4_max_dist, s0, args=([kuhn, lm, slope, dd, A, val_inter]))[0]
+
+
+def estimate_max_dist_intra(p, val_inter):
+    return np.abs(_solve(p, val_inter, 500))
+
+
+def estimate_max_dist_intra_nuis(p, val_inter, old_s):
+    return _solve(p, val_inter, old_s)

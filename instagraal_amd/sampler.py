@@ -1,13 +1,33 @@
-"""Host-side mirror of the reference's ``sampler`` (cuda_lib_gl_single.py:91-3186) over the HIP C ABI."""
+"""Host-side mirror of the reference's ``sampler`` over the HIP C ABI (drop-in for the scoring path).
+
+Mirrors ``/root/reference/src/instagraal/cuda_lib_gl_single.py`` ("CL"): same constructor
+arguments (CL:92-125), same public methods and attributes that ``simulation`` and
+``instagraal_class.full_em`` touch:
+
+    step_sampler(id_frag, n_neighbours, dt) -> 6-tuple            CL:1401-1465
+    step_nuisance_parameters(dt, t, n_step) -> 8-tuple            CL:2961-3051
+    estimate_parameters_rippe / eval_likelihood_init              CL:2239-2372, 1193-1243
+    bomb_the_genome, modify_gl_cuda_buffer, dist_inter_genome     CL:1925-1948, 2715-2881, 665-716
+    apply_replay_simu, free_gpu                                   CL:2546-2553, 3167-3177
+    gpu_vect_frags.copy_from_gpu() + numpy attributes             gpustruct.py:162-186
+
+What the reference does with ~450 synchronous pycuda launches and 5 PCIe sorts per move is ONE
+call here (``ig_step``: eight launches, one 80-byte D2H).  ``step_sampler_batch`` enqueues many
+moves without any host round trip; candidate draws do not depend on the genome state
+(CL:3103-3141 reads fixed distributions), so they can be drawn ahead with the same RNG stream.
+"""
 from __future__ import annotations
 
 import numpy as np
 
 from . import hip_lib
+from . import optim_rippe_curve_update as opti
 
 LIST_SIZE = np.array([1, 3, 5, 10, 20, 50, 200, 200], dtype=np.int32)  # CL:417
 N_INSERT_BLOCKS = 6  # CL:192
+N_TMP_STRUCT = 24  # CL:194
 PARAM_NAMES = ("kuhn", "lm", "c1", "slope", "d", "d_max", "fact", "v_inter")  # KA:91-100
+PARAM_DTYPE = np.dtype([(k, np.float32) for k in PARAM_NAMES], align=True)  # CL:235-247
 
 
 def soa17_from_dict(S_o_A_frags, n):
@@ -36,3 +56,331 @@ def problem_to_context(prob, params=None, device_id=0, rank=0, world=1):
     ctx.set_params([np.float32(p[k]) for k in PARAM_NAMES], mean_kb, 0)
     ctx.set_params([np.float32(p[k]) for k in PARAM_NAMES], mean_kb, 1)
     return ctx
+
+
+class DeviceFrags:
+    """Stand-in for GPUStruct (gpustruct.py): ``copy_from_gpu()`` refreshes numpy attributes
+    ``pos, sub_pos, id_c, ...`` from the device (contig ids canonically renumbered)."""
+
+    def __init__(self, ctx):
+        self._ctx = ctx
+        self.copy_from_gpu()
+
+    def copy_from_gpu(self, skip=None):
+        soa = self._ctx.download_state()
+        for k, name in enumerate(hip_lib.FRAG_FIELDS):
+            setattr(self, name, soa[k].copy())
+        return self
+
+    def soa17(self):
+        return np.stack([getattr(self, k) for k in hip_lib.FRAG_FIELDS]).astype(np.int32)
+
+
+class sampler:  # noqa: N801 - the reference's class name
+    def __init__(self, use_rippe, S_o_A_frags, collector_id_repeats, frag_dispatcher, id_frag_duplicated,
+                 id_frags_blacklisted, n_frags, n_new_frags, init_n_sub_frags, n_new_sub_frags, np_rep_sub_frags_id,
+                 sub_sampled_sparse_matrix, np_sub_frags_len_bp, np_sub_frags_id, np_sub_frags_accu, np_sub_frags_2_frags,
+                 mean_squared_frags_per_bin, norm_vect_accu, sub_candidates_dup, sub_candidates_output_data,
+                 S_o_A_sub_frags, sub_collector_id_repeats, sub_frag_dispatcher, sparse_matrix, mean_value_trans,
+                 n_iterations, is_simu, vel=None, pos=None, device_id=0, coo=None):
+        if not use_rippe:
+            raise NotImplementedError("use_rippe=False is unreachable from the reference CLI (instagraal.py:564)")
+        if len(sub_candidates_dup) or len(id_frag_duplicated):
+            raise NotImplementedError("repeated fragments are dead in the reference (simu_single.py:513)")
+        self.o = 0
+        self.log_e = 0.43429448190325182  # CL:128
+        self.n_frags = np.int32(n_frags)
+        self.n_new_frags = np.int32(n_new_frags)
+        self.init_n_sub_frags = np.int32(init_n_sub_frags)
+        self.n_new_sub_frags = np.int32(n_new_sub_frags)
+        self.id_frags_blacklisted = list(id_frags_blacklisted)
+        self.S_o_A_frags = S_o_A_frags
+        self.S_o_A_sub_frags = S_o_A_sub_frags
+        self.np_sub_frags_id = np_sub_frags_id
+        self.np_sub_frags_2_frags = np_sub_frags_2_frags
+        self.sub_sampled_sparse_matrix = sub_sampled_sparse_matrix
+        self.mean_len_bp_frags = S_o_A_sub_frags["len_bp"].mean()  # CL:231
+        self.mean_value_trans = mean_value_trans
+        self.n_iterations = n_iterations
+        self.is_simu = is_simu
+        self.dt = np.float32(0.01)
+        self.n_insert_blocks = N_INSERT_BLOCKS
+        self.n_tmp_struct = N_TMP_STRUCT
+        N, M = int(n_new_frags), int(n_new_sub_frags)
+
+        # contacts: CL:129, 564-615 (symmetrise, strict upper triangle, COO row-major)
+        if coo is None:
+            import scipy.sparse as sp
+
+            self.sparse_matrix = sparse_matrix + sparse_matrix.transpose()
+            c = sp.triu(self.sparse_matrix.tocoo(), k=1, format="coo")
+            order = np.lexsort((c.col, c.row))
+            row, col, dat = c.row[order], c.col[order], c.data[order]
+        else:
+            row, col, dat = coo
+            self.sparse_matrix = None
+        self.n_non_zero = int(len(dat))
+
+        self.ctx = hip_lib.Context(device_id)
+        self.ctx.upload_subfrag_table(np_sub_frags_2_frags)
+        self.ctx.upload_contacts(row, col, dat, M)
+        self.max_bounds_insert = LIST_SIZE[:N_INSERT_BLOCKS].max() * np.int32(np.round(S_o_A_frags["sub_len"].mean()) + 1)
+        self.ctx.set_insert_config(LIST_SIZE[:N_INSERT_BLOCKS], int(self.max_bounds_insert))
+        self.ctx.upload_state(soa17_from_dict(S_o_A_frags, N))
+        # CL:269-276
+        self.np_init_prev = np.copy(S_o_A_frags["prev"])
+        self.np_init_next = np.copy(S_o_A_frags["next"])
+        self.np_init_orientable = np.array([np_sub_frags_id[S_o_A_frags["id_d"][i]]["w"] > 1 for i in range(N)],
+                                           dtype=np.int32)
+        self.np_init_ori = np.ones(N, dtype=np.int32)
+        self.ctx.set_initial_genome(self.np_init_prev, self.np_init_next, self.np_init_orientable, self.id_frags_blacklisted)
+        self.gpu_vect_frags = DeviceFrags(self.ctx)
+        self.setup_distri_frags()
+        self.param_simu = None
+        self.param_simu_test = None
+        self.likelihood_t = 0.0
+        n, m, _ = self.ctx.renumber_contigs()
+        self.n_contigs, self.mean_length_contigs = n, m
+        self.candidates = []
+        self.all_scores = np.zeros(0)
+
+    # ------------------------------------------------------------ parameters
+    def mean_kb(self):
+        return np.float32(self.mean_len_bp_frags / 1000.0)  # CL:1120
+
+    def setup_rippe_parameters(self, param, d_max):  # CL:2206-2221
+        kuhn, lm, slope, d, fact = param
+        fact = np.float32(np.abs(fact))
+        kuhn = np.float32(np.abs(kuhn))
+        lm = np.float32(np.abs(lm))
+        c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+        return np.array([(kuhn, lm, c1, np.float32(slope), np.float32(d), np.float32(d_max), np.float32(fact),
+                          self.mean_value_trans)], dtype=PARAM_DTYPE)
+
+    def set_param_simu(self, p, which=0):
+        """p: dict or 1-element structured array (KA:91-100 fields)."""
+        if isinstance(p, dict):
+            arr = np.zeros(1, PARAM_DTYPE)
+            for k in PARAM_NAMES:
+                arr[k] = np.float32(p[k])
+            p = arr
+        p = np.array(p, dtype=PARAM_DTYPE).reshape(1)
+        vals = [p[k][0] for k in PARAM_NAMES]
+        if which == 0:
+            self.param_simu = p
+            self.ctx.set_params(vals, self.mean_kb(), 0)
+            if self.param_simu_test is None:
+                self.param_simu_test = p.copy()
+                self.ctx.set_params(vals, self.mean_kb(), 1)
+        else:
+            self.param_simu_test = p
+            self.ctx.set_params(vals, self.mean_kb(), 1)
+
+    def estimate_parameters_rippe(self, max_dist_kb, size_bin_kb, display_graph=False):
+        """CL:2239-2372: binned mean cis contacts of the first n_frags/10 sub-fragment rows, leastsq fit,
+        cis/trans cut-off; then the initial likelihood."""
+        self.bins = np.arange(size_bin_kb, max_dist_kb + size_bin_kb, size_bin_kb)
+        nb = len(self.bins)
+        sm = self.sparse_matrix.tocsr()
+        sub2frag = self.np_sub_frags_2_frags
+        parent = sub2frag["x"].astype(np.int64)
+        id_c = self.S_o_A_frags["id_c"][parent]
+        s_all = self.S_o_A_frags["start_bp"][parent] / 1000.0 + sub2frag["y"]
+        len_kb = self.S_o_A_frags["l_cont_bp"][parent] / 1000
+        acc = np.zeros(nb, np.float64)
+        rows = 0
+        for i in range(0, int(self.n_frags) // 10):
+            if not (size_bin_kb < len_kb[i]):
+                continue
+            s, e = sm.indptr[i], sm.indptr[i + 1]
+            j, dat = sm.indices[s:e], sm.data[s:e]
+            keep = id_c[j] == id_c[i]
+            d = np.abs(s_all[i] - s_all[j[keep]])
+            ok = d < max_dist_kb
+            acc += np.bincount((d[ok] / size_bin_kb).astype(np.int64), weights=dat[keep][ok], minlength=nb)[:nb]
+            rows += 1
+        mean = acc / max(rows, 1)
+        epsi = self.mean_value_trans
+        mean_contacts = np.where((rows == 0) | (mean == 0), np.nan, mean + epsi).astype(np.float32)
+        good = ~np.isnan(mean_contacts)
+        self.bins_upd = np.array(self.bins[good])
+        self.mean_contacts_upd = np.array(mean_contacts[good])
+        p, self.y_estim = opti.estimate_param_rippe(self.mean_contacts_upd, self.bins_upd)
+        self.mean_value_trans = self.mean_value_trans / 10.0  # CL:2338
+        estim_max_dist = opti.estimate_max_dist_intra(p, self.mean_value_trans)
+        self.set_param_simu(self.setup_rippe_parameters(p, estim_max_dist), 0)
+        self.set_param_simu(self.param_simu, 1)
+        self.eval_likelihood_init()
+
+    # ------------------------------------------------------------- neighbours
+    def setup_distri_frags(self):  # CL:3053-3101
+        m = (self.sub_sampled_sparse_matrix + self.sub_sampled_sparse_matrix.T).tocsr()
+        self.sym_sub_sampled_sparse_matrix = m
+        self.distri_frags = {}
+        fact = 3.0
+        indptr, indices, data = m.indptr, m.indices, m.data
+        for i in range(int(self.n_frags)):
+            s, e = indptr[i], indptr[i + 1]
+            yk, vk = indices[s:e], data[s:e]
+            het = yk != i
+            xk = yk[het]
+            dat = np.float32(vk[het]) * fact
+            if dat.sum() > 0:
+                pk = dat / np.linalg.norm(dat, 1)
+            else:
+                tmp = np.ones_like(dat, dtype=np.float32)
+                pk = tmp / tmp.sum()
+            if len(xk) > 0:
+                self.distri_frags[i] = dict(distri="ok", xk=np.array(xk), pk=pk)
+            else:
+                self.distri_frags[i] = dict(distri=None)
+
+    def return_neighbours(self, id_fA, delta0):  # CL:3103-3141
+        ori_id = int(id_fA)  # id_d is the identity without repeats
+        d = self.distri_frags[ori_id]
+        if d["distri"] is not None:
+            distri = d["pk"]
+            n_max = min(delta0, np.nonzero(distri != 0)[0].shape[0])
+            init_id = np.random.choice(d["xk"], n_max, p=distri, replace=False)
+        else:
+            init_id = np.random.choice(self.n_frags, delta0, replace=False)
+        black = self.id_frags_blacklisted
+        return [int(e) for e in init_id if e not in black]
+
+    # ------------------------------------------------------------ likelihood
+    def eval_likelihood_init(self):  # CL:1193-1243
+        nz, z, _ = self.ctx.full_likelihood(0)
+        self.curr_likelihood_on_nz = np.array([nz])
+        # the reference's initial zero-pixel scalar is garbage (-inf): an int is passed where the kernel
+        # takes a float (CL:743, quirk Q8).  It never reaches a score and likelihood_t is overwritten by
+        # the first step_sampler (CL:1457); the well-defined value is reported instead.
+        self.curr_likelihood_on_z = z
+        self.likelihood_t = self.curr_likelihood_on_nz + z
+
+    def eval_likelihood(self):  # CL:1245-1292
+        nz, z, _ = self.ctx.full_likelihood(0)
+        return nz
+
+    def eval_likelihood_4_nuisance(self):  # CL:1296-1344: test parameters, coordinates of the state BEFORE the last move
+        nz, z, _ = self.ctx.full_likelihood(1, use_prev_tables=True)
+        self.curr_likelihood_nuis = np.array([nz]) + z
+        return self.curr_likelihood_nuis
+
+    # ------------------------------------------------------------------ moves
+    def _clean(self, id_frag, candidates):
+        c = sorted(int(x) for x in candidates)
+        if int(id_frag) in c:
+            # reachable only through the uniform fallback draw (CL:3124); the reference then scores
+            # stale collector buffers (quirk Q13) -- no defined result to reproduce
+            c = [x for x in c if x != int(id_frag)]
+        return c
+
+    def step_sampler(self, id_frag, n_neighbours, dt=None, candidates=None):  # CL:1401-1465
+        if candidates is None:
+            candidates = self.return_neighbours(id_frag, n_neighbours)
+        self.candidates = self._clean(id_frag, candidates)
+        res, sc = self.ctx.step(int(id_frag), self.candidates, want_scores=True)
+        self.all_scores = sc
+        self.o = res.o
+        self.likelihood_t = res.o
+        self.n_contigs = np.int32(res.n_contigs)
+        self.mean_length_contigs = np.float32(res.mean_len)
+        self.last_result = res
+        return (res.o, res.dist, res.op_sampled, res.id_f_sampled, self.mean_length_contigs, self.n_contigs)
+
+    def draw_candidates(self, frags, n_neighbours):
+        """Candidates of consecutive moves, consuming numpy's global RNG exactly as successive
+        step_sampler calls would (state-independent: CL:3103-3141)."""
+        out = np.full((len(frags), max(1, n_neighbours)), -1, np.int32)
+        for i, f in enumerate(frags):
+            c = self._clean(f, self.return_neighbours(int(f), n_neighbours))
+            out[i, : len(c)] = c
+        return out
+
+    def step_sampler_batch(self, frags, n_neighbours, candidates=None):
+        """len(frags) consecutive step_sampler calls with no host round trip; returns the structured
+        result array (fields o, dist, op_sampled, id_f_sampled, mean_len, n_contigs, ...)."""
+        frags = np.ascontiguousarray(frags, np.int32)
+        if candidates is None:
+            candidates = self.draw_candidates(frags, n_neighbours)
+        res = self.ctx.step_batch(frags, candidates)
+        last = res[-1]
+        self.o = self.likelihood_t = float(last["o"])
+        self.n_contigs = np.int32(last["n_contigs"])
+        self.mean_length_contigs = np.float32(last["mean_len"])
+        return res
+
+    def apply_replay_simu(self, id_fA, id_fB, op_sampled, dt=None):  # CL:2546-2553
+        self.ctx.apply(int(id_fA), int(id_fB), int(op_sampled))
+        self.gpu_vect_frags.copy_from_gpu()
+
+    def test_copy_struct(self, id_fA, id_f_sampled, mode, max_id=None):  # CL:2094-2151
+        self.ctx.apply(int(id_fA), int(id_f_sampled), int(mode))
+
+    def modify_gl_cuda_buffer(self, id_fi=0, dt=None):  # CL:2715-2881
+        n, m, max_id = self.ctx.renumber_contigs()
+        self.n_contigs, self.mean_length_contigs = np.int32(n), m
+        return np.int32(max_id)
+
+    def bomb_the_genome(self):  # CL:1925-1948
+        a = np.arange(0, self.n_new_frags, dtype=np.int32)
+        np.random.shuffle(a)
+        self.ctx.bomb(a)
+        self.modify_gl_cuda_buffer(0, self.dt)
+
+    def dist_inter_genome(self, tmp_gpu_vect_frags=None):  # CL:665-716
+        return self.ctx.genome_distance()
+
+    # -------------------------------------------------------------- nuisance
+    def temperature(self, t, n_step):  # CL:3163-3165
+        return 1.0
+
+    def step_nuisance_parameters(self, dt, t, n_step):  # CL:2961-3051
+        curr_param = np.copy(self.param_simu)
+        kuhn, lm, c1, slope, d, d_max, fact, d_nuc = curr_param[0]
+        self.sigma_fact = 10 ** (np.log10(fact) - 2)
+        self.sigma_slope = 0.005
+        self.sigma_d_max = 100
+        self.sigma_d_nuc = 10 ** (np.log10(d_nuc) - 2)
+        self.sigma_d = 10
+        id_modif = np.random.choice(4)
+        if id_modif == 0:
+            new_fact = fact + np.random.normal(loc=0.0, scale=self.sigma_fact)
+            new_d_max = opti.estimate_max_dist_intra_nuis([kuhn, lm, slope, d, new_fact], d_nuc, d_max)
+            c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+            out = [(kuhn, lm, c1, slope, d, new_d_max, new_fact, d_nuc)]
+        elif id_modif == 1:
+            new_slope = slope + np.random.normal(loc=0.0, scale=self.sigma_slope)
+            new_d_max = opti.estimate_max_dist_intra_nuis([kuhn, lm, new_slope, d, fact], d_nuc, d_max)
+            c1 = np.float32((0.53 * np.power(lm / kuhn, new_slope)) * np.power(kuhn, -3))
+            out = [(kuhn, lm, c1, new_slope, d, new_d_max, fact, d_nuc)]
+        elif id_modif == 2:
+            new_d_max = d_max + np.random.normal(loc=0.0, scale=self.sigma_d_max)
+            new_d_nuc = opti.peval(new_d_max, [kuhn, lm, slope, d, fact])  # 5 values where 4 are read (quirk Q12)
+            c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+            out = [(kuhn, lm, c1, slope, d, new_d_max, fact, new_d_nuc)]
+        else:
+            if self.sigma_d_nuc <= 0:
+                new_d_nuc = d_nuc
+            else:
+                new_d_nuc = d_nuc + np.random.normal(loc=0.0, scale=self.sigma_d_nuc)
+            new_d_max = opti.estimate_max_dist_intra_nuis([kuhn, lm, slope, d, fact], new_d_nuc, d_max)
+            c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+            out = [(kuhn, lm, c1, slope, d, new_d_max, fact, new_d_nuc)]
+        out = np.array(out, dtype=PARAM_DTYPE)
+        self.set_param_simu(out, 1)
+        self.likelihood_nuis = self.eval_likelihood_4_nuisance()
+        F_t = self.temperature(t, n_step)
+        ratio = np.exp((self.likelihood_nuis - self.likelihood_t) / F_t)
+        u = np.random.rand()
+        success = 0
+        if ratio >= u:
+            success = 1
+            self.set_param_simu(out, 0)
+            self.likelihood_t = self.likelihood_nuis
+        kuhn, lm, c1, slope, d, d_max, fact, d_nuc = self.param_simu[0]
+        y_rippe = opti.peval(self.bins, [kuhn, lm, slope, d, fact]) if hasattr(self, "bins") else None
+        return (fact, d, d_max, d_nuc, slope, self.likelihood_t, success, y_rippe)
+
+    def free_gpu(self):  # CL:3167-3177
+        self.ctx.close()
