@@ -71,10 +71,9 @@ struct State { /* N-length arrays */
 
 struct Tables { /* M-length current coordinates (uni_fill_vect_dist, KA:3763-3822) */
     float* dist;
-    int* cid;
     float* stot;
-    int* pos;
     int* len;
+    int2* cp; /* (contig id, rank in contig) packed: one 8-byte gather per contact endpoint */
 };
 
 struct CandMeta {
@@ -118,7 +117,8 @@ struct MoveBuf {
     int* lbloc;     /* [capC][N] */
     int* slloc;     /* [capC][N] */
     int* subs;      /* [capC][M] global sub-frag id of local sub index */
-    uint2* coords;  /* [capC][M][NSLOT] {dist bits, pos | code<<28} column k */
+    int* rowcnt;    /* [capC][M] sliced contacts per local row (column 0 pass) */
+    uint2* coords;  /* [capC][NSLOT][M] column k: {dist bits, pos | code<<28} per local sub index */
     int* loc;       /* [capC][NSLOT][NDYN][N] candidate genomes on the local window */
     CandMeta* meta; /* [capC] */
     ColMeta* cmeta; /* [capC][NSLOT][NCODE] */
@@ -338,9 +338,8 @@ __global__ void k_fill_tables(State st, const SubTab* __restrict__ sub, Tables t
     const int stot_i = (int)((float)(st.circ[f] == 1) * (float)st.LB[f] / 1000.0f);
     const float dfi = (ori == 1) ? b.wat : b.cri;
     t.dist[s] = (float)st.sbp[f] / 1000.0f + dfi;
-    t.cid[s] = st.cid[f];
     t.stot[s] = (float)stot_i;
-    t.pos[s] = (ori == 1) ? sp + b.w : sp + (sl - 1) - b.w;
+    t.cp[s] = make_int2(st.cid[f], (ori == 1) ? sp + b.w : sp + (sl - 1) - b.w);
     t.len[s] = st.SL[f];
 }
 
@@ -359,15 +358,17 @@ __global__ void k_full_nz(const long long* __restrict__ rowptr, const int2* __re
         const long long b = rowptr[i], e = rowptr[i + 1];
         if (b == e) continue;
         const float di = t.dist[i], sti = t.stot[i];
-        const int ci = t.cid[i], pi = t.pos[i], li = t.len[i];
+        const int2 cpi = t.cp[i];
+        const int ci = cpi.x, pi = cpi.y, li = t.len[i];
         for (long long k = b + lane; k < e; k += 64) {
             const int2 v = cc[k];
             const int j = v.x;
+            const int2 cpj = t.cp[j];
             const float s = fabsf(di - t.dist[j]);
-            const int dp = pi - t.pos[j];
+            const int dp = pi - cpj.y;
             const float s_z = (float)(dp < 0 ? -dp : dp) * mean;
             float ex, ex_z;
-            expected_pair(p, ci == t.cid[j], s, s_z, sti, (float)li * mean, ex, ex_z);
+            expected_pair(p, ci == cpj.x, s, s_z, sti, (float)li * mean, ex, ex_z);
             const long long q = ig_quantize(ig_pixel_term(ex, ex_z, v.y, lgfact_dev(v.y, lgf_tab)));
             hi += q >> 32;
             lo += (long long)(unsigned int)q;
@@ -388,7 +389,7 @@ __global__ void k_full_zero(Tables t, const Glob* g, int which, int M, long long
     const float mean = g->mean_kb;
     long long hi = 0, lo = 0, ni = 0;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < M; s += gridDim.x * blockDim.x) {
-        const int pos = t.pos[s], len = t.len[s];
+        const int pos = t.cp[s].y, len = t.len[s];
         if (pos == 0) ni += ((long long)len * (long long)(len - 1)) / 2;
         if (pos > 0) {
             const long long q = zero_q(p, pos, len, t.stot[s], mean);
@@ -487,9 +488,8 @@ __global__ void k_gather(State st, Glob* g, MoveBuf mb, const int* __restrict__ 
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g->n_prev_touched; i += gridDim.x * blockDim.x) {
         const int s = prev_touched[i];
         tab_prev.dist[s] = tab.dist[s];
-        tab_prev.cid[s] = tab.cid[s];
         tab_prev.stot[s] = tab.stot[s];
-        tab_prev.pos[s] = tab.pos[s];
+        tab_prev.cp[s] = tab.cp[s];
         tab_prev.len[s] = tab.len[s];
     }
     __shared__ int sh_flags[IG_MAX_CANDIDATES][12];
@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
     /* ---- coordinate column k (fill_vect_dist, KA:3699-3760) + zero-pixel sums on the window */
     const ig_params p = g->par[0];
     const float mean = g->mean_kb;
-    uint2* col = mb.coords + (size_t)c * M * NSLOT;
+    uint2* col = mb.coords + (size_t)(c * NSLOT + k) * M;
     ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
     int* subs = mb.subs + (size_t)c * M;
     long long hi = 0, lo = 0, ni = 0;
@@ -677,11 +677,11 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
             const SubTab b = sub[s];
             const float dist = sbp_kb + ((ori == 1) ? b.wat : b.cri);
             const int npos = (ori == 1) ? sp + w : sp + sl - (w + 1);
-            const int ls = lbase + tab.pos[s];
+            const int ls = lbase + tab.cp[s].y;
             uint2 v;
             v.x = __float_as_uint(dist);
             v.y = (unsigned)npos | ((unsigned)code << 28);
-            col[(size_t)ls * NSLOT + k] = v;
+            col[ls] = v;
             if (k == 0) subs[ls] = s;
             if (npos == 0) ni += ((long long)SLc * (long long)(SLc - 1)) / 2;
             if (npos > 0) {
@@ -710,210 +710,289 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
     }
 }
 
-/* k_score: the hot kernel.  A wave owns a strided set of CSR rows of candidate c; for each
- * coordinate column it streams those rows (coalesced int2 loads), evaluates the Rippe/Poisson
- * term and adds it as a 64-bit integer; one wave reduction + two atomics per (wave, column). */
+/* k_score: the hot kernel.  One workgroup = (candidate c, coordinate column k, row block):
+ * the column (8 B per local sub-fragment) is staged in LDS, the four waves stride over the CSR
+ * rows of the touched contigs (coalesced 8-byte (col,count) loads, one packed (contig,pos) gather
+ * per contact, LDS reads for both endpoints), each contact's Rippe/Poisson term is added as a
+ * 64-bit integer; wave shuffles + one LDS step + two atomics per workgroup. */
+#define SCORE_RB 32       /* row blocks per (candidate, column) */
+#define DELTA_RB 128
+#define LDS_COL_CAP 4096  /* local sub-fragments whose column fits the 32 KB LDS stage */
+
 template <bool UNWINDOWED>
 __global__ void __launch_bounds__(SCORE_THREADS)
     k_score(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, const Glob* g, MoveBuf mb,
-            const double* __restrict__ lgf_tab, int rank, int world, int only_c)
+            const double* __restrict__ lgf_tab, int rank, int world)
 {
-    (void)only_c;
-    const int c = UNWINDOWED ? g->ch_c : (int)blockIdx.y;
+    __shared__ uint2 lcol[LDS_COL_CAP];
+    __shared__ long long red[3][SCORE_THREADS / 64];
+    const int c = UNWINDOWED ? g->ch_c : (int)blockIdx.z;
     if (c < 0 || c >= g->C) return;
-    if (UNWINDOWED && (!g->ch_windowed || g->error)) return; /* the slice was already the whole contig pair */
+    if (UNWINDOWED && (!g->ch_windowed || g->error)) return; /* the slice already was the whole contig pair */
     const CandMeta& m = mb.meta[c];
-    const int M = mb.M;
+    const int kk = blockIdx.y;
+    const int ncol = UNWINDOWED ? 2 : m.n_uniq + 1;
+    if (kk >= ncol) return;
+    const int k = UNWINDOWED ? (kk == 0 ? 0 : g->ch_k) : kk;
+    const int M = mb.M, m_loc = m.m_loc;
     const ig_params p = g->par[0];
     const float mean = g->mean_kb;
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * SCORE_THREADS + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * SCORE_THREADS) >> 6;
-    const uint2* col = mb.coords + (size_t)c * M * NSLOT;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint2* gcol = mb.coords + (size_t)(c * NSLOT + k) * M;
+    const bool staged = m_loc <= LDS_COL_CAP;
+    if (staged) {
+        for (int i = threadIdx.x; i < m_loc; i += SCORE_THREADS) lcol[i] = gcol[i];
+        __syncthreads();
+    }
     const int* subs = mb.subs + (size_t)c * M;
-    const int ncol = UNWINDOWED ? 2 : m.n_uniq + 1;
-    long long* part = UNWINDOWED ? nullptr : mb.part + (size_t)c * P_STRIDE;
-    const int ch_k = g->ch_k;
-    for (int kk = 0; kk < ncol; kk++) {
-        const int k = UNWINDOWED ? (kk == 0 ? 0 : ch_k) : kk;
-        const ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
-        long long hi = 0, lo = 0;
-        int cnt = 0;
-        for (int r = wave; r < m.m_loc; r += nwaves) {
-            if (world > 1 && (r % world) != rank) continue;
-            const int i = subs[r];
-            const long long b = rowptr[i], e = rowptr[i + 1];
-            if (b == e) continue;
-            const int c1 = tab.cid[i], p1 = tab.pos[i];
-            const uint2 ai = col[(size_t)r * NSLOT + k];
+    int* rowcnt = mb.rowcnt + (size_t)c * M;
+    const ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
+    long long hi = 0, lo = 0;
+    int cnt = 0;
+    const int nrw = gridDim.x * (SCORE_THREADS / 64);
+    for (int r = blockIdx.x * (SCORE_THREADS / 64) + wv; r < m_loc; r += nrw) {
+        if (world > 1 && (r % world) != rank) continue;
+        const int i = subs[r];
+        const long long b = rowptr[i], e = rowptr[i + 1];
+        int rc = 0;
+        if (b != e) {
+            const int2 cp1 = tab.cp[i];
+            const uint2 ai = staged ? lcol[r] : gcol[r];
             for (long long q0 = b + lane; q0 < e; q0 += 64) {
                 const int2 v = cc[q0];
-                const int j = v.x;
-                const int c2 = tab.cid[j], p2 = tab.pos[j];
-                if (!slice_keep(m, c1, c2, p1, p2, v.y, UNWINDOWED)) continue;
-                const int lj = ((m.same || c2 == m.ctgA) ? 0 : m.SLA) + p2;
-                const uint2 bj = col[(size_t)lj * NSLOT + k];
+                const int2 cp2 = tab.cp[v.x];
+                if (!slice_keep(m, cp1.x, cp2.x, cp1.y, cp2.y, v.y, UNWINDOWED)) continue;
+                const int lj = ((m.same || cp2.x == m.ctgA) ? 0 : m.SLA) + cp2.y;
+                const uint2 bj = staged ? lcol[lj] : gcol[lj];
                 const long long q = eval_q(p, mean, ai, bj, cm, v.y, lgfact_dev(v.y, lgf_tab));
                 hi += q >> 32;
                 lo += (long long)(unsigned int)q;
-                cnt++;
+                rc++;
             }
         }
-        hi = wave_sum_ll(hi);
-        lo = wave_sum_ll(lo);
+        if (!UNWINDOWED && kk == 0) { /* kept contacts of this row: the tail walk of k_finalize needs them */
+            const int rs = wave_sum_i(rc);
+            if (lane == 0) rowcnt[r] = rs;
+        }
+        cnt += rc;
+    }
+    hi = wave_sum_ll(hi);
+    lo = wave_sum_ll(lo);
+    long long cn = wave_sum_ll((long long)cnt);
+    if (lane == 0) {
+        red[0][wv] = hi;
+        red[1][wv] = lo;
+        red[2][wv] = cn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        hi = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        lo = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        cn = red[2][0] + red[2][1] + red[2][2] + red[2][3];
         if (UNWINDOWED) {
-            if (lane == 0 && (hi | lo)) {
-                Glob* gw = const_cast<Glob*>(g);
+            Glob* gw = const_cast<Glob*>(g);
+            if (hi | lo) {
                 atomic_add_ll(&gw->d_hi, kk == 0 ? -hi : hi);
                 atomic_add_ll(&gw->d_lo, kk == 0 ? -lo : lo);
             }
         } else {
-            if (kk == 0) cnt = wave_sum_i(cnt);
-            if (lane == 0) {
-                if (hi | lo) {
-                    atomic_add_ll(&part[P_NZ + 2 * k], hi);
-                    atomic_add_ll(&part[P_NZ + 2 * k + 1], lo);
-                }
-                if (kk == 0 && cnt) atomic_add_ll(&part[P_CNT], (long long)cnt);
+            long long* part = mb.part + (size_t)c * P_STRIDE;
+            if (hi | lo) {
+                atomic_add_ll(&part[P_NZ + 2 * k], hi);
+                atomic_add_ll(&part[P_NZ + 2 * k + 1], lo);
             }
+            if (kk == 0 && cn) atomic_add_ll(&part[P_CNT], cn);
         }
     }
 }
 
-/* k_finalize: tail quirk, zero-pixel totals, scores (KA:4005-4046), host argmax (CL:1435-1446).
- * One wave; everything here is O(C * 24) except the tail walk (< 64 contacts per candidate). */
 __device__ __forceinline__ int wave_max_i(int v)
 {
     for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
     return v;
 }
 
-__global__ void __launch_bounds__(64) k_finalize(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
-                                                 Glob* g, MoveBuf mb, long long* q_part, const double* __restrict__ lgf_tab,
-                                                 int tail_quirk)
+/* k_finalize: one workgroup per candidate -- tail quirk (Q5), zero-pixel totals and scores
+ * (eval_all_likelihood_on_zero_2nd KA:4005-4027, eval_all_scores KA:4029-4046). */
+__global__ void __launch_bounds__(256) k_finalize(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
+                                                  Glob* g, MoveBuf mb, long long* q_part, const double* __restrict__ lgf_tab,
+                                                  int tail_quirk)
 {
-    __shared__ int t_li[64], t_lj[64], t_ob[64];
-    const int lane = threadIdx.x;
-    const int C = g->C, M = mb.M;
+    __shared__ int t_li[64], t_lj[64], t_ob[64], t_rows[64];
+    __shared__ int sh_n_rows, sh_n_tail, sh_cnt;
+    __shared__ long long sh_red[4];
+    const int c = blockIdx.x;
+    if (c >= g->C) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int M = mb.M;
     const ig_params p = g->par[0];
     const float mean = g->mean_kb;
     const double log_e = IG_LOG_E_F;
-    const double cur_nz = ig_acc_to_double(g->nz_hi, g->nz_lo);
-    long long tot_slice = 0, tot_eval = 0, bytes = 0;
-    for (int c = 0; c < C; c++) {
-        const CandMeta& m = mb.meta[c];
-        long long* part = mb.part + (size_t)c * P_STRIDE;
-        long long* qp = q_part + (size_t)c * Q_STRIDE;
-        const uint2* col = mb.coords + (size_t)c * M * NSLOT;
-        const int* subs = mb.subs + (size_t)c * M;
-        const int ncol = m.n_uniq + 1;
-        for (int k = lane; k < ncol; k += 64) { /* uncorrected sums: the exact full-likelihood update uses them */
-            qp[Q_NZFULL + 2 * k] = part[P_NZ + 2 * k];
-            qp[Q_NZFULL + 2 * k + 1] = part[P_NZ + 2 * k + 1];
+    const CandMeta& m = mb.meta[c];
+    long long* part = mb.part + (size_t)c * P_STRIDE;
+    long long* qp = q_part + (size_t)c * Q_STRIDE;
+    const int* subs = mb.subs + (size_t)c * M;
+    const int* rowcnt = mb.rowcnt + (size_t)c * M;
+    const int ncol = m.n_uniq + 1;
+    for (int k = tid; k < ncol; k += blockDim.x) { /* uncorrected sums: the exact full-likelihood update uses them */
+        qp[Q_NZFULL + 2 * k] = part[P_NZ + 2 * k];
+        qp[Q_NZFULL + 2 * k + 1] = part[P_NZ + 2 * k + 1];
+    }
+    __syncthreads();
+    const long long Sc = part[P_CNT];
+    /* quirk Q5 (KA:4362, block 64 CL:200): with r = S_c mod 64 > 0, the columns at list positions >= r never
+     * receive the last r sliced contacts.  Canonical order = COO order, so "last" = highest rows: find by
+     * bisection the row id T such that rows >= T hold >= r kept contacts and rows > T hold fewer. */
+    const int r = (int)(Sc % 64);
+    if (tail_quirk && r > 0 && m.n_uniq > r) {
+        int lo_t = 0, hi_t = M; /* count(lo_t) >= r, count(hi_t) < r */
+        while (hi_t - lo_t > 1) {
+            const int mid = lo_t + (hi_t - lo_t) / 2;
+            long long s = 0;
+            for (int ls = tid; ls < m.m_loc; ls += blockDim.x)
+                if (subs[ls] >= mid) s += rowcnt[ls];
+            s = wave_sum_ll(s);
+            if (lane == 0) sh_red[wv] = s;
+            __syncthreads();
+            const long long tot = sh_red[0] + sh_red[1] + sh_red[2] + sh_red[3];
+            __syncthreads();
+            if (tot >= r) lo_t = mid;
+            else hi_t = mid;
+        }
+        const int T = lo_t;
+        if (tid == 0) {
+            sh_n_rows = 0;
+            sh_n_tail = 0;
+            sh_cnt = 0;
         }
         __syncthreads();
-        const long long Sc = part[P_CNT];
-        tot_slice += Sc;
-        tot_eval += Sc * ncol;
-        bytes += 12 * Sc + 20LL * m.m_loc * m.n_uniq + 8LL * m.n_uniq;
-        /* quirk Q5 (KA:4362, block 64 CL:200): with r = S_c mod 64 > 0, the columns at list positions
-         * >= r never receive the last r sliced contacts (canonical order = COO order). */
-        const int r = (int)(Sc % 64);
-        if (tail_quirk && r > 0 && m.n_uniq > r) {
-            int remaining = r, bound = 0x7fffffff, n_tail = 0;
-            while (remaining > 0) {
-                int best = -1;
-                for (int ls = lane; ls < m.m_loc; ls += 64) {
-                    const int s = subs[ls];
-                    if (s < bound && rowptr[s + 1] > rowptr[s]) best = max(best, s);
-                }
-                best = wave_max_i(best);
-                if (best < 0) break;
-                bound = best;
-                const int i = best;
-                const int c1 = tab.cid[i], p1 = tab.pos[i];
-                const int li = ((m.same || c1 == m.ctgA) ? 0 : m.SLA) + p1;
-                const long long b = rowptr[i], e = rowptr[i + 1];
-                for (long long end = e; end > b && remaining > 0; end -= 64) {
-                    const long long q0 = end - 1 - lane;
-                    bool keep = false;
-                    int2 v = make_int2(0, 0);
-                    int lj = 0;
-                    if (q0 >= b) {
-                        v = cc[q0];
-                        const int c2 = tab.cid[v.x], p2 = tab.pos[v.x];
-                        keep = slice_keep(m, c1, c2, p1, p2, v.y, false);
-                        lj = ((m.same || c2 == m.ctgA) ? 0 : m.SLA) + p2;
-                    }
-                    const unsigned long long mask = __ballot(keep);
-                    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-                    if (keep && rank < remaining) {
-                        t_li[n_tail + rank] = li;
-                        t_lj[n_tail + rank] = lj;
-                        t_ob[n_tail + rank] = v.y;
-                    }
-                    const int took = min(__popcll(mask), remaining);
-                    n_tail += took;
-                    remaining -= took;
-                }
+        int above = 0; /* kept contacts in rows > T */
+        for (int ls = tid; ls < m.m_loc; ls += blockDim.x) {
+            const int s = subs[ls];
+            if (s >= T && rowcnt[ls] > 0) {
+                const int slot = atomicAdd(&sh_n_rows, 1);
+                if (slot < 64) t_rows[slot] = ls;
+                if (s > T) above += rowcnt[ls];
             }
-            __syncthreads();
-            for (int kk = r; kk < m.n_uniq; kk++) {
-                const int k = kk + 1;
-                const ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
-                long long hi = 0, lo = 0;
-                if (lane < n_tail) {
-                    const long long q = eval_q(p, mean, col[(size_t)t_li[lane] * NSLOT + k], col[(size_t)t_lj[lane] * NSLOT + k],
-                                               cm, t_ob[lane], lgfact_dev(t_ob[lane], lgf_tab));
-                    hi = q >> 32;
-                    lo = (long long)(unsigned int)q;
-                }
-                hi = wave_sum_ll(hi);
-                lo = wave_sum_ll(lo);
-                if (lane == 0) {
-                    part[P_NZ + 2 * k] -= hi;
-                    part[P_NZ + 2 * k + 1] -= lo;
-                }
-            }
-            __syncthreads();
         }
-        /* eval_all_likelihood_on_zero_2nd (KA:4005-4027) + eval_all_scores (KA:4029-4046) */
-        const double ext = ig_acc_to_double(part[P_NZ], part[P_NZ + 1]);
-        for (int k = 1 + lane; k < ncol; k += 64) {
-            const long long zhi = g->z_hi + qp[Q_Z + 2 * k] - qp[Q_Z];
-            const long long zlo = g->z_lo + qp[Q_Z + 2 * k + 1] - qp[Q_Z + 1];
-            const long long ni = g->n_intra + qp[Q_NI + k] - qp[Q_NI];
-            const double val_inter = -1.0 * log_e * (g->n_tot_pxl - (double)ni) * p.v_inter;
-            const double val_intra = ig_acc_to_double(zhi, zlo) * log_e;
-            const double z = val_intra + val_inter;
-            const double nz = ig_acc_to_double(part[P_NZ + 2 * k], part[P_NZ + 2 * k + 1]);
-            mb.scores[c * IG_N_TMP_STRUCT + m.uniq[k - 1]] = nz + z + cur_nz - ext;
+        above = wave_sum_i(above);
+        if (lane == 0 && above) atomicAdd(&sh_cnt, above);
+        __syncthreads();
+        const int n_rows = min(sh_n_rows, 64);
+        const int need_T = r - sh_cnt; /* contacts to take from the END of row T */
+        for (int ri = wv; ri < n_rows; ri += 4) {
+            const int ls = t_rows[ri];
+            const int i = subs[ls];
+            const int2 cp1 = tab.cp[i];
+            const long long b = rowptr[i], e = rowptr[i + 1];
+            int remaining = (i == T) ? need_T : 0x7fffffff;
+            for (long long end = e; end > b && remaining > 0; end -= 64) {
+                const long long q0 = end - 1 - lane;
+                bool keep = false;
+                int2 v = make_int2(0, 0);
+                int lj = 0;
+                if (q0 >= b) {
+                    v = cc[q0];
+                    const int2 cp2 = tab.cp[v.x];
+                    keep = slice_keep(m, cp1.x, cp2.x, cp1.y, cp2.y, v.y, false);
+                    lj = ((m.same || cp2.x == m.ctgA) ? 0 : m.SLA) + cp2.y;
+                }
+                const unsigned long long mask = __ballot(keep);
+                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+                const int took = min((int)__popcll(mask), remaining);
+                int basei = 0;
+                if (lane == 0 && took) basei = atomicAdd(&sh_n_tail, took);
+                basei = __shfl(basei, 0, 64);
+                if (keep && rank < remaining && basei + rank < 64) {
+                    t_li[basei + rank] = ls;
+                    t_lj[basei + rank] = lj;
+                    t_ob[basei + rank] = v.y;
+                }
+                remaining -= took;
+            }
+        }
+        __syncthreads();
+        const int n_tail = min(sh_n_tail, 64);
+        if (tid == 0 && n_tail != r) g->error = 5; /* the walk must find exactly r contacts */
+        for (int kk2 = r + wv; kk2 < m.n_uniq; kk2 += 4) {
+            const int k = kk2 + 1;
+            const uint2* col = mb.coords + (size_t)(c * NSLOT + k) * M;
+            const ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
+            long long hi = 0, lo = 0;
+            if (lane < n_tail) {
+                const long long q = eval_q(p, mean, col[t_li[lane]], col[t_lj[lane]], cm, t_ob[lane], lgfact_dev(t_ob[lane], lgf_tab));
+                hi = q >> 32;
+                lo = (long long)(unsigned int)q;
+            }
+            hi = wave_sum_ll(hi);
+            lo = wave_sum_ll(lo);
+            if (lane == 0) {
+                part[P_NZ + 2 * k] -= hi;
+                part[P_NZ + 2 * k + 1] -= lo;
+            }
         }
         __syncthreads();
     }
-    if (lane == 0) { /* CL:1435-1446 */
-        const int n = C * IG_N_TMP_STRUCT;
-        double mx = -IG_INF;
-        for (int i = 0; i < n; i++) {
-            const double s = mb.scores[i];
-            const double ok = (s == 0.0) ? -IG_INF : s;
-            if (ok > mx) mx = ok;
+    const double cur_nz = ig_acc_to_double(g->nz_hi, g->nz_lo);
+    const double ext = ig_acc_to_double(part[P_NZ], part[P_NZ + 1]);
+    for (int k = 1 + tid; k < ncol; k += blockDim.x) {
+        const long long zhi = g->z_hi + qp[Q_Z + 2 * k] - qp[Q_Z];
+        const long long zlo = g->z_lo + qp[Q_Z + 2 * k + 1] - qp[Q_Z + 1];
+        const long long ni = g->n_intra + qp[Q_NI + k] - qp[Q_NI];
+        const double val_inter = -1.0 * log_e * (g->n_tot_pxl - (double)ni) * p.v_inter;
+        const double val_intra = ig_acc_to_double(zhi, zlo) * log_e;
+        const double z = val_intra + val_inter;
+        const double nz = ig_acc_to_double(part[P_NZ + 2 * k], part[P_NZ + 2 * k + 1]);
+        mb.scores[c * IG_N_TMP_STRUCT + m.uniq[k - 1]] = nz + z + cur_nz - ext;
+    }
+}
+
+/* the host argmax of CL:1435-1446 (zeros -> -inf, shifted/clipped scores, FIRST index of the maximum) */
+__global__ void __launch_bounds__(64) k_argmax(Glob* g, MoveBuf mb, long long* q_part)
+{
+    const int lane = threadIdx.x;
+    const int C = g->C, n = C * IG_N_TMP_STRUCT;
+    double mx = -IG_INF;
+    for (int i = lane; i < n; i += 64) {
+        const double s = mb.scores[i];
+        const double ok = (s == 0.0) ? -IG_INF : s;
+        mx = ok > mx ? ok : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(mx, off, 64);
+        mx = o > mx ? o : mx;
+    }
+    double bestv = -IG_INF;
+    int best = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) {
+        const double s = mb.scores[i];
+        const double ok = (s == 0.0) ? -IG_INF : s;
+        double fs = ok - (mx - 30.0);
+        if (fs < 0) fs = 0;
+        if (fs > bestv) { /* strictly greater: the first index wins inside a lane */
+            bestv = fs;
+            best = i;
         }
-        int best = 0;
-        double bestv = -IG_INF;
-        for (int i = 0; i < n; i++) {
-            const double s = mb.scores[i];
-            const double ok = (s == 0.0) ? -IG_INF : s;
-            double fs = ok - (mx - 30.0);
-            if (fs < 0) fs = 0;
-            if (i == 0 || fs > bestv) {
-                if (i == 0 || fs > bestv) {
-                    bestv = fs;
-                    best = i;
-                }
-            }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(bestv, off, 64);
+        const int oi = __shfl_xor(best, off, 64);
+        if (ov > bestv || (ov == bestv && oi < best)) {
+            bestv = ov;
+            best = oi;
         }
+    }
+    if (lane == 0) {
+        if (best >= n) best = 0;
         const int cc_ = best / IG_N_TMP_STRUCT, slot = best % IG_N_TMP_STRUCT;
+        long long tot_slice = 0, tot_eval = 0, bytes = 0;
+        for (int c = 0; c < C; c++) {
+            const CandMeta& m = mb.meta[c];
+            const long long Sc = mb.part[(size_t)c * P_STRIDE + P_CNT];
+            tot_slice += Sc;
+            tot_eval += Sc * (m.n_uniq + 1);
+            bytes += 12 * Sc + 20LL * m.m_loc * m.n_uniq + 8LL * m.n_uniq;
+        }
         g->ch_c = cc_;
         g->ch_slot = slot;
         g->ch_k = mb.meta[cc_].kidx[slot] < 0 ? 0 : mb.meta[cc_].kidx[slot];
@@ -972,17 +1051,16 @@ __global__ void k_apply(State st, Tables tab, Glob* g, MoveBuf mb, long long* q_
     }
     heads = wave_sum_i(heads);
     if ((threadIdx.x & 63) == 0 && heads) atomicAdd(&g->n_contigs, heads);
-    const uint2* col = mb.coords + (size_t)c * M * NSLOT;
+    const uint2* col = mb.coords + (size_t)(c * NSLOT + k) * M;
     const ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
     const int* subs = mb.subs + (size_t)c * M;
     const int fresh = g->next_cid;
     for (int ls = tid; ls < m.m_loc; ls += nth) {
         const int s = subs[ls];
-        const uint2 v = col[(size_t)ls * NSLOT + k];
+        const uint2 v = col[ls];
         const int code = (int)(v.y >> 28);
         tab.dist[s] = __uint_as_float(v.x);
-        tab.pos[s] = (int)(v.y & 0x0fffffffu);
-        tab.cid[s] = code == 0 ? m.ctgA : (code == 1 ? m.ctgB : fresh + (code - 2));
+        tab.cp[s] = make_int2(code == 0 ? m.ctgA : (code == 1 ? m.ctgB : fresh + (code - 2)), (int)(v.y & 0x0fffffffu));
         tab.stot[s] = cm[code].stot;
         tab.len[s] = cm[code].len;
         prev_touched[ls] = s;
@@ -1184,6 +1262,7 @@ static void free_move_buffers(ig_ctx* c)
     hipFree(m.lbloc);
     hipFree(m.slloc);
     hipFree(m.subs);
+    hipFree(m.rowcnt);
     hipFree(m.coords);
     hipFree(m.loc);
     hipFree(m.meta);
@@ -1255,6 +1334,7 @@ static int ensure_move_buffers(ig_ctx* c, int capC)
     DALLOC(m.lbloc, C * N);
     DALLOC(m.slloc, C * N);
     DALLOC(m.subs, C * M);
+    DALLOC(m.rowcnt, C * M);
     DALLOC(m.coords, C * M * NSLOT);
     DALLOC(m.loc, C * NSLOT * NDYN * N);
     DALLOC(m.meta, C);
@@ -1322,12 +1402,11 @@ extern "C" int ig_upload_subfrag_table(ig_ctx* c, const float* xyzw, int32_t M)
     hipFree(c->tab_prev.dist);
     for (Tables* tb : {&c->tab, &c->tab_prev}) {
         int* blk;
-        DALLOC(blk, 5 * (size_t)M);
+        DALLOC(blk, 6 * (size_t)M + 2);
         tb->dist = (float*)blk;
-        tb->cid = blk + (size_t)M;
-        tb->stot = (float*)(blk + 2 * (size_t)M);
-        tb->pos = blk + 3 * (size_t)M;
-        tb->len = blk + 4 * (size_t)M;
+        tb->stot = (float*)(blk + (size_t)M);
+        tb->len = blk + 2 * (size_t)M;
+        tb->cp = (int2*)(blk + 4 * (size_t)M + ((4 * (size_t)M) & 1)); /* keep the int2 array 8-byte aligned */
     }
     hipFree(c->prev_touched);
     DALLOC(c->prev_touched, (size_t)M);
@@ -1420,7 +1499,7 @@ static int launch_recompute(ig_ctx* c)
     if (!c->have_state || !c->have_sub) return 0;
     const int N = c->N, M = c->M;
     hipLaunchKernelGGL(k_fill_tables, dim3((M + 255) / 256), dim3(256), 0, c->stream, c->st, c->sub_tab, c->tab, M);
-    HIPCK(hipMemcpyAsync(c->tab_prev.dist, c->tab.dist, 5 * (size_t)M * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(hipMemcpyAsync(c->tab_prev.dist, c->tab.dist, (6 * (size_t)M + 2) * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
     long long* scratch;
     DALLOC(scratch, 8);
     HIPCK(hipMemsetAsync(scratch, 0, 8 * sizeof(long long), c->stream));
@@ -1664,15 +1743,16 @@ static void enqueue_move(ig_ctx* c, int move, int max_c, int force_slot, int pha
         }
         if (force_slot < 0) {
             TimedLaunch t(c, T_SCORE);
-            hipLaunchKernelGGL(k_score<false>, dim3(SCORE_BLOCKS, max_c), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab,
-                               c->glob, c->mb, c->lgf_tab, c->rank, c->world, -1);
+            hipLaunchKernelGGL(k_score<false>, dim3(SCORE_RB, NSLOT, max_c), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab,
+                               c->glob, c->mb, c->lgf_tab, c->rank, c->world);
         }
     }
     if (phase == 1 || phase == 2) {
         if (force_slot < 0) {
             TimedLaunch t(c, T_FINALIZE);
-            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->q_part,
+            hipLaunchKernelGGL(k_finalize, dim3(max_c), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->q_part,
                                c->lgf_tab, g_tail_quirk);
+            hipLaunchKernelGGL(k_argmax, dim3(1), dim3(64), 0, c->stream, c->glob, c->mb, c->q_part);
         } else {
             hipLaunchKernelGGL(k_force_choice, dim3(1), dim3(1), 0, c->stream, c->glob, c->mb, force_slot);
         }
@@ -1684,8 +1764,8 @@ static void enqueue_apply(ig_ctx* c, int move, int forced)
     const int N = c->N;
     {
         TimedLaunch t(c, T_DELTA);
-        hipLaunchKernelGGL(k_score<true>, dim3(SCORE_BLOCKS), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob,
-                           c->mb, c->lgf_tab, 0, 1, -2);
+        hipLaunchKernelGGL(k_score<true>, dim3(DELTA_RB, 2, 1), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob,
+                           c->mb, c->lgf_tab, 0, 1);
     }
     {
         TimedLaunch t(c, T_APPLY);
@@ -1993,10 +2073,14 @@ extern "C" int ig_debug_tables(ig_ctx* c, float* dist, int32_t* id_c, float* s_t
     HIPCK(hipStreamSynchronize(c->stream));
     const size_t m = c->M;
     HIPCK(hipMemcpy(dist, c->tab.dist, m * 4, hipMemcpyDeviceToHost));
-    HIPCK(hipMemcpy(id_c, c->tab.cid, m * 4, hipMemcpyDeviceToHost));
     HIPCK(hipMemcpy(s_tot, c->tab.stot, m * 4, hipMemcpyDeviceToHost));
-    HIPCK(hipMemcpy(pos, c->tab.pos, m * 4, hipMemcpyDeviceToHost));
     HIPCK(hipMemcpy(len, c->tab.len, m * 4, hipMemcpyDeviceToHost));
+    std::vector<int2> cp(m);
+    HIPCK(hipMemcpy(cp.data(), c->tab.cp, m * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < m; i++) {
+        id_c[i] = cp[i].x;
+        pos[i] = cp[i].y;
+    }
     return 0;
 }
 
