@@ -117,7 +117,11 @@ struct MoveBuf {
     int* lbloc;     /* [capC][N] */
     int* slloc;     /* [capC][N] */
     int* subs;      /* [capC][M] global sub-frag id of local sub index */
-    int* rowcnt;    /* [capC][M] sliced contacts per local row (column 0 pass) */
+    int* rowcnt;    /* [capC][M] sliced contacts per local row */
+    int* sl_li;     /* [capC][Z] the slice of candidate c: local row index, */
+    int* sl_lj;     /*           local column index, */
+    int* sl_ob;     /*           observed count (order = arrival, sums are order-free) */
+    long long Zcap;
     uint2* coords;  /* [capC][NSLOT][M] column k: {dist bits, pos | code<<28} per local sub index */
     int* loc;       /* [capC][NSLOT][NDYN][N] candidate genomes on the local window */
     CandMeta* meta; /* [capC] */
@@ -164,6 +168,8 @@ struct ig_ctx {
     int cands_cap;
     int* prev_touched;
     unsigned timing_mask;
+    float* pz_tab;
+    int pz_n;
     /* timers */
     bool timing;
     struct Timer {
@@ -171,7 +177,7 @@ struct ig_ctx {
         std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
         double total_ms;
         long long n;
-    } timers[8];
+    } timers[10];
     bool have_contacts, have_sub, have_state, have_init, have_params;
 };
 
@@ -219,29 +225,66 @@ __device__ __forceinline__ double lgfact_dev(int ob, const double* __restrict__ 
 }
 
 /* quantised likelihood term of one contact under one coordinate column */
+/* P(s) of the zero-pixel companion term only ever sees s_z = d * mean_kb for an INTEGER rank distance d
+ * (KA:4324-4334): pz[d] holds exactly the value the direct evaluation would produce (built by k_build_pz with
+ * the same functions), for d < PZ_MAX; beyond the table s_z >= d_max by construction, i.e. v_inter. */
+#define PZ_MAX 4096
+struct PzTab {
+    const float* v;
+    int n;
+};
+
+__device__ __forceinline__ float pz_lookup(const PzTab& t, const ig_params& p, float mean_kb, int d)
+{
+    if (d < t.n) return t.v[d];
+    const float s_z = (float)d * mean_kb;
+    return (s_z < p.d_max) ? ig_rippe(s_z, p) : p.v_inter;
+}
+
 __device__ __forceinline__ long long eval_q(const ig_params& p, float mean_kb, uint2 a, uint2 b, const ColMeta* __restrict__ cm,
-                                            int ob, double lgf)
+                                            int ob, double lgf, const PzTab& pz)
 {
     const float di = __uint_as_float(a.x), dj = __uint_as_float(b.x);
     const int pi = (int)(a.y & 0x0fffffffu), pj = (int)(b.y & 0x0fffffffu);
     const int ci = (int)(a.y >> 28), cj = (int)(b.y >> 28);
-    const float s = fabsf(di - dj);
-    const float s_z = fabsf((float)pi - (float)pj) * mean_kb;
-    const float s_tot = cm[ci].stot;
-    const float s_tot_z = (float)cm[cj].len * mean_kb;
     float ex, ex_z;
-    expected_pair(p, ci == cj, s, s_z, s_tot, s_tot_z, ex, ex_z);
+    if (ci == cj) {
+        const float s = fabsf(di - dj);
+        const float s_tot = cm[ci].stot;
+        const int d = pi > pj ? pi - pj : pj - pi;
+        if (s_tot == 0) {
+            ex = ig_rippe(s, p);
+            ex_z = pz_lookup(pz, p, mean_kb, d);
+        } else {
+            const float s_z = (float)d * mean_kb;
+            ex = ig_rippe_circ(s, s_tot, p);
+            ex_z = (s_z < p.d_max) ? ig_rippe_circ(s_z, (float)cm[cj].len * mean_kb, p) : p.v_inter;
+        }
+    } else {
+        ex = p.v_inter;
+        ex_z = p.v_inter;
+    }
     return ig_quantize(ig_pixel_term(ex, ex_z, ob, lgf));
 }
 
+__global__ void k_build_pz(const Glob* g, float* pz, int n)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n) return;
+    const ig_params p = g->par[0];
+    const float s_z = (float)d * g->mean_kb;
+    pz[d] = (s_z < p.d_max) ? ig_rippe(s_z, p) : p.v_inter;
+}
+
 /* one sub-fragment's zero-pixel term: KA:3882-3899 */
-__device__ __forceinline__ long long zero_q(const ig_params& p, int pos, int len_cont, float s_tot, float mean_kb)
+__device__ __forceinline__ long long zero_q(const ig_params& p, int pos, int len_cont, float s_tot, float mean_kb,
+                                            const float* __restrict__ pz, int pz_n)
 {
     const float s = (float)pos * mean_kb;
     const float s_tot_z = (float)len_cont * mean_kb;
     double ve;
     if (s < p.d_max) {
-        if (s_tot == 0) ve = (double)ig_rippe(s, p);
+        if (s_tot == 0) ve = (double)((pz && pos < pz_n) ? pz[pos] : ig_rippe(s, p));
         else ve = (double)ig_rippe_circ(s, s_tot_z, p);
     } else {
         ve = (double)p.v_inter;
@@ -392,7 +435,7 @@ __global__ void k_full_zero(Tables t, const Glob* g, int which, int M, long long
         const int pos = t.cp[s].y, len = t.len[s];
         if (pos == 0) ni += ((long long)len * (long long)(len - 1)) / 2;
         if (pos > 0) {
-            const long long q = zero_q(p, pos, len, t.stot[s], mean);
+            const long long q = zero_q(p, pos, len, t.stot[s], mean, nullptr, 0);
             hi += q >> 32;
             lo += (long long)(unsigned int)q;
         }
@@ -588,7 +631,7 @@ __global__ void k_gather(State st, Glob* g, MoveBuf mb, const int* __restrict__ 
 
 /* k_mutate: one workgroup = one candidate genome on the local window. */
 __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubTab* __restrict__ sub, Glob* g, MoveBuf mb,
-                                                long long* q_part)
+                                                long long* q_part, PzTab pz)
 {
     const int slot = blockIdx.x, c = blockIdx.y;
     if (c >= g->C) return;
@@ -685,7 +728,7 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
             if (k == 0) subs[ls] = s;
             if (npos == 0) ni += ((long long)SLc * (long long)(SLc - 1)) / 2;
             if (npos > 0) {
-                const long long q = zero_q(p, npos, SLc, stot, mean);
+                const long long q = zero_q(p, npos, SLc, stot, mean, pz.v, pz.n);
                 hi += q >> 32;
                 lo += (long long)(unsigned int)q;
             }
@@ -719,13 +762,135 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
 #define DELTA_RB 128
 #define LDS_COL_CAP 4096  /* local sub-fragments whose column fits the 32 KB LDS stage */
 
+/* k_slice: slice_sp_mat (KA:485-607) restricted to the CSR rows of the touched contigs (instead of a scan of
+ * all Z contacts): kept contacts are appended to the candidate's list with one wave-aggregated atomic per
+ * 64 contacts (ballot + popcount ranks); no sort is needed afterwards (the reference sorted by row only to
+ * feed its shared-memory row cache, CL:1045-1050). */
+#define SLICE_RB 32
+__global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
+                                               const Glob* g, MoveBuf mb, int rank, int world)
+{
+    const int c = blockIdx.y;
+    if (c >= g->C) return;
+    const CandMeta& m = mb.meta[c];
+    const int M = mb.M, m_loc = m.m_loc;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int* subs = mb.subs + (size_t)c * M;
+    int* rowcnt = mb.rowcnt + (size_t)c * M;
+    int* sli = mb.sl_li + (size_t)c * mb.Zcap;
+    int* slj = mb.sl_lj + (size_t)c * mb.Zcap;
+    int* slo = mb.sl_ob + (size_t)c * mb.Zcap;
+    unsigned long long* cursor = (unsigned long long*)(mb.part + (size_t)c * P_STRIDE + P_CNT);
+    const int nrw = gridDim.x * 4;
+    for (int r = blockIdx.x * 4 + wv; r < m_loc; r += nrw) {
+        const int i = subs[r];
+        const long long b = rowptr[i], e = rowptr[i + 1];
+        const bool mine = (world <= 1) || ((r % world) == rank);
+        int rc = 0;
+        if (b != e) {
+            const int2 cp1 = tab.cp[i];
+            for (long long q0 = b; q0 < e; q0 += 64) {
+                const long long qi = q0 + lane;
+                bool keep = false;
+                int lj = 0, ob = 0;
+                if (qi < e) {
+                    const int2 v = cc[qi];
+                    const int2 cp2 = tab.cp[v.x];
+                    keep = slice_keep(m, cp1.x, cp2.x, cp1.y, cp2.y, v.y, false);
+                    lj = ((m.same || cp2.x == m.ctgA) ? 0 : m.SLA) + cp2.y;
+                    ob = v.y;
+                }
+                const unsigned long long mask = __ballot(keep);
+                if (mask) {
+                    const int add = __popcll(mask);
+                    rc += add;
+                    if (mine) {
+                        unsigned long long base = 0;
+                        if (lane == 0) base = atomicAdd(cursor, (unsigned long long)add);
+                        base = __shfl(base, 0, 64);
+                        if (keep) {
+                            const long long at = (long long)base + __popcll(mask & lt_mask);
+                            sli[at] = r;
+                            slj[at] = lj;
+                            slo[at] = ob;
+                        }
+                    }
+                }
+            }
+        }
+        if (lane == 0) rowcnt[r] = rc; /* every rank knows every row's count: the tail walk needs them */
+    }
+}
+
+/* k_score_list: the hot kernel.  One workgroup = (entry block, coordinate column k, candidate c).  The
+ * column (8 B per local sub-fragment) is staged in LDS; lanes stream the slice list (three coalesced 4-byte
+ * loads per contact), read both endpoints' coordinates from LDS, evaluate the Rippe / Poisson term and add
+ * it as a 64-bit integer.  Wave shuffles, one LDS step, two atomics per workgroup. */
+#define SCORE_EB 32
+__global__ void __launch_bounds__(SCORE_THREADS)
+    k_score_list(const Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz)
+{
+    __shared__ uint2 lcol[LDS_COL_CAP];
+    __shared__ long long red[2][SCORE_THREADS / 64];
+    const int c = blockIdx.z;
+    if (c >= g->C) return;
+    const CandMeta& m = mb.meta[c];
+    const int k = blockIdx.y;
+    if (k > m.n_uniq) return;
+    const int M = mb.M, m_loc = m.m_loc;
+    const long long n = mb.part[(size_t)c * P_STRIDE + P_CNT];
+    const ig_params p = g->par[0];
+    const float mean = g->mean_kb;
+    const uint2* gcol = mb.coords + (size_t)(c * NSLOT + k) * M;
+    const bool staged = m_loc <= LDS_COL_CAP;
+    if (staged) {
+        for (int i = threadIdx.x; i < m_loc; i += SCORE_THREADS) lcol[i] = gcol[i];
+        __syncthreads();
+    }
+    const ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
+    const int* sli = mb.sl_li + (size_t)c * mb.Zcap;
+    const int* slj = mb.sl_lj + (size_t)c * mb.Zcap;
+    const int* slo = mb.sl_ob + (size_t)c * mb.Zcap;
+    long long hi = 0, lo = 0;
+    const long long stride = (long long)gridDim.x * SCORE_THREADS;
+    for (long long e = (long long)blockIdx.x * SCORE_THREADS + threadIdx.x; e < n; e += stride) {
+        const int li = sli[e], lj = slj[e], ob = slo[e];
+        const uint2 ai = staged ? lcol[li] : gcol[li];
+        const uint2 bj = staged ? lcol[lj] : gcol[lj];
+        const long long q = eval_q(p, mean, ai, bj, cm, ob, lgfact_dev(ob, lgf_tab), pz);
+        hi += q >> 32;
+        lo += (long long)(unsigned int)q;
+    }
+    hi = wave_sum_ll(hi);
+    lo = wave_sum_ll(lo);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][wv] = hi;
+        red[1][wv] = lo;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        hi = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        lo = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        if (hi | lo) {
+            long long* part = mb.part + (size_t)c * P_STRIDE;
+            atomic_add_ll(&part[P_NZ + 2 * k], hi);
+            atomic_add_ll(&part[P_NZ + 2 * k + 1], lo);
+        }
+    }
+}
+
 template <bool UNWINDOWED>
 __global__ void __launch_bounds__(SCORE_THREADS)
     k_score(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, const Glob* g, MoveBuf mb,
-            const double* __restrict__ lgf_tab, int rank, int world)
+            const double* __restrict__ lgf_tab, int rank, int world, PzTab pz)
 {
     __shared__ uint2 lcol[LDS_COL_CAP];
     __shared__ long long red[3][SCORE_THREADS / 64];
+    /* per-wave compaction queue: only ~40-80 % of a row's contacts survive the slice predicate, so kept
+     * contacts are queued (ballot + popcount ranks) and the transcendental math runs on full waves */
+    __shared__ int q_li[SCORE_THREADS / 64][128], q_lj[SCORE_THREADS / 64][128], q_ob[SCORE_THREADS / 64][128];
     const int c = UNWINDOWED ? g->ch_c : (int)blockIdx.z;
     if (c < 0 || c >= g->C) return;
     if (UNWINDOWED && (!g->ch_windowed || g->error)) return; /* the slice already was the whole contig pair */
@@ -738,6 +903,7 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     const ig_params p = g->par[0];
     const float mean = g->mean_kb;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint2* gcol = mb.coords + (size_t)(c * NSLOT + k) * M;
     const bool staged = m_loc <= LDS_COL_CAP;
     if (staged) {
@@ -747,8 +913,21 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     const int* subs = mb.subs + (size_t)c * M;
     int* rowcnt = mb.rowcnt + (size_t)c * M;
     const ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
+    int* qli = q_li[wv];
+    int* qlj = q_lj[wv];
+    int* qob = q_ob[wv];
     long long hi = 0, lo = 0;
-    int cnt = 0;
+    int cnt = 0, qn = 0;
+    auto drain = [&](int n_take) {
+        if (lane < n_take) {
+            const int li = qli[lane], lj = qlj[lane], ob = qob[lane];
+            const uint2 ai = staged ? lcol[li] : gcol[li];
+            const uint2 bj = staged ? lcol[lj] : gcol[lj];
+            const long long q = eval_q(p, mean, ai, bj, cm, ob, lgfact_dev(ob, lgf_tab), pz);
+            hi += q >> 32;
+            lo += (long long)(unsigned int)q;
+        }
+    };
     const int nrw = gridDim.x * (SCORE_THREADS / 64);
     for (int r = blockIdx.x * (SCORE_THREADS / 64) + wv; r < m_loc; r += nrw) {
         if (world > 1 && (r % world) != rank) continue;
@@ -757,38 +936,67 @@ __global__ void __launch_bounds__(SCORE_THREADS)
         int rc = 0;
         if (b != e) {
             const int2 cp1 = tab.cp[i];
-            const uint2 ai = staged ? lcol[r] : gcol[r];
-            for (long long q0 = b + lane; q0 < e; q0 += 64) {
-                const int2 v = cc[q0];
-                const int2 cp2 = tab.cp[v.x];
-                if (!slice_keep(m, cp1.x, cp2.x, cp1.y, cp2.y, v.y, UNWINDOWED)) continue;
-                const int lj = ((m.same || cp2.x == m.ctgA) ? 0 : m.SLA) + cp2.y;
-                const uint2 bj = staged ? lcol[lj] : gcol[lj];
-                const long long q = eval_q(p, mean, ai, bj, cm, v.y, lgfact_dev(v.y, lgf_tab));
-                hi += q >> 32;
-                lo += (long long)(unsigned int)q;
-                rc++;
+            for (long long q0 = b; q0 < e; q0 += 64) {
+                const long long qi = q0 + lane;
+                bool keep = false;
+                int lj = 0, ob = 0;
+                if (qi < e) {
+                    const int2 v = cc[qi];
+                    const int2 cp2 = tab.cp[v.x];
+                    keep = slice_keep(m, cp1.x, cp2.x, cp1.y, cp2.y, v.y, UNWINDOWED);
+                    lj = ((m.same || cp2.x == m.ctgA) ? 0 : m.SLA) + cp2.y;
+                    ob = v.y;
+                }
+                const unsigned long long mask = __ballot(keep);
+                if (mask) {
+                    if (keep) {
+                        const int at = qn + __popcll(mask & lt_mask);
+                        qli[at] = r;
+                        qlj[at] = lj;
+                        qob[at] = ob;
+                    }
+                    const int add = __popcll(mask);
+                    qn += add;
+                    rc += add;
+                    __builtin_amdgcn_wave_barrier();
+                    if (qn >= 64) {
+                        drain(64);
+                        __builtin_amdgcn_wave_barrier();
+                        const int rem = qn - 64;
+                        int t0 = 0, t1 = 0, t2 = 0;
+                        if (lane < rem) {
+                            t0 = qli[64 + lane];
+                            t1 = qlj[64 + lane];
+                            t2 = qob[64 + lane];
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < rem) {
+                            qli[lane] = t0;
+                            qlj[lane] = t1;
+                            qob[lane] = t2;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        qn = rem;
+                    }
+                }
             }
         }
-        if (!UNWINDOWED && kk == 0) { /* kept contacts of this row: the tail walk of k_finalize needs them */
-            const int rs = wave_sum_i(rc);
-            if (lane == 0) rowcnt[r] = rs;
-        }
+        if (!UNWINDOWED && kk == 0 && lane == 0) rowcnt[r] = rc; /* kept contacts of this row: needed by the tail walk */
         cnt += rc;
     }
+    drain(qn);
     hi = wave_sum_ll(hi);
     lo = wave_sum_ll(lo);
-    long long cn = wave_sum_ll((long long)cnt);
     if (lane == 0) {
         red[0][wv] = hi;
         red[1][wv] = lo;
-        red[2][wv] = cn;
+        red[2][wv] = (long long)cnt;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         hi = red[0][0] + red[0][1] + red[0][2] + red[0][3];
         lo = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        cn = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        const long long cn = red[2][0] + red[2][1] + red[2][2] + red[2][3];
         if (UNWINDOWED) {
             Glob* gw = const_cast<Glob*>(g);
             if (hi | lo) {
@@ -816,7 +1024,7 @@ __device__ __forceinline__ int wave_max_i(int v)
  * (eval_all_likelihood_on_zero_2nd KA:4005-4027, eval_all_scores KA:4029-4046). */
 __global__ void __launch_bounds__(256) k_finalize(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
                                                   Glob* g, MoveBuf mb, long long* q_part, const double* __restrict__ lgf_tab,
-                                                  int tail_quirk)
+                                                  int tail_quirk, PzTab pz)
 {
     __shared__ int t_li[64], t_lj[64], t_ob[64], t_rows[64];
     __shared__ int sh_n_rows, sh_n_tail, sh_cnt;
@@ -920,7 +1128,7 @@ __global__ void __launch_bounds__(256) k_finalize(const long long* __restrict__ 
             const ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
             long long hi = 0, lo = 0;
             if (lane < n_tail) {
-                const long long q = eval_q(p, mean, col[t_li[lane]], col[t_lj[lane]], cm, t_ob[lane], lgfact_dev(t_ob[lane], lgf_tab));
+                const long long q = eval_q(p, mean, col[t_li[lane]], col[t_lj[lane]], cm, t_ob[lane], lgfact_dev(t_ob[lane], lgf_tab), pz);
                 hi = q >> 32;
                 lo = (long long)(unsigned int)q;
             }
@@ -1145,8 +1353,8 @@ static int dalloc(T** p, size_t n)
         if (dalloc(&(p), (n))) return -1; \
     } while (0)
 
-enum { T_GATHER = 0, T_MUTATE, T_SCORE, T_FINALIZE, T_DELTA, T_APPLY, T_POST, T_COMMIT };
-static const char* kTimerNames[8] = {"gather", "mutate", "score", "finalize", "delta", "apply", "post", "commit"};
+enum { T_GATHER = 0, T_MUTATE, T_SCORE, T_FINALIZE, T_DELTA, T_APPLY, T_POST, T_COMMIT, T_SLICE, T_ARGMAX, T_COUNT };
+static const char* kTimerNames[T_COUNT] = {"gather", "mutate", "score", "finalize", "delta", "apply", "post", "commit", "slice", "argmax"};
 
 struct TimedLaunch {
     ig_ctx* c;
@@ -1172,7 +1380,7 @@ struct TimedLaunch {
 
 static void drain_timers(ig_ctx* c)
 {
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < T_COUNT; i++) {
         for (auto& pr : c->timers[i].ev) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
@@ -1218,9 +1426,11 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->d_frags = c->d_cands = nullptr;
     c->cands_cap = 0;
     c->prev_touched = nullptr;
-    c->timing_mask = 0xff;
+    c->pz_tab = nullptr;
+    c->pz_n = 0;
+    c->timing_mask = 0xffff;
     c->timing = false;
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < T_COUNT; i++) {
         c->timers[i].name = kTimerNames[i];
         c->timers[i].total_ms = 0;
         c->timers[i].n = 0;
@@ -1263,6 +1473,9 @@ static void free_move_buffers(ig_ctx* c)
     hipFree(m.slloc);
     hipFree(m.subs);
     hipFree(m.rowcnt);
+    hipFree(m.sl_li);
+    hipFree(m.sl_lj);
+    hipFree(m.sl_ob);
     hipFree(m.coords);
     hipFree(m.loc);
     hipFree(m.meta);
@@ -1297,6 +1510,7 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipFree(c->d_frags);
     hipFree(c->d_cands);
     hipFree(c->prev_touched);
+    hipFree(c->pz_tab);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1325,7 +1539,7 @@ extern "C" int ig_set_stream(ig_ctx* c, void* s)
 
 static int ensure_move_buffers(ig_ctx* c, int capC)
 {
-    if (c->mb.capC >= capC && c->mb.N == c->N && c->mb.M == c->M) return 0;
+    if (c->mb.capC >= capC && c->mb.N == c->N && c->mb.M == c->M && c->mb.Zcap == std::max<long long>(c->Z, 1)) return 0;
     if (c->N == 0 || c->M == 0) return 0;
     free_move_buffers(c);
     MoveBuf& m = c->mb;
@@ -1335,6 +1549,13 @@ static int ensure_move_buffers(ig_ctx* c, int capC)
     DALLOC(m.slloc, C * N);
     DALLOC(m.subs, C * M);
     DALLOC(m.rowcnt, C * M);
+    {
+        const size_t Zc = (size_t)std::max<long long>(c->Z, 1);
+        DALLOC(m.sl_li, C * Zc);
+        DALLOC(m.sl_lj, C * Zc);
+        DALLOC(m.sl_ob, C * Zc);
+        m.Zcap = (long long)Zc;
+    }
     DALLOC(m.coords, C * M * NSLOT);
     DALLOC(m.loc, C * NSLOT * NDYN * N);
     DALLOC(m.meta, C);
@@ -1543,6 +1764,12 @@ extern "C" int ig_set_params(ig_ctx* c, const float p[8], float mean_subfrag_kb,
     HIPCK(hipMemcpy(&c->glob->mean_kb, &mean_subfrag_kb, sizeof(float), hipMemcpyHostToDevice));
     if (which == 0) {
         c->have_params = true;
+        if (!c->pz_tab) DALLOC(c->pz_tab, PZ_MAX);
+        /* table length: first rank distance whose s_z reaches d_max (+1), capped */
+        double need = (mean_subfrag_kb > 0) ? (double)p[5] / (double)mean_subfrag_kb + 2.0 : 0.0;
+        c->pz_n = (need > 0 && need < (double)PZ_MAX) ? (int)need : ((need >= (double)PZ_MAX) ? PZ_MAX : 0);
+        if (c->pz_n > 0)
+            hipLaunchKernelGGL(k_build_pz, dim3((c->pz_n + 255) / 256), dim3(256), 0, c->stream, c->glob, c->pz_tab, c->pz_n);
         return launch_recompute(c); /* the maintained exact sums depend on param_simu */
     }
     return 0;
@@ -1739,19 +1966,26 @@ static void enqueue_move(ig_ctx* c, int move, int max_c, int force_slot, int pha
         {
             TimedLaunch t(c, T_MUTATE);
             hipLaunchKernelGGL(k_mutate, dim3(NSLOT, max_c), dim3(256), 0, c->stream, c->st, c->tab, c->sub_tab, c->glob, c->mb,
-                               c->q_part);
+                               c->q_part, PzTab{c->pz_tab, c->pz_n});
         }
         if (force_slot < 0) {
+            {
+                TimedLaunch t(c, T_SLICE);
+                hipLaunchKernelGGL(k_slice, dim3(SLICE_RB, max_c), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb,
+                                   c->rank, c->world);
+            }
             TimedLaunch t(c, T_SCORE);
-            hipLaunchKernelGGL(k_score<false>, dim3(SCORE_RB, NSLOT, max_c), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab,
-                               c->glob, c->mb, c->lgf_tab, c->rank, c->world);
+            if (0) hipLaunchKernelGGL(k_slice, dim3(SLICE_RB, max_c), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb,
+                               c->rank, c->world);
+            hipLaunchKernelGGL(k_score_list, dim3(SCORE_EB, NSLOT, max_c), dim3(SCORE_THREADS), 0, c->stream, c->glob, c->mb,
+                               c->lgf_tab, PzTab{c->pz_tab, c->pz_n});
         }
     }
     if (phase == 1 || phase == 2) {
         if (force_slot < 0) {
             TimedLaunch t(c, T_FINALIZE);
             hipLaunchKernelGGL(k_finalize, dim3(max_c), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->q_part,
-                               c->lgf_tab, g_tail_quirk);
+                               c->lgf_tab, g_tail_quirk, PzTab{c->pz_tab, c->pz_n});
             hipLaunchKernelGGL(k_argmax, dim3(1), dim3(64), 0, c->stream, c->glob, c->mb, c->q_part);
         } else {
             hipLaunchKernelGGL(k_force_choice, dim3(1), dim3(1), 0, c->stream, c->glob, c->mb, force_slot);
@@ -1765,7 +1999,7 @@ static void enqueue_apply(ig_ctx* c, int move, int forced)
     {
         TimedLaunch t(c, T_DELTA);
         hipLaunchKernelGGL(k_score<true>, dim3(DELTA_RB, 2, 1), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob,
-                           c->mb, c->lgf_tab, 0, 1);
+                           c->mb, c->lgf_tab, 0, 1, PzTab{c->pz_tab, c->pz_n});
     }
     {
         TimedLaunch t(c, T_APPLY);
@@ -1933,7 +2167,7 @@ extern "C" int ig_step_finish(ig_ctx* c, ig_move_result* out, double* scores)
 extern "C" int ig_kernel_time_ms(ig_ctx* c, const char* name, double* avg_ms, int64_t* n)
 {
     drain_timers(c);
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < T_COUNT; i++)
         if (!strcmp(name, c->timers[i].name)) {
             if (avg_ms) *avg_ms = c->timers[i].n ? c->timers[i].total_ms / (double)c->timers[i].n : 0.0;
             if (n) *n = c->timers[i].n;
@@ -1946,12 +2180,12 @@ extern "C" int ig_reset_timers(ig_ctx* c, int enable)
 {
     HIPCK(hipStreamSynchronize(c->stream));
     drain_timers(c);
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < T_COUNT; i++) {
         c->timers[i].total_ms = 0;
         c->timers[i].n = 0;
     }
     c->timing = enable != 0;
-    c->timing_mask = enable > 1 ? (unsigned)(enable >> 1) : 0xffu; /* enable = 1 | (mask << 1) */
+    c->timing_mask = enable > 1 ? (unsigned)(enable >> 1) : 0xffffu; /* enable = 1 | (mask << 1) */
     return 0;
 }
 
