@@ -19,7 +19,7 @@
  *   kernels/kernel_sparse_adapt.cu:4172-4208, 4315-4353, 4426-4462  per-contact term
  *   kernels/kernel_sparse_adapt.cu:3882-3899, 3955-3972           zero-pixel term
  * The reference calls CUDA's powf/expf/log10; those are replaced here by
- * double-precision range-reduction + polynomial evaluations whose result,
+ * double-precision table-driven range reduction + short polynomials whose result,
  * rounded to the reference's precision class (float for P(s), double for the
  * Poisson term), is within 1 ulp of the correctly rounded value.
  */
@@ -27,6 +27,8 @@
 #define IG_DETMATH_H
 
 #include <stdint.h>
+
+#include "ig_detmath_tables.h"
 
 #if defined(__HIPCC__)
 #define IG_HD __host__ __device__ __forceinline__
@@ -65,62 +67,59 @@ IG_HD float ig_fmaxf(float a, float b)
 }
 
 /* ---- log2 of a positive, finite, normal double ------------------------
- * x = 2^e * m, m in (sqrt(1/2), sqrt(2)];  ln m = 2 atanh(f), f=(m-1)/(m+1),
- * |f| <= 0.1716; odd series to f^23 (truncation < 2e-19 relative). */
+ * Table-driven (Tang): x = 2^e * m; the top 6 mantissa bits pick an interval with centre c_j and a
+ * tabulated, rounded reciprocal r_j ~ 1/c_j; u = m*r_j - 1 is formed with one fma (|u| < 2^-6.9), and
+ * log2(m) = -log2(r_j) + log2(1+u) with a degree-8 alternating series (truncation < 1e-19).
+ * Intervals above sqrt(2)-ish are folded to m/2 so that x ~ 1 is evaluated without cancellation.
+ * No division: the reciprocal comes from the table, identical bits on every target. */
 IG_HD double ig_log2_pos(double x)
 {
-    uint64_t b = ig_d2u(x);
+    static const double rcp[64] = IG_LOG_RCP_INIT;
+    static const double val[64] = IG_LOG_VAL_INIT;
+    const uint64_t b = ig_d2u(x);
     int e = (int)((b >> 52) & 0x7ffu) - 1023;
+    const int j = (int)((b >> 46) & 63u);
     double m = ig_u2d((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
-    if (m > 1.4142135623730951) {
+    if (j >= IG_LOG_SPLIT) {
         m = m * 0.5;
         e += 1;
     }
-    double f = (m - 1.0) / (m + 1.0);
-    double f2 = f * f;
-    double p = 1.0 / 23.0;
-    p = ig_fma(p, f2, 1.0 / 21.0);
-    p = ig_fma(p, f2, 1.0 / 19.0);
-    p = ig_fma(p, f2, 1.0 / 17.0);
-    p = ig_fma(p, f2, 1.0 / 15.0);
-    p = ig_fma(p, f2, 1.0 / 13.0);
-    p = ig_fma(p, f2, 1.0 / 11.0);
-    p = ig_fma(p, f2, 1.0 / 9.0);
-    p = ig_fma(p, f2, 1.0 / 7.0);
-    p = ig_fma(p, f2, 1.0 / 5.0);
-    p = ig_fma(p, f2, 1.0 / 3.0);
-    p = ig_fma(p, f2, 1.0);
-    double lnm = (2.0 * f) * p;
-    /* 1/ln2 split: hi part has 32 significant bits so lnm*hi is nearly exact */
-    return ig_fma(lnm, 1.4426950408889634, (double)e);
+    const double u = ig_fma(m, rcp[j], -1.0);
+    double p = IG_LOG_C8;
+    p = ig_fma(p, u, IG_LOG_C7);
+    p = ig_fma(p, u, IG_LOG_C6);
+    p = ig_fma(p, u, IG_LOG_C5);
+    p = ig_fma(p, u, IG_LOG_C4);
+    p = ig_fma(p, u, IG_LOG_C3);
+    p = ig_fma(p, u, IG_LOG_C2);
+    p = ig_fma(p, u, IG_LOG_C1);
+    return ig_fma(p, u, val[j]) + (double)e;
 }
 
-/* ---- 2^y for |y| <= 1022 (clamped outside) ---------------------------- */
+/* ---- 2^y -----------------------------------------------------------------
+ * y = k + j/32 + t with k = rint(y), j = rint(32 (y-k)) in [-16,16], |t| <= 1/64 (all exact);
+ * 2^y = 2^k * T[j] * (1 + sum_{n=1..7} (t ln2)^n / n!)   (truncation < 1e-20). */
 IG_HD double ig_exp2(double y)
 {
+    static const double tab[33] = IG_EXP_TAB_INIT;
     if (ig_isnan(y)) return IG_NAN; /* canonical NaN: payloads differ between targets */
     if (y > 1000.0) return IG_INF;
     if (y < -1000.0) return 0.0;
-    double k = __builtin_rint(y); /* round-half-even, exact */
-    double r = y - k;             /* exact, |r| <= 0.5 */
-    double t = r * 0.6931471805599453;
-    double p = 1.0 / 6227020800.0; /* 1/13! */
-    p = ig_fma(p, t, 1.0 / 479001600.0);
-    p = ig_fma(p, t, 1.0 / 39916800.0);
-    p = ig_fma(p, t, 1.0 / 3628800.0);
-    p = ig_fma(p, t, 1.0 / 362880.0);
-    p = ig_fma(p, t, 1.0 / 40320.0);
-    p = ig_fma(p, t, 1.0 / 5040.0);
-    p = ig_fma(p, t, 1.0 / 720.0);
-    p = ig_fma(p, t, 1.0 / 120.0);
-    p = ig_fma(p, t, 1.0 / 24.0);
-    p = ig_fma(p, t, 1.0 / 6.0);
-    p = ig_fma(p, t, 0.5);
-    p = ig_fma(p, t, 1.0);
-    p = ig_fma(p, t, 1.0);
-    int ki = (int)k;
-    double sc = ig_u2d((uint64_t)(ki + 1023) << 52);
-    return p * sc;
+    const double k = __builtin_rint(y); /* round-half-even, exact */
+    const double r = y - k;             /* exact, |r| <= 0.5 */
+    const double jd = __builtin_rint(r * 32.0);
+    const double t = r - jd * 0.03125;  /* exact */
+    double p = IG_EXP_C7;
+    p = ig_fma(p, t, IG_EXP_C6);
+    p = ig_fma(p, t, IG_EXP_C5);
+    p = ig_fma(p, t, IG_EXP_C4);
+    p = ig_fma(p, t, IG_EXP_C3);
+    p = ig_fma(p, t, IG_EXP_C2);
+    p = ig_fma(p, t, IG_EXP_C1);
+    const double tj = tab[(int)jd + 16];
+    const double v = ig_fma(tj * p, t, tj);
+    const int ki = (int)k;
+    return v * ig_u2d((uint64_t)(ki + 1023) << 52);
 }
 
 /* ---- the three libm calls of the reference kernels --------------------- */
@@ -141,7 +140,7 @@ IG_HD float ig_powf(float x, float y)
 IG_HD float ig_expf(float x)
 {
     if (ig_isnanf(x)) return IG_NANF;
-    return (float)ig_exp2((double)x * 1.4426950408889634);
+    return (float)ig_exp2((double)x * IG_LOG2_E);
 }
 
 /* log10(x), double, as used by KA:259-262. */
@@ -151,7 +150,7 @@ IG_HD double ig_log10(double x)
     if (x < 0.0) return IG_NAN;
     if (x == 0.0) return -IG_INF;
     if (ig_isinf(x)) return x;
-    return ig_log2_pos(x) * 0.30102999566398120;
+    return ig_log2_pos(x) * IG_LOG2_10_INV;
 }
 
 /* ---- model ------------------------------------------------------------- */
@@ -165,8 +164,11 @@ IG_HD float ig_rippe(float s, const ig_params p)
     float result = 0.0f;
     if ((s > 0.0f) && (s < p.d_max)) {
         float pw = ig_powf(s, p.slope);
-        float t = s * p.lm / p.kuhn;
-        float e = ig_expf((p.d - 2.0f) / (ig_powf(t, 2.0f) + p.d));
+        float e = 1.0f; /* d == 2 (always, optim_rippe_curve_update.py:8): expf(0 / (t^2 + 2)) is exactly 1 */
+        if (p.d != 2.0f) {
+            float t = s * p.lm / p.kuhn;
+            e = ig_expf((p.d - 2.0f) / (ig_powf(t, 2.0f) + p.d));
+        }
         result = (p.c1 * pw * e) * p.fact;
     }
     return ig_fmaxf(result, p.v_inter);
