@@ -763,10 +763,12 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
 #define LDS_COL_CAP 4096  /* local sub-fragments whose column fits the 32 KB LDS stage */
 
 /* k_slice: slice_sp_mat (KA:485-607) restricted to the CSR rows of the touched contigs (instead of a scan of
- * all Z contacts): kept contacts are appended to the candidate's list with one wave-aggregated atomic per
- * 64 contacts (ballot + popcount ranks); no sort is needed afterwards (the reference sorted by row only to
- * feed its shared-memory row cache, CL:1045-1050). */
-#define SLICE_RB 32
+ * all Z contacts).  One wave per row: up to SLICE_UNROLL x 64 contacts are loaded back to back (coalesced
+ * 8-byte loads, then one packed (contig, rank) gather each), the predicate is evaluated, and the kept ones
+ * are appended to the candidate's list with ONE wave-aggregated atomic per batch (ballot + popcount ranks).
+ * No sort afterwards: the reference sorted by row only to feed its shared-memory row cache (CL:1045-1050). */
+#define SLICE_RB 128
+#define SLICE_UNROLL 4
 __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
                                                const Glob* g, MoveBuf mb, int rank, int world)
 {
@@ -790,30 +792,40 @@ __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ row
         int rc = 0;
         if (b != e) {
             const int2 cp1 = tab.cp[i];
-            for (long long q0 = b; q0 < e; q0 += 64) {
-                const long long qi = q0 + lane;
-                bool keep = false;
-                int lj = 0, ob = 0;
-                if (qi < e) {
-                    const int2 v = cc[qi];
-                    const int2 cp2 = tab.cp[v.x];
-                    keep = slice_keep(m, cp1.x, cp2.x, cp1.y, cp2.y, v.y, false);
-                    lj = ((m.same || cp2.x == m.ctgA) ? 0 : m.SLA) + cp2.y;
-                    ob = v.y;
+            for (long long q0 = b; q0 < e; q0 += 64 * SLICE_UNROLL) {
+                int2 v[SLICE_UNROLL], cp2[SLICE_UNROLL];
+                bool keep[SLICE_UNROLL];
+                unsigned long long mask[SLICE_UNROLL];
+#pragma unroll
+                for (int u = 0; u < SLICE_UNROLL; u++) {
+                    const long long qi = q0 + u * 64 + lane;
+                    v[u] = (qi < e) ? cc[qi] : make_int2(-1, 0);
                 }
-                const unsigned long long mask = __ballot(keep);
-                if (mask) {
-                    const int add = __popcll(mask);
+#pragma unroll
+                for (int u = 0; u < SLICE_UNROLL; u++) cp2[u] = (v[u].x >= 0) ? tab.cp[v[u].x] : make_int2(-1, -1);
+                int add = 0;
+#pragma unroll
+                for (int u = 0; u < SLICE_UNROLL; u++) {
+                    keep[u] = (v[u].x >= 0) && slice_keep(m, cp1.x, cp2[u].x, cp1.y, cp2[u].y, v[u].y, false);
+                    mask[u] = __ballot(keep[u]);
+                    add += __popcll(mask[u]);
+                }
+                if (add) {
                     rc += add;
                     if (mine) {
                         unsigned long long base = 0;
                         if (lane == 0) base = atomicAdd(cursor, (unsigned long long)add);
                         base = __shfl(base, 0, 64);
-                        if (keep) {
-                            const long long at = (long long)base + __popcll(mask & lt_mask);
-                            sli[at] = r;
-                            slj[at] = lj;
-                            slo[at] = ob;
+                        int off = 0;
+#pragma unroll
+                        for (int u = 0; u < SLICE_UNROLL; u++) {
+                            if (keep[u]) {
+                                const long long at = (long long)base + off + __popcll(mask[u] & lt_mask);
+                                sli[at] = r;
+                                slj[at] = ((m.same || cp2[u].x == m.ctgA) ? 0 : m.SLA) + cp2[u].y;
+                                slo[at] = v[u].y;
+                            }
+                            off += __popcll(mask[u]);
                         }
                     }
                 }
@@ -824,14 +836,21 @@ __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ row
 }
 
 /* k_score_list: the hot kernel.  One workgroup = (entry block, coordinate column k, candidate c).  The
- * column (8 B per local sub-fragment) is staged in LDS; lanes stream the slice list (three coalesced 4-byte
- * loads per contact), read both endpoints' coordinates from LDS, evaluate the Rippe / Poisson term and add
- * it as a 64-bit integer.  Wave shuffles, one LDS step, two atomics per workgroup. */
+ * column (8 B per local sub-fragment), the P_z table, the log10(ob!) table and the per-contig constants are
+ * staged in LDS; lanes stream the slice list four contacts at a time (coalesced 4-byte loads issued together),
+ * read both endpoints' coordinates from LDS, evaluate the Rippe / Poisson term and add it as a 64-bit integer.
+ * Wave shuffles, one LDS step, two atomics per workgroup. */
 #define SCORE_EB 32
+#define SCORE_BATCH 4
+#define LDS_PZ 1024
+#define LDS_LGF 256
 __global__ void __launch_bounds__(SCORE_THREADS)
     k_score_list(const Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz)
 {
     __shared__ uint2 lcol[LDS_COL_CAP];
+    __shared__ float pz_s[LDS_PZ];
+    __shared__ double lgf_s[LDS_LGF];
+    __shared__ ColMeta cm_s[NCODE];
     __shared__ long long red[2][SCORE_THREADS / 64];
     const int c = blockIdx.z;
     if (c >= g->C) return;
@@ -844,23 +863,40 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     const float mean = g->mean_kb;
     const uint2* gcol = mb.coords + (size_t)(c * NSLOT + k) * M;
     const bool staged = m_loc <= LDS_COL_CAP;
-    if (staged) {
+    if (staged)
         for (int i = threadIdx.x; i < m_loc; i += SCORE_THREADS) lcol[i] = gcol[i];
-        __syncthreads();
-    }
-    const ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
+    const int pzn = min(pz.n, LDS_PZ);
+    for (int i = threadIdx.x; i < pzn; i += SCORE_THREADS) pz_s[i] = pz.v[i];
+    for (int i = threadIdx.x; i < LDS_LGF; i += SCORE_THREADS) lgf_s[i] = lgf_tab[i];
+    if (threadIdx.x < NCODE) cm_s[threadIdx.x] = mb.cmeta[(size_t)(c * NSLOT + k) * NCODE + threadIdx.x];
+    __syncthreads();
+    const PzTab pzl = {pz_s, pzn};
     const int* sli = mb.sl_li + (size_t)c * mb.Zcap;
     const int* slj = mb.sl_lj + (size_t)c * mb.Zcap;
     const int* slo = mb.sl_ob + (size_t)c * mb.Zcap;
     long long hi = 0, lo = 0;
     const long long stride = (long long)gridDim.x * SCORE_THREADS;
-    for (long long e = (long long)blockIdx.x * SCORE_THREADS + threadIdx.x; e < n; e += stride) {
-        const int li = sli[e], lj = slj[e], ob = slo[e];
-        const uint2 ai = staged ? lcol[li] : gcol[li];
-        const uint2 bj = staged ? lcol[lj] : gcol[lj];
-        const long long q = eval_q(p, mean, ai, bj, cm, ob, lgfact_dev(ob, lgf_tab), pz);
-        hi += q >> 32;
-        lo += (long long)(unsigned int)q;
+    for (long long e0 = (long long)blockIdx.x * SCORE_THREADS + threadIdx.x; e0 < n; e0 += stride * SCORE_BATCH) {
+        int li[SCORE_BATCH], lj[SCORE_BATCH], ob[SCORE_BATCH];
+#pragma unroll
+        for (int u = 0; u < SCORE_BATCH; u++) {
+            const long long e = e0 + u * stride;
+            const bool ok = e < n;
+            li[u] = ok ? sli[e] : -1;
+            lj[u] = ok ? slj[e] : 0;
+            ob[u] = ok ? slo[e] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < SCORE_BATCH; u++) {
+            if (li[u] < 0) continue;
+            const uint2 ai = staged ? lcol[li[u]] : gcol[li[u]];
+            const uint2 bj = staged ? lcol[lj[u]] : gcol[lj[u]];
+            const double lgf = (ob[u] > 0 && ob[u] < LDS_LGF) ? lgf_s[ob[u]] : lgfact_dev(ob[u], lgf_tab);
+            const int d_ = abs((int)(ai.y & 0x0fffffffu) - (int)(bj.y & 0x0fffffffu));
+            const long long q = eval_q(p, mean, ai, bj, cm_s, ob[u], lgf, (d_ < pzn) ? pzl : pz);
+            hi += q >> 32;
+            lo += (long long)(unsigned int)q;
+        }
     }
     hi = wave_sum_ll(hi);
     lo = wave_sum_ll(lo);
