@@ -66,16 +66,26 @@ IG_HD float ig_fmaxf(float a, float b)
     return a > b ? a : b;
 }
 
+/* One table for both functions: [0,64) reciprocals r_j, [64,128) -log2(r_j), [128,161) 2^(j/32), j=-16..16.
+ * Every function below takes the table pointer explicitly so that a GPU kernel can pass its LDS copy
+ * (ds_read instead of a global gather); ig_tab() is the constant-memory / static copy. */
+#define IG_TAB_SIZE 161
+#define IG_TAB_VAL 64
+#define IG_TAB_EXP 128
+IG_HD const double* ig_tab(void)
+{
+    static const double tab[IG_TAB_SIZE] = IG_TAB_INIT;
+    return tab;
+}
+
 /* ---- log2 of a positive, finite, normal double ------------------------
  * Table-driven (Tang): x = 2^e * m; the top 6 mantissa bits pick an interval with centre c_j and a
  * tabulated, rounded reciprocal r_j ~ 1/c_j; u = m*r_j - 1 is formed with one fma (|u| < 2^-6.9), and
  * log2(m) = -log2(r_j) + log2(1+u) with a degree-8 alternating series (truncation < 1e-19).
  * Intervals above sqrt(2)-ish are folded to m/2 so that x ~ 1 is evaluated without cancellation.
  * No division: the reciprocal comes from the table, identical bits on every target. */
-IG_HD double ig_log2_pos(double x)
+IG_HD double ig_log2_pos(double x, const double* T)
 {
-    static const double rcp[64] = IG_LOG_RCP_INIT;
-    static const double val[64] = IG_LOG_VAL_INIT;
     const uint64_t b = ig_d2u(x);
     int e = (int)((b >> 52) & 0x7ffu) - 1023;
     const int j = (int)((b >> 46) & 63u);
@@ -84,7 +94,7 @@ IG_HD double ig_log2_pos(double x)
         m = m * 0.5;
         e += 1;
     }
-    const double u = ig_fma(m, rcp[j], -1.0);
+    const double u = ig_fma(m, T[j], -1.0);
     double p = IG_LOG_C8;
     p = ig_fma(p, u, IG_LOG_C7);
     p = ig_fma(p, u, IG_LOG_C6);
@@ -93,15 +103,14 @@ IG_HD double ig_log2_pos(double x)
     p = ig_fma(p, u, IG_LOG_C3);
     p = ig_fma(p, u, IG_LOG_C2);
     p = ig_fma(p, u, IG_LOG_C1);
-    return ig_fma(p, u, val[j]) + (double)e;
+    return ig_fma(p, u, T[IG_TAB_VAL + j]) + (double)e;
 }
 
 /* ---- 2^y -----------------------------------------------------------------
  * y = k + j/32 + t with k = rint(y), j = rint(32 (y-k)) in [-16,16], |t| <= 1/64 (all exact);
  * 2^y = 2^k * T[j] * (1 + sum_{n=1..7} (t ln2)^n / n!)   (truncation < 1e-20). */
-IG_HD double ig_exp2(double y)
+IG_HD double ig_exp2(double y, const double* T)
 {
-    static const double tab[33] = IG_EXP_TAB_INIT;
     if (ig_isnan(y)) return IG_NAN; /* canonical NaN: payloads differ between targets */
     if (y > 1000.0) return IG_INF;
     if (y < -1000.0) return 0.0;
@@ -116,7 +125,7 @@ IG_HD double ig_exp2(double y)
     p = ig_fma(p, t, IG_EXP_C3);
     p = ig_fma(p, t, IG_EXP_C2);
     p = ig_fma(p, t, IG_EXP_C1);
-    const double tj = tab[(int)jd + 16];
+    const double tj = T[IG_TAB_EXP + (int)jd + 16];
     const double v = ig_fma(tj * p, t, tj);
     const int ki = (int)k;
     return v * ig_u2d((uint64_t)(ki + 1023) << 52);
@@ -125,7 +134,7 @@ IG_HD double ig_exp2(double y)
 /* ---- the three libm calls of the reference kernels --------------------- */
 
 /* powf(x, y) as used by KA:159, 217 (x = distance or n, y = slope / 2.0f / -3.0f / n). */
-IG_HD float ig_powf(float x, float y)
+IG_HD float ig_powf(float x, float y, const double* T)
 {
     if (ig_isnanf(x) || ig_isnanf(y)) return IG_NANF;
     if (y == 0.0f) return 1.0f;
@@ -133,24 +142,24 @@ IG_HD float ig_powf(float x, float y)
     if (x < 0.0f) return IG_NANF; /* non-integer exponents only on this path */
     if (x == 0.0f) return y < 0.0f ? IG_INFF : 0.0f;
     if (ig_isinff(x)) return y < 0.0f ? 0.0f : IG_INFF;
-    return (float)ig_exp2((double)y * ig_log2_pos((double)x));
+    return (float)ig_exp2((double)y * ig_log2_pos((double)x, T), T);
 }
 
 /* expf(x) as used by KA:121, 159, 217. */
-IG_HD float ig_expf(float x)
+IG_HD float ig_expf(float x, const double* T)
 {
     if (ig_isnanf(x)) return IG_NANF;
-    return (float)ig_exp2((double)x * IG_LOG2_E);
+    return (float)ig_exp2((double)x * IG_LOG2_E, T);
 }
 
 /* log10(x), double, as used by KA:259-262. */
-IG_HD double ig_log10(double x)
+IG_HD double ig_log10(double x, const double* T)
 {
     if (ig_isnan(x)) return IG_NAN;
     if (x < 0.0) return IG_NAN;
     if (x == 0.0) return -IG_INF;
     if (ig_isinf(x)) return x;
-    return ig_log2_pos(x) * IG_LOG2_10_INV;
+    return ig_log2_pos(x, T) * IG_LOG2_10_INV;
 }
 
 /* ---- model ------------------------------------------------------------- */
@@ -159,15 +168,15 @@ typedef struct ig_params {
 } ig_params;
 
 /* KA:153-163 */
-IG_HD float ig_rippe(float s, const ig_params p)
+IG_HD float ig_rippe(float s, const ig_params p, const double* T)
 {
     float result = 0.0f;
     if ((s > 0.0f) && (s < p.d_max)) {
-        float pw = ig_powf(s, p.slope);
+        float pw = ig_powf(s, p.slope, T);
         float e = 1.0f; /* d == 2 (always, optim_rippe_curve_update.py:8): expf(0 / (t^2 + 2)) is exactly 1 */
         if (p.d != 2.0f) {
             float t = s * p.lm / p.kuhn;
-            e = ig_expf((p.d - 2.0f) / (ig_powf(t, 2.0f) + p.d));
+            e = ig_expf((p.d - 2.0f) / (ig_powf(t, 2.0f, T) + p.d), T);
         }
         result = (p.c1 * pw * e) * p.fact;
     }
@@ -175,14 +184,14 @@ IG_HD float ig_rippe(float s, const ig_params p)
 }
 
 /* KA:200-225 (note the clamp with d_max, quirk Q6) */
-IG_HD float ig_rippe_circ(float s, float s_tot, const ig_params p)
+IG_HD float ig_rippe_circ(float s, float s_tot, const ig_params p, const double* T)
 {
     float result = 0.0f;
     if ((s > 0.0f) && (s < p.d_max)) {
         float K = p.lm / p.kuhn;
         float n = K * s * (s_tot - s) / s_tot;
-        result = (ig_powf(p.kuhn, -3.0f) * ig_powf(n, p.slope) *
-                  ig_expf((p.d - 2.0f) / (ig_powf(n, 2.0f) + p.d))) *
+        result = (ig_powf(p.kuhn, -3.0f, T) * ig_powf(n, p.slope, T) *
+                  ig_expf((p.d - 2.0f) / (ig_powf(n, 2.0f, T) + p.d), T)) *
                  p.fact;
     }
     return ig_fmaxf(result, p.d_max);
@@ -191,12 +200,12 @@ IG_HD float ig_rippe_circ(float s, float s_tot, const ig_params p)
 /* log10(ob!) part of KA:251-270; ob >= 1. `lgf_small` = table of
  * log10((double)factorial_f32(ob)) for ob = 0..14 (KA:111-124), built once on
  * the host by ig_build_lgf_table(). */
-IG_HD double ig_lgfact(int ob, const double* lgf_small)
+IG_HD double ig_lgfact(int ob, const double* lgf_small, const double* T)
 {
     if (ob < 15) return lgf_small[ob];
     double o = (double)ob;
     /* ob*log10(ob) - ob + log10(sqrt(2*pi*ob)); the sqrt is folded into the log */
-    return (o * ig_log10(o) - o) + 0.5 * ig_log10(o * 2.0 * 3.14159265358979323846);
+    return (o * ig_log10(o, T) - o) + 0.5 * ig_log10(o * 2.0 * 3.14159265358979323846, T);
 }
 
 /* The float literal 0.43429448190325182f of KA:4019, 4208, 4353, 4462. */
@@ -205,13 +214,13 @@ IG_HD double ig_lgfact(int ob, const double* lgf_small)
 /* One non-zero pixel: KA:4207-4208 / 4352-4353 / 4462.
  * ex, ex_z : expected contacts (float, already clamped), ob : observed count,
  * lgf = ig_lgfact(ob).  Evaluation order follows the reference expression. */
-IG_HD double ig_pixel_term(float ex, float ex_z, int ob, double lgf)
+IG_HD double ig_pixel_term(float ex, float ex_z, int ob, double lgf, const double* T)
 {
     double e = (double)ex;
     double res = 0.0;
     if (e != 0.0) {
         double o = (double)ob;
-        if (ob > 0) res = o * ig_log10(e) - e - lgf;
+        if (ob > 0) res = o * ig_log10(e, T) - e - lgf;
         else res = -e;
     }
     return res + (double)ex_z * IG_LOG_E_F;

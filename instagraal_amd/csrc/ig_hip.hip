@@ -204,11 +204,11 @@ __device__ __forceinline__ void expected_pair(const ig_params& p, bool cis, floa
 {
     if (cis) {
         if (s_tot == 0) {
-            ex = ig_rippe(s, p);
-            ex_z = (s_z < p.d_max) ? ig_rippe(s_z, p) : p.v_inter;
+            ex = ig_rippe(s, p, ig_tab());
+            ex_z = (s_z < p.d_max) ? ig_rippe(s_z, p, ig_tab()) : p.v_inter;
         } else {
-            ex = ig_rippe_circ(s, s_tot, p);
-            ex_z = (s_z < p.d_max) ? ig_rippe_circ(s_z, s_tot_z, p) : p.v_inter;
+            ex = ig_rippe_circ(s, s_tot, p, ig_tab());
+            ex_z = (s_z < p.d_max) ? ig_rippe_circ(s_z, s_tot_z, p, ig_tab()) : p.v_inter;
         }
     } else {
         ex = p.v_inter;
@@ -216,12 +216,12 @@ __device__ __forceinline__ void expected_pair(const ig_params& p, bool cis, floa
     }
 }
 
+__device__ __noinline__ double lgfact_big(int ob);
 __device__ __forceinline__ double lgfact_dev(int ob, const double* __restrict__ lgf_tab)
 {
     if (ob <= 0) return 0.0;
     if (ob < LGF_TAB) return lgf_tab[ob];
-    double o = (double)ob;
-    return (o * ig_log10(o) - o) + 0.5 * ig_log10(o * 2.0 * 3.14159265358979323846);
+    return lgfact_big(ob);
 }
 
 /* quantised likelihood term of one contact under one coordinate column */
@@ -234,15 +234,35 @@ struct PzTab {
     int n;
 };
 
+/* rare paths, kept out of line so that the hot loop stays small (I-cache) */
+__device__ __noinline__ float pz_direct(const ig_params p, float mean_kb, int d)
+{
+    const float s_z = (float)d * mean_kb;
+    return (s_z < p.d_max) ? ig_rippe(s_z, p, ig_tab()) : p.v_inter;
+}
+__device__ __noinline__ void expected_circ(const ig_params p, float mean_kb, float s, float s_tot, int d, int len_j, float* ex,
+                                           float* ex_z)
+{
+    const float s_z = (float)d * mean_kb;
+    *ex = ig_rippe_circ(s, s_tot, p, ig_tab());
+    *ex_z = (s_z < p.d_max) ? ig_rippe_circ(s_z, (float)len_j * mean_kb, p, ig_tab()) : p.v_inter;
+}
+__device__ __noinline__ double lgfact_big(int ob)
+{
+    const double* T = ig_tab();
+    double o = (double)ob;
+    return (o * ig_log10(o, T) - o) + 0.5 * ig_log10(o * 2.0 * 3.14159265358979323846, T);
+}
+
 __device__ __forceinline__ float pz_lookup(const PzTab& t, const ig_params& p, float mean_kb, int d)
 {
     if (d < t.n) return t.v[d];
-    const float s_z = (float)d * mean_kb;
-    return (s_z < p.d_max) ? ig_rippe(s_z, p) : p.v_inter;
+    return pz_direct(p, mean_kb, d);
 }
 
+/* T: the log2/exp2 table of ig_detmath.h (a kernel passes its LDS copy, everything else ig_tab()) */
 __device__ __forceinline__ long long eval_q(const ig_params& p, float mean_kb, uint2 a, uint2 b, const ColMeta* __restrict__ cm,
-                                            int ob, double lgf, const PzTab& pz)
+                                            int ob, double lgf, const PzTab& pz, const double* T)
 {
     const float di = __uint_as_float(a.x), dj = __uint_as_float(b.x);
     const int pi = (int)(a.y & 0x0fffffffu), pj = (int)(b.y & 0x0fffffffu);
@@ -253,18 +273,16 @@ __device__ __forceinline__ long long eval_q(const ig_params& p, float mean_kb, u
         const float s_tot = cm[ci].stot;
         const int d = pi > pj ? pi - pj : pj - pi;
         if (s_tot == 0) {
-            ex = ig_rippe(s, p);
+            ex = ig_rippe(s, p, T);
             ex_z = pz_lookup(pz, p, mean_kb, d);
         } else {
-            const float s_z = (float)d * mean_kb;
-            ex = ig_rippe_circ(s, s_tot, p);
-            ex_z = (s_z < p.d_max) ? ig_rippe_circ(s_z, (float)cm[cj].len * mean_kb, p) : p.v_inter;
+            expected_circ(p, mean_kb, s, s_tot, d, cm[cj].len, &ex, &ex_z);
         }
     } else {
         ex = p.v_inter;
         ex_z = p.v_inter;
     }
-    return ig_quantize(ig_pixel_term(ex, ex_z, ob, lgf));
+    return ig_quantize(ig_pixel_term(ex, ex_z, ob, lgf, T));
 }
 
 __global__ void k_build_pz(const Glob* g, float* pz, int n)
@@ -273,7 +291,7 @@ __global__ void k_build_pz(const Glob* g, float* pz, int n)
     if (d >= n) return;
     const ig_params p = g->par[0];
     const float s_z = (float)d * g->mean_kb;
-    pz[d] = (s_z < p.d_max) ? ig_rippe(s_z, p) : p.v_inter;
+    pz[d] = (s_z < p.d_max) ? ig_rippe(s_z, p, ig_tab()) : p.v_inter;
 }
 
 /* one sub-fragment's zero-pixel term: KA:3882-3899 */
@@ -284,8 +302,8 @@ __device__ __forceinline__ long long zero_q(const ig_params& p, int pos, int len
     const float s_tot_z = (float)len_cont * mean_kb;
     double ve;
     if (s < p.d_max) {
-        if (s_tot == 0) ve = (double)((pz && pos < pz_n) ? pz[pos] : ig_rippe(s, p));
-        else ve = (double)ig_rippe_circ(s, s_tot_z, p);
+        if (s_tot == 0) ve = (double)((pz && pos < pz_n) ? pz[pos] : ig_rippe(s, p, ig_tab()));
+        else ve = (double)ig_rippe_circ(s, s_tot_z, p, ig_tab());
     } else {
         ve = (double)p.v_inter;
     }
@@ -365,7 +383,7 @@ __device__ __forceinline__ bool slice_keep(const CandMeta& m, int c1, int c2, in
 __global__ void k_lgf_table(double* tab, const double* small15)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < LGF_TAB) tab[i] = ig_lgfact(i < 1 ? 1 : i, small15);
+    if (i < LGF_TAB) tab[i] = ig_lgfact(i < 1 ? 1 : i, small15, ig_tab());
     if (i == 0) tab[0] = 0.0;
 }
 
@@ -412,7 +430,7 @@ __global__ void k_full_nz(const long long* __restrict__ rowptr, const int2* __re
             const float s_z = (float)(dp < 0 ? -dp : dp) * mean;
             float ex, ex_z;
             expected_pair(p, ci == cpj.x, s, s_z, sti, (float)li * mean, ex, ex_z);
-            const long long q = ig_quantize(ig_pixel_term(ex, ex_z, v.y, lgfact_dev(v.y, lgf_tab)));
+            const long long q = ig_quantize(ig_pixel_term(ex, ex_z, v.y, lgfact_dev(v.y, lgf_tab), ig_tab()));
             hi += q >> 32;
             lo += (long long)(unsigned int)q;
         }
@@ -835,21 +853,22 @@ __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ row
     }
 }
 
-/* k_score_list: the hot kernel.  One workgroup = (entry block, coordinate column k, candidate c).  The
- * column (8 B per local sub-fragment), the P_z table, the log10(ob!) table and the per-contig constants are
- * staged in LDS; lanes stream the slice list four contacts at a time (coalesced 4-byte loads issued together),
- * read both endpoints' coordinates from LDS, evaluate the Rippe / Poisson term and add it as a 64-bit integer.
- * Wave shuffles, one LDS step, two atomics per workgroup. */
-#define SCORE_EB 32
+/* k_score_list: the hot kernel.  One workgroup = (entry block, coordinate column k, candidate c).
+ * Staged in LDS: the column (8 B per local sub-fragment), the P_z table, the log10(ob!) table, the log2/exp2
+ * tables of the arithmetic contract and the per-contig constants.  Lanes stream the slice list (coalesced
+ * 4-byte loads, SCORE_BATCH contacts in flight), read both endpoints' coordinates from LDS, evaluate the
+ * Rippe / Poisson term and add it as a 64-bit integer.  Wave shuffles, one LDS step, two atomics per workgroup. */
+#define SCORE_EB 16
 #define SCORE_BATCH 4
 #define LDS_PZ 1024
 #define LDS_LGF 256
 __global__ void __launch_bounds__(SCORE_THREADS)
-    k_score_list(const Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz)
+    k_score_list(const Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int ablate)
 {
     __shared__ uint2 lcol[LDS_COL_CAP];
     __shared__ float pz_s[LDS_PZ];
     __shared__ double lgf_s[LDS_LGF];
+    __shared__ double mt_s[IG_TAB_SIZE];
     __shared__ ColMeta cm_s[NCODE];
     __shared__ long long red[2][SCORE_THREADS / 64];
     const int c = blockIdx.z;
@@ -868,9 +887,12 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     const int pzn = min(pz.n, LDS_PZ);
     for (int i = threadIdx.x; i < pzn; i += SCORE_THREADS) pz_s[i] = pz.v[i];
     for (int i = threadIdx.x; i < LDS_LGF; i += SCORE_THREADS) lgf_s[i] = lgf_tab[i];
+    {
+        const double* T0 = ig_tab();
+        for (int i = threadIdx.x; i < IG_TAB_SIZE; i += SCORE_THREADS) mt_s[i] = T0[i];
+    }
     if (threadIdx.x < NCODE) cm_s[threadIdx.x] = mb.cmeta[(size_t)(c * NSLOT + k) * NCODE + threadIdx.x];
     __syncthreads();
-    const PzTab pzl = {pz_s, pzn};
     const int* sli = mb.sl_li + (size_t)c * mb.Zcap;
     const int* slj = mb.sl_lj + (size_t)c * mb.Zcap;
     const int* slo = mb.sl_ob + (size_t)c * mb.Zcap;
@@ -886,14 +908,40 @@ __global__ void __launch_bounds__(SCORE_THREADS)
             lj[u] = ok ? slj[e] : 0;
             ob[u] = ok ? slo[e] : 0;
         }
-#pragma unroll
+#pragma unroll 1
         for (int u = 0; u < SCORE_BATCH; u++) {
-            if (li[u] < 0) continue;
-            const uint2 ai = staged ? lcol[li[u]] : gcol[li[u]];
-            const uint2 bj = staged ? lcol[lj[u]] : gcol[lj[u]];
-            const double lgf = (ob[u] > 0 && ob[u] < LDS_LGF) ? lgf_s[ob[u]] : lgfact_dev(ob[u], lgf_tab);
-            const int d_ = abs((int)(ai.y & 0x0fffffffu) - (int)(bj.y & 0x0fffffffu));
-            const long long q = eval_q(p, mean, ai, bj, cm_s, ob[u], lgf, (d_ < pzn) ? pzl : pz);
+            const int l_i = li[u], l_j = lj[u], o_b = ob[u];
+            if (l_i < 0) break;
+            uint2 ai, bj;
+            if (staged) {
+                ai = lcol[l_i];
+                bj = lcol[l_j];
+            } else {
+                ai = gcol[l_i];
+                bj = gcol[l_j];
+            }
+            long long q;
+            if (ablate & 1) {
+                q = (long long)(ai.x ^ bj.y) + o_b;
+            } else {
+                const double lgf = (o_b > 0 && o_b < LDS_LGF) ? lgf_s[o_b] : lgfact_dev(o_b, lgf_tab);
+                /* the hot case in line: two sub-fragments of one LINEAR contig */
+                const int ci = (int)(ai.y >> 28), cj = (int)(bj.y >> 28);
+                const int pi = (int)(ai.y & 0x0fffffffu), pj = (int)(bj.y & 0x0fffffffu);
+                const int d = pi > pj ? pi - pj : pj - pi;
+                float ex, ex_z;
+                if (ci != cj) {
+                    ex = p.v_inter;
+                    ex_z = p.v_inter;
+                } else if (cm_s[ci].stot == 0) {
+                    ex = ig_rippe(fabsf(__uint_as_float(ai.x) - __uint_as_float(bj.x)), p, mt_s);
+                    ex_z = (d < pzn) ? pz_s[d] : pz_direct(p, mean, d);
+                } else {
+                    expected_circ(p, mean, fabsf(__uint_as_float(ai.x) - __uint_as_float(bj.x)), cm_s[ci].stot, d, cm_s[cj].len, &ex,
+                                  &ex_z);
+                }
+                q = ig_quantize(ig_pixel_term(ex, ex_z, o_b, lgf, mt_s));
+            }
             hi += q >> 32;
             lo += (long long)(unsigned int)q;
         }
@@ -959,7 +1007,7 @@ __global__ void __launch_bounds__(SCORE_THREADS)
             const int li = qli[lane], lj = qlj[lane], ob = qob[lane];
             const uint2 ai = staged ? lcol[li] : gcol[li];
             const uint2 bj = staged ? lcol[lj] : gcol[lj];
-            const long long q = eval_q(p, mean, ai, bj, cm, ob, lgfact_dev(ob, lgf_tab), pz);
+            const long long q = eval_q(p, mean, ai, bj, cm, ob, lgfact_dev(ob, lgf_tab), pz, ig_tab());
             hi += q >> 32;
             lo += (long long)(unsigned int)q;
         }
@@ -1164,7 +1212,7 @@ __global__ void __launch_bounds__(256) k_finalize(const long long* __restrict__ 
             const ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
             long long hi = 0, lo = 0;
             if (lane < n_tail) {
-                const long long q = eval_q(p, mean, col[t_li[lane]], col[t_lj[lane]], cm, t_ob[lane], lgfact_dev(t_ob[lane], lgf_tab), pz);
+                const long long q = eval_q(p, mean, col[t_li[lane]], col[t_lj[lane]], cm, t_ob[lane], lgfact_dev(t_ob[lane], lgf_tab), pz, ig_tab());
                 hi = q >> 32;
                 lo = (long long)(unsigned int)q;
             }
@@ -1367,9 +1415,9 @@ __global__ void k_debug_terms(const float* s, const float* stot, const int* ob, 
     long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const ig_params p = g->par[0];
-    ex[i] = ig_rippe(s[i], p);
-    exc[i] = ig_rippe_circ(s[i], stot[i], p);
-    term[i] = ig_pixel_term(ex[i], exc[i], ob[i], lgfact_dev(ob[i], lgf_tab));
+    ex[i] = ig_rippe(s[i], p, ig_tab());
+    exc[i] = ig_rippe_circ(s[i], stot[i], p, ig_tab());
+    term[i] = ig_pixel_term(ex[i], exc[i], ob[i], lgfact_dev(ob[i], lgf_tab), ig_tab());
     q[i] = ig_quantize(term[i]);
 }
 
@@ -1483,9 +1531,9 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
         if (k < 10) {
             for (int q = 1; q <= k; q++) r = r * q;
         } else {
-            r = ig_powf((float)k, (float)k) * ig_expf(-(float)k) * __builtin_sqrtf((float)(2 * 3.14159265358979323846 * (float)k));
+            r = ig_powf((float)k, (float)k, ig_tab()) * ig_expf(-(float)k, ig_tab()) * __builtin_sqrtf((float)(2 * 3.14159265358979323846 * (float)k));
         }
-        small[k] = ig_log10((double)r);
+        small[k] = ig_log10((double)r, ig_tab());
     }
     Glob hg;
     memset(&hg, 0, sizeof hg);
@@ -2013,8 +2061,10 @@ static void enqueue_move(ig_ctx* c, int move, int max_c, int force_slot, int pha
             TimedLaunch t(c, T_SCORE);
             if (0) hipLaunchKernelGGL(k_slice, dim3(SLICE_RB, max_c), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb,
                                c->rank, c->world);
-            hipLaunchKernelGGL(k_score_list, dim3(SCORE_EB, NSLOT, max_c), dim3(SCORE_THREADS), 0, c->stream, c->glob, c->mb,
-                               c->lgf_tab, PzTab{c->pz_tab, c->pz_n});
+            static int s_eb = getenv("IG_SCORE_EB") ? atoi(getenv("IG_SCORE_EB")) : SCORE_EB;
+            static int s_abl = getenv("IG_ABLATE") ? atoi(getenv("IG_ABLATE")) : 0;
+            hipLaunchKernelGGL(k_score_list, dim3(s_eb, NSLOT, max_c), dim3(SCORE_THREADS), 0, c->stream, c->glob, c->mb,
+                               c->lgf_tab, PzTab{c->pz_tab, c->pz_n}, s_abl);
         }
     }
     if (phase == 1 || phase == 2) {

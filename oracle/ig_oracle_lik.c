@@ -64,13 +64,13 @@ static float factorial_det(float n)
     if (n < 10) {
         for (int c = 1; c <= n; c++) result = result * c;
     } else {
-        result = ig_powf(n, n) * ig_expf(-n) * sqrtf((float)(2 * M_PI * n));
+        result = ig_powf(n, n, ig_tab()) * ig_expf(-n, ig_tab()) * sqrtf((float)(2 * M_PI * n));
     }
     return result;
 }
 void igo_lgf_table(double* out15)
 {
-    for (int k = 0; k < 15; k++) out15[k] = ig_log10((double)factorial_det((float)k));
+    for (int k = 0; k < 15; k++) out15[k] = ig_log10((double)factorial_det((float)k), ig_tab());
 }
 static void lgf_init(void)
 {
@@ -117,10 +117,10 @@ static double pxl_libm(double ex, double ob)
     return res;
 }
 
-static inline float m_rippe(float s, const ig_params p) { return g_mode ? ig_rippe(s, p) : rippe_libm(s, p); }
+static inline float m_rippe(float s, const ig_params p) { return g_mode ? ig_rippe(s, p, ig_tab()) : rippe_libm(s, p); }
 static inline float m_rippe_circ(float s, float st, const ig_params p)
 {
-    return g_mode ? ig_rippe_circ(s, st, p) : rippe_circ_libm(s, st, p);
+    return g_mode ? ig_rippe_circ(s, st, p, ig_tab()) : rippe_circ_libm(s, st, p);
 }
 
 /* expected contacts of one (i,j) pair: KA:4430-4459 (same text at 4182-4206, 4327-4351) */
@@ -144,7 +144,7 @@ static inline void expected_pair(const ig_params p, int cis, float s, float s_z,
 /* KA:4462: pxl(ex, ob) + ex_z * 0.43429448190325182f */
 static inline double pixel_term(float ex, float ex_z, int ob)
 {
-    if (g_mode) return ig_pixel_term(ex, ex_z, ob, ob > 0 ? ig_lgfact(ob, g_lgf_det) : 0.0);
+    if (g_mode) return ig_pixel_term(ex, ex_z, ob, ob > 0 ? ig_lgfact(ob, g_lgf_det, ig_tab()) : 0.0, ig_tab());
     return pxl_libm((double)ex, (double)ob) + (double)ex_z * 0.43429448190325182f;
 }
 

@@ -12,13 +12,13 @@ __global__ void gpu_eval(const float* s, const float* stot, const int* ob, size_
 {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    o_pow[i] = ig_powf(s[i], p.slope);
-    o_exp[i] = ig_expf(-s[i] * 0.01f);
-    o_log10[i] = ig_log10((double)s[i]);
-    o_r[i] = ig_rippe(s[i], p);
-    o_rc[i] = ig_rippe_circ(s[i], stot[i], p);
-    double lg = ig_lgfact(ob[i] > 0 ? ob[i] : 1, lgf);
-    o_term[i] = ig_pixel_term(o_r[i], o_rc[i], ob[i], lg);
+    o_pow[i] = ig_powf(s[i], p.slope, ig_tab());
+    o_exp[i] = ig_expf(-s[i] * 0.01f, ig_tab());
+    o_log10[i] = ig_log10((double)s[i], ig_tab());
+    o_r[i] = ig_rippe(s[i], p, ig_tab());
+    o_rc[i] = ig_rippe_circ(s[i], stot[i], p, ig_tab());
+    double lg = ig_lgfact(ob[i] > 0 ? ob[i] : 1, lgf, ig_tab());
+    o_term[i] = ig_pixel_term(o_r[i], o_rc[i], ob[i], lg, ig_tab());
     o_q[i] = ig_quantize(o_term[i]);
 }
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(2);} }while(0)
