@@ -84,7 +84,7 @@ class SynthProblem:
             np_sub_frags_accu=self.np_sub_frags_accu,
             np_sub_frags_2_frags=self.np_sub_frags_2_frags,
             mean_squared_frags_per_bin=np.float32(1.0),
-            norm_vect_accu=np.asmatrix(np.full(N, 3)),
+            norm_vect_accu=np.full((1, N), 3),
             sub_candidates_dup=[],
             sub_candidates_output_data=[],
             S_o_A_sub_frags=self.S_o_A_sub_frags,

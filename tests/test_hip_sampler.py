@@ -1,0 +1,176 @@
+"""GPU tests of the drop-in host surface (instagraal_amd.sampler.sampler) against the oracle run live:
+larger problem, nuisance-parameter steps, batch == step-by-step, forced apply, error behaviour."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(cfg, mode=1):
+    from instagraal_amd import synth
+    from instagraal_amd.sampler import sampler as hip_sampler
+    from oracle import oracle_lib as ol
+    from oracle.sampler_oracle import OracleSampler
+
+    ol.build()
+    prob = synth.make_problem(*synth.CONFIGS[cfg])
+    kw = prob.sampler_kwargs()
+    s = hip_sampler(**kw, device_id=0)
+    s.set_param_simu(prob.params)
+    s.bins = np.arange(1.0, 60.0, 1.0)
+    s.eval_likelihood_init()
+    o = OracleSampler(**kw, mode=ol.MODE_DET)
+    o.set_param_simu(prob.params)
+    o.bins = np.arange(1.0, 60.0, 1.0)
+    o.eval_likelihood_init()
+    return prob, s, o
+
+
+def test_small_problem_live_oracle():
+    """N=1000 / Z=150k, 40 moves with the reference's own candidate draw: scores bit-exact, same
+    winner, same return tuple; final genome identical field by field."""
+    prob, s, o = make_pair("small")
+    assert float(s.curr_likelihood_on_nz[0]) == float(o.gpu_curr_likelihood_nz[0])
+    np.random.seed(3)
+    frags = np.arange(prob.n_frags)
+    np.random.shuffle(frags)
+    for f in frags[:40]:
+        cands = s.return_neighbours(int(f), 5)
+        a = s.step_sampler(int(f), 5, candidates=cands)
+        b = o.step_sampler(int(f), 5, o.dt, candidates=cands)
+        assert s.candidates == o.candidates
+        assert np.array_equal(s.all_scores, o.all_scores)
+        assert (a[0], a[1], a[2], a[3], float(a[4]), int(a[5])) == (b[0], b[1], b[2], b[3], float(b[4]), int(b[5]))
+    assert np.array_equal(s.gpu_vect_frags.copy_from_gpu().soa17(), o.gpu_vect_frags.soa17())
+
+
+def test_nuisance_trajectory_matches_golden():
+    """step_sampler + step_nuisance_parameters (CL:2961-3051) against the reference-driven golden: RNG
+    stream, fsolve'd d_max, the full-Z likelihood under test parameters on the PRE-move tables (Q12),
+    accept/reject, and the parameter-dependent maintained sums after an accepted step."""
+    from instagraal_amd import synth
+    from instagraal_amd.sampler import sampler as hip_sampler
+
+    g = np.load(os.path.join(GOLDEN, "tiny_nuis_mode1.npz"))
+    prob = synth.make_problem(*synth.CONFIGS[str(g["config"])])
+    np.random.seed(int(g["seed"]))
+    s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
+    s.set_param_simu(prob.params)
+    s.bins = np.arange(1.0, 60.0, 1.0)
+    s.eval_likelihood_init()
+    frags = np.arange(0, s.n_new_frags)
+    np.random.shuffle(frags)
+    nuis_from = int(g["nuis_from"])
+    k = 0
+    for t, f in enumerate(g["frag"]):
+        r = s.step_sampler(int(f), 5, s.dt)
+        c = list(s.candidates) + [-1] * (5 - len(s.candidates))
+        assert c == list(g["cands"][t]), t
+        exp = g["scores"][t][: len(s.candidates) * 24]
+        assert np.array_equal(s.all_scores, exp), t
+        assert [float(r[0]), float(r[1]), float(r[2]), float(r[3]), float(r[4]), float(r[5])] == list(g["ret"][t]), t
+        if t >= nuis_from:
+            q = s.step_nuisance_parameters(s.dt, t, len(g["frag"]))
+            got = [float(q[0]), float(q[1]), float(q[2]), float(q[3]), float(q[4]), float(np.ravel(q[5])[0]), float(q[6])]
+            assert got == list(g["nuis"][k]), (t, got, list(g["nuis"][k]))
+            k += 1
+    assert np.array_equal(np.random.get_state()[1][:8], g["rng_after"])
+    assert np.array_equal(s.gpu_vect_frags.copy_from_gpu().soa17(), g["states"][-1])
+
+
+def test_batch_equals_step_by_step():
+    from instagraal_amd import synth
+    from instagraal_amd.sampler import sampler as hip_sampler
+
+    prob = synth.make_problem(*synth.CONFIGS["tiny"])
+    outs = []
+    for batch in (False, True):
+        np.random.seed(5)
+        s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
+        s.set_param_simu(prob.params)
+        frags = np.arange(prob.n_frags)
+        np.random.shuffle(frags)
+        frags = frags[:50]
+        if batch:
+            res = s.step_sampler_batch(frags, 5)
+            rows = [(float(r["o"]), float(r["dist"]), int(r["op_sampled"]), int(r["id_f_sampled"]), float(r["mean_len"]),
+                     int(r["n_contigs"])) for r in res]
+        else:
+            rows = []
+            for f in frags:
+                r = s.step_sampler(int(f), 5)
+                rows.append((float(r[0]), float(r[1]), int(r[2]), int(r[3]), float(r[4]), int(r[5])))
+        outs.append((rows, s.gpu_vect_frags.copy_from_gpu().soa17(), np.random.get_state()[1][:4].copy()))
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2])
+
+
+def test_forced_apply_matches_oracle_and_keeps_sums_exact():
+    """ig_apply == test_copy_struct (CL:2094-2151) for every mutation family; the maintained exact
+    likelihood equals a from-scratch recomputation after each."""
+    prob, s, o = make_pair("tiny")
+    rng = np.random.RandomState(11)
+    for op in (0, 1, 2, 5, 6, 9, 10, 12, 15, 19, 22, 23):
+        a, b = rng.choice(prob.n_frags, 2, replace=False)
+        max_id = o.modify_gl_cuda_buffer(int(a), o.dt)
+        o.test_copy_struct(int(a), int(b), op, max_id)
+        o.modify_gl_cuda_buffer(int(a), o.dt)
+        s.test_copy_struct(int(a), int(b), op)
+        assert np.array_equal(s.gpu_vect_frags.copy_from_gpu().soa17(), o.gpu_vect_frags.soa17()), op
+        sums, _ = s.ctx.debug_globals()
+        _, _, limbs = s.ctx.full_likelihood(0)
+        assert [int(v) for v in sums] == [int(v) for v in limbs], op
+
+
+def test_candidate_states_match_oracle():
+    """All 24 candidate genomes of a move (CL:1918-1923) against the oracle's collector structs:
+    every field of every fragment, contig ids up to relabelling."""
+    prob, s, o = make_pair("tiny")
+    rng = np.random.RandomState(2)
+
+    def canon(ids):
+        _, first = np.unique(ids, return_index=True)
+        order = np.argsort(first)
+        lut = {ids[first[i]]: r for r, i in enumerate(order)}
+        return np.array([lut[v] for v in ids])
+
+    for trial in range(6):
+        a = int(rng.randint(prob.n_frags))
+        cands = sorted(int(x) for x in rng.choice([x for x in range(prob.n_frags) if x != a], 3, replace=False))
+        s.ctx.score_move(a, cands)
+        o.fill_dist_single()
+        max_id = o.modify_gl_cuda_buffer(a, o.dt)
+        for ci, b in enumerate(cands):
+            o.extract_uniq_mutations(a, b, 1 if ci == 0 else 0)
+            uniq = [int(v) for v in o.gpu_list_uniq_mutations[: int(o.gpu_n_uniq[0])]]
+            o.perform_mutations(a, b, max_id)
+            for slot in uniq:
+                got = s.ctx.debug_candidate_state(ci, slot)
+                exp = o.collector_gpu_vect_frags[slot].soa17()
+                for k in range(17):
+                    if k == 2:
+                        assert np.array_equal(canon(got[k]), canon(exp[k])), (trial, b, slot, "id_c")
+                    else:
+                        assert np.array_equal(got[k], exp[k]), (trial, b, slot, k)
+
+
+def test_errors_are_loud():
+    from instagraal_amd import hip_lib, synth
+    from instagraal_amd.sampler import problem_to_context
+
+    prob = synth.make_problem(*synth.CONFIGS["tiny"])
+    ctx = problem_to_context(prob)
+    with pytest.raises(hip_lib.HipError):
+        ctx.step(0, [0, 5])  # candidate == focal fragment
+    with pytest.raises(hip_lib.HipError):
+        ctx.step(0, [prob.n_frags + 3])
+    with pytest.raises(hip_lib.HipError):
+        ctx.apply(1, 2, 24)
+    c2 = hip_lib.Context(0)
+    with pytest.raises(hip_lib.HipError):
+        c2.step(0, [1])  # nothing uploaded
