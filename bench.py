@@ -151,6 +151,17 @@ def main():
         bytes_min = float(res["bytes_min"].mean())
         n_evals = float(res["n_evals"].mean())
         achieved = bytes_min / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+        # WRITE_SIZE, separate passes; profiles/*_pmc_traffic.json): a committed measurement of THIS workload, or null
+        traffic = None
+        try:
+            import glob
+
+            pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_pmc_traffic.json" % a.config)))
+            if pmc and world == 1:
+                traffic = float(json.load(open(pmc[-1]))["k_score_list"]["traffic_bytes_per_launch"])
+        except Exception:
+            traffic = None
         out = {
             "metric": "MCMC moves/s (accepted+rejected) at fixed n_frags x nnz",
             "value": a.steps / elapsed,
@@ -169,10 +180,12 @@ def main():
                 "candidates_scored_per_s": float(res["n_candidates"].sum()) * 24 / elapsed,
                 "term_evals_per_move": n_evals, "maintained_likelihood_exact": exact_ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "kernel": "k_score", "avg_launch_ms": score_ms, "launches": int(n_launch),
+                         "traffic": traffic, "kernel": "k_score_list", "avg_launch_ms": score_ms, "launches": int(n_launch),
                          "algorithmic_bytes_per_launch": bytes_min,
+                         "term_evals_per_launch": n_evals,
+                         "f64_fma_tflops": (n_evals * 33 * 2 / (score_ms * 1e-3) / 1e12) if score_ms > 0 else 0.0,
                          "note": "B_min = sum_c[12 S_c + 20 m_c U + 8 U] + 68 n_touched (SURVEY 8(d)); the kernel is bound by "
-                                 "f64 transcendental math on an L2-resident working set, not by HBM: see DESIGN.md"},
+                                 "exact f64 term arithmetic on an L2-resident working set, not by HBM: DESIGN.md section 4"},
         }
         if not a.no_cpu_baseline:
             try:
