@@ -47,6 +47,20 @@ IG_HD uint32_t ig_f2u(float x) { uint32_t u; __builtin_memcpy(&u, &x, 4); return
 IG_HD float ig_u2f(uint32_t u) { float x; __builtin_memcpy(&x, &u, 4); return x; }
 
 IG_HD double ig_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+/* fma whose addend is a compile-time constant (polynomial coefficients).  On gfx950 the three-operand form with
+ * the constant in a scalar register pair is spelled out: left alone, the compiler keeps every coefficient in a
+ * vector register pair and copies it before each two-operand v_fmac (twice the instructions, +40 VGPRs).
+ * Same single-rounding fma, same bits. */
+#if defined(__HIP_DEVICE_COMPILE__)
+IG_HD double ig_fma_k(double a, double b, double k)
+{
+    double r;
+    __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
+#else
+IG_HD double ig_fma_k(double a, double b, double k) { return __builtin_fma(a, b, k); }
+#endif
 
 #define IG_INF (ig_u2d(0x7ff0000000000000ULL))
 #define IG_NAN (ig_u2d(0x7ff8000000000000ULL))
@@ -66,72 +80,60 @@ IG_HD float ig_fmaxf(float a, float b)
     return a > b ? a : b;
 }
 
-/* One table for both functions: [0,64) reciprocals r_j, [64,128) -log2(r_j), [128,161) 2^(j/32), j=-16..16.
+/* One table for both functions: [0,256) pairs (r_j, -log2 r_j) of the 128 log intervals, [256,384) 2^(j/128).
  * Every function below takes the table pointer explicitly so that a GPU kernel can pass its LDS copy
  * (ds_read instead of a global gather); ig_tab() is the constant-memory / static copy. */
-#define IG_TAB_SIZE 161
-#define IG_TAB_VAL 64
-#define IG_TAB_EXP 128
+#define IG_TAB_SIZE 384
+#define IG_TAB_EXP 256
 IG_HD const double* ig_tab(void)
 {
     static const double tab[IG_TAB_SIZE] = IG_TAB_INIT;
     return tab;
 }
 
-/* ---- log2 of a positive, finite, normal double ------------------------
- * Table-driven (Tang): x = 2^e * m; the top 6 mantissa bits pick an interval with centre c_j and a
- * tabulated, rounded reciprocal r_j ~ 1/c_j; u = m*r_j - 1 is formed with one fma (|u| < 2^-6.9), and
- * log2(m) = -log2(r_j) + log2(1+u) with a degree-8 alternating series (truncation < 1e-19).
- * Intervals above sqrt(2)-ish are folded to m/2 so that x ~ 1 is evaluated without cancellation.
- * No division: the reciprocal comes from the table, identical bits on every target. */
+/* log2 of a positive, finite, NORMAL double.  m in [1,2) falls in interval j (7 bits); with the tabulated
+ * reciprocal r_j of the interval centre u = m r_j - 1 is tiny (|u| <= 2^-8, the fma makes it exact up to
+ * its own rounding) and log2(x) = e - log2(r_j) + log2(1 + u), a degree-5 polynomial.  Intervals above
+ * sqrt(2) use m/2 (folded into r_j) and e + 1 so that log2 near 1 from below does not cancel. */
 IG_HD double ig_log2_pos(double x, const double* T)
 {
     const uint64_t b = ig_d2u(x);
-    int e = (int)((b >> 52) & 0x7ffu) - 1023;
-    const int j = (int)((b >> 46) & 63u);
-    double m = ig_u2d((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
-    if (j >= IG_LOG_SPLIT) {
-        m = m * 0.5;
-        e += 1;
-    }
-    const double u = ig_fma(m, T[j], -1.0);
-    double p = IG_LOG_C8;
-    p = ig_fma(p, u, IG_LOG_C7);
-    p = ig_fma(p, u, IG_LOG_C6);
-    p = ig_fma(p, u, IG_LOG_C5);
-    p = ig_fma(p, u, IG_LOG_C4);
-    p = ig_fma(p, u, IG_LOG_C3);
-    p = ig_fma(p, u, IG_LOG_C2);
-    p = ig_fma(p, u, IG_LOG_C1);
-    return ig_fma(p, u, T[IG_TAB_VAL + j]) + (double)e;
+    const int j = (int)((b >> 45) & 127u);
+    const int e = (int)((b >> 52) & 0x7ffu) - 1023 + (j >= IG_LOG_SPLIT);
+    const double m = ig_u2d((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+    const double u = ig_fma(m, T[2 * j], -1.0);
+    double p = IG_LOG_C5;
+    p = ig_fma_k(p, u, IG_LOG_C4);
+    p = ig_fma_k(p, u, IG_LOG_C3);
+    p = ig_fma_k(p, u, IG_LOG_C2);
+    p = ig_fma_k(p, u, IG_LOG_C1);
+    return ig_fma(p, u, T[2 * j + 1]) + (double)e;
 }
 
-/* ---- 2^y -----------------------------------------------------------------
- * y = k + j/32 + t with k = rint(y), j = rint(32 (y-k)) in [-16,16], |t| <= 1/64 (all exact);
- * 2^y = 2^k * T[j] * (1 + sum_{n=1..7} (t ln2)^n / n!)   (truncation < 1e-20). */
+/* 2^y for |y| <= 1000 (finite): y = (128 k + i)/128 + t with |t| <= 2^-8 (all steps exact),
+ * 2^y = 2^k * 2^(i/128) * (1 + P(t)), P of degree 4. */
+IG_HD double ig_exp2_core(double y, const double* T)
+{
+    const double jd = __builtin_rint(y * 128.0); /* round-half-even of an exact product */
+    const double t = ig_fma(jd, -0.0078125, y);  /* exact */
+    const int ji = (int)jd;
+    double p = IG_EXP_C4;
+    p = ig_fma_k(p, t, IG_EXP_C3);
+    p = ig_fma_k(p, t, IG_EXP_C2);
+    p = ig_fma_k(p, t, IG_EXP_C1);
+    p = p * t;
+    const double tj = T[IG_TAB_EXP + (ji & 127)];
+    const double v = ig_fma(tj, p, tj);
+    return v * ig_u2d((uint64_t)((ji >> 7) + 1023) << 52); /* exact scaling, never sub-normal for |y| <= 1000 */
+}
+
 IG_HD double ig_exp2(double y, const double* T)
 {
     if (ig_isnan(y)) return IG_NAN; /* canonical NaN: payloads differ between targets */
     if (y > 1000.0) return IG_INF;
     if (y < -1000.0) return 0.0;
-    const double k = __builtin_rint(y); /* round-half-even, exact */
-    const double r = y - k;             /* exact, |r| <= 0.5 */
-    const double jd = __builtin_rint(r * 32.0);
-    const double t = r - jd * 0.03125;  /* exact */
-    double p = IG_EXP_C7;
-    p = ig_fma(p, t, IG_EXP_C6);
-    p = ig_fma(p, t, IG_EXP_C5);
-    p = ig_fma(p, t, IG_EXP_C4);
-    p = ig_fma(p, t, IG_EXP_C3);
-    p = ig_fma(p, t, IG_EXP_C2);
-    p = ig_fma(p, t, IG_EXP_C1);
-    const double tj = T[IG_TAB_EXP + (int)jd + 16];
-    const double v = ig_fma(tj * p, t, tj);
-    const int ki = (int)k;
-    return v * ig_u2d((uint64_t)(ki + 1023) << 52);
+    return ig_exp2_core(y, T);
 }
-
-/* ---- the three libm calls of the reference kernels --------------------- */
 
 /* powf(x, y) as used by KA:159, 217 (x = distance or n, y = slope / 2.0f / -3.0f / n). */
 IG_HD float ig_powf(float x, float y, const double* T)

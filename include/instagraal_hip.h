@@ -88,10 +88,15 @@ int ig_score_move(ig_ctx* ctx, int32_t frag_a, const int32_t* cands, int32_t C, 
 int ig_apply(ig_ctx* ctx, int32_t frag_a, int32_t frag_b, int32_t op);
 /* score + device argmax (CL:1435-1446) + apply + bookkeeping, one small D2H */
 int ig_step(ig_ctx* ctx, int32_t frag_a, const int32_t* cands, int32_t C, ig_move_result* out, double* scores_or_null);
-/* n_moves consecutive moves enqueued back to back without host round trips.
- * cands: n_moves x max_c, -1 padded.  results: n_moves entries. */
+/* n_moves consecutive moves (the reference's inner loop over step_sampler calls, main.py full_em / CL:1401-1465).
+ * cands: n_moves x max_c, -1 padded.  results: n_moves entries.
+ * Moves are scored W at a time against the same state ("speculative batches": candidate draws do not depend on the
+ * genome) and committed in order on the device; a move whose contigs an earlier move of its batch modified is
+ * re-scored in the next batch, so the results are identical to n_moves calls of ig_step for every W. */
 int ig_step_batch(ig_ctx* ctx, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c,
                   ig_move_result* results);
+int ig_set_batch_width(int w);                        /* W in 1..32 (default 16, env IG_BATCH_W); 1 = no speculation */
+int ig_batch_stats(ig_ctx* ctx, int64_t out3[3]);     /* {batches launched, moves committed in-batch, one-move tails} */
 
 /* ---- bookkeeping -------------------------------------------------------- */
 int ig_renumber_contigs(ig_ctx* ctx, int32_t* n_contigs, float* mean_len, int32_t* max_id); /* CL:2715-2881 */

@@ -97,7 +97,6 @@ struct Glob {
     int slice_nb;
     int list_bounds[6];
     long long nz_hi, nz_lo, z_hi, z_lo, n_intra;
-    long long d_hi, d_lo; /* k_delta accumulator */
     long long credit2, credit2_acc;
     double n_tot_pxl;
     double lgf[15];
@@ -105,30 +104,43 @@ struct Glob {
     int n_prev_touched;
     int valid_insert[12];
     int error;
-    /* move in flight */
-    int A, C, force_slot;
+    int stamp_ctr;
+};
+
+/* one move slot of a batch (W = 1: the move in flight) */
+#define IG_MAX_BATCH 32
+struct MoveCtl {
+    int A, C, force_slot, fresh; /* fresh: first of the NFRESH contig ids this move may create */
     int ch_c, ch_k, ch_slot, ch_windowed;
+    int superset0; /* candidate 0 was scored with every insert slot (its stale flags were not known yet) */
+    int overflow;  /* the slice pool could not hold this slot: it is re-run at the head of the next batch */
+    int n_dirty, pad;
     double ch_score;
     long long n_slice_tot, n_eval_tot, bytes_min;
+    long long d_hi, d_lo; /* k_delta accumulator */
 };
 
 struct MoveBuf {
-    int* Lloc;      /* [capC][N] global ids of local fragments */
-    int* lbloc;     /* [capC][N] */
-    int* slloc;     /* [capC][N] */
-    int* subs;      /* [capC][M] global sub-frag id of local sub index */
-    int* rowcnt;    /* [capC][M] sliced contacts per local row */
-    int* sl_li;     /* [capC][Z] the slice of candidate c: local row index, */
+    int* Lloc;      /* [capW*capC][N] global ids of local fragments */
+    int* lbloc;     /* [..][N] */
+    int* slloc;     /* [..][N] */
+    int* subs;      /* [..][M] global sub-frag id of local sub index */
+    int* rowcnt;    /* [..][M] sliced contacts per local row */
+    int* sl_li;     /* slice pool: candidate cw's list starts at slice_offset(w, c): local row index, */
     int* sl_lj;     /*           local column index, */
     int* sl_ob;     /*           observed count (order = arrival, sums are order-free) */
-    long long Zcap;
-    uint2* coords;  /* [capC][NSLOT][M] column k: {dist bits, pos | code<<28} per local sub index */
-    int* loc;       /* [capC][NSLOT][NDYN][N] candidate genomes on the local window */
-    CandMeta* meta; /* [capC] */
-    ColMeta* cmeta; /* [capC][NSLOT][NCODE] */
-    long long* part;/* partial sums, see P_* offsets */
-    double* scores; /* [capC][24] */
-    int N, M, capC;
+    long long* slbound; /* [..] upper bound of the list length = contacts in the rows of the touched contigs */
+    long long* sloff;   /* [..] start of the list in the pool, -1 = does not fit (k_offsets) */
+    long long pool_cap;
+    uint2* coords;  /* [..][NSLOT][M] column k: {dist bits, pos | code<<28} per local sub index */
+    int* loc;       /* [..][NSLOT][NDYN][N] candidate genomes on the local window */
+    CandMeta* meta; /* [..] */
+    ColMeta* cmeta; /* [..][NSLOT][NCODE] */
+    long long* part;/* [..][P_STRIDE] partial sums (all-reduced across ranks when sharded) */
+    long long* qpart;/* [..][Q_STRIDE] sums every rank computes redundantly */
+    double* scores; /* [..][24] */
+    MoveCtl* ctl;   /* [capW] */
+    int N, M, capC, capW;
 };
 /* layout of MoveBuf.part per candidate (int64 units) */
 #define P_NZ 0                 /* [NSLOT][2] slice sums per column k (k=0: current = "extract") */
@@ -138,7 +150,8 @@ struct MoveBuf {
 #define Q_Z 0                  /* [NSLOT][2] zero-pixel sums on the local window, per column k */
 #define Q_NI (NSLOT * 2)       /* [NSLOT] intra pair counts */
 #define Q_NZFULL (NSLOT * 3)   /* [NSLOT][2] slice sums before the tail correction */
-#define Q_STRIDE (NSLOT * 5)
+#define Q_TAIL (NSLOT * 5)     /* [NSLOT][2] sum of the last S_c mod 64 sliced contacts' terms (quirk Q5) */
+#define Q_STRIDE (NSLOT * 7)
 
 struct ig_ctx {
     int device;
@@ -160,7 +173,8 @@ struct ig_ctx {
     double* lgf_tab;
     Glob* glob;
     MoveBuf mb;
-    long long* q_part; /* [capC][Q_STRIDE] */
+    int* stamp;     /* [N] claim stamps of the incremental genome distance */
+    int* batch_out; /* [2] committed moves, pending slot */
     ig_move_result* d_results;
     int results_cap;
     int* d_frags;
@@ -178,6 +192,8 @@ struct ig_ctx {
         double total_ms;
         long long n;
     } timers[10];
+    long long n_batches, n_batch_committed, n_batch_pending;
+    int large_seen;
     bool have_contacts, have_sub, have_state, have_init, have_params;
 };
 
@@ -535,14 +551,43 @@ __global__ void k_post(State st, const int* __restrict__ ip, const int* __restri
     if ((threadIdx.x & 63) == 0 && c2) atomic_add_ll(&g->credit2_acc, (long long)c2);
 }
 
-/* ------------------------------------------------------------------ the move */
+/* ------------------------------------------------------------------ the move(s)
+ *
+ * Candidate draws do not depend on the genome (CL:3103-3141 reads fixed distributions), so W consecutive
+ * moves can be SCORED against the same base state in single launches (slot dimension w below) and then
+ * COMMITTED in order by one workgroup (k_commit_batch) that stops at the first move whose contigs were
+ * modified by an earlier move of the batch.  W = 1 is the plain one-move-at-a-time path.
+ * Buffers of candidate c of slot w live at index cw = w * capC + c. */
+
+#define CW(w, c) ((w) * mb.capC + (c))
+
+/* uniq-mutation list of extract_uniq_mutations (KA:4492-4553); vf == nullptr -> every insert slot (superset) */
+__device__ inline int build_uniq(int* u, bool first, int LA, int LB, const int* vf)
+{
+    int n = 0;
+    if (first) {
+        u[n++] = 0;
+        u[n++] = 1;
+    }
+    u[n++] = 2;
+    u[n++] = 3;
+    if (LB != 1)
+        for (int k = 4; k < 8; k++) u[n++] = k;
+    if (LA != 1)
+        for (int k = 8; k < 12; k++) u[n++] = k;
+    for (int k = 12; k < IG_N_TMP_STRUCT; k++)
+        if (!vf || vf[k - 12] != -1) u[n++] = k;
+    return n;
+}
 
 /* k_gather: every fragment of a touched contig drops itself at its rank (no compaction needed);
- * block 0 also derives per-candidate metadata, get_bounds flags and the uniq-mutation lists
- * (extract_uniq_mutations KA:4492-4553, with the STALE flags of quirk Q4). */
-__global__ void k_gather(State st, Glob* g, MoveBuf mb, const int* __restrict__ cands_all, const int* __restrict__ frags_all,
-                         int move, int max_c, long long* q_part, Tables tab, Tables tab_prev, const int* __restrict__ prev_touched,
-                         int force_slot)
+ * block w also derives the metadata of move slot w: get_bounds flags (KA:2124-2252), slice windows
+ * (KA:530-548) and the uniq-mutation lists with the STALE flags of quirk Q4.  For slots w > 0 the flags
+ * the first candidate will see depend on the outcome of move w-1, so that candidate is scored with the
+ * superset list and the commit step selects the actual one. */
+__global__ void __launch_bounds__(256)
+    k_gather(State st, Glob* g, MoveBuf mb, const int* __restrict__ cands_all, const int* __restrict__ frags_all, int move0, int W,
+             int max_c, Tables tab, Tables tab_prev, const int* __restrict__ prev_touched, int force_slot)
 {
     /* tab_prev := coordinates before the LAST applied move (eval_likelihood_4_nuisance reads tables that
      * were filled before the move was applied, CL:1296-1344 / quirk Q12): catch up the entries that move touched */
@@ -553,42 +598,68 @@ __global__ void k_gather(State st, Glob* g, MoveBuf mb, const int* __restrict__ 
         tab_prev.cp[s] = tab.cp[s];
         tab_prev.len[s] = tab.len[s];
     }
+    __shared__ int sh_cA[IG_MAX_BATCH], sh_LA[IG_MAX_BATCH], sh_C[IG_MAX_BATCH];
+    __shared__ int sh_cB[IG_MAX_BATCH * IG_MAX_CANDIDATES];
     __shared__ int sh_flags[IG_MAX_CANDIDATES][12];
-    const int A = frags_all[move];
-    const int* cands = cands_all + (size_t)move * max_c;
-    int C = 0;
-    for (int i = 0; i < max_c; i++) C += (cands[i] >= 0);
     const int N = mb.N;
-    const int cA = st.cid[A], LA = st.L[A];
+    for (int i = threadIdx.x; i < W; i += blockDim.x) {
+        const int A = frags_all[move0 + i];
+        sh_cA[i] = st.cid[A];
+        sh_LA[i] = st.L[A];
+        int C = 0;
+        for (int q = 0; q < max_c; q++) C += (cands_all[(size_t)(move0 + i) * max_c + q] >= 0);
+        sh_C[i] = C;
+    }
+    for (int i = threadIdx.x; i < W * max_c; i += blockDim.x) {
+        const int b = cands_all[(size_t)move0 * max_c + i];
+        sh_cB[(i / max_c) * IG_MAX_CANDIDATES + (i % max_c)] = b >= 0 ? st.cid[b] : -1;
+    }
+    __syncthreads();
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f < N) {
         const int cf = st.cid[f], pf = st.pos[f];
         const int lb = st.lb[f], sl = st.sl[f];
-        for (int c = 0; c < C; c++) {
-            const int cB = st.cid[cands[c]];
-            int slot = -1;
-            if (cf == cA) slot = pf;
-            else if (cf == cB) slot = LA + pf;
-            if (slot >= 0) {
-                const size_t o = (size_t)c * N + slot;
-                mb.Lloc[o] = f;
-                mb.lbloc[o] = lb;
-                mb.slloc[o] = sl;
+        for (int w = 0; w < W; w++) {
+            const int cA = sh_cA[w], LA = sh_LA[w], C = sh_C[w];
+            for (int c = 0; c < C; c++) {
+                int slot = -1;
+                if (cf == cA) slot = pf;
+                else if (cf == sh_cB[w * IG_MAX_CANDIDATES + c]) slot = LA + pf;
+                if (slot >= 0) {
+                    const size_t o = (size_t)CW(w, c) * N + slot;
+                    mb.Lloc[o] = f;
+                    mb.lbloc[o] = lb;
+                    mb.slloc[o] = sl;
+                }
             }
         }
     }
-    if (blockIdx.x != 0) return;
+    const int w = blockIdx.x;
+    if (w >= W) return;
     const int t = threadIdx.x;
+    const int A = frags_all[move0 + w];
+    const int* cands = cands_all + (size_t)(move0 + w) * max_c;
+    const int C = sh_C[w];
+    const int cA = sh_cA[w], LA = sh_LA[w];
     if (t == 0) {
-        g->A = A;
-        g->C = C;
-        g->d_hi = 0;
-        g->d_lo = 0;
-        g->force_slot = force_slot;
+        MoveCtl mc;
+        mc.A = A;
+        mc.C = C;
+        mc.force_slot = force_slot;
+        mc.fresh = g->next_cid + NFRESH * w;
+        mc.ch_c = mc.ch_k = mc.ch_slot = mc.ch_windowed = 0;
+        mc.ch_score = 0.0;
+        mc.n_slice_tot = mc.n_eval_tot = mc.bytes_min = 0;
+        mc.d_hi = mc.d_lo = 0;
+        mc.superset0 = (w > 0 && force_slot < 0) ? 1 : 0;
+        mc.n_dirty = 0;
+        mc.overflow = 0;
+        mc.pad = 0;
+        mb.ctl[w] = mc;
     }
-    for (int i = t; i < C * P_STRIDE; i += blockDim.x) mb.part[i] = 0;
-    for (int i = t; i < C * Q_STRIDE; i += blockDim.x) q_part[i] = 0;
-    for (int i = t; i < C * IG_N_TMP_STRUCT; i += blockDim.x) mb.scores[i] = 0.0;
+    for (int i = t; i < C * P_STRIDE; i += blockDim.x) mb.part[(size_t)CW(w, 0) * P_STRIDE + i] = 0;
+    for (int i = t; i < C * Q_STRIDE; i += blockDim.x) mb.qpart[(size_t)CW(w, 0) * Q_STRIDE + i] = 0;
+    for (int i = t; i < C * IG_N_TMP_STRUCT; i += blockDim.x) mb.scores[(size_t)CW(w, 0) * IG_N_TMP_STRUCT + i] = 0.0;
     if (t < C) {
         CandMeta m;
         const int B = cands[t];
@@ -614,32 +685,24 @@ __global__ void k_gather(State st, Glob* g, MoveBuf mb, const int* __restrict__ 
         m.up_fb = max(0, m.pos_fb - slb);
         m.down_fb = min(m.SLB - 1, m.pos_fb + slb);
         m.windowed = m.same && (st.circ[A] == 0);
+        /* a window that spans the whole contig keeps every pair: the slice is then the full contig */
+        if (m.windowed && ((m.up_fa == 0 && m.down_fa == m.SLA - 1) || (m.up_fb == 0 && m.down_fb == m.SLA - 1))) m.windowed = 0;
         bounds_scalar(st, g, A, B, m.pos_up, m.pos_down, m.flags);
         for (int i = 0; i < 12; i++) sh_flags[t][i] = m.flags[i];
-        mb.meta[t] = m;
+        mb.meta[CW(w, t)] = m;
     }
     __syncthreads();
     if (t < C) {
-        CandMeta* m = &mb.meta[t];
-        const int* vf = (t == 0) ? g->valid_insert : sh_flags[t - 1];
+        CandMeta* m = &mb.meta[CW(w, t)];
         int n = 0;
         int* u = m->uniq;
         for (int k = 0; k < NSLOT; k++) m->kidx[k] = -1;
         if (force_slot >= 0) {
             u[n++] = force_slot;
+        } else if (t == 0) {
+            n = build_uniq(u, true, m->LA, m->LB, (w == 0) ? g->valid_insert : nullptr);
         } else {
-            if (t == 0) {
-                u[n++] = 0;
-                u[n++] = 1;
-            }
-            u[n++] = 2;
-            u[n++] = 3;
-            if (m->LB != 1)
-                for (int k = 4; k < 8; k++) u[n++] = k;
-            if (m->LA != 1)
-                for (int k = 8; k < 12; k++) u[n++] = k;
-            for (int k = 12; k < IG_N_TMP_STRUCT; k++)
-                if (vf[k - 12] != -1) u[n++] = k;
+            n = build_uniq(u, false, m->LA, m->LB, sh_flags[t - 1]);
         }
         m->n_uniq = n;
         m->kidx[IG_N_TMP_STRUCT] = 0; /* current genome = column 0 */
@@ -648,16 +711,18 @@ __global__ void k_gather(State st, Glob* g, MoveBuf mb, const int* __restrict__ 
 }
 
 /* k_mutate: one workgroup = one candidate genome on the local window. */
-__global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubTab* __restrict__ sub, Glob* g, MoveBuf mb,
-                                                long long* q_part, PzTab pz)
+__global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubTab* __restrict__ sub, const long long* __restrict__ rowptr,
+                                                Glob* g, MoveBuf mb, PzTab pz)
 {
-    const int slot = blockIdx.x, c = blockIdx.y;
-    if (c >= g->C) return;
-    const CandMeta& m = mb.meta[c];
+    const int slot = blockIdx.x, c = blockIdx.y, w = blockIdx.z;
+    const MoveCtl& mc = mb.ctl[w];
+    if (c >= mc.C) return;
+    const int cw = CW(w, c);
+    const CandMeta& m = mb.meta[cw];
     const int k = m.kidx[slot];
     if (k < 0) return;
     const int N = mb.N, M = mb.M, n = m.n_loc;
-    int* base = mb.loc + ((size_t)(c * NSLOT + slot) * NDYN) * N;
+    int* base = mb.loc + ((size_t)(cw * NSLOT + slot) * NDYN) * N;
     igd::Loc S;
     S.pos = base;
     S.spos = base + (size_t)N;
@@ -670,9 +735,9 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
     S.SL = base + (size_t)8 * N;
     S.LB = base + (size_t)9 * N;
     S.ori = base + (size_t)10 * N;
-    S.gid = mb.Lloc + (size_t)c * N;
-    S.lb = mb.lbloc + (size_t)c * N;
-    S.sl = mb.slloc + (size_t)c * N;
+    S.gid = mb.Lloc + (size_t)cw * N;
+    S.lb = mb.lbloc + (size_t)cw * N;
+    S.sl = mb.slloc + (size_t)cw * N;
     S.n = n;
     for (int x = threadIdx.x; x < n; x += blockDim.x) {
         const int f = S.gid[x];
@@ -690,7 +755,7 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
     }
     __syncthreads();
     const int A = m.lA, B = m.lB;
-    const int fresh = g->next_cid;
+    const int fresh = mc.fresh;
     if (slot == 0) { /* CL:1672 */
         igd::op_pop_out(S, A, fresh);
     } else if (slot == 1) { /* CL:1680 */
@@ -716,10 +781,10 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
     /* ---- coordinate column k (fill_vect_dist, KA:3699-3760) + zero-pixel sums on the window */
     const ig_params p = g->par[0];
     const float mean = g->mean_kb;
-    uint2* col = mb.coords + (size_t)(c * NSLOT + k) * M;
-    ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
-    int* subs = mb.subs + (size_t)c * M;
-    long long hi = 0, lo = 0, ni = 0;
+    uint2* col = mb.coords + (size_t)(cw * NSLOT + k) * M;
+    ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
+    int* subs = mb.subs + (size_t)cw * M;
+    long long hi = 0, lo = 0, ni = 0, bound = 0;
     for (int x = threadIdx.x; x < n; x += blockDim.x) {
         const int f = S.gid[x];
         const int cid = S.cid[x];
@@ -733,52 +798,74 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
         const float sbp_kb = (float)S.sbp[x] / 1000.0f;
         const int sf = st.sub_first[f];
         const int lbase = (x < m.LA) ? 0 : m.SLA;
-        for (int w = 0; w < sl; w++) {
-            const int s = sf + w;
+        for (int q = 0; q < sl; q++) {
+            const int s = sf + q;
             const SubTab b = sub[s];
             const float dist = sbp_kb + ((ori == 1) ? b.wat : b.cri);
-            const int npos = (ori == 1) ? sp + w : sp + sl - (w + 1);
+            const int npos = (ori == 1) ? sp + q : sp + sl - (q + 1);
             const int ls = lbase + tab.cp[s].y;
             uint2 v;
             v.x = __float_as_uint(dist);
             v.y = (unsigned)npos | ((unsigned)code << 28);
             col[ls] = v;
-            if (k == 0) subs[ls] = s;
+            if (k == 0) {
+                subs[ls] = s;
+                bound += rowptr[s + 1] - rowptr[s]; /* upper bound of this candidate's slice */
+            }
             if (npos == 0) ni += ((long long)SLc * (long long)(SLc - 1)) / 2;
             if (npos > 0) {
-                const long long q = zero_q(p, npos, SLc, stot, mean, pz.v, pz.n);
-                hi += q >> 32;
-                lo += (long long)(unsigned int)q;
+                const long long q2 = zero_q(p, npos, SLc, stot, mean, pz.v, pz.n);
+                hi += q2 >> 32;
+                lo += (long long)(unsigned int)q2;
             }
         }
     }
-    __shared__ long long red[3][4];
+    __shared__ long long red[4][4];
     hi = wave_sum_ll(hi);
     lo = wave_sum_ll(lo);
     ni = wave_sum_ll(ni);
+    bound = wave_sum_ll(bound);
     const int wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
         red[0][wv] = hi;
         red[1][wv] = lo;
         red[2][wv] = ni;
+        red[3][wv] = bound;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        long long* q = q_part + (size_t)c * Q_STRIDE;
+        long long* q = mb.qpart + (size_t)cw * Q_STRIDE;
         q[Q_Z + 2 * k] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
         q[Q_Z + 2 * k + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
         q[Q_NI + k] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        if (k == 0) mb.slbound[cw] = red[3][0] + red[3][1] + red[3][2] + red[3][3];
     }
 }
 
-/* k_score: the hot kernel.  One workgroup = (candidate c, coordinate column k, row block):
- * the column (8 B per local sub-fragment) is staged in LDS, the four waves stride over the CSR
- * rows of the touched contigs (coalesced 8-byte (col,count) loads, one packed (contig,pos) gather
- * per contact, LDS reads for both endpoints), each contact's Rippe/Poisson term is added as a
- * 64-bit integer; wave shuffles + one LDS step + two atomics per workgroup. */
-#define SCORE_RB 32       /* row blocks per (candidate, column) */
-#define DELTA_RB 128
+/* k_offsets: where each candidate's slice list starts in the pool = exclusive prefix sum of the upper bounds
+ * (one small workgroup; a slot whose lists do not fit is flagged and re-run at the head of the next batch) */
+__global__ void k_offsets(MoveBuf mb, int W)
+{
+    if (threadIdx.x != 0) return;
+    long long off = 0;
+    for (int w = 0; w < W; w++) {
+        const int C = mb.ctl[w].C;
+        for (int c = 0; c < C; c++) {
+            const int cw = CW(w, c);
+            const long long b = mb.slbound[cw];
+            if (off + b > mb.pool_cap) {
+                mb.sloff[cw] = -1;
+                mb.ctl[w].overflow = 1;
+            } else {
+                mb.sloff[cw] = off;
+                off += b;
+            }
+        }
+    }
+}
+
 #define LDS_COL_CAP 4096  /* local sub-fragments whose column fits the 32 KB LDS stage */
+#define DELTA_RB 128
 
 /* k_slice: slice_sp_mat (KA:485-607) restricted to the CSR rows of the touched contigs (instead of a scan of
  * all Z contacts).  One wave per row: up to SLICE_UNROLL x 64 contacts are loaded back to back (coalesced
@@ -788,20 +875,23 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
 #define SLICE_RB 128
 #define SLICE_UNROLL 4
 __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
-                                               const Glob* g, MoveBuf mb, int rank, int world)
+                                               Glob* g, MoveBuf mb, int rank, int world)
 {
-    const int c = blockIdx.y;
-    if (c >= g->C) return;
-    const CandMeta& m = mb.meta[c];
+    const int c = blockIdx.y, w = blockIdx.z;
+    if (c >= mb.ctl[w].C) return;
+    const int cw = CW(w, c);
+    const CandMeta& m = mb.meta[cw];
     const int M = mb.M, m_loc = m.m_loc;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const int* subs = mb.subs + (size_t)c * M;
-    int* rowcnt = mb.rowcnt + (size_t)c * M;
-    int* sli = mb.sl_li + (size_t)c * mb.Zcap;
-    int* slj = mb.sl_lj + (size_t)c * mb.Zcap;
-    int* slo = mb.sl_ob + (size_t)c * mb.Zcap;
-    unsigned long long* cursor = (unsigned long long*)(mb.part + (size_t)c * P_STRIDE + P_CNT);
+    const long long off = mb.sloff[cw];
+    if (off < 0) return; /* slice pool exhausted */
+    const int* subs = mb.subs + (size_t)cw * M;
+    int* rowcnt = mb.rowcnt + (size_t)cw * M;
+    int* sli = mb.sl_li + off;
+    int* slj = mb.sl_lj + off;
+    int* slo = mb.sl_ob + off;
+    unsigned long long* cursor = (unsigned long long*)(mb.part + (size_t)cw * P_STRIDE + P_CNT);
     const int nrw = gridDim.x * 4;
     for (int r = blockIdx.x * 4 + wv; r < m_loc; r += nrw) {
         const int i = subs[r];
@@ -834,16 +924,16 @@ __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ row
                         unsigned long long base = 0;
                         if (lane == 0) base = atomicAdd(cursor, (unsigned long long)add);
                         base = __shfl(base, 0, 64);
-                        int off = 0;
+                        int o2 = 0;
 #pragma unroll
                         for (int u = 0; u < SLICE_UNROLL; u++) {
                             if (keep[u]) {
-                                const long long at = (long long)base + off + __popcll(mask[u] & lt_mask);
+                                const long long at = (long long)base + o2 + __popcll(mask[u] & lt_mask);
                                 sli[at] = r;
                                 slj[at] = ((m.same || cp2[u].x == m.ctgA) ? 0 : m.SLA) + cp2[u].y;
                                 slo[at] = v[u].y;
                             }
-                            off += __popcll(mask[u]);
+                            o2 += __popcll(mask[u]);
                         }
                     }
                 }
@@ -853,35 +943,207 @@ __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ row
     }
 }
 
-/* k_score_list: the hot kernel.  One workgroup = (entry block, coordinate column k, candidate c).
+#define SCORE_EB 16
+#define LDS_PZ 1024
+#define LDS_LGF 256
+
+struct HotPar {
+    float d_max, v_inter, c1, fact, ex_out;
+    int fast;
+    double slope;
+};
+/* |slope * log2(s)| <= 1000 for every positive float s (log2 in [-149, 128]): ig_exp2's range checks cannot fire */
+#define HOT_SLOPE_MAX 6.5f
+
+__device__ __forceinline__ HotPar hot_params(const ig_params& p)
+{
+    HotPar h;
+    h.d_max = p.d_max;
+    h.v_inter = p.v_inter;
+    h.c1 = p.c1;
+    h.fact = p.fact;
+    h.ex_out = ig_fmaxf(0.0f, p.v_inter); /* ig_rippe outside (0, d_max) */
+    h.slope = (double)p.slope;
+    h.fast = (p.d == 2.0f) && (p.slope != 0.0f) && (p.slope != 2.0f) && (p.slope > -HOT_SLOPE_MAX) && (p.slope < HOT_SLOPE_MAX) &&
+             (p.v_inter > 0.0f) && (p.v_inter < IG_INFF); /* all false for NaNs */
+    return h;
+}
+
+/* general (checked) evaluation of a linear-cis / trans pair, out of line */
+__device__ __noinline__ double term_general(const ig_params p, float mean_kb, float s, int dkey, int ob, double lgf, PzTab pz)
+{
+    float ex, ex_z;
+    if (dkey < 0) {
+        ex = p.v_inter;
+        ex_z = p.v_inter;
+    } else {
+        ex = ig_rippe(s, p, ig_tab());
+        ex_z = pz_lookup(pz, p, mean_kb, dkey);
+    }
+    return ig_pixel_term(ex, ex_z, ob, lgf, ig_tab());
+}
+
+/* q = ig_quantize(t) as (q >> 32, (uint32) q): the same integer, split without 64-bit conversions */
+__device__ __forceinline__ void quantize_split(double t, int& qh, unsigned& ql)
+{
+    t = (t != t) ? 0.0 : t;
+    t = __builtin_fmin(__builtin_fmax(t, -IG_QCLAMP), IG_QCLAMP); /* t is a number here: same as the two compares */
+    const double Q = __builtin_rint(t * IG_QSCALE);
+    const double H = __builtin_floor(Q * (1.0 / IG_QSCALE));
+    qh = (int)H;
+    ql = (unsigned)ig_fma(H, -IG_QSCALE, Q);
+}
+
+/* circular contigs (rare): the general functions, out of line */
+__device__ __noinline__ double term_circ(const ig_params p, float mean_kb, float s, float s_tot, int d, int len_j, int ob, double lgf)
+{
+    float ex, ex_z;
+    expected_circ(p, mean_kb, s, s_tot, d, len_j, &ex, &ex_z);
+    return ig_pixel_term(ex, ex_z, ob, lgf, ig_tab());
+}
+
+/* dkey: rank distance d of a linear cis pair; -1 for a trans pair; d | code << 27 | 1 << 30 for a pair on a circular contig.
+ * Straight-line for the hot case (HotPar.fast parameters, linear contig or trans pair, small count, rank distance inside
+ * the LDS P_z table); everything else is fixed up afterwards behind wave-uniform branches that are almost never taken. */
+#define DKEY_CIRC 0x40000000
+__device__ __forceinline__ void term_hot(const HotPar& hp, const ig_params& p, float mean_kb, float s, int dkey, int ob,
+                                         const float* pz_s, int pzn_s, const PzTab& pz, const double* lgf_s,
+                                         const double* __restrict__ lgf_tab, const ColMeta* cm_s, const double* T, int& qh,
+                                         unsigned& ql)
+{
+    const bool inter = dkey < 0;
+    const bool in = (s > 0.0f) && (s < hp.d_max);
+    double lgf = lgf_s[min(ob, LDS_LGF - 1)];
+    const double L = ig_log2_pos((double)(in ? s : 1.0f), T);
+    const float pw = (float)ig_exp2_core(hp.slope * L, T); /* hp.fast: in range, see HOT_SLOPE_MAX (else the result is unused) */
+    const float res = (hp.c1 * pw) * hp.fact;
+    float ex = in ? ((res > hp.v_inter) ? res : hp.v_inter) : hp.ex_out;
+    ex = inter ? hp.v_inter : ex;
+    float ex_z = pz_s[min(max(dkey, 0), pzn_s - 1)];
+    ex_z = inter ? hp.v_inter : ex_z;
+    const bool ok = ex < IG_INFF; /* hp.fast: ex >= v_inter > 0 and NaN-free by construction */
+    const double e = (double)ex;
+    const double lg = ig_log2_pos(ok ? e : 1.0, T) * IG_LOG2_10_INV;
+    double t = (((double)ob * lg) - e) - lgf;
+    t = t + (double)ex_z * IG_LOG_E_F;
+    const bool rare = (ob >= LDS_LGF) || (dkey >= pzn_s) || !ok || !hp.fast || (ob <= 0);
+    if (__any(rare)) {
+        if (rare) {
+            if (ob >= LDS_LGF) lgf = lgfact_dev(ob, lgf_tab);
+            if (!inter && (dkey & DKEY_CIRC)) {
+                const int code = (dkey >> 27) & 7;
+                t = term_circ(p, mean_kb, s, cm_s[code].stot, dkey & 0x07ffffff, cm_s[code].len, ob, lgf);
+            } else {
+                t = term_general(p, mean_kb, s, dkey, ob, lgf, pz);
+            }
+        }
+    }
+    quantize_split(t, qh, ql);
+}
+
+/* classification of one slice entry under one coordinate column: what its term is computed from */
+__device__ __forceinline__ void classify_pair(uint2 ai, uint2 bj, unsigned circ_mask, float& sv, int& dkey)
+{
+    const unsigned ci = ai.y >> 28, cj = bj.y >> 28;
+    const int pi = (int)(ai.y & 0x0fffffffu), pj = (int)(bj.y & 0x0fffffffu);
+    const bool cis = ci == cj;
+    sv = cis ? fabsf(__uint_as_float(ai.x) - __uint_as_float(bj.x)) : 0.0f;
+    dkey = cis ? (pi > pj ? pi - pj : pj - pi) : -1;
+    if (cis && ((circ_mask >> ci) & 1u)) dkey = (dkey & 0x07ffffff) | ((int)ci << 27) | DKEY_CIRC;
+}
+
+struct ScoreArgs {
+    const int *sli, *slj, *slo; /* the candidate's slice list (one candidate: < 2^31 entries, 32-bit offsets from a uniform base) */
+    unsigned n;
+    const uint2* gcol; /* column k in global memory */
+    const uint2* lcol; /* and its LDS copy */
+    const float* pz_s;
+    const double *lgf_s, *mt_s;
+    const ColMeta* cm_s;
+    const double* lgf_tab;
+    PzTab pz;
+    int pzn;
+    unsigned circ_mask;
+    float mean;
+    int ablate;
+};
+
+/* the streaming loop of k_score_list; STAGED: the column fits the LDS stage (ds_read), else 8-byte gathers from L2 */
+#define SCORE_BATCH 4
+template <bool STAGED>
+__device__ __forceinline__ void score_loop(const ScoreArgs& a, const HotPar& hp, const ig_params& p, long long& hi, long long& lo)
+{
+    const unsigned stride = gridDim.x * SCORE_THREADS;
+    for (unsigned e0 = blockIdx.x * SCORE_THREADS + threadIdx.x; e0 < a.n; e0 += stride * SCORE_BATCH) {
+        int li[SCORE_BATCH], lj[SCORE_BATCH], ob[SCORE_BATCH];
+#pragma unroll
+        for (int u = 0; u < SCORE_BATCH; u++) {
+            const unsigned e = e0 + u * stride;
+            const bool ok = e < a.n;
+            li[u] = ok ? a.sli[e] : -1;
+            lj[u] = ok ? a.slj[e] : 0;
+            ob[u] = ok ? a.slo[e] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < SCORE_BATCH; u++) { /* unrolled: the batch stays in registers */
+            const bool valid = li[u] >= 0; /* lanes past the end evaluate entry 0 and drop the result */
+            if (!__any(valid)) break;      /* wave-uniform */
+            const int l_i = valid ? li[u] : 0, l_j = lj[u], o_b = valid ? ob[u] : 1;
+            const uint2 ai = STAGED ? a.lcol[l_i] : a.gcol[l_i];
+            const uint2 bj = STAGED ? a.lcol[l_j] : a.gcol[l_j];
+            float sv;
+            int dkey;
+            classify_pair(ai, bj, a.circ_mask, sv, dkey);
+            int qh;
+            unsigned ql;
+            if (a.ablate & 1) {
+                qh = (int)__float_as_uint(sv) >> 12;
+                ql = (unsigned)(dkey + o_b);
+            } else {
+                term_hot(hp, p, a.mean, sv, dkey, o_b, a.pz_s, a.pzn, a.pz, a.lgf_s, a.lgf_tab, a.cm_s, a.mt_s, qh, ql);
+            }
+            hi += valid ? qh : 0;
+            lo += (long long)(valid ? ql : 0u);
+        }
+    }
+}
+
+/* k_score_list: the hot kernel.  One workgroup = (entry block, coordinate column k, candidate cw).
  * Staged in LDS: the column (8 B per local sub-fragment), the P_z table, the log10(ob!) table, the log2/exp2
  * tables of the arithmetic contract and the per-contig constants.  Lanes stream the slice list (coalesced
  * 4-byte loads, SCORE_BATCH contacts in flight), read both endpoints' coordinates from LDS, evaluate the
- * Rippe / Poisson term and add it as a 64-bit integer.  Wave shuffles, one LDS step, two atomics per workgroup. */
-#define SCORE_EB 16
-#define SCORE_BATCH 4
-#define LDS_PZ 1024
-#define LDS_LGF 256
+ * Rippe / Poisson term (term_hot: the arithmetic contract of ig_detmath.h with the argument checks hoisted) and add
+ * it as an exact integer.  Wave shuffles, one LDS step, two atomics per workgroup. */
+#define LDS_COL_SMALL 1024
+/* two instantiations per launch site: windows of <= LDS_COL_SMALL sub-fragments (8 KB column: more workgroups per CU)
+ * and the rest (<= LDS_COL_CAP staged, larger ones gathered from L2); each workgroup serves its own class only */
+template <int CAP>
 __global__ void __launch_bounds__(SCORE_THREADS)
-    k_score_list(const Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int ablate)
+    k_score_list(const Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int ablate, int max_c, int large_on)
 {
-    __shared__ uint2 lcol[LDS_COL_CAP];
+    __shared__ uint2 lcol[CAP];
     __shared__ float pz_s[LDS_PZ];
     __shared__ double lgf_s[LDS_LGF];
     __shared__ double mt_s[IG_TAB_SIZE];
     __shared__ ColMeta cm_s[NCODE];
     __shared__ long long red[2][SCORE_THREADS / 64];
-    const int c = blockIdx.z;
-    if (c >= g->C) return;
-    const CandMeta& m = mb.meta[c];
+    const int w = blockIdx.z / max_c, c = blockIdx.z % max_c;
+    if (c >= mb.ctl[w].C) return;
+    const int cw = CW(w, c);
+    const CandMeta& m = mb.meta[cw];
     const int k = blockIdx.y;
     if (k > m.n_uniq) return;
+    const long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT];
+    if ((long long)blockIdx.x * SCORE_THREADS >= n) return;
+    const long long off = mb.sloff[cw];
+    if (off < 0) return;
     const int M = mb.M, m_loc = m.m_loc;
-    const long long n = mb.part[(size_t)c * P_STRIDE + P_CNT];
+    if (large_on && ((CAP == LDS_COL_SMALL) != (m_loc <= LDS_COL_SMALL))) return;
     const ig_params p = g->par[0];
+    const HotPar hp = hot_params(p);
     const float mean = g->mean_kb;
-    const uint2* gcol = mb.coords + (size_t)(c * NSLOT + k) * M;
-    const bool staged = m_loc <= LDS_COL_CAP;
+    const uint2* gcol = mb.coords + (size_t)(cw * NSLOT + k) * M;
+    const bool staged = m_loc <= CAP;
     if (staged)
         for (int i = threadIdx.x; i < m_loc; i += SCORE_THREADS) lcol[i] = gcol[i];
     const int pzn = min(pz.n, LDS_PZ);
@@ -891,61 +1153,15 @@ __global__ void __launch_bounds__(SCORE_THREADS)
         const double* T0 = ig_tab();
         for (int i = threadIdx.x; i < IG_TAB_SIZE; i += SCORE_THREADS) mt_s[i] = T0[i];
     }
-    if (threadIdx.x < NCODE) cm_s[threadIdx.x] = mb.cmeta[(size_t)(c * NSLOT + k) * NCODE + threadIdx.x];
+    if (threadIdx.x < NCODE) cm_s[threadIdx.x] = mb.cmeta[(size_t)(cw * NSLOT + k) * NCODE + threadIdx.x];
     __syncthreads();
-    const int* sli = mb.sl_li + (size_t)c * mb.Zcap;
-    const int* slj = mb.sl_lj + (size_t)c * mb.Zcap;
-    const int* slo = mb.sl_ob + (size_t)c * mb.Zcap;
-    long long hi = 0, lo = 0;
-    const long long stride = (long long)gridDim.x * SCORE_THREADS;
-    for (long long e0 = (long long)blockIdx.x * SCORE_THREADS + threadIdx.x; e0 < n; e0 += stride * SCORE_BATCH) {
-        int li[SCORE_BATCH], lj[SCORE_BATCH], ob[SCORE_BATCH];
+    unsigned circ_mask = 0;
 #pragma unroll
-        for (int u = 0; u < SCORE_BATCH; u++) {
-            const long long e = e0 + u * stride;
-            const bool ok = e < n;
-            li[u] = ok ? sli[e] : -1;
-            lj[u] = ok ? slj[e] : 0;
-            ob[u] = ok ? slo[e] : 0;
-        }
-#pragma unroll 1
-        for (int u = 0; u < SCORE_BATCH; u++) {
-            const int l_i = li[u], l_j = lj[u], o_b = ob[u];
-            if (l_i < 0) break;
-            uint2 ai, bj;
-            if (staged) {
-                ai = lcol[l_i];
-                bj = lcol[l_j];
-            } else {
-                ai = gcol[l_i];
-                bj = gcol[l_j];
-            }
-            long long q;
-            if (ablate & 1) {
-                q = (long long)(ai.x ^ bj.y) + o_b;
-            } else {
-                const double lgf = (o_b > 0 && o_b < LDS_LGF) ? lgf_s[o_b] : lgfact_dev(o_b, lgf_tab);
-                /* the hot case in line: two sub-fragments of one LINEAR contig */
-                const int ci = (int)(ai.y >> 28), cj = (int)(bj.y >> 28);
-                const int pi = (int)(ai.y & 0x0fffffffu), pj = (int)(bj.y & 0x0fffffffu);
-                const int d = pi > pj ? pi - pj : pj - pi;
-                float ex, ex_z;
-                if (ci != cj) {
-                    ex = p.v_inter;
-                    ex_z = p.v_inter;
-                } else if (cm_s[ci].stot == 0) {
-                    ex = ig_rippe(fabsf(__uint_as_float(ai.x) - __uint_as_float(bj.x)), p, mt_s);
-                    ex_z = (d < pzn) ? pz_s[d] : pz_direct(p, mean, d);
-                } else {
-                    expected_circ(p, mean, fabsf(__uint_as_float(ai.x) - __uint_as_float(bj.x)), cm_s[ci].stot, d, cm_s[cj].len, &ex,
-                                  &ex_z);
-                }
-                q = ig_quantize(ig_pixel_term(ex, ex_z, o_b, lgf, mt_s));
-            }
-            hi += q >> 32;
-            lo += (long long)(unsigned int)q;
-        }
-    }
+    for (int q = 0; q < NCODE; q++) circ_mask |= (cm_s[q].stot != 0) ? (1u << q) : 0u;
+    long long hi = 0, lo = 0;
+    const ScoreArgs sa{mb.sl_li + off, mb.sl_lj + off, mb.sl_ob + off, (unsigned)n, gcol, lcol, pz_s, lgf_s, mt_s, cm_s, lgf_tab, pz, pzn, circ_mask, mean, ablate};
+    if (staged) score_loop<true>(sa, hp, p, hi, lo);
+    else score_loop<false>(sa, hp, p, hi, lo);
     hi = wave_sum_ll(hi);
     lo = wave_sum_ll(lo);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -958,50 +1174,48 @@ __global__ void __launch_bounds__(SCORE_THREADS)
         hi = red[0][0] + red[0][1] + red[0][2] + red[0][3];
         lo = red[1][0] + red[1][1] + red[1][2] + red[1][3];
         if (hi | lo) {
-            long long* part = mb.part + (size_t)c * P_STRIDE;
+            long long* part = mb.part + (size_t)cw * P_STRIDE;
             atomic_add_ll(&part[P_NZ + 2 * k], hi);
             atomic_add_ll(&part[P_NZ + 2 * k + 1], lo);
         }
     }
 }
 
-template <bool UNWINDOWED>
+/* k_delta: exact update of the full likelihood when the winner's slice was windowed (KA:565-586 keeps only
+ * pairs near A and B): sum over ALL pairs of the contig of (term under the winner - term under the current
+ * genome).  Row-parallel with a per-wave compaction queue; two columns (current, winner). */
 __global__ void __launch_bounds__(SCORE_THREADS)
-    k_score(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, const Glob* g, MoveBuf mb,
-            const double* __restrict__ lgf_tab, int rank, int world, PzTab pz)
+    k_delta(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, Glob* g, MoveBuf mb,
+            const double* __restrict__ lgf_tab, PzTab pz, int w)
 {
     __shared__ uint2 lcol[LDS_COL_CAP];
-    __shared__ long long red[3][SCORE_THREADS / 64];
-    /* per-wave compaction queue: only ~40-80 % of a row's contacts survive the slice predicate, so kept
-     * contacts are queued (ballot + popcount ranks) and the transcendental math runs on full waves */
+    __shared__ long long red[2][SCORE_THREADS / 64];
     __shared__ int q_li[SCORE_THREADS / 64][128], q_lj[SCORE_THREADS / 64][128], q_ob[SCORE_THREADS / 64][128];
-    const int c = UNWINDOWED ? g->ch_c : (int)blockIdx.z;
-    if (c < 0 || c >= g->C) return;
-    if (UNWINDOWED && (!g->ch_windowed || g->error)) return; /* the slice already was the whole contig pair */
-    const CandMeta& m = mb.meta[c];
+    MoveCtl& mc = mb.ctl[w];
+    if (!mc.ch_windowed || g->error) return;
+    const int c = mc.ch_c;
+    const int cw = CW(w, c);
+    const CandMeta& m = mb.meta[cw];
     const int kk = blockIdx.y;
-    const int ncol = UNWINDOWED ? 2 : m.n_uniq + 1;
-    if (kk >= ncol) return;
-    const int k = UNWINDOWED ? (kk == 0 ? 0 : g->ch_k) : kk;
+    const int k = (kk == 0) ? 0 : mc.ch_k;
     const int M = mb.M, m_loc = m.m_loc;
     const ig_params p = g->par[0];
     const float mean = g->mean_kb;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint2* gcol = mb.coords + (size_t)(c * NSLOT + k) * M;
+    const uint2* gcol = mb.coords + (size_t)(cw * NSLOT + k) * M;
     const bool staged = m_loc <= LDS_COL_CAP;
     if (staged) {
         for (int i = threadIdx.x; i < m_loc; i += SCORE_THREADS) lcol[i] = gcol[i];
         __syncthreads();
     }
-    const int* subs = mb.subs + (size_t)c * M;
-    int* rowcnt = mb.rowcnt + (size_t)c * M;
-    const ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
+    const int* subs = mb.subs + (size_t)cw * M;
+    const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
     int* qli = q_li[wv];
     int* qlj = q_lj[wv];
     int* qob = q_ob[wv];
     long long hi = 0, lo = 0;
-    int cnt = 0, qn = 0;
+    int qn = 0;
     auto drain = [&](int n_take) {
         if (lane < n_take) {
             const int li = qli[lane], lj = qlj[lane], ob = qob[lane];
@@ -1014,59 +1228,52 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     };
     const int nrw = gridDim.x * (SCORE_THREADS / 64);
     for (int r = blockIdx.x * (SCORE_THREADS / 64) + wv; r < m_loc; r += nrw) {
-        if (world > 1 && (r % world) != rank) continue;
         const int i = subs[r];
         const long long b = rowptr[i], e = rowptr[i + 1];
-        int rc = 0;
-        if (b != e) {
-            const int2 cp1 = tab.cp[i];
-            for (long long q0 = b; q0 < e; q0 += 64) {
-                const long long qi = q0 + lane;
-                bool keep = false;
-                int lj = 0, ob = 0;
-                if (qi < e) {
-                    const int2 v = cc[qi];
-                    const int2 cp2 = tab.cp[v.x];
-                    keep = slice_keep(m, cp1.x, cp2.x, cp1.y, cp2.y, v.y, UNWINDOWED);
-                    lj = ((m.same || cp2.x == m.ctgA) ? 0 : m.SLA) + cp2.y;
-                    ob = v.y;
+        if (b == e) continue;
+        const int2 cp1 = tab.cp[i];
+        for (long long q0 = b; q0 < e; q0 += 64) {
+            const long long qi = q0 + lane;
+            bool keep = false;
+            int lj = 0, ob = 0;
+            if (qi < e) {
+                const int2 v = cc[qi];
+                const int2 cp2 = tab.cp[v.x];
+                keep = slice_keep(m, cp1.x, cp2.x, cp1.y, cp2.y, v.y, true);
+                lj = ((m.same || cp2.x == m.ctgA) ? 0 : m.SLA) + cp2.y;
+                ob = v.y;
+            }
+            const unsigned long long mask = __ballot(keep);
+            if (mask) {
+                if (keep) {
+                    const int at = qn + __popcll(mask & lt_mask);
+                    qli[at] = r;
+                    qlj[at] = lj;
+                    qob[at] = ob;
                 }
-                const unsigned long long mask = __ballot(keep);
-                if (mask) {
-                    if (keep) {
-                        const int at = qn + __popcll(mask & lt_mask);
-                        qli[at] = r;
-                        qlj[at] = lj;
-                        qob[at] = ob;
-                    }
-                    const int add = __popcll(mask);
-                    qn += add;
-                    rc += add;
+                qn += __popcll(mask);
+                __builtin_amdgcn_wave_barrier();
+                if (qn >= 64) {
+                    drain(64);
                     __builtin_amdgcn_wave_barrier();
-                    if (qn >= 64) {
-                        drain(64);
-                        __builtin_amdgcn_wave_barrier();
-                        const int rem = qn - 64;
-                        int t0 = 0, t1 = 0, t2 = 0;
-                        if (lane < rem) {
-                            t0 = qli[64 + lane];
-                            t1 = qlj[64 + lane];
-                            t2 = qob[64 + lane];
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                        if (lane < rem) {
-                            qli[lane] = t0;
-                            qlj[lane] = t1;
-                            qob[lane] = t2;
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                        qn = rem;
+                    const int rem = qn - 64;
+                    int t0 = 0, t1 = 0, t2 = 0;
+                    if (lane < rem) {
+                        t0 = qli[64 + lane];
+                        t1 = qlj[64 + lane];
+                        t2 = qob[64 + lane];
                     }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < rem) {
+                        qli[lane] = t0;
+                        qlj[lane] = t1;
+                        qob[lane] = t2;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    qn = rem;
                 }
             }
         }
-        if (!UNWINDOWED && kk == 0 && lane == 0) rowcnt[r] = rc; /* kept contacts of this row: needed by the tail walk */
-        cnt += rc;
     }
     drain(qn);
     hi = wave_sum_ll(hi);
@@ -1074,26 +1281,14 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     if (lane == 0) {
         red[0][wv] = hi;
         red[1][wv] = lo;
-        red[2][wv] = (long long)cnt;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         hi = red[0][0] + red[0][1] + red[0][2] + red[0][3];
         lo = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        const long long cn = red[2][0] + red[2][1] + red[2][2] + red[2][3];
-        if (UNWINDOWED) {
-            Glob* gw = const_cast<Glob*>(g);
-            if (hi | lo) {
-                atomic_add_ll(&gw->d_hi, kk == 0 ? -hi : hi);
-                atomic_add_ll(&gw->d_lo, kk == 0 ? -lo : lo);
-            }
-        } else {
-            long long* part = mb.part + (size_t)c * P_STRIDE;
-            if (hi | lo) {
-                atomic_add_ll(&part[P_NZ + 2 * k], hi);
-                atomic_add_ll(&part[P_NZ + 2 * k + 1], lo);
-            }
-            if (kk == 0 && cn) atomic_add_ll(&part[P_CNT], cn);
+        if (hi | lo) {
+            atomic_add_ll(&mc.d_hi, kk == 0 ? -hi : hi);
+            atomic_add_ll(&mc.d_lo, kk == 0 ? -lo : lo);
         }
     }
 }
@@ -1104,226 +1299,280 @@ __device__ __forceinline__ int wave_max_i(int v)
     return v;
 }
 
-/* k_finalize: one workgroup per candidate -- tail quirk (Q5), zero-pixel totals and scores
- * (eval_all_likelihood_on_zero_2nd KA:4005-4027, eval_all_scores KA:4029-4046). */
-__global__ void __launch_bounds__(256) k_finalize(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
-                                                  Glob* g, MoveBuf mb, long long* q_part, const double* __restrict__ lgf_tab,
-                                                  int tail_quirk, PzTab pz)
+/* k_prefinal: one workgroup per (candidate, slot).  Keeps the uncorrected slice sums and computes, for
+ * every column, T[k] = sum of the terms of the LAST r = S_c mod 64 sliced contacts (canonical order = COO
+ * order, so "last" = highest rows, found by bisection on the row id).  Quirk Q5 (KA:4362, block 64 CL:200):
+ * a column at list position >= r never receives those contacts; which columns that applies to is decided
+ * when the uniq list is known (k_scores / k_commit_batch). */
+__global__ void __launch_bounds__(256) k_prefinal(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
+                                                  Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz)
 {
     __shared__ int t_li[64], t_lj[64], t_ob[64], t_rows[64];
     __shared__ int sh_n_rows, sh_n_tail, sh_cnt;
     __shared__ long long sh_red[4];
-    const int c = blockIdx.x;
-    if (c >= g->C) return;
+    const int c = blockIdx.x, w = blockIdx.y;
+    if (c >= mb.ctl[w].C) return;
+    const int cw = CW(w, c);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int M = mb.M;
     const ig_params p = g->par[0];
     const float mean = g->mean_kb;
-    const double log_e = IG_LOG_E_F;
-    const CandMeta& m = mb.meta[c];
-    long long* part = mb.part + (size_t)c * P_STRIDE;
-    long long* qp = q_part + (size_t)c * Q_STRIDE;
-    const int* subs = mb.subs + (size_t)c * M;
-    const int* rowcnt = mb.rowcnt + (size_t)c * M;
+    const CandMeta& m = mb.meta[cw];
+    const long long* part = mb.part + (size_t)cw * P_STRIDE;
+    long long* qp = mb.qpart + (size_t)cw * Q_STRIDE;
+    const int* subs = mb.subs + (size_t)cw * M;
+    const int* rowcnt = mb.rowcnt + (size_t)cw * M;
     const int ncol = m.n_uniq + 1;
-    for (int k = tid; k < ncol; k += blockDim.x) { /* uncorrected sums: the exact full-likelihood update uses them */
+    for (int k = tid; k < ncol; k += blockDim.x) {
         qp[Q_NZFULL + 2 * k] = part[P_NZ + 2 * k];
         qp[Q_NZFULL + 2 * k + 1] = part[P_NZ + 2 * k + 1];
+        qp[Q_TAIL + 2 * k] = 0;
+        qp[Q_TAIL + 2 * k + 1] = 0;
     }
     __syncthreads();
     const long long Sc = part[P_CNT];
-    /* quirk Q5 (KA:4362, block 64 CL:200): with r = S_c mod 64 > 0, the columns at list positions >= r never
-     * receive the last r sliced contacts.  Canonical order = COO order, so "last" = highest rows: find by
-     * bisection the row id T such that rows >= T hold >= r kept contacts and rows > T hold fewer. */
     const int r = (int)(Sc % 64);
-    if (tail_quirk && r > 0 && m.n_uniq > r) {
-        int lo_t = 0, hi_t = M; /* count(lo_t) >= r, count(hi_t) < r */
-        while (hi_t - lo_t > 1) {
-            const int mid = lo_t + (hi_t - lo_t) / 2;
-            long long s = 0;
-            for (int ls = tid; ls < m.m_loc; ls += blockDim.x)
-                if (subs[ls] >= mid) s += rowcnt[ls];
-            s = wave_sum_ll(s);
-            if (lane == 0) sh_red[wv] = s;
-            __syncthreads();
-            const long long tot = sh_red[0] + sh_red[1] + sh_red[2] + sh_red[3];
-            __syncthreads();
-            if (tot >= r) lo_t = mid;
-            else hi_t = mid;
-        }
-        const int T = lo_t;
-        if (tid == 0) {
-            sh_n_rows = 0;
-            sh_n_tail = 0;
-            sh_cnt = 0;
-        }
+    if (!(tail_quirk && r > 0)) return;
+    int lo_t = 0, hi_t = M; /* count(lo_t) >= r, count(hi_t) < r */
+    while (hi_t - lo_t > 1) {
+        const int mid = lo_t + (hi_t - lo_t) / 2;
+        long long s = 0;
+        for (int ls = tid; ls < m.m_loc; ls += blockDim.x)
+            if (subs[ls] >= mid) s += rowcnt[ls];
+        s = wave_sum_ll(s);
+        if (lane == 0) sh_red[wv] = s;
         __syncthreads();
-        int above = 0; /* kept contacts in rows > T */
-        for (int ls = tid; ls < m.m_loc; ls += blockDim.x) {
-            const int s = subs[ls];
-            if (s >= T && rowcnt[ls] > 0) {
-                const int slot = atomicAdd(&sh_n_rows, 1);
-                if (slot < 64) t_rows[slot] = ls;
-                if (s > T) above += rowcnt[ls];
-            }
-        }
-        above = wave_sum_i(above);
-        if (lane == 0 && above) atomicAdd(&sh_cnt, above);
+        const long long tot = sh_red[0] + sh_red[1] + sh_red[2] + sh_red[3];
         __syncthreads();
-        const int n_rows = min(sh_n_rows, 64);
-        const int need_T = r - sh_cnt; /* contacts to take from the END of row T */
-        for (int ri = wv; ri < n_rows; ri += 4) {
-            const int ls = t_rows[ri];
-            const int i = subs[ls];
-            const int2 cp1 = tab.cp[i];
-            const long long b = rowptr[i], e = rowptr[i + 1];
-            int remaining = (i == T) ? need_T : 0x7fffffff;
-            for (long long end = e; end > b && remaining > 0; end -= 64) {
-                const long long q0 = end - 1 - lane;
-                bool keep = false;
-                int2 v = make_int2(0, 0);
-                int lj = 0;
-                if (q0 >= b) {
-                    v = cc[q0];
-                    const int2 cp2 = tab.cp[v.x];
-                    keep = slice_keep(m, cp1.x, cp2.x, cp1.y, cp2.y, v.y, false);
-                    lj = ((m.same || cp2.x == m.ctgA) ? 0 : m.SLA) + cp2.y;
-                }
-                const unsigned long long mask = __ballot(keep);
-                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-                const int took = min((int)__popcll(mask), remaining);
-                int basei = 0;
-                if (lane == 0 && took) basei = atomicAdd(&sh_n_tail, took);
-                basei = __shfl(basei, 0, 64);
-                if (keep && rank < remaining && basei + rank < 64) {
-                    t_li[basei + rank] = ls;
-                    t_lj[basei + rank] = lj;
-                    t_ob[basei + rank] = v.y;
-                }
-                remaining -= took;
-            }
-        }
-        __syncthreads();
-        const int n_tail = min(sh_n_tail, 64);
-        if (tid == 0 && n_tail != r) g->error = 5; /* the walk must find exactly r contacts */
-        for (int kk2 = r + wv; kk2 < m.n_uniq; kk2 += 4) {
-            const int k = kk2 + 1;
-            const uint2* col = mb.coords + (size_t)(c * NSLOT + k) * M;
-            const ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
-            long long hi = 0, lo = 0;
-            if (lane < n_tail) {
-                const long long q = eval_q(p, mean, col[t_li[lane]], col[t_lj[lane]], cm, t_ob[lane], lgfact_dev(t_ob[lane], lgf_tab), pz, ig_tab());
-                hi = q >> 32;
-                lo = (long long)(unsigned int)q;
-            }
-            hi = wave_sum_ll(hi);
-            lo = wave_sum_ll(lo);
-            if (lane == 0) {
-                part[P_NZ + 2 * k] -= hi;
-                part[P_NZ + 2 * k + 1] -= lo;
-            }
-        }
-        __syncthreads();
+        if (tot >= r) lo_t = mid;
+        else hi_t = mid;
     }
+    const int T = lo_t;
+    if (tid == 0) {
+        sh_n_rows = 0;
+        sh_n_tail = 0;
+        sh_cnt = 0;
+    }
+    __syncthreads();
+    int above = 0; /* kept contacts in rows > T */
+    for (int ls = tid; ls < m.m_loc; ls += blockDim.x) {
+        const int s = subs[ls];
+        if (s >= T && rowcnt[ls] > 0) {
+            const int slot = atomicAdd(&sh_n_rows, 1);
+            if (slot < 64) t_rows[slot] = ls;
+            if (s > T) above += rowcnt[ls];
+        }
+    }
+    above = wave_sum_i(above);
+    if (lane == 0 && above) atomicAdd(&sh_cnt, above);
+    __syncthreads();
+    const int n_rows = min(sh_n_rows, 64);
+    const int need_T = r - sh_cnt; /* contacts to take from the END of row T */
+    for (int ri = wv; ri < n_rows; ri += 4) {
+        const int ls = t_rows[ri];
+        const int i = subs[ls];
+        const int2 cp1 = tab.cp[i];
+        const long long b = rowptr[i], e = rowptr[i + 1];
+        int remaining = (i == T) ? need_T : 0x7fffffff;
+        for (long long end = e; end > b && remaining > 0; end -= 64) {
+            const long long q0 = end - 1 - lane;
+            bool keep = false;
+            int2 v = make_int2(0, 0);
+            int lj = 0;
+            if (q0 >= b) {
+                v = cc[q0];
+                const int2 cp2 = tab.cp[v.x];
+                keep = slice_keep(m, cp1.x, cp2.x, cp1.y, cp2.y, v.y, false);
+                lj = ((m.same || cp2.x == m.ctgA) ? 0 : m.SLA) + cp2.y;
+            }
+            const unsigned long long mask = __ballot(keep);
+            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+            const int took = min((int)__popcll(mask), remaining);
+            int basei = 0;
+            if (lane == 0 && took) basei = atomicAdd(&sh_n_tail, took);
+            basei = __shfl(basei, 0, 64);
+            if (keep && rank < remaining && basei + rank < 64) {
+                t_li[basei + rank] = ls;
+                t_lj[basei + rank] = lj;
+                t_ob[basei + rank] = v.y;
+            }
+            remaining -= took;
+        }
+    }
+    __syncthreads();
+    const int n_tail = min(sh_n_tail, 64);
+    if (tid == 0 && n_tail != r) g->error = 5; /* the walk must find exactly r contacts */
+    for (int k = 1 + wv; k < ncol; k += 4) {
+        const uint2* col = mb.coords + (size_t)(cw * NSLOT + k) * M;
+        const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
+        long long hi = 0, lo = 0;
+        if (lane < n_tail) {
+            const long long q = eval_q(p, mean, col[t_li[lane]], col[t_lj[lane]], cm, t_ob[lane], lgfact_dev(t_ob[lane], lgf_tab), pz,
+                                       ig_tab());
+            hi = q >> 32;
+            lo = (long long)(unsigned int)q;
+        }
+        hi = wave_sum_ll(hi);
+        lo = wave_sum_ll(lo);
+        if (lane == 0) {
+            qp[Q_TAIL + 2 * k] = hi;
+            qp[Q_TAIL + 2 * k + 1] = lo;
+        }
+    }
+}
+
+/* scores of one move slot (eval_all_likelihood_on_zero_2nd KA:4005-4027, eval_all_scores KA:4029-4046) and the
+ * host argmax of CL:1435-1446 (zeros -> -inf, shifted/clipped scores, FIRST index of the maximum).  Executed by
+ * one workgroup; `vf0` = the stale insert flags the first candidate sees (quirk Q4). */
+__device__ void score_and_choose(Glob* g, const MoveBuf& mb, int w, const int* vf0, double* sc_lds /* [C*24] */)
+{
+    const int tid = threadIdx.x;
+    MoveCtl& mc = mb.ctl[w];
+    const int C = mc.C;
+    const ig_params p = g->par[0];
+    const double log_e = IG_LOG_E_F;
     const double cur_nz = ig_acc_to_double(g->nz_hi, g->nz_lo);
-    const double ext = ig_acc_to_double(part[P_NZ], part[P_NZ + 1]);
-    for (int k = 1 + tid; k < ncol; k += blockDim.x) {
+    const int n = C * IG_N_TMP_STRUCT;
+    for (int i = tid; i < n; i += blockDim.x) sc_lds[i] = 0.0;
+    __syncthreads();
+    for (int i = tid; i < n; i += blockDim.x) {
+        const int c = i / IG_N_TMP_STRUCT, slot = i % IG_N_TMP_STRUCT;
+        const int cw = CW(w, c);
+        const CandMeta& m = mb.meta[cw];
+        const int k = m.kidx[slot];
+        if (k <= 0) continue;
+        /* position of this slot in the ACTUAL uniq list (the scored list may be a superset for c == 0) */
+        int pos;
+        if (c == 0 && mc.superset0) {
+            if (slot >= 12 && vf0[slot - 12] == -1) continue; /* not scored by the reference */
+            pos = 0;
+            for (int q = 0; q < m.n_uniq; q++) {
+                const int s2 = m.uniq[q];
+                if (s2 >= slot) break;
+                if (s2 < 12 || vf0[s2 - 12] != -1) pos++;
+            }
+        } else {
+            pos = k - 1;
+        }
+        const long long* part = mb.part + (size_t)cw * P_STRIDE;
+        const long long* qp = mb.qpart + (size_t)cw * Q_STRIDE;
+        const int r = (int)(part[P_CNT] % 64);
+        long long nh = qp[Q_NZFULL + 2 * k], nl = qp[Q_NZFULL + 2 * k + 1];
+        if (r > 0 && pos >= r) { /* quirk Q5 */
+            nh -= qp[Q_TAIL + 2 * k];
+            nl -= qp[Q_TAIL + 2 * k + 1];
+        }
+        const double ext = ig_acc_to_double(qp[Q_NZFULL], qp[Q_NZFULL + 1]);
         const long long zhi = g->z_hi + qp[Q_Z + 2 * k] - qp[Q_Z];
         const long long zlo = g->z_lo + qp[Q_Z + 2 * k + 1] - qp[Q_Z + 1];
         const long long ni = g->n_intra + qp[Q_NI + k] - qp[Q_NI];
         const double val_inter = -1.0 * log_e * (g->n_tot_pxl - (double)ni) * p.v_inter;
         const double val_intra = ig_acc_to_double(zhi, zlo) * log_e;
         const double z = val_intra + val_inter;
-        const double nz = ig_acc_to_double(part[P_NZ + 2 * k], part[P_NZ + 2 * k + 1]);
-        mb.scores[c * IG_N_TMP_STRUCT + m.uniq[k - 1]] = nz + z + cur_nz - ext;
+        const double nz = ig_acc_to_double(nh, nl);
+        sc_lds[i] = nz + z + cur_nz - ext;
     }
+    __syncthreads();
+    if (tid < 64) {
+        const int lane = tid;
+        double mx = -IG_INF;
+        for (int i = lane; i < n; i += 64) {
+            const double s = sc_lds[i];
+            const double ok = (s == 0.0) ? -IG_INF : s;
+            mx = ok > mx ? ok : mx;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(mx, off, 64);
+            mx = o > mx ? o : mx;
+        }
+        double bestv = -IG_INF;
+        int best = 0x7fffffff;
+        for (int i = lane; i < n; i += 64) {
+            const double s = sc_lds[i];
+            const double ok = (s == 0.0) ? -IG_INF : s;
+            double fs = ok - (mx - 30.0);
+            if (fs < 0) fs = 0;
+            if (fs > bestv) { /* strictly greater: the first index wins inside a lane */
+                bestv = fs;
+                best = i;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bestv, off, 64);
+            const int oi = __shfl_xor(best, off, 64);
+            if (ov > bestv || (ov == bestv && oi < best)) {
+                bestv = ov;
+                best = oi;
+            }
+        }
+        if (lane == 0) {
+            if (best >= n) best = 0;
+            const int cc_ = best / IG_N_TMP_STRUCT, slot = best % IG_N_TMP_STRUCT;
+            long long tot_slice = 0, tot_eval = 0, bytes = 0;
+            for (int c = 0; c < C; c++) {
+                const CandMeta& m = mb.meta[CW(w, c)];
+                const long long Sc = mb.part[(size_t)CW(w, c) * P_STRIDE + P_CNT];
+                tot_slice += Sc;
+                int nu = m.n_uniq;
+                if (c == 0 && mc.superset0) /* the list the reference would have scored */
+                    for (int q = 0; q < m.n_uniq; q++) nu -= (m.uniq[q] >= 12 && vf0[m.uniq[q] - 12] == -1);
+                tot_eval += Sc * (nu + 1);
+                bytes += 12 * Sc + 20LL * m.m_loc * nu + 8LL * nu;
+            }
+            const CandMeta& mch = mb.meta[CW(w, cc_)];
+            mc.ch_c = cc_;
+            mc.ch_slot = slot;
+            mc.ch_k = mch.kidx[slot] < 0 ? 0 : mch.kidx[slot];
+            mc.ch_windowed = mch.windowed;
+            mc.ch_score = sc_lds[best];
+            mc.n_slice_tot = tot_slice;
+            mc.n_eval_tot = tot_eval;
+            mc.bytes_min = bytes;
+            if (mch.kidx[slot] < 0) g->error = 3; /* an unscored slot won: cannot happen */
+        }
+    }
+    __syncthreads();
 }
 
-/* the host argmax of CL:1435-1446 (zeros -> -inf, shifted/clipped scores, FIRST index of the maximum) */
-__global__ void __launch_bounds__(64) k_argmax(Glob* g, MoveBuf mb, long long* q_part)
+/* one-move path: scores + argmax of slot w (then k_delta / k_apply / k_post / k_commit) */
+__global__ void __launch_bounds__(256) k_scores(Glob* g, MoveBuf mb, int w)
 {
-    const int lane = threadIdx.x;
-    const int C = g->C, n = C * IG_N_TMP_STRUCT;
-    double mx = -IG_INF;
-    for (int i = lane; i < n; i += 64) {
-        const double s = mb.scores[i];
-        const double ok = (s == 0.0) ? -IG_INF : s;
-        mx = ok > mx ? ok : mx;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double o = __shfl_xor(mx, off, 64);
-        mx = o > mx ? o : mx;
-    }
-    double bestv = -IG_INF;
-    int best = 0x7fffffff;
-    for (int i = lane; i < n; i += 64) {
-        const double s = mb.scores[i];
-        const double ok = (s == 0.0) ? -IG_INF : s;
-        double fs = ok - (mx - 30.0);
-        if (fs < 0) fs = 0;
-        if (fs > bestv) { /* strictly greater: the first index wins inside a lane */
-            bestv = fs;
-            best = i;
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(bestv, off, 64);
-        const int oi = __shfl_xor(best, off, 64);
-        if (ov > bestv || (ov == bestv && oi < best)) {
-            bestv = ov;
-            best = oi;
-        }
-    }
-    if (lane == 0) {
-        if (best >= n) best = 0;
-        const int cc_ = best / IG_N_TMP_STRUCT, slot = best % IG_N_TMP_STRUCT;
-        long long tot_slice = 0, tot_eval = 0, bytes = 0;
-        for (int c = 0; c < C; c++) {
-            const CandMeta& m = mb.meta[c];
-            const long long Sc = mb.part[(size_t)c * P_STRIDE + P_CNT];
-            tot_slice += Sc;
-            tot_eval += Sc * (m.n_uniq + 1);
-            bytes += 12 * Sc + 20LL * m.m_loc * m.n_uniq + 8LL * m.n_uniq;
-        }
-        g->ch_c = cc_;
-        g->ch_slot = slot;
-        g->ch_k = mb.meta[cc_].kidx[slot] < 0 ? 0 : mb.meta[cc_].kidx[slot];
-        g->ch_windowed = mb.meta[cc_].windowed;
-        g->ch_score = mb.scores[best];
-        g->n_slice_tot = tot_slice;
-        g->n_eval_tot = tot_eval;
-        g->bytes_min = bytes;
-        g->credit2_acc = 0;
-        if (mb.meta[cc_].kidx[slot] < 0) g->error = 3; /* an unscored slot won: cannot happen */
-    }
+    __shared__ double sc[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT];
+    __shared__ int vf[12];
+    if (threadIdx.x < 12) vf[threadIdx.x] = g->valid_insert[threadIdx.x];
+    __syncthreads();
+    score_and_choose(g, mb, w, vf, sc);
+    const int n = mb.ctl[w].C * IG_N_TMP_STRUCT;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) mb.scores[(size_t)CW(w, 0) * IG_N_TMP_STRUCT + i] = sc[i];
 }
 
 /* forced choice for ig_apply (test_copy_struct / apply_replay_simu, CL:2094-2151, 2546-2553) */
 __global__ void k_force_choice(Glob* g, MoveBuf mb, int slot)
 {
-    g->ch_c = 0;
-    g->ch_slot = slot;
-    g->ch_k = mb.meta[0].kidx[slot];
-    g->ch_windowed = 1; /* always take the exact-delta path */
-    g->ch_score = 0.0;
-    g->n_slice_tot = 0;
-    g->n_eval_tot = 0;
-    g->bytes_min = 0;
-    g->credit2_acc = 0;
-    if (g->ch_k < 0) g->error = 4;
+    MoveCtl& mc = mb.ctl[0];
+    mc.ch_c = 0;
+    mc.ch_slot = slot;
+    mc.ch_k = mb.meta[0].kidx[slot];
+    mc.ch_windowed = 1; /* always take the exact-delta path */
+    mc.ch_score = 0.0;
+    mc.n_slice_tot = 0;
+    mc.n_eval_tot = 0;
+    mc.bytes_min = 0;
+    if (mc.ch_k < 0) g->error = 4;
 }
 
-/* k_apply: the winner becomes the live genome (copy_struct KA:4566-4591) and the coordinate
- * tables of the touched sub-fragments are refreshed from its column. */
-__global__ void k_apply(State st, Tables tab, Glob* g, MoveBuf mb, long long* q_part, int forced, int* prev_touched)
+/* the winner becomes the live genome (copy_struct KA:4566-4591) and the coordinate tables of the touched
+ * sub-fragments are refreshed from its column; executed cooperatively by the calling threads (tid/nth). */
+__device__ void apply_winner(State st, Tables tab, Glob* g, const MoveBuf& mb, int w, int forced, int* prev_touched, int tid, int nth,
+                             bool single_block)
 {
-    const int c = g->ch_c, slot = g->ch_slot, k = g->ch_k;
-    if (g->error) return;
-    const CandMeta& m = mb.meta[c];
+    MoveCtl& mc = mb.ctl[w];
+    const int c = mc.ch_c, slot = mc.ch_slot, k = mc.ch_k;
+    const int cw = CW(w, c);
+    const CandMeta& m = mb.meta[cw];
     const int N = mb.N, M = mb.M;
-    const int* base = mb.loc + ((size_t)(c * NSLOT + slot) * NDYN) * N;
-    const int* gid = mb.Lloc + (size_t)c * N;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    const int* base = mb.loc + ((size_t)(cw * NSLOT + slot) * NDYN) * N;
+    const int* gid = mb.Lloc + (size_t)cw * N;
     int heads = 0;
     for (int x = tid; x < m.n_loc; x += nth) {
         const int f = gid[x];
@@ -1343,10 +1592,10 @@ __global__ void k_apply(State st, Tables tab, Glob* g, MoveBuf mb, long long* q_
     }
     heads = wave_sum_i(heads);
     if ((threadIdx.x & 63) == 0 && heads) atomicAdd(&g->n_contigs, heads);
-    const uint2* col = mb.coords + (size_t)(c * NSLOT + k) * M;
-    const ColMeta* cm = mb.cmeta + (size_t)(c * NSLOT + k) * NCODE;
-    const int* subs = mb.subs + (size_t)c * M;
-    const int fresh = g->next_cid;
+    const uint2* col = mb.coords + (size_t)(cw * NSLOT + k) * M;
+    const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
+    const int* subs = mb.subs + (size_t)cw * M;
+    const int fresh = mc.fresh;
     for (int ls = tid; ls < m.m_loc; ls += nth) {
         const int s = subs[ls];
         const uint2 v = col[ls];
@@ -1358,13 +1607,13 @@ __global__ void k_apply(State st, Tables tab, Glob* g, MoveBuf mb, long long* q_
         prev_touched[ls] = s;
     }
     if (tid == 0) {
-        const long long* qp = q_part + (size_t)c * Q_STRIDE;
+        const long long* qp = mb.qpart + (size_t)cw * Q_STRIDE;
         g->n_prev_touched = m.m_loc;
         atomicAdd(&g->n_contigs, m.same ? -1 : -2);
         long long dh, dl;
-        if (g->ch_windowed) {
-            dh = g->d_hi;
-            dl = g->d_lo;
+        if (mc.ch_windowed) {
+            dh = mc.d_hi;
+            dl = mc.d_lo;
         } else {
             dh = qp[Q_NZFULL + 2 * k] - qp[Q_NZFULL];
             dl = qp[Q_NZFULL + 2 * k + 1] - qp[Q_NZFULL + 1];
@@ -1382,31 +1631,183 @@ __global__ void k_apply(State st, Tables tab, Glob* g, MoveBuf mb, long long* q_
         /* stale-flag state (quirk Q4): flags of the last candidate, or of the winner when its
          * family re-ran get_bounds in test_copy_struct (op >= 12, CL:2125-2126) */
         if (!forced || slot >= 12) {
-            const int* fl = (slot >= 12) ? m.flags : mb.meta[g->C - 1].flags;
+            const int* fl = (slot >= 12) ? m.flags : mb.meta[CW(w, mc.C - 1)].flags;
             for (int i = 0; i < 12; i++) g->valid_insert[i] = fl[i];
         }
     }
+    (void)single_block;
 }
 
-__global__ void k_commit(Glob* g, MoveBuf mb, ig_move_result* res, int move)
+__global__ void k_apply(State st, Tables tab, Glob* g, MoveBuf mb, int w, int forced, int* prev_touched)
+{
+    if (g->error) return;
+    apply_winner(st, tab, g, mb, w, forced, prev_touched, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, false);
+}
+
+__device__ __forceinline__ void write_result(Glob* g, const MoveBuf& mb, int w, ig_move_result* out)
+{
+    const MoveCtl& mc = mb.ctl[w];
+    ig_move_result r;
+    const double norm = 3.0 * (double)(g->N - g->n_black);
+    r.o = mc.ch_score;
+    r.dist = (norm - 0.5 * (double)g->credit2) / norm;
+    r.mean_len = (double)((float)g->N / (float)g->n_contigs);
+    r.op_sampled = mc.ch_slot;
+    r.id_f_sampled = mb.meta[CW(w, mc.ch_c)].B;
+    r.n_contigs = g->n_contigs;
+    r.n_candidates = mc.C;
+    r.n_slice = mc.n_slice_tot;
+    r.n_evals = mc.n_eval_tot;
+    r.bytes_min = mc.bytes_min + 68LL * mb.meta[CW(w, mc.ch_c)].n_loc;
+    r.error = g->error;
+    r.pad = 0;
+    *out = r;
+}
+
+__global__ void k_commit(Glob* g, MoveBuf mb, ig_move_result* res, int move, int w)
 {
     g->next_cid += NFRESH;
     g->credit2 = g->credit2_acc;
-    ig_move_result r;
-    const double norm = 3.0 * (double)(g->N - g->n_black);
-    r.o = g->ch_score;
-    r.dist = (norm - 0.5 * (double)g->credit2) / norm;
-    r.mean_len = (double)((float)g->N / (float)g->n_contigs);
-    r.op_sampled = g->ch_slot;
-    r.id_f_sampled = mb.meta[g->ch_c].B;
-    r.n_contigs = g->n_contigs;
-    r.n_candidates = g->C;
-    r.n_slice = g->n_slice_tot;
-    r.n_evals = g->n_eval_tot;
-    r.bytes_min = g->bytes_min + 68LL * mb.meta[g->ch_c].n_loc;
-    r.error = g->error;
-    r.pad = 0;
-    res[move] = r;
+    g->credit2_acc = 0;
+    write_result(g, mb, w, res + move);
+}
+
+/* k_commit_batch: the sequential half of a batch, one workgroup.  For w = 0, 1, ...: stop if a contig of move w
+ * was modified by an earlier move of this batch (its scores were computed against a stale state); otherwise
+ * score + argmax with the live scalars, apply, update the genome distance incrementally, write the result.
+ * A winner whose slice was windowed needs the exact k_delta pass first: the batch then stops BEFORE applying it
+ * (pending) and the host finishes that move with the one-move kernels. */
+__global__ void __launch_bounds__(256)
+    k_commit_batch(State st, Tables tab, Tables tab_prev, Glob* g, MoveBuf mb, const int* __restrict__ ip, const int* __restrict__ in,
+                   const int* __restrict__ orientable, const unsigned char* __restrict__ black, int* stamp, int* prev_touched,
+                   ig_move_result* res, int move0, int W, int* batch_out /* [0] = committed, [1] = pending slot or -1 */)
+{
+    __shared__ double sc[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT];
+    __shared__ int vf[12];
+    __shared__ int dirty[IG_MAX_BATCH * 2];
+    __shared__ int n_dirty, sh_stop, sh_changed;
+    __shared__ long long sh_c2[2];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        n_dirty = 0;
+        batch_out[0] = 0;
+        batch_out[1] = -1;
+    }
+    __syncthreads();
+    for (int w = 0; w < W; w++) {
+        MoveCtl& mc = mb.ctl[w];
+        /* 1. conflict: any contig of this move modified earlier in the batch? */
+        if (tid == 0) {
+            int stop = (g->error != 0) || mc.overflow;
+            for (int c = 0; c < mc.C && !stop; c++) {
+                const CandMeta& m = mb.meta[CW(w, c)];
+                for (int q = 0; q < n_dirty; q++)
+                    if (dirty[q] == m.ctgA || dirty[q] == m.ctgB) stop = 1;
+            }
+            sh_stop = stop;
+        }
+        if (tid < 12) vf[tid] = g->valid_insert[tid];
+        __syncthreads();
+        if (sh_stop) break;
+        /* 2. scores with the live scalars, argmax */
+        score_and_choose(g, mb, w, vf, sc);
+        const int c = mc.ch_c, slot = mc.ch_slot;
+        const int cw = CW(w, c);
+        const CandMeta& m = mb.meta[cw];
+        /* 3. does the winner change anything?  (an identical genome needs no delta and dirties nothing) */
+        if (tid == 0) {
+            sh_changed = 0;
+            sh_c2[0] = 0;
+            sh_c2[1] = 0;
+        }
+        __syncthreads();
+        {
+            const int N = mb.N;
+            const int* base = mb.loc + ((size_t)(cw * NSLOT + slot) * NDYN) * N;
+            const int* gid = mb.Lloc + (size_t)cw * N;
+            int ch = 0;
+            for (int x = tid; x < m.n_loc; x += blockDim.x) {
+                const int f = gid[x];
+                ch |= (st.pos[f] != base[x]) | (st.spos[f] != base[(size_t)N + x]) | (st.cid[f] != base[(size_t)2 * N + x]) |
+                      (st.sbp[f] != base[(size_t)3 * N + x]) | (st.circ[f] != base[(size_t)4 * N + x]) |
+                      (st.prev[f] != base[(size_t)5 * N + x]) | (st.next[f] != base[(size_t)6 * N + x]) |
+                      (st.L[f] != base[(size_t)7 * N + x]) | (st.SL[f] != base[(size_t)8 * N + x]) |
+                      (st.LB[f] != base[(size_t)9 * N + x]) | (st.ori[f] != base[(size_t)10 * N + x]);
+            }
+            if (ch) atomicOr(&sh_changed, 1);
+        }
+        __syncthreads();
+        if (mc.ch_windowed && sh_changed) { /* needs k_delta: hand this move to the one-move tail */
+            if (tid == 0) batch_out[1] = w;
+            break;
+        }
+        if (tid == 0 && mc.ch_windowed) { /* identical genome: the delta is exactly zero */
+            mc.d_hi = 0;
+            mc.d_lo = 0;
+        }
+        /* 4. genome distance, incremental and exact: credit(f) depends on prev/next/ori of f and on the
+         * orientation of its INITIAL neighbours only (CL:665-716), so the fragments whose credit can change are the
+         * touched ones and their initial neighbours; each is claimed once through a stamp. */
+        const int st1 = 2 * g->stamp_ctr + 1, st2 = st1 + 1;
+        {
+            const int* gid = mb.Lloc + (size_t)cw * mb.N;
+            long long old2 = 0;
+            if (sh_changed)
+                for (int x = tid; x < m.n_loc; x += blockDim.x) {
+                    const int f0 = gid[x];
+                    const int cand3[3] = {f0, ip[f0], in[f0]};
+                    for (int q = 0; q < 3; q++) {
+                        const int f = cand3[q];
+                        if (f < 0 || black[f]) continue;
+                        if (atomicExch(&stamp[f], st1) != st1) old2 += credit2_of(st, ip, in, orientable, f);
+                    }
+                }
+            old2 = wave_sum_ll(old2);
+            if ((tid & 63) == 0 && old2) atomic_add_ll(&sh_c2[0], old2);
+        }
+        __syncthreads();
+        /* 5. catch tab_prev up with the previous commit, then apply */
+        for (int i = tid; i < g->n_prev_touched; i += blockDim.x) {
+            const int s = prev_touched[i];
+            tab_prev.dist[s] = tab.dist[s];
+            tab_prev.stot[s] = tab.stot[s];
+            tab_prev.cp[s] = tab.cp[s];
+            tab_prev.len[s] = tab.len[s];
+        }
+        __syncthreads();
+        apply_winner(st, tab, g, mb, w, 0, prev_touched, tid, blockDim.x, true);
+        __threadfence_block();
+        __syncthreads();
+        {
+            const int* gid = mb.Lloc + (size_t)cw * mb.N;
+            long long new2 = 0;
+            if (sh_changed)
+                for (int x = tid; x < m.n_loc; x += blockDim.x) {
+                    const int f0 = gid[x];
+                    const int cand3[3] = {f0, ip[f0], in[f0]};
+                    for (int q = 0; q < 3; q++) {
+                        const int f = cand3[q];
+                        if (f < 0 || black[f]) continue;
+                        if (atomicExch(&stamp[f], st2) != st2) new2 += credit2_of(st, ip, in, orientable, f);
+                    }
+                }
+            new2 = wave_sum_ll(new2);
+            if ((tid & 63) == 0 && new2) atomic_add_ll(&sh_c2[1], new2);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            g->stamp_ctr += 1;
+            g->credit2 += sh_c2[1] - sh_c2[0];
+            g->next_cid += NFRESH;
+            if (sh_changed) {
+                dirty[n_dirty++] = m.ctgA;
+                if (!m.same) dirty[n_dirty++] = m.ctgB;
+            }
+            write_result(g, mb, w, res + move0 + w);
+            batch_out[0] = w + 1;
+        }
+        __syncthreads();
+    }
 }
 
 __global__ void k_debug_terms(const float* s, const float* stot, const int* ob, long long n, const Glob* g,
@@ -1504,7 +1905,8 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->cc = nullptr;
     c->init_prev = c->init_next = c->orientable = nullptr;
     c->black = nullptr;
-    c->q_part = nullptr;
+    c->stamp = nullptr;
+    c->batch_out = nullptr;
     c->d_results = nullptr;
     c->results_cap = 0;
     c->d_frags = c->d_cands = nullptr;
@@ -1514,6 +1916,8 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->pz_n = 0;
     c->timing_mask = 0xffff;
     c->timing = false;
+    c->n_batches = c->n_batch_committed = c->n_batch_pending = 0;
+    c->large_seen = 1;
     for (int i = 0; i < T_COUNT; i++) {
         c->timers[i].name = kTimerNames[i];
         c->timers[i].total_ms = 0;
@@ -1538,7 +1942,6 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     Glob hg;
     memset(&hg, 0, sizeof hg);
     for (int k = 0; k < 15; k++) hg.lgf[k] = small[k];
-    hg.force_slot = -1;
     const int lb[6] = {1, 3, 5, 10, 20, 50}; /* CL:417 */
     for (int k = 0; k < 6; k++) hg.list_bounds[k] = lb[k];
     hg.slice_nb = 50 * 4;
@@ -1566,9 +1969,15 @@ static void free_move_buffers(ig_ctx* c)
     hipFree(m.cmeta);
     hipFree(m.part);
     hipFree(m.scores);
-    hipFree(c->q_part);
+    hipFree(m.slbound);
+    hipFree(m.sloff);
+    hipFree(m.qpart);
+    hipFree(m.ctl);
+    hipFree(c->stamp);
+    hipFree(c->batch_out);
     memset((void*)&m, 0, sizeof m);
-    c->q_part = nullptr;
+    c->stamp = nullptr;
+    c->batch_out = nullptr;
 }
 
 extern "C" void ig_destroy(ig_ctx* c)
@@ -1621,36 +2030,49 @@ extern "C" int ig_set_stream(ig_ctx* c, void* s)
     return 0;
 }
 
-static int ensure_move_buffers(ig_ctx* c, int capC)
+static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
 {
-    if (c->mb.capC >= capC && c->mb.N == c->N && c->mb.M == c->M && c->mb.Zcap == std::max<long long>(c->Z, 1)) return 0;
+    if (c->mb.capC >= capC && c->mb.capW >= capW && c->mb.N == c->N && c->mb.M == c->M) return 0;
     if (c->N == 0 || c->M == 0) return 0;
+    capC = std::max(capC, c->mb.capC);
+    capW = std::max(capW, c->mb.capW);
     free_move_buffers(c);
     MoveBuf& m = c->mb;
-    const size_t N = c->N, M = c->M, C = capC;
+    const size_t N = c->N, M = c->M, C = (size_t)capC * capW;
     DALLOC(m.Lloc, C * N);
     DALLOC(m.lbloc, C * N);
     DALLOC(m.slloc, C * N);
     DALLOC(m.subs, C * M);
     DALLOC(m.rowcnt, C * M);
     {
-        const size_t Zc = (size_t)std::max<long long>(c->Z, 1);
-        DALLOC(m.sl_li, C * Zc);
-        DALLOC(m.sl_lj, C * Zc);
-        DALLOC(m.sl_ob, C * Zc);
-        m.Zcap = (long long)Zc;
+        /* one slot never needs more than capC x Z entries; a batch shares the pool and the slots that do not fit
+         * are re-run (MoveCtl.overflow) */
+        const size_t Zc = (size_t)std::max<long long>(c->Z, 1) * (size_t)std::max(capC, capW > 1 ? 16 : 1);
+        DALLOC(m.sl_li, Zc);
+        DALLOC(m.sl_lj, Zc);
+        DALLOC(m.sl_ob, Zc);
+        m.pool_cap = (long long)Zc;
     }
+    DALLOC(m.slbound, C);
+    DALLOC(m.sloff, C);
     DALLOC(m.coords, C * M * NSLOT);
     DALLOC(m.loc, C * NSLOT * NDYN * N);
     DALLOC(m.meta, C);
     DALLOC(m.cmeta, C * NSLOT * NCODE);
     DALLOC(m.part, C * P_STRIDE);
+    DALLOC(m.qpart, C * Q_STRIDE);
     DALLOC(m.scores, C * IG_N_TMP_STRUCT);
-    DALLOC(c->q_part, C * Q_STRIDE);
+    DALLOC(m.ctl, (size_t)capW);
+    DALLOC(c->stamp, N);
+    DALLOC(c->batch_out, 2);
     HIPCK(hipMemset(m.cmeta, 0, C * NSLOT * NCODE * sizeof(ColMeta)));
+    HIPCK(hipMemset(m.slbound, 0, C * sizeof(long long)));
+    HIPCK(hipMemset(m.ctl, 0, (size_t)capW * sizeof(MoveCtl)));
+    HIPCK(hipMemset(c->stamp, 0, N * sizeof(int)));
     m.N = c->N;
     m.M = c->M;
     m.capC = capC;
+    m.capW = capW;
     return 0;
 }
 
@@ -1833,6 +2255,7 @@ static int launch_recompute(ig_ctx* c)
     hg.n_intra = h[4];
     hg.n_contigs = ((int*)&h[6])[0];
     hg.credit2 = hg.credit2_acc;
+    hg.credit2_acc = 0;
     hg.n_prev_touched = 0;
     HIPCK(hipMemcpy(c->glob, &hg, sizeof hg, hipMemcpyHostToDevice));
     return 0;
@@ -2036,60 +2459,75 @@ static int check_ready(ig_ctx* c)
 
 static int g_tail_quirk = 1;
 
-/* enqueue the launches of one move; phase 0 = up to k_score, phase 1 = the rest, 2 = both */
-static void enqueue_move(ig_ctx* c, int move, int max_c, int force_slot, int phase)
+/* enqueue the scoring launches of W move slots (moves move0 .. move0+W-1 of the uploaded lists);
+ * phase 0 = up to k_score_list (the sums that are all-reduced when sharded), 1 = the rest, 2 = both */
+static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot, int phase)
 {
     const int N = c->N;
-    const int gN = (N + 255) / 256;
+    const int gN = std::max((N + 255) / 256, W);
+    const PzTab pz{c->pz_tab, c->pz_n};
     if (phase == 0 || phase == 2) {
         {
             TimedLaunch t(c, T_GATHER);
-            hipLaunchKernelGGL(k_gather, dim3(gN), dim3(256), 0, c->stream, c->st, c->glob, c->mb, c->d_cands, c->d_frags, move, max_c,
-                               c->q_part, c->tab, c->tab_prev, c->prev_touched, force_slot);
+            hipLaunchKernelGGL(k_gather, dim3(gN), dim3(256), 0, c->stream, c->st, c->glob, c->mb, c->d_cands, c->d_frags, move0, W, max_c,
+                               c->tab, c->tab_prev, c->prev_touched, force_slot);
         }
         {
             TimedLaunch t(c, T_MUTATE);
-            hipLaunchKernelGGL(k_mutate, dim3(NSLOT, max_c), dim3(256), 0, c->stream, c->st, c->tab, c->sub_tab, c->glob, c->mb,
-                               c->q_part, PzTab{c->pz_tab, c->pz_n});
+            hipLaunchKernelGGL(k_mutate, dim3(NSLOT, max_c, W), dim3(256), 0, c->stream, c->st, c->tab, c->sub_tab, c->rowptr, c->glob,
+                               c->mb, pz);
         }
         if (force_slot < 0) {
             {
                 TimedLaunch t(c, T_SLICE);
-                hipLaunchKernelGGL(k_slice, dim3(SLICE_RB, max_c), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb,
+                hipLaunchKernelGGL(k_offsets, dim3(1), dim3(64), 0, c->stream, c->mb, W);
+                hipLaunchKernelGGL(k_slice, dim3(SLICE_RB, max_c, W), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb,
                                    c->rank, c->world);
             }
             TimedLaunch t(c, T_SCORE);
-            if (0) hipLaunchKernelGGL(k_slice, dim3(SLICE_RB, max_c), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb,
-                               c->rank, c->world);
             static int s_eb = getenv("IG_SCORE_EB") ? atoi(getenv("IG_SCORE_EB")) : SCORE_EB;
             static int s_abl = getenv("IG_ABLATE") ? atoi(getenv("IG_ABLATE")) : 0;
-            hipLaunchKernelGGL(k_score_list, dim3(s_eb, NSLOT, max_c), dim3(SCORE_THREADS), 0, c->stream, c->glob, c->mb,
-                               c->lgf_tab, PzTab{c->pz_tab, c->pz_n}, s_abl);
+            /* the large-window variant is launched only when the previous batch saw windows above LDS_COL_SMALL
+             * sub-fragments; without it the small variant serves every window (unstaged above its cap) */
+            static int s_large = getenv("IG_LARGE") ? atoi(getenv("IG_LARGE")) : -1;
+            const int large_on = s_large >= 0 ? s_large : c->large_seen;
+            hipLaunchKernelGGL(k_score_list<LDS_COL_SMALL>, dim3(s_eb, NSLOT, max_c * W), dim3(SCORE_THREADS), 0, c->stream, c->glob,
+                               c->mb, c->lgf_tab, pz, s_abl, max_c, large_on);
+            if (large_on)
+                hipLaunchKernelGGL(k_score_list<LDS_COL_CAP>, dim3(s_eb, NSLOT, max_c * W), dim3(SCORE_THREADS), 0, c->stream, c->glob,
+                                   c->mb, c->lgf_tab, pz, s_abl, max_c, large_on);
         }
     }
     if (phase == 1 || phase == 2) {
         if (force_slot < 0) {
             TimedLaunch t(c, T_FINALIZE);
-            hipLaunchKernelGGL(k_finalize, dim3(max_c), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->q_part,
-                               c->lgf_tab, g_tail_quirk, PzTab{c->pz_tab, c->pz_n});
-            hipLaunchKernelGGL(k_argmax, dim3(1), dim3(64), 0, c->stream, c->glob, c->mb, c->q_part);
-        } else {
-            hipLaunchKernelGGL(k_force_choice, dim3(1), dim3(1), 0, c->stream, c->glob, c->mb, force_slot);
+            hipLaunchKernelGGL(k_prefinal, dim3(max_c, W), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->lgf_tab,
+                               g_tail_quirk, pz);
         }
     }
 }
 
-static void enqueue_apply(ig_ctx* c, int move, int forced)
+/* scores + argmax of slot w (or the forced choice of ig_apply) */
+static void enqueue_choose(ig_ctx* c, int w, int force_slot)
+{
+    TimedLaunch t(c, T_ARGMAX);
+    if (force_slot < 0) hipLaunchKernelGGL(k_scores, dim3(1), dim3(256), 0, c->stream, c->glob, c->mb, w);
+    else hipLaunchKernelGGL(k_force_choice, dim3(1), dim3(1), 0, c->stream, c->glob, c->mb, force_slot);
+}
+
+/* one-move tail: exact delta, apply, genome distance, result record */
+static void enqueue_apply(ig_ctx* c, int move, int w, int forced)
 {
     const int N = c->N;
+    const PzTab pz{c->pz_tab, c->pz_n};
     {
         TimedLaunch t(c, T_DELTA);
-        hipLaunchKernelGGL(k_score<true>, dim3(DELTA_RB, 2, 1), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob,
-                           c->mb, c->lgf_tab, 0, 1, PzTab{c->pz_tab, c->pz_n});
+        hipLaunchKernelGGL(k_delta, dim3(DELTA_RB, 2, 1), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb,
+                           c->lgf_tab, pz, w);
     }
     {
         TimedLaunch t(c, T_APPLY);
-        hipLaunchKernelGGL(k_apply, dim3(64), dim3(256), 0, c->stream, c->st, c->tab, c->glob, c->mb, c->q_part, forced, c->prev_touched);
+        hipLaunchKernelGGL(k_apply, dim3(64), dim3(256), 0, c->stream, c->st, c->tab, c->glob, c->mb, w, forced, c->prev_touched);
     }
     {
         TimedLaunch t(c, T_POST);
@@ -2098,8 +2536,14 @@ static void enqueue_apply(ig_ctx* c, int move, int forced)
     }
     {
         TimedLaunch t(c, T_COMMIT);
-        hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, c->stream, c->glob, c->mb, c->d_results, move);
+        hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, c->stream, c->glob, c->mb, c->d_results, move, w);
     }
+}
+
+static void enqueue_move(ig_ctx* c, int move, int max_c, int force_slot, int phase)
+{
+    enqueue_score(c, move, 1, max_c, force_slot, phase);
+    if (phase == 1 || phase == 2) enqueue_choose(c, 0, force_slot);
 }
 
 static int validate_move(ig_ctx* c, int frag_a, const int32_t* cands, int C)
@@ -2113,6 +2557,8 @@ static int validate_move(ig_ctx* c, int frag_a, const int32_t* cands, int C)
     }
     return 0;
 }
+
+static int g_batch_w = -1; /* moves scored per launch in ig_step_batch: env IG_BATCH_W, default 16; 1 = one move at a time */
 
 extern "C" int ig_step_batch(ig_ctx* c, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c,
                              ig_move_result* results)
@@ -2128,13 +2574,51 @@ extern "C" int ig_step_batch(ig_ctx* c, int32_t n_moves, const int32_t* frags, c
             if (cands[(size_t)i * max_c + k] >= 0) return fail("ig_step_batch: candidates must be packed before the -1 padding");
         if (validate_move(c, frags[i], cands + (size_t)i * max_c, C)) return -1;
     }
-    if (ensure_move_buffers(c, std::max(8, (int)max_c))) return -1;
+    if (g_batch_w < 0) {
+        const char* e = getenv("IG_BATCH_W");
+        g_batch_w = e ? atoi(e) : 16;
+        g_batch_w = std::min(std::max(g_batch_w, 1), IG_MAX_BATCH);
+    }
+    const int Wmax = (c->world > 1) ? 1 : g_batch_w;
+    if (ensure_move_buffers(c, std::max(8, (int)max_c), Wmax)) return -1;
     if (ensure_io(c, n_moves, max_c)) return -1;
     HIPCK(hipMemcpyAsync(c->d_frags, frags, (size_t)n_moves * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCK(hipMemcpyAsync(c->d_cands, cands, (size_t)n_moves * max_c * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    for (int i = 0; i < n_moves; i++) {
-        enqueue_move(c, i, max_c, -1, 2);
-        enqueue_apply(c, i, 0);
+    if (Wmax == 1) {
+        for (int i = 0; i < n_moves; i++) {
+            enqueue_move(c, i, max_c, -1, 2);
+            enqueue_apply(c, i, 0, 0);
+        }
+    } else {
+        /* speculative batches: score W moves against the same state, commit the conflict-free prefix on the device,
+         * finish a winner that needs the exact delta pass with the one-move tail, continue after it */
+        int done = 0;
+        int W = Wmax;
+        while (done < n_moves) {
+            const int w_now = std::min(W, n_moves - done);
+            enqueue_score(c, done, w_now, max_c, -1, 2);
+            {
+                TimedLaunch t(c, T_COMMIT);
+                hipLaunchKernelGGL(k_commit_batch, dim3(1), dim3(256), 0, c->stream, c->st, c->tab, c->tab_prev, c->glob, c->mb,
+                                   c->init_prev, c->init_next, c->orientable, c->black, c->stamp, c->prev_touched, c->d_results, done,
+                                   w_now, c->batch_out);
+            }
+            int bo[2];
+            HIPCK(hipMemcpyAsync(bo, c->batch_out, sizeof bo, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(hipStreamSynchronize(c->stream));
+            c->n_batches++;
+            c->n_batch_committed += bo[0];
+            done += bo[0];
+            if (bo[1] >= 0) { /* slot bo[1] == bo[0] chose a windowed winner: delta + apply with the one-move kernels */
+                enqueue_apply(c, done, bo[1], 0);
+                c->n_batch_pending++;
+                done += 1;
+            } else if (bo[0] == 0) {
+                Glob hg;
+                HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));
+                return fail("device-side consistency failure %d in a batch at move %d", hg.error, done);
+            }
+        }
     }
     HIPCK(hipMemcpyAsync(results, c->d_results, (size_t)n_moves * sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
@@ -2142,6 +2626,20 @@ extern "C" int ig_step_batch(ig_ctx* c, int32_t n_moves, const int32_t* frags, c
     drain_timers(c);
     for (int i = 0; i < n_moves; i++)
         if (results[i].error) return fail("device-side consistency failure %d at move %d", results[i].error, i);
+    return 0;
+}
+
+extern "C" int ig_set_batch_width(int w)
+{
+    g_batch_w = std::min(std::max(w, 1), IG_MAX_BATCH);
+    return 0;
+}
+
+extern "C" int ig_batch_stats(ig_ctx* c, int64_t out3[3])
+{
+    out3[0] = c->n_batches;
+    out3[1] = c->n_batch_committed;
+    out3[2] = c->n_batch_pending;
     return 0;
 }
 
@@ -2156,7 +2654,7 @@ extern "C" int ig_step(ig_ctx* c, int32_t frag_a, const int32_t* cands, int32_t 
     HIPCK(hipMemcpyAsync(c->d_cands, cands, (size_t)C * sizeof(int), hipMemcpyHostToDevice, c->stream));
     enqueue_move(c, 0, C, -1, 2);
     if (scores) HIPCK(hipMemcpyAsync(scores, c->mb.scores, (size_t)C * IG_N_TMP_STRUCT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    enqueue_apply(c, 0, 0);
+    enqueue_apply(c, 0, 0, 0);
     HIPCK(hipMemcpyAsync(out, c->d_results, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
     HIPCK(hipGetLastError());
@@ -2193,7 +2691,7 @@ extern "C" int ig_apply(ig_ctx* c, int32_t frag_a, int32_t frag_b, int32_t op)
     HIPCK(hipMemcpyAsync(c->d_frags, &frag_a, sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCK(hipMemcpyAsync(c->d_cands, &frag_b, sizeof(int), hipMemcpyHostToDevice, c->stream));
     enqueue_move(c, 0, 1, op, 2);
-    enqueue_apply(c, 0, 1);
+    enqueue_apply(c, 0, 0, 1);
     ig_move_result r;
     HIPCK(hipMemcpyAsync(&r, c->d_results, sizeof r, hipMemcpyDeviceToHost, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
@@ -2236,12 +2734,12 @@ extern "C" int ig_step_finish(ig_ctx* c, ig_move_result* out, double* scores)
     enqueue_move(c, 0, IG_MAX_CANDIDATES, -1, 1);
     (void)C;
     if (scores) {
-        Glob hg;
-        HIPCK(hipMemcpyAsync(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost, c->stream));
+        MoveCtl mc;
+        HIPCK(hipMemcpyAsync(&mc, c->mb.ctl, sizeof mc, hipMemcpyDeviceToHost, c->stream));
         HIPCK(hipStreamSynchronize(c->stream));
-        HIPCK(hipMemcpyAsync(scores, c->mb.scores, (size_t)hg.C * IG_N_TMP_STRUCT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipMemcpyAsync(scores, c->mb.scores, (size_t)mc.C * IG_N_TMP_STRUCT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
-    enqueue_apply(c, 0, 0);
+    enqueue_apply(c, 0, 0, 0);
     HIPCK(hipMemcpyAsync(out, c->d_results, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
     HIPCK(hipGetLastError());
@@ -2348,11 +2846,13 @@ extern "C" int ig_debug_last_sums(ig_ctx* c, int64_t* nz_hi, int64_t* nz_lo, int
     HIPCK(hipStreamSynchronize(c->stream));
     Glob hg;
     HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));
-    const int C = hg.C;
+    MoveCtl mc;
+    HIPCK(hipMemcpy(&mc, c->mb.ctl, sizeof mc, hipMemcpyDeviceToHost));
+    const int C = mc.C;
     std::vector<long long> part((size_t)C * P_STRIDE), qp((size_t)C * Q_STRIDE);
     std::vector<CandMeta> meta(C);
     HIPCK(hipMemcpy(part.data(), c->mb.part, part.size() * sizeof(long long), hipMemcpyDeviceToHost));
-    HIPCK(hipMemcpy(qp.data(), c->q_part, qp.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(qp.data(), c->mb.qpart, qp.size() * sizeof(long long), hipMemcpyDeviceToHost));
     HIPCK(hipMemcpy(meta.data(), c->mb.meta, C * sizeof(CandMeta), hipMemcpyDeviceToHost));
     for (int cc_ = 0; cc_ < C; cc_++) {
         const long long* p = &part[(size_t)cc_ * P_STRIDE];
@@ -2372,7 +2872,12 @@ extern "C" int ig_debug_last_sums(ig_ctx* c, int64_t* nz_hi, int64_t* nz_lo, int
             const int s = meta[cc_].uniq[k - 1];
             const int o = cc_ * IG_N_TMP_STRUCT + s;
             uniq[cc_ * IG_N_TMP_STRUCT + (k - 1)] = s;
-            int64_t h = p[P_NZ + 2 * k], l = p[P_NZ + 2 * k + 1];
+            int64_t h = q[Q_NZFULL + 2 * k], l = q[Q_NZFULL + 2 * k + 1];
+            const int r = (int)(p[P_CNT] % 64);
+            if (r > 0 && (k - 1) >= r) { /* quirk Q5 */
+                h -= q[Q_TAIL + 2 * k];
+                l -= q[Q_TAIL + 2 * k + 1];
+            }
             ig_acc_normalize(&h, &l);
             nz_hi[o] = h;
             nz_lo[o] = l;
@@ -2424,9 +2929,13 @@ extern "C" int ig_debug_globals(ig_ctx* c, int64_t* sums5, int32_t* ints6)
     sums5[4] = hg.n_intra;
     ints6[0] = hg.n_contigs;
     ints6[1] = hg.next_cid;
-    ints6[2] = hg.ch_c;
-    ints6[3] = hg.ch_k;
-    ints6[4] = hg.ch_slot;
-    ints6[5] = hg.ch_windowed;
+    MoveCtl mc;
+    memset(&mc, 0, sizeof mc);
+    if (c->mb.ctl) HIPCK(hipMemcpy(&mc, c->mb.ctl, sizeof mc, hipMemcpyDeviceToHost));
+    ints6[2] = mc.ch_c;
+    ints6[3] = mc.ch_k;
+    ints6[4] = mc.ch_slot;
+    ints6[5] = mc.ch_windowed;
+
     return 0;
 }

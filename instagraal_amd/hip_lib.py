@@ -44,7 +44,7 @@ def build_lib(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in DEPS):
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-Wno-unused-result", "-o", LIB_PATH, SRC]
+           "-Wno-unused-result", "-Wno-unused-value", "-o", LIB_PATH, SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -80,6 +80,11 @@ def _ck(rc):
 
 def _p(a):
     return C.c_void_p(0) if a is None else C.c_void_p(a.ctypes.data)
+
+
+def set_batch_width(w):
+    """moves scored per launch by ``Context.step_batch`` (1 = one move at a time; results do not depend on it)"""
+    _ck(lib().ig_set_batch_width(C.c_int(int(w))))
 
 
 class Context:
@@ -181,6 +186,11 @@ class Context:
         res = np.zeros(f.size, MOVE_RESULT_DTYPE)
         _ck(lib().ig_step_batch(self._h, C.c_int32(f.size), _p(f), _p(c), C.c_int32(c.shape[1]), _p(res)))
         return res
+
+    def batch_stats(self):
+        o = np.zeros(3, np.int64)
+        _ck(lib().ig_batch_stats(self._h, _p(o)))
+        return dict(batches=int(o[0]), committed_in_batch=int(o[1]), one_move_tails=int(o[2]))
 
     # ---- bookkeeping
     def renumber_contigs(self):

@@ -110,6 +110,40 @@ def test_batch_equals_step_by_step():
     assert np.array_equal(outs[0][2], outs[1][2])
 
 
+@pytest.mark.parametrize("cfg,n_moves", [("tiny", 150), ("small", 400)])
+def test_speculative_batches_equal_one_move_at_a_time(cfg, n_moves):
+    """ig_step_batch scores W moves against one state and commits them in order on the device; every result
+    record, the final genome, the maintained exact sums and the pre-move tables (quirk Q12) must not depend on W."""
+    from instagraal_amd import hip_lib, synth
+    from instagraal_amd.sampler import sampler as hip_sampler
+
+    prob = synth.make_problem(*synth.CONFIGS[cfg])
+    outs = []
+    try:
+        for W in (1, 2, 5, 16, 32):
+            hip_lib.set_batch_width(W)
+            np.random.seed(9)
+            s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
+            s.set_param_simu(prob.params)
+            s.eval_likelihood_init()
+            frags = np.resize(np.random.permutation(prob.n_frags), n_moves).astype(np.int32)
+            cands = s.draw_candidates(frags, 5)
+            res = s.ctx.step_batch(frags, cands)
+            sums, ints = s.ctx.debug_globals()
+            _, _, limbs = s.ctx.full_likelihood(0)
+            assert (int(sums[0]), int(sums[1])) == (int(limbs[0]), int(limbs[1])), W
+            prev = s.ctx.full_likelihood(0, use_prev_tables=True)
+            outs.append((res.tobytes(), s.gpu_vect_frags.copy_from_gpu().soa17(), [int(x) for x in sums], int(ints[0]),
+                         [int(x) for x in prev[2]], [int(x) for x in s.ctx.valid_insert()], s.ctx.batch_stats()))
+    finally:
+        hip_lib.set_batch_width(16)
+    for W, o in zip((2, 5, 16, 32), outs[1:]):
+        assert o[0] == outs[0][0], W
+        assert np.array_equal(o[1], outs[0][1]), W
+        assert o[2:6] == outs[0][2:6], W
+    assert outs[3][6]["batches"] < n_moves  # speculation actually happened
+
+
 def test_forced_apply_matches_oracle_and_keeps_sums_exact():
     """ig_apply == test_copy_struct (CL:2094-2151) for every mutation family; the maintained exact
     likelihood equals a from-scratch recomputation after each."""
