@@ -95,7 +95,7 @@ int ig_step(ig_ctx* ctx, int32_t frag_a, const int32_t* cands, int32_t C, ig_mov
  * re-scored in the next batch, so the results are identical to n_moves calls of ig_step for every W. */
 int ig_step_batch(ig_ctx* ctx, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c,
                   ig_move_result* results);
-int ig_set_batch_width(int w);                        /* W in 1..32 (default 16, env IG_BATCH_W); 1 = no speculation */
+int ig_set_batch_width(int w);                        /* W in 1..32 (default 24, env IG_BATCH_W); 1 = no speculation */
 int ig_batch_stats(ig_ctx* ctx, int64_t out3[3]);     /* {batches launched, moves committed in-batch, one-move tails} */
 
 /* ---- bookkeeping -------------------------------------------------------- */

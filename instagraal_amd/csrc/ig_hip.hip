@@ -120,6 +120,25 @@ struct MoveCtl {
     long long d_hi, d_lo; /* k_delta accumulator */
 };
 
+/* what the commit step needs about one (candidate, mutation slot), written slot-major by k_prefinal */
+struct SlotPre {
+    long long nz_hi, nz_lo;     /* slice sum under this slot's genome (all sliced contacts) */
+    long long tail_hi, tail_lo; /* the part quirk Q5 drops when the slot's list position is >= S_c mod 64 */
+    long long dz_hi, dz_lo, dni; /* zero-pixel sum and intra pair count: this genome minus the current one, on the window */
+    int k;                      /* coordinate column (0 = not scored) */
+    int changed;                /* the mutated window differs from the current genome */
+    int heads;                  /* contigs on the mutated window */
+    int pad;
+};
+struct CandPre {
+    long long ext_hi, ext_lo; /* slice sum under the current genome */
+    long long n_slice;
+    int r;                    /* S_c mod 64 */
+    int base_cnt;             /* list entries before the block-insert slots */
+    int n_uniq_basic;         /* == base_cnt (kept for the statistics) */
+    int pad;
+};
+
 struct MoveBuf {
     int* Lloc;      /* [capW*capC][N] global ids of local fragments */
     int* lbloc;     /* [..][N] */
@@ -140,6 +159,9 @@ struct MoveBuf {
     long long* qpart;/* [..][Q_STRIDE] sums every rank computes redundantly */
     double* scores; /* [..][24] */
     MoveCtl* ctl;   /* [capW] */
+    int2* sinfo;    /* [..][NSLOT] (changed, contig heads) of each candidate genome (k_mutate) */
+    SlotPre* pre;   /* [..][24] */
+    CandPre* cpre;  /* [..] */
     int N, M, capC, capW;
 };
 /* layout of MoveBuf.part per candidate (int64 units) */
@@ -174,7 +196,9 @@ struct ig_ctx {
     Glob* glob;
     MoveBuf mb;
     int* stamp;     /* [N] claim stamps of the incremental genome distance */
-    int* batch_out; /* [2] committed moves, pending slot */
+    int* batch_out; /* [4] committed moves, pending slot, windows above LDS_COL_SMALL, candidates */
+    int* dirty_buf; /* [1 + 2 * IG_MAX_BATCH + 2] contigs modified by the committed moves of the batch in flight */
+    int *own_tag, *own_idx; /* [N] which committed move of the current batch owns a fragment, and where in its window */
     ig_move_result* d_results;
     int results_cap;
     int* d_frags;
@@ -778,6 +802,29 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
         igd::op_extract_block(S, A, cutpos, up, fresh);
         igd::op_insert_block(S, A, B, g_ext, m.flags[slot - 12], up);
     }
+    /* ---- does this slot change the genome at all, and how many contigs does the window hold afterwards */
+    __syncthreads();
+    {
+        int ch = 0, hd = 0;
+        for (int x = threadIdx.x; x < n; x += blockDim.x) {
+            const int f = S.gid[x];
+            ch |= (S.pos[x] != st.pos[f]) | (S.spos[x] != st.spos[f]) | (S.cid[x] != st.cid[f]) | (S.sbp[x] != st.sbp[f]) |
+                  (S.circ[x] != st.circ[f]) | (S.prev[x] != st.prev[f]) | (S.next[x] != st.next[f]) | (S.L[x] != st.L[f]) |
+                  (S.SL[x] != st.SL[f]) | (S.LB[x] != st.LB[f]) | (S.ori[x] != st.ori[f]);
+            hd += (S.pos[x] == 0);
+        }
+        __shared__ int sh_ch, sh_hd;
+        if (threadIdx.x == 0) {
+            sh_ch = 0;
+            sh_hd = 0;
+        }
+        __syncthreads();
+        hd = wave_sum_i(hd);
+        if ((threadIdx.x & 63) == 0 && hd) atomicAdd(&sh_hd, hd);
+        if (ch) atomicOr(&sh_ch, 1);
+        __syncthreads();
+        if (threadIdx.x == 0) mb.sinfo[cw * NSLOT + slot] = make_int2(sh_ch, sh_hd);
+    }
     /* ---- coordinate column k (fill_vect_dist, KA:3699-3760) + zero-pixel sums on the window */
     const ig_params p = g->par[0];
     const float mean = g->mean_kb;
@@ -844,22 +891,45 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
 
 /* k_offsets: where each candidate's slice list starts in the pool = exclusive prefix sum of the upper bounds
  * (one small workgroup; a slot whose lists do not fit is flagged and re-run at the head of the next batch) */
-__global__ void k_offsets(MoveBuf mb, int W)
+__global__ void __launch_bounds__(64) k_offsets(MoveBuf mb, int W)
 {
-    if (threadIdx.x != 0) return;
-    long long off = 0;
-    for (int w = 0; w < W; w++) {
-        const int C = mb.ctl[w].C;
-        for (int c = 0; c < C; c++) {
-            const int cw = CW(w, c);
-            const long long b = mb.slbound[cw];
-            if (off + b > mb.pool_cap) {
-                mb.sloff[cw] = -1;
-                mb.ctl[w].overflow = 1;
-            } else {
-                mb.sloff[cw] = off;
-                off += b;
+    /* one wave: lane l owns the `per` consecutive (slot, candidate) entries l*per .. ; exclusive scan across lanes */
+    const int lane = threadIdx.x;
+    const int n = W * mb.capC;
+    const int per = (n + 63) / 64;
+    long long b[(IG_MAX_BATCH * IG_MAX_CANDIDATES + 63) / 64];
+    long long sum = 0;
+#pragma unroll
+    for (int q = 0; q < (IG_MAX_BATCH * IG_MAX_CANDIDATES + 63) / 64; q++) {
+        const int i = lane * per + q;
+        long long v = 0;
+        if (q < per && i < n) {
+            const int w = i / mb.capC, c = i % mb.capC;
+            if (c < mb.ctl[w].C) v = mb.slbound[i];
+        }
+        b[q] = v;
+        sum += v;
+    }
+    long long incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    long long run = incl - sum;
+#pragma unroll
+    for (int q = 0; q < (IG_MAX_BATCH * IG_MAX_CANDIDATES + 63) / 64; q++) {
+        const int i = lane * per + q;
+        if (q < per && i < n) {
+            const int w = i / mb.capC, c = i % mb.capC;
+            if (c < mb.ctl[w].C) {
+                if (run + b[q] > mb.pool_cap) {
+                    mb.sloff[i] = -1;
+                    mb.ctl[w].overflow = 1;
+                } else {
+                    mb.sloff[i] = run;
+                }
             }
+            run += b[q];
         }
     }
 }
@@ -1185,9 +1255,18 @@ __global__ void __launch_bounds__(SCORE_THREADS)
  * pairs near A and B): sum over ALL pairs of the contig of (term under the winner - term under the current
  * genome).  Row-parallel with a per-wave compaction queue; two columns (current, winner). */
 __global__ void __launch_bounds__(SCORE_THREADS)
-    k_delta(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, Glob* g, MoveBuf mb,
-            const double* __restrict__ lgf_tab, PzTab pz, int w)
+    k_delta(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, Tables tab_prev,
+            const int* __restrict__ prev_touched, Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int w)
 {
+    /* tab_prev catches up with the last applied move before k_apply replaces the touched list (quirk Q12) */
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < g->n_prev_touched;
+         i += gridDim.x * gridDim.y * blockDim.x) {
+        const int s = prev_touched[i];
+        tab_prev.dist[s] = tab.dist[s];
+        tab_prev.stot[s] = tab.stot[s];
+        tab_prev.cp[s] = tab.cp[s];
+        tab_prev.len[s] = tab.len[s];
+    }
     __shared__ uint2 lcol[LDS_COL_CAP];
     __shared__ long long red[2][SCORE_THREADS / 64];
     __shared__ int q_li[SCORE_THREADS / 64][128], q_lj[SCORE_THREADS / 64][128], q_ob[SCORE_THREADS / 64][128];
@@ -1304,8 +1383,8 @@ __device__ __forceinline__ int wave_max_i(int v)
  * order, so "last" = highest rows, found by bisection on the row id).  Quirk Q5 (KA:4362, block 64 CL:200):
  * a column at list position >= r never receives those contacts; which columns that applies to is decided
  * when the uniq list is known (k_scores / k_commit_batch). */
-__global__ void __launch_bounds__(256) k_prefinal(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
-                                                  Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz)
+__device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, Glob* g, MoveBuf mb,
+                              const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz)
 {
     __shared__ int t_li[64], t_lj[64], t_ob[64], t_rows[64];
     __shared__ int sh_n_rows, sh_n_tail, sh_cnt;
@@ -1418,6 +1497,53 @@ __global__ void __launch_bounds__(256) k_prefinal(const long long* __restrict__ 
             qp[Q_TAIL + 2 * k] = hi;
             qp[Q_TAIL + 2 * k + 1] = lo;
         }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_prefinal(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
+                                                  Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz)
+{
+    const int c = blockIdx.x, w = blockIdx.y;
+    if (c >= mb.ctl[w].C) return;
+    prefinal_tail(rowptr, cc, tab, g, mb, lgf_tab, tail_quirk, pz);
+    __syncthreads();
+    /* slot-major records for the commit step */
+    const int cw = CW(w, c);
+    const CandMeta& m = mb.meta[cw];
+    const long long* qp = mb.qpart + (size_t)cw * Q_STRIDE;
+    const int t = threadIdx.x;
+    if (t < IG_N_TMP_STRUCT) {
+        SlotPre r;
+        const int k = m.kidx[t];
+        r.k = k > 0 ? k : 0;
+        r.nz_hi = r.nz_lo = r.tail_hi = r.tail_lo = r.dz_hi = r.dz_lo = r.dni = 0;
+        r.changed = r.heads = r.pad = 0;
+        if (k > 0) {
+            r.nz_hi = qp[Q_NZFULL + 2 * k];
+            r.nz_lo = qp[Q_NZFULL + 2 * k + 1];
+            r.tail_hi = qp[Q_TAIL + 2 * k];
+            r.tail_lo = qp[Q_TAIL + 2 * k + 1];
+            r.dz_hi = qp[Q_Z + 2 * k] - qp[Q_Z];
+            r.dz_lo = qp[Q_Z + 2 * k + 1] - qp[Q_Z + 1];
+            r.dni = qp[Q_NI + k] - qp[Q_NI];
+            const int2 si = mb.sinfo[cw * NSLOT + t];
+            r.changed = si.x;
+            r.heads = si.y;
+        }
+        mb.pre[(size_t)cw * IG_N_TMP_STRUCT + t] = r;
+    }
+    if (t == 0) {
+        CandPre cp;
+        cp.ext_hi = qp[Q_NZFULL];
+        cp.ext_lo = qp[Q_NZFULL + 1];
+        cp.n_slice = mb.part[(size_t)cw * P_STRIDE + P_CNT];
+        cp.r = (int)(cp.n_slice % 64);
+        int nb = 0;
+        for (int q = 0; q < m.n_uniq; q++) nb += (m.uniq[q] < 12);
+        cp.base_cnt = nb;
+        cp.n_uniq_basic = nb;
+        cp.pad = 0;
+        mb.cpre[cw] = cp;
     }
 }
 
@@ -1672,141 +1798,403 @@ __global__ void k_commit(Glob* g, MoveBuf mb, ig_move_result* res, int move, int
     write_result(g, mb, w, res + move);
 }
 
-/* k_commit_batch: the sequential half of a batch, one workgroup.  For w = 0, 1, ...: stop if a contig of move w
- * was modified by an earlier move of this batch (its scores were computed against a stale state); otherwise
- * score + argmax with the live scalars, apply, update the genome distance incrementally, write the result.
- * A winner whose slice was windowed needs the exact k_delta pass first: the batch then stops BEFORE applying it
- * (pending) and the host finishes that move with the one-move kernels. */
-__global__ void __launch_bounds__(256)
-    k_commit_batch(State st, Tables tab, Tables tab_prev, Glob* g, MoveBuf mb, const int* __restrict__ ip, const int* __restrict__ in,
-                   const int* __restrict__ orientable, const unsigned char* __restrict__ black, int* stamp, int* prev_touched,
-                   ig_move_result* res, int move0, int W, int* batch_out /* [0] = committed, [1] = pending slot or -1 */)
+/* credit of fragment f (dist_inter_genome, CL:665-716) when the genome is read through an accessor: V(x) returns
+ * (prev, next, ori) of x as of the moment being evaluated */
+template <class V>
+__device__ __forceinline__ int credit2_view(V view, const int* ip, const int* in, const int* orientable, int f)
 {
-    __shared__ double sc[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT];
-    __shared__ int vf[12];
-    __shared__ int dirty[IG_MAX_BATCH * 2];
-    __shared__ int n_dirty, sh_stop, sh_changed;
-    __shared__ long long sh_c2[2];
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        n_dirty = 0;
-        batch_out[0] = 0;
-        batch_out[1] = -1;
+    const int p0 = ip[f], n0 = in[f];
+    const int3 sf = view(f);
+    int p1 = sf.x, n1 = sf.y;
+    const int o1 = sf.z;
+    int c2 = 0;
+    if (((p1 == p0) && (n1 == n0)) || ((p1 == n0) && (n1 == p0))) c2 += 2;
+    if (orientable[f]) {
+        int swap = 1;
+        if (1 != o1) {
+            int t = p1;
+            p1 = n1;
+            n1 = t;
+            swap = -1;
+        }
+        if (p0 == p1) {
+            if (p0 == -1) c2 += 2;
+            else if (!orientable[p1]) c2 += 2;
+            else c2 += 1 + ((1 == swap * view(p1).z) ? 1 : 0);
+        }
+        if (n0 == n1) {
+            if (n0 == -1) c2 += 2;
+            else if (!orientable[n1]) c2 += 2;
+            else c2 += 1 + ((1 == swap * view(n1).z) ? 1 : 0);
+        }
+    } else {
+        if ((p1 == p0) || (p1 == n0)) c2 += 2;
+        if ((n1 == n0) || (n1 == p0)) c2 += 2;
+    }
+    return c2;
+}
+
+/* k_commit_batch: the sequential half of a batch, one workgroup.
+ *
+ * 1. DECIDE (wave 0, no barriers): for w = 0, 1, ...: stop if a contig of move w was modified by an earlier move of
+ *    this batch (its scores were computed against a stale state) or if its slice did not fit the pool; otherwise score
+ *    and argmax with the LIVE scalars (kept in registers) from the slot-major records of k_prefinal, update the scalars,
+ *    write the result record.  A winner whose slice was windowed and that changes the genome needs the exact k_delta
+ *    pass: the batch stops BEFORE it (pending) and the host finishes that move with the one-move kernels.
+ * 2. APPLY (whole workgroup): the committed moves touch pairwise disjoint contigs, so their winners are applied
+ *    together: ownership marks, exact genome-distance deltas (each move's credits evaluated on the genome as of just
+ *    before / just after that move, read through the marks), state + coordinate tables, the distance column of the
+ *    results.  tab_prev receives every committed move but the last one (quirk Q12: tables before the last move). */
+#define COMMIT_THREADS 1024
+__global__ void __launch_bounds__(COMMIT_THREADS)
+    k_commit_batch(State st, Tables tab, Tables tab_prev, Glob* g, MoveBuf mb, const int* __restrict__ ip, const int* __restrict__ in,
+                   const int* __restrict__ orientable, const unsigned char* __restrict__ black, int* stamp, int* own_tag, int* own_idx,
+                   int* prev_touched, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out)
+{
+    /* w_start > 0: slot w_start - 1 was the pending move, meanwhile applied by the one-move kernels; the rest of the batch
+     * is still valid wherever it does not touch a contig modified so far (dirty_buf carries the list across the calls) */
+    __shared__ int dirty[IG_MAX_BATCH * 2 + 2];
+    __shared__ int sh_committed, sh_pending;
+    __shared__ long long sh_delta[IG_MAX_BATCH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tag_base = g->stamp_ctr; /* tags/stamps of this batch: tag_base + w */
+    if (tid < IG_MAX_BATCH) sh_delta[tid] = 0;
+    if (tid < 64) {
+        /* ------------------------------------------------------------ 1. decide */
+        long long nz_hi = g->nz_hi, nz_lo = g->nz_lo, z_hi = g->z_hi, z_lo = g->z_lo, n_intra = g->n_intra;
+        int n_contigs = g->n_contigs, next_cid = g->next_cid;
+        const int err0 = g->error;
+        unsigned vmask = 0;
+        {
+            const int v = (lane < 12) ? g->valid_insert[lane] : -1;
+            vmask = (unsigned)__ballot(lane < 12 && v != -1);
+        }
+        const ig_params p = g->par[0];
+        const double log_e = IG_LOG_E_F;
+        const double n_tot_pxl = g->n_tot_pxl;
+        int n_dirty = 0, committed = w_start, pending = -1, n_large = 0, n_cand = 0;
+        if (w_start > 0) {
+            n_dirty = dirty_buf[0];
+            for (int q = lane; q < n_dirty; q += 64) dirty[q] = dirty_buf[1 + q];
+            const MoveCtl pm = mb.ctl[w_start - 1];
+            const CandMeta& m = mb.meta[CW(w_start - 1, pm.ch_c)];
+            if (lane == 0) {
+                dirty[n_dirty] = m.ctgA;
+                dirty[n_dirty + 1] = m.ctgB;
+            }
+            n_dirty += 2;
+        }
+        for (int w = w_start; w < W; w++) {
+            const MoveCtl mc = mb.ctl[w];
+            const int C = mc.C;
+            /* conflict with an earlier move of this batch? */
+            int cA = -1, cB = -1, mloc = 0;
+            if (lane < C) {
+                const CandMeta& m = mb.meta[CW(w, lane)];
+                cA = m.ctgA;
+                cB = m.ctgB;
+                mloc = m.m_loc;
+            }
+            bool hitd = false;
+            for (int q = 0; q < n_dirty; q++) hitd |= (dirty[q] == cA) | (dirty[q] == cB);
+            if (err0 || mc.overflow || __any(hitd && lane < C)) break;
+            n_large += __popcll(__ballot(lane < C && mloc > LDS_COL_SMALL));
+            n_cand += C;
+            /* scores (eval_all_likelihood_on_zero_2nd KA:4005-4027, eval_all_scores KA:4029-4046) with the live scalars */
+            const double cur_nz = ig_acc_to_double(nz_hi, nz_lo);
+            const int n = C * IG_N_TMP_STRUCT;
+            double sc[(IG_MAX_CANDIDATES * IG_N_TMP_STRUCT + 63) / 64];
+            double mx = -IG_INF;
+#pragma unroll
+            for (int j = 0; j < (IG_MAX_CANDIDATES * IG_N_TMP_STRUCT + 63) / 64; j++) {
+                const int i = lane + 64 * j;
+                double v = 0.0;
+                if (i < n) {
+                    const int c = i / IG_N_TMP_STRUCT, slot = i % IG_N_TMP_STRUCT;
+                    const int cw = CW(w, c);
+                    const SlotPre r = mb.pre[(size_t)cw * IG_N_TMP_STRUCT + slot];
+                    const CandPre cp = mb.cpre[cw];
+                    const bool sup = (c == 0) && mc.superset0 && (slot >= 12);
+                    const bool scored = (r.k > 0) && !(sup && !((vmask >> (slot - 12)) & 1u));
+                    if (scored) {
+                        const int pos = sup ? cp.base_cnt + __popc(vmask & ((1u << (slot - 12)) - 1u)) : r.k - 1;
+                        long long nh = r.nz_hi, nl = r.nz_lo;
+                        if (cp.r > 0 && pos >= cp.r) { /* quirk Q5 */
+                            nh -= r.tail_hi;
+                            nl -= r.tail_lo;
+                        }
+                        const double ext = ig_acc_to_double(cp.ext_hi, cp.ext_lo);
+                        const double val_inter = -1.0 * log_e * (n_tot_pxl - (double)(n_intra + r.dni)) * p.v_inter;
+                        const double val_intra = ig_acc_to_double(z_hi + r.dz_hi, z_lo + r.dz_lo) * log_e;
+                        const double z = val_intra + val_inter;
+                        v = ig_acc_to_double(nh, nl) + z + cur_nz - ext;
+                    }
+                }
+                sc[j] = v;
+                const double ok = (v == 0.0) ? -IG_INF : v;
+                mx = ok > mx ? ok : mx;
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double o = __shfl_xor(mx, off, 64);
+                mx = o > mx ? o : mx;
+            }
+            /* host argmax of CL:1435-1446: zeros -> -inf, shifted and clipped, FIRST index of the maximum */
+            double bestv = -IG_INF, bests = 0.0;
+            int best = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < (IG_MAX_CANDIDATES * IG_N_TMP_STRUCT + 63) / 64; j++) {
+                const int i = lane + 64 * j;
+                if (i < n) {
+                    const double ok = (sc[j] == 0.0) ? -IG_INF : sc[j];
+                    double fs = ok - (mx - 30.0);
+                    if (fs < 0) fs = 0;
+                    if (fs > bestv) {
+                        bestv = fs;
+                        best = i;
+                        bests = sc[j];
+                    }
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ov = __shfl_xor(bestv, off, 64);
+                const double os = __shfl_xor(bests, off, 64);
+                const int oi = __shfl_xor(best, off, 64);
+                if (ov > bestv || (ov == bestv && oi < best)) {
+                    bestv = ov;
+                    best = oi;
+                    bests = os;
+                }
+            }
+            if (best >= n) {
+                best = 0;
+                bests = __shfl(sc[0], 0, 64);
+            }
+            const int bc = best / IG_N_TMP_STRUCT, bslot = best % IG_N_TMP_STRUCT;
+            const int bcw = CW(w, bc);
+            const SlotPre br = mb.pre[(size_t)bcw * IG_N_TMP_STRUCT + bslot];
+            const CandMeta& bm = mb.meta[bcw];
+            const int windowed = bm.windowed;
+            /* statistics of the move */
+            long long Sc = 0, ev = 0, by = 0;
+            if (lane < C) {
+                const CandMeta& m = mb.meta[CW(w, lane)];
+                const CandPre cp = mb.cpre[CW(w, lane)];
+                int nu = m.n_uniq;
+                if (lane == 0 && mc.superset0) nu = cp.base_cnt + __popc(vmask); /* the list the reference would have scored */
+                Sc = cp.n_slice;
+                ev = Sc * (nu + 1);
+                by = 12 * Sc + 20LL * m.m_loc * nu + 8LL * nu;
+            }
+            Sc = wave_sum_ll(Sc);
+            ev = wave_sum_ll(ev);
+            by = wave_sum_ll(by);
+            Sc = __shfl(Sc, 0, 64);
+            ev = __shfl(ev, 0, 64);
+            by = __shfl(by, 0, 64);
+            if (lane == 0) {
+                MoveCtl& o = mb.ctl[w];
+                o.ch_c = bc;
+                o.ch_slot = bslot;
+                o.ch_k = br.k;
+                o.ch_windowed = windowed;
+                o.ch_score = bests;
+                o.n_slice_tot = Sc;
+                o.n_eval_tot = ev;
+                o.bytes_min = by;
+                o.d_hi = 0;
+                o.d_lo = 0;
+                o.n_dirty = br.changed;
+                if (br.k <= 0) g->error = 3; /* an unscored slot won: cannot happen */
+            }
+            if (windowed && br.changed) { /* needs k_delta: hand this move to the one-move tail */
+                pending = w;
+                break;
+            }
+            /* commit: scalars (exact), stale-flag state (quirk Q4), fresh ids */
+            nz_hi += br.nz_hi - mb.cpre[bcw].ext_hi;
+            nz_lo += br.nz_lo - mb.cpre[bcw].ext_lo;
+            ig_acc_normalize((int64_t*)&nz_hi, (int64_t*)&nz_lo);
+            z_hi += br.dz_hi;
+            z_lo += br.dz_lo;
+            ig_acc_normalize((int64_t*)&z_hi, (int64_t*)&z_lo);
+            n_intra += br.dni;
+            n_contigs += br.heads - (bm.same ? 1 : 2);
+            next_cid += NFRESH;
+            {
+                const CandMeta& fm = (bslot >= 12) ? bm : mb.meta[CW(w, C - 1)];
+                const int v = (lane < 12) ? fm.flags[lane] : -1;
+                vmask = (unsigned)__ballot(lane < 12 && v != -1);
+            }
+            if (lane == 0) {
+                ig_move_result r;
+                r.o = bests;
+                r.dist = 0.0; /* step 2 */
+                r.mean_len = (double)((float)g->N / (float)n_contigs);
+                r.op_sampled = bslot;
+                r.id_f_sampled = bm.B;
+                r.n_contigs = n_contigs;
+                r.n_candidates = C;
+                r.n_slice = Sc;
+                r.n_evals = ev;
+                r.bytes_min = by + 68LL * bm.n_loc;
+                r.error = err0;
+                r.pad = 0;
+                res[move0 + w] = r;
+                if (br.changed) {
+                    dirty[n_dirty] = bm.ctgA;
+                    dirty[n_dirty + 1] = bm.ctgB;
+                }
+            }
+            if (br.changed) n_dirty += 2;
+            committed = w + 1;
+        }
+        if (lane == 0) {
+            g->nz_hi = nz_hi;
+            g->nz_lo = nz_lo;
+            g->z_hi = z_hi;
+            g->z_lo = z_lo;
+            g->n_intra = n_intra;
+            g->n_contigs = n_contigs;
+            g->next_cid = next_cid;
+            sh_committed = committed;
+            sh_pending = pending;
+            dirty_buf[0] = n_dirty;
+            for (int q = 0; q < n_dirty; q++) dirty_buf[1 + q] = dirty[q];
+            batch_out[0] = committed;
+            batch_out[1] = pending;
+            batch_out[2] = n_large;
+            batch_out[3] = n_cand;
+        }
+        if (lane < 12) g->valid_insert[lane] = ((vmask >> lane) & 1u) ? 1 : -1;
     }
     __syncthreads();
-    for (int w = 0; w < W; w++) {
-        MoveCtl& mc = mb.ctl[w];
-        /* 1. conflict: any contig of this move modified earlier in the batch? */
-        if (tid == 0) {
-            int stop = (g->error != 0) || mc.overflow;
-            for (int c = 0; c < mc.C && !stop; c++) {
-                const CandMeta& m = mb.meta[CW(w, c)];
-                for (int q = 0; q < n_dirty; q++)
-                    if (dirty[q] == m.ctgA || dirty[q] == m.ctgB) stop = 1;
-            }
-            sh_stop = stop;
+    const int committed = sh_committed;
+    if (committed == w_start) return;
+    /* ---------------------------------------------------------------- 2. apply */
+    const int N = mb.N, M = mb.M;
+    auto winner_loc = [&](int w) -> const int* {
+        const MoveCtl& mc = mb.ctl[w];
+        return mb.loc + ((size_t)(CW(w, mc.ch_c) * NSLOT + mc.ch_slot) * NDYN) * N;
+    };
+    /* 2a. ownership marks of the fragments whose state changes */
+    for (int w = w_start; w < committed; w++) {
+        const MoveCtl& mc = mb.ctl[w];
+        if (!mc.n_dirty) continue;
+        const int cw = CW(w, mc.ch_c);
+        const int n_loc = mb.meta[cw].n_loc;
+        const int* gid = mb.Lloc + (size_t)cw * N;
+        for (int x = tid; x < n_loc; x += blockDim.x) {
+            const int f = gid[x];
+            own_tag[f] = tag_base + w;
+            own_idx[f] = x;
         }
-        if (tid < 12) vf[tid] = g->valid_insert[tid];
-        __syncthreads();
-        if (sh_stop) break;
-        /* 2. scores with the live scalars, argmax */
-        score_and_choose(g, mb, w, vf, sc);
-        const int c = mc.ch_c, slot = mc.ch_slot;
-        const int cw = CW(w, c);
+    }
+    __syncthreads();
+    /* 2b. genome distance: credit(f) depends on prev/next/ori of f and on the orientation of its INITIAL neighbours
+     * (CL:665-716), so move w can change the credits of its window and of the window's initial neighbours only; each is
+     * evaluated on the genome as of move w-1 and as of move w (moves < t applied, read through the marks) */
+    for (int w = w_start; w < committed; w++) {
+        const MoveCtl& mc = mb.ctl[w];
+        if (!mc.n_dirty) continue;
+        const int cw = CW(w, mc.ch_c);
+        const int n_loc = mb.meta[cw].n_loc;
+        const int* gid = mb.Lloc + (size_t)cw * N;
+        const int stampv = tag_base + w + 1; /* != 0 */
+        long long d = 0;
+        for (int item = tid; item < 3 * n_loc; item += blockDim.x) {
+            const int f0 = gid[item / 3];
+            const int q = item % 3;
+            const int f = (q == 0) ? f0 : ((q == 1) ? ip[f0] : in[f0]);
+            if (f < 0 || black[f]) continue;
+            if (atomicExch(&stamp[f], stampv) == stampv) continue; /* claimed by another item of this move */
+            auto view_at = [&](int t) {
+                return [=](int x) -> int3 {
+                    const int tg = own_tag[x] - tag_base;
+                    if (tg >= 0 && tg <= t) {
+                        const int* b = winner_loc(tg);
+                        const int xi = own_idx[x];
+                        return make_int3(b[(size_t)5 * N + xi], b[(size_t)6 * N + xi], b[(size_t)10 * N + xi]);
+                    }
+                    return make_int3(st.prev[x], st.next[x], st.ori[x]);
+                };
+            };
+            d += credit2_view(view_at(w), ip, in, orientable, f) - credit2_view(view_at(w - 1), ip, in, orientable, f);
+        }
+        d = wave_sum_ll(d);
+        if (lane == 0 && d) atomic_add_ll(&sh_delta[w], d);
+    }
+    __syncthreads();
+    /* 2c. the winners become the live genome (copy_struct KA:4566-4591); coordinate tables of the touched sub-fragments.
+     * First tab_prev catches up with the move applied last before this call. */
+    for (int i = tid; i < g->n_prev_touched; i += blockDim.x) {
+        const int s2 = prev_touched[i];
+        tab_prev.dist[s2] = tab.dist[s2];
+        tab_prev.stot[s2] = tab.stot[s2];
+        tab_prev.cp[s2] = tab.cp[s2];
+        tab_prev.len[s2] = tab.len[s2];
+    }
+    __syncthreads();
+    for (int w = w_start; w < committed; w++) {
+        const MoveCtl& mc = mb.ctl[w];
+        const int cw = CW(w, mc.ch_c);
         const CandMeta& m = mb.meta[cw];
-        /* 3. does the winner change anything?  (an identical genome needs no delta and dirties nothing) */
-        if (tid == 0) {
-            sh_changed = 0;
-            sh_c2[0] = 0;
-            sh_c2[1] = 0;
+        const bool last = (w == committed - 1);
+        if (last && tid == 0) g->n_prev_touched = mc.n_dirty ? m.m_loc : 0;
+        if (!mc.n_dirty) continue;
+        const int* base = winner_loc(w);
+        const int* gid = mb.Lloc + (size_t)cw * N;
+        for (int x = tid; x < m.n_loc; x += blockDim.x) {
+            const int f = gid[x];
+            st.pos[f] = base[x];
+            st.spos[f] = base[(size_t)N + x];
+            st.cid[f] = base[(size_t)2 * N + x];
+            st.sbp[f] = base[(size_t)3 * N + x];
+            st.circ[f] = base[(size_t)4 * N + x];
+            st.prev[f] = base[(size_t)5 * N + x];
+            st.next[f] = base[(size_t)6 * N + x];
+            st.L[f] = base[(size_t)7 * N + x];
+            st.SL[f] = base[(size_t)8 * N + x];
+            st.LB[f] = base[(size_t)9 * N + x];
+            st.ori[f] = base[(size_t)10 * N + x];
         }
-        __syncthreads();
-        {
-            const int N = mb.N;
-            const int* base = mb.loc + ((size_t)(cw * NSLOT + slot) * NDYN) * N;
-            const int* gid = mb.Lloc + (size_t)cw * N;
-            int ch = 0;
-            for (int x = tid; x < m.n_loc; x += blockDim.x) {
-                const int f = gid[x];
-                ch |= (st.pos[f] != base[x]) | (st.spos[f] != base[(size_t)N + x]) | (st.cid[f] != base[(size_t)2 * N + x]) |
-                      (st.sbp[f] != base[(size_t)3 * N + x]) | (st.circ[f] != base[(size_t)4 * N + x]) |
-                      (st.prev[f] != base[(size_t)5 * N + x]) | (st.next[f] != base[(size_t)6 * N + x]) |
-                      (st.L[f] != base[(size_t)7 * N + x]) | (st.SL[f] != base[(size_t)8 * N + x]) |
-                      (st.LB[f] != base[(size_t)9 * N + x]) | (st.ori[f] != base[(size_t)10 * N + x]);
+        const int k = mc.ch_k;
+        const uint2* col = mb.coords + (size_t)(cw * NSLOT + k) * M;
+        const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
+        const int* subs = mb.subs + (size_t)cw * M;
+        const int fresh = mc.fresh;
+        for (int ls = tid; ls < m.m_loc; ls += blockDim.x) {
+            const int s = subs[ls];
+            const uint2 v = col[ls];
+            const int code = (int)(v.y >> 28);
+            const float dist = __uint_as_float(v.x);
+            const int2 cp = make_int2(code == 0 ? m.ctgA : (code == 1 ? m.ctgB : fresh + (code - 2)), (int)(v.y & 0x0fffffffu));
+            const float stot = cm[code].stot;
+            const int len = cm[code].len;
+            tab.dist[s] = dist;
+            tab.cp[s] = cp;
+            tab.stot[s] = stot;
+            tab.len[s] = len;
+            if (last) {
+                prev_touched[ls] = s;
+            } else {
+                tab_prev.dist[s] = dist;
+                tab_prev.cp[s] = cp;
+                tab_prev.stot[s] = stot;
+                tab_prev.len[s] = len;
             }
-            if (ch) atomicOr(&sh_changed, 1);
         }
-        __syncthreads();
-        if (mc.ch_windowed && sh_changed) { /* needs k_delta: hand this move to the one-move tail */
-            if (tid == 0) batch_out[1] = w;
-            break;
+    }
+    __syncthreads();
+    /* 2d. the distance column */
+    if (tid == 0) {
+        long long c2 = g->credit2;
+        const double norm = 3.0 * (double)(g->N - g->n_black);
+        for (int w = w_start; w < committed; w++) {
+            c2 += sh_delta[w];
+            res[move0 + w].dist = (norm - 0.5 * (double)c2) / norm;
         }
-        if (tid == 0 && mc.ch_windowed) { /* identical genome: the delta is exactly zero */
-            mc.d_hi = 0;
-            mc.d_lo = 0;
-        }
-        /* 4. genome distance, incremental and exact: credit(f) depends on prev/next/ori of f and on the
-         * orientation of its INITIAL neighbours only (CL:665-716), so the fragments whose credit can change are the
-         * touched ones and their initial neighbours; each is claimed once through a stamp. */
-        const int st1 = 2 * g->stamp_ctr + 1, st2 = st1 + 1;
-        {
-            const int* gid = mb.Lloc + (size_t)cw * mb.N;
-            long long old2 = 0;
-            if (sh_changed)
-                for (int x = tid; x < m.n_loc; x += blockDim.x) {
-                    const int f0 = gid[x];
-                    const int cand3[3] = {f0, ip[f0], in[f0]};
-                    for (int q = 0; q < 3; q++) {
-                        const int f = cand3[q];
-                        if (f < 0 || black[f]) continue;
-                        if (atomicExch(&stamp[f], st1) != st1) old2 += credit2_of(st, ip, in, orientable, f);
-                    }
-                }
-            old2 = wave_sum_ll(old2);
-            if ((tid & 63) == 0 && old2) atomic_add_ll(&sh_c2[0], old2);
-        }
-        __syncthreads();
-        /* 5. catch tab_prev up with the previous commit, then apply */
-        for (int i = tid; i < g->n_prev_touched; i += blockDim.x) {
-            const int s = prev_touched[i];
-            tab_prev.dist[s] = tab.dist[s];
-            tab_prev.stot[s] = tab.stot[s];
-            tab_prev.cp[s] = tab.cp[s];
-            tab_prev.len[s] = tab.len[s];
-        }
-        __syncthreads();
-        apply_winner(st, tab, g, mb, w, 0, prev_touched, tid, blockDim.x, true);
-        __threadfence_block();
-        __syncthreads();
-        {
-            const int* gid = mb.Lloc + (size_t)cw * mb.N;
-            long long new2 = 0;
-            if (sh_changed)
-                for (int x = tid; x < m.n_loc; x += blockDim.x) {
-                    const int f0 = gid[x];
-                    const int cand3[3] = {f0, ip[f0], in[f0]};
-                    for (int q = 0; q < 3; q++) {
-                        const int f = cand3[q];
-                        if (f < 0 || black[f]) continue;
-                        if (atomicExch(&stamp[f], st2) != st2) new2 += credit2_of(st, ip, in, orientable, f);
-                    }
-                }
-            new2 = wave_sum_ll(new2);
-            if ((tid & 63) == 0 && new2) atomic_add_ll(&sh_c2[1], new2);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            g->stamp_ctr += 1;
-            g->credit2 += sh_c2[1] - sh_c2[0];
-            g->next_cid += NFRESH;
-            if (sh_changed) {
-                dirty[n_dirty++] = m.ctgA;
-                if (!m.same) dirty[n_dirty++] = m.ctgB;
-            }
-            write_result(g, mb, w, res + move0 + w);
-            batch_out[0] = w + 1;
-        }
-        __syncthreads();
+        g->credit2 = c2;
+        g->stamp_ctr = tag_base + W + 2;
     }
 }
 
@@ -1907,6 +2295,8 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->black = nullptr;
     c->stamp = nullptr;
     c->batch_out = nullptr;
+    c->own_tag = c->own_idx = nullptr;
+    c->dirty_buf = nullptr;
     c->d_results = nullptr;
     c->results_cap = 0;
     c->d_frags = c->d_cands = nullptr;
@@ -1973,8 +2363,16 @@ static void free_move_buffers(ig_ctx* c)
     hipFree(m.sloff);
     hipFree(m.qpart);
     hipFree(m.ctl);
+    hipFree(m.sinfo);
+    hipFree(m.pre);
+    hipFree(m.cpre);
+    hipFree(c->own_tag);
+    hipFree(c->own_idx);
+    c->own_tag = c->own_idx = nullptr;
     hipFree(c->stamp);
     hipFree(c->batch_out);
+    hipFree(c->dirty_buf);
+    c->dirty_buf = nullptr;
     memset((void*)&m, 0, sizeof m);
     c->stamp = nullptr;
     c->batch_out = nullptr;
@@ -2063,8 +2461,15 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
     DALLOC(m.qpart, C * Q_STRIDE);
     DALLOC(m.scores, C * IG_N_TMP_STRUCT);
     DALLOC(m.ctl, (size_t)capW);
+    DALLOC(m.sinfo, C * NSLOT);
+    DALLOC(m.pre, C * IG_N_TMP_STRUCT);
+    DALLOC(m.cpre, C);
+    DALLOC(c->own_tag, N);
+    DALLOC(c->own_idx, N);
+    HIPCK(hipMemset(c->own_tag, 0xff, N * sizeof(int)));
     DALLOC(c->stamp, N);
-    DALLOC(c->batch_out, 2);
+    DALLOC(c->batch_out, 4);
+    DALLOC(c->dirty_buf, 2 * IG_MAX_BATCH + 4);
     HIPCK(hipMemset(m.cmeta, 0, C * NSLOT * NCODE * sizeof(ColMeta)));
     HIPCK(hipMemset(m.slbound, 0, C * sizeof(long long)));
     HIPCK(hipMemset(m.ctl, 0, (size_t)capW * sizeof(MoveCtl)));
@@ -2522,8 +2927,8 @@ static void enqueue_apply(ig_ctx* c, int move, int w, int forced)
     const PzTab pz{c->pz_tab, c->pz_n};
     {
         TimedLaunch t(c, T_DELTA);
-        hipLaunchKernelGGL(k_delta, dim3(DELTA_RB, 2, 1), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb,
-                           c->lgf_tab, pz, w);
+        hipLaunchKernelGGL(k_delta, dim3(DELTA_RB, 2, 1), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->tab_prev,
+                           c->prev_touched, c->glob, c->mb, c->lgf_tab, pz, w);
     }
     {
         TimedLaunch t(c, T_APPLY);
@@ -2558,7 +2963,7 @@ static int validate_move(ig_ctx* c, int frag_a, const int32_t* cands, int C)
     return 0;
 }
 
-static int g_batch_w = -1; /* moves scored per launch in ig_step_batch: env IG_BATCH_W, default 16; 1 = one move at a time */
+static int g_batch_w = -1; /* moves scored per launch in ig_step_batch: env IG_BATCH_W, default 24; 1 = one move at a time */
 
 extern "C" int ig_step_batch(ig_ctx* c, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c,
                              ig_move_result* results)
@@ -2576,10 +2981,17 @@ extern "C" int ig_step_batch(ig_ctx* c, int32_t n_moves, const int32_t* frags, c
     }
     if (g_batch_w < 0) {
         const char* e = getenv("IG_BATCH_W");
-        g_batch_w = e ? atoi(e) : 16;
+        g_batch_w = e ? atoi(e) : 24;
         g_batch_w = std::min(std::max(g_batch_w, 1), IG_MAX_BATCH);
     }
-    const int Wmax = (c->world > 1) ? 1 : g_batch_w;
+    int Wmax = (c->world > 1) ? 1 : g_batch_w;
+    {
+        /* the per-slot work buffers are sized for the worst case (a window = the whole genome): keep them under ~64 GB */
+        const double per_slot = (double)std::max(8, (int)max_c) *
+                                ((double)NSLOT * NDYN * c->N * 4.0 + (double)c->M * NSLOT * 8.0 + 3.0 * c->N * 4.0 + 2.0 * c->M * 4.0);
+        const int fit = (int)std::max(1.0, 64e9 / std::max(per_slot, 1.0));
+        Wmax = std::min(Wmax, fit);
+    }
     if (ensure_move_buffers(c, std::max(8, (int)max_c), Wmax)) return -1;
     if (ensure_io(c, n_moves, max_c)) return -1;
     HIPCK(hipMemcpyAsync(c->d_frags, frags, (size_t)n_moves * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -2597,27 +3009,37 @@ extern "C" int ig_step_batch(ig_ctx* c, int32_t n_moves, const int32_t* frags, c
         while (done < n_moves) {
             const int w_now = std::min(W, n_moves - done);
             enqueue_score(c, done, w_now, max_c, -1, 2);
-            {
-                TimedLaunch t(c, T_COMMIT);
-                hipLaunchKernelGGL(k_commit_batch, dim3(1), dim3(256), 0, c->stream, c->st, c->tab, c->tab_prev, c->glob, c->mb,
-                                   c->init_prev, c->init_next, c->orientable, c->black, c->stamp, c->prev_touched, c->d_results, done,
-                                   w_now, c->batch_out);
+            int next = 0; /* slots [0, next) of this batch are committed */
+            for (;;) {
+                {
+                    TimedLaunch t(c, T_COMMIT);
+                    hipLaunchKernelGGL(k_commit_batch, dim3(1), dim3(COMMIT_THREADS), 0, c->stream, c->st, c->tab, c->tab_prev, c->glob,
+                                       c->mb, c->init_prev, c->init_next, c->orientable, c->black, c->stamp, c->own_tag, c->own_idx,
+                                       c->prev_touched, c->d_results, done, w_now, next, c->dirty_buf, c->batch_out);
+                }
+                int bo[4];
+                HIPCK(hipMemcpyAsync(bo, c->batch_out, sizeof bo, hipMemcpyDeviceToHost, c->stream));
+                HIPCK(hipStreamSynchronize(c->stream));
+                if (next == 0) {
+                    c->n_batches++;
+                    c->large_seen = (bo[2] * 4 > bo[3]); /* a quarter of the windows above LDS_COL_SMALL: launch the large variant too */
+                }
+                c->n_batch_committed += bo[0] - next;
+                next = bo[0];
+                if (bo[1] >= 0) { /* slot bo[1] chose a windowed winner: delta + apply with the one-move kernels, then go on */
+                    enqueue_apply(c, done + bo[1], bo[1], 0);
+                    c->n_batch_pending++;
+                    next = bo[1] + 1;
+                    if (next < w_now) continue;
+                }
+                break;
             }
-            int bo[2];
-            HIPCK(hipMemcpyAsync(bo, c->batch_out, sizeof bo, hipMemcpyDeviceToHost, c->stream));
-            HIPCK(hipStreamSynchronize(c->stream));
-            c->n_batches++;
-            c->n_batch_committed += bo[0];
-            done += bo[0];
-            if (bo[1] >= 0) { /* slot bo[1] == bo[0] chose a windowed winner: delta + apply with the one-move kernels */
-                enqueue_apply(c, done, bo[1], 0);
-                c->n_batch_pending++;
-                done += 1;
-            } else if (bo[0] == 0) {
+            if (next == 0) {
                 Glob hg;
                 HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));
                 return fail("device-side consistency failure %d in a batch at move %d", hg.error, done);
             }
+            done += next;
         }
     }
     HIPCK(hipMemcpyAsync(results, c->d_results, (size_t)n_moves * sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));

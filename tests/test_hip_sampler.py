@@ -136,7 +136,7 @@ def test_speculative_batches_equal_one_move_at_a_time(cfg, n_moves):
             outs.append((res.tobytes(), s.gpu_vect_frags.copy_from_gpu().soa17(), [int(x) for x in sums], int(ints[0]),
                          [int(x) for x in prev[2]], [int(x) for x in s.ctx.valid_insert()], s.ctx.batch_stats()))
     finally:
-        hip_lib.set_batch_width(16)
+        hip_lib.set_batch_width(24)
     for W, o in zip((2, 5, 16, 32), outs[1:]):
         assert o[0] == outs[0][0], W
         assert np.array_equal(o[1], outs[0][1]), W
