@@ -13,10 +13,11 @@ moves W at a time against one state and commits them in order on the device ("sp
 the results are identical to K single calls, tests/test_hip_sampler.py), so one launch of the
 dominant kernel covers several moves.
 
-Multi-GPU (N > 1): every rank holds the full problem and scores its share of the candidate rows of
-each move (rows r with r % N == rank); the partial exact integer sums are all-reduced over RCCL, after
-which every rank applies the identical winner.  Results are bit-identical for any N ("strong" scaling:
-the same chain, split N ways).
+Multi-GPU (N > 1): every rank holds the full problem; the slots of each speculative batch are split
+over the ranks (rank r slices and scores W/N of the W moves), the slot-major score records (exact
+int64 sums, ~15 KB per slot) are all-gathered over RCCL once per batch, and every rank runs the same
+commit step on identical inputs.  Results are bit-identical for any N ("strong" scaling: the same
+chain, split N ways); the commit step is the serial fraction.
 
 Prints ONE JSON line (rank 0).
 """
@@ -119,9 +120,9 @@ def main():
     log("[rank %d] %d candidate lists drawn in %.2fs (%.1f us each, host numpy RNG)" % (rank, n_total, t_draw, 1e6 * t_draw / n_total))
 
     if world > 1:
-        from instagraal_amd.multi_gpu import ShardedRunner
+        from instagraal_amd.multi_gpu import BatchRunner
 
-        runner = ShardedRunner(s.ctx, rank, world)
+        runner = BatchRunner(s.ctx, rank, world, dist=dist)
         run = runner.run
     else:
         run = s.ctx.step_batch
@@ -184,6 +185,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "synthetic Hi-C %s (%d sub-frags), level 4, %d neighbours, nuisance sampling off" % (
                 prob_name(prob), prob.n_sub_frags, a.neighbours), "name": a.config, "seed": a.seed,
+                "parallelism": "1 GPU" if world == 1 else "batch slots split over %d ranks, all-gather of score records" % world,
                 "candidates_scored_per_s": float(res["n_candidates"].sum()) * 24 / elapsed,
                 "term_evals_per_move": float(res["n_evals"].mean()), "moves_per_launch": a.steps / n_launch,
                 "batches": bstats, "maintained_likelihood_exact": exact_ok},

@@ -108,7 +108,7 @@ struct Glob {
 };
 
 /* one move slot of a batch (W = 1: the move in flight) */
-#define IG_MAX_BATCH 32
+#define IG_MAX_BATCH 64
 struct MoveCtl {
     int A, C, force_slot, fresh; /* fresh: first of the NFRESH contig ids this move may create */
     int ch_c, ch_k, ch_slot, ch_windowed;
@@ -218,6 +218,7 @@ struct ig_ctx {
     } timers[10];
     long long n_batches, n_batch_committed, n_batch_pending;
     int large_seen;
+    int up_moves, up_max_c; /* the uploaded move lists */
     bool have_contacts, have_sub, have_state, have_init, have_params;
 };
 
@@ -891,7 +892,7 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
 
 /* k_offsets: where each candidate's slice list starts in the pool = exclusive prefix sum of the upper bounds
  * (one small workgroup; a slot whose lists do not fit is flagged and re-run at the head of the next batch) */
-__global__ void __launch_bounds__(64) k_offsets(MoveBuf mb, int W)
+__global__ void __launch_bounds__(64) k_offsets(MoveBuf mb, int W, int w_begin, int w_end)
 {
     /* one wave: lane l owns the `per` consecutive (slot, candidate) entries l*per .. ; exclusive scan across lanes */
     const int lane = threadIdx.x;
@@ -905,7 +906,7 @@ __global__ void __launch_bounds__(64) k_offsets(MoveBuf mb, int W)
         long long v = 0;
         if (q < per && i < n) {
             const int w = i / mb.capC, c = i % mb.capC;
-            if (c < mb.ctl[w].C) v = mb.slbound[i];
+            if (w >= w_begin && w < w_end && c < mb.ctl[w].C) v = mb.slbound[i];
         }
         b[q] = v;
         sum += v;
@@ -921,7 +922,7 @@ __global__ void __launch_bounds__(64) k_offsets(MoveBuf mb, int W)
         const int i = lane * per + q;
         if (q < per && i < n) {
             const int w = i / mb.capC, c = i % mb.capC;
-            if (c < mb.ctl[w].C) {
+            if (w >= w_begin && w < w_end && c < mb.ctl[w].C) {
                 if (run + b[q] > mb.pool_cap) {
                     mb.sloff[i] = -1;
                     mb.ctl[w].overflow = 1;
@@ -945,9 +946,9 @@ __global__ void __launch_bounds__(64) k_offsets(MoveBuf mb, int W)
 #define SLICE_RB 128
 #define SLICE_UNROLL 4
 __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
-                                               Glob* g, MoveBuf mb, int rank, int world)
+                                               Glob* g, MoveBuf mb, int rank, int world, int w_begin)
 {
-    const int c = blockIdx.y, w = blockIdx.z;
+    const int c = blockIdx.y, w = w_begin + blockIdx.z;
     if (c >= mb.ctl[w].C) return;
     const int cw = CW(w, c);
     const CandMeta& m = mb.meta[cw];
@@ -1189,7 +1190,8 @@ __device__ __forceinline__ void score_loop(const ScoreArgs& a, const HotPar& hp,
  * and the rest (<= LDS_COL_CAP staged, larger ones gathered from L2); each workgroup serves its own class only */
 template <int CAP>
 __global__ void __launch_bounds__(SCORE_THREADS)
-    k_score_list(const Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int ablate, int max_c, int large_on)
+    k_score_list(const Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int ablate, int max_c, int large_on,
+                 int w_begin)
 {
     __shared__ uint2 lcol[CAP];
     __shared__ float pz_s[LDS_PZ];
@@ -1197,7 +1199,7 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     __shared__ double mt_s[IG_TAB_SIZE];
     __shared__ ColMeta cm_s[NCODE];
     __shared__ long long red[2][SCORE_THREADS / 64];
-    const int w = blockIdx.z / max_c, c = blockIdx.z % max_c;
+    const int w = w_begin + blockIdx.z / max_c, c = blockIdx.z % max_c;
     if (c >= mb.ctl[w].C) return;
     const int cw = CW(w, c);
     const CandMeta& m = mb.meta[cw];
@@ -1384,12 +1386,12 @@ __device__ __forceinline__ int wave_max_i(int v)
  * a column at list position >= r never receives those contacts; which columns that applies to is decided
  * when the uniq list is known (k_scores / k_commit_batch). */
 __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, Glob* g, MoveBuf mb,
-                              const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz)
+                              const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int w_begin)
 {
     __shared__ int t_li[64], t_lj[64], t_ob[64], t_rows[64];
     __shared__ int sh_n_rows, sh_n_tail, sh_cnt;
     __shared__ long long sh_red[4];
-    const int c = blockIdx.x, w = blockIdx.y;
+    const int c = blockIdx.x, w = w_begin + blockIdx.y;
     if (c >= mb.ctl[w].C) return;
     const int cw = CW(w, c);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1501,11 +1503,12 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
 }
 
 __global__ void __launch_bounds__(256) k_prefinal(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
-                                                  Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz)
+                                                  Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz,
+                                                  int w_begin)
 {
-    const int c = blockIdx.x, w = blockIdx.y;
+    const int c = blockIdx.x, w = w_begin + blockIdx.y;
     if (c >= mb.ctl[w].C) return;
-    prefinal_tail(rowptr, cc, tab, g, mb, lgf_tab, tail_quirk, pz);
+    prefinal_tail(rowptr, cc, tab, g, mb, lgf_tab, tail_quirk, pz, w_begin);
     __syncthreads();
     /* slot-major records for the commit step */
     const int cw = CW(w, c);
@@ -1542,7 +1545,7 @@ __global__ void __launch_bounds__(256) k_prefinal(const long long* __restrict__ 
         for (int q = 0; q < m.n_uniq; q++) nb += (m.uniq[q] < 12);
         cp.base_cnt = nb;
         cp.n_uniq_basic = nb;
-        cp.pad = 0;
+        cp.pad = mb.ctl[w].overflow; /* travels with the records: the slot must be re-run */
         mb.cpre[cw] = cp;
     }
 }
@@ -1897,7 +1900,7 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
             }
             bool hitd = false;
             for (int q = 0; q < n_dirty; q++) hitd |= (dirty[q] == cA) | (dirty[q] == cB);
-            if (err0 || mc.overflow || __any(hitd && lane < C)) break;
+            if (err0 || mb.cpre[CW(w, 0)].pad || __any(hitd && lane < C)) break;
             n_large += __popcll(__ballot(lane < C && mloc > LDS_COL_SMALL));
             n_cand += C;
             /* scores (eval_all_likelihood_on_zero_2nd KA:4005-4027, eval_all_scores KA:4029-4046) with the live scalars */
@@ -2308,6 +2311,7 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->timing = false;
     c->n_batches = c->n_batch_committed = c->n_batch_pending = 0;
     c->large_seen = 1;
+    c->up_moves = c->up_max_c = 0;
     for (int i = 0; i < T_COUNT; i++) {
         c->timers[i].name = kTimerNames[i];
         c->timers[i].total_ms = 0;
@@ -2866,8 +2870,12 @@ static int g_tail_quirk = 1;
 
 /* enqueue the scoring launches of W move slots (moves move0 .. move0+W-1 of the uploaded lists);
  * phase 0 = up to k_score_list (the sums that are all-reduced when sharded), 1 = the rest, 2 = both */
-static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot, int phase)
+static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot, int phase, int w_begin = 0, int w_end = -1)
 {
+    /* slots [w_begin, w_end) are sliced and scored here (multi-GPU: the other ranks score the rest and the slot-major
+     * records are all-gathered); the candidate genomes of EVERY slot are built on every rank, the commit step needs them */
+    if (w_end < 0) w_end = W;
+    const int nW = w_end - w_begin;
     const int N = c->N;
     const int gN = std::max((N + 255) / 256, W);
     const PzTab pz{c->pz_tab, c->pz_n};
@@ -2882,12 +2890,12 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
             hipLaunchKernelGGL(k_mutate, dim3(NSLOT, max_c, W), dim3(256), 0, c->stream, c->st, c->tab, c->sub_tab, c->rowptr, c->glob,
                                c->mb, pz);
         }
-        if (force_slot < 0) {
+        if (force_slot < 0 && nW > 0) {
             {
                 TimedLaunch t(c, T_SLICE);
-                hipLaunchKernelGGL(k_offsets, dim3(1), dim3(64), 0, c->stream, c->mb, W);
-                hipLaunchKernelGGL(k_slice, dim3(SLICE_RB, max_c, W), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb,
-                                   c->rank, c->world);
+                hipLaunchKernelGGL(k_offsets, dim3(1), dim3(64), 0, c->stream, c->mb, W, w_begin, w_end);
+                hipLaunchKernelGGL(k_slice, dim3(SLICE_RB, max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb,
+                                   c->rank, c->world, w_begin);
             }
             TimedLaunch t(c, T_SCORE);
             static int s_eb = getenv("IG_SCORE_EB") ? atoi(getenv("IG_SCORE_EB")) : SCORE_EB;
@@ -2896,18 +2904,18 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
              * sub-fragments; without it the small variant serves every window (unstaged above its cap) */
             static int s_large = getenv("IG_LARGE") ? atoi(getenv("IG_LARGE")) : -1;
             const int large_on = s_large >= 0 ? s_large : c->large_seen;
-            hipLaunchKernelGGL(k_score_list<LDS_COL_SMALL>, dim3(s_eb, NSLOT, max_c * W), dim3(SCORE_THREADS), 0, c->stream, c->glob,
-                               c->mb, c->lgf_tab, pz, s_abl, max_c, large_on);
+            hipLaunchKernelGGL(k_score_list<LDS_COL_SMALL>, dim3(s_eb, NSLOT, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->glob,
+                               c->mb, c->lgf_tab, pz, s_abl, max_c, large_on, w_begin);
             if (large_on)
-                hipLaunchKernelGGL(k_score_list<LDS_COL_CAP>, dim3(s_eb, NSLOT, max_c * W), dim3(SCORE_THREADS), 0, c->stream, c->glob,
-                                   c->mb, c->lgf_tab, pz, s_abl, max_c, large_on);
+                hipLaunchKernelGGL(k_score_list<LDS_COL_CAP>, dim3(s_eb, NSLOT, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->glob,
+                                   c->mb, c->lgf_tab, pz, s_abl, max_c, large_on, w_begin);
         }
     }
     if (phase == 1 || phase == 2) {
-        if (force_slot < 0) {
+        if (force_slot < 0 && nW > 0) {
             TimedLaunch t(c, T_FINALIZE);
-            hipLaunchKernelGGL(k_prefinal, dim3(max_c, W), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->lgf_tab,
-                               g_tail_quirk, pz);
+            hipLaunchKernelGGL(k_prefinal, dim3(max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->lgf_tab,
+                               g_tail_quirk, pz, w_begin);
         }
     }
 }
@@ -2963,7 +2971,88 @@ static int validate_move(ig_ctx* c, int frag_a, const int32_t* cands, int C)
     return 0;
 }
 
+/* commit the scored batch [move0, move0 + w_now): k_commit_batch, the one-move tail for a windowed winner, resume */
+static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
+{
+    int next = 0; /* slots [0, next) of this batch are committed */
+    for (;;) {
+        {
+            TimedLaunch t(c, T_COMMIT);
+            hipLaunchKernelGGL(k_commit_batch, dim3(1), dim3(COMMIT_THREADS), 0, c->stream, c->st, c->tab, c->tab_prev, c->glob,
+                               c->mb, c->init_prev, c->init_next, c->orientable, c->black, c->stamp, c->own_tag, c->own_idx,
+                               c->prev_touched, c->d_results, done, w_now, next, c->dirty_buf, c->batch_out);
+        }
+        int bo[4];
+        HIPCK(hipMemcpyAsync(bo, c->batch_out, sizeof bo, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));
+        if (next == 0) {
+            c->n_batches++;
+            c->large_seen = (bo[2] * 4 > bo[3]); /* a quarter of the windows above LDS_COL_SMALL: launch the large variant too */
+        }
+        c->n_batch_committed += bo[0] - next;
+        next = bo[0];
+        if (bo[1] >= 0) { /* slot bo[1] chose a windowed winner: delta + apply with the one-move kernels, then go on */
+            enqueue_apply(c, done + bo[1], bo[1], 0);
+            c->n_batch_pending++;
+            next = bo[1] + 1;
+            if (next < w_now) continue;
+        }
+        break;
+    }
+    if (next == 0) {
+        Glob hg;
+        HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));
+        return fail("device-side consistency failure %d in a batch at move %d", hg.error, done);
+    }
+    *next_out = next;
+    return 0;
+}
+
 static int g_batch_w = -1; /* moves scored per launch in ig_step_batch: env IG_BATCH_W, default 24; 1 = one move at a time */
+
+static int batch_width(ig_ctx* c, int max_c)
+{
+    if (g_batch_w < 0) {
+        const char* e = getenv("IG_BATCH_W");
+        g_batch_w = e ? atoi(e) : 24;
+        g_batch_w = std::min(std::max(g_batch_w, 1), IG_MAX_BATCH);
+    }
+    /* the per-slot work buffers are sized for the worst case (a window = the whole genome): keep them under ~64 GB */
+    const double per_slot = (double)std::max(8, max_c) *
+                            ((double)NSLOT * NDYN * c->N * 4.0 + (double)c->M * NSLOT * 8.0 + 3.0 * c->N * 4.0 + 2.0 * c->M * 4.0);
+    const int fit = (int)std::max(1.0, 64e9 / std::max(per_slot, 1.0));
+    return std::min(g_batch_w, fit);
+}
+
+/* validate and upload the pre-drawn (fragment, candidates) lists of a run of moves */
+static int upload_moves(ig_ctx* c, int n_moves, const int32_t* frags, const int32_t* cands, int max_c)
+{
+    if (max_c < 1 || max_c > IG_MAX_CANDIDATES) return fail("max_c out of range");
+    for (int i = 0; i < n_moves; i++) {
+        int C = 0;
+        while (C < max_c && cands[(size_t)i * max_c + C] >= 0) C++;
+        for (int k = C; k < max_c; k++)
+            if (cands[(size_t)i * max_c + k] >= 0) return fail("candidates must be packed before the -1 padding");
+        if (validate_move(c, frags[i], cands + (size_t)i * max_c, C)) return -1;
+    }
+    if (ensure_io(c, n_moves, max_c)) return -1;
+    HIPCK(hipMemcpyAsync(c->d_frags, frags, (size_t)n_moves * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCK(hipMemcpyAsync(c->d_cands, cands, (size_t)n_moves * max_c * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    c->up_moves = n_moves;
+    c->up_max_c = max_c;
+    return 0;
+}
+
+static int download_results(ig_ctx* c, int n_moves, ig_move_result* results)
+{
+    HIPCK(hipMemcpyAsync(results, c->d_results, (size_t)n_moves * sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    HIPCK(hipGetLastError());
+    drain_timers(c);
+    for (int i = 0; i < n_moves; i++)
+        if (results[i].error) return fail("device-side consistency failure %d at move %d", results[i].error, i);
+    return 0;
+}
 
 extern "C" int ig_step_batch(ig_ctx* c, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c,
                              ig_move_result* results)
@@ -2972,30 +3061,9 @@ extern "C" int ig_step_batch(ig_ctx* c, int32_t n_moves, const int32_t* frags, c
     if (check_ready(c)) return -1;
     if (n_moves <= 0) return 0;
     if (max_c < 1 || max_c > IG_MAX_CANDIDATES) return fail("ig_step_batch: max_c out of range");
-    for (int i = 0; i < n_moves; i++) {
-        int C = 0;
-        while (C < max_c && cands[(size_t)i * max_c + C] >= 0) C++;
-        for (int k = C; k < max_c; k++)
-            if (cands[(size_t)i * max_c + k] >= 0) return fail("ig_step_batch: candidates must be packed before the -1 padding");
-        if (validate_move(c, frags[i], cands + (size_t)i * max_c, C)) return -1;
-    }
-    if (g_batch_w < 0) {
-        const char* e = getenv("IG_BATCH_W");
-        g_batch_w = e ? atoi(e) : 24;
-        g_batch_w = std::min(std::max(g_batch_w, 1), IG_MAX_BATCH);
-    }
-    int Wmax = (c->world > 1) ? 1 : g_batch_w;
-    {
-        /* the per-slot work buffers are sized for the worst case (a window = the whole genome): keep them under ~64 GB */
-        const double per_slot = (double)std::max(8, (int)max_c) *
-                                ((double)NSLOT * NDYN * c->N * 4.0 + (double)c->M * NSLOT * 8.0 + 3.0 * c->N * 4.0 + 2.0 * c->M * 4.0);
-        const int fit = (int)std::max(1.0, 64e9 / std::max(per_slot, 1.0));
-        Wmax = std::min(Wmax, fit);
-    }
+    const int Wmax = (c->world > 1) ? 1 : batch_width(c, max_c);
     if (ensure_move_buffers(c, std::max(8, (int)max_c), Wmax)) return -1;
-    if (ensure_io(c, n_moves, max_c)) return -1;
-    HIPCK(hipMemcpyAsync(c->d_frags, frags, (size_t)n_moves * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCK(hipMemcpyAsync(c->d_cands, cands, (size_t)n_moves * max_c * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (upload_moves(c, n_moves, frags, cands, max_c)) return -1;
     if (Wmax == 1) {
         for (int i = 0; i < n_moves; i++) {
             enqueue_move(c, i, max_c, -1, 2);
@@ -3005,50 +3073,66 @@ extern "C" int ig_step_batch(ig_ctx* c, int32_t n_moves, const int32_t* frags, c
         /* speculative batches: score W moves against the same state, commit the conflict-free prefix on the device,
          * finish a winner that needs the exact delta pass with the one-move tail, continue after it */
         int done = 0;
-        int W = Wmax;
         while (done < n_moves) {
-            const int w_now = std::min(W, n_moves - done);
+            const int w_now = std::min(Wmax, n_moves - done);
             enqueue_score(c, done, w_now, max_c, -1, 2);
-            int next = 0; /* slots [0, next) of this batch are committed */
-            for (;;) {
-                {
-                    TimedLaunch t(c, T_COMMIT);
-                    hipLaunchKernelGGL(k_commit_batch, dim3(1), dim3(COMMIT_THREADS), 0, c->stream, c->st, c->tab, c->tab_prev, c->glob,
-                                       c->mb, c->init_prev, c->init_next, c->orientable, c->black, c->stamp, c->own_tag, c->own_idx,
-                                       c->prev_touched, c->d_results, done, w_now, next, c->dirty_buf, c->batch_out);
-                }
-                int bo[4];
-                HIPCK(hipMemcpyAsync(bo, c->batch_out, sizeof bo, hipMemcpyDeviceToHost, c->stream));
-                HIPCK(hipStreamSynchronize(c->stream));
-                if (next == 0) {
-                    c->n_batches++;
-                    c->large_seen = (bo[2] * 4 > bo[3]); /* a quarter of the windows above LDS_COL_SMALL: launch the large variant too */
-                }
-                c->n_batch_committed += bo[0] - next;
-                next = bo[0];
-                if (bo[1] >= 0) { /* slot bo[1] chose a windowed winner: delta + apply with the one-move kernels, then go on */
-                    enqueue_apply(c, done + bo[1], bo[1], 0);
-                    c->n_batch_pending++;
-                    next = bo[1] + 1;
-                    if (next < w_now) continue;
-                }
-                break;
-            }
-            if (next == 0) {
-                Glob hg;
-                HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));
-                return fail("device-side consistency failure %d in a batch at move %d", hg.error, done);
-            }
+            int next = 0;
+            if (commit_loop(c, done, w_now, &next)) return -1;
             done += next;
         }
     }
-    HIPCK(hipMemcpyAsync(results, c->d_results, (size_t)n_moves * sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
-    HIPCK(hipStreamSynchronize(c->stream));
+    return download_results(c, n_moves, results);
+}
+
+/* ---- the same, one step at a time, for callers that split the slots of a batch over several GPUs ---------- */
+
+extern "C" int ig_batch_upload(ig_ctx* c, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c, int32_t max_w)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (check_ready(c)) return -1;
+    if (n_moves <= 0) return fail("ig_batch_upload: no moves");
+    if (max_w < 1 || max_w > IG_MAX_BATCH) return fail("ig_batch_upload: batch width %d out of 1..%d", max_w, IG_MAX_BATCH);
+    if (c->world > 1) return fail("ig_batch_upload: contact shards (ig_set_shard) and slot splitting are exclusive");
+    if (max_c < 1 || max_c > IG_MAX_CANDIDATES) return fail("ig_batch_upload: max_c out of range");
+    if (ensure_move_buffers(c, std::max(8, (int)max_c), max_w)) return -1;
+    return upload_moves(c, n_moves, frags, cands, max_c);
+}
+
+extern "C" int ig_batch_score(ig_ctx* c, int32_t move0, int32_t W, int32_t slot_begin, int32_t slot_end)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (W < 1 || W > c->mb.capW || move0 < 0 || move0 + W > c->up_moves) return fail("ig_batch_score: batch out of range");
+    if (slot_begin < 0 || slot_end > W || slot_begin > slot_end) return fail("ig_batch_score: slot range out of range");
+    enqueue_score(c, move0, W, c->up_max_c, -1, 2, slot_begin, slot_end);
     HIPCK(hipGetLastError());
-    drain_timers(c);
-    for (int i = 0; i < n_moves; i++)
-        if (results[i].error) return fail("device-side consistency failure %d at move %d", results[i].error, i);
     return 0;
+}
+
+extern "C" int ig_batch_records(ig_ctx* c, void** pre, int64_t* pre_bytes_per_slot, void** cpre, int64_t* cpre_bytes_per_slot)
+{
+    if (!c->mb.pre) return fail("ig_batch_records: no batch buffers yet (ig_batch_upload first)");
+    *pre = c->mb.pre;
+    *pre_bytes_per_slot = (int64_t)c->mb.capC * IG_N_TMP_STRUCT * (int64_t)sizeof(SlotPre);
+    *cpre = c->mb.cpre;
+    *cpre_bytes_per_slot = (int64_t)c->mb.capC * (int64_t)sizeof(CandPre);
+    return 0;
+}
+
+extern "C" int ig_batch_commit(ig_ctx* c, int32_t move0, int32_t W, int32_t* n_committed)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (W < 1 || W > c->mb.capW || move0 < 0 || move0 + W > c->up_moves) return fail("ig_batch_commit: batch out of range");
+    int next = 0;
+    if (commit_loop(c, move0, W, &next)) return -1;
+    *n_committed = next;
+    return 0;
+}
+
+extern "C" int ig_batch_results(ig_ctx* c, int32_t n_moves, ig_move_result* results)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (n_moves < 0 || n_moves > c->up_moves) return fail("ig_batch_results: out of range");
+    return download_results(c, n_moves, results);
 }
 
 extern "C" int ig_set_batch_width(int w)

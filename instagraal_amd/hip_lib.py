@@ -60,6 +60,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libinstagraal_hip.so is missing (%s): run __graft_entry__.build(); "
                                "the MI355X path has no CPU fallback" % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME, requested under an
+        # unversioned name), so if our library pulled in /opt/rocm's copy first a later `import torch` would bring a
+        # second runtime that sees no devices.  Loading torch first makes our NEEDED entry resolve to its copy.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.ig_last_error.restype = C.c_char_p
         _lib.ig_partials_count.restype = C.c_int64
@@ -185,6 +192,33 @@ class Context:
         assert c.ndim == 2 and c.shape[0] == f.size
         res = np.zeros(f.size, MOVE_RESULT_DTYPE)
         _ck(lib().ig_step_batch(self._h, C.c_int32(f.size), _p(f), _p(c), C.c_int32(c.shape[1]), _p(res)))
+        return res
+
+    # ---- speculative batches in steps (slots of a batch split over several GPUs)
+    def batch_upload(self, frags, cands, max_w):
+        f = np.ascontiguousarray(frags, np.int32)
+        c = np.ascontiguousarray(cands, np.int32)
+        assert c.ndim == 2 and c.shape[0] == f.size
+        _ck(lib().ig_batch_upload(self._h, C.c_int32(f.size), _p(f), _p(c), C.c_int32(c.shape[1]), C.c_int32(int(max_w))))
+
+    def batch_score(self, move0, w, slot_begin, slot_end):
+        _ck(lib().ig_batch_score(self._h, C.c_int32(int(move0)), C.c_int32(int(w)), C.c_int32(int(slot_begin)), C.c_int32(int(slot_end))))
+
+    def batch_records(self):
+        """-> ((device pointer, bytes per slot) of the per-slot records, the same for the per-candidate records)"""
+        p1, p2 = C.c_void_p(), C.c_void_p()
+        b1, b2 = C.c_int64(), C.c_int64()
+        _ck(lib().ig_batch_records(self._h, C.byref(p1), C.byref(b1), C.byref(p2), C.byref(b2)))
+        return (p1.value, b1.value), (p2.value, b2.value)
+
+    def batch_commit(self, move0, w):
+        n = C.c_int32()
+        _ck(lib().ig_batch_commit(self._h, C.c_int32(int(move0)), C.c_int32(int(w)), C.byref(n)))
+        return n.value
+
+    def batch_results(self, n_moves):
+        res = np.zeros(int(n_moves), MOVE_RESULT_DTYPE)
+        _ck(lib().ig_batch_results(self._h, C.c_int32(int(n_moves)), _p(res)))
         return res
 
     def batch_stats(self):

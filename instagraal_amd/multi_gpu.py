@@ -1,5 +1,14 @@
 """One chain split over N GPUs of a node (one process per GPU, torch.distributed / RCCL).
 
+Two ways to split, both bit-identical to the one-GPU chain for any N:
+
+``BatchRunner`` (used by bench.py): the candidate draws of consecutive moves do not depend on the genome, so W moves
+are scored against one state ("speculative batch") and committed in order.  Every rank holds the full problem; rank r
+slices and scores the slots [r * W/N, (r+1) * W/N) of each batch, the slot-major score records (exact int64 sums,
+~15 KB per slot) are all-gathered once per batch, and every rank runs the same commit step on identical inputs.
+
+``ShardedRunner`` (one move at a time, contact rows split):
+
 The genome state is tiny (68 N bytes) and replicated; every rank holds the contacts (6 GB at the
 human-scale shape, 288 GB HBM per GPU) and scores the candidate CSR rows r with r % N == rank of each
 move.  The partial sums are exact 64-bit integers (include/ig_detmath.h), so ONE all-reduce(SUM) of
@@ -56,3 +65,78 @@ class ShardedRunner:
             for k in res.dtype.names:
                 res[k][i] = getattr(r, k)
         return res
+
+
+class _DevBytes:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+class BatchRunner:
+    """W moves per batch, the slots of a batch split over the ranks (see the module docstring).
+
+    ``tensor_factory(kind, nbytes)`` (tests) returns the uint8 tensor standing for a record buffer; by default the
+    device buffers of the context are wrapped without a copy."""
+
+    def __init__(self, ctx, rank, world, dist=None, width=None, tensor_factory=None):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        if dist is None and world > 1:
+            import torch.distributed as dist
+        self.dist = dist
+        self.width = int(width) if width else max(24, 8 * world)
+        self.width = max(world, min(self.width, (64 // world) * world))  # equal chunks of at most 64 slots in total
+        self._tensor_factory = tensor_factory
+        self._bufs = None
+        self.batches = 0
+
+    def _buffers(self, cap_slots):
+        if self._bufs is None:
+            (p1, b1), (p2, b2) = self.ctx.batch_records()
+            if self._tensor_factory is not None:
+                t1 = self._tensor_factory("pre", b1 * cap_slots)
+                t2 = self._tensor_factory("cpre", b2 * cap_slots)
+            else:
+                import torch
+
+                t1 = torch.as_tensor(_DevBytes(p1, b1 * cap_slots), device="cuda")
+                t2 = torch.as_tensor(_DevBytes(p2, b2 * cap_slots), device="cuda")
+            self._bufs = ((t1, b1), (t2, b2))
+        return self._bufs
+
+    def _exchange(self, per):
+        """all-gather the records: rank r produced slots [r * per, (r + 1) * per)"""
+        for t, b in self._bufs:
+            chunk = per * b
+            out = t[: self.world * chunk]
+            mine = out[self.rank * chunk:(self.rank + 1) * chunk].clone()
+            try:
+                self.dist.all_gather_into_tensor(out, mine)
+            except (RuntimeError, AttributeError, NotImplementedError):
+                parts = [out[r * chunk:(r + 1) * chunk] for r in range(self.world)]
+                self.dist.all_gather(parts, mine)
+
+    def run(self, frags, cands):
+        frags = np.ascontiguousarray(frags, np.int32)
+        cands = np.ascontiguousarray(cands, np.int32)
+        n = frags.size
+        world, rank = self.world, self.rank
+        per_max = -(-self.width // world)
+        cap_slots = per_max * world  # the all-gather works on equal chunks
+        if self._tensor_factory is None and world > 1:
+            import torch
+
+            self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.ctx.batch_upload(frags, cands, cap_slots)
+        if world > 1:
+            self._buffers(cap_slots)
+        done = 0
+        while done < n:
+            w_now = min(self.width, n - done)
+            per = -(-w_now // world)
+            b, e = min(rank * per, w_now), min((rank + 1) * per, w_now)
+            self.ctx.batch_score(done, w_now, b, e)
+            if world > 1:
+                self._exchange(per)
+            done += self.ctx.batch_commit(done, w_now)
+            self.batches += 1
+        return self.ctx.batch_results(n)

@@ -144,6 +144,75 @@ def test_speculative_batches_equal_one_move_at_a_time(cfg, n_moves):
     assert outs[3][6]["batches"] < n_moves  # speculation actually happened
 
 
+def test_batch_slots_split_over_two_ranks_equal_one_gpu():
+    """multi_gpu.BatchRunner with world = 2 emulated on one GPU (two contexts, two threads, an in-process all-gather):
+    each rank scores half of the slots of every batch, the records are exchanged, both commit -- results and final
+    genomes identical to ig_step_batch on one context."""
+    import threading
+
+    import torch
+
+    from instagraal_amd import synth
+    from instagraal_amd.multi_gpu import BatchRunner
+    from instagraal_amd.sampler import sampler as hip_sampler
+
+    prob = synth.make_problem(*synth.CONFIGS["small"])
+
+    def fresh():
+        s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
+        s.set_param_simu(prob.params)
+        s.eval_likelihood_init()
+        return s
+
+    np.random.seed(21)
+    frags = np.resize(np.random.permutation(prob.n_frags), 300).astype(np.int32)
+    ref = fresh()
+    cands = ref.draw_candidates(frags, 5)
+    want = ref.ctx.step_batch(frags, cands)
+    want_state = ref.gpu_vect_frags.copy_from_gpu().soa17()
+
+    world = 2
+    barrier = threading.Barrier(world)
+    parts = {}
+
+    class InProcessDist:
+        def __init__(self, rank):
+            self.rank = rank
+
+        def all_gather_into_tensor(self, out, mine):
+            parts[(self.rank, out.numel())] = mine
+            torch.cuda.synchronize()
+            barrier.wait()
+            chunk = mine.numel()
+            for r in range(world):
+                out[r * chunk:(r + 1) * chunk].copy_(parts[(r, out.numel())])
+            torch.cuda.synchronize()
+            barrier.wait()
+
+    samplers = [fresh() for _ in range(world)]
+    got, errs = [None] * world, []
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            got[r] = BatchRunner(samplers[r].ctx, r, world, dist=InProcessDist(r), width=10).run(frags, cands)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for r in range(world):
+        assert got[r].tobytes() == want.tobytes(), r
+        assert np.array_equal(samplers[r].gpu_vect_frags.copy_from_gpu().soa17(), want_state), r
+    one = fresh()
+    assert BatchRunner(one.ctx, 0, 1, width=10).run(frags, cands).tobytes() == want.tobytes()
+
+
 def test_forced_apply_matches_oracle_and_keeps_sums_exact():
     """ig_apply == test_copy_struct (CL:2094-2151) for every mutation family; the maintained exact
     likelihood equals a from-scratch recomputation after each."""

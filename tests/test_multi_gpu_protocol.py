@@ -79,3 +79,92 @@ def test_two_rank_gloo_allreduce_of_exact_limbs():
         assert p.exitcode == 0
     out.sort()
     assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
+
+
+# ---------------------------------------------------------------- slots of a speculative batch split over the ranks
+
+
+class FakeBatchCtx:
+    """Mimics the batch-step API (ig_batch_*): the score records of slot w of the batch starting at move0 are a
+    deterministic byte pattern; the commit step checks that it sees the records of EVERY slot, whoever produced them."""
+
+    PRE_B, CPRE_B = 96, 16
+
+    def __init__(self):
+        self.t = {}
+        self.log = []
+
+    def tensor(self, kind, nbytes):
+        import torch
+
+        self.t[kind] = torch.zeros(nbytes, dtype=torch.uint8)
+        return self.t[kind]
+
+    def batch_records(self):
+        return (0, self.PRE_B), (0, self.CPRE_B)
+
+    def batch_upload(self, frags, cands, max_w):
+        self.frags, self.max_w = np.asarray(frags), max_w
+
+    @staticmethod
+    def pattern(move, nbytes, salt):
+        return np.random.RandomState(7919 * int(move) + salt).randint(0, 256, nbytes).astype(np.uint8)
+
+    def batch_score(self, move0, w, b, e):
+        import torch
+
+        for kind, nb, salt in (("pre", self.PRE_B, 1), ("cpre", self.CPRE_B, 2)):
+            self.t[kind].zero_()
+            for slot in range(b, e):
+                self.t[kind][slot * nb:(slot + 1) * nb] = torch.from_numpy(self.pattern(self.frags[move0 + slot], nb, salt))
+
+    def batch_commit(self, move0, w):
+        for kind, nb, salt in (("pre", self.PRE_B, 1), ("cpre", self.CPRE_B, 2)):
+            got = self.t[kind].numpy()
+            for slot in range(w):
+                assert np.array_equal(got[slot * nb:(slot + 1) * nb], self.pattern(self.frags[move0 + slot], nb, salt)), (kind, move0, slot)
+        n = min(w, 1 + (move0 * 7) % 5)  # a deterministic "conflict-free prefix"
+        self.log.append((move0, w, n))
+        return n
+
+    def batch_results(self, n):
+        from instagraal_amd import hip_lib
+
+        return np.zeros(n, hip_lib.MOVE_RESULT_DTYPE)
+
+
+def _batch_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    from instagraal_amd.multi_gpu import BatchRunner
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = FakeBatchCtx()
+    runner = BatchRunner(ctx, rank, world, dist=dist, width=7, tensor_factory=ctx.tensor)
+    frags = np.arange(100, 143, dtype=np.int32)
+    cands = np.tile(np.array([[1, 2, 3, -1, -1]], np.int32), (frags.size, 1))
+    res = runner.run(frags, cands)
+    q.put((rank, ctx.log, len(res)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_batch_slots_allgather():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out.sort()
+    assert out[0][1] == out[1][1]  # both ranks walked the same batches in lockstep
+    assert sum(n for _, _, n in out[0][1]) == 43 and out[0][2] == 43
+    assert all(w <= 7 for _, w, _ in out[0][1]) and any(w == 7 for _, w, _ in out[0][1])  # ragged last chunk: rank 1 owns 3 of 7 slots
