@@ -37,6 +37,7 @@ class ShardedRunner:
         ctx.set_shard(rank, world)
         self._tensor_factory = tensor_factory
         self._t = None
+        self._stream = None
 
     def _partials(self):
         if self._t is None:
@@ -45,12 +46,22 @@ class ShardedRunner:
             else:
                 import torch
 
-                self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
                 ptr, n = self.ctx.partials()
                 self._t = torch.as_tensor(_DevArray(ptr, n), device="cuda")
         return self._t
 
     def run(self, frags, cands):
+        if self._tensor_factory is None:
+            import torch
+
+            if self._stream is None:  # one stream for kernels and collectives, see BatchRunner.run
+                self._stream = torch.cuda.Stream()
+                self.ctx.set_stream(self._stream.cuda_stream)
+            with torch.cuda.stream(self._stream):
+                return self._run(frags, cands)
+        return self._run(frags, cands)
+
+    def _run(self, frags, cands):
         frags = np.ascontiguousarray(frags, np.int32)
         cands = np.ascontiguousarray(cands, np.int32)
         res = np.zeros(frags.size, hip_lib.MOVE_RESULT_DTYPE)
@@ -87,6 +98,7 @@ class BatchRunner:
         self.width = max(world, min(self.width, (64 // world) * world))  # equal chunks of at most 64 slots in total
         self._tensor_factory = tensor_factory
         self._bufs = None
+        self._stream = None
         self.batches = 0
 
     def _buffers(self, cap_slots):
@@ -123,9 +135,20 @@ class BatchRunner:
         per_max = -(-self.width // world)
         cap_slots = per_max * world  # the all-gather works on equal chunks
         if self._tensor_factory is None and world > 1:
+            # kernels and collectives must be ordered on ONE stream: a dedicated torch stream (its handle is not the
+            # null stream, which ig_set_stream reads as "make your own") becomes the library's stream and, inside the
+            # `with`, torch's current stream, which is what ProcessGroupNCCL orders its collectives against
             import torch
 
-            self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+                self.ctx.set_stream(self._stream.cuda_stream)
+            with torch.cuda.stream(self._stream):
+                return self._run(frags, cands, n, cap_slots)
+        return self._run(frags, cands, n, cap_slots)
+
+    def _run(self, frags, cands, n, cap_slots):
+        world, rank = self.world, self.rank
         self.ctx.batch_upload(frags, cands, cap_slots)
         if world > 1:
             self._buffers(cap_slots)
