@@ -43,6 +43,41 @@ def soa17_from_dict(S_o_A_frags, n):
     return out
 
 
+def estimate_rippe_host(sparse_matrix, np_sub_frags_2_frags, S_o_A_frags, n_frags, mean_value_trans, max_dist_kb, size_bin_kb):
+    """Host part of estimate_parameters_rippe (CL:2239-2341), vectorised: for the first n_frags // 10 sub-fragment rows
+    whose contig is longer than one bin, the cis contacts are binned by genomic distance (zeros included: every such
+    row contributes one value per bin, CL:2289-2292); the per-bin means (+ the trans level) are fitted with
+    optim_rippe_curve_update.estimate_param_rippe; the trans level is then lowered tenfold (CL:2338) before the
+    cis/trans cut-off is solved.  -> (bins_upd, mean_contacts_upd, p, y_estim, mean_value_trans / 10, d_max)"""
+    bins = np.arange(size_bin_kb, max_dist_kb + size_bin_kb, size_bin_kb)
+    nb = len(bins)
+    sm = sparse_matrix.tocsr()
+    parent = np_sub_frags_2_frags["x"].astype(np.int64)
+    id_c = S_o_A_frags["id_c"][parent]
+    s_all = S_o_A_frags["start_bp"][parent] / 1000.0 + np_sub_frags_2_frags["y"]
+    len_kb = S_o_A_frags["l_cont_bp"][parent] / 1000
+    acc = np.zeros(nb, np.float64)
+    rows = 0
+    for i in range(0, int(n_frags) // 10):
+        if not (size_bin_kb < len_kb[i]):
+            continue
+        s, e = sm.indptr[i], sm.indptr[i + 1]
+        j, dat = sm.indices[s:e], sm.data[s:e]
+        keep = id_c[j] == id_c[i]
+        d = np.abs(s_all[i] - s_all[j[keep]])
+        ok = d < max_dist_kb
+        acc += np.bincount((d[ok] / size_bin_kb).astype(np.int64), weights=dat[keep][ok], minlength=nb)[:nb]
+        rows += 1
+    mean = acc / max(rows, 1)
+    mean_contacts = np.where((rows == 0) | (mean == 0), np.nan, mean + mean_value_trans).astype(np.float32)
+    good = ~np.isnan(mean_contacts)
+    bins_upd = np.array(bins[good])
+    mean_contacts_upd = np.array(mean_contacts[good])
+    p, y_estim = opti.estimate_param_rippe(mean_contacts_upd, bins_upd)
+    mvt = mean_value_trans / 10.0  # CL:2338
+    return bins_upd, mean_contacts_upd, p, y_estim, mvt, opti.estimate_max_dist_intra(p, mvt)
+
+
 def problem_to_context(prob, params=None, device_id=0, rank=0, world=1):
     """Upload a synth.SynthProblem (contacts, sub-fragment table, state, fixed parameters)."""
     ctx = hip_lib.Context(device_id)
@@ -180,34 +215,9 @@ class sampler:  # noqa: N801 - the reference's class name
         """CL:2239-2372: binned mean cis contacts of the first n_frags/10 sub-fragment rows, leastsq fit,
         cis/trans cut-off; then the initial likelihood."""
         self.bins = np.arange(size_bin_kb, max_dist_kb + size_bin_kb, size_bin_kb)
-        nb = len(self.bins)
-        sm = self.sparse_matrix.tocsr()
-        sub2frag = self.np_sub_frags_2_frags
-        parent = sub2frag["x"].astype(np.int64)
-        id_c = self.S_o_A_frags["id_c"][parent]
-        s_all = self.S_o_A_frags["start_bp"][parent] / 1000.0 + sub2frag["y"]
-        len_kb = self.S_o_A_frags["l_cont_bp"][parent] / 1000
-        acc = np.zeros(nb, np.float64)
-        rows = 0
-        for i in range(0, int(self.n_frags) // 10):
-            if not (size_bin_kb < len_kb[i]):
-                continue
-            s, e = sm.indptr[i], sm.indptr[i + 1]
-            j, dat = sm.indices[s:e], sm.data[s:e]
-            keep = id_c[j] == id_c[i]
-            d = np.abs(s_all[i] - s_all[j[keep]])
-            ok = d < max_dist_kb
-            acc += np.bincount((d[ok] / size_bin_kb).astype(np.int64), weights=dat[keep][ok], minlength=nb)[:nb]
-            rows += 1
-        mean = acc / max(rows, 1)
-        epsi = self.mean_value_trans
-        mean_contacts = np.where((rows == 0) | (mean == 0), np.nan, mean + epsi).astype(np.float32)
-        good = ~np.isnan(mean_contacts)
-        self.bins_upd = np.array(self.bins[good])
-        self.mean_contacts_upd = np.array(mean_contacts[good])
-        p, self.y_estim = opti.estimate_param_rippe(self.mean_contacts_upd, self.bins_upd)
-        self.mean_value_trans = self.mean_value_trans / 10.0  # CL:2338
-        estim_max_dist = opti.estimate_max_dist_intra(p, self.mean_value_trans)
+        self.bins_upd, self.mean_contacts_upd, p, self.y_estim, self.mean_value_trans, estim_max_dist = estimate_rippe_host(
+            self.sparse_matrix, self.np_sub_frags_2_frags, self.S_o_A_frags, self.n_frags, self.mean_value_trans, max_dist_kb,
+            size_bin_kb)
         self.set_param_simu(self.setup_rippe_parameters(p, estim_max_dist), 0)
         self.set_param_simu(self.param_simu, 1)
         self.eval_likelihood_init()

@@ -99,6 +99,37 @@ def run_case(name, mode, outdir):
     print("wrote", out, "launches/move %.0f" % launches, "last ret", rec["ret"][-1])
 
 
+def estimate_golden(outdir, mode):
+    """the reference's own estimate_parameters_rippe (CL:2239-2372) driven as simu_single does
+    (SS:157-171) on the synthetic 'small' problem: binned mean contacts, fitted parameters, cut-off, initial likelihood."""
+    from instagraal_amd import synth
+    from oracle import oracle_lib as ol
+    import pycuda.driver as cuda  # noqa: F401
+    from instagraal.cuda_lib_gl_single import sampler as ref_sampler
+
+    ol.set_mode(mode)
+    prob = synth.make_problem(*synth.CONFIGS["small"])
+    kw = prob.sampler_kwargs()
+    np.random.seed(5)
+    s = ref_sampler(*[kw[k] for k in kw])
+    g = s.gpu_vect_frags
+    g.copy_from_gpu()
+    id_start = np.nonzero(g.start_bp == 0)[0]
+    max_dist_kb = g.l_cont_bp[id_start].max() / 1000.0
+    mean_size_bin_kb = 1.8  # synthetic sub-fragments are log-normal around 1.8 kb (SS:161 takes the measured mean)
+    mvt0 = float(s.mean_value_trans)
+    s.estimate_parameters_rippe(max_dist_kb, mean_size_bin_kb / 2.0, False)
+    par = s.param_simu
+    out = os.path.join(outdir, "small_estimate_mode%d.npz" % mode)
+    np.savez_compressed(out, config="small", max_dist_kb=max_dist_kb, size_bin_kb=mean_size_bin_kb / 2.0, mean_value_trans_in=mvt0,
+                        mean_value_trans_out=float(s.mean_value_trans), bins_upd=np.asarray(s.bins_upd, np.float64),
+                        mean_contacts_upd=np.asarray(s.mean_contacts_upd, np.float64), y_estim=np.asarray(s.y_estim, np.float64),
+                        params=np.array([par[k][0] for k in ("kuhn", "lm", "c1", "slope", "d", "d_max", "fact", "v_inter")], np.float64),
+                        init_nz=float(s.gpu_curr_likelihood_nz.get()[0]), init_full=float(s.likelihood_t))
+    print("wrote", out, "params", [float(par[k][0]) for k in ("kuhn", "lm", "slope", "d", "d_max", "fact", "v_inter")],
+          "nz", float(s.gpu_curr_likelihood_nz.get()[0]))
+
+
 def host_helper_goldens(outdir):
     """Reference host helpers that need no kernels ('importable-and-runnable pieces')."""
     from instagraal import optim_rippe_curve_update as opti
@@ -118,12 +149,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--cases", default=",".join(CASES))
+    ap.add_argument("--extra", default="estimate")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     os.chdir(tempfile.mkdtemp())  # the reference's log.py drops a log file in the CWD
     for name in a.cases.split(","):
         for mode in (0, 1):
             run_case(name, mode, a.out)
+    if "estimate" in a.extra.split(","):
+        for mode in (0, 1):
+            estimate_golden(a.out, mode)
     host_helper_goldens(a.out)
 
 
