@@ -144,6 +144,49 @@ def test_speculative_batches_equal_one_move_at_a_time(cfg, n_moves):
     assert outs[3][6]["batches"] < n_moves  # speculation actually happened
 
 
+def test_headline_size_properties():
+    """BASELINE.json's headline shape (50 k bins / 50 M contacts), where the oracle is far too slow to follow: the
+    size-independent properties of the path.  (1) the incrementally maintained exact likelihood limbs equal a from-scratch
+    recomputation after the run; (2) the trajectory does not depend on the batch width (24 moves per launch vs one move
+    at a time): result records, final genome, stale flags; (3) the genome stays a valid set of linear contigs."""
+    from instagraal_amd import hip_lib, synth
+    from instagraal_amd.sampler import sampler as hip_sampler
+
+    prob = synth.make_problem(*synth.CONFIGS["cfg3"])
+    np.random.seed(0)
+    frags = np.resize(np.random.permutation(prob.n_frags), 120).astype(np.int32)
+    outs = []
+    try:
+        for W in (24, 1):
+            hip_lib.set_batch_width(W)
+            s = hip_sampler(**prob.sampler_kwargs(), device_id=0, coo=(prob.coo_row, prob.coo_col, prob.coo_cnt))
+            s.set_param_simu(prob.params)
+            s.eval_likelihood_init()
+            np.random.seed(1)
+            cands = s.draw_candidates(frags, 5)
+            res = s.ctx.step_batch(frags, cands)
+            sums, _ = s.ctx.debug_globals()
+            _, _, limbs = s.ctx.full_likelihood(0)
+            assert [int(x) for x in sums[:5]] == [int(x) for x in limbs[:5]], W
+            st = s.gpu_vect_frags.copy_from_gpu().soa17()
+            outs.append((res.tobytes(), st, [int(x) for x in s.ctx.valid_insert()]))
+            s.free_gpu()
+    finally:
+        hip_lib.set_batch_width(24)
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+    # structural validity of the final genome (names of the 17 rows: hip_lib.FRAG_FIELDS)
+    f = dict(zip(hip_lib.FRAG_FIELDS, outs[0][1]))
+    for cid in np.unique(f["id_c"])[:200]:
+        m = np.nonzero(f["id_c"] == cid)[0]
+        order = m[np.argsort(f["pos"][m])]
+        assert np.array_equal(f["pos"][order], np.arange(len(m)))
+        assert np.all(f["l_cont"][m] == len(m))
+        assert f["prev"][order[0]] == -1 and f["next"][order[-1]] == -1
+        assert np.array_equal(f["next"][order[:-1]], order[1:]) and np.array_equal(f["prev"][order[1:]], order[:-1])
+        assert np.array_equal(f["start_bp"][order], np.concatenate([[0], np.cumsum(f["len_bp"][order])[:-1]]))
+
+
 def test_estimate_parameters_rippe_matches_reference_golden():
     """SURVEY 8(f) f2 end to end: estimate_parameters_rippe (CL:2239-2372) on the GPU sampler = the reference's own
     method over the oracle kernels: parameter struct (float32 fields) and the initial likelihood, bit for bit."""
