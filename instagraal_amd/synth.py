@@ -298,3 +298,69 @@ CONFIGS = {
     "cfg3": (50_000, 50_000_000),
     "cfg5": (200_000, 500_000_000),
 }
+
+
+def write_text_dataset(folder, n_contigs=10, mean_frags=110, seed=7, contacts_per_frag=40):
+    """A small synthetic instaGRAAL INPUT folder (the three text files `run_instagraal` reads, instagraal.py:502-517,
+    pyramid_sparse.py:198-200, plus the FASTA): restriction fragments of log-normal size on `n_contigs` contigs, a few
+    fragments shorter than 50 bp and a few without any contact (both are removed by the builder's filter), P(s)-like
+    cis contacts and uniform trans contacts.  Formats: fragments_list.txt `id chrom start_pos end_pos size gc_content`
+    (id 1-based per contig), info_contigs.txt `contig length n_frags cumul_length`, abs_fragments_contacts_weighted.txt
+    `id_frag_a id_frag_b n_contact` with 0-based absolute ids.  Returns (n_frags, n_contact_lines)."""
+    import os
+
+    rng = np.random.default_rng(seed)
+    os.makedirs(folder, exist_ok=True)
+    sizes = np.maximum(8, rng.poisson(mean_frags, n_contigs))
+    names = ["ctg%02d" % (i + 1) for i in range(n_contigs)]
+    frag_rows, contig_rows, seqs = [], [], []
+    starts_abs, mids_kb, contig_of = [], [], []
+    cumul = 0
+    for ci, (name, nf) in enumerate(zip(names, sizes)):
+        lens = np.clip(np.round(rng.lognormal(np.log(900.0), 0.8, size=nf)), 20, 12000).astype(np.int64)
+        lens[rng.random(nf) < 0.02] = rng.integers(20, 50)  # a few fragments below the 50 bp filter
+        ends = np.cumsum(lens)
+        begins = ends - lens
+        for k in range(nf):
+            frag_rows.append("%d\t%s\t%d\t%d\t%d\t%.4f\n" % (k + 1, name, begins[k], ends[k], lens[k], rng.uniform(0.3, 0.6)))
+            mids_kb.append((begins[k] + ends[k]) / 2000.0)
+            contig_of.append(ci)
+        contig_rows.append("%s\t%d\t%d\t%d\n" % (name, ends[-1], nf, cumul))
+        cumul += nf
+        seqs.append("".join(rng.choice(list("ACGT"), size=int(ends[-1]))))
+    n = cumul
+    mids_kb, contig_of = np.array(mids_kb), np.array(contig_of)
+    dead = rng.random(n) < 0.015  # fragments that never appear in a contact
+    pairs = {}
+    n_draw = n * contacts_per_frag
+    a = rng.integers(0, n, size=n_draw)
+    cis = rng.random(n_draw) < 0.85
+    # cis partner: a log-uniform genomic offset (~ s^-1 decay), trans partner: uniform
+    off = np.exp(rng.uniform(np.log(0.3), np.log(300.0), size=n_draw)) * rng.choice([-1.0, 1.0], size=n_draw)
+    for i in range(n_draw):
+        fa = int(a[i])
+        if cis[i]:
+            members = np.nonzero(contig_of == contig_of[fa])[0]
+            fb = int(members[np.argmin(np.abs(mids_kb[members] - (mids_kb[fa] + off[i])))])
+        else:
+            fb = int(rng.integers(0, n))
+        if fa == fb or dead[fa] or dead[fb]:
+            continue
+        key = (min(fa, fb), max(fa, fb))
+        pairs[key] = pairs.get(key, 0) + 1
+    with open(os.path.join(folder, "fragments_list.txt"), "w") as f:
+        f.write("id\tchrom\tstart_pos\tend_pos\tsize\tgc_content\n")
+        f.writelines(frag_rows)
+    with open(os.path.join(folder, "info_contigs.txt"), "w") as f:
+        f.write("contig\tlength\tn_frags\tcumul_length\n")
+        f.writelines(contig_rows)
+    with open(os.path.join(folder, "abs_fragments_contacts_weighted.txt"), "w") as f:
+        f.write("id_frag_a\tid_frag_b\tn_contact\n")
+        for (fa, fb) in sorted(pairs):
+            f.write("%d\t%d\t%d\n" % (fa, fb, pairs[(fa, fb)]))
+    with open(os.path.join(folder, "genome.fa"), "w") as f:
+        for name, seq in zip(names, seqs):
+            f.write(">%s\n" % name)
+            for i in range(0, len(seq), 70):
+                f.write(seq[i:i + 70] + "\n")
+    return n, len(pairs)

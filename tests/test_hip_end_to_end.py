@@ -1,0 +1,82 @@
+"""GPU end-to-end: an instaGRAAL input folder (text files + FASTA) -> pyramid -> MI355X sampler -> cycles -> info_frags.txt /
+genome.fasta (instagraal_amd.simulation), checked against the oracle sampler replaying the same run on the
+CPU with the same fitted parameters: every move, the final genome, the output files byte for byte."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LEVEL = 2
+
+
+@pytest.mark.parametrize("id_start_sample_param", [4, 0])
+def test_text_folder_to_assembly_matches_oracle_replay(tmp_path, id_start_sample_param):
+    from instagraal_amd import io_frags, synth
+    from instagraal_amd.simulation import assemble_sampler_args, instagraal_class
+    from oracle import oracle_lib as ol
+    from oracle.sampler_oracle import OracleSampler
+
+    ol.build()
+    data, out = str(tmp_path / "data"), str(tmp_path / "out")
+    synth.write_text_dataset(data, n_contigs=10, mean_frags=110, seed=7, contacts_per_frag=40)
+    np.random.seed(17)
+    p2 = instagraal_class(name="synth", folder_path=data, fasta=os.path.join(data, "genome.fa"), device=0, level=LEVEL,
+                          n_iterations_em=30, n_iterations_mcmc=100, is_simu=False, scrambled=False, perform_em=False, use_rippe=True,
+                          sample_param=True, thresh_factor=1, output_folder=out)
+    s = p2.simulation.sampler
+    fitted = {k: float(s.param_simu[k][0]) for k in s.param_simu.dtype.names}
+    n_cycles = 2
+    p2.full_em(n_cycles=n_cycles, n_neighbours=5, bomb=True, id_start_sample_param=id_start_sample_param)
+    folder = p2.simulation.output_folder
+    for f in ("info_frags.txt", "genome.fasta", "list_mutations.txt", "list_likelihood.txt", "save_simu_step_1.txt"):
+        assert os.path.getsize(os.path.join(folder, f)) > 0, f
+    got_state = s.gpu_vect_frags.copy_from_gpu().soa17()
+
+    # ---- the oracle replays the run: same arguments, same fitted parameters, same RNG stream
+    args, lev, sub = assemble_sampler_args(p2.simulation.hic_pyr, LEVEL, 30, False, True)
+    args.pop("vel"), args.pop("pos")
+    o = OracleSampler(**args, vel=None, pos=None, mode=ol.MODE_DET)
+    o.set_param_simu(fitted)
+    o.bins = s.bins
+    o.eval_likelihood_init()
+    np.random.seed(17)
+    o.bomb_the_genome()
+    list_frags = np.arange(0, o.n_new_frags)
+    rows, nuis = [], []
+    t, n_iter = 0, n_cycles * o.n_new_frags
+    for j in range(n_cycles):
+        np.random.shuffle(list_frags)
+        for id_frag in list_frags:
+            r = o.step_sampler(int(id_frag), 5, o.dt)
+            rows.append((int(id_frag), int(r[3]), int(r[2]), float(r[0]), float(r[1]), int(r[5])))
+            if j > id_start_sample_param:  # IG:241-252: nuisance parameters are sampled after every move
+                q = o.step_nuisance_parameters(o.dt, t, n_iter)
+                nuis.append((float(q[0]), float(q[4]), float(q[2]), int(q[6])))
+            t += 1
+    want_mut = "id_fA\tid_fB\tid_mutation\n" + "".join("%s\t%s\t%s\n" % (a, b, m) for a, b, m, _, _, _ in rows)
+    assert open(os.path.join(folder, "list_mutations.txt")).read() == want_mut
+    assert [float(x) for x in open(os.path.join(folder, "list_likelihood.txt")).read().split()] == [r[3] for r in rows]
+    assert [float(x) for x in open(os.path.join(folder, "list_dist_init_genome.txt")).read().split()] == [r[4] for r in rows]
+    assert [int(x) for x in open(os.path.join(folder, "list_n_contigs.txt")).read().split()] == [r[5] for r in rows]
+    assert np.array_equal(got_state, o.gpu_vect_frags.soa17())
+    for name, col in (("fact", 0), ("slope", 1), ("d_max", 2)):
+        got = [np.float32(x) for x in open(os.path.join(folder, "list_%s.txt" % name)).read().split()]  # written as float32 repr
+        assert got == [np.float32(q[col]) for q in nuis], name
+    assert [int(float(x)) for x in open(os.path.join(folder, "list_success.txt")).read().split()] == [q[3] for q in nuis]
+    assert (len(nuis) > 0) == (id_start_sample_param == 0)
+
+    class V:
+        pass
+
+    v = V()
+    g = o.gpu_vect_frags
+    for k in ("id_c", "pos", "ori", "activ", "id_d"):
+        setattr(v, k, np.asarray(getattr(g, k)))
+    spec = p2.simulation.hic_pyr.spec_level[str(LEVEL)]
+    fa, info = str(tmp_path / "o.fasta"), str(tmp_path / "o_info.txt")
+    io_frags.write_assembly(v, p2.simulation.level.frags_init_contigs, spec["start_pos"], spec["end_pos"],
+                            p2.simulation.hic_pyr.dict_sequence_contigs, fa, info)
+    assert open(info, "rb").read() == open(os.path.join(folder, "info_frags.txt"), "rb").read()
+    assert open(fa, "rb").read() == open(os.path.join(folder, "genome.fasta"), "rb").read()
