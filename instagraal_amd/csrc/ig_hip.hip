@@ -2449,7 +2449,9 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
     {
         /* one slot never needs more than capC x Z entries; a batch shares the pool and the slots that do not fit
          * are re-run (MoveCtl.overflow) */
-        const size_t Zc = (size_t)std::max<long long>(c->Z, 1) * (size_t)std::max(capC, capW > 1 ? 16 : 1);
+        size_t Zc = (size_t)std::max<long long>(c->Z, 1) * (size_t)std::max(capC, capW > 1 ? 16 : 1);
+        if (const char* e = getenv("IG_POOL_ENTRIES")) /* tests: a small pool forces the overflow / re-run path */
+            Zc = std::max<size_t>((size_t)atoll(e), (size_t)std::max<long long>(c->Z, 1) * (size_t)capC);
         DALLOC(m.sl_li, Zc);
         DALLOC(m.sl_lj, Zc);
         DALLOC(m.sl_ob, Zc);

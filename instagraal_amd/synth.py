@@ -297,6 +297,8 @@ CONFIGS = {
     "cfg2": (5_000, 2_000_000),
     "cfg3": (50_000, 50_000_000),
     "cfg5": (200_000, 500_000_000),
+    # few long contigs: windows of 1 000 .. 7 000 sub-fragments (the 32 KB LDS stage and the unstaged path of k_score_list)
+    "bigctg": (4_000, 400_000, DEFAULT_SEED, 1_000),
 }
 
 

@@ -144,6 +144,53 @@ def test_speculative_batches_equal_one_move_at_a_time(cfg, n_moves):
     assert outs[3][6]["batches"] < n_moves  # speculation actually happened
 
 
+def test_large_windows_match_oracle():
+    """Contigs of thousands of sub-fragments: the 32 KB column stage of k_score_list<4096> and, above 4096 sub-fragments,
+    the unstaged path (8-byte gathers from L2), against the oracle move by move; then a batch."""
+    prob, s, o = make_pair("bigctg")
+    soa = prob.sampler_kwargs()["S_o_A_frags"]
+    assert soa["sub_l_cont"].max() > 4096 and np.sum((soa["sub_l_cont"] > 1024) & (soa["sub_l_cont"] <= 4096)) > 0
+    np.random.seed(4)
+    frags = np.random.permutation(prob.n_frags)[:24]
+    for f in frags[:6]:
+        cands = s.return_neighbours(int(f), 5)
+        a = s.step_sampler(int(f), 5, candidates=cands)
+        b = o.step_sampler(int(f), 5, o.dt, candidates=cands)
+        assert np.array_equal(s.all_scores, o.all_scores)
+        assert (a[0], a[1], a[2], a[3], int(a[5])) == (b[0], b[1], b[2], b[3], int(b[5]))
+    rest = frags[6:].astype(np.int32)
+    cands = s.draw_candidates(rest, 5)
+    res = s.ctx.step_batch(rest, cands)
+    for f, c, r in zip(rest, cands, res):
+        b = o.step_sampler(int(f), 5, o.dt, candidates=[int(x) for x in c if x >= 0])
+        assert (float(r["o"]), float(r["dist"]), int(r["op_sampled"]), int(r["id_f_sampled"])) == (b[0], b[1], b[2], b[3])
+    assert np.array_equal(s.gpu_vect_frags.copy_from_gpu().soa17(), o.gpu_vect_frags.soa17())
+
+
+def test_slice_pool_overflow_reruns_the_slot(monkeypatch):
+    """a pool that holds one move's slice lists but not a batch's: the slots that do not fit are flagged by k_offsets and
+    re-run at the head of the next batch; results identical to the roomy pool"""
+    from instagraal_amd import synth
+    from instagraal_amd.sampler import sampler as hip_sampler
+
+    prob = synth.make_problem(*synth.CONFIGS["small"])
+    np.random.seed(2)
+    frags = np.resize(np.random.permutation(prob.n_frags), 200).astype(np.int32)
+    outs = []
+    for pool in (None, str(8 * prob.n_contacts + 1)):
+        if pool:
+            monkeypatch.setenv("IG_POOL_ENTRIES", pool)
+        s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
+        s.set_param_simu(prob.params)
+        s.eval_likelihood_init()
+        np.random.seed(3)
+        cands = s.draw_candidates(frags, 5)
+        res = s.ctx.step_batch(frags, cands)
+        outs.append((res.tobytes(), s.gpu_vect_frags.copy_from_gpu().soa17(), s.ctx.batch_stats()["batches"]))
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
+    assert outs[1][2] > outs[0][2]  # the small pool really cut batches short
+
+
 def test_headline_size_properties():
     """BASELINE.json's headline shape (50 k bins / 50 M contacts), where the oracle is far too slow to follow: the
     size-independent properties of the path.  (1) the incrementally maintained exact likelihood limbs equal a from-scratch
