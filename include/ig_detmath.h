@@ -228,6 +228,73 @@ IG_HD double ig_pixel_term(float ex, float ex_z, int ob, double lgf, const doubl
     return res + (double)ex_z * IG_LOG_E_F;
 }
 
+/* ---- the per-contact term --------------------------------------------------------------------------------
+ * Linear contig, d == 2 (the only value the reference ever uses, optim_rippe_curve_update.py:8), sane parameters:
+ *     P(s) = amp * s^slope,  amp = c1 * fact,  clamped below by v_inter and replaced by it outside (0, d_max);
+ *     term = ob * log10 P(s) - P(s) - log10(ob!) + P_z * log10(e)               (KA:4426-4462, 251-270)
+ * Evaluated with ONE log2 and ONE exp2 in double: y = slope * log2(s), P = amp * 2^y, log10 P = (y + log2 amp) * log10(2)
+ * (the reference rounds P(s) to float and takes log10 of that float again: a second log for 1e-7 of relative
+ * difference per term, inside its own float noise).  ig_hot holds what does not depend on the contact.
+ * Everything else (circular contigs, d != 2, degenerate parameters, ob == 0) composes ig_rippe* and ig_pixel_term. */
+typedef struct ig_hot {
+    int fast;         /* the parameters are in the domain of the one-log evaluation */
+    float d_max, v_inter;
+    double slope, amp, log2_amp, v_inter_d, lg_v_inter;
+} ig_hot;
+
+IG_HD ig_hot ig_hot_make(const ig_params p, const double* T)
+{
+    ig_hot h;
+    h.d_max = p.d_max;
+    h.v_inter = p.v_inter;
+    h.slope = (double)p.slope;
+    h.amp = (double)p.c1 * (double)p.fact; /* exact: two 24-bit significands */
+    h.v_inter_d = (double)p.v_inter;
+    /* |slope * log2(s)| <= 1000 for every positive float s (log2 in [-149, 128]): ig_exp2's range checks cannot fire;
+     * amp a normal positive double; all comparisons false for NaNs */
+    h.fast = (p.d == 2.0f) && (p.slope != 0.0f) && (p.slope != 2.0f) && (p.slope > -6.5f) && (p.slope < 6.5f) &&
+             (p.v_inter > 0.0f) && (p.v_inter < IG_INFF) && (h.amp > 1e-300) && (h.amp < 1e300);
+    h.log2_amp = h.fast ? ig_log2_pos(h.amp, T) : 0.0;
+    h.lg_v_inter = h.fast ? ig_log2_pos(h.v_inter_d, T) * IG_LOG2_10_INV : 0.0; /* == ig_log10(v_inter) */
+    return h;
+}
+
+/* h->fast, ob > 0.  inter: trans pair (P = P_z = v_inter, the caller passes ex_z = v_inter) */
+IG_HD double ig_term_hot(float s, int inter, int ob, double lgf, float ex_z, const ig_hot* h, const double* T)
+{
+    const int in = (s > 0.0f) && (s < h->d_max);
+    const double L = ig_log2_pos((double)(in ? s : 1.0f), T);
+    const double y = h->slope * L;
+    const double res = h->amp * ig_exp2_core(y, T);
+    const int cis_model = in && !inter && (res > h->v_inter_d); /* else: the trans level (KA:153-163 max(., v_inter)) */
+    const double ex = cis_model ? res : h->v_inter_d;
+    const double lg = cis_model ? (y + h->log2_amp) * IG_LOG2_10_INV : h->lg_v_inter;
+    const double t = (((double)ob * lg) - ex) - lgf;
+    return t + (double)ex_z * IG_LOG_E_F;
+}
+
+/* one (i, j) contact: KA:4430-4462 (same text at 4182-4208, 4327-4353) */
+IG_HD double ig_pair_term(const ig_params p, const ig_hot* h, int cis, float s, float s_z, float s_tot, float s_tot_z, int ob,
+                          double lgf, const double* T)
+{
+    float ex, ex_z;
+    if (cis) {
+        if (s_tot == 0) {
+            ex_z = (s_z < p.d_max) ? ig_rippe(s_z, p, T) : p.v_inter;
+            if (h->fast && ob > 0) return ig_term_hot(s, 0, ob, lgf, ex_z, h, T);
+            ex = ig_rippe(s, p, T);
+        } else {
+            ex = ig_rippe_circ(s, s_tot, p, T);
+            ex_z = (s_z < p.d_max) ? ig_rippe_circ(s_z, s_tot_z, p, T) : p.v_inter;
+        }
+    } else {
+        ex = p.v_inter;
+        ex_z = p.v_inter;
+        if (h->fast && ob > 0) return ig_term_hot(0.0f, 1, ob, lgf, ex_z, h, T);
+    }
+    return ig_pixel_term(ex, ex_z, ob, lgf, T);
+}
+
 /* ---- exact accumulation -------------------------------------------------
  * A term is quantised to a multiple of 2^-32 (round-half-even) and added as
  * a 64-bit integer; integer addition is associative, so any thread/wave/

@@ -302,8 +302,8 @@ __device__ __forceinline__ float pz_lookup(const PzTab& t, const ig_params& p, f
 }
 
 /* T: the log2/exp2 table of ig_detmath.h (a kernel passes its LDS copy, everything else ig_tab()) */
-__device__ __forceinline__ long long eval_q(const ig_params& p, float mean_kb, uint2 a, uint2 b, const ColMeta* __restrict__ cm,
-                                            int ob, double lgf, const PzTab& pz, const double* T)
+__device__ __forceinline__ long long eval_q(const ig_params& p, const ig_hot& h, float mean_kb, uint2 a, uint2 b,
+                                            const ColMeta* __restrict__ cm, int ob, double lgf, const PzTab& pz, const double* T)
 {
     const float di = __uint_as_float(a.x), dj = __uint_as_float(b.x);
     const int pi = (int)(a.y & 0x0fffffffu), pj = (int)(b.y & 0x0fffffffu);
@@ -314,14 +314,16 @@ __device__ __forceinline__ long long eval_q(const ig_params& p, float mean_kb, u
         const float s_tot = cm[ci].stot;
         const int d = pi > pj ? pi - pj : pj - pi;
         if (s_tot == 0) {
-            ex = ig_rippe(s, p, T);
             ex_z = pz_lookup(pz, p, mean_kb, d);
+            if (h.fast && ob > 0) return ig_quantize(ig_term_hot(s, 0, ob, lgf, ex_z, &h, T));
+            ex = ig_rippe(s, p, T);
         } else {
             expected_circ(p, mean_kb, s, s_tot, d, cm[cj].len, &ex, &ex_z);
         }
     } else {
         ex = p.v_inter;
         ex_z = p.v_inter;
+        if (h.fast && ob > 0) return ig_quantize(ig_term_hot(0.0f, 1, ob, lgf, ex_z, &h, T));
     }
     return ig_quantize(ig_pixel_term(ex, ex_z, ob, lgf, T));
 }
@@ -450,6 +452,7 @@ __global__ void k_full_nz(const long long* __restrict__ rowptr, const int2* __re
                           const double* __restrict__ lgf_tab, int M, int rank, int world, long long* out)
 {
     const ig_params p = g->par[which];
+    const ig_hot hot = ig_hot_make(p, ig_tab());
     const float mean = g->mean_kb;
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -469,9 +472,8 @@ __global__ void k_full_nz(const long long* __restrict__ rowptr, const int2* __re
             const float s = fabsf(di - t.dist[j]);
             const int dp = pi - cpj.y;
             const float s_z = (float)(dp < 0 ? -dp : dp) * mean;
-            float ex, ex_z;
-            expected_pair(p, ci == cpj.x, s, s_z, sti, (float)li * mean, ex, ex_z);
-            const long long q = ig_quantize(ig_pixel_term(ex, ex_z, v.y, lgfact_dev(v.y, lgf_tab), ig_tab()));
+            const long long q = ig_quantize(ig_pair_term(p, &hot, ci == cpj.x, s, s_z, sti, (float)li * mean, v.y, lgfact_dev(v.y, lgf_tab),
+                                                         ig_tab()));
             hi += q >> 32;
             lo += (long long)(unsigned int)q;
         }
@@ -1018,39 +1020,15 @@ __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ row
 #define LDS_PZ 1024
 #define LDS_LGF 256
 
-struct HotPar {
-    float d_max, v_inter, c1, fact, ex_out;
-    int fast;
-    double slope;
-};
-/* |slope * log2(s)| <= 1000 for every positive float s (log2 in [-149, 128]): ig_exp2's range checks cannot fire */
-#define HOT_SLOPE_MAX 6.5f
-
-__device__ __forceinline__ HotPar hot_params(const ig_params& p)
-{
-    HotPar h;
-    h.d_max = p.d_max;
-    h.v_inter = p.v_inter;
-    h.c1 = p.c1;
-    h.fact = p.fact;
-    h.ex_out = ig_fmaxf(0.0f, p.v_inter); /* ig_rippe outside (0, d_max) */
-    h.slope = (double)p.slope;
-    h.fast = (p.d == 2.0f) && (p.slope != 0.0f) && (p.slope != 2.0f) && (p.slope > -HOT_SLOPE_MAX) && (p.slope < HOT_SLOPE_MAX) &&
-             (p.v_inter > 0.0f) && (p.v_inter < IG_INFF); /* all false for NaNs */
-    return h;
-}
-
-/* general (checked) evaluation of a linear-cis / trans pair, out of line */
+/* general (checked) evaluation of a linear-cis / trans pair, out of line: counts >= LDS_LGF, rank distances beyond the
+ * LDS P_z table, parameters outside the one-log domain */
 __device__ __noinline__ double term_general(const ig_params p, float mean_kb, float s, int dkey, int ob, double lgf, PzTab pz)
 {
-    float ex, ex_z;
-    if (dkey < 0) {
-        ex = p.v_inter;
-        ex_z = p.v_inter;
-    } else {
-        ex = ig_rippe(s, p, ig_tab());
-        ex_z = pz_lookup(pz, p, mean_kb, dkey);
-    }
+    const ig_hot h = ig_hot_make(p, ig_tab()); /* rare path: recomputed rather than passed */
+    const int inter = dkey < 0;
+    const float ex_z = inter ? p.v_inter : pz_lookup(pz, p, mean_kb, dkey);
+    if (h.fast && ob > 0) return ig_term_hot(s, inter, ob, lgf, ex_z, &h, ig_tab());
+    const float ex = inter ? p.v_inter : ig_rippe(s, p, ig_tab());
     return ig_pixel_term(ex, ex_z, ob, lgf, ig_tab());
 }
 
@@ -1074,30 +1052,23 @@ __device__ __noinline__ double term_circ(const ig_params p, float mean_kb, float
 }
 
 /* dkey: rank distance d of a linear cis pair; -1 for a trans pair; d | code << 27 | 1 << 30 for a pair on a circular contig.
- * Straight-line for the hot case (HotPar.fast parameters, linear contig or trans pair, small count, rank distance inside
- * the LDS P_z table); everything else is fixed up afterwards behind wave-uniform branches that are almost never taken. */
+ * The hot case is the contract's ig_term_hot (one log2, one exp2) with the count's log-factorial and P_z from the LDS
+ * tables; everything else (circular contig, count >= 256, rank distance beyond the LDS table, parameters outside the
+ * one-log domain) is fixed up afterwards behind a wave-uniform branch that is almost never taken. */
 #define DKEY_CIRC 0x40000000
-__device__ __forceinline__ void term_hot(const HotPar& hp, const ig_params& p, float mean_kb, float s, int dkey, int ob,
+__device__ __forceinline__ void term_hot(const ig_hot& h, const ig_params& p, float mean_kb, float s, int dkey, int ob,
                                          const float* pz_s, int pzn_s, const PzTab& pz, const double* lgf_s,
                                          const double* __restrict__ lgf_tab, const ColMeta* cm_s, const double* T, int& qh,
                                          unsigned& ql)
 {
     const bool inter = dkey < 0;
-    const bool in = (s > 0.0f) && (s < hp.d_max);
     double lgf = lgf_s[min(ob, LDS_LGF - 1)];
-    const double L = ig_log2_pos((double)(in ? s : 1.0f), T);
-    const float pw = (float)ig_exp2_core(hp.slope * L, T); /* hp.fast: in range, see HOT_SLOPE_MAX (else the result is unused) */
-    const float res = (hp.c1 * pw) * hp.fact;
-    float ex = in ? ((res > hp.v_inter) ? res : hp.v_inter) : hp.ex_out;
-    ex = inter ? hp.v_inter : ex;
     float ex_z = pz_s[min(max(dkey, 0), pzn_s - 1)];
-    ex_z = inter ? hp.v_inter : ex_z;
-    const bool ok = ex < IG_INFF; /* hp.fast: ex >= v_inter > 0 and NaN-free by construction */
-    const double e = (double)ex;
-    const double lg = ig_log2_pos(ok ? e : 1.0, T) * IG_LOG2_10_INV;
-    double t = (((double)ob * lg) - e) - lgf;
-    t = t + (double)ex_z * IG_LOG_E_F;
-    const bool rare = (ob >= LDS_LGF) || (dkey >= pzn_s) || !ok || !hp.fast || (ob <= 0);
+    /* a P_z table shorter than PZ_MAX ends where s_z reaches d_max (ig_set_params): beyond it P_z is the trans level */
+    const bool past_table = (pz.n < PZ_MAX) && (dkey >= pz.n) && !(dkey & DKEY_CIRC);
+    ex_z = (inter || past_table) ? h.v_inter : ex_z;
+    double t = ig_term_hot(s, inter, ob, lgf, ex_z, &h, T);
+    const bool rare = (ob >= LDS_LGF) || (dkey >= pzn_s && !past_table) || !h.fast || (ob <= 0);
     if (__any(rare)) {
         if (rare) {
             if (ob >= LDS_LGF) lgf = lgfact_dev(ob, lgf_tab);
@@ -1142,7 +1113,7 @@ struct ScoreArgs {
 /* the streaming loop of k_score_list; STAGED: the column fits the LDS stage (ds_read), else 8-byte gathers from L2 */
 #define SCORE_BATCH 4
 template <bool STAGED>
-__device__ __forceinline__ void score_loop(const ScoreArgs& a, const HotPar& hp, const ig_params& p, long long& hi, long long& lo)
+__device__ __forceinline__ void score_loop(const ScoreArgs& a, const ig_hot& hp, const ig_params& p, long long& hi, long long& lo)
 {
     const unsigned stride = gridDim.x * SCORE_THREADS;
     for (unsigned e0 = blockIdx.x * SCORE_THREADS + threadIdx.x; e0 < a.n; e0 += stride * SCORE_BATCH) {
@@ -1212,7 +1183,7 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     const int M = mb.M, m_loc = m.m_loc;
     if (large_on && ((CAP == LDS_COL_SMALL) != (m_loc <= LDS_COL_SMALL))) return;
     const ig_params p = g->par[0];
-    const HotPar hp = hot_params(p);
+    const ig_hot hp = ig_hot_make(p, ig_tab());
     const float mean = g->mean_kb;
     const uint2* gcol = mb.coords + (size_t)(cw * NSLOT + k) * M;
     const bool staged = m_loc <= CAP;
@@ -1281,6 +1252,7 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     const int k = (kk == 0) ? 0 : mc.ch_k;
     const int M = mb.M, m_loc = m.m_loc;
     const ig_params p = g->par[0];
+    const ig_hot hot = ig_hot_make(p, ig_tab());
     const float mean = g->mean_kb;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -1302,7 +1274,7 @@ __global__ void __launch_bounds__(SCORE_THREADS)
             const int li = qli[lane], lj = qlj[lane], ob = qob[lane];
             const uint2 ai = staged ? lcol[li] : gcol[li];
             const uint2 bj = staged ? lcol[lj] : gcol[lj];
-            const long long q = eval_q(p, mean, ai, bj, cm, ob, lgfact_dev(ob, lgf_tab), pz, ig_tab());
+            const long long q = eval_q(p, hot, mean, ai, bj, cm, ob, lgfact_dev(ob, lgf_tab), pz, ig_tab());
             hi += q >> 32;
             lo += (long long)(unsigned int)q;
         }
@@ -1397,6 +1369,7 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int M = mb.M;
     const ig_params p = g->par[0];
+    const ig_hot hot = ig_hot_make(p, ig_tab());
     const float mean = g->mean_kb;
     const CandMeta& m = mb.meta[cw];
     const long long* part = mb.part + (size_t)cw * P_STRIDE;
@@ -1488,7 +1461,7 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
         const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
         long long hi = 0, lo = 0;
         if (lane < n_tail) {
-            const long long q = eval_q(p, mean, col[t_li[lane]], col[t_lj[lane]], cm, t_ob[lane], lgfact_dev(t_ob[lane], lgf_tab), pz,
+            const long long q = eval_q(p, hot, mean, col[t_li[lane]], col[t_lj[lane]], cm, t_ob[lane], lgfact_dev(t_ob[lane], lgf_tab), pz,
                                        ig_tab());
             hi = q >> 32;
             lo = (long long)(unsigned int)q;
@@ -2207,9 +2180,12 @@ __global__ void k_debug_terms(const float* s, const float* stot, const int* ob, 
     long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const ig_params p = g->par[0];
+    const ig_hot hot = ig_hot_make(p, ig_tab());
     ex[i] = ig_rippe(s[i], p, ig_tab());
     exc[i] = ig_rippe_circ(s[i], stot[i], p, ig_tab());
-    term[i] = ig_pixel_term(ex[i], exc[i], ob[i], lgfact_dev(ob[i], lgf_tab), ig_tab());
+    /* the contract's term with P_z := exc (same probe as the oracle's igo_eval_terms) */
+    if (hot.fast && ob[i] > 0) term[i] = ig_term_hot(s[i], 0, ob[i], lgfact_dev(ob[i], lgf_tab), exc[i], &hot, ig_tab());
+    else term[i] = ig_pixel_term(ex[i], exc[i], ob[i], lgfact_dev(ob[i], lgf_tab), ig_tab());
     q[i] = ig_quantize(term[i]);
 }
 

@@ -148,6 +148,16 @@ static inline double pixel_term(float ex, float ex_z, int ob)
     return pxl_libm((double)ex, (double)ob) + (double)ex_z * 0.43429448190325182f;
 }
 
+/* the term of one contact, KA:4430-4462: LIBM mode composes the reference's functions literally; DET mode is the
+ * arithmetic contract's definition (include/ig_detmath.h ig_pair_term: one log2 + one exp2 for the linear-contig case) */
+static inline double pair_term(const ig_params p, const ig_hot* h, int cis, float s, float s_z, float s_tot, float s_tot_z, int ob)
+{
+    if (g_mode) return ig_pair_term(p, h, cis, s, s_z, s_tot, s_tot_z, ob, ob > 0 ? ig_lgfact(ob, g_lgf_det, ig_tab()) : 0.0, ig_tab());
+    float ex, ex_z;
+    expected_pair(p, cis, s, s_z, s_tot, s_tot_z, &ex, &ex_z);
+    return pixel_term(ex, ex_z, ob);
+}
+
 /* one sub-fragment's zero-pixel contribution: KA:3882-3899 / 3955-3972 */
 static inline double zero_term(const ig_params p, int pos, int len_cont, float s_tot, float mean_size_frag)
 {
@@ -175,10 +185,13 @@ void igo_eval_terms(const float* s, const float* s_tot, const int32_t* ob, int64
                     float* ex_circ, double* term, int64_t* q)
 {
     lgf_init();
+    const ig_hot hot = ig_hot_make(*P, ig_tab());
     for (int64_t i = 0; i < n; i++) {
         ex[i] = m_rippe(s[i], *P);
         ex_circ[i] = m_rippe_circ(s[i], s_tot[i], *P);
-        term[i] = pixel_term(ex[i], ex_circ[i], ob[i]);
+        /* DET mode: the contract's term with P_z := ex_circ (any float will do for a bit-parity probe) */
+        if (g_mode && hot.fast && ob[i] > 0) term[i] = ig_term_hot(s[i], 0, ob[i], ig_lgfact(ob[i], g_lgf_det, ig_tab()), ex_circ[i], &hot, ig_tab());
+        else term[i] = pixel_term(ex[i], ex_circ[i], ob[i]);
         q[i] = ig_quantize(term[i]);
     }
 }
@@ -469,6 +482,7 @@ void igo_extract_sub_likelihood(const int32_t* dat, const ig_int3* info_block, c
     (void)n_sub_frags;
     lgf_init();
     const ig_params p = *P;
+    const ig_hot hot = ig_hot_make(p, ig_tab());
     const int B = IGO_SIZE_BLOCK_4_SUB;
     const int n_blocks = n_data / B + 1;
     ig_acc acc = {0, 0};
@@ -494,9 +508,7 @@ void igo_extract_sub_likelihood(const int32_t* dat, const ig_int3* info_block, c
                 float s = fabsf(si - sj);
                 float s_z = fabsf(pos_i - pos_j) * mean_size_frag;
                 float s_tot_z = (float)len[fj] * mean_size_frag;
-                float ex, ex_z;
-                expected_pair(p, contig_i == contig_j, s, s_z, st, s_tot_z, &ex, &ex_z);
-                v = pixel_term(ex, ex_z, dat[g]);
+                v = pair_term(p, &hot, contig_i == contig_j, s, s_z, st, s_tot_z, dat[g]);
                 if (g_mode) ig_acc_add(&acc, ig_quantize(v));
             }
             sdata[t] = v;
@@ -524,6 +536,7 @@ void igo_eval_sub_likelihood(const int32_t* dat, const ig_int3* info_block, cons
     (void)n_sub_frags;
     lgf_init();
     const ig_params p = *P;
+    const ig_hot hot = ig_hot_make(p, ig_tab());
     const int B = IGO_SIZE_BLOCK_4_SUB, T = IGO_N_TMP_STRUCT;
     const int n_blocks = n_data / B + 1;
     const int nu = n_uniq[0];
@@ -553,9 +566,7 @@ void igo_eval_sub_likelihood(const int32_t* dat, const ig_int3* info_block, cons
                     float s = fabsf(si - sj);
                     float s_z = fabsf(pos_i - pos_j) * mean_size_frag;
                     float s_tot_z = (float)len[fj] * mean_size_frag;
-                    float ex, ex_z;
-                    expected_pair(p, contig_i == contig_j, s, s_z, st, s_tot_z, &ex, &ex_z);
-                    double v = pixel_term(ex, ex_z, dat[g]);
+                    double v = pair_term(p, &hot, contig_i == contig_j, s, s_z, st, s_tot_z, dat[g]);
                     loc[t * T + m] = v;
                     locq[t * T + m] = ig_quantize(v);
                 }
@@ -593,6 +604,7 @@ void igo_evaluate_likelihood_sparse(const int32_t* dat, const int32_t* row, cons
 {
     lgf_init();
     const ig_params p = *P;
+    const ig_hot hot = ig_hot_make(p, ig_tab());
     const int B = 1024;
     if (g_mode) {
         int64_t hi = 0, lo = 0;
@@ -605,9 +617,7 @@ void igo_evaluate_likelihood_sparse(const int32_t* dat, const int32_t* row, cons
             int dp = pos[fi] - pos[fj];
             float s_z = (float)(dp < 0 ? -dp : dp) * mean_size_frag;
             float s_tot_z = (float)len[fi] * mean_size_frag;
-            float ex, ex_z;
-            expected_pair(p, id_c[fi] == id_c[fj], s, s_z, s_tot[fi], s_tot_z, &ex, &ex_z);
-            int64_t q = ig_quantize(pixel_term(ex, ex_z, dat[k]));
+            int64_t q = ig_quantize(pair_term(p, &hot, id_c[fi] == id_c[fj], s, s_z, s_tot[fi], s_tot_z, dat[k]));
             hi += q >> 32;
             lo += (int64_t)(uint32_t)q;
         }
@@ -628,9 +638,7 @@ void igo_evaluate_likelihood_sparse(const int32_t* dat, const int32_t* row, cons
                 int dp = pos[fi] - pos[fj];
                 float s_z = (float)(dp < 0 ? -dp : dp) * mean_size_frag;
                 float s_tot_z = (float)len[fi] * mean_size_frag;
-                float ex, ex_z;
-                expected_pair(p, id_c[fi] == id_c[fj], s, s_z, s_tot[fi], s_tot_z, &ex, &ex_z);
-                v = pixel_term(ex, ex_z, dat[k]);
+                v = pair_term(p, &hot, id_c[fi] == id_c[fj], s, s_z, s_tot[fi], s_tot_z, dat[k]);
             }
             sdata[t] = v;
         }
