@@ -1822,20 +1822,16 @@ __device__ __forceinline__ int credit2_view(V view, const int* ip, const int* in
  *    before / just after that move, read through the marks), state + coordinate tables, the distance column of the
  *    results.  tab_prev receives every committed move but the last one (quirk Q12: tables before the last move). */
 #define COMMIT_THREADS 1024
-__global__ void __launch_bounds__(COMMIT_THREADS)
-    k_commit_batch(State st, Tables tab, Tables tab_prev, Glob* g, MoveBuf mb, const int* __restrict__ ip, const int* __restrict__ in,
-                   const int* __restrict__ orientable, const unsigned char* __restrict__ black, int* stamp, int* own_tag, int* own_idx,
-                   int* prev_touched, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out)
+/* step 1 of the batch commit: ONE wave (it may use the whole register file: the data of the next move is held in
+ * registers while the current one is decided) */
+__global__ void __launch_bounds__(64)
+    k_decide_batch(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out)
 {
     /* w_start > 0: slot w_start - 1 was the pending move, meanwhile applied by the one-move kernels; the rest of the batch
      * is still valid wherever it does not touch a contig modified so far (dirty_buf carries the list across the calls) */
     __shared__ int dirty[IG_MAX_BATCH * 2 + 2];
-    __shared__ int sh_committed, sh_pending;
-    __shared__ long long sh_delta[IG_MAX_BATCH];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int tag_base = g->stamp_ctr; /* tags/stamps of this batch: tag_base + w */
-    if (tid < IG_MAX_BATCH) sh_delta[tid] = 0;
-    if (tid < 64) {
+    {
         /* ------------------------------------------------------------ 1. decide */
         long long nz_hi = g->nz_hi, nz_lo = g->nz_lo, z_hi = g->z_hi, z_lo = g->z_lo, n_intra = g->n_intra;
         int n_contigs = g->n_contigs, next_cid = g->next_cid;
@@ -1860,46 +1856,126 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
             }
             n_dirty += 2;
         }
-        for (int w = w_start; w < W; w++) {
-            const MoveCtl mc = mb.ctl[w];
-            const int C = mc.C;
-            /* conflict with an earlier move of this batch? */
-            int cA = -1, cB = -1, mloc = 0;
-            if (lane < C) {
+        /* Everything a decision reads is loaded ONE MOVE AHEAD (none of it depends on earlier decisions, only its
+         * interpretation does): while move w is decided from registers with wave shuffles only, the loads of move w + 1
+         * are in flight.  Moves with more than 5 candidates (> 2 score records per lane) take the unpipelined path. */
+        struct MoveData {
+            int C, superset0;                                       /* uniform */
+            int cA, cB, mloc, same, windowed, B, n_loc, n_uniq;     /* lane c < C: candidate c */
+            long long c_ext_hi, c_ext_lo, c_n_slice;
+            int c_base_cnt, c_overflow;
+            int flag;                                               /* lane < 12 * min(C, 5): flags[lane % 12] of candidate lane / 12 */
+            SlotPre rec[2];                                         /* score records lane, lane + 64 */
+            long long e_ext_hi[2], e_ext_lo[2];                     /* their candidates' slice sum under the current genome, */
+            int e_r[2], e_base[2];                                  /* S_c mod 64, list entries before the block inserts */
+        };
+        auto load_move = [&](int w) {
+            MoveData d;
+            const MoveCtl& mc = mb.ctl[w];
+            d.C = mc.C;
+            d.superset0 = mc.superset0;
+            d.cA = d.cB = -1;
+            d.mloc = d.same = d.windowed = d.B = d.n_loc = d.n_uniq = 0;
+            d.c_ext_hi = d.c_ext_lo = d.c_n_slice = 0;
+            d.c_base_cnt = d.c_overflow = 0;
+            if (lane < d.C) {
                 const CandMeta& m = mb.meta[CW(w, lane)];
-                cA = m.ctgA;
-                cB = m.ctgB;
-                mloc = m.m_loc;
+                d.cA = m.ctgA;
+                d.cB = m.ctgB;
+                d.mloc = m.m_loc;
+                d.same = m.same;
+                d.windowed = m.windowed;
+                d.B = m.B;
+                d.n_loc = m.n_loc;
+                d.n_uniq = m.n_uniq;
+                const CandPre& cp = mb.cpre[CW(w, lane)];
+                d.c_ext_hi = cp.ext_hi;
+                d.c_ext_lo = cp.ext_lo;
+                d.c_n_slice = cp.n_slice;
+                d.c_base_cnt = cp.base_cnt;
+                d.c_overflow = cp.pad;
             }
+            d.flag = -1;
+            if (lane < 12 * min(d.C, 5)) d.flag = mb.meta[CW(w, lane / 12)].flags[lane % 12];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int i = lane + 64 * j;
+                d.rec[j].k = 0;
+                d.e_ext_hi[j] = d.e_ext_lo[j] = 0;
+                d.e_r[j] = d.e_base[j] = 0;
+                if (i < d.C * IG_N_TMP_STRUCT) {
+                    const int cw = CW(w, i / IG_N_TMP_STRUCT);
+                    d.rec[j] = mb.pre[(size_t)cw * IG_N_TMP_STRUCT + i % IG_N_TMP_STRUCT];
+                    const CandPre& cp = mb.cpre[cw];
+                    d.e_ext_hi[j] = cp.ext_hi;
+                    d.e_ext_lo[j] = cp.ext_lo;
+                    d.e_r[j] = cp.r;
+                    d.e_base[j] = cp.base_cnt;
+                }
+            }
+            return d;
+        };
+        auto rl = [](int v, int src) { return __builtin_amdgcn_readlane(v, src); };
+        auto rl64 = [](long long v, int src) {
+            const int lo = __builtin_amdgcn_readlane((int)(unsigned)v, src), hi = __builtin_amdgcn_readlane((int)(v >> 32), src);
+            return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+        };
+        auto rld = [&](double v, int src) { return __longlong_as_double(rl64(__double_as_longlong(v), src)); };
+        MoveData cur = load_move(w_start < W ? w_start : W - 1);
+        for (int w = w_start; w < W; w++) {
+            const MoveData d = cur;
+            if (w + 1 < W) cur = load_move(w + 1);
+            const int C = d.C;
+            /* conflict with an earlier move of this batch?  slice pool overflow? */
             bool hitd = false;
-            for (int q = 0; q < n_dirty; q++) hitd |= (dirty[q] == cA) | (dirty[q] == cB);
-            if (err0 || mb.cpre[CW(w, 0)].pad || __any(hitd && lane < C)) break;
-            n_large += __popcll(__ballot(lane < C && mloc > LDS_COL_SMALL));
+            for (int q = 0; q < n_dirty; q++) hitd |= (dirty[q] == d.cA) | (dirty[q] == d.cB);
+            if (err0 || rl(d.c_overflow, 0) || __any(hitd && lane < C)) break;
+            n_large += __popcll(__ballot(lane < C && d.mloc > LDS_COL_SMALL));
             n_cand += C;
             /* scores (eval_all_likelihood_on_zero_2nd KA:4005-4027, eval_all_scores KA:4029-4046) with the live scalars */
             const double cur_nz = ig_acc_to_double(nz_hi, nz_lo);
             const int n = C * IG_N_TMP_STRUCT;
-            double sc[(IG_MAX_CANDIDATES * IG_N_TMP_STRUCT + 63) / 64];
-            double mx = -IG_INF;
+            constexpr int NJ = (IG_MAX_CANDIDATES * IG_N_TMP_STRUCT + 63) / 64;
+            double sc[NJ];
+            /* host argmax of CL:1435-1446: zeros -> -inf, scores shifted by (max - 30) and clipped at 0, FIRST index of the
+             * maximum.  The clipped maximum is 30 > 0 and is reached exactly where the score is maximal, so this is the first
+             * index of the maximal score (all scores zero: index 0) -- one reduction of (score, index). */
+            double bestv = -IG_INF;
+            int best = 0x7fffffff;
 #pragma unroll
-            for (int j = 0; j < (IG_MAX_CANDIDATES * IG_N_TMP_STRUCT + 63) / 64; j++) {
+            for (int j = 0; j < NJ; j++) {
                 const int i = lane + 64 * j;
                 double v = 0.0;
-                if (i < n) {
+                if (j < 2 || i < n) { /* j >= 2: only moves with more than 5 candidates get here with i < n */
+                    SlotPre r;
+                    long long ext_hi, ext_lo;
+                    int cr, cbase;
+                    if (j < 2) {
+                        r = d.rec[j];
+                        ext_hi = d.e_ext_hi[j];
+                        ext_lo = d.e_ext_lo[j];
+                        cr = d.e_r[j];
+                        cbase = d.e_base[j];
+                    } else {
+                        const int cw = CW(w, i / IG_N_TMP_STRUCT);
+                        r = mb.pre[(size_t)cw * IG_N_TMP_STRUCT + i % IG_N_TMP_STRUCT];
+                        const CandPre cp = mb.cpre[cw];
+                        ext_hi = cp.ext_hi;
+                        ext_lo = cp.ext_lo;
+                        cr = cp.r;
+                        cbase = cp.base_cnt;
+                    }
                     const int c = i / IG_N_TMP_STRUCT, slot = i % IG_N_TMP_STRUCT;
-                    const int cw = CW(w, c);
-                    const SlotPre r = mb.pre[(size_t)cw * IG_N_TMP_STRUCT + slot];
-                    const CandPre cp = mb.cpre[cw];
-                    const bool sup = (c == 0) && mc.superset0 && (slot >= 12);
-                    const bool scored = (r.k > 0) && !(sup && !((vmask >> (slot - 12)) & 1u));
+                    const bool sup = (c == 0) && d.superset0 && (slot >= 12);
+                    const bool scored = (i < n) && (r.k > 0) && !(sup && !((vmask >> (slot - 12)) & 1u));
                     if (scored) {
-                        const int pos = sup ? cp.base_cnt + __popc(vmask & ((1u << (slot - 12)) - 1u)) : r.k - 1;
+                        const int pos = sup ? cbase + __popc(vmask & ((1u << (slot - 12)) - 1u)) : r.k - 1;
                         long long nh = r.nz_hi, nl = r.nz_lo;
-                        if (cp.r > 0 && pos >= cp.r) { /* quirk Q5 */
+                        if (cr > 0 && pos >= cr) { /* quirk Q5 */
                             nh -= r.tail_hi;
                             nl -= r.tail_lo;
                         }
-                        const double ext = ig_acc_to_double(cp.ext_hi, cp.ext_lo);
+                        const double ext = ig_acc_to_double(ext_hi, ext_lo);
                         const double val_inter = -1.0 * log_e * (n_tot_pxl - (double)(n_intra + r.dni)) * p.v_inter;
                         const double val_intra = ig_acc_to_double(z_hi + r.dz_hi, z_lo + r.dz_lo) * log_e;
                         const double z = val_intra + val_inter;
@@ -1908,65 +1984,62 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
                 }
                 sc[j] = v;
                 const double ok = (v == 0.0) ? -IG_INF : v;
-                mx = ok > mx ? ok : mx;
-            }
-            for (int off = 32; off > 0; off >>= 1) {
-                const double o = __shfl_xor(mx, off, 64);
-                mx = o > mx ? o : mx;
-            }
-            /* host argmax of CL:1435-1446: zeros -> -inf, shifted and clipped, FIRST index of the maximum */
-            double bestv = -IG_INF, bests = 0.0;
-            int best = 0x7fffffff;
-#pragma unroll
-            for (int j = 0; j < (IG_MAX_CANDIDATES * IG_N_TMP_STRUCT + 63) / 64; j++) {
-                const int i = lane + 64 * j;
-                if (i < n) {
-                    const double ok = (sc[j] == 0.0) ? -IG_INF : sc[j];
-                    double fs = ok - (mx - 30.0);
-                    if (fs < 0) fs = 0;
-                    if (fs > bestv) {
-                        bestv = fs;
-                        best = i;
-                        bests = sc[j];
-                    }
+                if (i < n && ok > bestv) { /* strictly greater: the lower index wins inside a lane */
+                    bestv = ok;
+                    best = i;
                 }
             }
             for (int off = 32; off > 0; off >>= 1) {
                 const double ov = __shfl_xor(bestv, off, 64);
-                const double os = __shfl_xor(bests, off, 64);
                 const int oi = __shfl_xor(best, off, 64);
                 if (ov > bestv || (ov == bestv && oi < best)) {
                     bestv = ov;
                     best = oi;
-                    bests = os;
                 }
             }
-            if (best >= n) {
-                best = 0;
-                bests = __shfl(sc[0], 0, 64);
-            }
+            best = rl(best, 0);
+            if (best >= n) best = 0;
             const int bc = best / IG_N_TMP_STRUCT, bslot = best % IG_N_TMP_STRUCT;
-            const int bcw = CW(w, bc);
-            const SlotPre br = mb.pre[(size_t)bcw * IG_N_TMP_STRUCT + bslot];
-            const CandMeta& bm = mb.meta[bcw];
-            const int windowed = bm.windowed;
-            /* statistics of the move */
-            long long Sc = 0, ev = 0, by = 0;
-            if (lane < C) {
-                const CandMeta& m = mb.meta[CW(w, lane)];
-                const CandPre cp = mb.cpre[CW(w, lane)];
-                int nu = m.n_uniq;
-                if (lane == 0 && mc.superset0) nu = cp.base_cnt + __popc(vmask); /* the list the reference would have scored */
-                Sc = cp.n_slice;
-                ev = Sc * (nu + 1);
-                by = 12 * Sc + 20LL * m.m_loc * nu + 8LL * nu;
+            const int owner = best & 63, bj = best >> 6; /* the lane and register that hold the winner's record */
+            SlotPre br;
+            double bests;
+            if (bj < 2) {
+                const SlotPre mine = (bj == 0) ? d.rec[0] : d.rec[1];
+                br.nz_hi = rl64(mine.nz_hi, owner);
+                br.nz_lo = rl64(mine.nz_lo, owner);
+                br.dz_hi = rl64(mine.dz_hi, owner);
+                br.dz_lo = rl64(mine.dz_lo, owner);
+                br.dni = rl64(mine.dni, owner);
+                br.k = rl(mine.k, owner);
+                br.changed = rl(mine.changed, owner);
+                br.heads = rl(mine.heads, owner);
+                bests = rld((bj == 0) ? sc[0] : sc[1], owner);
+            } else {
+                br = mb.pre[(size_t)CW(w, bc) * IG_N_TMP_STRUCT + bslot];
+                double sv = 0.0;
+#pragma unroll
+                for (int j = 2; j < NJ; j++) sv = (bj == j) ? sc[j] : sv;
+                bests = rld(sv, owner);
             }
-            Sc = wave_sum_ll(Sc);
-            ev = wave_sum_ll(ev);
-            by = wave_sum_ll(by);
-            Sc = __shfl(Sc, 0, 64);
-            ev = __shfl(ev, 0, 64);
-            by = __shfl(by, 0, 64);
+            const int windowed = rl(d.windowed, bc), b_same = rl(d.same, bc), b_B = rl(d.B, bc), b_nloc = rl(d.n_loc, bc);
+            const int b_cA = rl(d.cA, bc), b_cB = rl(d.cB, bc);
+            const long long b_ext_hi = rl64(d.c_ext_hi, bc), b_ext_lo = rl64(d.c_ext_lo, bc);
+            /* statistics of the move: off the critical path, k_commit_batch fills them in from the flag mask kept here
+             * (a pending move needs them now: its record is written by the one-move kernels) */
+            long long Sc = 0, ev = 0, by = 0;
+            const bool is_pending = windowed && br.changed;
+            if (is_pending) {
+                if (lane < C) {
+                    int nu = d.n_uniq;
+                    if (lane == 0 && d.superset0) nu = d.c_base_cnt + __popc(vmask); /* the list the reference would have scored */
+                    Sc = d.c_n_slice;
+                    ev = Sc * (nu + 1);
+                    by = 12 * Sc + 20LL * d.mloc * nu + 8LL * nu;
+                }
+                Sc = rl64(wave_sum_ll(Sc), 0);
+                ev = rl64(wave_sum_ll(ev), 0);
+                by = rl64(wave_sum_ll(by), 0);
+            }
             if (lane == 0) {
                 MoveCtl& o = mb.ctl[w];
                 o.ch_c = bc;
@@ -1980,26 +2053,31 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
                 o.d_hi = 0;
                 o.d_lo = 0;
                 o.n_dirty = br.changed;
+                o.pad = (int)vmask; /* the stale flags this move was scored under */
                 if (br.k <= 0) g->error = 3; /* an unscored slot won: cannot happen */
             }
-            if (windowed && br.changed) { /* needs k_delta: hand this move to the one-move tail */
+            if (is_pending) { /* needs k_delta: hand this move to the one-move tail */
                 pending = w;
                 break;
             }
             /* commit: scalars (exact), stale-flag state (quirk Q4), fresh ids */
-            nz_hi += br.nz_hi - mb.cpre[bcw].ext_hi;
-            nz_lo += br.nz_lo - mb.cpre[bcw].ext_lo;
+            nz_hi += br.nz_hi - b_ext_hi;
+            nz_lo += br.nz_lo - b_ext_lo;
             ig_acc_normalize((int64_t*)&nz_hi, (int64_t*)&nz_lo);
             z_hi += br.dz_hi;
             z_lo += br.dz_lo;
             ig_acc_normalize((int64_t*)&z_hi, (int64_t*)&z_lo);
             n_intra += br.dni;
-            n_contigs += br.heads - (bm.same ? 1 : 2);
+            n_contigs += br.heads - (b_same ? 1 : 2);
             next_cid += NFRESH;
             {
-                const CandMeta& fm = (bslot >= 12) ? bm : mb.meta[CW(w, C - 1)];
-                const int v = (lane < 12) ? fm.flags[lane] : -1;
-                vmask = (unsigned)__ballot(lane < 12 && v != -1);
+                const int sel = (bslot >= 12) ? bc : C - 1; /* the family of the winner re-ran get_bounds (CL:2125-2126) */
+                if (sel < 5) {
+                    vmask = (unsigned)((__ballot(d.flag != -1) >> (12 * sel)) & 0xfffull);
+                } else {
+                    const int v = (lane < 12) ? mb.meta[CW(w, sel)].flags[lane] : -1;
+                    vmask = (unsigned)__ballot(lane < 12 && v != -1);
+                }
             }
             if (lane == 0) {
                 ig_move_result r;
@@ -2007,18 +2085,18 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
                 r.dist = 0.0; /* step 2 */
                 r.mean_len = (double)((float)g->N / (float)n_contigs);
                 r.op_sampled = bslot;
-                r.id_f_sampled = bm.B;
+                r.id_f_sampled = b_B;
                 r.n_contigs = n_contigs;
                 r.n_candidates = C;
-                r.n_slice = Sc;
-                r.n_evals = ev;
-                r.bytes_min = by + 68LL * bm.n_loc;
+                r.n_slice = 0; /* step 2 */
+                r.n_evals = 0;
+                r.bytes_min = 68LL * b_nloc;
                 r.error = err0;
                 r.pad = 0;
                 res[move0 + w] = r;
                 if (br.changed) {
-                    dirty[n_dirty] = bm.ctgA;
-                    dirty[n_dirty + 1] = bm.ctgB;
+                    dirty[n_dirty] = b_cA;
+                    dirty[n_dirty + 1] = b_cB;
                 }
             }
             if (br.changed) n_dirty += 2;
@@ -2032,8 +2110,6 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
             g->n_intra = n_intra;
             g->n_contigs = n_contigs;
             g->next_cid = next_cid;
-            sh_committed = committed;
-            sh_pending = pending;
             dirty_buf[0] = n_dirty;
             for (int q = 0; q < n_dirty; q++) dirty_buf[1 + q] = dirty[q];
             batch_out[0] = committed;
@@ -2043,8 +2119,20 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
         }
         if (lane < 12) g->valid_insert[lane] = ((vmask >> lane) & 1u) ? 1 : -1;
     }
+}
+
+/* step 2 of the batch commit: one workgroup applies the moves [w_start, batch_out[0]) k_decide_batch committed */
+__global__ void __launch_bounds__(COMMIT_THREADS)
+    k_commit_batch(State st, Tables tab, Tables tab_prev, Glob* g, MoveBuf mb, const int* __restrict__ ip, const int* __restrict__ in,
+                   const int* __restrict__ orientable, const unsigned char* __restrict__ black, int* stamp, int* own_tag, int* own_idx,
+                   int* prev_touched, ig_move_result* res, int move0, int W, int w_start, const int* batch_out)
+{
+    __shared__ long long sh_delta[IG_MAX_BATCH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tag_base = g->stamp_ctr; /* tags/stamps of this batch: tag_base + w */
+    if (tid < IG_MAX_BATCH) sh_delta[tid] = 0;
+    const int committed = batch_out[0];
     __syncthreads();
-    const int committed = sh_committed;
     if (committed == w_start) return;
     /* ---------------------------------------------------------------- 2. apply */
     const int N = mb.N, M = mb.M;
@@ -2161,7 +2249,25 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
         }
     }
     __syncthreads();
-    /* 2d. the distance column */
+    /* 2d. the statistics columns (one thread per move), the distance column */
+    if (tid >= w_start && tid < committed) {
+        const int w = tid;
+        const MoveCtl& mc = mb.ctl[w];
+        const unsigned vmask = (unsigned)mc.pad;
+        long long Sc = 0, ev = 0, by = 0;
+        for (int c = 0; c < mc.C; c++) {
+            const CandMeta& m = mb.meta[CW(w, c)];
+            const CandPre& cp = mb.cpre[CW(w, c)];
+            int nu = m.n_uniq;
+            if (c == 0 && mc.superset0) nu = cp.base_cnt + __popc(vmask); /* the list the reference would have scored */
+            Sc += cp.n_slice;
+            ev += cp.n_slice * (nu + 1);
+            by += 12 * cp.n_slice + 20LL * m.m_loc * nu + 8LL * nu;
+        }
+        res[move0 + w].n_slice = Sc;
+        res[move0 + w].n_evals = ev;
+        res[move0 + w].bytes_min += by;
+    }
     if (tid == 0) {
         long long c2 = g->credit2;
         const double norm = 3.0 * (double)(g->N - g->n_black);
@@ -2956,9 +3062,11 @@ static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
     for (;;) {
         {
             TimedLaunch t(c, T_COMMIT);
+            hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(64), 0, c->stream, c->glob, c->mb, c->d_results, done, w_now, next,
+                               c->dirty_buf, c->batch_out);
             hipLaunchKernelGGL(k_commit_batch, dim3(1), dim3(COMMIT_THREADS), 0, c->stream, c->st, c->tab, c->tab_prev, c->glob,
                                c->mb, c->init_prev, c->init_next, c->orientable, c->black, c->stamp, c->own_tag, c->own_idx,
-                               c->prev_touched, c->d_results, done, w_now, next, c->dirty_buf, c->batch_out);
+                               c->prev_touched, c->d_results, done, w_now, next, c->batch_out);
         }
         int bo[4];
         HIPCK(hipMemcpyAsync(bo, c->batch_out, sizeof bo, hipMemcpyDeviceToHost, c->stream));
