@@ -181,7 +181,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32 P(s) / f64 Poisson term / exact i64 fixed-point sums",
+            "dtype": "f64 terms (f32 inputs) / exact i64 fixed-point sums",
             "data": "synthetic",
             "config": {"workload": "synthetic Hi-C %s (%d sub-frags), level 4, %d neighbours, nuisance sampling off" % (
                 prob_name(prob), prob.n_sub_frags, a.neighbours), "name": a.config, "seed": a.seed,
@@ -195,8 +195,8 @@ def main():
                          "term_evals_per_launch": n_evals,
                          "term_evals_per_s": (n_evals / (score_ms * 1e-3)) if score_ms > 0 else 0.0,
                          "note": "B_min = sum_c[12 S_c + 20 m_c U + 8 U] + 68 n_touched per move (SURVEY 8(d)), summed over the moves "
-                                 "of a launch; the kernel is VALU-issue bound (VALUBusy 93 %, profiles/) by the exact f64 term "
-                                 "arithmetic on an L2-resident working set, not by HBM: DESIGN.md section 4"},
+                                 "of a launch; the kernel is VALU-issue bound (VALUBusy 92 %, profiles/) by the exact f64 term "
+                                 "arithmetic on an L2-resident working set, not by HBM: DESIGN.md section 4.3"},
         }
         if not a.no_cpu_baseline:
             try:
