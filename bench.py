@@ -91,12 +91,20 @@ def main():
         log("WARNING: --gpus %d but WORLD_SIZE %d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # IG_BENCH_ONE_DEVICE=1 (test rigs with a single GPU): every rank uses cuda:0 and the collectives go through gloo --
+    # exercises the multi-process protocol end to end, not a performance configuration
+    one_device = os.environ.get("IG_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     t0 = time.time()
     prob = synth.make_problem(*synth.CONFIGS[a.config])

@@ -3096,6 +3096,15 @@ static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
 
 static int g_batch_w = -1; /* moves scored per launch in ig_step_batch: env IG_BATCH_W, default 24; 1 = one move at a time */
 
+/* the per-slot work buffers are sized for the worst case (a window = the whole genome): keep them under ~64 GB */
+static int max_batch_width(ig_ctx* c, int max_c)
+{
+    const double per_slot = (double)std::max(8, max_c) *
+                            ((double)NSLOT * NDYN * c->N * 4.0 + (double)c->M * NSLOT * 8.0 + 3.0 * c->N * 4.0 + 2.0 * c->M * 4.0);
+    const int fit = (int)std::max(1.0, 64e9 / std::max(per_slot, 1.0));
+    return std::min(fit, IG_MAX_BATCH);
+}
+
 static int batch_width(ig_ctx* c, int max_c)
 {
     if (g_batch_w < 0) {
@@ -3103,12 +3112,10 @@ static int batch_width(ig_ctx* c, int max_c)
         g_batch_w = e ? atoi(e) : 24;
         g_batch_w = std::min(std::max(g_batch_w, 1), IG_MAX_BATCH);
     }
-    /* the per-slot work buffers are sized for the worst case (a window = the whole genome): keep them under ~64 GB */
-    const double per_slot = (double)std::max(8, max_c) *
-                            ((double)NSLOT * NDYN * c->N * 4.0 + (double)c->M * NSLOT * 8.0 + 3.0 * c->N * 4.0 + 2.0 * c->M * 4.0);
-    const int fit = (int)std::max(1.0, 64e9 / std::max(per_slot, 1.0));
-    return std::min(g_batch_w, fit);
+    return std::min(g_batch_w, max_batch_width(c, max_c));
 }
+
+extern "C" int ig_batch_max_width(ig_ctx* c, int32_t max_c) { return max_batch_width(c, max_c); }
 
 /* validate and upload the pre-drawn (fragment, candidates) lists of a run of moves */
 static int upload_moves(ig_ctx* c, int n_moves, const int32_t* frags, const int32_t* cands, int max_c)
@@ -3177,7 +3184,8 @@ extern "C" int ig_batch_upload(ig_ctx* c, int32_t n_moves, const int32_t* frags,
     HIPCK(hipSetDevice(c->device));
     if (check_ready(c)) return -1;
     if (n_moves <= 0) return fail("ig_batch_upload: no moves");
-    if (max_w < 1 || max_w > IG_MAX_BATCH) return fail("ig_batch_upload: batch width %d out of 1..%d", max_w, IG_MAX_BATCH);
+    if (max_w < 1 || max_w > max_batch_width(c, max_c))
+        return fail("ig_batch_upload: batch width %d out of 1..%d (ig_batch_max_width)", max_w, max_batch_width(c, max_c));
     if (c->world > 1) return fail("ig_batch_upload: contact shards (ig_set_shard) and slot splitting are exclusive");
     if (max_c < 1 || max_c > IG_MAX_CANDIDATES) return fail("ig_batch_upload: max_c out of range");
     if (ensure_move_buffers(c, std::max(8, (int)max_c), max_w)) return -1;

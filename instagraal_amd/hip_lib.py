@@ -195,6 +195,9 @@ class Context:
         return res
 
     # ---- speculative batches in steps (slots of a batch split over several GPUs)
+    def batch_max_width(self, max_c=5):
+        return int(lib().ig_batch_max_width(self._h, C.c_int32(int(max_c))))
+
     def batch_upload(self, frags, cands, max_w):
         f = np.ascontiguousarray(frags, np.int32)
         c = np.ascontiguousarray(cands, np.int32)

@@ -132,6 +132,9 @@ class BatchRunner:
         cands = np.ascontiguousarray(cands, np.int32)
         n = frags.size
         world, rank = self.world, self.rank
+        if hasattr(self.ctx, "batch_max_width"):  # work buffers are sized per slot: stay inside what fits (same on every rank)
+            fit = self.ctx.batch_max_width(cands.shape[1])
+            self.width = max(world, min(self.width, (fit // world) * world))
         per_max = -(-self.width // world)
         cap_slots = per_max * world  # the all-gather works on equal chunks
         if self._tensor_factory is None and world > 1:
