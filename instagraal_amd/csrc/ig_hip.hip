@@ -179,6 +179,8 @@ struct ig_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
+    hipStream_t stream2;           /* k_tail next to k_score_list */
+    hipEvent_t ev_slice, ev_tail;
     int N, M;
     long long Z;
     int rank, world;
@@ -1378,8 +1380,6 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
     const int* rowcnt = mb.rowcnt + (size_t)cw * M;
     const int ncol = m.n_uniq + 1;
     for (int k = tid; k < ncol; k += blockDim.x) {
-        qp[Q_NZFULL + 2 * k] = part[P_NZ + 2 * k];
-        qp[Q_NZFULL + 2 * k + 1] = part[P_NZ + 2 * k + 1];
         qp[Q_TAIL + 2 * k] = 0;
         qp[Q_TAIL + 2 * k + 1] = 0;
     }
@@ -1475,19 +1475,31 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
     }
 }
 
-__global__ void __launch_bounds__(256) k_prefinal(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
-                                                  Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz,
-                                                  int w_begin)
+/* k_tail: needs the slice only (list length, per-row counts), not the column sums: it runs on a second stream next to
+ * k_score_list */
+__global__ void __launch_bounds__(256) k_tail(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, Glob* g,
+                                              MoveBuf mb, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int w_begin)
+{
+    prefinal_tail(rowptr, cc, tab, g, mb, lgf_tab, tail_quirk, pz, w_begin);
+}
+
+/* k_records: after k_score_list and k_tail: the slot-major records of the commit step */
+__global__ void __launch_bounds__(64) k_records(MoveBuf mb, int w_begin)
 {
     const int c = blockIdx.x, w = w_begin + blockIdx.y;
     if (c >= mb.ctl[w].C) return;
-    prefinal_tail(rowptr, cc, tab, g, mb, lgf_tab, tail_quirk, pz, w_begin);
-    __syncthreads();
-    /* slot-major records for the commit step */
     const int cw = CW(w, c);
     const CandMeta& m = mb.meta[cw];
-    const long long* qp = mb.qpart + (size_t)cw * Q_STRIDE;
+    long long* qp = mb.qpart + (size_t)cw * Q_STRIDE;
     const int t = threadIdx.x;
+    {
+        const long long* part = mb.part + (size_t)cw * P_STRIDE;
+        if (t <= m.n_uniq) {
+            qp[Q_NZFULL + 2 * t] = part[P_NZ + 2 * t];
+            qp[Q_NZFULL + 2 * t + 1] = part[P_NZ + 2 * t + 1];
+        }
+    }
+    __syncthreads();
     if (t < IG_N_TMP_STRUCT) {
         SlotPre r;
         const int k = m.kidx[t];
@@ -2401,6 +2413,9 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     }
     c->have_contacts = c->have_sub = c->have_state = c->have_init = c->have_params = false;
     HIPCK(hipStreamCreate(&c->stream));
+    HIPCK(hipStreamCreate(&c->stream2));
+    HIPCK(hipEventCreateWithFlags(&c->ev_slice, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
     DALLOC(c->glob, 1);
     HIPCK(hipMemset(c->glob, 0, sizeof(Glob)));
     DALLOC(c->lgf_tab, LGF_TAB);
@@ -2469,6 +2484,10 @@ extern "C" void ig_destroy(ig_ctx* c)
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->stream2);
+    hipStreamDestroy(c->stream2);
+    hipEventDestroy(c->ev_slice);
+    hipEventDestroy(c->ev_tail);
     drain_timers(c);
     free_move_buffers(c);
     hipFree(c->st_block);
@@ -2981,6 +3000,13 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                 hipLaunchKernelGGL(k_slice, dim3(SLICE_RB, max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb,
                                    c->rank, c->world, w_begin);
             }
+            if (phase == 2) { /* the Q5 tail walk only needs the slice: second stream, next to k_score_list */
+                hipEventRecord(c->ev_slice, c->stream);
+                hipStreamWaitEvent(c->stream2, c->ev_slice, 0);
+                hipLaunchKernelGGL(k_tail, dim3(max_c, nW), dim3(256), 0, c->stream2, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->lgf_tab,
+                                   g_tail_quirk, pz, w_begin);
+                hipEventRecord(c->ev_tail, c->stream2);
+            }
             TimedLaunch t(c, T_SCORE);
             static int s_eb = getenv("IG_SCORE_EB") ? atoi(getenv("IG_SCORE_EB")) : SCORE_EB;
             static int s_abl = getenv("IG_ABLATE") ? atoi(getenv("IG_ABLATE")) : 0;
@@ -2997,9 +3023,13 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
     }
     if (phase == 1 || phase == 2) {
         if (force_slot < 0 && nW > 0) {
+            if (phase == 1) /* after the all-reduce of the list lengths (contact shards): no overlap */
+                hipLaunchKernelGGL(k_tail, dim3(max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->lgf_tab,
+                                   g_tail_quirk, pz, w_begin);
+            else
+                hipStreamWaitEvent(c->stream, c->ev_tail, 0);
             TimedLaunch t(c, T_FINALIZE);
-            hipLaunchKernelGGL(k_prefinal, dim3(max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->lgf_tab,
-                               g_tail_quirk, pz, w_begin);
+            hipLaunchKernelGGL(k_records, dim3(max_c, nW), dim3(64), 0, c->stream, c->mb, w_begin);
         }
     }
 }
