@@ -1,0 +1,210 @@
+/* ig_common.cuh -- includes, error plumbing and the device-side data structures shared by every kernel of
+ * libinstagraal_hip.so (one translation unit: ig_hip.hip includes the parts in order). */
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/ig_detmath.h"
+#include "../../include/instagraal_hip.h"
+#include "ig_ops.cuh"
+
+#define NSLOT 25          /* 24 mutation slots + the current genome */
+#define NCODE 8           /* contig codes inside a candidate: A, B, fresh0..fresh3 (+spare) */
+#define NFRESH 4
+#define LGF_TAB 1024
+#define SCORE_THREADS 256
+
+static thread_local std::string g_err;
+static int fail(const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+#define HIPCK(x)                                                                                     \
+    do {                                                                                             \
+        hipError_t e_ = (x);                                                                         \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+/* ------------------------------------------------------------------ device data */
+
+struct SubTab {
+    int parent;
+    float wat, cri;
+    int w;
+};
+
+struct State { /* N-length arrays */
+    int *pos, *spos, *cid, *sbp, *circ, *prev, *next, *L, *SL, *LB, *ori; /* dynamic, order = Loc */
+    int *lb, *sl, *sub_first, *rep, *activ, *id_d;                        /* constant */
+};
+#define NDYN 11
+
+struct Tables { /* M-length current coordinates (uni_fill_vect_dist, KA:3763-3822) */
+    float* dist;
+    float* stot;
+    int* len;
+    int2* cp; /* (contig id, rank in contig) packed: one 8-byte gather per contact endpoint */
+};
+
+struct CandMeta {
+    int B, ctgA, ctgB, same, windowed;
+    int LA, LB, SLA, SLB, n_loc, m_loc;
+    int lA, lB; /* local indices of A and B */
+    int n_uniq, uniq[24], kidx[NSLOT];
+    int flags[12], pos_up[6], pos_down[6];
+    /* slice windows (KA:530-548) */
+    int pos_fa, pos_fb, up_fa, down_fa, up_fb, down_fb;
+};
+
+struct ColMeta {
+    float stot;
+    int len;
+};
+
+struct Glob {
+    ig_params par[2];
+    float mean_kb;
+    int slice_nb;
+    int list_bounds[6];
+    long long nz_hi, nz_lo, z_hi, z_lo, n_intra;
+    long long credit2, credit2_acc;
+    double n_tot_pxl;
+    double lgf[15];
+    int n_contigs, next_cid, n_black, N, M;
+    int n_prev_touched;
+    int valid_insert[12];
+    int error;
+    int stamp_ctr;
+};
+
+/* one move slot of a batch (W = 1: the move in flight) */
+#define IG_MAX_BATCH 64
+struct MoveCtl {
+    int A, C, force_slot, fresh; /* fresh: first of the NFRESH contig ids this move may create */
+    int ch_c, ch_k, ch_slot, ch_windowed;
+    int superset0; /* candidate 0 was scored with every insert slot (its stale flags were not known yet) */
+    int overflow;  /* the slice pool could not hold this slot: it is re-run at the head of the next batch */
+    int n_dirty, pad;
+    double ch_score;
+    long long n_slice_tot, n_eval_tot, bytes_min;
+    long long d_hi, d_lo; /* k_delta accumulator */
+};
+
+/* what the commit step needs about one (candidate, mutation slot), written slot-major by k_records */
+struct SlotPre {
+    long long nz_hi, nz_lo;     /* slice sum under this slot's genome (all sliced contacts) */
+    long long tail_hi, tail_lo; /* the part quirk Q5 drops when the slot's list position is >= S_c mod 64 */
+    long long dz_hi, dz_lo, dni; /* zero-pixel sum and intra pair count: this genome minus the current one, on the window */
+    int k;                      /* coordinate column (0 = not scored) */
+    int changed;                /* the mutated window differs from the current genome */
+    int heads;                  /* contigs on the mutated window */
+    int pad;
+};
+struct CandPre {
+    long long ext_hi, ext_lo; /* slice sum under the current genome */
+    long long n_slice;
+    int r;                    /* S_c mod 64 */
+    int base_cnt;             /* list entries before the block-insert slots */
+    int n_uniq_basic;         /* == base_cnt (kept for the statistics) */
+    int pad;
+};
+
+struct MoveBuf {
+    int* Lloc;      /* [capW*capC][N] global ids of local fragments */
+    int* lbloc;     /* [..][N] */
+    int* slloc;     /* [..][N] */
+    int* subs;      /* [..][M] global sub-frag id of local sub index */
+    int* rowcnt;    /* [..][M] sliced contacts per local row */
+    int* sl_li;     /* slice pool: candidate cw's list starts at slice_offset(w, c): local row index, */
+    int* sl_lj;     /*           local column index, */
+    int* sl_ob;     /*           observed count (order = arrival, sums are order-free) */
+    long long* slbound; /* [..] upper bound of the list length = contacts in the rows of the touched contigs */
+    long long* sloff;   /* [..] start of the list in the pool, -1 = does not fit (k_offsets) */
+    long long pool_cap;
+    uint2* coords;  /* [..][NSLOT][M] column k: {dist bits, pos | code<<28} per local sub index */
+    int* loc;       /* [..][NSLOT][NDYN][N] candidate genomes on the local window */
+    CandMeta* meta; /* [..] */
+    ColMeta* cmeta; /* [..][NSLOT][NCODE] */
+    long long* part;/* [..][P_STRIDE] partial sums (all-reduced across ranks when sharded) */
+    long long* qpart;/* [..][Q_STRIDE] sums every rank computes redundantly */
+    double* scores; /* [..][24] */
+    MoveCtl* ctl;   /* [capW] */
+    int2* sinfo;    /* [..][NSLOT] (changed, contig heads) of each candidate genome (k_mutate) */
+    SlotPre* pre;   /* [..][24] */
+    CandPre* cpre;  /* [..] */
+    int N, M, capC, capW;
+};
+/* layout of MoveBuf.part per candidate (int64 units) */
+#define P_NZ 0                 /* [NSLOT][2] slice sums per column k (k=0: current = "extract") */
+#define P_CNT (NSLOT * 2)      /* [1] kept entries S_c */
+#define P_STRIDE (NSLOT * 2 + 2)
+/* not all-reduced (computed redundantly on every rank) */
+#define Q_Z 0                  /* [NSLOT][2] zero-pixel sums on the local window, per column k */
+#define Q_NI (NSLOT * 2)       /* [NSLOT] intra pair counts */
+#define Q_NZFULL (NSLOT * 3)   /* [NSLOT][2] slice sums before the tail correction */
+#define Q_TAIL (NSLOT * 5)     /* [NSLOT][2] sum of the last S_c mod 64 sliced contacts' terms (quirk Q5) */
+#define Q_STRIDE (NSLOT * 7)
+
+struct ig_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    hipStream_t stream2;           /* k_tail next to k_score_list */
+    hipEvent_t ev_slice, ev_tail;
+    int N, M;
+    long long Z;
+    int rank, world;
+    State st;
+    int* st_block; /* one allocation for all state arrays */
+    Tables tab, tab_prev;
+    SubTab* sub_tab;
+    long long* rowptr;
+    int2* cc; /* (col, count) */
+    int* init_prev;
+    int* init_next;
+    int* orientable;
+    unsigned char* black;
+    double* lgf_tab;
+    Glob* glob;
+    MoveBuf mb;
+    int* stamp;     /* [N] claim stamps of the incremental genome distance */
+    int* batch_out; /* [4] committed moves, pending slot, windows above LDS_COL_SMALL, candidates */
+    int* dirty_buf; /* [1 + 2 * IG_MAX_BATCH + 2] contigs modified by the committed moves of the batch in flight */
+    int *own_tag, *own_idx; /* [N] which committed move of the current batch owns a fragment, and where in its window */
+    ig_move_result* d_results;
+    int results_cap;
+    int* d_frags;
+    int* d_cands;
+    int cands_cap;
+    int* prev_touched;
+    unsigned timing_mask;
+    float* pz_tab;
+    int pz_n;
+    /* timers */
+    bool timing;
+    struct Timer {
+        const char* name;
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+        double total_ms;
+        long long n;
+    } timers[10];
+    long long n_batches, n_batch_committed, n_batch_pending;
+    int large_seen;
+    int up_moves, up_max_c; /* the uploaded move lists */
+    bool have_contacts, have_sub, have_state, have_init, have_params;
+};

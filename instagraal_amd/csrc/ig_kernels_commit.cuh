@@ -1,0 +1,775 @@
+/* ig_kernels_commit.cuh -- choosing and applying: the one-move kernels (k_scores, k_apply, k_commit) and the batch
+ * commit (k_decide_batch, k_commit_batch). */
+#pragma once
+
+/* scores of one move slot (eval_all_likelihood_on_zero_2nd KA:4005-4027, eval_all_scores KA:4029-4046) and the
+ * host argmax of CL:1435-1446 (zeros -> -inf, shifted/clipped scores, FIRST index of the maximum).  Executed by
+ * one workgroup; `vf0` = the stale insert flags the first candidate sees (quirk Q4). */
+__device__ void score_and_choose(Glob* g, const MoveBuf& mb, int w, const int* vf0, double* sc_lds /* [C*24] */)
+{
+    const int tid = threadIdx.x;
+    MoveCtl& mc = mb.ctl[w];
+    const int C = mc.C;
+    const ig_params p = g->par[0];
+    const double log_e = IG_LOG_E_F;
+    const double cur_nz = ig_acc_to_double(g->nz_hi, g->nz_lo);
+    const int n = C * IG_N_TMP_STRUCT;
+    for (int i = tid; i < n; i += blockDim.x) sc_lds[i] = 0.0;
+    __syncthreads();
+    for (int i = tid; i < n; i += blockDim.x) {
+        const int c = i / IG_N_TMP_STRUCT, slot = i % IG_N_TMP_STRUCT;
+        const int cw = CW(w, c);
+        const CandMeta& m = mb.meta[cw];
+        const int k = m.kidx[slot];
+        if (k <= 0) continue;
+        /* position of this slot in the ACTUAL uniq list (the scored list may be a superset for c == 0) */
+        int pos;
+        if (c == 0 && mc.superset0) {
+            if (slot >= 12 && vf0[slot - 12] == -1) continue; /* not scored by the reference */
+            pos = 0;
+            for (int q = 0; q < m.n_uniq; q++) {
+                const int s2 = m.uniq[q];
+                if (s2 >= slot) break;
+                if (s2 < 12 || vf0[s2 - 12] != -1) pos++;
+            }
+        } else {
+            pos = k - 1;
+        }
+        const long long* part = mb.part + (size_t)cw * P_STRIDE;
+        const long long* qp = mb.qpart + (size_t)cw * Q_STRIDE;
+        const int r = (int)(part[P_CNT] % 64);
+        long long nh = qp[Q_NZFULL + 2 * k], nl = qp[Q_NZFULL + 2 * k + 1];
+        if (r > 0 && pos >= r) { /* quirk Q5 */
+            nh -= qp[Q_TAIL + 2 * k];
+            nl -= qp[Q_TAIL + 2 * k + 1];
+        }
+        const double ext = ig_acc_to_double(qp[Q_NZFULL], qp[Q_NZFULL + 1]);
+        const long long zhi = g->z_hi + qp[Q_Z + 2 * k] - qp[Q_Z];
+        const long long zlo = g->z_lo + qp[Q_Z + 2 * k + 1] - qp[Q_Z + 1];
+        const long long ni = g->n_intra + qp[Q_NI + k] - qp[Q_NI];
+        const double val_inter = -1.0 * log_e * (g->n_tot_pxl - (double)ni) * p.v_inter;
+        const double val_intra = ig_acc_to_double(zhi, zlo) * log_e;
+        const double z = val_intra + val_inter;
+        const double nz = ig_acc_to_double(nh, nl);
+        sc_lds[i] = nz + z + cur_nz - ext;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int lane = tid;
+        double mx = -IG_INF;
+        for (int i = lane; i < n; i += 64) {
+            const double s = sc_lds[i];
+            const double ok = (s == 0.0) ? -IG_INF : s;
+            mx = ok > mx ? ok : mx;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(mx, off, 64);
+            mx = o > mx ? o : mx;
+        }
+        double bestv = -IG_INF;
+        int best = 0x7fffffff;
+        for (int i = lane; i < n; i += 64) {
+            const double s = sc_lds[i];
+            const double ok = (s == 0.0) ? -IG_INF : s;
+            double fs = ok - (mx - 30.0);
+            if (fs < 0) fs = 0;
+            if (fs > bestv) { /* strictly greater: the first index wins inside a lane */
+                bestv = fs;
+                best = i;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bestv, off, 64);
+            const int oi = __shfl_xor(best, off, 64);
+            if (ov > bestv || (ov == bestv && oi < best)) {
+                bestv = ov;
+                best = oi;
+            }
+        }
+        if (lane == 0) {
+            if (best >= n) best = 0;
+            const int cc_ = best / IG_N_TMP_STRUCT, slot = best % IG_N_TMP_STRUCT;
+            long long tot_slice = 0, tot_eval = 0, bytes = 0;
+            for (int c = 0; c < C; c++) {
+                const CandMeta& m = mb.meta[CW(w, c)];
+                const long long Sc = mb.part[(size_t)CW(w, c) * P_STRIDE + P_CNT];
+                tot_slice += Sc;
+                int nu = m.n_uniq;
+                if (c == 0 && mc.superset0) /* the list the reference would have scored */
+                    for (int q = 0; q < m.n_uniq; q++) nu -= (m.uniq[q] >= 12 && vf0[m.uniq[q] - 12] == -1);
+                tot_eval += Sc * (nu + 1);
+                bytes += 12 * Sc + 20LL * m.m_loc * nu + 8LL * nu;
+            }
+            const CandMeta& mch = mb.meta[CW(w, cc_)];
+            mc.ch_c = cc_;
+            mc.ch_slot = slot;
+            mc.ch_k = mch.kidx[slot] < 0 ? 0 : mch.kidx[slot];
+            mc.ch_windowed = mch.windowed;
+            mc.ch_score = sc_lds[best];
+            mc.n_slice_tot = tot_slice;
+            mc.n_eval_tot = tot_eval;
+            mc.bytes_min = bytes;
+            if (mch.kidx[slot] < 0) g->error = 3; /* an unscored slot won: cannot happen */
+        }
+    }
+    __syncthreads();
+}
+
+/* one-move path: scores + argmax of slot w (then k_delta / k_apply / k_post / k_commit) */
+__global__ void __launch_bounds__(256) k_scores(Glob* g, MoveBuf mb, int w)
+{
+    __shared__ double sc[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT];
+    __shared__ int vf[12];
+    if (threadIdx.x < 12) vf[threadIdx.x] = g->valid_insert[threadIdx.x];
+    __syncthreads();
+    score_and_choose(g, mb, w, vf, sc);
+    const int n = mb.ctl[w].C * IG_N_TMP_STRUCT;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) mb.scores[(size_t)CW(w, 0) * IG_N_TMP_STRUCT + i] = sc[i];
+}
+
+/* forced choice for ig_apply (test_copy_struct / apply_replay_simu, CL:2094-2151, 2546-2553) */
+__global__ void k_force_choice(Glob* g, MoveBuf mb, int slot)
+{
+    MoveCtl& mc = mb.ctl[0];
+    mc.ch_c = 0;
+    mc.ch_slot = slot;
+    mc.ch_k = mb.meta[0].kidx[slot];
+    mc.ch_windowed = 1; /* always take the exact-delta path */
+    mc.ch_score = 0.0;
+    mc.n_slice_tot = 0;
+    mc.n_eval_tot = 0;
+    mc.bytes_min = 0;
+    if (mc.ch_k < 0) g->error = 4;
+}
+
+/* the winner becomes the live genome (copy_struct KA:4566-4591) and the coordinate tables of the touched
+ * sub-fragments are refreshed from its column; executed cooperatively by the calling threads (tid/nth). */
+__device__ void apply_winner(State st, Tables tab, Glob* g, const MoveBuf& mb, int w, int forced, int* prev_touched, int tid, int nth,
+                             bool single_block)
+{
+    MoveCtl& mc = mb.ctl[w];
+    const int c = mc.ch_c, slot = mc.ch_slot, k = mc.ch_k;
+    const int cw = CW(w, c);
+    const CandMeta& m = mb.meta[cw];
+    const int N = mb.N, M = mb.M;
+    const int* base = mb.loc + ((size_t)(cw * NSLOT + slot) * NDYN) * N;
+    const int* gid = mb.Lloc + (size_t)cw * N;
+    int heads = 0;
+    for (int x = tid; x < m.n_loc; x += nth) {
+        const int f = gid[x];
+        const int np_ = base[x];
+        st.pos[f] = np_;
+        st.spos[f] = base[(size_t)N + x];
+        st.cid[f] = base[(size_t)2 * N + x];
+        st.sbp[f] = base[(size_t)3 * N + x];
+        st.circ[f] = base[(size_t)4 * N + x];
+        st.prev[f] = base[(size_t)5 * N + x];
+        st.next[f] = base[(size_t)6 * N + x];
+        st.L[f] = base[(size_t)7 * N + x];
+        st.SL[f] = base[(size_t)8 * N + x];
+        st.LB[f] = base[(size_t)9 * N + x];
+        st.ori[f] = base[(size_t)10 * N + x];
+        heads += (np_ == 0);
+    }
+    heads = wave_sum_i(heads);
+    if ((threadIdx.x & 63) == 0 && heads) atomicAdd(&g->n_contigs, heads);
+    const uint2* col = mb.coords + (size_t)(cw * NSLOT + k) * M;
+    const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
+    const int* subs = mb.subs + (size_t)cw * M;
+    const int fresh = mc.fresh;
+    for (int ls = tid; ls < m.m_loc; ls += nth) {
+        const int s = subs[ls];
+        const uint2 v = col[ls];
+        const int code = (int)(v.y >> 28);
+        tab.dist[s] = __uint_as_float(v.x);
+        tab.cp[s] = make_int2(code == 0 ? m.ctgA : (code == 1 ? m.ctgB : fresh + (code - 2)), (int)(v.y & 0x0fffffffu));
+        tab.stot[s] = cm[code].stot;
+        tab.len[s] = cm[code].len;
+        prev_touched[ls] = s;
+    }
+    if (tid == 0) {
+        const long long* qp = mb.qpart + (size_t)cw * Q_STRIDE;
+        g->n_prev_touched = m.m_loc;
+        atomicAdd(&g->n_contigs, m.same ? -1 : -2);
+        long long dh, dl;
+        if (mc.ch_windowed) {
+            dh = mc.d_hi;
+            dl = mc.d_lo;
+        } else {
+            dh = qp[Q_NZFULL + 2 * k] - qp[Q_NZFULL];
+            dl = qp[Q_NZFULL + 2 * k + 1] - qp[Q_NZFULL + 1];
+        }
+        long long h = g->nz_hi + dh, l = g->nz_lo + dl;
+        ig_acc_normalize((int64_t*)&h, (int64_t*)&l);
+        g->nz_hi = h;
+        g->nz_lo = l;
+        h = g->z_hi + qp[Q_Z + 2 * k] - qp[Q_Z];
+        l = g->z_lo + qp[Q_Z + 2 * k + 1] - qp[Q_Z + 1];
+        ig_acc_normalize((int64_t*)&h, (int64_t*)&l);
+        g->z_hi = h;
+        g->z_lo = l;
+        g->n_intra += qp[Q_NI + k] - qp[Q_NI];
+        /* stale-flag state (quirk Q4): flags of the last candidate, or of the winner when its
+         * family re-ran get_bounds in test_copy_struct (op >= 12, CL:2125-2126) */
+        if (!forced || slot >= 12) {
+            const int* fl = (slot >= 12) ? m.flags : mb.meta[CW(w, mc.C - 1)].flags;
+            for (int i = 0; i < 12; i++) g->valid_insert[i] = fl[i];
+        }
+    }
+    (void)single_block;
+}
+
+__global__ void k_apply(State st, Tables tab, Glob* g, MoveBuf mb, int w, int forced, int* prev_touched)
+{
+    if (g->error) return;
+    apply_winner(st, tab, g, mb, w, forced, prev_touched, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, false);
+}
+
+__device__ __forceinline__ void write_result(Glob* g, const MoveBuf& mb, int w, ig_move_result* out)
+{
+    const MoveCtl& mc = mb.ctl[w];
+    ig_move_result r;
+    const double norm = 3.0 * (double)(g->N - g->n_black);
+    r.o = mc.ch_score;
+    r.dist = (norm - 0.5 * (double)g->credit2) / norm;
+    r.mean_len = (double)((float)g->N / (float)g->n_contigs);
+    r.op_sampled = mc.ch_slot;
+    r.id_f_sampled = mb.meta[CW(w, mc.ch_c)].B;
+    r.n_contigs = g->n_contigs;
+    r.n_candidates = mc.C;
+    r.n_slice = mc.n_slice_tot;
+    r.n_evals = mc.n_eval_tot;
+    r.bytes_min = mc.bytes_min + 68LL * mb.meta[CW(w, mc.ch_c)].n_loc;
+    r.error = g->error;
+    r.pad = 0;
+    *out = r;
+}
+
+__global__ void k_commit(Glob* g, MoveBuf mb, ig_move_result* res, int move, int w)
+{
+    g->next_cid += NFRESH;
+    g->credit2 = g->credit2_acc;
+    g->credit2_acc = 0;
+    write_result(g, mb, w, res + move);
+}
+
+/* credit of fragment f (dist_inter_genome, CL:665-716) when the genome is read through an accessor: V(x) returns
+ * (prev, next, ori) of x as of the moment being evaluated */
+template <class V>
+__device__ __forceinline__ int credit2_view(V view, const int* ip, const int* in, const int* orientable, int f)
+{
+    const int p0 = ip[f], n0 = in[f];
+    const int3 sf = view(f);
+    int p1 = sf.x, n1 = sf.y;
+    const int o1 = sf.z;
+    int c2 = 0;
+    if (((p1 == p0) && (n1 == n0)) || ((p1 == n0) && (n1 == p0))) c2 += 2;
+    if (orientable[f]) {
+        int swap = 1;
+        if (1 != o1) {
+            int t = p1;
+            p1 = n1;
+            n1 = t;
+            swap = -1;
+        }
+        if (p0 == p1) {
+            if (p0 == -1) c2 += 2;
+            else if (!orientable[p1]) c2 += 2;
+            else c2 += 1 + ((1 == swap * view(p1).z) ? 1 : 0);
+        }
+        if (n0 == n1) {
+            if (n0 == -1) c2 += 2;
+            else if (!orientable[n1]) c2 += 2;
+            else c2 += 1 + ((1 == swap * view(n1).z) ? 1 : 0);
+        }
+    } else {
+        if ((p1 == p0) || (p1 == n0)) c2 += 2;
+        if ((n1 == n0) || (n1 == p0)) c2 += 2;
+    }
+    return c2;
+}
+
+/* k_commit_batch: the sequential half of a batch, one workgroup.
+ *
+ * 1. DECIDE (wave 0, no barriers): for w = 0, 1, ...: stop if a contig of move w was modified by an earlier move of
+ *    this batch (its scores were computed against a stale state) or if its slice did not fit the pool; otherwise score
+ *    and argmax with the LIVE scalars (kept in registers) from the slot-major records of k_records, update the scalars,
+ *    write the result record.  A winner whose slice was windowed and that changes the genome needs the exact k_delta
+ *    pass: the batch stops BEFORE it (pending) and the host finishes that move with the one-move kernels.
+ * 2. APPLY (whole workgroup): the committed moves touch pairwise disjoint contigs, so their winners are applied
+ *    together: ownership marks, exact genome-distance deltas (each move's credits evaluated on the genome as of just
+ *    before / just after that move, read through the marks), state + coordinate tables, the distance column of the
+ *    results.  tab_prev receives every committed move but the last one (quirk Q12: tables before the last move). */
+#define COMMIT_THREADS 1024
+/* step 1 of the batch commit: ONE wave (it may use the whole register file: the data of the next move is held in
+ * registers while the current one is decided) */
+__global__ void __launch_bounds__(64)
+    k_decide_batch(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out)
+{
+    /* w_start > 0: slot w_start - 1 was the pending move, meanwhile applied by the one-move kernels; the rest of the batch
+     * is still valid wherever it does not touch a contig modified so far (dirty_buf carries the list across the calls) */
+    __shared__ int dirty[IG_MAX_BATCH * 2 + 2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    {
+        /* ------------------------------------------------------------ 1. decide */
+        long long nz_hi = g->nz_hi, nz_lo = g->nz_lo, z_hi = g->z_hi, z_lo = g->z_lo, n_intra = g->n_intra;
+        int n_contigs = g->n_contigs, next_cid = g->next_cid;
+        const int err0 = g->error;
+        unsigned vmask = 0;
+        {
+            const int v = (lane < 12) ? g->valid_insert[lane] : -1;
+            vmask = (unsigned)__ballot(lane < 12 && v != -1);
+        }
+        const ig_params p = g->par[0];
+        const double log_e = IG_LOG_E_F;
+        const double n_tot_pxl = g->n_tot_pxl;
+        int n_dirty = 0, committed = w_start, pending = -1, n_large = 0, n_cand = 0;
+        if (w_start > 0) {
+            n_dirty = dirty_buf[0];
+            for (int q = lane; q < n_dirty; q += 64) dirty[q] = dirty_buf[1 + q];
+            const MoveCtl pm = mb.ctl[w_start - 1];
+            const CandMeta& m = mb.meta[CW(w_start - 1, pm.ch_c)];
+            if (lane == 0) {
+                dirty[n_dirty] = m.ctgA;
+                dirty[n_dirty + 1] = m.ctgB;
+            }
+            n_dirty += 2;
+        }
+        /* Everything a decision reads is loaded ONE MOVE AHEAD (none of it depends on earlier decisions, only its
+         * interpretation does): while move w is decided from registers with wave shuffles only, the loads of move w + 1
+         * are in flight.  Moves with more than 5 candidates (> 2 score records per lane) take the unpipelined path. */
+        struct MoveData {
+            int C, superset0;                                       /* uniform */
+            int cA, cB, mloc, same, windowed, B, n_loc, n_uniq;     /* lane c < C: candidate c */
+            long long c_ext_hi, c_ext_lo, c_n_slice;
+            int c_base_cnt, c_overflow;
+            int flag;                                               /* lane < 12 * min(C, 5): flags[lane % 12] of candidate lane / 12 */
+            SlotPre rec[2];                                         /* score records lane, lane + 64 */
+            long long e_ext_hi[2], e_ext_lo[2];                     /* their candidates' slice sum under the current genome, */
+            int e_r[2], e_base[2];                                  /* S_c mod 64, list entries before the block inserts */
+        };
+        auto load_move = [&](int w) {
+            MoveData d;
+            const MoveCtl& mc = mb.ctl[w];
+            d.C = mc.C;
+            d.superset0 = mc.superset0;
+            d.cA = d.cB = -1;
+            d.mloc = d.same = d.windowed = d.B = d.n_loc = d.n_uniq = 0;
+            d.c_ext_hi = d.c_ext_lo = d.c_n_slice = 0;
+            d.c_base_cnt = d.c_overflow = 0;
+            if (lane < d.C) {
+                const CandMeta& m = mb.meta[CW(w, lane)];
+                d.cA = m.ctgA;
+                d.cB = m.ctgB;
+                d.mloc = m.m_loc;
+                d.same = m.same;
+                d.windowed = m.windowed;
+                d.B = m.B;
+                d.n_loc = m.n_loc;
+                d.n_uniq = m.n_uniq;
+                const CandPre& cp = mb.cpre[CW(w, lane)];
+                d.c_ext_hi = cp.ext_hi;
+                d.c_ext_lo = cp.ext_lo;
+                d.c_n_slice = cp.n_slice;
+                d.c_base_cnt = cp.base_cnt;
+                d.c_overflow = cp.pad;
+            }
+            d.flag = -1;
+            if (lane < 12 * min(d.C, 5)) d.flag = mb.meta[CW(w, lane / 12)].flags[lane % 12];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int i = lane + 64 * j;
+                d.rec[j].k = 0;
+                d.e_ext_hi[j] = d.e_ext_lo[j] = 0;
+                d.e_r[j] = d.e_base[j] = 0;
+                if (i < d.C * IG_N_TMP_STRUCT) {
+                    const int cw = CW(w, i / IG_N_TMP_STRUCT);
+                    d.rec[j] = mb.pre[(size_t)cw * IG_N_TMP_STRUCT + i % IG_N_TMP_STRUCT];
+                    const CandPre& cp = mb.cpre[cw];
+                    d.e_ext_hi[j] = cp.ext_hi;
+                    d.e_ext_lo[j] = cp.ext_lo;
+                    d.e_r[j] = cp.r;
+                    d.e_base[j] = cp.base_cnt;
+                }
+            }
+            return d;
+        };
+        auto rl = [](int v, int src) { return __builtin_amdgcn_readlane(v, src); };
+        auto rl64 = [](long long v, int src) {
+            const int lo = __builtin_amdgcn_readlane((int)(unsigned)v, src), hi = __builtin_amdgcn_readlane((int)(v >> 32), src);
+            return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+        };
+        auto rld = [&](double v, int src) { return __longlong_as_double(rl64(__double_as_longlong(v), src)); };
+        MoveData cur = load_move(w_start < W ? w_start : W - 1);
+        for (int w = w_start; w < W; w++) {
+            const MoveData d = cur;
+            if (w + 1 < W) cur = load_move(w + 1);
+            const int C = d.C;
+            /* conflict with an earlier move of this batch?  slice pool overflow? */
+            bool hitd = false;
+            for (int q = 0; q < n_dirty; q++) hitd |= (dirty[q] == d.cA) | (dirty[q] == d.cB);
+            if (err0 || rl(d.c_overflow, 0) || __any(hitd && lane < C)) break;
+            n_large += __popcll(__ballot(lane < C && d.mloc > LDS_COL_SMALL));
+            n_cand += C;
+            /* scores (eval_all_likelihood_on_zero_2nd KA:4005-4027, eval_all_scores KA:4029-4046) with the live scalars */
+            const double cur_nz = ig_acc_to_double(nz_hi, nz_lo);
+            const int n = C * IG_N_TMP_STRUCT;
+            constexpr int NJ = (IG_MAX_CANDIDATES * IG_N_TMP_STRUCT + 63) / 64;
+            double sc[NJ];
+            /* host argmax of CL:1435-1446: zeros -> -inf, scores shifted by (max - 30) and clipped at 0, FIRST index of the
+             * maximum.  The clipped maximum is 30 > 0 and is reached exactly where the score is maximal, so this is the first
+             * index of the maximal score (all scores zero: index 0) -- one reduction of (score, index). */
+            double bestv = -IG_INF;
+            int best = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                const int i = lane + 64 * j;
+                double v = 0.0;
+                if (j < 2 || i < n) { /* j >= 2: only moves with more than 5 candidates get here with i < n */
+                    SlotPre r;
+                    long long ext_hi, ext_lo;
+                    int cr, cbase;
+                    if (j < 2) {
+                        r = d.rec[j];
+                        ext_hi = d.e_ext_hi[j];
+                        ext_lo = d.e_ext_lo[j];
+                        cr = d.e_r[j];
+                        cbase = d.e_base[j];
+                    } else {
+                        const int cw = CW(w, i / IG_N_TMP_STRUCT);
+                        r = mb.pre[(size_t)cw * IG_N_TMP_STRUCT + i % IG_N_TMP_STRUCT];
+                        const CandPre cp = mb.cpre[cw];
+                        ext_hi = cp.ext_hi;
+                        ext_lo = cp.ext_lo;
+                        cr = cp.r;
+                        cbase = cp.base_cnt;
+                    }
+                    const int c = i / IG_N_TMP_STRUCT, slot = i % IG_N_TMP_STRUCT;
+                    const bool sup = (c == 0) && d.superset0 && (slot >= 12);
+                    const bool scored = (i < n) && (r.k > 0) && !(sup && !((vmask >> (slot - 12)) & 1u));
+                    if (scored) {
+                        const int pos = sup ? cbase + __popc(vmask & ((1u << (slot - 12)) - 1u)) : r.k - 1;
+                        long long nh = r.nz_hi, nl = r.nz_lo;
+                        if (cr > 0 && pos >= cr) { /* quirk Q5 */
+                            nh -= r.tail_hi;
+                            nl -= r.tail_lo;
+                        }
+                        const double ext = ig_acc_to_double(ext_hi, ext_lo);
+                        const double val_inter = -1.0 * log_e * (n_tot_pxl - (double)(n_intra + r.dni)) * p.v_inter;
+                        const double val_intra = ig_acc_to_double(z_hi + r.dz_hi, z_lo + r.dz_lo) * log_e;
+                        const double z = val_intra + val_inter;
+                        v = ig_acc_to_double(nh, nl) + z + cur_nz - ext;
+                    }
+                }
+                sc[j] = v;
+                const double ok = (v == 0.0) ? -IG_INF : v;
+                if (i < n && ok > bestv) { /* strictly greater: the lower index wins inside a lane */
+                    bestv = ok;
+                    best = i;
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ov = __shfl_xor(bestv, off, 64);
+                const int oi = __shfl_xor(best, off, 64);
+                if (ov > bestv || (ov == bestv && oi < best)) {
+                    bestv = ov;
+                    best = oi;
+                }
+            }
+            best = rl(best, 0);
+            if (best >= n) best = 0;
+            const int bc = best / IG_N_TMP_STRUCT, bslot = best % IG_N_TMP_STRUCT;
+            const int owner = best & 63, bj = best >> 6; /* the lane and register that hold the winner's record */
+            SlotPre br;
+            double bests;
+            if (bj < 2) {
+                const SlotPre mine = (bj == 0) ? d.rec[0] : d.rec[1];
+                br.nz_hi = rl64(mine.nz_hi, owner);
+                br.nz_lo = rl64(mine.nz_lo, owner);
+                br.dz_hi = rl64(mine.dz_hi, owner);
+                br.dz_lo = rl64(mine.dz_lo, owner);
+                br.dni = rl64(mine.dni, owner);
+                br.k = rl(mine.k, owner);
+                br.changed = rl(mine.changed, owner);
+                br.heads = rl(mine.heads, owner);
+                bests = rld((bj == 0) ? sc[0] : sc[1], owner);
+            } else {
+                br = mb.pre[(size_t)CW(w, bc) * IG_N_TMP_STRUCT + bslot];
+                double sv = 0.0;
+#pragma unroll
+                for (int j = 2; j < NJ; j++) sv = (bj == j) ? sc[j] : sv;
+                bests = rld(sv, owner);
+            }
+            const int windowed = rl(d.windowed, bc), b_same = rl(d.same, bc), b_B = rl(d.B, bc), b_nloc = rl(d.n_loc, bc);
+            const int b_cA = rl(d.cA, bc), b_cB = rl(d.cB, bc);
+            const long long b_ext_hi = rl64(d.c_ext_hi, bc), b_ext_lo = rl64(d.c_ext_lo, bc);
+            /* statistics of the move: off the critical path, k_commit_batch fills them in from the flag mask kept here
+             * (a pending move needs them now: its record is written by the one-move kernels) */
+            long long Sc = 0, ev = 0, by = 0;
+            const bool is_pending = windowed && br.changed;
+            if (is_pending) {
+                if (lane < C) {
+                    int nu = d.n_uniq;
+                    if (lane == 0 && d.superset0) nu = d.c_base_cnt + __popc(vmask); /* the list the reference would have scored */
+                    Sc = d.c_n_slice;
+                    ev = Sc * (nu + 1);
+                    by = 12 * Sc + 20LL * d.mloc * nu + 8LL * nu;
+                }
+                Sc = rl64(wave_sum_ll(Sc), 0);
+                ev = rl64(wave_sum_ll(ev), 0);
+                by = rl64(wave_sum_ll(by), 0);
+            }
+            if (lane == 0) {
+                MoveCtl& o = mb.ctl[w];
+                o.ch_c = bc;
+                o.ch_slot = bslot;
+                o.ch_k = br.k;
+                o.ch_windowed = windowed;
+                o.ch_score = bests;
+                o.n_slice_tot = Sc;
+                o.n_eval_tot = ev;
+                o.bytes_min = by;
+                o.d_hi = 0;
+                o.d_lo = 0;
+                o.n_dirty = br.changed;
+                o.pad = (int)vmask; /* the stale flags this move was scored under */
+                if (br.k <= 0) g->error = 3; /* an unscored slot won: cannot happen */
+            }
+            if (is_pending) { /* needs k_delta: hand this move to the one-move tail */
+                pending = w;
+                break;
+            }
+            /* commit: scalars (exact), stale-flag state (quirk Q4), fresh ids */
+            nz_hi += br.nz_hi - b_ext_hi;
+            nz_lo += br.nz_lo - b_ext_lo;
+            ig_acc_normalize((int64_t*)&nz_hi, (int64_t*)&nz_lo);
+            z_hi += br.dz_hi;
+            z_lo += br.dz_lo;
+            ig_acc_normalize((int64_t*)&z_hi, (int64_t*)&z_lo);
+            n_intra += br.dni;
+            n_contigs += br.heads - (b_same ? 1 : 2);
+            next_cid += NFRESH;
+            {
+                const int sel = (bslot >= 12) ? bc : C - 1; /* the family of the winner re-ran get_bounds (CL:2125-2126) */
+                if (sel < 5) {
+                    vmask = (unsigned)((__ballot(d.flag != -1) >> (12 * sel)) & 0xfffull);
+                } else {
+                    const int v = (lane < 12) ? mb.meta[CW(w, sel)].flags[lane] : -1;
+                    vmask = (unsigned)__ballot(lane < 12 && v != -1);
+                }
+            }
+            if (lane == 0) {
+                ig_move_result r;
+                r.o = bests;
+                r.dist = 0.0; /* step 2 */
+                r.mean_len = (double)((float)g->N / (float)n_contigs);
+                r.op_sampled = bslot;
+                r.id_f_sampled = b_B;
+                r.n_contigs = n_contigs;
+                r.n_candidates = C;
+                r.n_slice = 0; /* step 2 */
+                r.n_evals = 0;
+                r.bytes_min = 68LL * b_nloc;
+                r.error = err0;
+                r.pad = 0;
+                res[move0 + w] = r;
+                if (br.changed) {
+                    dirty[n_dirty] = b_cA;
+                    dirty[n_dirty + 1] = b_cB;
+                }
+            }
+            if (br.changed) n_dirty += 2;
+            committed = w + 1;
+        }
+        if (lane == 0) {
+            g->nz_hi = nz_hi;
+            g->nz_lo = nz_lo;
+            g->z_hi = z_hi;
+            g->z_lo = z_lo;
+            g->n_intra = n_intra;
+            g->n_contigs = n_contigs;
+            g->next_cid = next_cid;
+            dirty_buf[0] = n_dirty;
+            for (int q = 0; q < n_dirty; q++) dirty_buf[1 + q] = dirty[q];
+            batch_out[0] = committed;
+            batch_out[1] = pending;
+            batch_out[2] = n_large;
+            batch_out[3] = n_cand;
+        }
+        if (lane < 12) g->valid_insert[lane] = ((vmask >> lane) & 1u) ? 1 : -1;
+    }
+}
+
+/* step 2 of the batch commit: one workgroup applies the moves [w_start, batch_out[0]) k_decide_batch committed */
+__global__ void __launch_bounds__(COMMIT_THREADS)
+    k_commit_batch(State st, Tables tab, Tables tab_prev, Glob* g, MoveBuf mb, const int* __restrict__ ip, const int* __restrict__ in,
+                   const int* __restrict__ orientable, const unsigned char* __restrict__ black, int* stamp, int* own_tag, int* own_idx,
+                   int* prev_touched, ig_move_result* res, int move0, int W, int w_start, const int* batch_out)
+{
+    __shared__ long long sh_delta[IG_MAX_BATCH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tag_base = g->stamp_ctr; /* tags/stamps of this batch: tag_base + w */
+    if (tid < IG_MAX_BATCH) sh_delta[tid] = 0;
+    const int committed = batch_out[0];
+    __syncthreads();
+    if (committed == w_start) return;
+    /* ---------------------------------------------------------------- 2. apply */
+    const int N = mb.N, M = mb.M;
+    auto winner_loc = [&](int w) -> const int* {
+        const MoveCtl& mc = mb.ctl[w];
+        return mb.loc + ((size_t)(CW(w, mc.ch_c) * NSLOT + mc.ch_slot) * NDYN) * N;
+    };
+    /* 2a. ownership marks of the fragments whose state changes */
+    for (int w = w_start; w < committed; w++) {
+        const MoveCtl& mc = mb.ctl[w];
+        if (!mc.n_dirty) continue;
+        const int cw = CW(w, mc.ch_c);
+        const int n_loc = mb.meta[cw].n_loc;
+        const int* gid = mb.Lloc + (size_t)cw * N;
+        for (int x = tid; x < n_loc; x += blockDim.x) {
+            const int f = gid[x];
+            own_tag[f] = tag_base + w;
+            own_idx[f] = x;
+        }
+    }
+    __syncthreads();
+    /* 2b. genome distance: credit(f) depends on prev/next/ori of f and on the orientation of its INITIAL neighbours
+     * (CL:665-716), so move w can change the credits of its window and of the window's initial neighbours only; each is
+     * evaluated on the genome as of move w-1 and as of move w (moves < t applied, read through the marks) */
+    for (int w = w_start; w < committed; w++) {
+        const MoveCtl& mc = mb.ctl[w];
+        if (!mc.n_dirty) continue;
+        const int cw = CW(w, mc.ch_c);
+        const int n_loc = mb.meta[cw].n_loc;
+        const int* gid = mb.Lloc + (size_t)cw * N;
+        const int stampv = tag_base + w + 1; /* != 0 */
+        long long d = 0;
+        for (int item = tid; item < 3 * n_loc; item += blockDim.x) {
+            const int f0 = gid[item / 3];
+            const int q = item % 3;
+            const int f = (q == 0) ? f0 : ((q == 1) ? ip[f0] : in[f0]);
+            if (f < 0 || black[f]) continue;
+            if (atomicExch(&stamp[f], stampv) == stampv) continue; /* claimed by another item of this move */
+            auto view_at = [&](int t) {
+                return [=](int x) -> int3 {
+                    const int tg = own_tag[x] - tag_base;
+                    if (tg >= 0 && tg <= t) {
+                        const int* b = winner_loc(tg);
+                        const int xi = own_idx[x];
+                        return make_int3(b[(size_t)5 * N + xi], b[(size_t)6 * N + xi], b[(size_t)10 * N + xi]);
+                    }
+                    return make_int3(st.prev[x], st.next[x], st.ori[x]);
+                };
+            };
+            d += credit2_view(view_at(w), ip, in, orientable, f) - credit2_view(view_at(w - 1), ip, in, orientable, f);
+        }
+        d = wave_sum_ll(d);
+        if (lane == 0 && d) atomic_add_ll(&sh_delta[w], d);
+    }
+    __syncthreads();
+    /* 2c. the winners become the live genome (copy_struct KA:4566-4591); coordinate tables of the touched sub-fragments.
+     * First tab_prev catches up with the move applied last before this call. */
+    for (int i = tid; i < g->n_prev_touched; i += blockDim.x) {
+        const int s2 = prev_touched[i];
+        tab_prev.dist[s2] = tab.dist[s2];
+        tab_prev.stot[s2] = tab.stot[s2];
+        tab_prev.cp[s2] = tab.cp[s2];
+        tab_prev.len[s2] = tab.len[s2];
+    }
+    __syncthreads();
+    for (int w = w_start; w < committed; w++) {
+        const MoveCtl& mc = mb.ctl[w];
+        const int cw = CW(w, mc.ch_c);
+        const CandMeta& m = mb.meta[cw];
+        const bool last = (w == committed - 1);
+        if (last && tid == 0) g->n_prev_touched = mc.n_dirty ? m.m_loc : 0;
+        if (!mc.n_dirty) continue;
+        const int* base = winner_loc(w);
+        const int* gid = mb.Lloc + (size_t)cw * N;
+        for (int x = tid; x < m.n_loc; x += blockDim.x) {
+            const int f = gid[x];
+            st.pos[f] = base[x];
+            st.spos[f] = base[(size_t)N + x];
+            st.cid[f] = base[(size_t)2 * N + x];
+            st.sbp[f] = base[(size_t)3 * N + x];
+            st.circ[f] = base[(size_t)4 * N + x];
+            st.prev[f] = base[(size_t)5 * N + x];
+            st.next[f] = base[(size_t)6 * N + x];
+            st.L[f] = base[(size_t)7 * N + x];
+            st.SL[f] = base[(size_t)8 * N + x];
+            st.LB[f] = base[(size_t)9 * N + x];
+            st.ori[f] = base[(size_t)10 * N + x];
+        }
+        const int k = mc.ch_k;
+        const uint2* col = mb.coords + (size_t)(cw * NSLOT + k) * M;
+        const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
+        const int* subs = mb.subs + (size_t)cw * M;
+        const int fresh = mc.fresh;
+        for (int ls = tid; ls < m.m_loc; ls += blockDim.x) {
+            const int s = subs[ls];
+            const uint2 v = col[ls];
+            const int code = (int)(v.y >> 28);
+            const float dist = __uint_as_float(v.x);
+            const int2 cp = make_int2(code == 0 ? m.ctgA : (code == 1 ? m.ctgB : fresh + (code - 2)), (int)(v.y & 0x0fffffffu));
+            const float stot = cm[code].stot;
+            const int len = cm[code].len;
+            tab.dist[s] = dist;
+            tab.cp[s] = cp;
+            tab.stot[s] = stot;
+            tab.len[s] = len;
+            if (last) {
+                prev_touched[ls] = s;
+            } else {
+                tab_prev.dist[s] = dist;
+                tab_prev.cp[s] = cp;
+                tab_prev.stot[s] = stot;
+                tab_prev.len[s] = len;
+            }
+        }
+    }
+    __syncthreads();
+    /* 2d. the statistics columns (one thread per move), the distance column */
+    if (tid >= w_start && tid < committed) {
+        const int w = tid;
+        const MoveCtl& mc = mb.ctl[w];
+        const unsigned vmask = (unsigned)mc.pad;
+        long long Sc = 0, ev = 0, by = 0;
+        for (int c = 0; c < mc.C; c++) {
+            const CandMeta& m = mb.meta[CW(w, c)];
+            const CandPre& cp = mb.cpre[CW(w, c)];
+            int nu = m.n_uniq;
+            if (c == 0 && mc.superset0) nu = cp.base_cnt + __popc(vmask); /* the list the reference would have scored */
+            Sc += cp.n_slice;
+            ev += cp.n_slice * (nu + 1);
+            by += 12 * cp.n_slice + 20LL * m.m_loc * nu + 8LL * nu;
+        }
+        res[move0 + w].n_slice = Sc;
+        res[move0 + w].n_evals = ev;
+        res[move0 + w].bytes_min += by;
+    }
+    if (tid == 0) {
+        long long c2 = g->credit2;
+        const double norm = 3.0 * (double)(g->N - g->n_black);
+        for (int w = w_start; w < committed; w++) {
+            c2 += sh_delta[w];
+            res[move0 + w].dist = (norm - 0.5 * (double)c2) / norm;
+        }
+        g->credit2 = c2;
+        g->stamp_ctr = tag_base + W + 2;
+    }
+}
+
+__global__ void k_debug_terms(const float* s, const float* stot, const int* ob, long long n, const Glob* g,
+                              const double* __restrict__ lgf_tab, float* ex, float* exc, double* term, long long* q)
+{
+    long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ig_params p = g->par[0];
+    const ig_hot hot = ig_hot_make(p, ig_tab());
+    ex[i] = ig_rippe(s[i], p, ig_tab());
+    exc[i] = ig_rippe_circ(s[i], stot[i], p, ig_tab());
+    /* the contract's term with P_z := exc (same probe as the oracle's igo_eval_terms) */
+    if (hot.fast && ob[i] > 0) term[i] = ig_term_hot(s[i], 0, ob[i], lgfact_dev(ob[i], lgf_tab), exc[i], &hot, ig_tab());
+    else term[i] = ig_pixel_term(ex[i], exc[i], ob[i], lgfact_dev(ob[i], lgf_tab), ig_tab());
+    q[i] = ig_quantize(term[i]);
+}

@@ -1,0 +1,952 @@
+/* ig_kernels_score.cuh -- scoring half of a (batch of) move(s): k_gather, k_mutate, k_offsets, k_slice,
+ * k_score_list (the hot kernel), k_delta, k_tail, k_records. */
+#pragma once
+
+/* ------------------------------------------------------------------ the move(s)
+ *
+ * Candidate draws do not depend on the genome (CL:3103-3141 reads fixed distributions), so W consecutive
+ * moves can be SCORED against the same base state in single launches (slot dimension w below) and then
+ * COMMITTED in order by one workgroup (k_commit_batch) that stops at the first move whose contigs were
+ * modified by an earlier move of the batch.  W = 1 is the plain one-move-at-a-time path.
+ * Buffers of candidate c of slot w live at index cw = w * capC + c. */
+
+#define CW(w, c) ((w) * mb.capC + (c))
+
+/* uniq-mutation list of extract_uniq_mutations (KA:4492-4553); vf == nullptr -> every insert slot (superset) */
+__device__ inline int build_uniq(int* u, bool first, int LA, int LB, const int* vf)
+{
+    int n = 0;
+    if (first) {
+        u[n++] = 0;
+        u[n++] = 1;
+    }
+    u[n++] = 2;
+    u[n++] = 3;
+    if (LB != 1)
+        for (int k = 4; k < 8; k++) u[n++] = k;
+    if (LA != 1)
+        for (int k = 8; k < 12; k++) u[n++] = k;
+    for (int k = 12; k < IG_N_TMP_STRUCT; k++)
+        if (!vf || vf[k - 12] != -1) u[n++] = k;
+    return n;
+}
+
+/* k_gather: every fragment of a touched contig drops itself at its rank (no compaction needed);
+ * block w also derives the metadata of move slot w: get_bounds flags (KA:2124-2252), slice windows
+ * (KA:530-548) and the uniq-mutation lists with the STALE flags of quirk Q4.  For slots w > 0 the flags
+ * the first candidate will see depend on the outcome of move w-1, so that candidate is scored with the
+ * superset list and the commit step selects the actual one. */
+__global__ void __launch_bounds__(256)
+    k_gather(State st, Glob* g, MoveBuf mb, const int* __restrict__ cands_all, const int* __restrict__ frags_all, int move0, int W,
+             int max_c, Tables tab, Tables tab_prev, const int* __restrict__ prev_touched, int force_slot)
+{
+    /* tab_prev := coordinates before the LAST applied move (eval_likelihood_4_nuisance reads tables that
+     * were filled before the move was applied, CL:1296-1344 / quirk Q12): catch up the entries that move touched */
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g->n_prev_touched; i += gridDim.x * blockDim.x) {
+        const int s = prev_touched[i];
+        tab_prev.dist[s] = tab.dist[s];
+        tab_prev.stot[s] = tab.stot[s];
+        tab_prev.cp[s] = tab.cp[s];
+        tab_prev.len[s] = tab.len[s];
+    }
+    __shared__ int sh_cA[IG_MAX_BATCH], sh_LA[IG_MAX_BATCH], sh_C[IG_MAX_BATCH];
+    __shared__ int sh_cB[IG_MAX_BATCH * IG_MAX_CANDIDATES];
+    __shared__ int sh_flags[IG_MAX_CANDIDATES][12];
+    const int N = mb.N;
+    for (int i = threadIdx.x; i < W; i += blockDim.x) {
+        const int A = frags_all[move0 + i];
+        sh_cA[i] = st.cid[A];
+        sh_LA[i] = st.L[A];
+        int C = 0;
+        for (int q = 0; q < max_c; q++) C += (cands_all[(size_t)(move0 + i) * max_c + q] >= 0);
+        sh_C[i] = C;
+    }
+    for (int i = threadIdx.x; i < W * max_c; i += blockDim.x) {
+        const int b = cands_all[(size_t)move0 * max_c + i];
+        sh_cB[(i / max_c) * IG_MAX_CANDIDATES + (i % max_c)] = b >= 0 ? st.cid[b] : -1;
+    }
+    __syncthreads();
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < N) {
+        const int cf = st.cid[f], pf = st.pos[f];
+        const int lb = st.lb[f], sl = st.sl[f];
+        for (int w = 0; w < W; w++) {
+            const int cA = sh_cA[w], LA = sh_LA[w], C = sh_C[w];
+            for (int c = 0; c < C; c++) {
+                int slot = -1;
+                if (cf == cA) slot = pf;
+                else if (cf == sh_cB[w * IG_MAX_CANDIDATES + c]) slot = LA + pf;
+                if (slot >= 0) {
+                    const size_t o = (size_t)CW(w, c) * N + slot;
+                    mb.Lloc[o] = f;
+                    mb.lbloc[o] = lb;
+                    mb.slloc[o] = sl;
+                }
+            }
+        }
+    }
+    const int w = blockIdx.x;
+    if (w >= W) return;
+    const int t = threadIdx.x;
+    const int A = frags_all[move0 + w];
+    const int* cands = cands_all + (size_t)(move0 + w) * max_c;
+    const int C = sh_C[w];
+    const int cA = sh_cA[w], LA = sh_LA[w];
+    if (t == 0) {
+        MoveCtl mc;
+        mc.A = A;
+        mc.C = C;
+        mc.force_slot = force_slot;
+        mc.fresh = g->next_cid + NFRESH * w;
+        mc.ch_c = mc.ch_k = mc.ch_slot = mc.ch_windowed = 0;
+        mc.ch_score = 0.0;
+        mc.n_slice_tot = mc.n_eval_tot = mc.bytes_min = 0;
+        mc.d_hi = mc.d_lo = 0;
+        mc.superset0 = (w > 0 && force_slot < 0) ? 1 : 0;
+        mc.n_dirty = 0;
+        mc.overflow = 0;
+        mc.pad = 0;
+        mb.ctl[w] = mc;
+    }
+    for (int i = t; i < C * P_STRIDE; i += blockDim.x) mb.part[(size_t)CW(w, 0) * P_STRIDE + i] = 0;
+    for (int i = t; i < C * Q_STRIDE; i += blockDim.x) mb.qpart[(size_t)CW(w, 0) * Q_STRIDE + i] = 0;
+    for (int i = t; i < C * IG_N_TMP_STRUCT; i += blockDim.x) mb.scores[(size_t)CW(w, 0) * IG_N_TMP_STRUCT + i] = 0.0;
+    if (t < C) {
+        CandMeta m;
+        const int B = cands[t];
+        m.B = B;
+        m.ctgA = cA;
+        m.ctgB = st.cid[B];
+        m.same = (m.ctgA == m.ctgB);
+        m.LA = LA;
+        m.LB = st.L[B];
+        m.SLA = st.SL[A];
+        m.SLB = st.SL[B];
+        m.n_loc = m.same ? m.LA : m.LA + m.LB;
+        m.m_loc = m.same ? m.SLA : m.SLA + m.SLB;
+        m.lA = st.pos[A];
+        m.lB = (m.same ? 0 : m.LA) + st.pos[B];
+        /* slice windows, KA:530-548 */
+        const int sa = st.spos[A], sb = st.spos[B], oa = st.ori[A], ob = st.ori[B];
+        const int sla = st.sl[A], slb = st.sl[B];
+        m.pos_fa = max(0, sa * (oa == 1) + (sa - sla) * (oa == -1));
+        m.pos_fb = max(0, sb * (ob == 1) + (sb - slb) * (ob == -1));
+        m.up_fa = max(0, m.pos_fa - g->slice_nb - sla);
+        m.down_fa = min(m.SLA - 1, m.pos_fa + g->slice_nb + sla);
+        m.up_fb = max(0, m.pos_fb - slb);
+        m.down_fb = min(m.SLB - 1, m.pos_fb + slb);
+        m.windowed = m.same && (st.circ[A] == 0);
+        /* a window that spans the whole contig keeps every pair: the slice is then the full contig */
+        if (m.windowed && ((m.up_fa == 0 && m.down_fa == m.SLA - 1) || (m.up_fb == 0 && m.down_fb == m.SLA - 1))) m.windowed = 0;
+        bounds_scalar(st, g, A, B, m.pos_up, m.pos_down, m.flags);
+        for (int i = 0; i < 12; i++) sh_flags[t][i] = m.flags[i];
+        mb.meta[CW(w, t)] = m;
+    }
+    __syncthreads();
+    if (t < C) {
+        CandMeta* m = &mb.meta[CW(w, t)];
+        int n = 0;
+        int* u = m->uniq;
+        for (int k = 0; k < NSLOT; k++) m->kidx[k] = -1;
+        if (force_slot >= 0) {
+            u[n++] = force_slot;
+        } else if (t == 0) {
+            n = build_uniq(u, true, m->LA, m->LB, (w == 0) ? g->valid_insert : nullptr);
+        } else {
+            n = build_uniq(u, false, m->LA, m->LB, sh_flags[t - 1]);
+        }
+        m->n_uniq = n;
+        m->kidx[IG_N_TMP_STRUCT] = 0; /* current genome = column 0 */
+        for (int k = 0; k < n; k++) m->kidx[u[k]] = k + 1;
+    }
+}
+
+/* k_mutate: one workgroup = one candidate genome on the local window. */
+__global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubTab* __restrict__ sub, const long long* __restrict__ rowptr,
+                                                Glob* g, MoveBuf mb, PzTab pz)
+{
+    const int slot = blockIdx.x, c = blockIdx.y, w = blockIdx.z;
+    const MoveCtl& mc = mb.ctl[w];
+    if (c >= mc.C) return;
+    const int cw = CW(w, c);
+    const CandMeta& m = mb.meta[cw];
+    const int k = m.kidx[slot];
+    if (k < 0) return;
+    const int N = mb.N, M = mb.M, n = m.n_loc;
+    int* base = mb.loc + ((size_t)(cw * NSLOT + slot) * NDYN) * N;
+    igd::Loc S;
+    S.pos = base;
+    S.spos = base + (size_t)N;
+    S.cid = base + (size_t)2 * N;
+    S.sbp = base + (size_t)3 * N;
+    S.circ = base + (size_t)4 * N;
+    S.prev = base + (size_t)5 * N;
+    S.next = base + (size_t)6 * N;
+    S.L = base + (size_t)7 * N;
+    S.SL = base + (size_t)8 * N;
+    S.LB = base + (size_t)9 * N;
+    S.ori = base + (size_t)10 * N;
+    S.gid = mb.Lloc + (size_t)cw * N;
+    S.lb = mb.lbloc + (size_t)cw * N;
+    S.sl = mb.slloc + (size_t)cw * N;
+    S.n = n;
+    for (int x = threadIdx.x; x < n; x += blockDim.x) {
+        const int f = S.gid[x];
+        S.pos[x] = st.pos[f];
+        S.spos[x] = st.spos[f];
+        S.cid[x] = st.cid[f];
+        S.sbp[x] = st.sbp[f];
+        S.circ[x] = st.circ[f];
+        S.prev[x] = st.prev[f];
+        S.next[x] = st.next[f];
+        S.L[x] = st.L[f];
+        S.SL[x] = st.SL[f];
+        S.LB[x] = st.LB[f];
+        S.ori[x] = st.ori[f];
+    }
+    __syncthreads();
+    const int A = m.lA, B = m.lB;
+    const int fresh = mc.fresh;
+    if (slot == 0) { /* CL:1672 */
+        igd::op_pop_out(S, A, fresh);
+    } else if (slot == 1) { /* CL:1680 */
+        igd::op_flip(S, A);
+    } else if (slot < 8) { /* CL:1689-1760 */
+        igd::op_pop_out(S, A, fresh);
+        const int ori = (slot & 1) ? -1 : 1;
+        if (slot < 4) igd::op_pop_in_1(S, A, B, fresh + 1, ori);
+        else if (slot < 6) igd::op_pop_in_2(S, A, B, fresh + 1, ori);
+        else igd::op_pop_in_3(S, A, B, ori);
+    } else if (slot < 12) { /* CL:1780-1841: (upA, upB) = (0,0),(0,1),(1,0),(1,1) */
+        igd::op_split(S, A, (slot - 8) >> 1, fresh);
+        igd::op_split(S, B, (slot - 8) & 1, fresh + 1);
+        igd::op_paste(S, A, B);
+    } else if (slot < IG_N_TMP_STRUCT) { /* CL:1843-1916: slot = 12 + 2 i + (j == 1 ? 0 : 1) */
+        const int i = (slot - 12) >> 1;
+        const int up = ((slot - 12) & 1) ? 0 : 1;
+        const int cutpos = up ? m.pos_up[i] : m.pos_down[i];
+        const int g_ext = cutpos >= 0 ? S.gid[cutpos] : -1;
+        igd::op_extract_block(S, A, cutpos, up, fresh);
+        igd::op_insert_block(S, A, B, g_ext, m.flags[slot - 12], up);
+    }
+    /* ---- does this slot change the genome at all, and how many contigs does the window hold afterwards */
+    __syncthreads();
+    {
+        int ch = 0, hd = 0;
+        for (int x = threadIdx.x; x < n; x += blockDim.x) {
+            const int f = S.gid[x];
+            ch |= (S.pos[x] != st.pos[f]) | (S.spos[x] != st.spos[f]) | (S.cid[x] != st.cid[f]) | (S.sbp[x] != st.sbp[f]) |
+                  (S.circ[x] != st.circ[f]) | (S.prev[x] != st.prev[f]) | (S.next[x] != st.next[f]) | (S.L[x] != st.L[f]) |
+                  (S.SL[x] != st.SL[f]) | (S.LB[x] != st.LB[f]) | (S.ori[x] != st.ori[f]);
+            hd += (S.pos[x] == 0);
+        }
+        __shared__ int sh_ch, sh_hd;
+        if (threadIdx.x == 0) {
+            sh_ch = 0;
+            sh_hd = 0;
+        }
+        __syncthreads();
+        hd = wave_sum_i(hd);
+        if ((threadIdx.x & 63) == 0 && hd) atomicAdd(&sh_hd, hd);
+        if (ch) atomicOr(&sh_ch, 1);
+        __syncthreads();
+        if (threadIdx.x == 0) mb.sinfo[cw * NSLOT + slot] = make_int2(sh_ch, sh_hd);
+    }
+    /* ---- coordinate column k (fill_vect_dist, KA:3699-3760) + zero-pixel sums on the window */
+    const ig_params p = g->par[0];
+    const float mean = g->mean_kb;
+    uint2* col = mb.coords + (size_t)(cw * NSLOT + k) * M;
+    ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
+    int* subs = mb.subs + (size_t)cw * M;
+    long long hi = 0, lo = 0, ni = 0, bound = 0;
+    for (int x = threadIdx.x; x < n; x += blockDim.x) {
+        const int f = S.gid[x];
+        const int cid = S.cid[x];
+        const int code = (cid == m.ctgA) ? 0 : ((cid == m.ctgB) ? 1 : 2 + (cid - fresh));
+        const int ori = S.ori[x], sp = S.spos[x], sl = S.sl[x], SLc = S.SL[x];
+        const float stot = (float)(int)((float)S.circ[x] * (float)S.LB[x] / 1000.0f);
+        if (S.pos[x] == 0) {
+            cm[code].stot = stot;
+            cm[code].len = SLc;
+        }
+        const float sbp_kb = (float)S.sbp[x] / 1000.0f;
+        const int sf = st.sub_first[f];
+        const int lbase = (x < m.LA) ? 0 : m.SLA;
+        for (int q = 0; q < sl; q++) {
+            const int s = sf + q;
+            const SubTab b = sub[s];
+            const float dist = sbp_kb + ((ori == 1) ? b.wat : b.cri);
+            const int npos = (ori == 1) ? sp + q : sp + sl - (q + 1);
+            const int ls = lbase + tab.cp[s].y;
+            uint2 v;
+            v.x = __float_as_uint(dist);
+            v.y = (unsigned)npos | ((unsigned)code << 28);
+            col[ls] = v;
+            if (k == 0) {
+                subs[ls] = s;
+                bound += rowptr[s + 1] - rowptr[s]; /* upper bound of this candidate's slice */
+            }
+            if (npos == 0) ni += ((long long)SLc * (long long)(SLc - 1)) / 2;
+            if (npos > 0) {
+                const long long q2 = zero_q(p, npos, SLc, stot, mean, pz.v, pz.n);
+                hi += q2 >> 32;
+                lo += (long long)(unsigned int)q2;
+            }
+        }
+    }
+    __shared__ long long red[4][4];
+    hi = wave_sum_ll(hi);
+    lo = wave_sum_ll(lo);
+    ni = wave_sum_ll(ni);
+    bound = wave_sum_ll(bound);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[0][wv] = hi;
+        red[1][wv] = lo;
+        red[2][wv] = ni;
+        red[3][wv] = bound;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long* q = mb.qpart + (size_t)cw * Q_STRIDE;
+        q[Q_Z + 2 * k] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        q[Q_Z + 2 * k + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        q[Q_NI + k] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        if (k == 0) mb.slbound[cw] = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+    }
+}
+
+/* k_offsets: where each candidate's slice list starts in the pool = exclusive prefix sum of the upper bounds
+ * (one small workgroup; a slot whose lists do not fit is flagged and re-run at the head of the next batch) */
+__global__ void __launch_bounds__(64) k_offsets(MoveBuf mb, int W, int w_begin, int w_end)
+{
+    /* one wave: lane l owns the `per` consecutive (slot, candidate) entries l*per .. ; exclusive scan across lanes */
+    const int lane = threadIdx.x;
+    const int n = W * mb.capC;
+    const int per = (n + 63) / 64;
+    long long b[(IG_MAX_BATCH * IG_MAX_CANDIDATES + 63) / 64];
+    long long sum = 0;
+#pragma unroll
+    for (int q = 0; q < (IG_MAX_BATCH * IG_MAX_CANDIDATES + 63) / 64; q++) {
+        const int i = lane * per + q;
+        long long v = 0;
+        if (q < per && i < n) {
+            const int w = i / mb.capC, c = i % mb.capC;
+            if (w >= w_begin && w < w_end && c < mb.ctl[w].C) v = mb.slbound[i];
+        }
+        b[q] = v;
+        sum += v;
+    }
+    long long incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    long long run = incl - sum;
+#pragma unroll
+    for (int q = 0; q < (IG_MAX_BATCH * IG_MAX_CANDIDATES + 63) / 64; q++) {
+        const int i = lane * per + q;
+        if (q < per && i < n) {
+            const int w = i / mb.capC, c = i % mb.capC;
+            if (w >= w_begin && w < w_end && c < mb.ctl[w].C) {
+                if (run + b[q] > mb.pool_cap) {
+                    mb.sloff[i] = -1;
+                    mb.ctl[w].overflow = 1;
+                } else {
+                    mb.sloff[i] = run;
+                }
+            }
+            run += b[q];
+        }
+    }
+}
+
+#define LDS_COL_CAP 4096  /* local sub-fragments whose column fits the 32 KB LDS stage */
+#define DELTA_RB 128
+
+/* k_slice: slice_sp_mat (KA:485-607) restricted to the CSR rows of the touched contigs (instead of a scan of
+ * all Z contacts).  One wave per row: up to SLICE_UNROLL x 64 contacts are loaded back to back (coalesced
+ * 8-byte loads, then one packed (contig, rank) gather each), the predicate is evaluated, and the kept ones
+ * are appended to the candidate's list with ONE wave-aggregated atomic per batch (ballot + popcount ranks).
+ * No sort afterwards: the reference sorted by row only to feed its shared-memory row cache (CL:1045-1050). */
+#define SLICE_RB 128
+#define SLICE_UNROLL 4
+__global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
+                                               Glob* g, MoveBuf mb, int rank, int world, int w_begin)
+{
+    const int c = blockIdx.y, w = w_begin + blockIdx.z;
+    if (c >= mb.ctl[w].C) return;
+    const int cw = CW(w, c);
+    const CandMeta& m = mb.meta[cw];
+    const int M = mb.M, m_loc = m.m_loc;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const long long off = mb.sloff[cw];
+    if (off < 0) return; /* slice pool exhausted */
+    const int* subs = mb.subs + (size_t)cw * M;
+    int* rowcnt = mb.rowcnt + (size_t)cw * M;
+    int* sli = mb.sl_li + off;
+    int* slj = mb.sl_lj + off;
+    int* slo = mb.sl_ob + off;
+    unsigned long long* cursor = (unsigned long long*)(mb.part + (size_t)cw * P_STRIDE + P_CNT);
+    const int nrw = gridDim.x * 4;
+    for (int r = blockIdx.x * 4 + wv; r < m_loc; r += nrw) {
+        const int i = subs[r];
+        const long long b = rowptr[i], e = rowptr[i + 1];
+        const bool mine = (world <= 1) || ((r % world) == rank);
+        int rc = 0;
+        if (b != e) {
+            const int2 cp1 = tab.cp[i];
+            for (long long q0 = b; q0 < e; q0 += 64 * SLICE_UNROLL) {
+                int2 v[SLICE_UNROLL], cp2[SLICE_UNROLL];
+                bool keep[SLICE_UNROLL];
+                unsigned long long mask[SLICE_UNROLL];
+#pragma unroll
+                for (int u = 0; u < SLICE_UNROLL; u++) {
+                    const long long qi = q0 + u * 64 + lane;
+                    v[u] = (qi < e) ? cc[qi] : make_int2(-1, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < SLICE_UNROLL; u++) cp2[u] = (v[u].x >= 0) ? tab.cp[v[u].x] : make_int2(-1, -1);
+                int add = 0;
+#pragma unroll
+                for (int u = 0; u < SLICE_UNROLL; u++) {
+                    keep[u] = (v[u].x >= 0) && slice_keep(m, cp1.x, cp2[u].x, cp1.y, cp2[u].y, v[u].y, false);
+                    mask[u] = __ballot(keep[u]);
+                    add += __popcll(mask[u]);
+                }
+                if (add) {
+                    rc += add;
+                    if (mine) {
+                        unsigned long long base = 0;
+                        if (lane == 0) base = atomicAdd(cursor, (unsigned long long)add);
+                        base = __shfl(base, 0, 64);
+                        int o2 = 0;
+#pragma unroll
+                        for (int u = 0; u < SLICE_UNROLL; u++) {
+                            if (keep[u]) {
+                                const long long at = (long long)base + o2 + __popcll(mask[u] & lt_mask);
+                                sli[at] = r;
+                                slj[at] = ((m.same || cp2[u].x == m.ctgA) ? 0 : m.SLA) + cp2[u].y;
+                                slo[at] = v[u].y;
+                            }
+                            o2 += __popcll(mask[u]);
+                        }
+                    }
+                }
+            }
+        }
+        if (lane == 0) rowcnt[r] = rc; /* every rank knows every row's count: the tail walk needs them */
+    }
+}
+
+#define SCORE_EB 16
+#define LDS_PZ 1024
+#define LDS_LGF 256
+
+/* general (checked) evaluation of a linear-cis / trans pair, out of line: counts >= LDS_LGF, rank distances beyond the
+ * LDS P_z table, parameters outside the one-log domain */
+__device__ __noinline__ double term_general(const ig_params p, float mean_kb, float s, int dkey, int ob, double lgf, PzTab pz)
+{
+    const ig_hot h = ig_hot_make(p, ig_tab()); /* rare path: recomputed rather than passed */
+    const int inter = dkey < 0;
+    const float ex_z = inter ? p.v_inter : pz_lookup(pz, p, mean_kb, dkey);
+    if (h.fast && ob > 0) return ig_term_hot(s, inter, ob, lgf, ex_z, &h, ig_tab());
+    const float ex = inter ? p.v_inter : ig_rippe(s, p, ig_tab());
+    return ig_pixel_term(ex, ex_z, ob, lgf, ig_tab());
+}
+
+/* q = ig_quantize(t) as (q >> 32, (uint32) q): the same integer, split without 64-bit conversions */
+__device__ __forceinline__ void quantize_split(double t, int& qh, unsigned& ql)
+{
+    t = (t != t) ? 0.0 : t;
+    t = __builtin_fmin(__builtin_fmax(t, -IG_QCLAMP), IG_QCLAMP); /* t is a number here: same as the two compares */
+    const double Q = __builtin_rint(t * IG_QSCALE);
+    const double H = __builtin_floor(Q * (1.0 / IG_QSCALE));
+    qh = (int)H;
+    ql = (unsigned)ig_fma(H, -IG_QSCALE, Q);
+}
+
+/* circular contigs (rare): the general functions, out of line */
+__device__ __noinline__ double term_circ(const ig_params p, float mean_kb, float s, float s_tot, int d, int len_j, int ob, double lgf)
+{
+    float ex, ex_z;
+    expected_circ(p, mean_kb, s, s_tot, d, len_j, &ex, &ex_z);
+    return ig_pixel_term(ex, ex_z, ob, lgf, ig_tab());
+}
+
+/* dkey: rank distance d of a linear cis pair; -1 for a trans pair; d | code << 27 | 1 << 30 for a pair on a circular contig.
+ * The hot case is the contract's ig_term_hot (one log2, one exp2) with the count's log-factorial and P_z from the LDS
+ * tables; everything else (circular contig, count >= 256, rank distance beyond the LDS table, parameters outside the
+ * one-log domain) is fixed up afterwards behind a wave-uniform branch that is almost never taken. */
+#define DKEY_CIRC 0x40000000
+__device__ __forceinline__ void term_hot(const ig_hot& h, const ig_params& p, float mean_kb, float s, int dkey, int ob,
+                                         const float* pz_s, int pzn_s, const PzTab& pz, const double* lgf_s,
+                                         const double* __restrict__ lgf_tab, const ColMeta* cm_s, const double* T, int& qh,
+                                         unsigned& ql)
+{
+    const bool inter = dkey < 0;
+    double lgf = lgf_s[min(ob, LDS_LGF - 1)];
+    float ex_z = pz_s[min(max(dkey, 0), pzn_s - 1)];
+    /* a P_z table shorter than PZ_MAX ends where s_z reaches d_max (ig_set_params): beyond it P_z is the trans level */
+    const bool past_table = (pz.n < PZ_MAX) && (dkey >= pz.n) && !(dkey & DKEY_CIRC);
+    ex_z = (inter || past_table) ? h.v_inter : ex_z;
+    double t = ig_term_hot(s, inter, ob, lgf, ex_z, &h, T);
+    const bool rare = (ob >= LDS_LGF) || (dkey >= pzn_s && !past_table) || !h.fast || (ob <= 0);
+    if (__any(rare)) {
+        if (rare) {
+            if (ob >= LDS_LGF) lgf = lgfact_dev(ob, lgf_tab);
+            if (!inter && (dkey & DKEY_CIRC)) {
+                const int code = (dkey >> 27) & 7;
+                t = term_circ(p, mean_kb, s, cm_s[code].stot, dkey & 0x07ffffff, cm_s[code].len, ob, lgf);
+            } else {
+                t = term_general(p, mean_kb, s, dkey, ob, lgf, pz);
+            }
+        }
+    }
+    quantize_split(t, qh, ql);
+}
+
+/* classification of one slice entry under one coordinate column: what its term is computed from */
+__device__ __forceinline__ void classify_pair(uint2 ai, uint2 bj, unsigned circ_mask, float& sv, int& dkey)
+{
+    const unsigned ci = ai.y >> 28, cj = bj.y >> 28;
+    const int pi = (int)(ai.y & 0x0fffffffu), pj = (int)(bj.y & 0x0fffffffu);
+    const bool cis = ci == cj;
+    sv = cis ? fabsf(__uint_as_float(ai.x) - __uint_as_float(bj.x)) : 0.0f;
+    dkey = cis ? (pi > pj ? pi - pj : pj - pi) : -1;
+    if (cis && ((circ_mask >> ci) & 1u)) dkey = (dkey & 0x07ffffff) | ((int)ci << 27) | DKEY_CIRC;
+}
+
+struct ScoreArgs {
+    const int *sli, *slj, *slo; /* the candidate's slice list (one candidate: < 2^31 entries, 32-bit offsets from a uniform base) */
+    unsigned n;
+    const uint2* gcol; /* column k in global memory */
+    const uint2* lcol; /* and its LDS copy */
+    const float* pz_s;
+    const double *lgf_s, *mt_s;
+    const ColMeta* cm_s;
+    const double* lgf_tab;
+    PzTab pz;
+    int pzn;
+    unsigned circ_mask;
+    float mean;
+    int ablate;
+};
+
+/* the streaming loop of k_score_list; STAGED: the column fits the LDS stage (ds_read), else 8-byte gathers from L2 */
+#define SCORE_BATCH 4
+template <bool STAGED>
+__device__ __forceinline__ void score_loop(const ScoreArgs& a, const ig_hot& hp, const ig_params& p, long long& hi, long long& lo)
+{
+    const unsigned stride = gridDim.x * SCORE_THREADS;
+    for (unsigned e0 = blockIdx.x * SCORE_THREADS + threadIdx.x; e0 < a.n; e0 += stride * SCORE_BATCH) {
+        int li[SCORE_BATCH], lj[SCORE_BATCH], ob[SCORE_BATCH];
+#pragma unroll
+        for (int u = 0; u < SCORE_BATCH; u++) {
+            const unsigned e = e0 + u * stride;
+            const bool ok = e < a.n;
+            li[u] = ok ? a.sli[e] : -1;
+            lj[u] = ok ? a.slj[e] : 0;
+            ob[u] = ok ? a.slo[e] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < SCORE_BATCH; u++) { /* unrolled: the batch stays in registers */
+            const bool valid = li[u] >= 0; /* lanes past the end evaluate entry 0 and drop the result */
+            if (!__any(valid)) break;      /* wave-uniform */
+            const int l_i = valid ? li[u] : 0, l_j = lj[u], o_b = valid ? ob[u] : 1;
+            const uint2 ai = STAGED ? a.lcol[l_i] : a.gcol[l_i];
+            const uint2 bj = STAGED ? a.lcol[l_j] : a.gcol[l_j];
+            float sv;
+            int dkey;
+            classify_pair(ai, bj, a.circ_mask, sv, dkey);
+            int qh;
+            unsigned ql;
+            if (a.ablate & 1) {
+                qh = (int)__float_as_uint(sv) >> 12;
+                ql = (unsigned)(dkey + o_b);
+            } else {
+                term_hot(hp, p, a.mean, sv, dkey, o_b, a.pz_s, a.pzn, a.pz, a.lgf_s, a.lgf_tab, a.cm_s, a.mt_s, qh, ql);
+            }
+            hi += valid ? qh : 0;
+            lo += (long long)(valid ? ql : 0u);
+        }
+    }
+}
+
+/* k_score_list: the hot kernel.  One workgroup = (entry block, coordinate column k, candidate cw).
+ * Staged in LDS: the column (8 B per local sub-fragment), the P_z table, the log10(ob!) table, the log2/exp2
+ * tables of the arithmetic contract and the per-contig constants.  Lanes stream the slice list (coalesced
+ * 4-byte loads, SCORE_BATCH contacts in flight), read both endpoints' coordinates from LDS, evaluate the
+ * Rippe / Poisson term (term_hot: the arithmetic contract of ig_detmath.h with the argument checks hoisted) and add
+ * it as an exact integer.  Wave shuffles, one LDS step, two atomics per workgroup. */
+#define LDS_COL_SMALL 1024
+/* two instantiations per launch site: windows of <= LDS_COL_SMALL sub-fragments (8 KB column: more workgroups per CU)
+ * and the rest (<= LDS_COL_CAP staged, larger ones gathered from L2); each workgroup serves its own class only */
+template <int CAP>
+__global__ void __launch_bounds__(SCORE_THREADS)
+    k_score_list(const Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int ablate, int max_c, int large_on,
+                 int w_begin)
+{
+    __shared__ uint2 lcol[CAP];
+    __shared__ float pz_s[LDS_PZ];
+    __shared__ double lgf_s[LDS_LGF];
+    __shared__ double mt_s[IG_TAB_SIZE];
+    __shared__ ColMeta cm_s[NCODE];
+    __shared__ long long red[2][SCORE_THREADS / 64];
+    const int w = w_begin + blockIdx.z / max_c, c = blockIdx.z % max_c;
+    if (c >= mb.ctl[w].C) return;
+    const int cw = CW(w, c);
+    const CandMeta& m = mb.meta[cw];
+    const int k = blockIdx.y;
+    if (k > m.n_uniq) return;
+    const long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT];
+    if ((long long)blockIdx.x * SCORE_THREADS >= n) return;
+    const long long off = mb.sloff[cw];
+    if (off < 0) return;
+    const int M = mb.M, m_loc = m.m_loc;
+    if (large_on && ((CAP == LDS_COL_SMALL) != (m_loc <= LDS_COL_SMALL))) return;
+    const ig_params p = g->par[0];
+    const ig_hot hp = ig_hot_make(p, ig_tab());
+    const float mean = g->mean_kb;
+    const uint2* gcol = mb.coords + (size_t)(cw * NSLOT + k) * M;
+    const bool staged = m_loc <= CAP;
+    if (staged)
+        for (int i = threadIdx.x; i < m_loc; i += SCORE_THREADS) lcol[i] = gcol[i];
+    const int pzn = min(pz.n, LDS_PZ);
+    for (int i = threadIdx.x; i < pzn; i += SCORE_THREADS) pz_s[i] = pz.v[i];
+    for (int i = threadIdx.x; i < LDS_LGF; i += SCORE_THREADS) lgf_s[i] = lgf_tab[i];
+    {
+        const double* T0 = ig_tab();
+        for (int i = threadIdx.x; i < IG_TAB_SIZE; i += SCORE_THREADS) mt_s[i] = T0[i];
+    }
+    if (threadIdx.x < NCODE) cm_s[threadIdx.x] = mb.cmeta[(size_t)(cw * NSLOT + k) * NCODE + threadIdx.x];
+    __syncthreads();
+    unsigned circ_mask = 0;
+#pragma unroll
+    for (int q = 0; q < NCODE; q++) circ_mask |= (cm_s[q].stot != 0) ? (1u << q) : 0u;
+    long long hi = 0, lo = 0;
+    const ScoreArgs sa{mb.sl_li + off, mb.sl_lj + off, mb.sl_ob + off, (unsigned)n, gcol, lcol, pz_s, lgf_s, mt_s, cm_s, lgf_tab, pz, pzn, circ_mask, mean, ablate};
+    if (staged) score_loop<true>(sa, hp, p, hi, lo);
+    else score_loop<false>(sa, hp, p, hi, lo);
+    hi = wave_sum_ll(hi);
+    lo = wave_sum_ll(lo);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][wv] = hi;
+        red[1][wv] = lo;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        hi = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        lo = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        if (hi | lo) {
+            long long* part = mb.part + (size_t)cw * P_STRIDE;
+            atomic_add_ll(&part[P_NZ + 2 * k], hi);
+            atomic_add_ll(&part[P_NZ + 2 * k + 1], lo);
+        }
+    }
+}
+
+/* k_delta: exact update of the full likelihood when the winner's slice was windowed (KA:565-586 keeps only
+ * pairs near A and B): sum over ALL pairs of the contig of (term under the winner - term under the current
+ * genome).  Row-parallel with a per-wave compaction queue; two columns (current, winner). */
+__global__ void __launch_bounds__(SCORE_THREADS)
+    k_delta(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, Tables tab_prev,
+            const int* __restrict__ prev_touched, Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int w)
+{
+    /* tab_prev catches up with the last applied move before k_apply replaces the touched list (quirk Q12) */
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < g->n_prev_touched;
+         i += gridDim.x * gridDim.y * blockDim.x) {
+        const int s = prev_touched[i];
+        tab_prev.dist[s] = tab.dist[s];
+        tab_prev.stot[s] = tab.stot[s];
+        tab_prev.cp[s] = tab.cp[s];
+        tab_prev.len[s] = tab.len[s];
+    }
+    __shared__ uint2 lcol[LDS_COL_CAP];
+    __shared__ long long red[2][SCORE_THREADS / 64];
+    __shared__ int q_li[SCORE_THREADS / 64][128], q_lj[SCORE_THREADS / 64][128], q_ob[SCORE_THREADS / 64][128];
+    MoveCtl& mc = mb.ctl[w];
+    if (!mc.ch_windowed || g->error) return;
+    const int c = mc.ch_c;
+    const int cw = CW(w, c);
+    const CandMeta& m = mb.meta[cw];
+    const int kk = blockIdx.y;
+    const int k = (kk == 0) ? 0 : mc.ch_k;
+    const int M = mb.M, m_loc = m.m_loc;
+    const ig_params p = g->par[0];
+    const ig_hot hot = ig_hot_make(p, ig_tab());
+    const float mean = g->mean_kb;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint2* gcol = mb.coords + (size_t)(cw * NSLOT + k) * M;
+    const bool staged = m_loc <= LDS_COL_CAP;
+    if (staged) {
+        for (int i = threadIdx.x; i < m_loc; i += SCORE_THREADS) lcol[i] = gcol[i];
+        __syncthreads();
+    }
+    const int* subs = mb.subs + (size_t)cw * M;
+    const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
+    int* qli = q_li[wv];
+    int* qlj = q_lj[wv];
+    int* qob = q_ob[wv];
+    long long hi = 0, lo = 0;
+    int qn = 0;
+    auto drain = [&](int n_take) {
+        if (lane < n_take) {
+            const int li = qli[lane], lj = qlj[lane], ob = qob[lane];
+            const uint2 ai = staged ? lcol[li] : gcol[li];
+            const uint2 bj = staged ? lcol[lj] : gcol[lj];
+            const long long q = eval_q(p, hot, mean, ai, bj, cm, ob, lgfact_dev(ob, lgf_tab), pz, ig_tab());
+            hi += q >> 32;
+            lo += (long long)(unsigned int)q;
+        }
+    };
+    const int nrw = gridDim.x * (SCORE_THREADS / 64);
+    for (int r = blockIdx.x * (SCORE_THREADS / 64) + wv; r < m_loc; r += nrw) {
+        const int i = subs[r];
+        const long long b = rowptr[i], e = rowptr[i + 1];
+        if (b == e) continue;
+        const int2 cp1 = tab.cp[i];
+        for (long long q0 = b; q0 < e; q0 += 64) {
+            const long long qi = q0 + lane;
+            bool keep = false;
+            int lj = 0, ob = 0;
+            if (qi < e) {
+                const int2 v = cc[qi];
+                const int2 cp2 = tab.cp[v.x];
+                keep = slice_keep(m, cp1.x, cp2.x, cp1.y, cp2.y, v.y, true);
+                lj = ((m.same || cp2.x == m.ctgA) ? 0 : m.SLA) + cp2.y;
+                ob = v.y;
+            }
+            const unsigned long long mask = __ballot(keep);
+            if (mask) {
+                if (keep) {
+                    const int at = qn + __popcll(mask & lt_mask);
+                    qli[at] = r;
+                    qlj[at] = lj;
+                    qob[at] = ob;
+                }
+                qn += __popcll(mask);
+                __builtin_amdgcn_wave_barrier();
+                if (qn >= 64) {
+                    drain(64);
+                    __builtin_amdgcn_wave_barrier();
+                    const int rem = qn - 64;
+                    int t0 = 0, t1 = 0, t2 = 0;
+                    if (lane < rem) {
+                        t0 = qli[64 + lane];
+                        t1 = qlj[64 + lane];
+                        t2 = qob[64 + lane];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < rem) {
+                        qli[lane] = t0;
+                        qlj[lane] = t1;
+                        qob[lane] = t2;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    qn = rem;
+                }
+            }
+        }
+    }
+    drain(qn);
+    hi = wave_sum_ll(hi);
+    lo = wave_sum_ll(lo);
+    if (lane == 0) {
+        red[0][wv] = hi;
+        red[1][wv] = lo;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        hi = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        lo = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        if (hi | lo) {
+            atomic_add_ll(&mc.d_hi, kk == 0 ? -hi : hi);
+            atomic_add_ll(&mc.d_lo, kk == 0 ? -lo : lo);
+        }
+    }
+}
+
+/* prefinal_tail (k_tail): one workgroup per (candidate, slot).  Computes, for
+ * every column, T[k] = sum of the terms of the LAST r = S_c mod 64 sliced contacts (canonical order = COO
+ * order, so "last" = highest rows, found by bisection on the row id).  Quirk Q5 (KA:4362, block 64 CL:200):
+ * a column at list position >= r never receives those contacts; which columns that applies to is decided
+ * when the uniq list is known (k_scores / k_commit_batch). */
+__device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, Glob* g, MoveBuf mb,
+                              const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int w_begin)
+{
+    __shared__ int t_li[64], t_lj[64], t_ob[64], t_rows[64];
+    __shared__ int sh_n_rows, sh_n_tail, sh_cnt;
+    __shared__ long long sh_red[4];
+    const int c = blockIdx.x, w = w_begin + blockIdx.y;
+    if (c >= mb.ctl[w].C) return;
+    const int cw = CW(w, c);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int M = mb.M;
+    const ig_params p = g->par[0];
+    const ig_hot hot = ig_hot_make(p, ig_tab());
+    const float mean = g->mean_kb;
+    const CandMeta& m = mb.meta[cw];
+    const long long* part = mb.part + (size_t)cw * P_STRIDE;
+    long long* qp = mb.qpart + (size_t)cw * Q_STRIDE;
+    const int* subs = mb.subs + (size_t)cw * M;
+    const int* rowcnt = mb.rowcnt + (size_t)cw * M;
+    const int ncol = m.n_uniq + 1;
+    for (int k = tid; k < ncol; k += blockDim.x) {
+        qp[Q_TAIL + 2 * k] = 0;
+        qp[Q_TAIL + 2 * k + 1] = 0;
+    }
+    __syncthreads();
+    const long long Sc = part[P_CNT];
+    const int r = (int)(Sc % 64);
+    if (!(tail_quirk && r > 0)) return;
+    int lo_t = 0, hi_t = M; /* count(lo_t) >= r, count(hi_t) < r */
+    while (hi_t - lo_t > 1) {
+        const int mid = lo_t + (hi_t - lo_t) / 2;
+        long long s = 0;
+        for (int ls = tid; ls < m.m_loc; ls += blockDim.x)
+            if (subs[ls] >= mid) s += rowcnt[ls];
+        s = wave_sum_ll(s);
+        if (lane == 0) sh_red[wv] = s;
+        __syncthreads();
+        const long long tot = sh_red[0] + sh_red[1] + sh_red[2] + sh_red[3];
+        __syncthreads();
+        if (tot >= r) lo_t = mid;
+        else hi_t = mid;
+    }
+    const int T = lo_t;
+    if (tid == 0) {
+        sh_n_rows = 0;
+        sh_n_tail = 0;
+        sh_cnt = 0;
+    }
+    __syncthreads();
+    int above = 0; /* kept contacts in rows > T */
+    for (int ls = tid; ls < m.m_loc; ls += blockDim.x) {
+        const int s = subs[ls];
+        if (s >= T && rowcnt[ls] > 0) {
+            const int slot = atomicAdd(&sh_n_rows, 1);
+            if (slot < 64) t_rows[slot] = ls;
+            if (s > T) above += rowcnt[ls];
+        }
+    }
+    above = wave_sum_i(above);
+    if (lane == 0 && above) atomicAdd(&sh_cnt, above);
+    __syncthreads();
+    const int n_rows = min(sh_n_rows, 64);
+    const int need_T = r - sh_cnt; /* contacts to take from the END of row T */
+    for (int ri = wv; ri < n_rows; ri += 4) {
+        const int ls = t_rows[ri];
+        const int i = subs[ls];
+        const int2 cp1 = tab.cp[i];
+        const long long b = rowptr[i], e = rowptr[i + 1];
+        int remaining = (i == T) ? need_T : 0x7fffffff;
+        for (long long end = e; end > b && remaining > 0; end -= 64) {
+            const long long q0 = end - 1 - lane;
+            bool keep = false;
+            int2 v = make_int2(0, 0);
+            int lj = 0;
+            if (q0 >= b) {
+                v = cc[q0];
+                const int2 cp2 = tab.cp[v.x];
+                keep = slice_keep(m, cp1.x, cp2.x, cp1.y, cp2.y, v.y, false);
+                lj = ((m.same || cp2.x == m.ctgA) ? 0 : m.SLA) + cp2.y;
+            }
+            const unsigned long long mask = __ballot(keep);
+            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+            const int took = min((int)__popcll(mask), remaining);
+            int basei = 0;
+            if (lane == 0 && took) basei = atomicAdd(&sh_n_tail, took);
+            basei = __shfl(basei, 0, 64);
+            if (keep && rank < remaining && basei + rank < 64) {
+                t_li[basei + rank] = ls;
+                t_lj[basei + rank] = lj;
+                t_ob[basei + rank] = v.y;
+            }
+            remaining -= took;
+        }
+    }
+    __syncthreads();
+    const int n_tail = min(sh_n_tail, 64);
+    if (tid == 0 && n_tail != r) g->error = 5; /* the walk must find exactly r contacts */
+    for (int k = 1 + wv; k < ncol; k += 4) {
+        const uint2* col = mb.coords + (size_t)(cw * NSLOT + k) * M;
+        const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
+        long long hi = 0, lo = 0;
+        if (lane < n_tail) {
+            const long long q = eval_q(p, hot, mean, col[t_li[lane]], col[t_lj[lane]], cm, t_ob[lane], lgfact_dev(t_ob[lane], lgf_tab), pz,
+                                       ig_tab());
+            hi = q >> 32;
+            lo = (long long)(unsigned int)q;
+        }
+        hi = wave_sum_ll(hi);
+        lo = wave_sum_ll(lo);
+        if (lane == 0) {
+            qp[Q_TAIL + 2 * k] = hi;
+            qp[Q_TAIL + 2 * k + 1] = lo;
+        }
+    }
+}
+
+/* k_tail: needs the slice only (list length, per-row counts), not the column sums: it runs on a second stream next to
+ * k_score_list */
+__global__ void __launch_bounds__(256) k_tail(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, Glob* g,
+                                              MoveBuf mb, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int w_begin)
+{
+    prefinal_tail(rowptr, cc, tab, g, mb, lgf_tab, tail_quirk, pz, w_begin);
+}
+
+/* k_records: after k_score_list and k_tail: the slot-major records of the commit step */
+__global__ void __launch_bounds__(64) k_records(MoveBuf mb, int w_begin)
+{
+    const int c = blockIdx.x, w = w_begin + blockIdx.y;
+    if (c >= mb.ctl[w].C) return;
+    const int cw = CW(w, c);
+    const CandMeta& m = mb.meta[cw];
+    long long* qp = mb.qpart + (size_t)cw * Q_STRIDE;
+    const int t = threadIdx.x;
+    {
+        const long long* part = mb.part + (size_t)cw * P_STRIDE;
+        if (t <= m.n_uniq) {
+            qp[Q_NZFULL + 2 * t] = part[P_NZ + 2 * t];
+            qp[Q_NZFULL + 2 * t + 1] = part[P_NZ + 2 * t + 1];
+        }
+    }
+    __syncthreads();
+    if (t < IG_N_TMP_STRUCT) {
+        SlotPre r;
+        const int k = m.kidx[t];
+        r.k = k > 0 ? k : 0;
+        r.nz_hi = r.nz_lo = r.tail_hi = r.tail_lo = r.dz_hi = r.dz_lo = r.dni = 0;
+        r.changed = r.heads = r.pad = 0;
+        if (k > 0) {
+            r.nz_hi = qp[Q_NZFULL + 2 * k];
+            r.nz_lo = qp[Q_NZFULL + 2 * k + 1];
+            r.tail_hi = qp[Q_TAIL + 2 * k];
+            r.tail_lo = qp[Q_TAIL + 2 * k + 1];
+            r.dz_hi = qp[Q_Z + 2 * k] - qp[Q_Z];
+            r.dz_lo = qp[Q_Z + 2 * k + 1] - qp[Q_Z + 1];
+            r.dni = qp[Q_NI + k] - qp[Q_NI];
+            const int2 si = mb.sinfo[cw * NSLOT + t];
+            r.changed = si.x;
+            r.heads = si.y;
+        }
+        mb.pre[(size_t)cw * IG_N_TMP_STRUCT + t] = r;
+    }
+    if (t == 0) {
+        CandPre cp;
+        cp.ext_hi = qp[Q_NZFULL];
+        cp.ext_lo = qp[Q_NZFULL + 1];
+        cp.n_slice = mb.part[(size_t)cw * P_STRIDE + P_CNT];
+        cp.r = (int)(cp.n_slice % 64);
+        int nb = 0;
+        for (int q = 0; q < m.n_uniq; q++) nb += (m.uniq[q] < 12);
+        cp.base_cnt = nb;
+        cp.n_uniq_basic = nb;
+        cp.pad = mb.ctl[w].overflow; /* travels with the records: the slot must be re-run */
+        mb.cpre[cw] = cp;
+    }
+}

@@ -15,8 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB_PATH = os.path.join(HERE, "libinstagraal_hip.so")
 SRC = os.path.join(HERE, "csrc", "ig_hip.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "ig_ops.cuh"), os.path.join(ROOT, "include", "ig_detmath.h"),
-        os.path.join(ROOT, "include", "instagraal_hip.h")]
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("ig_ops.cuh", "ig_common.cuh", "ig_model.cuh", "ig_kernels_setup.cuh",
+                                                          "ig_kernels_score.cuh", "ig_kernels_commit.cuh")] + \
+       [os.path.join(ROOT, "include", f) for f in ("ig_detmath.h", "ig_detmath_tables.h", "instagraal_hip.h")]
 
 N_TMP_STRUCT = 24
 MAX_CANDIDATES = 16
