@@ -133,8 +133,11 @@ struct MoveBuf {
     int* sl_li;     /* slice pool: candidate cw's list starts at slice_offset(w, c): local row index, */
     int* sl_lj;     /*           local column index, */
     int* sl_ob;     /*           observed count (order = arrival, sums are order-free) */
-    long long* slbound; /* [..] upper bound of the list length = contacts in the rows of the touched contigs */
-    long long* sloff;   /* [..] start of the list in the pool, -1 = does not fit (k_offsets) */
+    /* a candidate's slice list is kept in SLICE_SEG segments (local row r -> segment r % SLICE_SEG): one append cursor
+     * per segment instead of one per candidate (same-address atomics were k_slice's bottleneck), and workgroup x of
+     * k_score_list streams exactly segment x */
+    long long* slbound; /* [..][SLICE_SEG] upper bound of a segment = contacts in its rows */
+    long long* sloff;   /* [..][SLICE_SEG] start of the segment in the pool, -1 = does not fit (k_offsets) */
     long long pool_cap;
     uint2* coords;  /* [..][NSLOT][M] column k: {dist bits, pos | code<<28} per local sub index */
     int* loc;       /* [..][NSLOT][NDYN][N] candidate genomes on the local window */
@@ -151,8 +154,9 @@ struct MoveBuf {
 };
 /* layout of MoveBuf.part per candidate (int64 units) */
 #define P_NZ 0                 /* [NSLOT][2] slice sums per column k (k=0: current = "extract") */
-#define P_CNT (NSLOT * 2)      /* [1] kept entries S_c */
-#define P_STRIDE (NSLOT * 2 + 2)
+#define SLICE_SEG 16
+#define P_CNT (NSLOT * 2)      /* [SLICE_SEG] kept entries per segment; S_c = their sum (slice_total) */
+#define P_STRIDE (NSLOT * 2 + SLICE_SEG)
 /* not all-reduced (computed redundantly on every rank) */
 #define Q_Z 0                  /* [NSLOT][2] zero-pixel sums on the local window, per column k */
 #define Q_NI (NSLOT * 2)       /* [NSLOT] intra pair counts */

@@ -20,8 +20,7 @@
  *   k_commit_batch  1 workgroup     winners applied together, exact genome-distance deltas, result records
  * plus the one-move kernels k_scores / k_delta / k_apply / k_post / k_commit (single moves, windowed winners).
  *
- * Environment knobs (tuning and tests only): IG_BATCH_W (moves per batch, default 24), IG_SCORE_EB (entry blocks per
- * column), IG_LARGE (force the 32 KB-column variant on/off), IG_POOL_ENTRIES (slice pool size), IG_ABLATE (skip the
+ * Environment knobs (tuning and tests only): IG_BATCH_W (moves per batch, default 24), IG_LARGE (force the 32 KB-column variant on/off), IG_POOL_ENTRIES (slice pool size), IG_ABLATE (skip the
  * term arithmetic: timing floor).
  */
 #include "ig_common.cuh"
@@ -281,8 +280,8 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
         DALLOC(m.sl_ob, Zc);
         m.pool_cap = (long long)Zc;
     }
-    DALLOC(m.slbound, C);
-    DALLOC(m.sloff, C);
+    DALLOC(m.slbound, C * SLICE_SEG);
+    DALLOC(m.sloff, C * SLICE_SEG);
     DALLOC(m.coords, C * M * NSLOT);
     DALLOC(m.loc, C * NSLOT * NDYN * N);
     DALLOC(m.meta, C);
@@ -301,7 +300,7 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
     DALLOC(c->batch_out, 4);
     DALLOC(c->dirty_buf, 2 * IG_MAX_BATCH + 4);
     HIPCK(hipMemset(m.cmeta, 0, C * NSLOT * NCODE * sizeof(ColMeta)));
-    HIPCK(hipMemset(m.slbound, 0, C * sizeof(long long)));
+    HIPCK(hipMemset(m.slbound, 0, C * SLICE_SEG * sizeof(long long)));
     HIPCK(hipMemset(m.ctl, 0, (size_t)capW * sizeof(MoveCtl)));
     HIPCK(hipMemset(c->stamp, 0, N * sizeof(int)));
     m.N = c->N;
@@ -719,7 +718,8 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
         if (force_slot < 0 && nW > 0) {
             {
                 TimedLaunch t(c, T_SLICE);
-                hipLaunchKernelGGL(k_offsets, dim3(1), dim3(64), 0, c->stream, c->mb, W, w_begin, w_end);
+                hipLaunchKernelGGL(k_offsets, dim3(1), dim3(OFFSETS_THREADS), 0, c->stream, c->mb, W, w_begin, w_end);
+                hipLaunchKernelGGL(k_offsets_seal, dim3(nW), dim3(128), 0, c->stream, c->mb, W, w_begin, w_end);
                 hipLaunchKernelGGL(k_slice, dim3(SLICE_RB, max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb,
                                    c->rank, c->world, w_begin);
             }
@@ -731,7 +731,7 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                 hipEventRecord(c->ev_tail, c->stream2);
             }
             TimedLaunch t(c, T_SCORE);
-            static int s_eb = getenv("IG_SCORE_EB") ? atoi(getenv("IG_SCORE_EB")) : SCORE_EB;
+            const int s_eb = SLICE_SEG; /* one workgroup per (segment, column, candidate) */
             static int s_abl = getenv("IG_ABLATE") ? atoi(getenv("IG_ABLATE")) : 0;
             /* the large-window variant is launched only when the previous batch saw windows above LDS_COL_SMALL
              * sub-fragments; without it the small variant serves every window (unstaged above its cap) */
@@ -1211,7 +1211,7 @@ extern "C" int ig_debug_last_sums(ig_ctx* c, int64_t* nz_hi, int64_t* nz_lo, int
         const long long* p = &part[(size_t)cc_ * P_STRIDE];
         const long long* q = &qp[(size_t)cc_ * Q_STRIDE];
         n_uniq[cc_] = meta[cc_].n_uniq;
-        n_slice[cc_] = p[P_CNT];
+        n_slice[cc_] = slice_total(p);
         int64_t eh = p[P_NZ], el = p[P_NZ + 1];
         ig_acc_normalize(&eh, &el);
         ext_hi[cc_] = eh;
@@ -1226,7 +1226,7 @@ extern "C" int ig_debug_last_sums(ig_ctx* c, int64_t* nz_hi, int64_t* nz_lo, int
             const int o = cc_ * IG_N_TMP_STRUCT + s;
             uniq[cc_ * IG_N_TMP_STRUCT + (k - 1)] = s;
             int64_t h = q[Q_NZFULL + 2 * k], l = q[Q_NZFULL + 2 * k + 1];
-            const int r = (int)(p[P_CNT] % 64);
+            const int r = (int)(slice_total(p) % 64);
             if (r > 0 && (k - 1) >= r) { /* quirk Q5 */
                 h -= q[Q_TAIL + 2 * k];
                 l -= q[Q_TAIL + 2 * k + 1];

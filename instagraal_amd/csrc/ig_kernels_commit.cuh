@@ -37,7 +37,7 @@ __device__ void score_and_choose(Glob* g, const MoveBuf& mb, int w, const int* v
         }
         const long long* part = mb.part + (size_t)cw * P_STRIDE;
         const long long* qp = mb.qpart + (size_t)cw * Q_STRIDE;
-        const int r = (int)(part[P_CNT] % 64);
+        const int r = (int)(slice_total(part) % 64);
         long long nh = qp[Q_NZFULL + 2 * k], nl = qp[Q_NZFULL + 2 * k + 1];
         if (r > 0 && pos >= r) { /* quirk Q5 */
             nh -= qp[Q_TAIL + 2 * k];
@@ -92,7 +92,7 @@ __device__ void score_and_choose(Glob* g, const MoveBuf& mb, int w, const int* v
             long long tot_slice = 0, tot_eval = 0, bytes = 0;
             for (int c = 0; c < C; c++) {
                 const CandMeta& m = mb.meta[CW(w, c)];
-                const long long Sc = mb.part[(size_t)CW(w, c) * P_STRIDE + P_CNT];
+                const long long Sc = slice_total(mb.part + (size_t)CW(w, c) * P_STRIDE);
                 tot_slice += Sc;
                 int nu = m.n_uniq;
                 if (c == 0 && mc.superset0) /* the list the reference would have scored */

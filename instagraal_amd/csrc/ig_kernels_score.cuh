@@ -258,7 +258,10 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
     uint2* col = mb.coords + (size_t)(cw * NSLOT + k) * M;
     ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
     int* subs = mb.subs + (size_t)cw * M;
-    long long hi = 0, lo = 0, ni = 0, bound = 0;
+    long long hi = 0, lo = 0, ni = 0;
+    __shared__ long long seg_bound[SLICE_SEG];
+    if (threadIdx.x < SLICE_SEG) seg_bound[threadIdx.x] = 0;
+    __syncthreads();
     for (int x = threadIdx.x; x < n; x += blockDim.x) {
         const int f = S.gid[x];
         const int cid = S.cid[x];
@@ -284,7 +287,8 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
             col[ls] = v;
             if (k == 0) {
                 subs[ls] = s;
-                bound += rowptr[s + 1] - rowptr[s]; /* upper bound of this candidate's slice */
+                /* upper bound of the slice segment this row appends to */
+                atomicAdd((unsigned long long*)&seg_bound[ls % SLICE_SEG], (unsigned long long)(rowptr[s + 1] - rowptr[s]));
             }
             if (npos == 0) ni += ((long long)SLc * (long long)(SLc - 1)) / 2;
             if (npos > 0) {
@@ -298,13 +302,11 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
     hi = wave_sum_ll(hi);
     lo = wave_sum_ll(lo);
     ni = wave_sum_ll(ni);
-    bound = wave_sum_ll(bound);
     const int wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
         red[0][wv] = hi;
         red[1][wv] = lo;
         red[2][wv] = ni;
-        red[3][wv] = bound;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -312,53 +314,67 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
         q[Q_Z + 2 * k] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
         q[Q_Z + 2 * k + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
         q[Q_NI + k] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
-        if (k == 0) mb.slbound[cw] = red[3][0] + red[3][1] + red[3][2] + red[3][3];
     }
+    if (k == 0 && threadIdx.x < SLICE_SEG) mb.slbound[(size_t)cw * SLICE_SEG + threadIdx.x] = seg_bound[threadIdx.x];
 }
 
 /* k_offsets: where each candidate's slice list starts in the pool = exclusive prefix sum of the upper bounds
  * (one small workgroup; a slot whose lists do not fit is flagged and re-run at the head of the next batch) */
-__global__ void __launch_bounds__(64) k_offsets(MoveBuf mb, int W, int w_begin, int w_end)
+#define OFFSETS_THREADS 1024
+__global__ void __launch_bounds__(OFFSETS_THREADS) k_offsets(MoveBuf mb, int W, int w_begin, int w_end)
 {
-    /* one wave: lane l owns the `per` consecutive (slot, candidate) entries l*per .. ; exclusive scan across lanes */
-    const int lane = threadIdx.x;
-    const int n = W * mb.capC;
-    const int per = (n + 63) / 64;
-    long long b[(IG_MAX_BATCH * IG_MAX_CANDIDATES + 63) / 64];
+    /* entries = (slot, candidate, segment) in this order; thread t owns `per` consecutive entries; exclusive scan of the
+     * per-thread sums across the workgroup (wave scans + one LDS step) */
+    __shared__ long long wave_tot[OFFSETS_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = W * mb.capC * SLICE_SEG;
+    const int per = (n + OFFSETS_THREADS - 1) / OFFSETS_THREADS;
+    auto bound_of = [&](int i) -> long long {
+        const int cw = i / SLICE_SEG;
+        const int w = cw / mb.capC, c = cw % mb.capC;
+        return (w >= w_begin && w < w_end && c < mb.ctl[w].C) ? mb.slbound[i] : -1; /* -1: not an entry of this launch */
+    };
     long long sum = 0;
-#pragma unroll
-    for (int q = 0; q < (IG_MAX_BATCH * IG_MAX_CANDIDATES + 63) / 64; q++) {
-        const int i = lane * per + q;
-        long long v = 0;
-        if (q < per && i < n) {
-            const int w = i / mb.capC, c = i % mb.capC;
-            if (w >= w_begin && w < w_end && c < mb.ctl[w].C) v = mb.slbound[i];
+    for (int q = 0; q < per; q++) {
+        const int i = tid * per + q;
+        if (i < n) {
+            const long long b = bound_of(i);
+            sum += b > 0 ? b : 0;
         }
-        b[q] = v;
-        sum += v;
     }
     long long incl = sum;
     for (int off = 1; off < 64; off <<= 1) {
         const long long o = __shfl_up(incl, off, 64);
         if (lane >= off) incl += o;
     }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
     long long run = incl - sum;
-#pragma unroll
-    for (int q = 0; q < (IG_MAX_BATCH * IG_MAX_CANDIDATES + 63) / 64; q++) {
-        const int i = lane * per + q;
-        if (q < per && i < n) {
-            const int w = i / mb.capC, c = i % mb.capC;
-            if (w >= w_begin && w < w_end && c < mb.ctl[w].C) {
-                if (run + b[q] > mb.pool_cap) {
+    for (int q = 0; q < wv; q++) run += wave_tot[q];
+    for (int q = 0; q < per; q++) {
+        const int i = tid * per + q;
+        if (i < n) {
+            const long long b = bound_of(i);
+            if (b >= 0) {
+                if (run + b > mb.pool_cap) {
                     mb.sloff[i] = -1;
-                    mb.ctl[w].overflow = 1;
+                    mb.ctl[i / SLICE_SEG / mb.capC].overflow = 1;
                 } else {
                     mb.sloff[i] = run;
                 }
+                run += b;
             }
-            run += b[q];
         }
     }
+}
+
+/* a slot with a segment that does not fit is dropped as a whole: its first segment's offset is what k_slice and the
+ * scoring kernels test */
+__global__ void k_offsets_seal(MoveBuf mb, int W, int w_begin, int w_end)
+{
+    const int w = w_begin + blockIdx.x;
+    if (w >= w_end || !mb.ctl[w].overflow) return;
+    for (int i = threadIdx.x; i < mb.capC * SLICE_SEG; i += blockDim.x) mb.sloff[(size_t)w * mb.capC * SLICE_SEG + i] = -1;
 }
 
 #define LDS_COL_CAP 4096  /* local sub-fragments whose column fits the 32 KB LDS stage */
@@ -381,16 +397,19 @@ __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ row
     const int M = mb.M, m_loc = m.m_loc;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const long long off = mb.sloff[cw];
-    if (off < 0) return; /* slice pool exhausted */
+    __shared__ long long seg_off[SLICE_SEG];
+    if (threadIdx.x < SLICE_SEG) seg_off[threadIdx.x] = mb.sloff[(size_t)cw * SLICE_SEG + threadIdx.x];
+    __syncthreads();
+    if (seg_off[0] < 0) return; /* slice pool exhausted (k_offsets flags all segments of a slot together) */
     const int* subs = mb.subs + (size_t)cw * M;
     int* rowcnt = mb.rowcnt + (size_t)cw * M;
-    int* sli = mb.sl_li + off;
-    int* slj = mb.sl_lj + off;
-    int* slo = mb.sl_ob + off;
-    unsigned long long* cursor = (unsigned long long*)(mb.part + (size_t)cw * P_STRIDE + P_CNT);
     const int nrw = gridDim.x * 4;
     for (int r = blockIdx.x * 4 + wv; r < m_loc; r += nrw) {
+        const long long off = seg_off[r % SLICE_SEG];
+        int* sli = mb.sl_li + off;
+        int* slj = mb.sl_lj + off;
+        int* slo = mb.sl_ob + off;
+        unsigned long long* cursor = (unsigned long long*)(mb.part + (size_t)cw * P_STRIDE + P_CNT + r % SLICE_SEG);
         const int i = subs[r];
         const long long b = rowptr[i], e = rowptr[i + 1];
         const bool mine = (world <= 1) || ((r % world) == rank);
@@ -539,8 +558,8 @@ struct ScoreArgs {
 template <bool STAGED>
 __device__ __forceinline__ void score_loop(const ScoreArgs& a, const ig_hot& hp, const ig_params& p, long long& hi, long long& lo)
 {
-    const unsigned stride = gridDim.x * SCORE_THREADS;
-    for (unsigned e0 = blockIdx.x * SCORE_THREADS + threadIdx.x; e0 < a.n; e0 += stride * SCORE_BATCH) {
+    const unsigned stride = SCORE_THREADS; /* the workgroup owns its segment */
+    for (unsigned e0 = threadIdx.x; e0 < a.n; e0 += stride * SCORE_BATCH) {
         int li[SCORE_BATCH], lj[SCORE_BATCH], ob[SCORE_BATCH];
 #pragma unroll
         for (int u = 0; u < SCORE_BATCH; u++) {
@@ -600,9 +619,9 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     const CandMeta& m = mb.meta[cw];
     const int k = blockIdx.y;
     if (k > m.n_uniq) return;
-    const long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT];
-    if ((long long)blockIdx.x * SCORE_THREADS >= n) return;
-    const long long off = mb.sloff[cw];
+    const long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + blockIdx.x]; /* workgroup x streams segment x */
+    if (n == 0) return;
+    const long long off = mb.sloff[(size_t)cw * SLICE_SEG + blockIdx.x];
     if (off < 0) return;
     const int M = mb.M, m_loc = m.m_loc;
     if (large_on && ((CAP == LDS_COL_SMALL) != (m_loc <= LDS_COL_SMALL))) return;
@@ -800,7 +819,7 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
         qp[Q_TAIL + 2 * k + 1] = 0;
     }
     __syncthreads();
-    const long long Sc = part[P_CNT];
+    const long long Sc = slice_total(part);
     const int r = (int)(Sc % 64);
     if (!(tail_quirk && r > 0)) return;
     int lo_t = 0, hi_t = M; /* count(lo_t) >= r, count(hi_t) < r */
@@ -940,7 +959,7 @@ __global__ void __launch_bounds__(64) k_records(MoveBuf mb, int w_begin)
         CandPre cp;
         cp.ext_hi = qp[Q_NZFULL];
         cp.ext_lo = qp[Q_NZFULL + 1];
-        cp.n_slice = mb.part[(size_t)cw * P_STRIDE + P_CNT];
+        cp.n_slice = slice_total(mb.part + (size_t)cw * P_STRIDE);
         cp.r = (int)(cp.n_slice % 64);
         int nb = 0;
         for (int q = 0; q < m.n_uniq; q++) nb += (m.uniq[q] < 12);

@@ -182,3 +182,11 @@ __device__ __forceinline__ bool slice_keep(const CandMeta& m, int c1, int c2, in
     if (m.same) return c2 == m.ctgB; /* ctgA == ctgB */
     return (c2 == m.ctgA) || (c2 == m.ctgB);
 }
+
+/* S_c: kept contacts of a candidate's slice = sum of its segment cursors */
+__host__ __device__ inline long long slice_total(const long long* part)
+{
+    long long n = 0;
+    for (int s = 0; s < SLICE_SEG; s++) n += part[P_CNT + s];
+    return n;
+}
