@@ -133,6 +133,9 @@ struct MoveBuf {
     int* sl_li;     /* slice pool: candidate cw's list starts at slice_offset(w, c): local row index, */
     int* sl_lj;     /*           local column index, */
     int* sl_ob;     /*           observed count (order = arrival, sums are order-free) */
+    unsigned long long* sl_pk; /* packed form used instead when M < 2^20 and every count < 2^24 (8 instead of 12 bytes per
+                                * entry: k_slice is bound by writing the lists): row | column << 20 | count << 40 */
+    int packed;
     /* a candidate's slice list is kept in SLICE_SEG segments (local row r -> segment r % SLICE_SEG): one append cursor
      * per segment instead of one per candidate (same-address atomics were k_slice's bottleneck), and workgroup x of
      * k_score_list streams exactly segment x */
@@ -172,6 +175,7 @@ struct ig_ctx {
     hipEvent_t ev_slice, ev_tail;
     int N, M;
     long long Z;
+    int max_count; /* largest contact count (packed slice entries need it below 2^24) */
     int rank, world;
     State st;
     int* st_block; /* one allocation for all state arrays */

@@ -106,6 +106,7 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->world = 1;
     c->N = c->M = 0;
     c->Z = 0;
+    c->max_count = 0;
     c->st_block = nullptr;
     c->sub_tab = nullptr;
     c->rowptr = nullptr;
@@ -176,6 +177,7 @@ static void free_move_buffers(ig_ctx* c)
     hipFree(m.sl_li);
     hipFree(m.sl_lj);
     hipFree(m.sl_ob);
+    hipFree(m.sl_pk);
     hipFree(m.coords);
     hipFree(m.loc);
     hipFree(m.meta);
@@ -257,7 +259,10 @@ extern "C" int ig_set_stream(ig_ctx* c, void* s)
 
 static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
 {
-    if (c->mb.capC >= capC && c->mb.capW >= capW && c->mb.N == c->N && c->mb.M == c->M) return 0;
+    const int want_packed = (!(getenv("IG_WIDE_LISTS") && atoi(getenv("IG_WIDE_LISTS"))) && c->M < (1 << 20) && c->max_count < (1 << 24)) ? 1 : 0;
+    if (c->mb.capC >= capC && c->mb.capW >= capW && c->mb.N == c->N && c->mb.M == c->M && c->mb.packed == want_packed &&
+        c->mb.pool_cap >= (long long)std::max<long long>(c->Z, 1) * std::max(capC, 1))
+        return 0;
     if (c->N == 0 || c->M == 0) return 0;
     capC = std::max(capC, c->mb.capC);
     capW = std::max(capW, c->mb.capW);
@@ -275,9 +280,14 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
         size_t Zc = (size_t)std::max<long long>(c->Z, 1) * (size_t)std::max(capC, capW > 1 ? 16 : 1);
         if (const char* e = getenv("IG_POOL_ENTRIES")) /* tests: a small pool forces the overflow / re-run path */
             Zc = std::max<size_t>((size_t)atoll(e), (size_t)std::max<long long>(c->Z, 1) * (size_t)capC);
-        DALLOC(m.sl_li, Zc);
-        DALLOC(m.sl_lj, Zc);
-        DALLOC(m.sl_ob, Zc);
+        m.packed = want_packed; /* IG_WIDE_LISTS=1 (tests) forces the 12-byte form */
+        if (m.packed) {
+            DALLOC(m.sl_pk, Zc);
+        } else {
+            DALLOC(m.sl_li, Zc);
+            DALLOC(m.sl_lj, Zc);
+            DALLOC(m.sl_ob, Zc);
+        }
         m.pool_cap = (long long)Zc;
     }
     DALLOC(m.slbound, C * SLICE_SEG);
@@ -319,7 +329,9 @@ extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* 
     if (c->M && c->M != M) return fail("ig_upload_contacts: M=%d does not match the sub-fragment table (%d)", M, c->M);
     std::vector<long long> rp((size_t)M + 1, 0);
     std::vector<int2> cc((size_t)Z);
+    int max_count = 0;
     for (int64_t k = 0; k < Z; k++) {
+        max_count = std::max(max_count, (int)cnt[k]);
         const int r = row[k], q = col[k];
         if (r < 0 || r >= M || q <= r || q >= M) return fail("ig_upload_contacts: entry %lld (%d,%d) is not strict upper triangle", (long long)k, r, q);
         if (k > 0 && (row[k - 1] > r || (row[k - 1] == r && col[k - 1] >= q)))
@@ -336,6 +348,7 @@ extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* 
     if (Z) HIPCK(hipMemcpy(c->cc, cc.data(), (size_t)Z * sizeof(int2), hipMemcpyHostToDevice));
     c->Z = Z;
     c->M = M;
+    c->max_count = max_count;
     c->rank = rank;
     c->world = world;
     c->have_contacts = true;
@@ -720,8 +733,12 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                 TimedLaunch t(c, T_SLICE);
                 hipLaunchKernelGGL(k_offsets, dim3(1), dim3(OFFSETS_THREADS), 0, c->stream, c->mb, W, w_begin, w_end);
                 hipLaunchKernelGGL(k_offsets_seal, dim3(nW), dim3(128), 0, c->stream, c->mb, W, w_begin, w_end);
-                hipLaunchKernelGGL(k_slice, dim3(SLICE_RB, max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb,
-                                   c->rank, c->world, w_begin);
+                if (c->mb.packed)
+                    hipLaunchKernelGGL(k_slice<true>, dim3(SLICE_RB, max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob,
+                                       c->mb, c->rank, c->world, w_begin);
+                else
+                    hipLaunchKernelGGL(k_slice<false>, dim3(SLICE_RB, max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob,
+                                       c->mb, c->rank, c->world, w_begin);
             }
             if (phase == 2) { /* the Q5 tail walk only needs the slice: second stream, next to k_score_list */
                 hipEventRecord(c->ev_slice, c->stream);

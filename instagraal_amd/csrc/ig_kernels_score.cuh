@@ -387,6 +387,7 @@ __global__ void k_offsets_seal(MoveBuf mb, int W, int w_begin, int w_end)
  * No sort afterwards: the reference sorted by row only to feed its shared-memory row cache (CL:1045-1050). */
 #define SLICE_RB 128
 #define SLICE_UNROLL 4
+template <bool PACKED>
 __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
                                                Glob* g, MoveBuf mb, int rank, int world, int w_begin)
 {
@@ -406,9 +407,10 @@ __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ row
     const int nrw = gridDim.x * 4;
     for (int r = blockIdx.x * 4 + wv; r < m_loc; r += nrw) {
         const long long off = seg_off[r % SLICE_SEG];
-        int* sli = mb.sl_li + off;
-        int* slj = mb.sl_lj + off;
-        int* slo = mb.sl_ob + off;
+        int* sli = PACKED ? nullptr : mb.sl_li + off;
+        int* slj = PACKED ? nullptr : mb.sl_lj + off;
+        int* slo = PACKED ? nullptr : mb.sl_ob + off;
+        unsigned long long* slp = PACKED ? mb.sl_pk + off : nullptr;
         unsigned long long* cursor = (unsigned long long*)(mb.part + (size_t)cw * P_STRIDE + P_CNT + r % SLICE_SEG);
         const int i = subs[r];
         const long long b = rowptr[i], e = rowptr[i + 1];
@@ -445,9 +447,14 @@ __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ row
                         for (int u = 0; u < SLICE_UNROLL; u++) {
                             if (keep[u]) {
                                 const long long at = (long long)base + o2 + __popcll(mask[u] & lt_mask);
-                                sli[at] = r;
-                                slj[at] = ((m.same || cp2[u].x == m.ctgA) ? 0 : m.SLA) + cp2[u].y;
-                                slo[at] = v[u].y;
+                                const int lj = ((m.same || cp2[u].x == m.ctgA) ? 0 : m.SLA) + cp2[u].y;
+                                if (PACKED) {
+                                    slp[at] = (unsigned long long)r | ((unsigned long long)lj << 20) | ((unsigned long long)v[u].y << 40);
+                                } else {
+                                    sli[at] = r;
+                                    slj[at] = lj;
+                                    slo[at] = v[u].y;
+                                }
                             }
                             o2 += __popcll(mask[u]);
                         }
@@ -538,7 +545,8 @@ __device__ __forceinline__ void classify_pair(uint2 ai, uint2 bj, unsigned circ_
 }
 
 struct ScoreArgs {
-    const int *sli, *slj, *slo; /* the candidate's slice list (one candidate: < 2^31 entries, 32-bit offsets from a uniform base) */
+    const int *sli, *slj, *slo; /* the segment of the slice list (< 2^31 entries, 32-bit offsets from a uniform base) */
+    const unsigned long long* slp; /* or its packed form */
     unsigned n;
     const uint2* gcol; /* column k in global memory */
     const uint2* lcol; /* and its LDS copy */
@@ -555,7 +563,7 @@ struct ScoreArgs {
 
 /* the streaming loop of k_score_list; STAGED: the column fits the LDS stage (ds_read), else 8-byte gathers from L2 */
 #define SCORE_BATCH 4
-template <bool STAGED>
+template <bool STAGED, bool PACKED>
 __device__ __forceinline__ void score_loop(const ScoreArgs& a, const ig_hot& hp, const ig_params& p, long long& hi, long long& lo)
 {
     const unsigned stride = SCORE_THREADS; /* the workgroup owns its segment */
@@ -565,9 +573,16 @@ __device__ __forceinline__ void score_loop(const ScoreArgs& a, const ig_hot& hp,
         for (int u = 0; u < SCORE_BATCH; u++) {
             const unsigned e = e0 + u * stride;
             const bool ok = e < a.n;
-            li[u] = ok ? a.sli[e] : -1;
-            lj[u] = ok ? a.slj[e] : 0;
-            ob[u] = ok ? a.slo[e] : 0;
+            if (PACKED) {
+                const unsigned long long pk = ok ? a.slp[e] : ~0ull;
+                li[u] = ok ? (int)(pk & 0xfffffu) : -1;
+                lj[u] = (int)((pk >> 20) & 0xfffffu);
+                ob[u] = ok ? (int)(pk >> 40) : 0;
+            } else {
+                li[u] = ok ? a.sli[e] : -1;
+                lj[u] = ok ? a.slj[e] : 0;
+                ob[u] = ok ? a.slo[e] : 0;
+            }
         }
 #pragma unroll
         for (int u = 0; u < SCORE_BATCH; u++) { /* unrolled: the batch stays in registers */
@@ -645,9 +660,15 @@ __global__ void __launch_bounds__(SCORE_THREADS)
 #pragma unroll
     for (int q = 0; q < NCODE; q++) circ_mask |= (cm_s[q].stot != 0) ? (1u << q) : 0u;
     long long hi = 0, lo = 0;
-    const ScoreArgs sa{mb.sl_li + off, mb.sl_lj + off, mb.sl_ob + off, (unsigned)n, gcol, lcol, pz_s, lgf_s, mt_s, cm_s, lgf_tab, pz, pzn, circ_mask, mean, ablate};
-    if (staged) score_loop<true>(sa, hp, p, hi, lo);
-    else score_loop<false>(sa, hp, p, hi, lo);
+    const ScoreArgs sa{mb.packed ? nullptr : mb.sl_li + off, mb.packed ? nullptr : mb.sl_lj + off, mb.packed ? nullptr : mb.sl_ob + off,
+                       mb.packed ? mb.sl_pk + off : nullptr, (unsigned)n, gcol, lcol, pz_s, lgf_s, mt_s, cm_s, lgf_tab, pz, pzn, circ_mask, mean, ablate};
+    if (mb.packed) {
+        if (staged) score_loop<true, true>(sa, hp, p, hi, lo);
+        else score_loop<false, true>(sa, hp, p, hi, lo);
+    } else {
+        if (staged) score_loop<true, false>(sa, hp, p, hi, lo);
+        else score_loop<false, false>(sa, hp, p, hi, lo);
+    }
     hi = wave_sum_ll(hi);
     lo = wave_sum_ll(lo);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;

@@ -191,6 +191,26 @@ def test_slice_pool_overflow_reruns_the_slot(monkeypatch):
     assert outs[1][2] > outs[0][2]  # the small pool really cut batches short
 
 
+def test_wide_slice_entries_equal_packed(monkeypatch):
+    """slice entries are packed in 8 bytes when M < 2^20 and the counts are below 2^24, else kept as three ints: same results"""
+    from instagraal_amd import synth
+    from instagraal_amd.sampler import sampler as hip_sampler
+
+    prob = synth.make_problem(*synth.CONFIGS["small"])
+    np.random.seed(6)
+    frags = np.resize(np.random.permutation(prob.n_frags), 150).astype(np.int32)
+    outs = []
+    for wide in ("0", "1"):
+        monkeypatch.setenv("IG_WIDE_LISTS", wide)
+        s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
+        s.set_param_simu(prob.params)
+        s.eval_likelihood_init()
+        np.random.seed(8)
+        cands = s.draw_candidates(frags, 5)
+        outs.append((s.ctx.step_batch(frags, cands).tobytes(), s.gpu_vect_frags.copy_from_gpu().soa17()))
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_headline_size_properties():
     """BASELINE.json's headline shape (50 k bins / 50 M contacts), where the oracle is far too slow to follow: the
     size-independent properties of the path.  (1) the incrementally maintained exact likelihood limbs equal a from-scratch
