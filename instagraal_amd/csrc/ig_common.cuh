@@ -201,8 +201,10 @@ struct ig_ctx {
     int cands_cap;
     int* prev_touched;
     unsigned timing_mask;
-    float* pz_tab;
+    float* pz_tab;  /* P_z table of parameter set 0 (the model in use) */
     int pz_n;
+    float* pz_tab1; /* and of set 1 (the nuisance step's test parameters) */
+    int pz_n1;
     /* timers */
     bool timing;
     struct Timer {

@@ -122,8 +122,8 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->d_frags = c->d_cands = nullptr;
     c->cands_cap = 0;
     c->prev_touched = nullptr;
-    c->pz_tab = nullptr;
-    c->pz_n = 0;
+    c->pz_tab = c->pz_tab1 = nullptr;
+    c->pz_n = c->pz_n1 = 0;
     c->timing_mask = 0xffff;
     c->timing = false;
     c->n_batches = c->n_batch_committed = c->n_batch_pending = 0;
@@ -231,6 +231,7 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipFree(c->d_cands);
     hipFree(c->prev_touched);
     hipFree(c->pz_tab);
+    hipFree(c->pz_tab1);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -484,7 +485,7 @@ static int launch_recompute(ig_ctx* c)
                        c->black, c->glob, N);
     if (c->have_params && c->have_contacts) {
         hipLaunchKernelGGL(k_full_nz, dim3(1024), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, 0, c->lgf_tab, M, 0, 1,
-                           scratch);
+                           scratch, PzTab{c->pz_tab, c->pz_n});
         hipLaunchKernelGGL(k_full_zero, dim3(256), dim3(256), 0, c->stream, c->tab, c->glob, 0, M, scratch + 2);
     }
     long long h[8];
@@ -516,14 +517,17 @@ extern "C" int ig_set_params(ig_ctx* c, const float p[8], float mean_subfrag_kb,
     ig_params hp = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]};
     HIPCK(hipMemcpy(&c->glob->par[which], &hp, sizeof hp, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(&c->glob->mean_kb, &mean_subfrag_kb, sizeof(float), hipMemcpyHostToDevice));
+    {
+        /* P_z table of this parameter set; length: first rank distance whose s_z reaches d_max (+1), capped */
+        float*& tab = which == 0 ? c->pz_tab : c->pz_tab1;
+        int& n = which == 0 ? c->pz_n : c->pz_n1;
+        if (!tab) DALLOC(tab, PZ_MAX);
+        double need = (mean_subfrag_kb > 0) ? (double)p[5] / (double)mean_subfrag_kb + 2.0 : 0.0;
+        n = (need > 0 && need < (double)PZ_MAX) ? (int)need : ((need >= (double)PZ_MAX) ? PZ_MAX : 0);
+        if (n > 0) hipLaunchKernelGGL(k_build_pz, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->glob, tab, n, which);
+    }
     if (which == 0) {
         c->have_params = true;
-        if (!c->pz_tab) DALLOC(c->pz_tab, PZ_MAX);
-        /* table length: first rank distance whose s_z reaches d_max (+1), capped */
-        double need = (mean_subfrag_kb > 0) ? (double)p[5] / (double)mean_subfrag_kb + 2.0 : 0.0;
-        c->pz_n = (need > 0 && need < (double)PZ_MAX) ? (int)need : ((need >= (double)PZ_MAX) ? PZ_MAX : 0);
-        if (c->pz_n > 0)
-            hipLaunchKernelGGL(k_build_pz, dim3((c->pz_n + 255) / 256), dim3(256), 0, c->stream, c->glob, c->pz_tab, c->pz_n);
         return launch_recompute(c); /* the maintained exact sums depend on param_simu */
     }
     return 0;
@@ -655,8 +659,10 @@ extern "C" int ig_full_likelihood(ig_ctx* c, int which, int use_prev, double* nz
     DALLOC(scratch, 8);
     HIPCK(hipMemsetAsync(scratch, 0, 8 * sizeof(long long), c->stream));
     Tables& t = use_prev ? c->tab_prev : c->tab;
+    /* which == 1 before any ig_set_params(.., 1): no table yet, every P_z is evaluated directly */
+    const PzTab pz = which == 0 ? PzTab{c->pz_tab, c->pz_n} : PzTab{c->pz_tab1, c->pz_tab1 ? c->pz_n1 : 0};
     hipLaunchKernelGGL(k_full_nz, dim3(1024), dim3(256), 0, c->stream, c->rowptr, c->cc, t, c->glob, which, c->lgf_tab, c->M, 0, 1,
-                       scratch);
+                       scratch, pz);
     hipLaunchKernelGGL(k_full_zero, dim3(256), dim3(256), 0, c->stream, t, c->glob, which, c->M, scratch + 2);
     long long h[8];
     HIPCK(hipMemcpyAsync(h, scratch, sizeof h, hipMemcpyDeviceToHost, c->stream));

@@ -90,11 +90,11 @@ __device__ __forceinline__ long long eval_q(const ig_params& p, const ig_hot& h,
     return ig_quantize(ig_pixel_term(ex, ex_z, ob, lgf, T));
 }
 
-__global__ void k_build_pz(const Glob* g, float* pz, int n)
+__global__ void k_build_pz(const Glob* g, float* pz, int n, int which)
 {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n) return;
-    const ig_params p = g->par[0];
+    const ig_params p = g->par[which];
     const float s_z = (float)d * g->mean_kb;
     pz[d] = (s_z < p.d_max) ? ig_rippe(s_z, p, ig_tab()) : p.v_inter;
 }
