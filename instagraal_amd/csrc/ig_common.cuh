@@ -189,6 +189,7 @@ struct ig_ctx {
     unsigned char* black;
     double* lgf_tab;
     Glob* glob;
+    long long* scratch8; /* 8 x int64 reduction scratch of the from-scratch passes */
     MoveBuf mb;
     int* stamp;     /* [N] claim stamps of the incremental genome distance */
     int* batch_out; /* [4] committed moves, pending slot, windows above LDS_COL_SMALL, candidates */

@@ -140,6 +140,7 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     HIPCK(hipEventCreateWithFlags(&c->ev_slice, hipEventDisableTiming));
     HIPCK(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
     DALLOC(c->glob, 1);
+    DALLOC(c->scratch8, 8);
     HIPCK(hipMemset(c->glob, 0, sizeof(Glob)));
     DALLOC(c->lgf_tab, LGF_TAB);
     /* log10(ob!) table (KA:111-124, 251-270): the 15 float-factorial constants on the host, the rest on the device */
@@ -231,6 +232,7 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipFree(c->d_cands);
     hipFree(c->prev_touched);
     hipFree(c->pz_tab);
+    hipFree(c->scratch8);
     hipFree(c->pz_tab1);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -475,8 +477,7 @@ static int launch_recompute(ig_ctx* c)
     const int N = c->N, M = c->M;
     hipLaunchKernelGGL(k_fill_tables, dim3((M + 255) / 256), dim3(256), 0, c->stream, c->st, c->sub_tab, c->tab, M);
     HIPCK(hipMemcpyAsync(c->tab_prev.dist, c->tab.dist, (6 * (size_t)M + 2) * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
-    long long* scratch;
-    DALLOC(scratch, 8);
+    long long* scratch = c->scratch8; /* persistent: an allocation per call costs more than the small kernels */
     HIPCK(hipMemsetAsync(scratch, 0, 8 * sizeof(long long), c->stream));
     int* heads = (int*)(scratch + 6);
     hipLaunchKernelGGL(k_count_heads, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->st, N, heads);
@@ -491,7 +492,6 @@ static int launch_recompute(ig_ctx* c)
     long long h[8];
     HIPCK(hipMemcpyAsync(h, scratch, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
-    hipFree(scratch);
     Glob hg;
     HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));
     ig_acc_normalize((int64_t*)&h[0], (int64_t*)&h[1]);
@@ -655,8 +655,7 @@ extern "C" int ig_full_likelihood(ig_ctx* c, int which, int use_prev, double* nz
     HIPCK(hipSetDevice(c->device));
     if (!c->have_contacts || !c->have_state || !c->have_params) return fail("ig_full_likelihood: contacts, state and parameters are required");
     if (which != 0 && which != 1) return fail("ig_full_likelihood: which must be 0 or 1");
-    long long* scratch;
-    DALLOC(scratch, 8);
+    long long* scratch = c->scratch8; /* persistent: an allocation per call costs more than the small kernels */
     HIPCK(hipMemsetAsync(scratch, 0, 8 * sizeof(long long), c->stream));
     Tables& t = use_prev ? c->tab_prev : c->tab;
     /* which == 1 before any ig_set_params(.., 1): no table yet, every P_z is evaluated directly */
@@ -667,7 +666,6 @@ extern "C" int ig_full_likelihood(ig_ctx* c, int which, int use_prev, double* nz
     long long h[8];
     HIPCK(hipMemcpyAsync(h, scratch, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
-    hipFree(scratch);
     Glob hg;
     HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));
     ig_acc_normalize((int64_t*)&h[0], (int64_t*)&h[1]);
