@@ -97,13 +97,13 @@ int ig_step_batch(ig_ctx* ctx, int32_t n_moves, const int32_t* frags, const int3
                   ig_move_result* results);
 /* The same in steps, for a caller that splits the slots of a batch over several GPUs (one process per GPU, every rank
  * holds the full problem): upload the lists once; per batch every rank builds all W candidate-genome sets but slices and
- * scores only slots [slot_begin, slot_end); the slot-major score records (ig_batch_records: two device buffers, a fixed
+ * scores only slots [slot_begin, slot_end); the slot-major score records (ig_batch_records: one device buffer, a fixed
  * number of bytes per slot) are all-gathered by the caller; then every rank commits the batch -- identical integer
  * inputs, identical decisions, no further communication.  W <= max_w <= 64. */
 int ig_batch_max_width(ig_ctx* ctx, int32_t max_c); /* largest W whose work buffers fit (<= 64; ~0.84 GB per slot at 50 k bins) */
 int ig_batch_upload(ig_ctx* ctx, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c, int32_t max_w);
 int ig_batch_score(ig_ctx* ctx, int32_t move0, int32_t W, int32_t slot_begin, int32_t slot_end); /* asynchronous */
-int ig_batch_records(ig_ctx* ctx, void** pre, int64_t* pre_bytes_per_slot, void** cpre, int64_t* cpre_bytes_per_slot);
+int ig_batch_records(ig_ctx* ctx, void** records, int64_t* bytes_per_slot); /* slot w: records + w * bytes_per_slot */
 int ig_batch_commit(ig_ctx* ctx, int32_t move0, int32_t W, int32_t* n_committed); /* moves move0 .. move0+n_committed-1 are done */
 int ig_batch_results(ig_ctx* ctx, int32_t n_moves, ig_move_result* results);
 int ig_set_batch_width(int w);                        /* W in 1..64 (default 24, env IG_BATCH_W); 1 = no speculation */

@@ -151,8 +151,10 @@ struct MoveBuf {
     double* scores; /* [..][24] */
     MoveCtl* ctl;   /* [capW] */
     int2* sinfo;    /* [..][NSLOT] (changed, contig heads) of each candidate genome (k_mutate) */
-    SlotPre* pre;   /* [..][24] */
-    CandPre* cpre;  /* [..] */
+    /* the score records of one slot are contiguous -- capC x 24 SlotPre, then capC CandPre -- so that the records of a range
+     * of slots are ONE block of memory (one all-gather per batch when the slots are split over GPUs): pre_at / cpre_at */
+    char* rec;
+    size_t rec_stride; /* bytes per slot */
     int N, M, capC, capW;
 };
 /* layout of MoveBuf.part per candidate (int64 units) */
@@ -219,3 +221,15 @@ struct ig_ctx {
     int up_moves, up_max_c; /* the uploaded move lists */
     bool have_contacts, have_sub, have_state, have_init, have_params;
 };
+
+__host__ __device__ inline size_t rec_bytes_per_slot(int capC) { return (size_t)capC * (IG_N_TMP_STRUCT * sizeof(SlotPre) + sizeof(CandPre)); }
+__device__ __forceinline__ SlotPre& pre_at(const MoveBuf& mb, int cw, int slot)
+{
+    const int w = cw / mb.capC, c = cw % mb.capC;
+    return ((SlotPre*)(mb.rec + (size_t)w * mb.rec_stride))[c * IG_N_TMP_STRUCT + slot];
+}
+__device__ __forceinline__ CandPre& cpre_at(const MoveBuf& mb, int cw)
+{
+    const int w = cw / mb.capC, c = cw % mb.capC;
+    return ((CandPre*)(mb.rec + (size_t)w * mb.rec_stride + (size_t)mb.capC * IG_N_TMP_STRUCT * sizeof(SlotPre)))[c];
+}

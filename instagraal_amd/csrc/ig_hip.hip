@@ -190,8 +190,7 @@ static void free_move_buffers(ig_ctx* c)
     hipFree(m.qpart);
     hipFree(m.ctl);
     hipFree(m.sinfo);
-    hipFree(m.pre);
-    hipFree(m.cpre);
+    hipFree(m.rec);
     hipFree(c->own_tag);
     hipFree(c->own_idx);
     c->own_tag = c->own_idx = nullptr;
@@ -304,8 +303,8 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
     DALLOC(m.scores, C * IG_N_TMP_STRUCT);
     DALLOC(m.ctl, (size_t)capW);
     DALLOC(m.sinfo, C * NSLOT);
-    DALLOC(m.pre, C * IG_N_TMP_STRUCT);
-    DALLOC(m.cpre, C);
+    m.rec_stride = rec_bytes_per_slot(capC);
+    DALLOC(m.rec, m.rec_stride * (size_t)capW);
     DALLOC(c->own_tag, N);
     DALLOC(c->own_idx, N);
     HIPCK(hipMemset(c->own_tag, 0xff, N * sizeof(int)));
@@ -976,13 +975,11 @@ extern "C" int ig_batch_score(ig_ctx* c, int32_t move0, int32_t W, int32_t slot_
     return 0;
 }
 
-extern "C" int ig_batch_records(ig_ctx* c, void** pre, int64_t* pre_bytes_per_slot, void** cpre, int64_t* cpre_bytes_per_slot)
+extern "C" int ig_batch_records(ig_ctx* c, void** records, int64_t* bytes_per_slot)
 {
-    if (!c->mb.pre) return fail("ig_batch_records: no batch buffers yet (ig_batch_upload first)");
-    *pre = c->mb.pre;
-    *pre_bytes_per_slot = (int64_t)c->mb.capC * IG_N_TMP_STRUCT * (int64_t)sizeof(SlotPre);
-    *cpre = c->mb.cpre;
-    *cpre_bytes_per_slot = (int64_t)c->mb.capC * (int64_t)sizeof(CandPre);
+    if (!c->mb.rec) return fail("ig_batch_records: no batch buffers yet (ig_batch_upload first)");
+    *records = c->mb.rec;
+    *bytes_per_slot = (int64_t)c->mb.rec_stride;
     return 0;
 }
 

@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(64)
                 d.B = m.B;
                 d.n_loc = m.n_loc;
                 d.n_uniq = m.n_uniq;
-                const CandPre& cp = mb.cpre[CW(w, lane)];
+                const CandPre& cp = cpre_at(mb, CW(w, lane));
                 d.c_ext_hi = cp.ext_hi;
                 d.c_ext_lo = cp.ext_lo;
                 d.c_n_slice = cp.n_slice;
@@ -384,8 +384,8 @@ __global__ void __launch_bounds__(64)
                 d.e_r[j] = d.e_base[j] = 0;
                 if (i < d.C * IG_N_TMP_STRUCT) {
                     const int cw = CW(w, i / IG_N_TMP_STRUCT);
-                    d.rec[j] = mb.pre[(size_t)cw * IG_N_TMP_STRUCT + i % IG_N_TMP_STRUCT];
-                    const CandPre& cp = mb.cpre[cw];
+                    d.rec[j] = pre_at(mb, cw, i % IG_N_TMP_STRUCT);
+                    const CandPre& cp = cpre_at(mb, cw);
                     d.e_ext_hi[j] = cp.ext_hi;
                     d.e_ext_lo[j] = cp.ext_lo;
                     d.e_r[j] = cp.r;
@@ -437,8 +437,8 @@ __global__ void __launch_bounds__(64)
                         cbase = d.e_base[j];
                     } else {
                         const int cw = CW(w, i / IG_N_TMP_STRUCT);
-                        r = mb.pre[(size_t)cw * IG_N_TMP_STRUCT + i % IG_N_TMP_STRUCT];
-                        const CandPre cp = mb.cpre[cw];
+                        r = pre_at(mb, cw, i % IG_N_TMP_STRUCT);
+                        const CandPre cp = cpre_at(mb, cw);
                         ext_hi = cp.ext_hi;
                         ext_lo = cp.ext_lo;
                         cr = cp.r;
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(64)
                 br.heads = rl(mine.heads, owner);
                 bests = rld((bj == 0) ? sc[0] : sc[1], owner);
             } else {
-                br = mb.pre[(size_t)CW(w, bc) * IG_N_TMP_STRUCT + bslot];
+                br = pre_at(mb, CW(w, bc), bslot);
                 double sv = 0.0;
 #pragma unroll
                 for (int j = 2; j < NJ; j++) sv = (bj == j) ? sc[j] : sv;
@@ -736,7 +736,7 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
         long long Sc = 0, ev = 0, by = 0;
         for (int c = 0; c < mc.C; c++) {
             const CandMeta& m = mb.meta[CW(w, c)];
-            const CandPre& cp = mb.cpre[CW(w, c)];
+            const CandPre& cp = cpre_at(mb, CW(w, c));
             int nu = m.n_uniq;
             if (c == 0 && mc.superset0) nu = cp.base_cnt + __popc(vmask); /* the list the reference would have scored */
             Sc += cp.n_slice;

@@ -974,7 +974,7 @@ __global__ void __launch_bounds__(64) k_records(MoveBuf mb, int w_begin)
             r.changed = si.x;
             r.heads = si.y;
         }
-        mb.pre[(size_t)cw * IG_N_TMP_STRUCT + t] = r;
+        pre_at(mb, cw, t) = r;
     }
     if (t == 0) {
         CandPre cp;
@@ -987,6 +987,6 @@ __global__ void __launch_bounds__(64) k_records(MoveBuf mb, int w_begin)
         cp.base_cnt = nb;
         cp.n_uniq_basic = nb;
         cp.pad = mb.ctl[w].overflow; /* travels with the records: the slot must be re-run */
-        mb.cpre[cw] = cp;
+        cpre_at(mb, cw) = cp;
     }
 }

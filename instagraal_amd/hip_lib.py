@@ -209,11 +209,11 @@ class Context:
         _ck(lib().ig_batch_score(self._h, C.c_int32(int(move0)), C.c_int32(int(w)), C.c_int32(int(slot_begin)), C.c_int32(int(slot_end))))
 
     def batch_records(self):
-        """-> ((device pointer, bytes per slot) of the per-slot records, the same for the per-candidate records)"""
-        p1, p2 = C.c_void_p(), C.c_void_p()
-        b1, b2 = C.c_int64(), C.c_int64()
-        _ck(lib().ig_batch_records(self._h, C.byref(p1), C.byref(b1), C.byref(p2), C.byref(b2)))
-        return (p1.value, b1.value), (p2.value, b2.value)
+        """-> (device pointer, bytes per slot) of the slot-major score records: slot w lives at pointer + w * bytes"""
+        p1 = C.c_void_p()
+        b1 = C.c_int64()
+        _ck(lib().ig_batch_records(self._h, C.byref(p1), C.byref(b1)))
+        return p1.value, b1.value
 
     def batch_commit(self, move0, w):
         n = C.c_int32()

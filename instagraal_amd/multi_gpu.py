@@ -5,7 +5,7 @@ Two ways to split, both bit-identical to the one-GPU chain for any N:
 ``BatchRunner`` (used by bench.py): the candidate draws of consecutive moves do not depend on the genome, so W moves
 are scored against one state ("speculative batch") and committed in order.  Every rank holds the full problem; rank r
 slices and scores the slots [r * W/N, (r+1) * W/N) of each batch, the slot-major score records (exact int64 sums,
-~15 KB per slot) are all-gathered once per batch, and every rank runs the same commit step on identical inputs.
+~16 KB per slot, one block of memory) are all-gathered once per batch, and every rank runs the same commit step on identical inputs.
 
 ``ShardedRunner`` (one move at a time, contact rows split):
 
@@ -103,29 +103,27 @@ class BatchRunner:
 
     def _buffers(self, cap_slots):
         if self._bufs is None:
-            (p1, b1), (p2, b2) = self.ctx.batch_records()
+            ptr, nbytes = self.ctx.batch_records()
             if self._tensor_factory is not None:
-                t1 = self._tensor_factory("pre", b1 * cap_slots)
-                t2 = self._tensor_factory("cpre", b2 * cap_slots)
+                t = self._tensor_factory("records", nbytes * cap_slots)
             else:
                 import torch
 
-                t1 = torch.as_tensor(_DevBytes(p1, b1 * cap_slots), device="cuda")
-                t2 = torch.as_tensor(_DevBytes(p2, b2 * cap_slots), device="cuda")
-            self._bufs = ((t1, b1), (t2, b2))
+                t = torch.as_tensor(_DevBytes(ptr, nbytes * cap_slots), device="cuda")
+            self._bufs = (t, nbytes)
         return self._bufs
 
     def _exchange(self, per):
-        """all-gather the records: rank r produced slots [r * per, (r + 1) * per)"""
-        for t, b in self._bufs:
-            chunk = per * b
-            out = t[: self.world * chunk]
-            mine = out[self.rank * chunk:(self.rank + 1) * chunk].clone()
-            try:
-                self.dist.all_gather_into_tensor(out, mine)
-            except (RuntimeError, AttributeError, NotImplementedError):
-                parts = [out[r * chunk:(r + 1) * chunk] for r in range(self.world)]
-                self.dist.all_gather(parts, mine)
+        """ONE all-gather of the records per batch: rank r produced slots [r * per, (r + 1) * per)"""
+        t, b = self._bufs
+        chunk = per * b
+        out = t[: self.world * chunk]
+        mine = out[self.rank * chunk:(self.rank + 1) * chunk].clone()
+        try:
+            self.dist.all_gather_into_tensor(out, mine)
+        except (RuntimeError, AttributeError, NotImplementedError):
+            parts = [out[r * chunk:(r + 1) * chunk] for r in range(self.world)]
+            self.dist.all_gather(parts, mine)
 
     def run(self, frags, cands):
         frags = np.ascontiguousarray(frags, np.int32)

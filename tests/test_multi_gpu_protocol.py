@@ -88,7 +88,7 @@ class FakeBatchCtx:
     """Mimics the batch-step API (ig_batch_*): the score records of slot w of the batch starting at move0 are a
     deterministic byte pattern; the commit step checks that it sees the records of EVERY slot, whoever produced them."""
 
-    PRE_B, CPRE_B = 96, 16
+    REC_B = 112
 
     def __init__(self):
         self.t = {}
@@ -101,7 +101,7 @@ class FakeBatchCtx:
         return self.t[kind]
 
     def batch_records(self):
-        return (0, self.PRE_B), (0, self.CPRE_B)
+        return 0, self.REC_B
 
     def batch_upload(self, frags, cands, max_w):
         self.frags, self.max_w = np.asarray(frags), max_w
@@ -113,13 +113,13 @@ class FakeBatchCtx:
     def batch_score(self, move0, w, b, e):
         import torch
 
-        for kind, nb, salt in (("pre", self.PRE_B, 1), ("cpre", self.CPRE_B, 2)):
+        for kind, nb, salt in (("records", self.REC_B, 1),):
             self.t[kind].zero_()
             for slot in range(b, e):
                 self.t[kind][slot * nb:(slot + 1) * nb] = torch.from_numpy(self.pattern(self.frags[move0 + slot], nb, salt))
 
     def batch_commit(self, move0, w):
-        for kind, nb, salt in (("pre", self.PRE_B, 1), ("cpre", self.CPRE_B, 2)):
+        for kind, nb, salt in (("records", self.REC_B, 1),):
             got = self.t[kind].numpy()
             for slot in range(w):
                 assert np.array_equal(got[slot * nb:(slot + 1) * nb], self.pattern(self.frags[move0 + slot], nb, salt)), (kind, move0, slot)
