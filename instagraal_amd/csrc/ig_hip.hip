@@ -129,6 +129,7 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->n_batches = c->n_batch_committed = c->n_batch_pending = 0;
     c->large_seen = 1;
     c->up_moves = c->up_max_c = 0;
+    c->own_begin = c->own_end = 0;
     for (int i = 0; i < T_COUNT; i++) {
         c->timers[i].name = kTimerNames[i];
         c->timers[i].total_ms = 0;
@@ -728,8 +729,13 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
         }
         {
             TimedLaunch t(c, T_MUTATE);
-            hipLaunchKernelGGL(k_mutate, dim3(NSLOT, max_c, W), dim3(256), 0, c->stream, c->st, c->tab, c->sub_tab, c->rowptr, c->glob,
-                               c->mb, pz);
+            /* slots split over GPUs: only the own slots' candidate genomes are built here; k_mutate_winners rebuilds what the
+             * commit step applies from the other ranks' slots */
+            c->own_begin = w_begin;
+            c->own_end = w_end;
+            if (nW > 0)
+                hipLaunchKernelGGL(k_mutate, dim3(NSLOT, max_c, nW), dim3(256), 0, c->stream, c->st, c->tab, c->sub_tab, c->rowptr,
+                                   c->glob, c->mb, pz, w_begin);
         }
         if (force_slot < 0 && nW > 0) {
             {
@@ -837,6 +843,9 @@ static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
             TimedLaunch t(c, T_COMMIT);
             hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(64), 0, c->stream, c->glob, c->mb, c->d_results, done, w_now, next,
                                c->dirty_buf, c->batch_out);
+            if (c->own_begin > 0 || c->own_end < w_now)
+                hipLaunchKernelGGL(k_mutate_winners, dim3(2, w_now), dim3(256), 0, c->stream, c->st, c->tab, c->sub_tab, c->rowptr,
+                                   c->glob, c->mb, PzTab{c->pz_tab, c->pz_n}, next, c->own_begin, c->own_end, c->batch_out);
             hipLaunchKernelGGL(k_commit_batch, dim3(1), dim3(COMMIT_THREADS), 0, c->stream, c->st, c->tab, c->tab_prev, c->glob,
                                c->mb, c->init_prev, c->init_next, c->orientable, c->black, c->stamp, c->own_tag, c->own_idx,
                                c->prev_touched, c->d_results, done, w_now, next, c->batch_out);

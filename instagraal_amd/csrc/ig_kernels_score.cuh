@@ -161,11 +161,11 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-/* k_mutate: one workgroup = one candidate genome on the local window. */
-__global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubTab* __restrict__ sub, const long long* __restrict__ rowptr,
-                                                Glob* g, MoveBuf mb, PzTab pz)
+/* one workgroup = one candidate genome (slot `slot` of candidate c of move slot w) on the local window */
+__device__ __forceinline__ void mutate_one(const State& st, const Tables& tab, const SubTab* __restrict__ sub,
+                                           const long long* __restrict__ rowptr, Glob* g, const MoveBuf& mb, const PzTab& pz, int slot,
+                                           int c, int w)
 {
-    const int slot = blockIdx.x, c = blockIdx.y, w = blockIdx.z;
     const MoveCtl& mc = mb.ctl[w];
     if (c >= mc.C) return;
     const int cw = CW(w, c);
@@ -316,6 +316,29 @@ __global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubT
         q[Q_NI + k] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
     }
     if (k == 0 && threadIdx.x < SLICE_SEG) mb.slbound[(size_t)cw * SLICE_SEG + threadIdx.x] = seg_bound[threadIdx.x];
+}
+
+/* k_mutate: the 25 genomes of every candidate of the move slots [w_begin, w_begin + gridDim.z) */
+__global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubTab* __restrict__ sub, const long long* __restrict__ rowptr,
+                                                Glob* g, MoveBuf mb, PzTab pz, int w_begin)
+{
+    mutate_one(st, tab, sub, rowptr, g, mb, pz, blockIdx.x, blockIdx.y, w_begin + blockIdx.z);
+}
+
+/* k_mutate_winners (slots split over GPUs): a rank builds the candidate genomes of its own slots only; once the batch is
+ * decided it rebuilds, for the slots of the OTHER ranks that the commit step is about to apply (and for a pending one),
+ * just what that step reads -- the current genome (column 0: local row -> sub-fragment map) and the winner. */
+__global__ void __launch_bounds__(256) k_mutate_winners(State st, Tables tab, const SubTab* __restrict__ sub,
+                                                        const long long* __restrict__ rowptr, Glob* g, MoveBuf mb, PzTab pz, int w_start,
+                                                        int own_begin, int own_end, const int* __restrict__ batch_out)
+{
+    const int w = blockIdx.y;
+    const int committed = batch_out[0], pending = batch_out[1];
+    if (w >= own_begin && w < own_end) return; /* built before scoring */
+    if (!((w >= w_start && w < committed) || w == pending)) return;
+    const MoveCtl& mc = mb.ctl[w];
+    if (blockIdx.x == 1 && mc.ch_slot == IG_N_TMP_STRUCT) return;
+    mutate_one(st, tab, sub, rowptr, g, mb, pz, blockIdx.x == 0 ? IG_N_TMP_STRUCT : mc.ch_slot, mc.ch_c, w);
 }
 
 /* k_offsets: where each candidate's slice list starts in the pool = exclusive prefix sum of the upper bounds
