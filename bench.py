@@ -164,8 +164,8 @@ def main():
         # algorithmic bytes of one launch of the dominant kernel = sum of the per-move B_min of the moves it scored
         # (committed moves only: a slot that had to be re-scored is work, not algorithmic traffic)
         n_launch = max(int(n_launch), 1)
-        bytes_min = float(res["bytes_min"].sum()) / n_launch
-        n_evals = float(res["n_evals"].sum()) / n_launch
+        bytes_min = float(res["bytes_min"].sum()) / n_launch / world  # N > 1: a rank scores 1/N of the slots of a launch
+        n_evals = float(res["n_evals"].sum()) / n_launch / world
         achieved = bytes_min / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
         # WRITE_SIZE, separate passes; profiles/*_pmc_traffic.json): a committed measurement of THIS workload, or null
