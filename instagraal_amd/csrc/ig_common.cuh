@@ -105,22 +105,27 @@ struct MoveCtl {
     long long d_hi, d_lo; /* k_delta accumulator */
 };
 
-/* what the commit step needs about one (candidate, mutation slot), written slot-major by k_records */
+/* what the decide step needs about one (candidate, mutation slot), written slot-major by k_records: 64 bytes (the decide
+ * wave is bound by the loads and instructions per move, so everything that does not depend on the live scalars is
+ * prepared here and nothing else is stored) */
 struct SlotPre {
-    long long nz_hi, nz_lo;     /* slice sum under this slot's genome (all sliced contacts) */
-    long long tail_hi, tail_lo; /* the part quirk Q5 drops when the slot's list position is >= S_c mod 64 */
+    long long nz_hi, nz_lo;      /* slice sum under this slot's genome (all sliced contacts) */
+    double nz_d, nz_cut_d;       /* ig_acc_to_double of it, whole and without the tail quirk Q5 drops (list position >= S_c mod 64) */
     long long dz_hi, dz_lo, dni; /* zero-pixel sum and intra pair count: this genome minus the current one, on the window */
-    int k;                      /* coordinate column (0 = not scored) */
-    int changed;                /* the mutated window differs from the current genome */
-    int heads;                  /* contigs on the mutated window */
-    int pad;
+    int k;                       /* coordinate column (0 = not scored) */
+    unsigned info;               /* bit 0: the mutated window differs from the current genome; bits 1..: contigs on the mutated window */
 };
+/* ... and about one candidate: its slice under the current genome and the few fields of its window the decisions read */
 struct CandPre {
     long long ext_hi, ext_lo; /* slice sum under the current genome */
+    double ext_d;             /* ig_acc_to_double(ext_hi, ext_lo) */
     long long n_slice;
     int r;                    /* S_c mod 64 */
     int base_cnt;             /* list entries before the block-insert slots */
-    int n_uniq_basic;         /* == base_cnt (kept for the statistics) */
+    int ctgA, ctgB, m_loc, n_loc, n_uniq, B;
+    int same_windowed;        /* bit 0: same contig, bit 1: windowed slice */
+    unsigned flag_mask;       /* get_bounds validity of the 12 block-insert slots (bit i: flags[i] != -1) */
+    int overflow;             /* the slot's slice did not fit the pool: re-run */
     int pad;
 };
 

@@ -339,55 +339,35 @@ __global__ void __launch_bounds__(64)
          * interpretation does): while move w is decided from registers with wave shuffles only, the loads of move w + 1
          * are in flight.  Moves with more than 5 candidates (> 2 score records per lane) take the unpipelined path. */
         struct MoveData {
-            int C, superset0;                                       /* uniform */
-            int cA, cB, mloc, same, windowed, B, n_loc, n_uniq;     /* lane c < C: candidate c */
-            long long c_ext_hi, c_ext_lo, c_n_slice;
-            int c_base_cnt, c_overflow;
-            int flag;                                               /* lane < 12 * min(C, 5): flags[lane % 12] of candidate lane / 12 */
-            SlotPre rec[2];                                         /* score records lane, lane + 64 */
-            long long e_ext_hi[2], e_ext_lo[2];                     /* their candidates' slice sum under the current genome, */
-            int e_r[2], e_base[2];                                  /* S_c mod 64, list entries before the block inserts */
+            int C, superset0;       /* uniform */
+            CandPre cand;           /* lane c < C: candidate c */
+            SlotPre rec[2];         /* score records lane, lane + 64 */
+            double e_ext_d[2];      /* their candidates' slice sum under the current genome, */
+            int e_r[2], e_base[2];  /* S_c mod 64, list entries before the block inserts */
         };
+        /* the candidate counts of all slots up front (lane w: slot w): a prefetch must not wait for its own first load */
+        const int all_C = (lane < W) ? mb.ctl[lane].C : 0;
+        const int all_sup = (lane < W) ? mb.ctl[lane].superset0 : 0;
         auto load_move = [&](int w) {
             MoveData d;
-            const MoveCtl& mc = mb.ctl[w];
-            d.C = mc.C;
-            d.superset0 = mc.superset0;
-            d.cA = d.cB = -1;
-            d.mloc = d.same = d.windowed = d.B = d.n_loc = d.n_uniq = 0;
-            d.c_ext_hi = d.c_ext_lo = d.c_n_slice = 0;
-            d.c_base_cnt = d.c_overflow = 0;
-            if (lane < d.C) {
-                const CandMeta& m = mb.meta[CW(w, lane)];
-                d.cA = m.ctgA;
-                d.cB = m.ctgB;
-                d.mloc = m.m_loc;
-                d.same = m.same;
-                d.windowed = m.windowed;
-                d.B = m.B;
-                d.n_loc = m.n_loc;
-                d.n_uniq = m.n_uniq;
-                const CandPre& cp = cpre_at(mb, CW(w, lane));
-                d.c_ext_hi = cp.ext_hi;
-                d.c_ext_lo = cp.ext_lo;
-                d.c_n_slice = cp.n_slice;
-                d.c_base_cnt = cp.base_cnt;
-                d.c_overflow = cp.pad;
+            d.C = __builtin_amdgcn_readlane(all_C, w);
+            d.superset0 = __builtin_amdgcn_readlane(all_sup, w);
+            d.cand = cpre_at(mb, CW(w, lane < d.C ? lane : 0));
+            if (lane >= d.C) {
+                d.cand.ctgA = d.cand.ctgB = -1;
+                d.cand.m_loc = 0;
             }
-            d.flag = -1;
-            if (lane < 12 * min(d.C, 5)) d.flag = mb.meta[CW(w, lane / 12)].flags[lane % 12];
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const int i = lane + 64 * j;
                 d.rec[j].k = 0;
-                d.e_ext_hi[j] = d.e_ext_lo[j] = 0;
+                d.e_ext_d[j] = 0.0;
                 d.e_r[j] = d.e_base[j] = 0;
                 if (i < d.C * IG_N_TMP_STRUCT) {
                     const int cw = CW(w, i / IG_N_TMP_STRUCT);
                     d.rec[j] = pre_at(mb, cw, i % IG_N_TMP_STRUCT);
                     const CandPre& cp = cpre_at(mb, cw);
-                    d.e_ext_hi[j] = cp.ext_hi;
-                    d.e_ext_lo[j] = cp.ext_lo;
+                    d.e_ext_d[j] = cp.ext_d;
                     d.e_r[j] = cp.r;
                     d.e_base[j] = cp.base_cnt;
                 }
@@ -407,9 +387,9 @@ __global__ void __launch_bounds__(64)
             const int C = d.C;
             /* conflict with an earlier move of this batch?  slice pool overflow? */
             bool hitd = false;
-            for (int q = 0; q < n_dirty; q++) hitd |= (dirty[q] == d.cA) | (dirty[q] == d.cB);
-            if (err0 || rl(d.c_overflow, 0) || __any(hitd && lane < C)) break;
-            n_large += __popcll(__ballot(lane < C && d.mloc > LDS_COL_SMALL));
+            for (int q = 0; q < n_dirty; q++) hitd |= (dirty[q] == d.cand.ctgA) | (dirty[q] == d.cand.ctgB);
+            if (err0 || rl(d.cand.overflow, 0) || __any(hitd && lane < C)) break;
+            n_large += __popcll(__ballot(lane < C && d.cand.m_loc > LDS_COL_SMALL));
             n_cand += C;
             /* scores (eval_all_likelihood_on_zero_2nd KA:4005-4027, eval_all_scores KA:4029-4046) with the live scalars */
             const double cur_nz = ig_acc_to_double(nz_hi, nz_lo);
@@ -421,51 +401,47 @@ __global__ void __launch_bounds__(64)
              * index of the maximal score (all scores zero: index 0) -- one reduction of (score, index). */
             double bestv = -IG_INF;
             int best = 0x7fffffff;
+            auto score_of = [&](int i, const SlotPre& r, double ext, int cr, int cbase) -> double {
+                const int c = i / IG_N_TMP_STRUCT, slot = i % IG_N_TMP_STRUCT;
+                const bool sup = (c == 0) && d.superset0 && (slot >= 12);
+                const bool scored = (i < n) && (r.k > 0) && !(sup && !((vmask >> (slot - 12)) & 1u));
+                if (!scored) return 0.0;
+                const int pos = sup ? cbase + __popc(vmask & ((1u << (slot - 12)) - 1u)) : r.k - 1;
+                const double nzd = (cr > 0 && pos >= cr) ? r.nz_cut_d : r.nz_d; /* quirk Q5 */
+                const double val_inter = -1.0 * log_e * (n_tot_pxl - (double)(n_intra + r.dni)) * p.v_inter;
+                const double val_intra = ig_acc_to_double(z_hi + r.dz_hi, z_lo + r.dz_lo) * log_e;
+                const double z = val_intra + val_inter;
+                return nzd + z + cur_nz - ext;
+            };
 #pragma unroll
-            for (int j = 0; j < NJ; j++) {
+            for (int j = 0; j < NJ; j++) sc[j] = 0.0;
+#pragma unroll
+            for (int j = 0; j < 2; j++) { /* the prefetched records: every move with <= 5 candidates */
                 const int i = lane + 64 * j;
-                double v = 0.0;
-                if (j < 2 || i < n) { /* j >= 2: only moves with more than 5 candidates get here with i < n */
-                    SlotPre r;
-                    long long ext_hi, ext_lo;
-                    int cr, cbase;
-                    if (j < 2) {
-                        r = d.rec[j];
-                        ext_hi = d.e_ext_hi[j];
-                        ext_lo = d.e_ext_lo[j];
-                        cr = d.e_r[j];
-                        cbase = d.e_base[j];
-                    } else {
-                        const int cw = CW(w, i / IG_N_TMP_STRUCT);
-                        r = pre_at(mb, cw, i % IG_N_TMP_STRUCT);
-                        const CandPre cp = cpre_at(mb, cw);
-                        ext_hi = cp.ext_hi;
-                        ext_lo = cp.ext_lo;
-                        cr = cp.r;
-                        cbase = cp.base_cnt;
-                    }
-                    const int c = i / IG_N_TMP_STRUCT, slot = i % IG_N_TMP_STRUCT;
-                    const bool sup = (c == 0) && d.superset0 && (slot >= 12);
-                    const bool scored = (i < n) && (r.k > 0) && !(sup && !((vmask >> (slot - 12)) & 1u));
-                    if (scored) {
-                        const int pos = sup ? cbase + __popc(vmask & ((1u << (slot - 12)) - 1u)) : r.k - 1;
-                        long long nh = r.nz_hi, nl = r.nz_lo;
-                        if (cr > 0 && pos >= cr) { /* quirk Q5 */
-                            nh -= r.tail_hi;
-                            nl -= r.tail_lo;
-                        }
-                        const double ext = ig_acc_to_double(ext_hi, ext_lo);
-                        const double val_inter = -1.0 * log_e * (n_tot_pxl - (double)(n_intra + r.dni)) * p.v_inter;
-                        const double val_intra = ig_acc_to_double(z_hi + r.dz_hi, z_lo + r.dz_lo) * log_e;
-                        const double z = val_intra + val_inter;
-                        v = ig_acc_to_double(nh, nl) + z + cur_nz - ext;
-                    }
-                }
+                const double v = score_of(i, d.rec[j], d.e_ext_d[j], d.e_r[j], d.e_base[j]);
                 sc[j] = v;
                 const double ok = (v == 0.0) ? -IG_INF : v;
                 if (i < n && ok > bestv) { /* strictly greater: the lower index wins inside a lane */
                     bestv = ok;
                     best = i;
+                }
+            }
+            if (n > 128) { /* more than 5 candidates: the rest straight from memory */
+#pragma unroll
+                for (int j = 2; j < NJ; j++) {
+                    const int i = lane + 64 * j;
+                    double v = 0.0;
+                    if (i < n) {
+                        const int cw = CW(w, i / IG_N_TMP_STRUCT);
+                        const CandPre cp = cpre_at(mb, cw);
+                        v = score_of(i, pre_at(mb, cw, i % IG_N_TMP_STRUCT), cp.ext_d, cp.r, cp.base_cnt);
+                    }
+                    sc[j] = v;
+                    const double ok = (v == 0.0) ? -IG_INF : v;
+                    if (i < n && ok > bestv) {
+                        bestv = ok;
+                        best = i;
+                    }
                 }
             }
             for (int off = 32; off > 0; off >>= 1) {
@@ -490,8 +466,7 @@ __global__ void __launch_bounds__(64)
                 br.dz_lo = rl64(mine.dz_lo, owner);
                 br.dni = rl64(mine.dni, owner);
                 br.k = rl(mine.k, owner);
-                br.changed = rl(mine.changed, owner);
-                br.heads = rl(mine.heads, owner);
+                br.info = (unsigned)rl((int)mine.info, owner);
                 bests = rld((bj == 0) ? sc[0] : sc[1], owner);
             } else {
                 br = pre_at(mb, CW(w, bc), bslot);
@@ -500,20 +475,22 @@ __global__ void __launch_bounds__(64)
                 for (int j = 2; j < NJ; j++) sv = (bj == j) ? sc[j] : sv;
                 bests = rld(sv, owner);
             }
-            const int windowed = rl(d.windowed, bc), b_same = rl(d.same, bc), b_B = rl(d.B, bc), b_nloc = rl(d.n_loc, bc);
-            const int b_cA = rl(d.cA, bc), b_cB = rl(d.cB, bc);
-            const long long b_ext_hi = rl64(d.c_ext_hi, bc), b_ext_lo = rl64(d.c_ext_lo, bc);
+            const int b_sw = rl(d.cand.same_windowed, bc), b_B = rl(d.cand.B, bc), b_nloc = rl(d.cand.n_loc, bc);
+            const int windowed = (b_sw >> 1) & 1, b_same = b_sw & 1;
+            const int b_cA = rl(d.cand.ctgA, bc), b_cB = rl(d.cand.ctgB, bc);
+            const long long b_ext_hi = rl64(d.cand.ext_hi, bc), b_ext_lo = rl64(d.cand.ext_lo, bc);
+            const int br_changed = (int)(br.info & 1u), br_heads = (int)(br.info >> 1);
             /* statistics of the move: off the critical path, k_commit_batch fills them in from the flag mask kept here
              * (a pending move needs them now: its record is written by the one-move kernels) */
             long long Sc = 0, ev = 0, by = 0;
-            const bool is_pending = windowed && br.changed;
+            const bool is_pending = windowed && br_changed;
             if (is_pending) {
                 if (lane < C) {
-                    int nu = d.n_uniq;
-                    if (lane == 0 && d.superset0) nu = d.c_base_cnt + __popc(vmask); /* the list the reference would have scored */
-                    Sc = d.c_n_slice;
+                    int nu = d.cand.n_uniq;
+                    if (lane == 0 && d.superset0) nu = d.cand.base_cnt + __popc(vmask); /* the list the reference would have scored */
+                    Sc = d.cand.n_slice;
                     ev = Sc * (nu + 1);
-                    by = 12 * Sc + 20LL * d.mloc * nu + 8LL * nu;
+                    by = 12 * Sc + 20LL * d.cand.m_loc * nu + 8LL * nu;
                 }
                 Sc = rl64(wave_sum_ll(Sc), 0);
                 ev = rl64(wave_sum_ll(ev), 0);
@@ -531,7 +508,7 @@ __global__ void __launch_bounds__(64)
                 o.bytes_min = by;
                 o.d_hi = 0;
                 o.d_lo = 0;
-                o.n_dirty = br.changed;
+                o.n_dirty = br_changed;
                 o.pad = (int)vmask; /* the stale flags this move was scored under */
                 if (br.k <= 0) g->error = 3; /* an unscored slot won: cannot happen */
             }
@@ -547,16 +524,11 @@ __global__ void __launch_bounds__(64)
             z_lo += br.dz_lo;
             ig_acc_normalize((int64_t*)&z_hi, (int64_t*)&z_lo);
             n_intra += br.dni;
-            n_contigs += br.heads - (b_same ? 1 : 2);
+            n_contigs += br_heads - (b_same ? 1 : 2);
             next_cid += NFRESH;
             {
                 const int sel = (bslot >= 12) ? bc : C - 1; /* the family of the winner re-ran get_bounds (CL:2125-2126) */
-                if (sel < 5) {
-                    vmask = (unsigned)((__ballot(d.flag != -1) >> (12 * sel)) & 0xfffull);
-                } else {
-                    const int v = (lane < 12) ? mb.meta[CW(w, sel)].flags[lane] : -1;
-                    vmask = (unsigned)__ballot(lane < 12 && v != -1);
-                }
+                vmask = (unsigned)rl((int)d.cand.flag_mask, sel);
             }
             if (lane == 0) {
                 ig_move_result r;
@@ -573,12 +545,12 @@ __global__ void __launch_bounds__(64)
                 r.error = err0;
                 r.pad = 0;
                 res[move0 + w] = r;
-                if (br.changed) {
+                if (br_changed) {
                     dirty[n_dirty] = b_cA;
                     dirty[n_dirty + 1] = b_cB;
                 }
             }
-            if (br.changed) n_dirty += 2;
+            if (br_changed) n_dirty += 2;
             committed = w + 1;
         }
         if (lane == 0) {

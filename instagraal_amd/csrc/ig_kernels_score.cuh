@@ -983,19 +983,19 @@ __global__ void __launch_bounds__(64) k_records(MoveBuf mb, int w_begin)
         SlotPre r;
         const int k = m.kidx[t];
         r.k = k > 0 ? k : 0;
-        r.nz_hi = r.nz_lo = r.tail_hi = r.tail_lo = r.dz_hi = r.dz_lo = r.dni = 0;
-        r.changed = r.heads = r.pad = 0;
+        r.nz_hi = r.nz_lo = r.dz_hi = r.dz_lo = r.dni = 0;
+        r.nz_d = r.nz_cut_d = 0.0;
+        r.info = 0;
         if (k > 0) {
             r.nz_hi = qp[Q_NZFULL + 2 * k];
             r.nz_lo = qp[Q_NZFULL + 2 * k + 1];
-            r.tail_hi = qp[Q_TAIL + 2 * k];
-            r.tail_lo = qp[Q_TAIL + 2 * k + 1];
             r.dz_hi = qp[Q_Z + 2 * k] - qp[Q_Z];
             r.dz_lo = qp[Q_Z + 2 * k + 1] - qp[Q_Z + 1];
             r.dni = qp[Q_NI + k] - qp[Q_NI];
+            r.nz_d = ig_acc_to_double(r.nz_hi, r.nz_lo);
+            r.nz_cut_d = ig_acc_to_double(r.nz_hi - qp[Q_TAIL + 2 * k], r.nz_lo - qp[Q_TAIL + 2 * k + 1]);
             const int2 si = mb.sinfo[cw * NSLOT + t];
-            r.changed = si.x;
-            r.heads = si.y;
+            r.info = (si.x ? 1u : 0u) | ((unsigned)si.y << 1);
         }
         pre_at(mb, cw, t) = r;
     }
@@ -1003,13 +1003,24 @@ __global__ void __launch_bounds__(64) k_records(MoveBuf mb, int w_begin)
         CandPre cp;
         cp.ext_hi = qp[Q_NZFULL];
         cp.ext_lo = qp[Q_NZFULL + 1];
+        cp.ext_d = ig_acc_to_double(cp.ext_hi, cp.ext_lo);
         cp.n_slice = slice_total(mb.part + (size_t)cw * P_STRIDE);
         cp.r = (int)(cp.n_slice % 64);
         int nb = 0;
         for (int q = 0; q < m.n_uniq; q++) nb += (m.uniq[q] < 12);
         cp.base_cnt = nb;
-        cp.n_uniq_basic = nb;
-        cp.pad = mb.ctl[w].overflow; /* travels with the records: the slot must be re-run */
+        cp.ctgA = m.ctgA;
+        cp.ctgB = m.ctgB;
+        cp.m_loc = m.m_loc;
+        cp.n_loc = m.n_loc;
+        cp.n_uniq = m.n_uniq;
+        cp.B = m.B;
+        cp.same_windowed = (m.same ? 1 : 0) | (m.windowed ? 2 : 0);
+        unsigned fm = 0;
+        for (int q = 0; q < 12; q++) fm |= (m.flags[q] != -1) ? (1u << q) : 0u;
+        cp.flag_mask = fm;
+        cp.overflow = mb.ctl[w].overflow; /* travels with the records: the slot must be re-run */
+        cp.pad = 0;
         cpre_at(mb, cw) = cp;
     }
 }
