@@ -107,7 +107,7 @@ int ig_batch_records(ig_ctx* ctx, void** records, int64_t* bytes_per_slot); /* s
 int ig_batch_commit(ig_ctx* ctx, int32_t move0, int32_t W, int32_t* n_committed); /* moves move0 .. move0+n_committed-1 are done */
 int ig_batch_results(ig_ctx* ctx, int32_t n_moves, ig_move_result* results);
 int ig_set_batch_width(int w);                        /* W in 1..64 (default 24, env IG_BATCH_W); 1 = no speculation */
-int ig_batch_stats(ig_ctx* ctx, int64_t out3[3]);     /* {batches launched, moves committed in-batch, one-move tails} */
+int ig_batch_stats(ig_ctx* ctx, int64_t out4[4]);     /* {batches, moves committed in-batch, one-move tails, predicted deltas used} */
 
 /* ---- bookkeeping -------------------------------------------------------- */
 int ig_renumber_contigs(ig_ctx* ctx, int32_t* n_contigs, float* mean_len, int32_t* max_id); /* CL:2715-2881 */

@@ -103,6 +103,10 @@ struct MoveCtl {
     double ch_score;
     long long n_slice_tot, n_eval_tot, bytes_min;
     long long d_hi, d_lo; /* k_delta accumulator */
+    /* the predicted winner (k_predict: scores under the batch-start scalars), when it is a windowed candidate that changes
+     * the genome, and its exact full-contig delta, computed before the decisions so that the batch need not pause for it */
+    int pred, pred_c, pred_k, pred_pad; /* pred = c * 24 + slot, or -1 */
+    long long pd_hi, pd_lo;
 };
 
 /* what the decide step needs about one (candidate, mutation slot), written slot-major by k_records: 64 bytes (the decide
@@ -126,7 +130,8 @@ struct CandPre {
     int same_windowed;        /* bit 0: same contig, bit 1: windowed slice */
     unsigned flag_mask;       /* get_bounds validity of the 12 block-insert slots (bit i: flags[i] != -1) */
     int overflow;             /* the slot's slice did not fit the pool: re-run */
-    int pad;
+    int pred;                 /* candidate 0 of a slot carries the slot's prediction (MoveCtl.pred, pd_hi, pd_lo) */
+    long long pd_hi, pd_lo;
 };
 
 struct MoveBuf {
@@ -221,7 +226,7 @@ struct ig_ctx {
         double total_ms;
         long long n;
     } timers[10];
-    long long n_batches, n_batch_committed, n_batch_pending;
+    long long n_batches, n_batch_committed, n_batch_pending, n_batch_predicted;
     int large_seen;
     int up_moves, up_max_c; /* the uploaded move lists */
     int own_begin, own_end; /* slots whose candidate genomes this handle built for the batch in flight */

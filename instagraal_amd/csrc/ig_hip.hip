@@ -126,7 +126,7 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->pz_n = c->pz_n1 = 0;
     c->timing_mask = 0xffff;
     c->timing = false;
-    c->n_batches = c->n_batch_committed = c->n_batch_pending = 0;
+    c->n_batches = c->n_batch_committed = c->n_batch_pending = c->n_batch_predicted = 0;
     c->large_seen = 1;
     c->up_moves = c->up_max_c = 0;
     c->own_begin = c->own_end = 0;
@@ -310,7 +310,7 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
     DALLOC(c->own_idx, N);
     HIPCK(hipMemset(c->own_tag, 0xff, N * sizeof(int)));
     DALLOC(c->stamp, N);
-    DALLOC(c->batch_out, 4);
+    DALLOC(c->batch_out, 8);
     DALLOC(c->dirty_buf, 2 * IG_MAX_BATCH + 4);
     HIPCK(hipMemset(m.cmeta, 0, C * NSLOT * NCODE * sizeof(ColMeta)));
     HIPCK(hipMemset(m.slbound, 0, C * SLICE_SEG * sizeof(long long)));
@@ -779,6 +779,12 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                 hipStreamWaitEvent(c->stream, c->ev_tail, 0);
             TimedLaunch t(c, T_FINALIZE);
             hipLaunchKernelGGL(k_records, dim3(max_c, nW), dim3(64), 0, c->stream, c->mb, w_begin);
+            if (phase == 2 && W > 1 && c->world == 1) { /* batches: predicted windowed winners get their exact delta now */
+                hipLaunchKernelGGL(k_predict, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, w_begin);
+                hipLaunchKernelGGL(k_delta, dim3(DELTA_RB, 2, nW), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->tab_prev,
+                                   c->prev_touched, c->glob, c->mb, c->lgf_tab, pz, w_begin, 1);
+                hipLaunchKernelGGL(k_pred_pack, dim3((nW + 63) / 64), dim3(64), 0, c->stream, c->mb, w_begin, nW);
+            }
         }
     }
 }
@@ -799,7 +805,7 @@ static void enqueue_apply(ig_ctx* c, int move, int w, int forced)
     {
         TimedLaunch t(c, T_DELTA);
         hipLaunchKernelGGL(k_delta, dim3(DELTA_RB, 2, 1), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->tab_prev,
-                           c->prev_touched, c->glob, c->mb, c->lgf_tab, pz, w);
+                           c->prev_touched, c->glob, c->mb, c->lgf_tab, pz, w, 0);
     }
     {
         TimedLaunch t(c, T_APPLY);
@@ -850,7 +856,7 @@ static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
                                c->mb, c->init_prev, c->init_next, c->orientable, c->black, c->stamp, c->own_tag, c->own_idx,
                                c->prev_touched, c->d_results, done, w_now, next, c->batch_out);
         }
-        int bo[4];
+        int bo[8];
         HIPCK(hipMemcpyAsync(bo, c->batch_out, sizeof bo, hipMemcpyDeviceToHost, c->stream));
         HIPCK(hipStreamSynchronize(c->stream));
         if (next == 0) {
@@ -858,6 +864,7 @@ static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
             c->large_seen = (bo[2] * 4 > bo[3]); /* a quarter of the windows above LDS_COL_SMALL: launch the large variant too */
         }
         c->n_batch_committed += bo[0] - next;
+        c->n_batch_predicted += bo[4];
         next = bo[0];
         if (bo[1] >= 0) { /* slot bo[1] chose a windowed winner: delta + apply with the one-move kernels, then go on */
             enqueue_apply(c, done + bo[1], bo[1], 0);
@@ -1015,11 +1022,12 @@ extern "C" int ig_set_batch_width(int w)
     return 0;
 }
 
-extern "C" int ig_batch_stats(ig_ctx* c, int64_t out3[3])
+extern "C" int ig_batch_stats(ig_ctx* c, int64_t out3[4])
 {
     out3[0] = c->n_batches;
     out3[1] = c->n_batch_committed;
     out3[2] = c->n_batch_pending;
+    out3[3] = c->n_batch_predicted;
     return 0;
 }
 

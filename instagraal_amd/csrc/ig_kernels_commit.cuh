@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(64)
         const ig_params p = g->par[0];
         const double log_e = IG_LOG_E_F;
         const double n_tot_pxl = g->n_tot_pxl;
-        int n_dirty = 0, committed = w_start, pending = -1, n_large = 0, n_cand = 0;
+        int n_dirty = 0, committed = w_start, pending = -1, n_large = 0, n_cand = 0, n_predicted = 0;
         if (w_start > 0) {
             n_dirty = dirty_buf[0];
             for (int q = lane; q < n_dirty; q += 64) dirty[q] = dirty_buf[1 + q];
@@ -483,7 +483,11 @@ __global__ void __launch_bounds__(64)
             /* statistics of the move: off the critical path, k_commit_batch fills them in from the flag mask kept here
              * (a pending move needs them now: its record is written by the one-move kernels) */
             long long Sc = 0, ev = 0, by = 0;
-            const bool is_pending = windowed && br_changed;
+            /* a windowed winner that changes the genome needs the exact full-contig delta: predicted and computed in advance
+             * (k_predict), or the batch pauses here */
+            const int pred = rl(d.cand.pred, 0);
+            const bool have_delta = windowed && br_changed && (best == pred);
+            const bool is_pending = windowed && br_changed && !have_delta;
             if (is_pending) {
                 if (lane < C) {
                     int nu = d.cand.n_uniq;
@@ -517,8 +521,14 @@ __global__ void __launch_bounds__(64)
                 break;
             }
             /* commit: scalars (exact), stale-flag state (quirk Q4), fresh ids */
-            nz_hi += br.nz_hi - b_ext_hi;
-            nz_lo += br.nz_lo - b_ext_lo;
+            if (have_delta) {
+                nz_hi += rl64(d.cand.pd_hi, 0);
+                nz_lo += rl64(d.cand.pd_lo, 0);
+                n_predicted++;
+            } else {
+                nz_hi += br.nz_hi - b_ext_hi;
+                nz_lo += br.nz_lo - b_ext_lo;
+            }
             ig_acc_normalize((int64_t*)&nz_hi, (int64_t*)&nz_lo);
             z_hi += br.dz_hi;
             z_lo += br.dz_lo;
@@ -567,6 +577,7 @@ __global__ void __launch_bounds__(64)
             batch_out[1] = pending;
             batch_out[2] = n_large;
             batch_out[3] = n_cand;
+            batch_out[4] = n_predicted;
         }
         if (lane < 12) g->valid_insert[lane] = ((vmask >> lane) & 1u) ? 1 : -1;
     }

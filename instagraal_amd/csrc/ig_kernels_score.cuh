@@ -104,6 +104,9 @@ __global__ void __launch_bounds__(256)
         mc.d_hi = mc.d_lo = 0;
         mc.superset0 = (w > 0 && force_slot < 0) ? 1 : 0;
         mc.n_dirty = 0;
+        mc.pred = -1;
+        mc.pred_c = mc.pred_k = mc.pred_pad = 0;
+        mc.pd_hi = mc.pd_lo = 0;
         mc.overflow = 0;
         mc.pad = 0;
         mb.ctl[w] = mc;
@@ -716,10 +719,12 @@ __global__ void __launch_bounds__(SCORE_THREADS)
  * genome).  Row-parallel with a per-wave compaction queue; two columns (current, winner). */
 __global__ void __launch_bounds__(SCORE_THREADS)
     k_delta(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, Tables tab_prev,
-            const int* __restrict__ prev_touched, Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int w)
+            const int* __restrict__ prev_touched, Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int w, int predicted)
 {
+    /* predicted = 0: the chosen winner of slot w (one-move tail); 1: the predicted winners of slots w + blockIdx.z */
+    if (predicted) w += blockIdx.z;
     /* tab_prev catches up with the last applied move before k_apply replaces the touched list (quirk Q12) */
-    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < g->n_prev_touched;
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < (predicted ? 0 : g->n_prev_touched);
          i += gridDim.x * gridDim.y * blockDim.x) {
         const int s = prev_touched[i];
         tab_prev.dist[s] = tab.dist[s];
@@ -731,12 +736,12 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     __shared__ long long red[2][SCORE_THREADS / 64];
     __shared__ int q_li[SCORE_THREADS / 64][128], q_lj[SCORE_THREADS / 64][128], q_ob[SCORE_THREADS / 64][128];
     MoveCtl& mc = mb.ctl[w];
-    if (!mc.ch_windowed || g->error) return;
-    const int c = mc.ch_c;
+    if (g->error || (predicted ? mc.pred < 0 : !mc.ch_windowed)) return;
+    const int c = predicted ? mc.pred_c : mc.ch_c;
     const int cw = CW(w, c);
     const CandMeta& m = mb.meta[cw];
     const int kk = blockIdx.y;
-    const int k = (kk == 0) ? 0 : mc.ch_k;
+    const int k = (kk == 0) ? 0 : (predicted ? mc.pred_k : mc.ch_k);
     const int M = mb.M, m_loc = m.m_loc;
     const ig_params p = g->par[0];
     const ig_hot hot = ig_hot_make(p, ig_tab());
@@ -827,10 +832,97 @@ __global__ void __launch_bounds__(SCORE_THREADS)
         hi = red[0][0] + red[0][1] + red[0][2] + red[0][3];
         lo = red[1][0] + red[1][1] + red[1][2] + red[1][3];
         if (hi | lo) {
-            atomic_add_ll(&mc.d_hi, kk == 0 ? -hi : hi);
-            atomic_add_ll(&mc.d_lo, kk == 0 ? -lo : lo);
+            atomic_add_ll(predicted ? &mc.pd_hi : &mc.d_hi, kk == 0 ? -hi : hi);
+            atomic_add_ll(predicted ? &mc.pd_lo : &mc.d_lo, kk == 0 ? -lo : lo);
         }
     }
+}
+
+/* k_predict: one workgroup per own slot.  The scores of a move depend on its predecessors only through scalars that are
+ * added to every candidate alike (up to rounding) and through the stale insert flags of candidate 0, so the winner can be
+ * predicted from the batch-start state: if it is a windowed candidate that changes the genome, its exact full-contig delta
+ * is computed NOW (k_delta, predicted) and the decide step does not have to pause the batch for it.  A wrong prediction
+ * costs nothing but the pause it failed to avoid. */
+__global__ void __launch_bounds__(256) k_predict(Glob* g, MoveBuf mb, int w_begin)
+{
+    __shared__ double sc[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT];
+    const int w = w_begin + blockIdx.x, tid = threadIdx.x;
+    MoveCtl& mc = mb.ctl[w];
+    const int C = mc.C, n = C * IG_N_TMP_STRUCT;
+    if (cpre_at(mb, CW(w, 0)).overflow) return;
+    /* the flags candidate 0 most likely sees: the live ones for the first slot, else those of the previous slot's last candidate */
+    unsigned vmask = 0;
+    if (w == 0) {
+        for (int q = 0; q < 12; q++) vmask |= (g->valid_insert[q] != -1) ? (1u << q) : 0u;
+    } else {
+        const CandMeta& pm = mb.meta[CW(w - 1, mb.ctl[w - 1].C - 1)];
+        for (int q = 0; q < 12; q++) vmask |= (pm.flags[q] != -1) ? (1u << q) : 0u;
+    }
+    const ig_params p = g->par[0];
+    const double log_e = IG_LOG_E_F, n_tot_pxl = g->n_tot_pxl;
+    const long long z_hi = g->z_hi, z_lo = g->z_lo, n_intra = g->n_intra;
+    const double cur_nz = ig_acc_to_double(g->nz_hi, g->nz_lo);
+    for (int i = tid; i < n; i += blockDim.x) {
+        const int c = i / IG_N_TMP_STRUCT, slot = i % IG_N_TMP_STRUCT;
+        const SlotPre r = pre_at(mb, CW(w, c), slot);
+        const CandPre& cp = cpre_at(mb, CW(w, c));
+        const bool sup = (c == 0) && mc.superset0 && (slot >= 12);
+        double v = 0.0;
+        if ((r.k > 0) && !(sup && !((vmask >> (slot - 12)) & 1u))) {
+            const int pos = sup ? cp.base_cnt + __popc(vmask & ((1u << (slot - 12)) - 1u)) : r.k - 1;
+            const double nzd = (cp.r > 0 && pos >= cp.r) ? r.nz_cut_d : r.nz_d;
+            const double val_inter = -1.0 * log_e * (n_tot_pxl - (double)(n_intra + r.dni)) * p.v_inter;
+            const double val_intra = ig_acc_to_double(z_hi + r.dz_hi, z_lo + r.dz_lo) * log_e;
+            v = nzd + (val_intra + val_inter) + cur_nz - cp.ext_d;
+        }
+        sc[i] = v;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double bestv = -IG_INF;
+        int best = 0x7fffffff;
+        for (int i = tid; i < n; i += 64) {
+            const double ok = (sc[i] == 0.0) ? -IG_INF : sc[i];
+            if (ok > bestv) {
+                bestv = ok;
+                best = i;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bestv, off, 64);
+            const int oi = __shfl_xor(best, off, 64);
+            if (ov > bestv || (ov == bestv && oi < best)) {
+                bestv = ov;
+                best = oi;
+            }
+        }
+        if (tid == 0) {
+            if (best >= n) best = 0;
+            const int c = best / IG_N_TMP_STRUCT, slot = best % IG_N_TMP_STRUCT;
+            const SlotPre r = pre_at(mb, CW(w, c), slot);
+            const bool windowed = (cpre_at(mb, CW(w, c)).same_windowed >> 1) & 1;
+            if (windowed && (r.info & 1u) && r.k > 0) {
+                mc.pred = best;
+                mc.pred_c = c;
+                mc.pred_k = r.k;
+            }
+        }
+    }
+}
+
+/* the prediction travels with the records (candidate 0 of the slot) */
+__global__ void k_pred_pack(MoveBuf mb, int w_begin, int nW)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nW) return;
+    const int w = w_begin + i;
+    const MoveCtl& mc = mb.ctl[w];
+    CandPre& cp = cpre_at(mb, CW(w, 0));
+    long long h = mc.pd_hi, l = mc.pd_lo;
+    ig_acc_normalize((int64_t*)&h, (int64_t*)&l);
+    cp.pred = mc.pred;
+    cp.pd_hi = h;
+    cp.pd_lo = l;
 }
 
 /* prefinal_tail (k_tail): one workgroup per (candidate, slot).  Computes, for
@@ -1020,7 +1112,8 @@ __global__ void __launch_bounds__(64) k_records(MoveBuf mb, int w_begin)
         for (int q = 0; q < 12; q++) fm |= (m.flags[q] != -1) ? (1u << q) : 0u;
         cp.flag_mask = fm;
         cp.overflow = mb.ctl[w].overflow; /* travels with the records: the slot must be re-run */
-        cp.pad = 0;
+        cp.pred = -1; /* k_pred_pack */
+        cp.pd_hi = cp.pd_lo = 0;
         cpre_at(mb, cw) = cp;
     }
 }

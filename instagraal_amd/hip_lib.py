@@ -226,9 +226,9 @@ class Context:
         return res
 
     def batch_stats(self):
-        o = np.zeros(3, np.int64)
+        o = np.zeros(4, np.int64)
         _ck(lib().ig_batch_stats(self._h, _p(o)))
-        return dict(batches=int(o[0]), committed_in_batch=int(o[1]), one_move_tails=int(o[2]))
+        return dict(batches=int(o[0]), committed_in_batch=int(o[1]), one_move_tails=int(o[2]), predicted_deltas=int(o[3]))
 
     # ---- bookkeeping
     def renumber_contigs(self):
