@@ -91,16 +91,28 @@ IG_HD const double* ig_tab(void)
     return tab;
 }
 
-/* log2 of a positive, finite, NORMAL double.  m in [1,2) falls in interval j (7 bits); with the tabulated
- * reciprocal r_j of the interval centre u = m r_j - 1 is tiny (|u| <= 2^-8, the fma makes it exact up to
- * its own rounding) and log2(x) = e - log2(r_j) + log2(1 + u), a degree-5 polynomial.  Intervals above
- * sqrt(2) use m/2 (folded into r_j) and e + 1 so that log2 near 1 from below does not cancel. */
+/* frexp of a positive, finite, NORMAL double: x = m * 2^e, m in [1/2, 1).  (One instruction each on gfx950; for
+ * other inputs the two targets differ, and every caller discards the result then.) */
+#if defined(__HIP_DEVICE_COMPILE__)
+IG_HD double ig_frexp_mant(double x) { return __builtin_amdgcn_frexp_mant(x); }
+IG_HD int ig_frexp_exp(double x) { return __builtin_amdgcn_frexp_exp(x); }
+IG_HD double ig_scale2(double v, int k) { return __builtin_ldexp(v, k); }
+#else
+IG_HD double ig_frexp_mant(double x) { return ig_u2d((ig_d2u(x) & 0x000fffffffffffffULL) | 0x3fe0000000000000ULL); }
+IG_HD int ig_frexp_exp(double x) { return (int)((ig_d2u(x) >> 52) & 0x7ffu) - 1022; }
+/* v * 2^k, exact: the callers keep the result normal */
+IG_HD double ig_scale2(double v, int k) { return v * ig_u2d((uint64_t)(k + 1023) << 52); }
+#endif
+
+/* log2 of a positive, finite, NORMAL double.  m in [1/2,1) falls in interval j (its 7 leading fraction bits); with the
+ * tabulated reciprocal r_j of the interval centre u = m r_j - 1 is tiny (|u| <= 2^-8, the fma makes it exact up to
+ * its own rounding) and log2(x) = e - log2(r_j) + log2(1 + u), a degree-5 polynomial: absolute error below 3e-16
+ * (what the callers need: they exponentiate it or multiply it by a count). */
 IG_HD double ig_log2_pos(double x, const double* T)
 {
-    const uint64_t b = ig_d2u(x);
-    const int j = (int)((b >> 45) & 127u);
-    const int e = (int)((b >> 52) & 0x7ffu) - 1023 + (j >= IG_LOG_SPLIT);
-    const double m = ig_u2d((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+    const int j = (int)((ig_d2u(x) >> 45) & 127u);
+    const double m = ig_frexp_mant(x);
+    const int e = ig_frexp_exp(x);
     const double u = ig_fma(m, T[2 * j], -1.0);
     double p = IG_LOG_C5;
     p = ig_fma_k(p, u, IG_LOG_C4);
@@ -111,12 +123,15 @@ IG_HD double ig_log2_pos(double x, const double* T)
 }
 
 /* 2^y for |y| <= 1000 (finite): y = (128 k + i)/128 + t with |t| <= 2^-8 (all steps exact),
- * 2^y = 2^k * 2^(i/128) * (1 + P(t)), P of degree 4. */
+ * 2^y = 2^k * 2^(i/128) * (1 + P(t)), P of degree 4.  128 y is rounded to an integer (half-even) by adding 1.5 * 2^52:
+ * the integer is then the low word of the sum. */
+#define IG_RINT_MAGIC 6755399441055744.0
 IG_HD double ig_exp2_core(double y, const double* T)
 {
-    const double jd = __builtin_rint(y * 128.0); /* round-half-even of an exact product */
-    const double t = ig_fma(jd, -0.0078125, y);  /* exact */
-    const int ji = (int)jd;
+    const double z = ig_fma(y, 128.0, IG_RINT_MAGIC);
+    const int ji = (int)(uint32_t)ig_d2u(z);
+    const double jd = z - IG_RINT_MAGIC;        /* exact */
+    const double t = ig_fma(jd, -0.0078125, y); /* exact */
     double p = IG_EXP_C4;
     p = ig_fma_k(p, t, IG_EXP_C3);
     p = ig_fma_k(p, t, IG_EXP_C2);
@@ -124,7 +139,7 @@ IG_HD double ig_exp2_core(double y, const double* T)
     p = p * t;
     const double tj = T[IG_TAB_EXP + (ji & 127)];
     const double v = ig_fma(tj, p, tj);
-    return v * ig_u2d((uint64_t)((ji >> 7) + 1023) << 52); /* exact scaling, never sub-normal for |y| <= 1000 */
+    return ig_scale2(v, ji >> 7); /* never sub-normal for |y| <= 1000 */
 }
 
 IG_HD double ig_exp2(double y, const double* T)
@@ -232,14 +247,15 @@ IG_HD double ig_pixel_term(float ex, float ex_z, int ob, double lgf, const doubl
  * Linear contig, d == 2 (the only value the reference ever uses, optim_rippe_curve_update.py:8), sane parameters:
  *     P(s) = amp * s^slope,  amp = c1 * fact,  clamped below by v_inter and replaced by it outside (0, d_max);
  *     term = ob * log10 P(s) - P(s) - log10(ob!) + P_z * log10(e)               (KA:4426-4462, 251-270)
- * Evaluated with ONE log2 and ONE exp2 in double: y = slope * log2(s), P = amp * 2^y, log10 P = (y + log2 amp) * log10(2)
+ * Evaluated with ONE log2 and ONE exp2 in double: y = slope * log2(s) + log2(amp), clamped below by log2(v_inter)
+ * (the max of KA:153-163 taken on the exponents), P = 2^y, log10 P = y * log10(2)
  * (the reference rounds P(s) to float and takes log10 of that float again: a second log for 1e-7 of relative
  * difference per term, inside its own float noise).  ig_hot holds what does not depend on the contact.
  * Everything else (circular contigs, d != 2, degenerate parameters, ob == 0) composes ig_rippe* and ig_pixel_term. */
 typedef struct ig_hot {
     int fast;         /* the parameters are in the domain of the one-log evaluation */
     float d_max, v_inter;
-    double slope, amp, log2_amp, v_inter_d, lg_v_inter;
+    double slope, log2_amp, log2_v_inter;
 } ig_hot;
 
 IG_HD ig_hot ig_hot_make(const ig_params p, const double* T)
@@ -248,28 +264,27 @@ IG_HD ig_hot ig_hot_make(const ig_params p, const double* T)
     h.d_max = p.d_max;
     h.v_inter = p.v_inter;
     h.slope = (double)p.slope;
-    h.amp = (double)p.c1 * (double)p.fact; /* exact: two 24-bit significands */
-    h.v_inter_d = (double)p.v_inter;
-    /* |slope * log2(s)| <= 1000 for every positive float s (log2 in [-149, 128]): ig_exp2's range checks cannot fire;
-     * amp a normal positive double; all comparisons false for NaNs */
+    const double amp = (double)p.c1 * (double)p.fact; /* exact: two 24-bit significands */
+    /* |slope * log2(s) + log2(amp)| < 6.5 * 149 + 30 < 1000 for every positive float s (log2 in [-149, 128]):
+     * ig_exp2_core's range is respected; all comparisons false for NaNs */
     h.fast = (p.d == 2.0f) && (p.slope != 0.0f) && (p.slope != 2.0f) && (p.slope > -6.5f) && (p.slope < 6.5f) &&
-             (p.v_inter > 0.0f) && (p.v_inter < IG_INFF) && (h.amp > 1e-300) && (h.amp < 1e300);
-    h.log2_amp = h.fast ? ig_log2_pos(h.amp, T) : 0.0;
-    h.lg_v_inter = h.fast ? ig_log2_pos(h.v_inter_d, T) * IG_LOG2_10_INV : 0.0; /* == ig_log10(v_inter) */
+             (p.v_inter > 0.0f) && (p.v_inter < IG_INFF) && (amp > 0x1p-30) && (amp < 0x1p30);
+    h.log2_amp = h.fast ? ig_log2_pos(amp, T) : 0.0;
+    h.log2_v_inter = h.fast ? ig_log2_pos((double)p.v_inter, T) : 0.0;
     return h;
 }
 
-/* h->fast, ob > 0.  inter: trans pair (P = P_z = v_inter, the caller passes ex_z = v_inter) */
+/* h->fast, ob > 0.  inter: trans pair (P = P_z = v_inter, the caller passes ex_z = v_inter).  ig_log2_pos of an s
+ * outside (0, inf) is finite garbage or NaN and is discarded by the select. */
 IG_HD double ig_term_hot(float s, int inter, int ob, double lgf, float ex_z, const ig_hot* h, const double* T)
 {
-    const int in = (s > 0.0f) && (s < h->d_max);
-    const double L = ig_log2_pos((double)(in ? s : 1.0f), T);
-    const double y = h->slope * L;
-    const double res = h->amp * ig_exp2_core(y, T);
-    const int cis_model = in && !inter && (res > h->v_inter_d); /* else: the trans level (KA:153-163 max(., v_inter)) */
-    const double ex = cis_model ? res : h->v_inter_d;
-    const double lg = cis_model ? (y + h->log2_amp) * IG_LOG2_10_INV : h->lg_v_inter;
-    const double t = (((double)ob * lg) - ex) - lgf;
+    const int in = (s > 0.0f) && (s < h->d_max) && !inter;
+    const double y = ig_fma(h->slope, ig_log2_pos((double)s, T), h->log2_amp);
+    const double yc = (y > h->log2_v_inter) ? y : h->log2_v_inter;
+    const double yy = in ? yc : h->log2_v_inter; /* else: the trans level */
+    const double ex = ig_exp2_core(yy, T);
+    const double lg = yy * IG_LOG2_10_INV;
+    const double t = ig_fma((double)ob, lg, -ex) - lgf;
     return t + (double)ex_z * IG_LOG_E_F;
 }
 

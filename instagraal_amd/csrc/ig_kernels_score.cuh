@@ -527,39 +527,22 @@ __device__ __noinline__ double term_circ(const ig_params p, float mean_kb, float
     return ig_pixel_term(ex, ex_z, ob, lgf, ig_tab());
 }
 
-/* dkey: rank distance d of a linear cis pair; -1 for a trans pair; d | code << 27 | 1 << 30 for a pair on a circular contig.
- * The hot case is the contract's ig_term_hot (one log2, one exp2) with the count's log-factorial and P_z from the LDS
- * tables; everything else (circular contig, count >= 256, rank distance beyond the LDS table, parameters outside the
- * one-log domain) is fixed up afterwards behind a wave-uniform branch that is almost never taken. */
 #define DKEY_CIRC 0x40000000
-__device__ __forceinline__ void term_hot(const ig_hot& h, const ig_params& p, float mean_kb, float s, int dkey, int ob,
-                                         const float* pz_s, int pzn_s, const PzTab& pz, const double* lgf_s,
-                                         const double* __restrict__ lgf_tab, const ColMeta* cm_s, const double* T, int& qh,
-                                         unsigned& ql)
+__device__ __forceinline__ void term_checked(const ig_hot& h, const ig_params& p, float mean_kb, float s, int dkey, int ob,
+                                             const PzTab& pz, const double* lgf_s, const double* __restrict__ lgf_tab,
+                                             const ColMeta* cm_s, const double* T, int& qh, unsigned& ql)
 {
     const bool inter = dkey < 0;
-    double lgf = lgf_s[min(ob, LDS_LGF - 1)];
-    float ex_z = pz_s[min(max(dkey, 0), pzn_s - 1)];
-    /* a P_z table shorter than PZ_MAX ends where s_z reaches d_max (ig_set_params): beyond it P_z is the trans level */
-    const bool past_table = (pz.n < PZ_MAX) && (dkey >= pz.n) && !(dkey & DKEY_CIRC);
-    ex_z = (inter || past_table) ? h.v_inter : ex_z;
-    double t = ig_term_hot(s, inter, ob, lgf, ex_z, &h, T);
-    const bool rare = (ob >= LDS_LGF) || (dkey >= pzn_s && !past_table) || !h.fast || (ob <= 0);
-    if (__any(rare)) {
-        if (rare) {
-            if (ob >= LDS_LGF) lgf = lgfact_dev(ob, lgf_tab);
-            if (!inter && (dkey & DKEY_CIRC)) {
-                const int code = (dkey >> 27) & 7;
-                t = term_circ(p, mean_kb, s, cm_s[code].stot, dkey & 0x07ffffff, cm_s[code].len, ob, lgf);
-            } else {
-                t = term_general(p, mean_kb, s, dkey, ob, lgf, pz);
-            }
-        }
+    const double lgf = (ob < LDS_LGF) ? lgf_s[max(ob, 0)] : lgfact_dev(ob, lgf_tab);
+    double t;
+    if (!inter && (dkey & DKEY_CIRC)) {
+        const int code = (dkey >> 27) & 7;
+        t = term_circ(p, mean_kb, s, cm_s[code].stot, dkey & 0x07ffffff, cm_s[code].len, ob, lgf);
+    } else {
+        t = term_general(p, mean_kb, s, dkey, ob, lgf, pz);
     }
     quantize_split(t, qh, ql);
 }
-
-/* classification of one slice entry under one coordinate column: what its term is computed from */
 __device__ __forceinline__ void classify_pair(uint2 ai, uint2 bj, unsigned circ_mask, float& sv, int& dkey)
 {
     const unsigned ci = ai.y >> 28, cj = bj.y >> 28;
@@ -569,98 +552,167 @@ __device__ __forceinline__ void classify_pair(uint2 ai, uint2 bj, unsigned circ_
     dkey = cis ? (pi > pj ? pi - pj : pj - pi) : -1;
     if (cis && ((circ_mask >> ci) & 1u)) dkey = (dkey & 0x07ffffff) | ((int)ci << 27) | DKEY_CIRC;
 }
-
 struct ScoreArgs {
-    const int *sli, *slj, *slo; /* the segment of the slice list (< 2^31 entries, 32-bit offsets from a uniform base) */
-    const unsigned long long* slp; /* or its packed form */
+    const int *sli, *slj, *slo;
+    const unsigned long long* slp;
     unsigned n;
-    const uint2* gcol; /* column k in global memory */
-    const uint2* lcol; /* and its LDS copy */
-    const float* pz_s;
-    const double *lgf_s, *mt_s;
+    const uint2* gcol;
+    const uint2* lcol;
+    const double *pzc_s, *lgf_s, *mt_s;
     const ColMeta* cm_s;
     const double* lgf_tab;
     PzTab pz;
-    int pzn;
     unsigned circ_mask;
     float mean;
-    int ablate;
 };
-
-/* the streaming loop of k_score_list; STAGED: the column fits the LDS stage (ds_read), else 8-byte gathers from L2 */
-#define SCORE_BATCH 4
-template <bool STAGED, bool PACKED>
-__device__ __forceinline__ void score_loop(const ScoreArgs& a, const ig_hot& hp, const ig_params& p, long long& hi, long long& lo)
+#ifndef SCORE_BATCH
+#define SCORE_BATCH 2
+#endif
+#ifndef SCORE_WAVES
+#define SCORE_WAVES 6
+#endif
+__device__ __forceinline__ unsigned abs_diff_u32(unsigned x, unsigned y)
 {
-    const unsigned stride = SCORE_THREADS; /* the workgroup owns its segment */
-    for (unsigned e0 = threadIdx.x; e0 < a.n; e0 += stride * SCORE_BATCH) {
-        int li[SCORE_BATCH], lj[SCORE_BATCH], ob[SCORE_BATCH];
-#pragma unroll
-        for (int u = 0; u < SCORE_BATCH; u++) {
-            const unsigned e = e0 + u * stride;
-            const bool ok = e < a.n;
-            if (PACKED) {
-                const unsigned long long pk = ok ? a.slp[e] : ~0ull;
-                li[u] = ok ? (int)(pk & 0xfffffu) : -1;
-                lj[u] = (int)((pk >> 20) & 0xfffffu);
-                ob[u] = ok ? (int)(pk >> 40) : 0;
-            } else {
-                li[u] = ok ? a.sli[e] : -1;
-                lj[u] = ok ? a.slj[e] : 0;
-                ob[u] = ok ? a.slo[e] : 0;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < SCORE_BATCH; u++) { /* unrolled: the batch stays in registers */
-            const bool valid = li[u] >= 0; /* lanes past the end evaluate entry 0 and drop the result */
-            if (!__any(valid)) break;      /* wave-uniform */
-            const int l_i = valid ? li[u] : 0, l_j = lj[u], o_b = valid ? ob[u] : 1;
-            const uint2 ai = STAGED ? a.lcol[l_i] : a.gcol[l_i];
-            const uint2 bj = STAGED ? a.lcol[l_j] : a.gcol[l_j];
-            float sv;
-            int dkey;
-            classify_pair(ai, bj, a.circ_mask, sv, dkey);
-            int qh;
-            unsigned ql;
-            if (a.ablate & 1) {
-                qh = (int)__float_as_uint(sv) >> 12;
-                ql = (unsigned)(dkey + o_b);
-            } else {
-                term_hot(hp, p, a.mean, sv, dkey, o_b, a.pz_s, a.pzn, a.pz, a.lgf_s, a.lgf_tab, a.cm_s, a.mt_s, qh, ql);
-            }
-            hi += valid ? qh : 0;
-            lo += (long long)(valid ? ql : 0u);
-        }
+    unsigned r;
+    __asm__("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+template <bool PACKED>
+__device__ __forceinline__ void load_entry(const ScoreArgs& a, unsigned e, unsigned& li, unsigned& lj, unsigned& ob)
+{
+    if (PACKED) {
+        const unsigned long long pk = a.slp[e];
+        li = (unsigned)pk & 0xfffffu;
+        lj = (unsigned)(pk >> 20) & 0xfffffu;
+        ob = (unsigned)(pk >> 40);
+    } else {
+        li = (unsigned)a.sli[e];
+        lj = (unsigned)a.slj[e];
+        ob = (unsigned)a.slo[e];
     }
 }
-
-/* k_score_list: the hot kernel.  One workgroup = (entry block, coordinate column k, candidate cw).
- * Staged in LDS: the column (8 B per local sub-fragment), the P_z table, the log10(ob!) table, the log2/exp2
- * tables of the arithmetic contract and the per-contig constants.  Lanes stream the slice list (coalesced
- * 4-byte loads, SCORE_BATCH contacts in flight), read both endpoints' coordinates from LDS, evaluate the
- * Rippe / Poisson term (term_hot: the arithmetic contract of ig_detmath.h with the argument checks hoisted) and add
- * it as an exact integer.  Wave shuffles, one LDS step, two atomics per workgroup. */
+template <bool STAGED, bool PACKED>
+__device__ __noinline__ longlong2 score_loop_general(const ScoreArgs a, const ig_params p)
+{
+    const ig_hot hp = ig_hot_make(p, ig_tab());
+    long long hi = 0, lo = 0;
+    for (unsigned e = threadIdx.x; e < a.n; e += SCORE_THREADS) {
+        unsigned l_i, l_j, o_b;
+        load_entry<PACKED>(a, e, l_i, l_j, o_b);
+        const uint2 ai = STAGED ? a.lcol[l_i] : a.gcol[l_i];
+        const uint2 bj = STAGED ? a.lcol[l_j] : a.gcol[l_j];
+        float sv;
+        int dkey, qh;
+        unsigned ql;
+        classify_pair(ai, bj, a.circ_mask, sv, dkey);
+        term_checked(hp, p, a.mean, sv, dkey, (int)o_b, a.pz, a.lgf_s, a.lgf_tab, a.cm_s, a.mt_s, qh, ql);
+        hi += qh;
+        lo += (long long)ql;
+    }
+    return make_longlong2(hi, lo);
+}
+#define IG_QMAGIC 6755399441055744.0
+#define IG_QMAGIC_BITS 0x4338000000000000ULL
+#define SCORE_FLUSH (1u << 20)
+__device__ __noinline__ double term_of_entry(const uint2* gcol, float mean, const double* lgf_tab, PzTab pz, const ig_params p, unsigned l_i,
+                                             unsigned l_j, unsigned o_b)
+{
+    const uint2 ai = gcol[l_i], bj = gcol[l_j];
+    const bool cis = (ai.y ^ bj.y) < 0x10000000u;
+    const unsigned d = abs_diff_u32(ai.y, bj.y);
+    const float sv = fabsf(__uint_as_float(ai.x) - __uint_as_float(bj.x));
+    return term_general(p, mean, cis ? sv : 0.0f, cis ? (int)d : -1, (int)o_b, lgfact_dev((int)o_b, lgf_tab), pz);
+}
+template <bool STAGED, bool PACKED>
+__device__ __forceinline__ void score_loop(const ScoreArgs& a, const ig_hot& h, const ig_params& p, long long& hi, long long& lo)
+{
+    const double* T = a.mt_s;
+    const unsigned cut = a.pz.n > LDS_PZ ? (unsigned)LDS_PZ : 0xffffffffu;
+    const double lv = h.log2_v_inter, slope = h.slope, la = h.log2_amp;
+    const float d_max = h.d_max;
+    for (unsigned base = 0; base < a.n; base += SCORE_FLUSH) {
+        const unsigned end = min(a.n, base + SCORE_FLUSH);
+        unsigned long long acc = 0, accl = 0;
+        for (unsigned e0 = base + threadIdx.x; e0 < end; e0 += SCORE_THREADS * SCORE_BATCH) {
+            unsigned li[SCORE_BATCH], lj[SCORE_BATCH], ob[SCORE_BATCH];
+#pragma unroll
+            for (int u = 0; u < SCORE_BATCH; u++) load_entry<PACKED>(a, min(e0 + u * SCORE_THREADS, end - 1), li[u], lj[u], ob[u]);
+            double t[SCORE_BATCH];
+            bool rare[SCORE_BATCH], any_rare = false;
+#pragma unroll
+            for (int u = 0; u < SCORE_BATCH; u++) {
+                const uint2 ai = STAGED ? a.lcol[li[u]] : a.gcol[li[u]];
+                const uint2 bj = STAGED ? a.lcol[lj[u]] : a.gcol[lj[u]];
+                const unsigned o_b = ob[u];
+                const bool cis = (ai.y ^ bj.y) < 0x10000000u;
+                const unsigned d = abs_diff_u32(ai.y, bj.y);
+                const float sv = fabsf(__uint_as_float(ai.x) - __uint_as_float(bj.x));
+                const bool in = cis && (sv > 0.0f) && (sv < d_max);
+                const double pzc = a.pzc_s[cis ? min(d, (unsigned)LDS_PZ) : (unsigned)LDS_PZ];
+                const double lgf = a.lgf_s[min(o_b, (unsigned)(LDS_LGF - 1))];
+                const double y = ig_fma(slope, ig_log2_pos((double)sv, T), la);
+                const double yy = in ? __builtin_fmax(y, lv) : lv;
+                const double ex = ig_exp2_core(yy, T);
+                const double lg = yy * IG_LOG2_10_INV;
+                t[u] = (ig_fma((double)o_b, lg, -ex) - lgf) + pzc;
+                rare[u] = (o_b - 1u >= (unsigned)(LDS_LGF - 1)) || (cis && d >= cut);
+                any_rare |= rare[u];
+            }
+            if (__any(any_rare)) {
+#pragma unroll
+                for (int u = 0; u < SCORE_BATCH; u++)
+                    if (rare[u]) t[u] = term_of_entry(a.gcol, a.mean, a.lgf_tab, a.pz, p, li[u], lj[u], ob[u]);
+            }
+            unsigned long long bits[SCORE_BATCH];
+            bool any_big = false;
+#pragma unroll
+            for (int u = 0; u < SCORE_BATCH; u++) {
+                bits[u] = ig_d2u(ig_fma(t[u], IG_QSCALE, IG_QMAGIC));
+                any_big |= !(__builtin_fabs(t[u]) < 524288.0);
+            }
+            if (__any(any_big)) {
+#pragma unroll
+                for (int u = 0; u < SCORE_BATCH; u++)
+                    if (!(__builtin_fabs(t[u]) < 524288.0)) bits[u] = (unsigned long long)ig_quantize(t[u]) + IG_QMAGIC_BITS;
+            }
+#pragma unroll
+            for (int u = 0; u < SCORE_BATCH; u++) {
+                if (e0 + u * SCORE_THREADS < end) {
+                    acc += bits[u];
+                    accl += (unsigned)bits[u];
+                }
+            }
+        }
+        const unsigned first = base + threadIdx.x;
+        const unsigned long long cnt = first < end ? (end - first + SCORE_THREADS - 1) / SCORE_THREADS : 0;
+        const long long q = (long long)(acc - cnt * IG_QMAGIC_BITS);
+        hi += (q - (long long)accl) >> 32;
+        lo += (long long)accl;
+    }
+}
 #define LDS_COL_SMALL 1024
-/* two instantiations per launch site: windows of <= LDS_COL_SMALL sub-fragments (8 KB column: more workgroups per CU)
- * and the rest (<= LDS_COL_CAP staged, larger ones gathered from L2); each workgroup serves its own class only */
 template <int CAP>
-__global__ void __launch_bounds__(SCORE_THREADS)
+struct ScoreLds {
+    double mt[IG_TAB_SIZE];
+    double pzc[LDS_PZ + 1];
+    double lgf[LDS_LGF];
+    uint2 col[CAP];
+    ColMeta cm[NCODE];
+    long long red[2][SCORE_THREADS / 64];
+};
+template <int CAP>
+__global__ void __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(SCORE_WAVES)))
     k_score_list(const Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int ablate, int max_c, int large_on,
                  int w_begin)
 {
-    __shared__ uint2 lcol[CAP];
-    __shared__ float pz_s[LDS_PZ];
-    __shared__ double lgf_s[LDS_LGF];
-    __shared__ double mt_s[IG_TAB_SIZE];
-    __shared__ ColMeta cm_s[NCODE];
-    __shared__ long long red[2][SCORE_THREADS / 64];
+    __shared__ ScoreLds<CAP> L;
     const int w = w_begin + blockIdx.z / max_c, c = blockIdx.z % max_c;
     if (c >= mb.ctl[w].C) return;
     const int cw = CW(w, c);
     const CandMeta& m = mb.meta[cw];
     const int k = blockIdx.y;
     if (k > m.n_uniq) return;
-    const long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + blockIdx.x]; /* workgroup x streams segment x */
+    const long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + blockIdx.x];
     if (n == 0) return;
     const long long off = mb.sloff[(size_t)cw * SLICE_SEG + blockIdx.x];
     if (off < 0) return;
@@ -672,23 +724,30 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     const uint2* gcol = mb.coords + (size_t)(cw * NSLOT + k) * M;
     const bool staged = m_loc <= CAP;
     if (staged)
-        for (int i = threadIdx.x; i < m_loc; i += SCORE_THREADS) lcol[i] = gcol[i];
+        for (int i = threadIdx.x; i < m_loc; i += SCORE_THREADS) L.col[i] = gcol[i];
     const int pzn = min(pz.n, LDS_PZ);
-    for (int i = threadIdx.x; i < pzn; i += SCORE_THREADS) pz_s[i] = pz.v[i];
-    for (int i = threadIdx.x; i < LDS_LGF; i += SCORE_THREADS) lgf_s[i] = lgf_tab[i];
+    for (int i = threadIdx.x; i <= LDS_PZ; i += SCORE_THREADS) L.pzc[i] = (double)(i < pzn ? pz.v[i] : p.v_inter) * IG_LOG_E_F;
+    for (int i = threadIdx.x; i < LDS_LGF; i += SCORE_THREADS) L.lgf[i] = lgf_tab[i];
     {
         const double* T0 = ig_tab();
-        for (int i = threadIdx.x; i < IG_TAB_SIZE; i += SCORE_THREADS) mt_s[i] = T0[i];
+        for (int i = threadIdx.x; i < IG_TAB_SIZE; i += SCORE_THREADS) L.mt[i] = T0[i];
     }
-    if (threadIdx.x < NCODE) cm_s[threadIdx.x] = mb.cmeta[(size_t)(cw * NSLOT + k) * NCODE + threadIdx.x];
+    if (threadIdx.x < NCODE) L.cm[threadIdx.x] = mb.cmeta[(size_t)(cw * NSLOT + k) * NCODE + threadIdx.x];
     __syncthreads();
     unsigned circ_mask = 0;
 #pragma unroll
-    for (int q = 0; q < NCODE; q++) circ_mask |= (cm_s[q].stot != 0) ? (1u << q) : 0u;
+    for (int q = 0; q < NCODE; q++) circ_mask |= (L.cm[q].stot != 0) ? (1u << q) : 0u;
     long long hi = 0, lo = 0;
     const ScoreArgs sa{mb.packed ? nullptr : mb.sl_li + off, mb.packed ? nullptr : mb.sl_lj + off, mb.packed ? nullptr : mb.sl_ob + off,
-                       mb.packed ? mb.sl_pk + off : nullptr, (unsigned)n, gcol, lcol, pz_s, lgf_s, mt_s, cm_s, lgf_tab, pz, pzn, circ_mask, mean, ablate};
-    if (mb.packed) {
+                       mb.packed ? mb.sl_pk + off : nullptr, (unsigned)n, gcol, L.col, L.pzc, L.lgf, L.mt, L.cm, lgf_tab, pz, circ_mask, mean};
+    const bool general = circ_mask || !hp.fast || (ablate & 2);
+    if (general) {
+        longlong2 r;
+        if (mb.packed) r = staged ? score_loop_general<true, true>(sa, p) : score_loop_general<false, true>(sa, p);
+        else r = staged ? score_loop_general<true, false>(sa, p) : score_loop_general<false, false>(sa, p);
+        hi = r.x;
+        lo = r.y;
+    } else if (mb.packed) {
         if (staged) score_loop<true, true>(sa, hp, p, hi, lo);
         else score_loop<false, true>(sa, hp, p, hi, lo);
     } else {
@@ -699,13 +758,13 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     lo = wave_sum_ll(lo);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) {
-        red[0][wv] = hi;
-        red[1][wv] = lo;
+        L.red[0][wv] = hi;
+        L.red[1][wv] = lo;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        hi = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        lo = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        hi = L.red[0][0] + L.red[0][1] + L.red[0][2] + L.red[0][3];
+        lo = L.red[1][0] + L.red[1][1] + L.red[1][2] + L.red[1][3];
         if (hi | lo) {
             long long* part = mb.part + (size_t)cw * P_STRIDE;
             atomic_add_ll(&part[P_NZ + 2 * k], hi);

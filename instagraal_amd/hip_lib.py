@@ -68,7 +68,7 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
-        _lib = C.CDLL(LIB_PATH)
+        _lib = C.CDLL(os.environ.get("IG_HIP_LIB", LIB_PATH))  # IG_HIP_LIB: tuning builds of the same source
         _lib.ig_last_error.restype = C.c_char_p
         _lib.ig_partials_count.restype = C.c_int64
         _lib.ig_partials_device_ptr.restype = C.c_void_p
