@@ -214,6 +214,7 @@ struct ig_ctx {
     int cands_cap;
     int* prev_touched;
     unsigned timing_mask;
+    struct ScoreConst* score_const; /* tables and constants k_score_list stages (parameter set 0) */
     float* pz_tab;  /* P_z table of parameter set 0 (the model in use) */
     int pz_n;
     float* pz_tab1; /* and of set 1 (the nuisance step's test parameters) */

@@ -123,6 +123,7 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->cands_cap = 0;
     c->prev_touched = nullptr;
     c->pz_tab = c->pz_tab1 = nullptr;
+    c->score_const = nullptr;
     c->pz_n = c->pz_n1 = 0;
     c->timing_mask = 0xffff;
     c->timing = false;
@@ -226,6 +227,7 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipFree(c->orientable);
     hipFree(c->black);
     hipFree(c->lgf_tab);
+    hipFree(c->score_const);
     hipFree(c->glob);
     hipFree(c->d_results);
     hipFree(c->d_frags);
@@ -525,6 +527,11 @@ extern "C" int ig_set_params(ig_ctx* c, const float p[8], float mean_subfrag_kb,
         double need = (mean_subfrag_kb > 0) ? (double)p[5] / (double)mean_subfrag_kb + 2.0 : 0.0;
         n = (need > 0 && need < (double)PZ_MAX) ? (int)need : ((need >= (double)PZ_MAX) ? PZ_MAX : 0);
         if (n > 0) hipLaunchKernelGGL(k_build_pz, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->glob, tab, n, which);
+        if (which == 0) { /* the constants k_score_list stages */
+            if (!c->score_const) DALLOC(c->score_const, 1);
+            hipLaunchKernelGGL(k_build_score_const, dim3((LDS_PZ + 2 + 255) / 256), dim3(256), 0, c->stream, c->glob, PzTab{tab, n}, c->lgf_tab,
+                               c->score_const);
+        }
     }
     if (which == 0) {
         c->have_params = true;
@@ -763,10 +770,10 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
              * sub-fragments; without it the small variant serves every window (unstaged above its cap) */
             static int s_large = getenv("IG_LARGE") ? atoi(getenv("IG_LARGE")) : -1;
             const int large_on = s_large >= 0 ? s_large : c->large_seen;
-            hipLaunchKernelGGL(k_score_list<LDS_COL_SMALL>, dim3(s_eb, NSLOT, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->glob,
+            hipLaunchKernelGGL(k_score_list<LDS_COL_SMALL>, dim3(s_eb, NSLOT, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->score_const,
                                c->mb, c->lgf_tab, pz, s_abl, max_c, large_on, w_begin);
             if (large_on)
-                hipLaunchKernelGGL(k_score_list<LDS_COL_CAP>, dim3(s_eb, NSLOT, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->glob,
+                hipLaunchKernelGGL(k_score_list<LDS_COL_CAP>, dim3(s_eb, NSLOT, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->score_const,
                                    c->mb, c->lgf_tab, pz, s_abl, max_c, large_on, w_begin);
         }
     }

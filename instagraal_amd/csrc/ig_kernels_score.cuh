@@ -691,47 +691,70 @@ __device__ __forceinline__ void score_loop(const ScoreArgs& a, const ig_hot& h, 
     }
 }
 #define LDS_COL_SMALL 1024
+/* what every workgroup of k_score_list stages: built once per parameter set (k_build_score_const), copied to LDS as is */
+struct ScoreTables {
+    double mt[IG_TAB_SIZE];  /* the log2 / exp2 tables of the arithmetic contract; at LDS offset 0: the table pair is read without address arithmetic */
+    double pzc[LDS_PZ + 2];  /* P_z * log10(e) per rank distance; from the table's end on (and for trans pairs): the trans level */
+    double lgf[LDS_LGF];     /* log10(ob!) */
+};
+struct ScoreConst {
+    ScoreTables tab;
+    ig_hot hot;
+    ig_params par;
+    float mean_kb;
+};
+static_assert(sizeof(ScoreTables) % 16 == 0, "copied as 16-byte vectors");
+__global__ void k_build_score_const(const Glob* g, PzTab pz, const double* __restrict__ lgf_tab, ScoreConst* out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const ig_params p = g->par[0];
+    const int pzn = min(pz.n, LDS_PZ);
+    if (i < IG_TAB_SIZE) out->tab.mt[i] = ig_tab()[i];
+    if (i < LDS_PZ + 2) out->tab.pzc[i] = (double)(i < pzn ? pz.v[i] : p.v_inter) * IG_LOG_E_F;
+    if (i < LDS_LGF) out->tab.lgf[i] = lgf_tab[i];
+    if (i == 0) {
+        out->hot = ig_hot_make(p, ig_tab());
+        out->par = p;
+        out->mean_kb = g->mean_kb;
+    }
+}
+
 template <int CAP>
 struct ScoreLds {
-    double mt[IG_TAB_SIZE];
-    double pzc[LDS_PZ + 1];
-    double lgf[LDS_LGF];
+    ScoreTables tab;
     uint2 col[CAP];
     ColMeta cm[NCODE];
     long long red[2][SCORE_THREADS / 64];
 };
 template <int CAP>
 __global__ void __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(SCORE_WAVES)))
-    k_score_list(const Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int ablate, int max_c, int large_on,
-                 int w_begin)
+    k_score_list(const ScoreConst* __restrict__ sc, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int ablate, int max_c,
+                 int large_on, int w_begin)
 {
     __shared__ ScoreLds<CAP> L;
+    /* everything the early exits and the set-up need is loaded before the first branch: one round trip, not five */
     const int w = w_begin + blockIdx.z / max_c, c = blockIdx.z % max_c;
-    if (c >= mb.ctl[w].C) return;
-    const int cw = CW(w, c);
-    const CandMeta& m = mb.meta[cw];
     const int k = blockIdx.y;
-    if (k > m.n_uniq) return;
-    const long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + blockIdx.x];
-    if (n == 0) return;
+    const int cw = CW(w, c);
+    const int C = mb.ctl[w].C;
+    const int n_uniq = mb.meta[cw].n_uniq, m_loc = mb.meta[cw].m_loc;
+    const long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + blockIdx.x]; /* workgroup x streams segment x */
     const long long off = mb.sloff[(size_t)cw * SLICE_SEG + blockIdx.x];
-    if (off < 0) return;
-    const int M = mb.M, m_loc = m.m_loc;
+    const ig_params p = sc->par;
+    const ig_hot hp = sc->hot;
+    const float mean = sc->mean_kb;
+    if (c >= C || k > n_uniq || n == 0 || off < 0) return;
     if (large_on && ((CAP == LDS_COL_SMALL) != (m_loc <= LDS_COL_SMALL))) return;
-    const ig_params p = g->par[0];
-    const ig_hot hp = ig_hot_make(p, ig_tab());
-    const float mean = g->mean_kb;
+    const int M = mb.M;
     const uint2* gcol = mb.coords + (size_t)(cw * NSLOT + k) * M;
     const bool staged = m_loc <= CAP;
+    {
+        const float4* src = (const float4*)&sc->tab;
+        float4* dst = (float4*)&L.tab;
+        for (int i = threadIdx.x; i < (int)(sizeof(ScoreTables) / 16); i += SCORE_THREADS) dst[i] = src[i];
+    }
     if (staged)
         for (int i = threadIdx.x; i < m_loc; i += SCORE_THREADS) L.col[i] = gcol[i];
-    const int pzn = min(pz.n, LDS_PZ);
-    for (int i = threadIdx.x; i <= LDS_PZ; i += SCORE_THREADS) L.pzc[i] = (double)(i < pzn ? pz.v[i] : p.v_inter) * IG_LOG_E_F;
-    for (int i = threadIdx.x; i < LDS_LGF; i += SCORE_THREADS) L.lgf[i] = lgf_tab[i];
-    {
-        const double* T0 = ig_tab();
-        for (int i = threadIdx.x; i < IG_TAB_SIZE; i += SCORE_THREADS) L.mt[i] = T0[i];
-    }
     if (threadIdx.x < NCODE) L.cm[threadIdx.x] = mb.cmeta[(size_t)(cw * NSLOT + k) * NCODE + threadIdx.x];
     __syncthreads();
     unsigned circ_mask = 0;
@@ -739,7 +762,7 @@ __global__ void __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per
     for (int q = 0; q < NCODE; q++) circ_mask |= (L.cm[q].stot != 0) ? (1u << q) : 0u;
     long long hi = 0, lo = 0;
     const ScoreArgs sa{mb.packed ? nullptr : mb.sl_li + off, mb.packed ? nullptr : mb.sl_lj + off, mb.packed ? nullptr : mb.sl_ob + off,
-                       mb.packed ? mb.sl_pk + off : nullptr, (unsigned)n, gcol, L.col, L.pzc, L.lgf, L.mt, L.cm, lgf_tab, pz, circ_mask, mean};
+                       mb.packed ? mb.sl_pk + off : nullptr, (unsigned)n, gcol, L.col, L.tab.pzc, L.tab.lgf, L.tab.mt, L.cm, lgf_tab, pz, circ_mask, mean};
     const bool general = circ_mask || !hp.fast || (ablate & 2);
     if (general) {
         longlong2 r;
