@@ -633,10 +633,24 @@ __device__ __forceinline__ void score_loop(const ScoreArgs& a, const ig_hot& h, 
     for (unsigned base = 0; base < a.n; base += SCORE_FLUSH) {
         const unsigned end = min(a.n, base + SCORE_FLUSH);
         unsigned long long acc = 0, accl = 0;
-        for (unsigned e0 = base + threadIdx.x; e0 < end; e0 += SCORE_THREADS * SCORE_BATCH) {
+        /* a wave takes steps of 64 x SCORE_BATCH consecutive entries (steps wave, wave + 4, ...: at most one partly filled
+         * step per wave); the entries of the next step are loaded before this step's terms are evaluated (the loads' L2
+         * latency is several times a step's arithmetic) */
+        const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const unsigned step = 64 * SCORE_BATCH, stride = step * (SCORE_THREADS / 64);
+        unsigned nli[SCORE_BATCH], nlj[SCORE_BATCH], nob[SCORE_BATCH];
+#pragma unroll
+        for (int u = 0; u < SCORE_BATCH; u++) load_entry<PACKED>(a, min(base + wave * step + u * 64 + lane, end - 1), nli[u], nlj[u], nob[u]);
+        for (unsigned e0 = base + wave * step + lane; e0 - lane < end; e0 += stride) {
             unsigned li[SCORE_BATCH], lj[SCORE_BATCH], ob[SCORE_BATCH];
 #pragma unroll
-            for (int u = 0; u < SCORE_BATCH; u++) load_entry<PACKED>(a, min(e0 + u * SCORE_THREADS, end - 1), li[u], lj[u], ob[u]);
+            for (int u = 0; u < SCORE_BATCH; u++) {
+                li[u] = nli[u];
+                lj[u] = nlj[u];
+                ob[u] = nob[u];
+            }
+#pragma unroll
+            for (int u = 0; u < SCORE_BATCH; u++) load_entry<PACKED>(a, min(e0 + stride + u * 64, end - 1), nli[u], nlj[u], nob[u]);
             double t[SCORE_BATCH];
             bool rare[SCORE_BATCH], any_rare = false;
 #pragma unroll
@@ -677,15 +691,13 @@ __device__ __forceinline__ void score_loop(const ScoreArgs& a, const ig_hot& h, 
             }
 #pragma unroll
             for (int u = 0; u < SCORE_BATCH; u++) {
-                if (e0 + u * SCORE_THREADS < end) {
-                    acc += bits[u];
+                if (e0 + u * 64 < end) { /* the constant of the rounding trick goes out with the entry */
+                    acc += bits[u] - IG_QMAGIC_BITS;
                     accl += (unsigned)bits[u];
                 }
             }
         }
-        const unsigned first = base + threadIdx.x;
-        const unsigned long long cnt = first < end ? (end - first + SCORE_THREADS - 1) / SCORE_THREADS : 0;
-        const long long q = (long long)(acc - cnt * IG_QMAGIC_BITS);
+        const long long q = (long long)acc;
         hi += (q - (long long)accl) >> 32;
         lo += (long long)accl;
     }
