@@ -203,7 +203,7 @@ def main():
                          "term_evals_per_launch": n_evals,
                          "term_evals_per_s": (n_evals / (score_ms * 1e-3)) if score_ms > 0 else 0.0,
                          "note": "B_min = sum_c[12 S_c + 20 m_c U + 8 U] + 68 n_touched per move (SURVEY 8(d)), summed over the moves "
-                                 "of a launch; the kernel is VALU-issue bound (VALUBusy 97 %, profiles/) by the exact f64 term "
+                                 "of a launch; the kernel is bound by VALU issue (VALUBusy 85 %, profiles/) of the exact f64 term "
                                  "arithmetic on an L2-resident working set, not by HBM: DESIGN.md section 4.3"},
         }
         if not a.no_cpu_baseline:
