@@ -527,6 +527,9 @@ __device__ __noinline__ double term_circ(const ig_params p, float mean_kb, float
     return ig_pixel_term(ex, ex_z, ob, lgf, ig_tab());
 }
 
+/* dkey: rank distance d of a linear cis pair; -1 for a trans pair; d | code << 27 | 1 << 30 for a pair on a circular contig.
+ * term_checked: the long way, for the workgroups of score_loop_general (a circular contig on the window, or parameters
+ * outside the one-log domain of the contract) */
 #define DKEY_CIRC 0x40000000
 __device__ __forceinline__ void term_checked(const ig_hot& h, const ig_params& p, float mean_kb, float s, int dkey, int ob,
                                              const PzTab& pz, const double* lgf_s, const double* __restrict__ lgf_tab,
@@ -543,6 +546,7 @@ __device__ __forceinline__ void term_checked(const ig_hot& h, const ig_params& p
     }
     quantize_split(t, qh, ql);
 }
+/* classification of one slice entry under one coordinate column: what its term is computed from */
 __device__ __forceinline__ void classify_pair(uint2 ai, uint2 bj, unsigned circ_mask, float& sv, int& dkey)
 {
     const unsigned ci = ai.y >> 28, cj = bj.y >> 28;
@@ -553,18 +557,19 @@ __device__ __forceinline__ void classify_pair(uint2 ai, uint2 bj, unsigned circ_
     if (cis && ((circ_mask >> ci) & 1u)) dkey = (dkey & 0x07ffffff) | ((int)ci << 27) | DKEY_CIRC;
 }
 struct ScoreArgs {
-    const int *sli, *slj, *slo;
-    const unsigned long long* slp;
+    const int *sli, *slj, *slo;    /* the segment of the slice list (< 2^31 entries, 32-bit offsets from a uniform base) */
+    const unsigned long long* slp; /* or its packed form */
     unsigned n;
-    const uint2* gcol;
-    const uint2* lcol;
-    const double *pzc_s, *lgf_s, *mt_s;
+    const uint2* gcol; /* column k in global memory */
+    const uint2* lcol; /* and its LDS copy */
+    const double *pzc_s, *lgf_s, *mt_s; /* LDS tables: P_z * log10(e) per rank distance, log10(ob!), log2 / exp2 */
     const ColMeta* cm_s;
     const double* lgf_tab;
     PzTab pz;
     unsigned circ_mask;
     float mean;
 };
+/* tuning (measured on cfg3): terms interleaved per lane, waves per SIMD the register budget is cut for */
 #ifndef SCORE_BATCH
 #define SCORE_BATCH 2
 #endif
@@ -577,6 +582,7 @@ __device__ __forceinline__ unsigned abs_diff_u32(unsigned x, unsigned y)
     __asm__("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(x), "v"(y));
     return r;
 }
+/* one entry of the list: (local row, local column, count) */
 template <bool PACKED>
 __device__ __forceinline__ void load_entry(const ScoreArgs& a, unsigned e, unsigned& li, unsigned& lj, unsigned& ob)
 {
@@ -591,6 +597,8 @@ __device__ __forceinline__ void load_entry(const ScoreArgs& a, unsigned e, unsig
         ob = (unsigned)a.slo[e];
     }
 }
+/* the streaming loop for the rare workgroups (see term_checked), out of line.  Arguments by value: a reference would put
+ * the caller's argument block in scratch memory for every thread of the kernel. */
 template <bool STAGED, bool PACKED>
 __device__ __noinline__ longlong2 score_loop_general(const ScoreArgs a, const ig_params p)
 {
@@ -611,9 +619,17 @@ __device__ __noinline__ longlong2 score_loop_general(const ScoreArgs a, const ig
     }
     return make_longlong2(hi, lo);
 }
+/* ... and for everything else: linear contigs only, parameters in the one-log domain (ig_hot.fast).  The term is the
+ * contract's ig_term_hot, spelled out with the count's log-factorial and P_z * log10(e) read from the LDS tables
+ * (entries from the table's end on hold the trans level: a trans pair, and a cis pair beyond the table, read that).
+ * Counts >= LDS_LGF, zero counts and rank distances beyond a table longer than the LDS copy are fixed up behind a
+ * wave-uniform branch (term_of_entry).  Quantisation: t * 2^32 + 1.5 * 2^52 rounds to the integer (half-even, as
+ * ig_quantize) and leaves it in the low 52 bits of the sum; |t| >= 2^19 (or NaN) takes ig_quantize itself.
+ * STAGED: the column is in LDS (ds_read), else 8-byte gathers from L2. */
 #define IG_QMAGIC 6755399441055744.0
 #define IG_QMAGIC_BITS 0x4338000000000000ULL
-#define SCORE_FLUSH (1u << 20)
+#define SCORE_FLUSH (1u << 20) /* entries between two folds of the lane sums into the limbs */
+/* the checked term of one entry, from scratch (coordinates from the global column): the fix-up of score_loop */
 __device__ __noinline__ double term_of_entry(const uint2* gcol, float mean, const double* lgf_tab, PzTab pz, const ig_params p, unsigned l_i,
                                              unsigned l_j, unsigned o_b)
 {
@@ -658,14 +674,14 @@ __device__ __forceinline__ void score_loop(const ScoreArgs& a, const ig_hot& h, 
                 const uint2 ai = STAGED ? a.lcol[li[u]] : a.gcol[li[u]];
                 const uint2 bj = STAGED ? a.lcol[lj[u]] : a.gcol[lj[u]];
                 const unsigned o_b = ob[u];
-                const bool cis = (ai.y ^ bj.y) < 0x10000000u;
-                const unsigned d = abs_diff_u32(ai.y, bj.y);
+                const bool cis = (ai.y ^ bj.y) < 0x10000000u; /* same contig code */
+                const unsigned d = abs_diff_u32(ai.y, bj.y);   /* then: the rank distance */
                 const float sv = fabsf(__uint_as_float(ai.x) - __uint_as_float(bj.x));
                 const bool in = cis && (sv > 0.0f) && (sv < d_max);
                 const double pzc = a.pzc_s[cis ? min(d, (unsigned)LDS_PZ) : (unsigned)LDS_PZ];
                 const double lgf = a.lgf_s[min(o_b, (unsigned)(LDS_LGF - 1))];
                 const double y = ig_fma(slope, ig_log2_pos((double)sv, T), la);
-                const double yy = in ? __builtin_fmax(y, lv) : lv;
+                const double yy = in ? __builtin_fmax(y, lv) : lv; /* in: y is a number */
                 const double ex = ig_exp2_core(yy, T);
                 const double lg = yy * IG_LOG2_10_INV;
                 t[u] = (ig_fma((double)o_b, lg, -ex) - lgf) + pzc;
@@ -698,10 +714,17 @@ __device__ __forceinline__ void score_loop(const ScoreArgs& a, const ig_hot& h, 
             }
         }
         const long long q = (long long)acc;
-        hi += (q - (long long)accl) >> 32;
-        lo += (long long)accl;
+        hi += (q - (long long)accl) >> 32; /* exact: the sum of the q >> 32 */
+        lo += (long long)accl;              /* the sum of the (uint32) q */
     }
 }
+/* k_score_list: the hot kernel.  One workgroup = (segment of the slice list, coordinate column k, candidate cw).
+ * Staged in LDS: the tables (ScoreTables, one 13 KB copy) and the column (8 B per local sub-fragment).  Waves stream the
+ * slice list (coalesced 8-byte entries), read both endpoints' coordinates from LDS, evaluate the Rippe / Poisson term
+ * and add it as an exact integer.  Wave shuffles, one LDS step, two atomics per workgroup.
+ * Two instantiations per launch site: windows of <= LDS_COL_SMALL sub-fragments (8 KB column) and -- launched when a
+ * quarter of the previous batch's windows were larger -- LDS_COL_CAP; a window above the cap of the instance that
+ * serves it is not staged (gathers from L2). */
 #define LDS_COL_SMALL 1024
 /* what every workgroup of k_score_list stages: built once per parameter set (k_build_score_const), copied to LDS as is */
 struct ScoreTables {
