@@ -195,6 +195,8 @@ struct ig_ctx {
     SubTab* sub_tab;
     long long* rowptr;
     int2* cc; /* (col, count) */
+    int* crow;    /* row of every contact (COO companion of cc: k_full_nz is contact-parallel) */
+    int4* tabrec; /* k_pack_tab: (dist, s_tot, contig, rank) per sub-fragment */
     int* init_prev;
     int* init_next;
     int* orientable;
@@ -215,6 +217,7 @@ struct ig_ctx {
     int* prev_touched;
     unsigned timing_mask;
     struct ScoreConst* score_const; /* tables and constants k_score_list stages (parameter set 0) */
+    struct ScoreConst* full_const;  /* the same for the parameter set a k_full_nz launch evaluates */
     float* pz_tab;  /* P_z table of parameter set 0 (the model in use) */
     int pz_n;
     float* pz_tab1; /* and of set 1 (the nuisance step's test parameters) */

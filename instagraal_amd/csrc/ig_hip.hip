@@ -111,6 +111,8 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->sub_tab = nullptr;
     c->rowptr = nullptr;
     c->cc = nullptr;
+    c->crow = nullptr;
+    c->tabrec = nullptr;
     c->init_prev = c->init_next = c->orientable = nullptr;
     c->black = nullptr;
     c->stamp = nullptr;
@@ -124,6 +126,7 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->prev_touched = nullptr;
     c->pz_tab = c->pz_tab1 = nullptr;
     c->score_const = nullptr;
+    c->full_const = nullptr;
     c->pz_n = c->pz_n1 = 0;
     c->timing_mask = 0xffff;
     c->timing = false;
@@ -222,12 +225,15 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipFree(c->sub_tab);
     hipFree(c->rowptr);
     hipFree(c->cc);
+    hipFree(c->crow);
+    hipFree(c->tabrec);
     hipFree(c->init_prev);
     hipFree(c->init_next);
     hipFree(c->orientable);
     hipFree(c->black);
     hipFree(c->lgf_tab);
     hipFree(c->score_const);
+    hipFree(c->full_const);
     hipFree(c->glob);
     hipFree(c->d_results);
     hipFree(c->d_frags);
@@ -260,6 +266,18 @@ extern "C" int ig_set_stream(ig_ctx* c, void* s)
         c->own_stream = true;
     }
     return 0;
+}
+
+/* the from-scratch likelihood of the non-zero pixels under tables `t` and parameter set `which` -> out[0..1] */
+static void launch_full_nz(ig_ctx* c, const Tables& t, int which, long long* out, PzTab pz)
+{
+    static int s_wgs = getenv("IG_FULL_WGS") ? atoi(getenv("IG_FULL_WGS")) : 8 * 256;
+    if (c->Z <= 0) return;
+    hipLaunchKernelGGL(k_pack_tab, dim3((c->M + 255) / 256), dim3(256), 0, c->stream, t, c->M, c->tabrec);
+    /* the tables of this parameter set (k_score_list's own block is parameter set 0's) */
+    hipLaunchKernelGGL(k_build_score_const, dim3((LDS_PZ + 2 + 255) / 256), dim3(256), 0, c->stream, c->glob, pz, c->lgf_tab, c->full_const, which);
+    hipLaunchKernelGGL(k_full_nz, dim3(s_wgs), dim3(256), 0, c->stream, c->crow, c->cc, c->tabrec, t.len, c->full_const, c->lgf_tab,
+                       (long long)c->Z, pz.n, out);
 }
 
 static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
@@ -347,8 +365,14 @@ extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* 
     for (int i = 0; i < M; i++) rp[(size_t)i + 1] += rp[(size_t)i];
     hipFree(c->rowptr);
     hipFree(c->cc);
+    hipFree(c->crow);
+    hipFree(c->tabrec);
     DALLOC(c->rowptr, (size_t)M + 1);
     DALLOC(c->cc, (size_t)Z);
+    DALLOC(c->crow, (size_t)std::max<int64_t>(Z, 1));
+    DALLOC(c->tabrec, (size_t)M);
+    if (!c->full_const) DALLOC(c->full_const, 1);
+    if (Z) HIPCK(hipMemcpy(c->crow, row, (size_t)Z * sizeof(int), hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(c->rowptr, rp.data(), ((size_t)M + 1) * sizeof(long long), hipMemcpyHostToDevice));
     if (Z) HIPCK(hipMemcpy(c->cc, cc.data(), (size_t)Z * sizeof(int2), hipMemcpyHostToDevice));
     c->Z = Z;
@@ -487,8 +511,7 @@ static int launch_recompute(ig_ctx* c)
     hipLaunchKernelGGL(k_post, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->st, c->init_prev, c->init_next, c->orientable,
                        c->black, c->glob, N);
     if (c->have_params && c->have_contacts) {
-        hipLaunchKernelGGL(k_full_nz, dim3(1024), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, 0, c->lgf_tab, M, 0, 1,
-                           scratch, PzTab{c->pz_tab, c->pz_n});
+        launch_full_nz(c, c->tab, 0, scratch, PzTab{c->pz_tab, c->pz_n});
         hipLaunchKernelGGL(k_full_zero, dim3(256), dim3(256), 0, c->stream, c->tab, c->glob, 0, M, scratch + 2);
     }
     long long h[8];
@@ -530,7 +553,7 @@ extern "C" int ig_set_params(ig_ctx* c, const float p[8], float mean_subfrag_kb,
         if (which == 0) { /* the constants k_score_list stages */
             if (!c->score_const) DALLOC(c->score_const, 1);
             hipLaunchKernelGGL(k_build_score_const, dim3((LDS_PZ + 2 + 255) / 256), dim3(256), 0, c->stream, c->glob, PzTab{tab, n}, c->lgf_tab,
-                               c->score_const);
+                               c->score_const, 0);
         }
     }
     if (which == 0) {
@@ -667,8 +690,7 @@ extern "C" int ig_full_likelihood(ig_ctx* c, int which, int use_prev, double* nz
     Tables& t = use_prev ? c->tab_prev : c->tab;
     /* which == 1 before any ig_set_params(.., 1): no table yet, every P_z is evaluated directly */
     const PzTab pz = which == 0 ? PzTab{c->pz_tab, c->pz_n} : PzTab{c->pz_tab1, c->pz_tab1 ? c->pz_n1 : 0};
-    hipLaunchKernelGGL(k_full_nz, dim3(1024), dim3(256), 0, c->stream, c->rowptr, c->cc, t, c->glob, which, c->lgf_tab, c->M, 0, 1,
-                       scratch, pz);
+    launch_full_nz(c, t, which, scratch, pz);
     hipLaunchKernelGGL(k_full_zero, dim3(256), dim3(256), 0, c->stream, t, c->glob, which, c->M, scratch + 2);
     long long h[8];
     HIPCK(hipMemcpyAsync(h, scratch, sizeof h, hipMemcpyDeviceToHost, c->stream));

@@ -739,10 +739,10 @@ struct ScoreConst {
     float mean_kb;
 };
 static_assert(sizeof(ScoreTables) % 16 == 0, "copied as 16-byte vectors");
-__global__ void k_build_score_const(const Glob* g, PzTab pz, const double* __restrict__ lgf_tab, ScoreConst* out)
+__global__ void k_build_score_const(const Glob* g, PzTab pz, const double* __restrict__ lgf_tab, ScoreConst* out, int which)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const ig_params p = g->par[0];
+    const ig_params p = g->par[which];
     const int pzn = min(pz.n, LDS_PZ);
     if (i < IG_TAB_SIZE) out->tab.mt[i] = ig_tab()[i];
     if (i < LDS_PZ + 2) out->tab.pzc[i] = (double)(i < pzn ? pz.v[i] : p.v_inter) * IG_LOG_E_F;
@@ -828,6 +828,162 @@ __global__ void __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per
             atomic_add_ll(&part[P_NZ + 2 * k], hi);
             atomic_add_ll(&part[P_NZ + 2 * k + 1], lo);
         }
+    }
+}
+
+/* k_full_nz: evaluate_likelihood_sparse (KA:4374-4488) over all contacts, exact sums -> out[0..1] (the from-scratch
+ * likelihood: set-up, every nuisance step).  Contact-parallel (the reference's own decomposition, KA:4426-4462): a wave
+ * takes steps of FULL_UNROLL x 64 consecutive contacts -- coalesced loads of (column, count) and of the row index, one
+ * 16-byte gather per endpoint (k_pack_tab; the row's record is the same line for most of a wave), the next step's
+ * contacts loaded before this step's terms -- so the work is balanced whatever the row lengths.  The term is
+ * score_loop's: tables of the parameter set in LDS (ScoreTables), one fma to quantise; circular contigs, counts >=
+ * LDS_LGF, rank distances the LDS table does not cover and parameters outside the one-log domain go through
+ * ig_pair_term behind a wave-uniform branch. */
+#ifndef FULL_UNROLL
+#define FULL_UNROLL 2
+#endif
+__device__ __noinline__ long long full_q_general(const ig_params p, float mean, int cis, float s, int d, float sti, int len_i, int ob,
+                                                 const double* lgf_tab)
+{
+    const ig_hot h = ig_hot_make(p, ig_tab());
+    return ig_quantize(ig_pair_term(p, &h, cis, s, (float)d * mean, sti, (float)len_i * mean, ob, lgfact_dev(ob, lgf_tab), ig_tab()));
+}
+/* streamed once: non-temporal, so that the contact arrays do not evict the endpoint records from L2 */
+__device__ __forceinline__ int2 ld_stream(const int2* p)
+{
+    const long long v = __builtin_nontemporal_load((const long long*)p);
+    return make_int2((int)(unsigned)v, (int)(v >> 32));
+}
+__device__ __forceinline__ int ld_stream(const int* p) { return __builtin_nontemporal_load(p); }
+__global__ void __launch_bounds__(256) k_full_nz(const int* __restrict__ crow, const int2* __restrict__ cc, const int4* __restrict__ rec,
+                                                 const int* __restrict__ len, const ScoreConst* __restrict__ sc,
+                                                 const double* __restrict__ lgf_tab, long long Z, int pz_n, long long* out)
+{
+    __shared__ ScoreTables L;
+    __shared__ long long red[2][4];
+    {
+        const float4* src = (const float4*)&sc->tab;
+        float4* dst = (float4*)&L;
+        for (int i = threadIdx.x; i < (int)(sizeof(ScoreTables) / 16); i += blockDim.x) dst[i] = src[i];
+    }
+    const ig_params p = sc->par;
+    const ig_hot hot = sc->hot;
+    const float mean = sc->mean_kb, d_max = hot.d_max;
+    const double lv = hot.log2_v_inter, slope = hot.slope, la = hot.log2_amp;
+    /* rank distances from `cut` on are not in the LDS table (no table at all: every cis pair the long way) */
+    const unsigned cut = pz_n <= 0 ? 0u : (pz_n > LDS_PZ ? (unsigned)LDS_PZ : 0xffffffffu);
+    const bool checked = !hot.fast;
+    __syncthreads();
+    const double* T = L.mt;
+    const int lane = threadIdx.x & 63;
+    const long long wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const long long step = 64 * FULL_UNROLL;
+    unsigned long long acc = 0, accl = 0;
+    /* three stages in flight: the contacts of step i + 2 are loaded and the endpoint records of step i + 1 gathered while
+     * the terms of step i are evaluated (HBM and L2 latencies are several times a step's arithmetic) */
+    int2 nv[FULL_UNROLL], gv[FULL_UNROLL];
+    int nr[FULL_UNROLL], grow[FULL_UNROLL];
+    int4 gri[FULL_UNROLL], grj[FULL_UNROLL];
+#pragma unroll
+    for (int u = 0; u < FULL_UNROLL; u++) {
+        const long long k = min(wave * step + u * 64 + lane, Z - 1);
+        gv[u] = ld_stream(cc + k);
+        grow[u] = ld_stream(crow + k);
+    }
+#pragma unroll
+    for (int u = 0; u < FULL_UNROLL; u++) {
+        const long long k = min((wave + nwaves) * step + u * 64 + lane, Z - 1);
+        nv[u] = ld_stream(cc + k);
+        nr[u] = ld_stream(crow + k);
+    }
+#pragma unroll
+    for (int u = 0; u < FULL_UNROLL; u++) {
+        gri[u] = rec[grow[u]];
+        grj[u] = rec[gv[u].x];
+    }
+    for (long long k0 = wave * step; k0 < Z; k0 += nwaves * step) {
+        int2 v[FULL_UNROLL];
+        int4 ri[FULL_UNROLL], rj[FULL_UNROLL];
+        int row[FULL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FULL_UNROLL; u++) {
+            v[u] = gv[u];
+            row[u] = grow[u];
+            ri[u] = gri[u];
+            rj[u] = grj[u];
+        }
+#pragma unroll
+        for (int u = 0; u < FULL_UNROLL; u++) {
+            gv[u] = nv[u];
+            grow[u] = nr[u];
+            gri[u] = rec[grow[u]];
+            grj[u] = rec[gv[u].x];
+        }
+#pragma unroll
+        for (int u = 0; u < FULL_UNROLL; u++) {
+            const long long k = min(k0 + 2 * nwaves * step + u * 64 + lane, Z - 1);
+            nv[u] = ld_stream(cc + k);
+            nr[u] = ld_stream(crow + k);
+        }
+        double t[FULL_UNROLL];
+        bool rare[FULL_UNROLL], any_rare = false, any_big = false;
+        unsigned long long bits[FULL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FULL_UNROLL; u++) {
+            const unsigned o_b = (unsigned)v[u].y;
+            const bool cis = ri[u].z == rj[u].z;
+            const unsigned d = abs_diff_u32((unsigned)ri[u].w, (unsigned)rj[u].w);
+            const float sv = fabsf(__int_as_float(ri[u].x) - __int_as_float(rj[u].x));
+            const bool in = cis && (sv > 0.0f) && (sv < d_max);
+            const double pzc = L.pzc[cis ? min(d, (unsigned)LDS_PZ) : (unsigned)LDS_PZ];
+            const double lgf = L.lgf[min(o_b, (unsigned)(LDS_LGF - 1))];
+            const double y = ig_fma(slope, ig_log2_pos((double)sv, T), la);
+            const double yy = in ? __builtin_fmax(y, lv) : lv; /* in: y is a number */
+            const double ex = ig_exp2_core(yy, T);
+            const double lg = yy * IG_LOG2_10_INV;
+            t[u] = (ig_fma((double)o_b, lg, -ex) - lgf) + pzc;
+            rare[u] = (o_b - 1u >= (unsigned)(LDS_LGF - 1)) || (cis && (d >= cut || __int_as_float(ri[u].y) != 0.0f)) || checked;
+            bits[u] = ig_d2u(ig_fma(t[u], IG_QSCALE, IG_QMAGIC));
+            any_rare |= rare[u];
+            any_big |= !(__builtin_fabs(t[u]) < 524288.0);
+        }
+        if (__any(any_big)) {
+#pragma unroll
+            for (int u = 0; u < FULL_UNROLL; u++)
+                if (!(__builtin_fabs(t[u]) < 524288.0)) bits[u] = (unsigned long long)ig_quantize(t[u]) + IG_QMAGIC_BITS;
+        }
+        if (__any(any_rare)) {
+#pragma unroll
+            for (int u = 0; u < FULL_UNROLL; u++)
+                if (rare[u]) {
+                    const int cis = ri[u].z == rj[u].z;
+                    const float sv = fabsf(__int_as_float(ri[u].x) - __int_as_float(rj[u].x));
+                    const int d = (int)abs_diff_u32((unsigned)ri[u].w, (unsigned)rj[u].w);
+                    bits[u] = (unsigned long long)full_q_general(p, mean, cis, sv, d, __int_as_float(ri[u].y), len[row[u]], v[u].y, lgf_tab) +
+                              IG_QMAGIC_BITS;
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < FULL_UNROLL; u++) {
+            if (k0 + u * 64 + lane < Z) {
+                acc += bits[u] - IG_QMAGIC_BITS;
+                accl += (unsigned)bits[u];
+            }
+        }
+    }
+    /* lane sums < 2^63 (|q| < 2^52, far fewer than 2^11 contacts per lane per launch is not guaranteed: fold as limbs) */
+    long long hi = ((long long)acc - (long long)accl) >> 32, lo = (long long)accl;
+    hi = wave_sum_ll(hi);
+    lo = wave_sum_ll(lo);
+    if (lane == 0) {
+        red[0][threadIdx.x >> 6] = hi;
+        red[1][threadIdx.x >> 6] = lo;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { /* one pair of atomics per workgroup (thousands of waves on two addresses serialise) */
+        atomic_add_ll(&out[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomic_add_ll(&out[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
     }
 }
 

@@ -28,80 +28,13 @@ __global__ void k_fill_tables(State st, const SubTab* __restrict__ sub, Tables t
     t.len[s] = st.SL[f];
 }
 
-#define FULL_UNROLL 4
-/* evaluate_likelihood_sparse (KA:4374-4488) over the whole CSR, exact sums -> out[0..1].  One wave per CSR row; the
- * log2/exp2 tables of the contract in LDS, the zero-pixel companion P_z from the table of parameter set `which`. */
-__global__ void __launch_bounds__(256) k_full_nz(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables t, const Glob* g,
-                                                 int which, const double* __restrict__ lgf_tab, int M, int rank, int world,
-                                                 long long* out, PzTab pz)
+/* (dist, s_tot, contig, rank) of every sub-fragment in one 16-byte record: one gather per contact endpoint in k_full_nz */
+__global__ void k_pack_tab(Tables t, int M, int4* __restrict__ rec)
 {
-    __shared__ double mt_s[IG_TAB_SIZE];
-    {
-        const double* T0 = ig_tab();
-        for (int i = threadIdx.x; i < IG_TAB_SIZE; i += blockDim.x) mt_s[i] = T0[i];
-    }
-    __syncthreads();
-    const ig_params p = g->par[which];
-    const ig_hot hot = ig_hot_make(p, ig_tab());
-    const float mean = g->mean_kb;
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    long long hi = 0, lo = 0;
-    for (int i = wave; i < M; i += nwaves) {
-        if (world > 1 && (i % world) != rank) continue;
-        const long long b = rowptr[i], e = rowptr[i + 1];
-        if (b == e) continue;
-        const float di = t.dist[i], sti = t.stot[i];
-        const int2 cpi = t.cp[i];
-        const int ci = cpi.x, pi = cpi.y, li = t.len[i];
-        /* FULL_UNROLL x 64 contacts of the row in flight: coalesced 8-byte loads, then both gathers of every contact */
-        for (long long k0 = b; k0 < e; k0 += 64 * FULL_UNROLL) {
-            int2 v[FULL_UNROLL], cpj[FULL_UNROLL];
-            float dj[FULL_UNROLL];
-#pragma unroll
-            for (int u = 0; u < FULL_UNROLL; u++) {
-                const long long k = k0 + u * 64 + lane;
-                v[u] = (k < e) ? cc[k] : make_int2(-1, 0);
-            }
-#pragma unroll
-            for (int u = 0; u < FULL_UNROLL; u++) {
-                const int j = v[u].x >= 0 ? v[u].x : i;
-                cpj[u] = t.cp[j];
-                dj[u] = t.dist[j];
-            }
-#pragma unroll
-            for (int u = 0; u < FULL_UNROLL; u++) {
-                if (v[u].x < 0) continue;
-                const int ob = v[u].y;
-                const float s = fabsf(di - dj[u]);
-                const int dp = pi - cpj[u].y;
-                const int d = dp < 0 ? -dp : dp;
-                const double lgf = lgfact_dev(ob, lgf_tab);
-                double term;
-                if (ci == cpj[u].x && sti == 0 && hot.fast && ob > 0) /* the hot case of ig_pair_term with P_z from its table */
-                    term = ig_term_hot(s, 0, ob, lgf, pz_lookup(pz, p, mean, d), &hot, mt_s);
-                else
-                    term = ig_pair_term(p, &hot, ci == cpj[u].x, s, (float)d * mean, sti, (float)li * mean, ob, lgf, mt_s);
-                const long long q = ig_quantize(term);
-                hi += q >> 32;
-                lo += (long long)(unsigned int)q;
-            }
-        }
-    }
-    /* one pair of atomics per workgroup (thousands of waves on two addresses serialise) */
-    __shared__ long long red[2][4];
-    hi = wave_sum_ll(hi);
-    lo = wave_sum_ll(lo);
-    if (lane == 0) {
-        red[0][threadIdx.x >> 6] = hi;
-        red[1][threadIdx.x >> 6] = lo;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomic_add_ll(&out[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomic_add_ll(&out[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
-    }
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= M) return;
+    const int2 cp = t.cp[s];
+    rec[s] = make_int4(__float_as_int(t.dist[s]), __float_as_int(t.stot[s]), cp.x, cp.y);
 }
 
 /* eval_likelihood_on_zero (KA:3850-3917) over all sub-fragments -> out[0..2] = hi, lo, n_intra */
