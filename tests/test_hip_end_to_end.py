@@ -85,6 +85,7 @@ def test_text_folder_to_assembly_matches_oracle_replay(tmp_path, id_start_sample
 def test_two_processes_batch_runner():
     """two real processes (torch.distributed.run) sharing the one GPU of the test box, gloo collectives: the slot-split
     BatchRunner of every rank reproduces ig_step_batch bit for bit (tests/_two_rank_worker.py)"""
+    import signal
     import socket
     import subprocess
     import sys
@@ -95,14 +96,17 @@ def test_two_processes_batch_runner():
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(here, "_two_rank_worker.py")]
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
         try:
-            r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                                "127.0.0.1", "--master-port", str(port), os.path.join(here, "_two_rank_worker.py")], capture_output=True,
-                               text=True, timeout=150)
-        except subprocess.TimeoutExpired as e:
-            last = "timeout: %s" % ((e.stdout or b"")[-2000:],)
+            out, err = p.communicate(timeout=150)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)  # the launcher and its two workers (own process group)
+            out, err = p.communicate()
+            last = "timeout: " + out[-1000:] + err[-2000:]
             continue
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-        assert "TWO_RANK_OK" in r.stdout
+        assert p.returncode == 0, out[-2000:] + err[-4000:]
+        assert "TWO_RANK_OK" in out
         return
     raise AssertionError(last)
