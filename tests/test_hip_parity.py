@@ -67,6 +67,39 @@ def test_full_likelihood_matches_oracle(tiny, oracle_lib):
     assert np.array_equal(p, s.vect_pos) and np.array_equal(ln, s.vect_len) and np.array_equal(st, s.vect_s_tot)
 
 
+def test_full_likelihood_rare_operands(oracle_lib):
+    """the from-scratch pass on the operands its straight-line term does not cover: counts >= 256 (beyond the LDS
+    log-factorial table) and >= 1024 (Stirling branch), and parameters outside the one-log domain of the contract
+    (slope 0: the generic composition for every contact).  Bit-exact limbs against the oracle."""
+    import copy
+
+    import scipy.sparse as sp
+
+    from instagraal_amd import synth
+    from oracle.sampler_oracle import OracleSampler
+
+    ol = oracle_lib
+    prob = copy.deepcopy(synth.make_problem(*synth.CONFIGS["tiny"]))
+    cnt = prob.coo_cnt.copy()
+    cnt[::7] *= 60    # 60 .. a few hundred
+    cnt[::131] *= 400  # thousands
+    assert (cnt >= 256).sum() > 50 and (cnt >= 1024).sum() > 5
+    prob.coo_cnt = cnt
+    M = prob.n_sub_frags
+    prob.sub_csr = sp.csr_matrix((cnt, (prob.coo_row, prob.coo_col)), shape=(M, M), dtype=np.int32)
+    prob.sub_csr.sort_indices()
+    for params in (prob.params, dict(prob.params, slope=0.0)):
+        ctx = make_ctx(prob, params=params)
+        s = OracleSampler(**prob.sampler_kwargs(), mode=ol.MODE_DET)
+        s.set_param_simu(params)
+        s.eval_likelihood_init()
+        hi, lo = ol.last_limbs()
+        nz, z, limbs = ctx.full_likelihood()
+        assert nz == float(s.gpu_curr_likelihood_nz[0])
+        assert (int(limbs[0]), int(limbs[1])) == (int(hi[0]), int(lo[0]))
+        ctx.close()
+
+
 # the nuisance trajectory (tiny_nuis) is replayed through the sampler class in tests/test_hip_sampler.py
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "tiny_*_mode1.npz")) if "nuis" not in p)
 
