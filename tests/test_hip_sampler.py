@@ -30,6 +30,47 @@ def make_pair(cfg, mode=1):
     return prob, s, o
 
 
+def test_moves_with_large_counts_live_oracle():
+    """contacts with counts >= 256 (beyond the LDS log-factorial table of the hot kernel) and >= 1024 (Stirling branch) in the
+    slices of the moves: the fix-up path of k_score_list / k_delta / k_tail.  Scores bit-exact, same winners, same genome."""
+    import copy
+
+    import scipy.sparse as sp
+
+    from instagraal_amd import synth
+    from instagraal_amd.sampler import sampler as hip_sampler
+    from oracle import oracle_lib as ol
+    from oracle.sampler_oracle import OracleSampler
+
+    ol.build()
+    prob = copy.deepcopy(synth.make_problem(*synth.CONFIGS["tiny"]))
+    cnt = prob.coo_cnt.copy()
+    cnt[::5] *= 70
+    cnt[::53] *= 500
+    prob.coo_cnt = cnt
+    M = prob.n_sub_frags
+    prob.sub_csr = sp.csr_matrix((cnt, (prob.coo_row, prob.coo_col)), shape=(M, M), dtype=np.int32)
+    prob.sub_csr.sort_indices()
+    kw = prob.sampler_kwargs()
+    s = hip_sampler(**kw, device_id=0)
+    o = OracleSampler(**kw, mode=ol.MODE_DET)
+    for x in (s, o):
+        x.set_param_simu(prob.params)
+        x.bins = np.arange(1.0, 60.0, 1.0)
+        x.eval_likelihood_init()
+    assert float(s.curr_likelihood_on_nz[0]) == float(o.gpu_curr_likelihood_nz[0])
+    np.random.seed(5)
+    frags = np.arange(prob.n_frags)
+    np.random.shuffle(frags)
+    for f in frags[:40]:
+        cands = s.return_neighbours(int(f), 5)
+        a = s.step_sampler(int(f), 5, candidates=cands)
+        b = o.step_sampler(int(f), 5, o.dt, candidates=cands)
+        assert np.array_equal(s.all_scores, o.all_scores)
+        assert (a[0], a[1], a[2], a[3], float(a[4]), int(a[5])) == (b[0], b[1], b[2], b[3], float(b[4]), int(b[5]))
+    assert np.array_equal(s.gpu_vect_frags.copy_from_gpu().soa17(), o.gpu_vect_frags.soa17())
+
+
 def test_small_problem_live_oracle():
     """N=1000 / Z=150k, 40 moves with the reference's own candidate draw: scores bit-exact, same
     winner, same return tuple; final genome identical field by field."""
