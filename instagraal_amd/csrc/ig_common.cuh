@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -207,6 +208,8 @@ struct ig_ctx {
     MoveBuf mb;
     int* stamp;     /* [N] claim stamps of the incremental genome distance */
     int* batch_out; /* [4] committed moves, pending slot, windows above LDS_COL_SMALL, candidates */
+    int *host_bo, *host_bo_dev; /* the same in mapped host memory (+ [7] = sequence number of the decide launch), and its device address */
+    int bo_seq;
     int* dirty_buf; /* [1 + 2 * IG_MAX_BATCH + 2] contigs modified by the committed moves of the batch in flight */
     int *own_tag, *own_idx; /* [N] which committed move of the current batch owns a fragment, and where in its window */
     ig_move_result* d_results;

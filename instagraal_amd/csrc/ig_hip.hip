@@ -102,6 +102,9 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     memset((void*)&c->mb, 0, sizeof c->mb);
     c->device = device_id;
     c->own_stream = true;
+    c->host_bo = nullptr;
+    c->host_bo_dev = nullptr;
+    c->bo_seq = 0;
     c->rank = 0;
     c->world = 1;
     c->N = c->M = 0;
@@ -217,6 +220,7 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipStreamDestroy(c->stream2);
     hipEventDestroy(c->ev_slice);
     hipEventDestroy(c->ev_tail);
+    if (c->host_bo) hipHostFree(c->host_bo);
     drain_timers(c);
     free_move_buffers(c);
     hipFree(c->st_block);
@@ -331,6 +335,21 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
     HIPCK(hipMemset(c->own_tag, 0xff, N * sizeof(int)));
     DALLOC(c->stamp, N);
     DALLOC(c->batch_out, 8);
+    if (!c->host_bo && !(getenv("IG_NO_HOST_FLAG") && atoi(getenv("IG_NO_HOST_FLAG")))) {
+        /* the batch outcome is also written to mapped host memory (commit_loop polls it); without it: copy + synchronise */
+        int* hp = nullptr;
+        if (hipHostMalloc((void**)&hp, 8 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+                memset(hp, 0, 8 * sizeof(int));
+                c->host_bo = hp;
+                c->host_bo_dev = (int*)dp;
+            } else {
+                hipHostFree(hp);
+            }
+        }
+        (void)hipGetLastError();
+    }
     DALLOC(c->dirty_buf, 2 * IG_MAX_BATCH + 4);
     HIPCK(hipMemset(m.cmeta, 0, C * NSLOT * NCODE * sizeof(ColMeta)));
     HIPCK(hipMemset(m.slbound, 0, C * SLICE_SEG * sizeof(long long)));
@@ -877,7 +896,7 @@ static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
         {
             TimedLaunch t(c, T_COMMIT);
             hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(64), 0, c->stream, c->glob, c->mb, c->d_results, done, w_now, next,
-                               c->dirty_buf, c->batch_out);
+                               c->dirty_buf, c->batch_out, (volatile int*)c->host_bo_dev, ++c->bo_seq);
             if (c->own_begin > 0 || c->own_end < w_now)
                 hipLaunchKernelGGL(k_mutate_winners, dim3(2, w_now), dim3(256), 0, c->stream, c->st, c->tab, c->sub_tab, c->rowptr,
                                    c->glob, c->mb, PzTab{c->pz_tab, c->pz_n}, next, c->own_begin, c->own_end, c->batch_out);
@@ -886,8 +905,30 @@ static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
                                c->prev_touched, c->d_results, done, w_now, next, c->batch_out);
         }
         int bo[8];
-        HIPCK(hipMemcpyAsync(bo, c->batch_out, sizeof bo, hipMemcpyDeviceToHost, c->stream));
-        HIPCK(hipStreamSynchronize(c->stream));
+        if (c->host_bo) {
+            /* spin on the mapped copy k_decide_batch writes; every so often make sure the stream is still alive (a fault
+             * must not hang the host) and fall back to the device copy when the stream has drained without the flag */
+            volatile int* hb = c->host_bo;
+            bool got = false;
+            for (unsigned spin = 0; !got; spin++) {
+                if (hb[7] == c->bo_seq) {
+                    got = true;
+                } else if ((spin & 0xfff) == 0xfff) {
+                    const hipError_t q = hipStreamQuery(c->stream);
+                    if (q == hipSuccess) break;
+                    if (q != hipErrorNotReady) return fail("batch commit failed: %s", hipGetErrorString(q));
+                }
+            }
+            if (got) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                for (int i = 0; i < 8; i++) bo[i] = hb[i];
+            } else {
+                HIPCK(hipMemcpy(bo, c->batch_out, sizeof bo, hipMemcpyDeviceToHost));
+            }
+        } else {
+            HIPCK(hipMemcpyAsync(bo, c->batch_out, sizeof bo, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(hipStreamSynchronize(c->stream));
+        }
         if (next == 0) {
             c->n_batches++;
             c->large_seen = (bo[2] * 4 > bo[3]); /* a quarter of the windows above LDS_COL_SMALL: launch the large variant too */

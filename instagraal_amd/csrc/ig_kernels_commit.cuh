@@ -304,7 +304,8 @@ __device__ __forceinline__ int credit2_view(V view, const int* ip, const int* in
 /* step 1 of the batch commit: ONE wave (it may use the whole register file: the data of the next move is held in
  * registers while the current one is decided) */
 __global__ void __launch_bounds__(64)
-    k_decide_batch(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out)
+    k_decide_batch(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out,
+                   volatile int* host_out, int seq)
 {
     /* w_start > 0: slot w_start - 1 was the pending move, meanwhile applied by the one-move kernels; the rest of the batch
      * is still valid wherever it does not touch a contig modified so far (dirty_buf carries the list across the calls) */
@@ -578,6 +579,17 @@ __global__ void __launch_bounds__(64)
             batch_out[2] = n_large;
             batch_out[3] = n_cand;
             batch_out[4] = n_predicted;
+            /* the host polls this copy (mapped, coherent host memory): it learns the outcome while k_commit_batch is still
+             * running and has the next launches queued behind it when it ends */
+            if (host_out) {
+                host_out[0] = committed;
+                host_out[1] = pending;
+                host_out[2] = n_large;
+                host_out[3] = n_cand;
+                host_out[4] = n_predicted;
+                __threadfence_system();
+                host_out[7] = seq;
+            }
         }
         if (lane < 12) g->valid_insert[lane] = ((vmask >> lane) & 1u) ? 1 : -1;
     }
