@@ -234,7 +234,6 @@ struct ig_ctx {
         long long n;
     } timers[10];
     long long n_batches, n_batch_committed, n_batch_pending, n_batch_predicted;
-    int large_seen;
     int up_moves, up_max_c; /* the uploaded move lists */
     int own_begin, own_end; /* slots whose candidate genomes this handle built for the batch in flight */
     bool have_contacts, have_sub, have_state, have_init, have_params;

@@ -20,7 +20,7 @@
  *   k_commit_batch  1 workgroup     winners applied together, exact genome-distance deltas, result records
  * plus the one-move kernels k_scores / k_delta / k_apply / k_post / k_commit (single moves, windowed winners).
  *
- * Environment knobs (tuning and tests only): IG_BATCH_W (moves per batch, default 24), IG_LARGE (force the 32 KB-column variant on/off), IG_POOL_ENTRIES (slice pool size), IG_ABLATE (skip the
+ * Environment knobs (tuning and tests only): IG_BATCH_W (moves per batch, default 24), IG_POOL_ENTRIES (slice pool size), IG_ABLATE (skip the
  * term arithmetic: timing floor).
  */
 #include "ig_common.cuh"
@@ -134,7 +134,6 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->timing_mask = 0xffff;
     c->timing = false;
     c->n_batches = c->n_batch_committed = c->n_batch_pending = c->n_batch_predicted = 0;
-    c->large_seen = 1;
     c->up_moves = c->up_max_c = 0;
     c->own_begin = c->own_end = 0;
     for (int i = 0; i < T_COUNT; i++) {
@@ -807,15 +806,8 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
             TimedLaunch t(c, T_SCORE);
             const int s_eb = SLICE_SEG; /* one workgroup per (segment, column, candidate) */
             static int s_abl = getenv("IG_ABLATE") ? atoi(getenv("IG_ABLATE")) : 0;
-            /* the large-window variant is launched only when the previous batch saw windows above LDS_COL_SMALL
-             * sub-fragments; without it the small variant serves every window (unstaged above its cap) */
-            static int s_large = getenv("IG_LARGE") ? atoi(getenv("IG_LARGE")) : -1;
-            const int large_on = s_large >= 0 ? s_large : c->large_seen;
             hipLaunchKernelGGL(k_score_list<LDS_COL_SMALL>, dim3(s_eb, NSLOT, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->score_const,
-                               c->mb, c->lgf_tab, pz, s_abl, max_c, large_on, w_begin);
-            if (large_on)
-                hipLaunchKernelGGL(k_score_list<LDS_COL_CAP>, dim3(s_eb, NSLOT, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->score_const,
-                                   c->mb, c->lgf_tab, pz, s_abl, max_c, large_on, w_begin);
+                               c->mb, c->lgf_tab, pz, s_abl, max_c, w_begin);
         }
     }
     if (phase == 1 || phase == 2) {
@@ -931,7 +923,6 @@ static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
         }
         if (next == 0) {
             c->n_batches++;
-            c->large_seen = (bo[2] * 4 > bo[3]); /* a quarter of the windows above LDS_COL_SMALL: launch the large variant too */
         }
         c->n_batch_committed += bo[0] - next;
         c->n_batch_predicted += bo[4];

@@ -722,9 +722,9 @@ __device__ __forceinline__ void score_loop(const ScoreArgs& a, const ig_hot& h, 
  * Staged in LDS: the tables (ScoreTables, one 13 KB copy) and the column (8 B per local sub-fragment).  Waves stream the
  * slice list (coalesced 8-byte entries), read both endpoints' coordinates from LDS, evaluate the Rippe / Poisson term
  * and add it as an exact integer.  Wave shuffles, one LDS step, two atomics per workgroup.
- * Two instantiations per launch site: windows of <= LDS_COL_SMALL sub-fragments (8 KB column) and -- launched when a
- * quarter of the previous batch's windows were larger -- LDS_COL_CAP; a window above the cap of the instance that
- * serves it is not staged (gathers from L2). */
+ * Windows above LDS_COL_SMALL sub-fragments are not staged: 8-byte gathers of the coordinates from L2 (a second instance of
+ * the loop behind a uniform branch).  A 32 KB-column instance for them was measured slower (3 waves / SIMD) even on windows
+ * of thousands of sub-fragments and is gone. */
 #define LDS_COL_SMALL 1024
 /* what every workgroup of k_score_list stages: built once per parameter set (k_build_score_const), copied to LDS as is */
 struct ScoreTables {
@@ -764,7 +764,7 @@ struct ScoreLds {
 template <int CAP>
 __global__ void __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(SCORE_WAVES)))
     k_score_list(const ScoreConst* __restrict__ sc, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int ablate, int max_c,
-                 int large_on, int w_begin)
+                 int w_begin)
 {
     __shared__ ScoreLds<CAP> L;
     /* everything the early exits and the set-up need is loaded before the first branch: one round trip, not five */
@@ -779,7 +779,6 @@ __global__ void __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per
     const ig_hot hp = sc->hot;
     const float mean = sc->mean_kb;
     if (c >= C || k > n_uniq || n == 0 || off < 0) return;
-    if (large_on && ((CAP == LDS_COL_SMALL) != (m_loc <= LDS_COL_SMALL))) return;
     const int M = mb.M;
     const uint2* gcol = mb.coords + (size_t)(cw * NSLOT + k) * M;
     const bool staged = m_loc <= CAP;
