@@ -921,9 +921,7 @@ static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
             HIPCK(hipMemcpyAsync(bo, c->batch_out, sizeof bo, hipMemcpyDeviceToHost, c->stream));
             HIPCK(hipStreamSynchronize(c->stream));
         }
-        if (next == 0) {
-            c->n_batches++;
-        }
+        if (next == 0) c->n_batches++;
         c->n_batch_committed += bo[0] - next;
         c->n_batch_predicted += bo[4];
         next = bo[0];
