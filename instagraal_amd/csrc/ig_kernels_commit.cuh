@@ -301,6 +301,9 @@ __device__ __forceinline__ int credit2_view(V view, const int* ip, const int* in
  *    before / just after that move, read through the marks), state + coordinate tables, the distance column of the
  *    results.  tab_prev receives every committed move but the last one (quirk Q12: tables before the last move). */
 #define COMMIT_THREADS 1024
+#ifndef COMMIT_GROUP
+#define COMMIT_GROUP 512 /* threads that apply one move together */
+#endif
 /* step 1 of the batch commit: ONE wave (it may use the whole register file: the data of the next move is held in
  * registers while the current one is decided) */
 __global__ void __launch_bounds__(64)
@@ -603,6 +606,7 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
 {
     __shared__ long long sh_delta[IG_MAX_BATCH];
     const int tid = threadIdx.x, lane = tid & 63;
+    const int grp = tid / COMMIT_GROUP, gtid = tid % COMMIT_GROUP, ngrp = COMMIT_THREADS / COMMIT_GROUP;
     const int tag_base = g->stamp_ctr; /* tags/stamps of this batch: tag_base + w */
     if (tid < IG_MAX_BATCH) sh_delta[tid] = 0;
     const int committed = batch_out[0];
@@ -614,14 +618,17 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
         const MoveCtl& mc = mb.ctl[w];
         return mb.loc + ((size_t)(CW(w, mc.ch_c) * NSLOT + mc.ch_slot) * NDYN) * N;
     };
-    /* 2a. ownership marks of the fragments whose state changes */
-    for (int w = w_start; w < committed; w++) {
+    /* The committed moves touch pairwise disjoint contigs: in every step below a group of COMMIT_GROUP threads takes a move
+     * (moves grp, grp + ngrp, ...), so that the chains of dependent loads of several moves (control block -> window ->
+     * fragment) overlap instead of being walked one move after the other by the whole workgroup.
+     * 2a. ownership marks of the fragments whose state changes */
+    for (int w = w_start + grp; w < committed; w += ngrp) {
         const MoveCtl& mc = mb.ctl[w];
         if (!mc.n_dirty) continue;
         const int cw = CW(w, mc.ch_c);
         const int n_loc = mb.meta[cw].n_loc;
         const int* gid = mb.Lloc + (size_t)cw * N;
-        for (int x = tid; x < n_loc; x += blockDim.x) {
+        for (int x = gtid; x < n_loc; x += COMMIT_GROUP) {
             const int f = gid[x];
             own_tag[f] = tag_base + w;
             own_idx[f] = x;
@@ -631,7 +638,7 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
     /* 2b. genome distance: credit(f) depends on prev/next/ori of f and on the orientation of its INITIAL neighbours
      * (CL:665-716), so move w can change the credits of its window and of the window's initial neighbours only; each is
      * evaluated on the genome as of move w-1 and as of move w (moves < t applied, read through the marks) */
-    for (int w = w_start; w < committed; w++) {
+    for (int w = w_start + grp; w < committed; w += ngrp) {
         const MoveCtl& mc = mb.ctl[w];
         if (!mc.n_dirty) continue;
         const int cw = CW(w, mc.ch_c);
@@ -639,7 +646,7 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
         const int* gid = mb.Lloc + (size_t)cw * N;
         const int stampv = tag_base + w + 1; /* != 0 */
         long long d = 0;
-        for (int item = tid; item < 3 * n_loc; item += blockDim.x) {
+        for (int item = gtid; item < 3 * n_loc; item += COMMIT_GROUP) {
             const int f0 = gid[item / 3];
             const int q = item % 3;
             const int f = (q == 0) ? f0 : ((q == 1) ? ip[f0] : in[f0]);
@@ -672,16 +679,16 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
         tab_prev.len[s2] = tab.len[s2];
     }
     __syncthreads();
-    for (int w = w_start; w < committed; w++) {
+    for (int w = w_start + grp; w < committed; w += ngrp) {
         const MoveCtl& mc = mb.ctl[w];
         const int cw = CW(w, mc.ch_c);
         const CandMeta& m = mb.meta[cw];
         const bool last = (w == committed - 1);
-        if (last && tid == 0) g->n_prev_touched = mc.n_dirty ? m.m_loc : 0;
+        if (last && gtid == 0) g->n_prev_touched = mc.n_dirty ? m.m_loc : 0;
         if (!mc.n_dirty) continue;
         const int* base = winner_loc(w);
         const int* gid = mb.Lloc + (size_t)cw * N;
-        for (int x = tid; x < m.n_loc; x += blockDim.x) {
+        for (int x = gtid; x < m.n_loc; x += COMMIT_GROUP) {
             const int f = gid[x];
             st.pos[f] = base[x];
             st.spos[f] = base[(size_t)N + x];
@@ -700,7 +707,7 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
         const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
         const int* subs = mb.subs + (size_t)cw * M;
         const int fresh = mc.fresh;
-        for (int ls = tid; ls < m.m_loc; ls += blockDim.x) {
+        for (int ls = gtid; ls < m.m_loc; ls += COMMIT_GROUP) {
             const int s = subs[ls];
             const uint2 v = col[ls];
             const int code = (int)(v.y >> 28);
