@@ -207,7 +207,7 @@ struct ig_ctx {
     long long* scratch8; /* 8 x int64 reduction scratch of the from-scratch passes */
     MoveBuf mb;
     int* stamp;     /* [N] claim stamps of the incremental genome distance */
-    int* batch_out; /* [4] committed moves, pending slot, windows above LDS_COL_SMALL, candidates */
+    int* batch_out; /* committed moves, pending slot, (unused), candidates, predicted deltas used */
     int *host_bo, *host_bo_dev; /* the same in mapped host memory (+ [7] = sequence number of the decide launch), and its device address */
     int bo_seq;
     int* dirty_buf; /* [1 + 2 * IG_MAX_BATCH + 2] contigs modified by the committed moves of the batch in flight */

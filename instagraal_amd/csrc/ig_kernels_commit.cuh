@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(64)
         const ig_params p = g->par[0];
         const double log_e = IG_LOG_E_F;
         const double n_tot_pxl = g->n_tot_pxl;
-        int n_dirty = 0, committed = w_start, pending = -1, n_large = 0, n_cand = 0, n_predicted = 0;
+        int n_dirty = 0, committed = w_start, pending = -1, n_cand = 0, n_predicted = 0;
         if (w_start > 0) {
             n_dirty = dirty_buf[0];
             for (int q = lane; q < n_dirty; q += 64) dirty[q] = dirty_buf[1 + q];
@@ -393,7 +393,6 @@ __global__ void __launch_bounds__(64)
             bool hitd = false;
             for (int q = 0; q < n_dirty; q++) hitd |= (dirty[q] == d.cand.ctgA) | (dirty[q] == d.cand.ctgB);
             if (err0 || rl(d.cand.overflow, 0) || __any(hitd && lane < C)) break;
-            n_large += __popcll(__ballot(lane < C && d.cand.m_loc > LDS_COL_SMALL));
             n_cand += C;
             /* scores (eval_all_likelihood_on_zero_2nd KA:4005-4027, eval_all_scores KA:4029-4046) with the live scalars */
             const double cur_nz = ig_acc_to_double(nz_hi, nz_lo);
@@ -579,7 +578,7 @@ __global__ void __launch_bounds__(64)
             for (int q = 0; q < n_dirty; q++) dirty_buf[1 + q] = dirty[q];
             batch_out[0] = committed;
             batch_out[1] = pending;
-            batch_out[2] = n_large;
+            batch_out[2] = 0;
             batch_out[3] = n_cand;
             batch_out[4] = n_predicted;
             /* the host polls this copy (mapped, coherent host memory): it learns the outcome while k_commit_batch is still
@@ -587,7 +586,7 @@ __global__ void __launch_bounds__(64)
             if (host_out) {
                 host_out[0] = committed;
                 host_out[1] = pending;
-                host_out[2] = n_large;
+                host_out[2] = 0;
                 host_out[3] = n_cand;
                 host_out[4] = n_predicted;
                 __threadfence_system();
