@@ -20,8 +20,10 @@
  *   k_commit_batch  1 workgroup     winners applied together, exact genome-distance deltas, result records
  * plus the one-move kernels k_scores / k_delta / k_apply / k_post / k_commit (single moves, windowed winners).
  *
- * Environment knobs (tuning and tests only): IG_BATCH_W (moves per batch, default 24), IG_POOL_ENTRIES (slice pool size), IG_ABLATE (skip the
- * term arithmetic: timing floor).
+ * Environment knobs (tuning and tests only): IG_BATCH_W (moves per batch, default 24), IG_POOL_ENTRIES (slice pool size: a small
+ * one forces the overflow / re-run path), IG_WIDE_LISTS=1 (12-byte slice entries even where the packed 8-byte form fits),
+ * IG_NO_HOST_FLAG=1 (batch outcome by copy + synchronise instead of the polled mapped copy), IG_FULL_WGS (grid of k_full_nz),
+ * IG_ABLATE (bit 1: every column of k_score_list through the checked path).
  */
 #include "ig_common.cuh"
 #include "ig_model.cuh"
@@ -805,7 +807,7 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
             }
             TimedLaunch t(c, T_SCORE);
             const int s_eb = SLICE_SEG; /* one workgroup per (segment, column, candidate) */
-            static int s_abl = getenv("IG_ABLATE") ? atoi(getenv("IG_ABLATE")) : 0;
+            const int s_abl = getenv("IG_ABLATE") ? atoi(getenv("IG_ABLATE")) : 0; /* read per launch: a test toggles it */
             hipLaunchKernelGGL(k_score_list<LDS_COL_SMALL>, dim3(s_eb, NSLOT, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->score_const,
                                c->mb, c->lgf_tab, pz, s_abl, max_c, w_begin);
         }

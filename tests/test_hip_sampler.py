@@ -208,6 +208,27 @@ def test_large_windows_match_oracle():
     assert np.array_equal(s.gpu_vect_frags.copy_from_gpu().soa17(), o.gpu_vect_frags.soa17())
 
 
+def test_checked_scoring_path_equals_the_hot_one(monkeypatch):
+    """IG_ABLATE=2 sends every column of k_score_list through the out-of-line checked loop (the one windows with a circular
+    contig or parameters outside the one-log domain take): result records, genome and exact sums identical to the hot loop"""
+    from instagraal_amd import synth
+    from instagraal_amd.sampler import sampler as hip_sampler
+
+    prob = synth.make_problem(*synth.CONFIGS["small"])
+    runs = []
+    for abl in ("0", "2"):
+        monkeypatch.setenv("IG_ABLATE", abl)
+        s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
+        s.set_param_simu(prob.params)
+        s.eval_likelihood_init()
+        np.random.seed(9)
+        frags = np.random.permutation(prob.n_frags)[:60].astype(np.int32)
+        res = s.ctx.step_batch(frags, s.draw_candidates(frags, 5))
+        runs.append((res.tobytes(), s.gpu_vect_frags.copy_from_gpu().soa17().tobytes(), [int(x) for x in s.ctx.full_likelihood(0)[2][:2]]))
+        s.free_gpu()
+    assert runs[0] == runs[1]
+
+
 def test_slice_pool_overflow_reruns_the_slot(monkeypatch):
     """a pool that holds one move's slice lists but not a batch's: the slots that do not fit are flagged by k_offsets and
     re-run at the head of the next batch; results identical to the roomy pool"""
