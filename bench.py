@@ -169,15 +169,17 @@ def main():
         achieved = bytes_min / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
         # WRITE_SIZE, separate passes; profiles/*_pmc_traffic.json): a committed measurement of THIS workload, or null
-        traffic = None
+        traffic = valu_busy = None
         try:
             import glob
 
             pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_pmc_traffic.json" % a.config)))
             if pmc and world == 1:
-                traffic = float(json.load(open(pmc[-1]))["k_score_list"]["traffic_bytes_per_launch"])
+                prof = json.load(open(pmc[-1]))["k_score_list"]
+                traffic = float(prof["traffic_bytes_per_launch"])
+                valu_busy = float(prof["VALUBusy_pct"]) / 100.0  # the bound that applies: fraction of cycles the VALUs issue
         except Exception:
-            traffic = None
+            traffic = valu_busy = None
         out = {
             "metric": "MCMC moves/s (accepted+rejected) at fixed n_frags x nnz",
             "value": a.steps / elapsed,
@@ -198,7 +200,7 @@ def main():
                 "term_evals_per_move": float(res["n_evals"].mean()), "moves_per_launch": a.steps / n_launch,
                 "batches": bstats, "maintained_likelihood_exact": exact_ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "kernel": "k_score_list", "avg_launch_ms": score_ms, "launches": int(n_launch),
+                         "traffic": traffic, "valu_busy_profiled": valu_busy, "kernel": "k_score_list", "avg_launch_ms": score_ms, "launches": int(n_launch),
                          "algorithmic_bytes_per_launch": bytes_min,
                          "term_evals_per_launch": n_evals,
                          "term_evals_per_s": (n_evals / (score_ms * 1e-3)) if score_ms > 0 else 0.0,

@@ -170,7 +170,9 @@ struct MoveBuf {
 };
 /* layout of MoveBuf.part per candidate (int64 units) */
 #define P_NZ 0                 /* [NSLOT][2] slice sums per column k (k=0: current = "extract") */
+#ifndef SLICE_SEG
 #define SLICE_SEG 16
+#endif
 #define P_CNT (NSLOT * 2)      /* [SLICE_SEG] kept entries per segment; S_c = their sum (slice_total) */
 #define P_STRIDE (NSLOT * 2 + SLICE_SEG)
 /* not all-reduced (computed redundantly on every rank) */
