@@ -715,15 +715,18 @@ extern "C" int ig_full_likelihood(ig_ctx* c, int which, int use_prev, double* nz
     long long h[8];
     HIPCK(hipMemcpyAsync(h, scratch, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
-    Glob hg;
-    HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));
     ig_acc_normalize((int64_t*)&h[0], (int64_t*)&h[1]);
     ig_acc_normalize((int64_t*)&h[2], (int64_t*)&h[3]);
     if (nz) *nz = ig_acc_to_double(h[0], h[1]);
     if (z) { /* CL:755-759 with the float log_e of the kernels replaced by the host's double constant */
         const double log_e = 0.43429448190325182;
+        double n_tot_pxl;
+        float v_inter;
+        const int vi_bits = (int)h[7];
+        memcpy(&n_tot_pxl, &h[5], sizeof n_tot_pxl); /* k_full_zero: n_tot_pxl and v_inter of the parameter set */
+        memcpy(&v_inter, &vi_bits, sizeof v_inter);
         const double val_intra = ig_acc_to_double(h[2], h[3]) * log_e;
-        const double val_inter = log_e * (hg.n_tot_pxl - (double)h[4]) * -1.0 * (double)hg.par[which].v_inter;
+        const double val_inter = log_e * (n_tot_pxl - (double)h[4]) * -1.0 * (double)v_inter;
         *z = val_intra + val_inter;
     }
     if (limbs5)

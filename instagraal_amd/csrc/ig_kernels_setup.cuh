@@ -60,6 +60,11 @@ __global__ void k_full_zero(Tables t, const Glob* g, int which, int M, long long
         atomic_add_ll(&out[1], lo);
         atomic_add_ll(&out[2], ni);
     }
+    /* what the host needs next to the sums to form the zero-pixel likelihood: one copy back instead of two */
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[3] = __double_as_longlong(g->n_tot_pxl);
+        out[5] = (long long)__float_as_int(g->par[which].v_inter);
+    }
 }
 
 __global__ void k_count_heads(State st, int N, int* out)
