@@ -793,7 +793,6 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
             {
                 TimedLaunch t(c, T_SLICE);
                 hipLaunchKernelGGL(k_offsets, dim3(1), dim3(OFFSETS_THREADS), 0, c->stream, c->mb, W, w_begin, w_end);
-                hipLaunchKernelGGL(k_offsets_seal, dim3(nW), dim3(128), 0, c->stream, c->mb, W, w_begin, w_end);
                 if (c->mb.packed)
                     hipLaunchKernelGGL(k_slice<true>, dim3(SLICE_RB, max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob,
                                        c->mb, c->rank, c->world, w_begin);

@@ -392,15 +392,12 @@ __global__ void __launch_bounds__(OFFSETS_THREADS) k_offsets(MoveBuf mb, int W, 
             }
         }
     }
-}
-
-/* a slot with a segment that does not fit is dropped as a whole: its first segment's offset is what k_slice and the
- * scoring kernels test */
-__global__ void k_offsets_seal(MoveBuf mb, int W, int w_begin, int w_end)
-{
-    const int w = w_begin + blockIdx.x;
-    if (w >= w_end || !mb.ctl[w].overflow) return;
-    for (int i = threadIdx.x; i < mb.capC * SLICE_SEG; i += blockDim.x) mb.sloff[(size_t)w * mb.capC * SLICE_SEG + i] = -1;
+    /* a slot that does not fit is re-run as a whole: all its segments are marked */
+    __syncthreads();
+    for (int q = 0; q < per; q++) {
+        const int i = tid * per + q;
+        if (i < n && bound_of(i) >= 0 && mb.ctl[i / SLICE_SEG / mb.capC].overflow) mb.sloff[i] = -1;
+    }
 }
 
 #define LDS_COL_CAP 4096  /* local sub-fragments whose column fits the 32 KB LDS stage */
