@@ -827,7 +827,6 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                 hipLaunchKernelGGL(k_predict, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, w_begin);
                 hipLaunchKernelGGL(k_delta, dim3(DELTA_RB, 2, nW), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->tab_prev,
                                    c->prev_touched, c->glob, c->mb, c->lgf_tab, pz, w_begin, 1);
-                hipLaunchKernelGGL(k_pred_pack, dim3((nW + 63) / 64), dim3(64), 0, c->stream, c->mb, w_begin, nW);
             }
         }
     }

@@ -1101,8 +1101,10 @@ __global__ void __launch_bounds__(SCORE_THREADS)
         hi = red[0][0] + red[0][1] + red[0][2] + red[0][3];
         lo = red[1][0] + red[1][1] + red[1][2] + red[1][3];
         if (hi | lo) {
-            atomic_add_ll(predicted ? &mc.pd_hi : &mc.d_hi, kk == 0 ? -hi : hi);
-            atomic_add_ll(predicted ? &mc.pd_lo : &mc.d_lo, kk == 0 ? -lo : lo);
+            /* a predicted winner's delta goes straight into the records (candidate 0 of the slot): the decide step reads it there */
+            CandPre& pc = cpre_at(mb, CW(w, 0));
+            atomic_add_ll(predicted ? &pc.pd_hi : &mc.d_hi, kk == 0 ? -hi : hi);
+            atomic_add_ll(predicted ? &pc.pd_lo : &mc.d_lo, kk == 0 ? -lo : lo);
         }
     }
 }
@@ -1172,26 +1174,12 @@ __global__ void __launch_bounds__(256) k_predict(Glob* g, MoveBuf mb, int w_begi
             const bool windowed = (cpre_at(mb, CW(w, c)).same_windowed >> 1) & 1;
             if (windowed && (r.info & 1u) && r.k > 0) {
                 mc.pred = best;
+                cpre_at(mb, CW(w, 0)).pred = best; /* travels with the records; pd_hi / pd_lo (zeroed by k_records) are k_delta's */
                 mc.pred_c = c;
                 mc.pred_k = r.k;
             }
         }
     }
-}
-
-/* the prediction travels with the records (candidate 0 of the slot) */
-__global__ void k_pred_pack(MoveBuf mb, int w_begin, int nW)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nW) return;
-    const int w = w_begin + i;
-    const MoveCtl& mc = mb.ctl[w];
-    CandPre& cp = cpre_at(mb, CW(w, 0));
-    long long h = mc.pd_hi, l = mc.pd_lo;
-    ig_acc_normalize((int64_t*)&h, (int64_t*)&l);
-    cp.pred = mc.pred;
-    cp.pd_hi = h;
-    cp.pd_lo = l;
 }
 
 /* prefinal_tail (k_tail): one workgroup per (candidate, slot).  Computes, for
@@ -1381,7 +1369,7 @@ __global__ void __launch_bounds__(64) k_records(MoveBuf mb, int w_begin)
         for (int q = 0; q < 12; q++) fm |= (m.flags[q] != -1) ? (1u << q) : 0u;
         cp.flag_mask = fm;
         cp.overflow = mb.ctl[w].overflow; /* travels with the records: the slot must be re-run */
-        cp.pred = -1; /* k_pred_pack */
+        cp.pred = -1; /* k_predict, k_delta */
         cp.pd_hi = cp.pd_lo = 0;
         cpre_at(mb, cw) = cp;
     }
