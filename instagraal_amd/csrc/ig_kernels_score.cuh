@@ -489,7 +489,6 @@ __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ row
     }
 }
 
-#define SCORE_EB 16
 #define LDS_PZ 1024
 #define LDS_LGF 256
 
