@@ -229,6 +229,27 @@ def test_checked_scoring_path_equals_the_hot_one(monkeypatch):
     assert runs[0] == runs[1]
 
 
+def test_batch_outcome_by_copy_equals_polled_flag(monkeypatch):
+    """IG_NO_HOST_FLAG=1: the host learns a batch's outcome by copy + synchronise instead of polling the mapped host copy
+    k_decide_batch writes; same result records, same genome"""
+    from instagraal_amd import synth
+    from instagraal_amd.sampler import sampler as hip_sampler
+
+    prob = synth.make_problem(*synth.CONFIGS["small"])
+    runs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("IG_NO_HOST_FLAG", flag)
+        s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
+        s.set_param_simu(prob.params)
+        s.eval_likelihood_init()
+        np.random.seed(11)
+        frags = np.random.permutation(prob.n_frags)[:80].astype(np.int32)
+        res = s.ctx.step_batch(frags, s.draw_candidates(frags, 5))
+        runs.append((res.tobytes(), s.gpu_vect_frags.copy_from_gpu().soa17().tobytes()))
+        s.free_gpu()
+    assert runs[0] == runs[1]
+
+
 def test_slice_pool_overflow_reruns_the_slot(monkeypatch):
     """a pool that holds one move's slice lists but not a batch's: the slots that do not fit are flagged by k_offsets and
     re-run at the head of the next batch; results identical to the roomy pool"""
