@@ -212,6 +212,7 @@ struct ig_ctx {
     int* batch_out; /* committed moves, pending slot, (unused), candidates, predicted deltas used */
     int *host_bo, *host_bo_dev; /* the same in mapped host memory (+ [7] = sequence number of the decide launch), and its device address */
     int bo_seq;
+    double w_ema; /* moving average of the moves a batch gets through: sets the width of the next one */
     int* dirty_buf; /* [1 + 2 * IG_MAX_BATCH + 2] contigs modified by the committed moves of the batch in flight */
     int *own_tag, *own_idx; /* [N] which committed move of the current batch owns a fragment, and where in its window */
     ig_move_result* d_results;

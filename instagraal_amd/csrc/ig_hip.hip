@@ -107,6 +107,7 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->host_bo = nullptr;
     c->host_bo_dev = nullptr;
     c->bo_seq = 0;
+    c->w_ema = 0.0;
     c->rank = 0;
     c->world = 1;
     c->N = c->M = 0;
@@ -1016,12 +1017,21 @@ extern "C" int ig_step_batch(ig_ctx* c, int32_t n_moves, const int32_t* frags, c
     } else {
         /* speculative batches: score W moves against the same state, commit the conflict-free prefix on the device,
          * finish a winner that needs the exact delta pass with the one-move tail, continue after it */
+        /* The width follows the conflict rate: where few contigs are left (late in an assembly) nearly every move touches a
+         * contig an earlier move of the batch modified, and slots scored behind the first conflict are wasted work.  Moving
+         * average of the moves a batch got through (a batch that got through all of them counts double: the run was at
+         * least that long); the next batch is 1.5 x that, at most Wmax.  Results do not depend on the widths. */
+        static const int s_adaptive = getenv("IG_ADAPTIVE_W") ? atoi(getenv("IG_ADAPTIVE_W")) : 1;
+        if (c->w_ema <= 0.0 || c->w_ema > Wmax) c->w_ema = Wmax;
         int done = 0;
         while (done < n_moves) {
-            const int w_now = std::min(Wmax, n_moves - done);
+            const int w_want = s_adaptive ? std::max(2, std::min(Wmax, (int)(1.5 * c->w_ema + 1.5))) : Wmax;
+            const int w_now = std::min(w_want, n_moves - done);
             enqueue_score(c, done, w_now, max_c, -1, 2);
             int next = 0;
             if (commit_loop(c, done, w_now, &next)) return -1;
+            if (w_now == w_want) /* a batch cut short by the end of the run says nothing */
+                c->w_ema = 0.6 * c->w_ema + 0.4 * (next >= w_now ? std::min(2.0 * w_now, (double)Wmax) : (double)next);
             done += next;
         }
     }
