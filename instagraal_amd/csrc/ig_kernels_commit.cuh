@@ -605,12 +605,14 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
 {
     __shared__ long long sh_delta[IG_MAX_BATCH];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int grp = tid / COMMIT_GROUP, gtid = tid % COMMIT_GROUP, ngrp = COMMIT_THREADS / COMMIT_GROUP;
     const int tag_base = g->stamp_ctr; /* tags/stamps of this batch: tag_base + w */
     if (tid < IG_MAX_BATCH) sh_delta[tid] = 0;
     const int committed = batch_out[0];
     __syncthreads();
     if (committed == w_start) return;
+    /* threads that apply one move together: the whole workgroup when there is a single move to apply */
+    const int gsz = (committed - w_start >= 2) ? COMMIT_GROUP : COMMIT_THREADS;
+    const int grp = tid / gsz, gtid = tid % gsz, ngrp = COMMIT_THREADS / gsz;
     /* ---------------------------------------------------------------- 2. apply */
     const int N = mb.N, M = mb.M;
     auto winner_loc = [&](int w) -> const int* {
@@ -627,7 +629,7 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
         const int cw = CW(w, mc.ch_c);
         const int n_loc = mb.meta[cw].n_loc;
         const int* gid = mb.Lloc + (size_t)cw * N;
-        for (int x = gtid; x < n_loc; x += COMMIT_GROUP) {
+        for (int x = gtid; x < n_loc; x += gsz) {
             const int f = gid[x];
             own_tag[f] = tag_base + w;
             own_idx[f] = x;
@@ -645,7 +647,7 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
         const int* gid = mb.Lloc + (size_t)cw * N;
         const int stampv = tag_base + w + 1; /* != 0 */
         long long d = 0;
-        for (int item = gtid; item < 3 * n_loc; item += COMMIT_GROUP) {
+        for (int item = gtid; item < 3 * n_loc; item += gsz) {
             const int f0 = gid[item / 3];
             const int q = item % 3;
             const int f = (q == 0) ? f0 : ((q == 1) ? ip[f0] : in[f0]);
@@ -687,7 +689,7 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
         if (!mc.n_dirty) continue;
         const int* base = winner_loc(w);
         const int* gid = mb.Lloc + (size_t)cw * N;
-        for (int x = gtid; x < m.n_loc; x += COMMIT_GROUP) {
+        for (int x = gtid; x < m.n_loc; x += gsz) {
             const int f = gid[x];
             st.pos[f] = base[x];
             st.spos[f] = base[(size_t)N + x];
@@ -706,7 +708,7 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
         const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
         const int* subs = mb.subs + (size_t)cw * M;
         const int fresh = mc.fresh;
-        for (int ls = gtid; ls < m.m_loc; ls += COMMIT_GROUP) {
+        for (int ls = gtid; ls < m.m_loc; ls += gsz) {
             const int s = subs[ls];
             const uint2 v = col[ls];
             const int code = (int)(v.y >> 28);
