@@ -209,9 +209,10 @@ struct ig_ctx {
     long long* scratch8; /* 8 x int64 reduction scratch of the from-scratch passes */
     MoveBuf mb;
     int* stamp;     /* [N] claim stamps of the incremental genome distance */
-    int* batch_out; /* committed moves, pending slot, (unused), candidates, predicted deltas used */
+    int* batch_out; /* committed moves, pending slot, (unused), candidates, predicted deltas used, contigs */
     int *host_bo, *host_bo_dev; /* the same in mapped host memory (+ [7] = sequence number of the decide launch), and its device address */
     int bo_seq;
+    int n_contigs_seen; /* contigs after the last batch (0: none yet): picks k_mutate's launch shape */
     double w_ema; /* moving average of the moves a batch gets through: sets the width of the next one */
     int* dirty_buf; /* [1 + 2 * IG_MAX_BATCH + 2] contigs modified by the committed moves of the batch in flight */
     int *own_tag, *own_idx; /* [N] which committed move of the current batch owns a fragment, and where in its window */

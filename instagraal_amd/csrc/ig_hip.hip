@@ -108,6 +108,7 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->host_bo_dev = nullptr;
     c->bo_seq = 0;
     c->w_ema = 0.0;
+    c->n_contigs_seen = 0;
     c->rank = 0;
     c->world = 1;
     c->N = c->M = 0;
@@ -787,7 +788,8 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
             c->own_begin = w_begin;
             c->own_end = w_end;
             if (nW > 0)
-                hipLaunchKernelGGL(k_mutate, dim3(NSLOT, max_c, nW), dim3(256), 0, c->stream, c->st, c->tab, c->sub_tab, c->rowptr,
+                /* long contigs (late in an assembly: windows of thousands of sub-fragments): twice the threads per candidate genome */
+                hipLaunchKernelGGL(k_mutate, dim3(NSLOT, max_c, nW), dim3((c->n_contigs_seen > 0 && c->N / c->n_contigs_seen >= 150) ? 512 : 256), 0, c->stream, c->st, c->tab, c->sub_tab, c->rowptr,
                                    c->glob, c->mb, pz, w_begin);
         }
         if (force_slot < 0 && nW > 0) {
@@ -928,6 +930,7 @@ static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
         if (next == 0) c->n_batches++;
         c->n_batch_committed += bo[0] - next;
         c->n_batch_predicted += bo[4];
+        c->n_contigs_seen = bo[5];
         next = bo[0];
         if (bo[1] >= 0) { /* slot bo[1] chose a windowed winner: delta + apply with the one-move kernels, then go on */
             enqueue_apply(c, done + bo[1], bo[1], 0);

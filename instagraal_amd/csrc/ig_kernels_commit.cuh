@@ -581,6 +581,7 @@ __global__ void __launch_bounds__(64)
             batch_out[2] = 0;
             batch_out[3] = n_cand;
             batch_out[4] = n_predicted;
+            batch_out[5] = n_contigs;
             /* the host polls this copy (mapped, coherent host memory): it learns the outcome while k_commit_batch is still
              * running and has the next launches queued behind it when it ends */
             if (host_out) {
@@ -589,6 +590,7 @@ __global__ void __launch_bounds__(64)
                 host_out[2] = 0;
                 host_out[3] = n_cand;
                 host_out[4] = n_predicted;
+                host_out[5] = n_contigs;
                 __threadfence_system();
                 host_out[7] = seq;
             }

@@ -301,7 +301,7 @@ __device__ __forceinline__ void mutate_one(const State& st, const Tables& tab, c
             }
         }
     }
-    __shared__ long long red[4][4];
+    __shared__ long long red[4][16];
     hi = wave_sum_ll(hi);
     lo = wave_sum_ll(lo);
     ni = wave_sum_ll(ni);
@@ -314,15 +314,21 @@ __device__ __forceinline__ void mutate_one(const State& st, const Tables& tab, c
     __syncthreads();
     if (threadIdx.x == 0) {
         long long* q = mb.qpart + (size_t)cw * Q_STRIDE;
-        q[Q_Z + 2 * k] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        q[Q_Z + 2 * k + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        q[Q_NI + k] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        long long s0 = 0, s1 = 0, s2 = 0;
+        for (int v = 0; v < (int)(blockDim.x >> 6); v++) { /* 4 or 16 waves (k_mutate's two launch shapes) */
+            s0 += red[0][v];
+            s1 += red[1][v];
+            s2 += red[2][v];
+        }
+        q[Q_Z + 2 * k] = s0;
+        q[Q_Z + 2 * k + 1] = s1;
+        q[Q_NI + k] = s2;
     }
     if (k == 0 && threadIdx.x < SLICE_SEG) mb.slbound[(size_t)cw * SLICE_SEG + threadIdx.x] = seg_bound[threadIdx.x];
 }
 
 /* k_mutate: the 25 genomes of every candidate of the move slots [w_begin, w_begin + gridDim.z) */
-__global__ void __launch_bounds__(256) k_mutate(State st, Tables tab, const SubTab* __restrict__ sub, const long long* __restrict__ rowptr,
+__global__ void __launch_bounds__(1024) k_mutate(State st, Tables tab, const SubTab* __restrict__ sub, const long long* __restrict__ rowptr,
                                                 Glob* g, MoveBuf mb, PzTab pz, int w_begin)
 {
     mutate_one(st, tab, sub, rowptr, g, mb, pz, blockIdx.x, blockIdx.y, w_begin + blockIdx.z);
