@@ -649,8 +649,14 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
         const int* gid = mb.Lloc + (size_t)cw * N;
         const int stampv = tag_base + w + 1; /* != 0 */
         long long d = 0;
+        const int* wl = winner_loc(w);
         for (int item = gtid; item < 3 * n_loc; item += gsz) {
-            const int f0 = gid[item / 3];
+            const int x0 = item / 3;
+            const int f0 = gid[x0];
+            /* credit(f) reads prev / next / ori of f and the orientation of its initial neighbours: only a fragment whose own
+             * three fields change can change a credit (its own, or those of its initial neighbours) */
+            if (wl[(size_t)5 * N + x0] == st.prev[f0] && wl[(size_t)6 * N + x0] == st.next[f0] && wl[(size_t)10 * N + x0] == st.ori[f0])
+                continue;
             const int q = item % 3;
             const int f = (q == 0) ? f0 : ((q == 1) ? ip[f0] : in[f0]);
             if (f < 0 || black[f]) continue;
