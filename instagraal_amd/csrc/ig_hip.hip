@@ -827,7 +827,9 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
             TimedLaunch t(c, T_FINALIZE);
             hipLaunchKernelGGL(k_records, dim3(max_c, nW), dim3(64), 0, c->stream, c->mb, w_begin);
             if (phase == 2 && W > 1 && c->world == 1) { /* batches: predicted windowed winners get their exact delta now */
-                hipLaunchKernelGGL(k_predict, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, w_begin);
+                static const int s_pred2 = getenv("IG_PREDICT_PASSES") ? atoi(getenv("IG_PREDICT_PASSES")) : 2;
+                if (s_pred2 >= 2) hipLaunchKernelGGL(k_predict, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, w_begin, 0);
+                hipLaunchKernelGGL(k_predict, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, w_begin, 1);
                 hipLaunchKernelGGL(k_delta, dim3(DELTA_RB, 2, nW), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->tab_prev,
                                    c->prev_touched, c->glob, c->mb, c->lgf_tab, pz, w_begin, 1);
             }

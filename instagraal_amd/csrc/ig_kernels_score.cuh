@@ -105,7 +105,8 @@ __global__ void __launch_bounds__(256)
         mc.superset0 = (w > 0 && force_slot < 0) ? 1 : 0;
         mc.n_dirty = 0;
         mc.pred = -1;
-        mc.pred_c = mc.pred_k = mc.pred_pad = 0;
+        mc.pred_c = mc.pred_k = 0;
+        mc.pred_pad = -1;
         mc.pd_hi = mc.pd_lo = 0;
         mc.overflow = 0;
         mc.pad = 0;
@@ -1119,7 +1120,7 @@ __global__ void __launch_bounds__(SCORE_THREADS)
  * predicted from the batch-start state: if it is a windowed candidate that changes the genome, its exact full-contig delta
  * is computed NOW (k_delta, predicted) and the decide step does not have to pause the batch for it.  A wrong prediction
  * costs nothing but the pause it failed to avoid. */
-__global__ void __launch_bounds__(256) k_predict(Glob* g, MoveBuf mb, int w_begin)
+__global__ void __launch_bounds__(256) k_predict(Glob* g, MoveBuf mb, int w_begin, int pass)
 {
     __shared__ double sc[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT];
     const int w = w_begin + blockIdx.x, tid = threadIdx.x;
@@ -1131,7 +1132,12 @@ __global__ void __launch_bounds__(256) k_predict(Glob* g, MoveBuf mb, int w_begi
     if (w == 0) {
         for (int q = 0; q < 12; q++) vmask |= (g->valid_insert[q] != -1) ? (1u << q) : 0u;
     } else {
-        const CandMeta& pm = mb.meta[CW(w - 1, mb.ctl[w - 1].C - 1)];
+        /* pass 0: the previous slot's last candidate; pass 1: the family the previous slot's predicted winner (pass 0) would
+         * leave the flags to (CL:2125-2126: a block-insert winner re-ran get_bounds for its own candidate) */
+        const MoveCtl& pc = mb.ctl[w - 1];
+        int sel = pc.C - 1;
+        if (pass == 1 && pc.pred_pad >= 0 && (pc.pred_pad % IG_N_TMP_STRUCT) >= 12) sel = pc.pred_pad / IG_N_TMP_STRUCT;
+        const CandMeta& pm = mb.meta[CW(w - 1, sel)];
         for (int q = 0; q < 12; q++) vmask |= (pm.flags[q] != -1) ? (1u << q) : 0u;
     }
     const ig_params p = g->par[0];
@@ -1174,6 +1180,10 @@ __global__ void __launch_bounds__(256) k_predict(Glob* g, MoveBuf mb, int w_begi
         }
         if (tid == 0) {
             if (best >= n) best = 0;
+            if (pass == 0) {
+                mc.pred_pad = best; /* read by the next slot's second pass */
+                return;
+            }
             const int c = best / IG_N_TMP_STRUCT, slot = best % IG_N_TMP_STRUCT;
             const SlotPre r = pre_at(mb, CW(w, c), slot);
             const bool windowed = (cpre_at(mb, CW(w, c)).same_windowed >> 1) & 1;
