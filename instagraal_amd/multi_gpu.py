@@ -100,6 +100,7 @@ class BatchRunner:
         self._bufs = None
         self._stream = None
         self.batches = 0
+        self._ema = float(self.width)  # moves a batch gets through, moving average: sets the next width (as ig_step_batch)
 
     def _buffers(self, cap_slots):
         if self._bufs is None:
@@ -155,12 +156,17 @@ class BatchRunner:
             self._buffers(cap_slots)
         done = 0
         while done < n:
-            w_now = min(self.width, n - done)
+            # the width follows the conflict rate (identical on every rank: it only depends on the committed counts)
+            w_want = max(world, min(self.width, int(1.5 * self._ema + 1.5)))
+            w_now = min(w_want, n - done)
             per = -(-w_now // world)
             b, e = min(rank * per, w_now), min((rank + 1) * per, w_now)
             self.ctx.batch_score(done, w_now, b, e)
             if world > 1:
                 self._exchange(per)
-            done += self.ctx.batch_commit(done, w_now)
+            got = self.ctx.batch_commit(done, w_now)
+            if w_now == w_want:
+                self._ema = 0.6 * self._ema + 0.4 * (min(2.0 * w_now, float(self.width)) if got >= w_now else float(got))
+            done += got
             self.batches += 1
         return self.ctx.batch_results(n)
