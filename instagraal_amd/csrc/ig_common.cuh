@@ -208,7 +208,6 @@ struct ig_ctx {
     Glob* glob;
     long long* scratch8; /* 8 x int64 reduction scratch of the from-scratch passes */
     MoveBuf mb;
-    int* stamp;     /* [N] claim stamps of the incremental genome distance */
     int* batch_out; /* committed moves, pending slot, (unused), candidates, predicted deltas used, contigs */
     int *host_bo, *host_bo_dev; /* the same in mapped host memory (+ [7] = sequence number of the decide launch), and its device address */
     int bo_seq;
@@ -241,6 +240,7 @@ struct ig_ctx {
     int up_moves, up_max_c; /* the uploaded move lists */
     int own_begin, own_end; /* slots whose candidate genomes this handle built for the batch in flight */
     bool have_contacts, have_sub, have_state, have_init, have_params;
+    bool init_links_inverse; /* initial prev / next are mutually inverse (k_commit_batch's de-duplication relies on it; else W = 1) */
 };
 
 __host__ __device__ inline size_t rec_bytes_per_slot(int capC) { return (size_t)capC * (IG_N_TMP_STRUCT * sizeof(SlotPre) + sizeof(CandPre)); }

@@ -122,7 +122,6 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->tabrec = nullptr;
     c->init_prev = c->init_next = c->orientable = nullptr;
     c->black = nullptr;
-    c->stamp = nullptr;
     c->batch_out = nullptr;
     c->own_tag = c->own_idx = nullptr;
     c->dirty_buf = nullptr;
@@ -146,6 +145,7 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
         c->timers[i].n = 0;
     }
     c->have_contacts = c->have_sub = c->have_state = c->have_init = c->have_params = false;
+    c->init_links_inverse = true;
     HIPCK(hipStreamCreate(&c->stream));
     HIPCK(hipStreamCreate(&c->stream2));
     HIPCK(hipEventCreateWithFlags(&c->ev_slice, hipEventDisableTiming));
@@ -205,12 +205,10 @@ static void free_move_buffers(ig_ctx* c)
     hipFree(c->own_tag);
     hipFree(c->own_idx);
     c->own_tag = c->own_idx = nullptr;
-    hipFree(c->stamp);
     hipFree(c->batch_out);
     hipFree(c->dirty_buf);
     c->dirty_buf = nullptr;
     memset((void*)&m, 0, sizeof m);
-    c->stamp = nullptr;
     c->batch_out = nullptr;
 }
 
@@ -336,7 +334,6 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
     DALLOC(c->own_tag, N);
     DALLOC(c->own_idx, N);
     HIPCK(hipMemset(c->own_tag, 0xff, N * sizeof(int)));
-    DALLOC(c->stamp, N);
     DALLOC(c->batch_out, 8);
     if (!c->host_bo && !(getenv("IG_NO_HOST_FLAG") && atoi(getenv("IG_NO_HOST_FLAG")))) {
         /* the batch outcome is also written to mapped host memory (commit_loop polls it); without it: copy + synchronise */
@@ -357,7 +354,6 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
     HIPCK(hipMemset(m.cmeta, 0, C * NSLOT * NCODE * sizeof(ColMeta)));
     HIPCK(hipMemset(m.slbound, 0, C * SLICE_SEG * sizeof(long long)));
     HIPCK(hipMemset(m.ctl, 0, (size_t)capW * sizeof(MoveCtl)));
-    HIPCK(hipMemset(c->stamp, 0, N * sizeof(int)));
     m.N = c->N;
     m.M = c->M;
     m.capC = capC;
@@ -442,6 +438,21 @@ extern "C" int ig_upload_subfrag_table(ig_ctx* c, const float* xyzw, int32_t M)
 
 static int launch_recompute(ig_ctx* c);
 
+/* the incremental genome distance of k_commit_batch evaluates every credit a move can change exactly once; its rule for
+ * telling who evaluates a fragment reached through several links needs the initial prev / next to be mutually inverse
+ * (true of every genome made of contigs; an arbitrary pair of arrays takes the one-move path, which recounts all credits) */
+static bool links_inverse(const int32_t* ip, const int32_t* in, size_t n)
+{
+    for (size_t f = 0; f < n; f++) {
+        const int p = ip[f], q = in[f];
+        if (p < -1 || q < -1 || p >= (int)n || q >= (int)n) return false;
+        if (p >= 0 && (in[p] != (int)f || p == (int)f)) return false;
+        if (q >= 0 && (ip[q] != (int)f || q == (int)f)) return false;
+        if (p >= 0 && p == q) return false;
+    }
+    return true;
+}
+
 extern "C" int ig_upload_state(ig_ctx* c, const int32_t* soa, int32_t N)
 {
     HIPCK(hipSetDevice(c->device));
@@ -502,6 +513,7 @@ extern "C" int ig_upload_state(ig_ctx* c, const int32_t* soa, int32_t N)
         HIPCK(hipMemcpy(c->orientable, orient.data(), n * sizeof(int), hipMemcpyHostToDevice));
         HIPCK(hipMemset(c->black, 0, n));
         c->have_init = true;
+        c->init_links_inverse = links_inverse(soa + 8 * n, soa + 9 * n, n);
     }
     Glob hg;
     HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));
@@ -613,6 +625,7 @@ extern "C" int ig_set_initial_genome(ig_ctx* c, const int32_t* ip, const int32_t
     for (size_t i = 0; i < n; i++) cnt += b[i];
     HIPCK(hipMemcpy(c->black, b.data(), n, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(&c->glob->n_black, &cnt, sizeof(int), hipMemcpyHostToDevice));
+    c->init_links_inverse = links_inverse(ip, in, n);
     return launch_recompute(c);
 }
 
@@ -901,7 +914,7 @@ static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
                 hipLaunchKernelGGL(k_mutate_winners, dim3(2, w_now), dim3(256), 0, c->stream, c->st, c->tab, c->sub_tab, c->rowptr,
                                    c->glob, c->mb, PzTab{c->pz_tab, c->pz_n}, next, c->own_begin, c->own_end, c->batch_out);
             hipLaunchKernelGGL(k_commit_batch, dim3(1), dim3(COMMIT_THREADS), 0, c->stream, c->st, c->tab, c->tab_prev, c->glob,
-                               c->mb, c->init_prev, c->init_next, c->orientable, c->black, c->stamp, c->own_tag, c->own_idx,
+                               c->mb, c->init_prev, c->init_next, c->orientable, c->black, c->own_tag, c->own_idx,
                                c->prev_touched, c->d_results, done, w_now, next, c->batch_out);
         }
         int bo[8];
@@ -1011,7 +1024,8 @@ extern "C" int ig_step_batch(ig_ctx* c, int32_t n_moves, const int32_t* frags, c
     if (check_ready(c)) return -1;
     if (n_moves <= 0) return 0;
     if (max_c < 1 || max_c > IG_MAX_CANDIDATES) return fail("ig_step_batch: max_c out of range");
-    const int Wmax = (c->world > 1) ? 1 : batch_width(c, max_c);
+    if (c->world > 1) return fail("ig_step_batch: this handle scores a contact shard (ig_set_shard %d/%d): use ig_step_begin / all-reduce / ig_step_finish", c->rank, c->world);
+    const int Wmax = c->init_links_inverse ? batch_width(c, max_c) : 1;
     if (ensure_move_buffers(c, std::max(8, (int)max_c), Wmax)) return -1;
     if (upload_moves(c, n_moves, frags, cands, max_c)) return -1;
     if (Wmax == 1) {
@@ -1053,6 +1067,7 @@ extern "C" int ig_batch_upload(ig_ctx* c, int32_t n_moves, const int32_t* frags,
     if (max_w < 1 || max_w > max_batch_width(c, max_c))
         return fail("ig_batch_upload: batch width %d out of 1..%d (ig_batch_max_width)", max_w, max_batch_width(c, max_c));
     if (c->world > 1) return fail("ig_batch_upload: contact shards (ig_set_shard) and slot splitting are exclusive");
+    if (!c->init_links_inverse && max_w > 1) return fail("ig_batch_upload: the initial prev / next arrays are not mutually inverse: batches of one move only");
     if (max_c < 1 || max_c > IG_MAX_CANDIDATES) return fail("ig_batch_upload: max_c out of range");
     if (ensure_move_buffers(c, std::max(8, (int)max_c), max_w)) return -1;
     return upload_moves(c, n_moves, frags, cands, max_c);
@@ -1112,6 +1127,7 @@ extern "C" int ig_step(ig_ctx* c, int32_t frag_a, const int32_t* cands, int32_t 
 {
     HIPCK(hipSetDevice(c->device));
     if (check_ready(c)) return -1;
+    if (c->world > 1) return fail("ig_step: this handle scores a contact shard (ig_set_shard %d/%d): partial sums only -- use ig_step_begin / all-reduce / ig_step_finish", c->rank, c->world);
     if (validate_move(c, frag_a, cands, C)) return -1;
     if (ensure_move_buffers(c, std::max(8, (int)C))) return -1;
     if (ensure_io(c, 1, C)) return -1;
@@ -1132,6 +1148,7 @@ extern "C" int ig_score_move(ig_ctx* c, int32_t frag_a, const int32_t* cands, in
 {
     HIPCK(hipSetDevice(c->device));
     if (check_ready(c)) return -1;
+    if (c->world > 1) return fail("ig_score_move: this handle scores a contact shard (ig_set_shard %d/%d): partial sums only -- use ig_step_begin / all-reduce / ig_step_finish", c->rank, c->world);
     if (validate_move(c, frag_a, cands, C)) return -1;
     if (ensure_move_buffers(c, std::max(8, (int)C))) return -1;
     if (ensure_io(c, 1, C)) return -1;
@@ -1149,6 +1166,7 @@ extern "C" int ig_apply(ig_ctx* c, int32_t frag_a, int32_t frag_b, int32_t op)
 {
     HIPCK(hipSetDevice(c->device));
     if (check_ready(c)) return -1;
+    if (c->world > 1) return fail("ig_apply: this handle scores a contact shard (ig_set_shard %d/%d): partial sums only -- use ig_step_begin / all-reduce / ig_step_finish", c->rank, c->world);
     if (op < 0 || op >= IG_N_TMP_STRUCT) return fail("ig_apply: op out of range");
     if (validate_move(c, frag_a, &frag_b, 1)) return -1;
     if (ensure_move_buffers(c, 8)) return -1;

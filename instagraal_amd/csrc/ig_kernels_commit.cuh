@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(64)
 /* step 2 of the batch commit: one workgroup applies the moves [w_start, batch_out[0]) k_decide_batch committed */
 __global__ void __launch_bounds__(COMMIT_THREADS)
     k_commit_batch(State st, Tables tab, Tables tab_prev, Glob* g, MoveBuf mb, const int* __restrict__ ip, const int* __restrict__ in,
-                   const int* __restrict__ orientable, const unsigned char* __restrict__ black, int* stamp, int* own_tag, int* own_idx,
+                   const int* __restrict__ orientable, const unsigned char* __restrict__ black, int* own_tag, int* own_idx,
                    int* prev_touched, ig_move_result* res, int move0, int W, int w_start, const int* batch_out)
 {
     __shared__ long long sh_delta[IG_MAX_BATCH];
@@ -647,9 +647,14 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
         const int cw = CW(w, mc.ch_c);
         const int n_loc = mb.meta[cw].n_loc;
         const int* gid = mb.Lloc + (size_t)cw * N;
-        const int stampv = tag_base + w + 1; /* != 0 */
         long long d = 0;
         const int* wl = winner_loc(w);
+        /* has fragment y one of its three fields changed by move w?  (then its own q = 0 item evaluates its credit) */
+        auto changed_member = [&](int y) -> bool {
+            if (y < 0 || own_tag[y] != tag_base + w) return false;
+            const int xi = own_idx[y];
+            return wl[(size_t)5 * N + xi] != st.prev[y] || wl[(size_t)6 * N + xi] != st.next[y] || wl[(size_t)10 * N + xi] != st.ori[y];
+        };
         for (int item = gtid; item < 3 * n_loc; item += gsz) {
             const int x0 = item / 3;
             const int f0 = gid[x0];
@@ -660,7 +665,15 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
             const int q = item % 3;
             const int f = (q == 0) ? f0 : ((q == 1) ? ip[f0] : in[f0]);
             if (f < 0 || black[f]) continue;
-            if (atomicExch(&stamp[f], stampv) == stampv) continue; /* claimed by another item of this move */
+            /* A fragment can be reached by up to three items of this move: as itself (q = 0), as the initial predecessor of
+             * in[f] (q = 1) and as the initial successor of ip[f] (q = 2); exactly one of them evaluates it.  The rule reads
+             * nothing another group writes (several moves are in flight side by side): the initial links are mutually
+             * inverse (checked at upload: ig_set_initial_genome, else the batch path is not used), so the q = 1 item that
+             * reaches f comes from in[f] and the q = 2 item from ip[f]. */
+            if (q > 0) {
+                if (changed_member(f)) continue;
+                if (q == 2 && (ip[f0] == f || changed_member(in[f]))) continue;
+            }
             auto view_at = [&](int t) {
                 return [=](int x) -> int3 {
                     const int tg = own_tag[x] - tag_base;

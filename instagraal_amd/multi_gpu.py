@@ -37,17 +37,23 @@ class ShardedRunner:
         ctx.set_shard(rank, world)
         self._tensor_factory = tensor_factory
         self._t = None
+        self._key = None
         self._stream = None
 
     def _partials(self):
-        if self._t is None:
-            if self._tensor_factory is not None:
+        """zero-copy int64 view of the library's partial-sum buffer.  The library may move the buffer (more candidates than
+        before, a new state): the view is rebuilt whenever pointer or length changed, and checked to alias the buffer."""
+        if self._tensor_factory is not None:
+            if self._t is None:
                 self._t = self._tensor_factory()
-            else:
-                import torch
+            return self._t
+        import torch
 
-                ptr, n = self.ctx.partials()
-                self._t = torch.as_tensor(_DevArray(ptr, n), device="cuda")
+        ptr, n = self.ctx.partials()
+        if self._t is None or self._key != (ptr, n):
+            self._t = torch.as_tensor(_DevArray(ptr, n), device="cuda")
+            assert self._t.data_ptr() == ptr, "torch copied the partial-sum buffer instead of wrapping it"
+            self._key = (ptr, n)
         return self._t
 
     def run(self, frags, cands):
@@ -65,12 +71,10 @@ class ShardedRunner:
         frags = np.ascontiguousarray(frags, np.int32)
         cands = np.ascontiguousarray(cands, np.int32)
         res = np.zeros(frags.size, hip_lib.MOVE_RESULT_DTYPE)
-        t = None
         for i in range(frags.size):
             c = cands[i][cands[i] >= 0]
             self.ctx.step_begin(int(frags[i]), c)
-            if t is None:
-                t = self._partials()
+            t = self._partials()  # after step_begin: that is where the library (re)allocates
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
             r, _ = self.ctx.step_finish(len(c))
             for k in res.dtype.names:
@@ -98,20 +102,26 @@ class BatchRunner:
         self.width = max(world, min(self.width, (64 // world) * world))  # equal chunks of at most 64 slots in total
         self._tensor_factory = tensor_factory
         self._bufs = None
+        self._key = None
         self._stream = None
         self.batches = 0
         self._ema = float(self.width)  # moves a batch gets through, moving average: sets the next width (as ig_step_batch)
 
     def _buffers(self, cap_slots):
-        if self._bufs is None:
-            ptr, nbytes = self.ctx.batch_records()
+        """zero-copy uint8 view of the library's record buffer; re-queried at the start of every run (the library frees and
+        reallocates its move buffers when a batch gets wider or the problem changes)"""
+        ptr, nbytes = self.ctx.batch_records()
+        key = (ptr, nbytes, cap_slots)
+        if self._bufs is None or self._key != key:
             if self._tensor_factory is not None:
                 t = self._tensor_factory("records", nbytes * cap_slots)
             else:
                 import torch
 
                 t = torch.as_tensor(_DevBytes(ptr, nbytes * cap_slots), device="cuda")
+                assert t.data_ptr() == ptr, "torch copied the record buffer instead of wrapping it"
             self._bufs = (t, nbytes)
+            self._key = key
         return self._bufs
 
     def _exchange(self, per):

@@ -243,11 +243,16 @@ def run_instagraal(hic_folder, reference_fa, output_folder=None, level=4, cycles
         root = str(output_folder) if output_folder is not None else os.path.join(os.getcwd(), "results")
         os.makedirs(root, exist_ok=True)
         return pyr.build_and_filter(str(hic_folder), SIZE_PYRAMID, FACTOR, thresh_factor=coverage_std, output_folder=root)
-    if circular:
-        raise NotImplementedError("--circular: the reference sets circ on the loader's arrays AFTER the sampler copied them "
-                                  "(IG:556-557), i.e. the flag has no effect there either")
     p2 = instagraal_class(name=name, folder_path=str(hic_folder), fasta=str(reference_fa), device=device, level=level,
                           n_iterations_em=30, n_iterations_mcmc=100, is_simu=False, scrambled=False, perform_em=False, use_rippe=True,
                           sample_param=True, thresh_factor=coverage_std, output_folder=str(output_folder) if output_folder else None)
+    if circular:
+        # IG:569-570: the flag is applied to the loader's arrays AFTER the sampler copied them to the device, i.e. it
+        # has no effect on the run in the reference either (quirk Q14).  Accepted and applied the same (ineffective) way.
+        import warnings
+
+        warnings.warn("--circular has no effect on the assembly (as in the reference: instagraal.py:569-570 sets the flag "
+                      "after the sampler copied the fragment arrays)")
+        p2.simulation.level.S_o_A_frags["circ"] += 1
     p2.full_em(n_cycles=cycles, n_neighbours=neighborhood, bomb=bomb, id_start_sample_param=4)
     return p2

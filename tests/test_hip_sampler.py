@@ -338,8 +338,10 @@ def test_headline_size_properties():
 
 
 def test_estimate_parameters_rippe_matches_reference_golden():
-    """SURVEY 8(f) f2 end to end: estimate_parameters_rippe (CL:2239-2372) on the GPU sampler = the reference's own
-    method over the oracle kernels: parameter struct (float32 fields) and the initial likelihood, bit for bit."""
+    """SURVEY 8(f) f2 end to end: estimate_parameters_rippe (CL:2239-2372) on the GPU sampler against the reference's own
+    method over the oracle kernels.  NOT bit for bit: the least-squares fit is ill-conditioned in the reference itself
+    (three of its parameters drift with numpy's float32 code paths), so the identifiable quantities are held to tolerances
+    -- slope and trans level 1e-6, the amplitude c1 * fact 1e-4, the cut-off 1e-3, the initial likelihood 1e-5."""
     from instagraal_amd import synth
     from instagraal_amd.sampler import sampler as hip_sampler
 

@@ -124,3 +124,25 @@ def test_dist_inter_genome_matches_literal_loop(oracle_lib):
                 if n1 == n0 or n1 == p0:
                     d -= 1
         assert s.dist_inter_genome(g) == d / (3.0 * N)
+
+
+def test_rippe_against_reference_peval(oracle_lib):
+    """The one piece of the reference that states P(s) in runnable form is optim_rippe_curve_update.peval (reference
+    l.21-31); with A = fact it is what rippe_contacts evaluates in float (KA:153-163).  The grid of peval values captured
+    from the reference itself (tools/gen_golden.py::host_helper_goldens) pins the oracle's rippe in BOTH arithmetic modes
+    -- an arithmetic check of the kernel half of the oracle that does not come from the oracle: float32 c1 and powf leave
+    ~2e-7 relative."""
+    ol = oracle_lib
+    g = np.load(os.path.join(GOLDEN, "host_helpers.npz"))
+    s, ref = g["rippe_grid_s"], g["rippe_grid_peval"]
+    p = np.zeros(1, ol.PARAM_DTYPE)
+    for k, v in zip(("kuhn", "lm", "c1", "slope", "d", "d_max", "fact", "v_inter"), g["rippe_grid_params"]):
+        p[k] = np.float32(v)
+    v_inter = float(p["v_inter"][0])
+    want = np.maximum(ref, v_inter)
+    for mode in (ol.MODE_LIBM, ol.MODE_DET):
+        ol.set_mode(mode)
+        ex, _, term, _ = ol.eval_terms(s, np.zeros_like(s), np.ones(s.size, np.int32), p)
+        rel = np.abs(ex.astype(np.float64) - want) / want
+        assert rel.max() < 1e-6, (mode, rel.max())
+    ol.set_mode(ol.MODE_DET)

@@ -140,8 +140,19 @@ def host_helper_goldens(outdir):
     dmax = opti.estimate_max_dist_intra([50.0, 9.6, -1.5, 2.0, 3.0e5], 5e-3)
     dmax_n = opti.estimate_max_dist_intra_nuis([50.0, 9.6, -1.45, 2.0, 3.0e5], 5e-3, dmax)
     fit, y_est = opti.estimate_param_rippe(opti.peval(x, p) * 1.0, x)
+    # P(s) itself: the one place the reference states the Rippe curve in runnable form (optim_rippe_curve_update.peval,
+    # reference l.21-31).  With A = fact it is the function kernel_sparse_adapt.cu:153-163 evaluates in float
+    # (c1 = 0.53 (lm/kuhn)^slope kuhn^-3, CL:2206-2221); the grid pins the oracle's rippe (both arithmetic modes) and the
+    # HIP kernels' to it: tests/test_oracle_golden.py::test_rippe_against_reference_peval, tests/test_hip_configs.py.
+    from instagraal_amd import synth
+
+    rp = synth.rippe_params(1.8)
+    grid = np.exp(np.linspace(np.log(0.05), np.log(0.999 * float(np.float32(rp["d_max"]))), 4000)).astype(np.float32)
+    ref = opti.peval(grid.astype(np.float64), [float(np.float32(rp["kuhn"])), float(np.float32(rp["lm"])),
+                                               float(np.float32(rp["slope"])), float(np.float32(rp["fact"]))])
     np.savez(os.path.join(outdir, "host_helpers.npz"), x=x, p=np.array(p), peval=y, dmax=dmax, dmax_nuis=dmax_n,
-             fit=np.array(fit, dtype=np.float64), y_est=y_est)
+             fit=np.array(fit, dtype=np.float64), y_est=y_est, rippe_grid_s=grid, rippe_grid_peval=np.asarray(ref, np.float64),
+             rippe_grid_params=np.array([rp[k] for k in ("kuhn", "lm", "c1", "slope", "d", "d_max", "fact", "v_inter")], np.float64))
     print("wrote host_helpers.npz", dmax, dmax_n, fit)
 
 
@@ -153,7 +164,7 @@ def main():
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     os.chdir(tempfile.mkdtemp())  # the reference's log.py drops a log file in the CWD
-    for name in a.cases.split(","):
+    for name in [n for n in a.cases.split(",") if n]:
         for mode in (0, 1):
             run_case(name, mode, a.out)
     if "estimate" in a.extra.split(","):
