@@ -1,29 +1,30 @@
 #!/usr/bin/env python3
 """MCMC moves/s of the instaGRAAL scoring path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W          one GPU
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is one move = one ``step_sampler`` call (CL:1401-1465): one focal bin, <= 5 partner bins,
-up to 5 x 24 candidate genomes scored, argmax applied.  Workload at N=1: BASELINE.json configs[2]
-(synthetic 50 k bins / 50 M contacts, the configuration the metric is quoted on).  Inputs are
-resident in HBM before the timed region; the timed region covers K consecutive moves including the
-H2D of the pre-drawn candidate lists and the D2H of the K result records.  ``ig_step_batch`` scores the
-moves W at a time against one state and commits them in order on the device ("speculative batches":
-the results are identical to K single calls, tests/test_hip_sampler.py), so one launch of the
-dominant kernel covers several moves.
+A "step" is one move = one complete ``step_sampler`` call (CL:1401-1465): the candidate draw (return_neighbours,
+CL:3103-3141, on numpy's generator stream), one focal bin, <= 5 partner bins, up to 5 x 24 candidate genomes scored, argmax
+applied.  Workload at N=1: BASELINE.json configs[2] (synthetic 50 k bins / 50 M contacts, the configuration the metric is
+quoted on).  The problem (contacts, genome state, jump distributions) is resident before the timed region; the timed
+region covers K consecutive moves END TO END: draw of the candidate lists (host thread, ahead of the launches), their
+H2D, every kernel, the D2H of the K result records.  ``ig_step_batch_draw`` scores the moves W at a time against one
+state and commits them in order on the device ("speculative batches": results identical to K single calls,
+tests/test_hip_sampler.py), so one launch of the dominant kernel covers several moves.
 
-Multi-GPU (N > 1): every rank holds the full problem; the slots of each speculative batch are split
-over the ranks (rank r slices and scores W/N of the W moves), the slot-major score records (exact
-int64 sums, ~15 KB per slot) are all-gathered over RCCL once per batch, and every rank runs the same
-commit step on identical inputs.  Results are bit-identical for any N ("strong" scaling: the same
-chain, split N ways); the commit step is the serial fraction.
+N > 1: launched by ``torch.distributed.run`` (the driver's way), or -- when WORLD_SIZE is not set -- this script starts
+the N workers itself (child processes, before anything touches the GPU) and relays rank 0's line.  One process per GPU,
+RCCL.  ``--runner batch`` (default): every rank holds the full problem, the slots of each speculative batch are split
+over the ranks, ONE all-gather of the slot-major score records (exact int64 sums) per batch, identical commit on every
+rank.  ``--runner sharded`` (BASELINE config 4's wording): contact rows split over the ranks, one all-reduce of the
+exact partial sums per move.  Both are bit-identical to one GPU for any N ("strong" scaling: one chain, split N ways).
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -37,34 +38,86 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def prob_name(prob):
+    return "%dk bins / %.0fM contacts" % (prob.n_frags // 1000, prob.n_contacts / 1e6)
+
+
 def cpu_baseline(prob, frags, cands, budget_s=20.0, max_moves=8):
-    """The oracle (a CPU port of the reference algorithm: full-N genome rewrites, full-Z slice scans)
-    timed on a bounded sample of the same workload: the first moves of the same trajectory."""
+    """The oracle (a CPU port of the reference ALGORITHM: full-N genome rewrites, full-Z slice scans) timed on a bounded
+    sample of the same workload -- the first moves of the same trajectory -- on one thread and on all host cores (OpenMP
+    over the contact-length loops: slice scans, full likelihood)."""
     from oracle import oracle_lib as ol
     from oracle.sampler_oracle import OracleSampler
 
     ol.build()
-    cores = 1
     t0 = time.time()
+    ol.set_threads(1)
     s = OracleSampler(**prob.sampler_kwargs(), mode=ol.MODE_DET)
     s.set_param_simu(prob.params)
     s.eval_likelihood_init()
     log("[cpu_baseline] oracle set-up %.1fs" % (time.time() - t0))
-    n = 0
-    t0 = time.time()
-    while n < min(max_moves, len(frags)):
-        c = [int(x) for x in cands[n] if x >= 0]
-        s.step_sampler(int(frags[n]), len(c), s.dt, candidates=c)
-        n += 1
-        if time.time() - t0 > budget_s:
+    ncores = os.cpu_count() or 1
+    rates, n_done, spent = {}, 0, {}
+    for threads in (1, ncores):
+        ol.set_threads(threads)
+        n = 0
+        t0 = time.time()
+        while n < max_moves // 2 and n_done < len(frags):
+            c = [int(x) for x in cands[n_done] if x >= 0]
+            s.step_sampler(int(frags[n_done]), len(c), s.dt, candidates=c)
+            n += 1
+            n_done += 1
+            if time.time() - t0 > budget_s / 2:
+                break
+        spent[threads] = time.time() - t0
+        rates[threads] = n / spent[threads]
+        if ncores == 1:
             break
-    dt = time.time() - t0
-    return dict(value=n / dt, unit="moves/s", cores=cores, kind="port",
-                sample="first %d moves of the same seeded trajectory on %s, oracle DET mode, %.1f s" % (n, prob_name(prob), dt))
+    ol.set_threads(1)
+    best = max(rates, key=lambda k: rates[k])
+    return dict(value=rates[best], unit="moves/s", cores=best, kind="port", value_1_thread=rates[1],
+                value_all_cores=rates.get(ncores), host_cores=ncores,
+                sample="the first %d moves of the same seeded trajectory on %s, oracle DET mode: %.1f s on 1 thread, then %.1f s on "
+                       "%d threads" % (n_done, prob_name(prob), spent[1], spent.get(ncores, 0.0), ncores))
 
 
-def prob_name(prob):
-    return "%dk bins / %.0fM contacts" % (prob.n_frags // 1000, prob.n_contacts / 1e6)
+def nuisance_rate(s, prob, n_moves, n_neighbours):
+    """moves/s of the reference's loop for cycles > 4 (IG:241-252): one step_sampler + one step_nuisance_parameters
+    (a full pass over all contacts under test parameters, CL:2961-3051) per move -- 95 of the default 100 cycles."""
+    s.bins = np.arange(1.0, 60.0, 1.0)
+    frags = np.random.permutation(prob.n_frags)[: n_moves + 10]
+    run = getattr(s, "step_sampler_nuisance_batch", None)
+    if run is not None:
+        run(frags[:10], n_neighbours, s.dt, 0, n_moves)
+        t0 = time.perf_counter()
+        out = run(frags[10:], n_neighbours, s.dt, 0, n_moves)
+        dt = time.perf_counter() - t0
+        return len(frags[10:]) / dt, float(np.mean([q[6] for q in out[1]])), "step_sampler_nuisance_batch"
+    for t, f in enumerate(frags[:10]):
+        s.step_sampler(int(f), n_neighbours, s.dt)
+        s.step_nuisance_parameters(s.dt, t, n_moves)
+    acc = 0
+    t0 = time.perf_counter()
+    for t, f in enumerate(frags[10:]):
+        s.step_sampler(int(f), n_neighbours, s.dt)
+        acc += s.step_nuisance_parameters(s.dt, t, n_moves)[6]
+    dt = time.perf_counter() - t0
+    return n_moves / dt, acc / float(n_moves), "step_sampler + step_nuisance_parameters per move"
+
+
+def spawn_workers(a):
+    """--gpus N without a launcher: start N ranks as children of this process (which never touches the GPU)."""
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] starting %d ranks: %s" % (a.gpus, " ".join(cmd)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run(cmd, env=env)
+    sys.exit(p.returncode)
 
 
 def main():
@@ -75,27 +128,35 @@ def main():
     ap.add_argument("--config", default="cfg3", help="synthetic shape: cfg2 | cfg3 | cfg5 | small | tiny")
     ap.add_argument("--neighbours", type=int, default=5)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--runner", default="batch", choices=("batch", "sharded"), help="N > 1: what is split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--nuisance-moves", type=int, default=150, help="moves of the nuisance-on loop timed after the run (0: skip)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_workers(a)  # does not return
 
     import torch
 
-    from instagraal_amd import hip_lib, synth
+    from instagraal_amd import synth
     from instagraal_amd.sampler import sampler as hip_sampler
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        log("WARNING: --gpus %d but WORLD_SIZE %d" % (a.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d" % (a.gpus, world))
     # IG_BENCH_ONE_DEVICE=1 (test rigs with a single GPU): every rank uses cuda:0 and the collectives go through gloo --
     # exercises the multi-process protocol end to end, not a performance configuration
     one_device = os.environ.get("IG_BENCH_ONE_DEVICE") == "1"
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if one_device:
         local_rank = 0
+    elif local_rank >= n_dev:
+        raise SystemExit("bench.py: rank %d has no device (%d visible, --gpus %d): refusing to share a GPU between ranks" % (rank, n_dev, world))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -105,6 +166,11 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # one process per GPU: no two ranks on the same device
+            ids = [None] * world
+            dist.all_gather_object(ids, (os.uname().nodename, torch.cuda.current_device()))
+            if len(set(ids)) != world:
+                raise SystemExit("bench.py: ranks share a device: %r" % (ids,))
 
     t0 = time.time()
     prob = synth.make_problem(*synth.CONFIGS[a.config])
@@ -116,60 +182,85 @@ def main():
     s.eval_likelihood_init()
     log("[rank %d] uploaded + initial likelihood %.6f in %.1fs" % (rank, float(s.curr_likelihood_on_nz[0]), time.time() - t0))
 
-    # trajectory: one shuffled cycle prefix, candidates pre-drawn with the reference's RNG consumption
+    # trajectory: a shuffled cycle prefix; the candidate lists are drawn INSIDE the timed region, as step_sampler does
     np.random.seed(a.seed)
     n_total = a.warmup + a.steps
     order = np.arange(prob.n_frags)
     np.random.shuffle(order)
     frags = np.resize(order, n_total).astype(np.int32)
-    t0 = time.time()
-    cands = s.draw_candidates(frags, a.neighbours)
-    t_draw = time.time() - t0
-    log("[rank %d] %d candidate lists drawn in %.2fs (%.1f us each, host numpy RNG)" % (rank, n_total, t_draw, 1e6 * t_draw / n_total))
 
+    runner = None
     if world > 1:
-        from instagraal_amd.multi_gpu import BatchRunner
+        from instagraal_amd.multi_gpu import BatchRunner, ShardedRunner
 
-        runner = BatchRunner(s.ctx, rank, world, dist=dist)
-        run = runner.run
-    else:
-        run = s.ctx.step_batch
+        runner = (BatchRunner if a.runner == "batch" else ShardedRunner)(s.ctx, rank, world, dist=dist)
+
+    def run(fr):
+        """K complete step_sampler calls: draw + score + apply"""
+        if runner is None:
+            res = s.step_sampler_batch(fr, a.neighbours)
+            return res, s.last_candidates
+        cands = s.draw_candidates(fr, a.neighbours)  # every rank draws the same lists from the same generator state
+        return runner.run(fr, cands), cands
 
     if a.warmup:
-        run(frags[: a.warmup], cands[: a.warmup])
-    s.ctx.reset_timers(1 | ((1 << 2) << 1))  # hipEvent pairs around k_score only
+        run(frags[: a.warmup])
+    s.ctx.reset_timers(1 | ((1 << 2) << 1))  # hipEvent pairs around k_score_list only
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res = run(frags[a.warmup:], cands[a.warmup:])
+    res, cands = run(frags[a.warmup:])
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     score_ms, n_launch = s.ctx.kernel_time_ms("score")
     s.ctx.reset_timers(0)
     bstats = s.ctx.batch_stats() if world == 1 else None
 
+    # the draw alone, for the record (it ran on a host thread next to the launches above)
+    st = np.random.get_state()
+    t0 = time.perf_counter()
+    s.draw_candidates(frags[a.warmup:], a.neighbours)
+    draw_us = 1e6 * (time.perf_counter() - t0) / a.steps
+    np.random.set_state(st)
+
     # self-check: the incrementally maintained exact likelihood equals a from-scratch recomputation
-    sums, _ = s.ctx.debug_globals()
-    _, _, limbs = s.ctx.full_likelihood(0)
-    exact_ok = bool(int(sums[0]) == int(limbs[0]) and int(sums[1]) == int(limbs[1]))
+    exact_ok = None
+    if world == 1 or a.runner == "batch":
+        sums, _ = s.ctx.debug_globals()
+        _, _, limbs = s.ctx.full_likelihood(0)
+        exact_ok = bool(int(sums[0]) == int(limbs[0]) and int(sums[1]) == int(limbs[1]))
+
+    nuis = None
+    if rank == 0 and world == 1 and a.nuisance_moves > 0:
+        try:
+            rate, acc, how = nuisance_rate(s, prob, a.nuisance_moves, a.neighbours)
+            nuis = {"moves_per_s": rate, "accept_rate": acc, "moves": a.nuisance_moves, "loop": how}
+        except Exception as e:  # a diagnostic next to the headline, never instead of it
+            nuis = {"moves_per_s": None, "error": repr(e)}
 
     if rank == 0:
         # algorithmic bytes of one launch of the dominant kernel = sum of the per-move B_min of the moves it scored
         # (committed moves only: a slot that had to be re-scored is work, not algorithmic traffic)
         n_launch = max(int(n_launch), 1)
-        bytes_min = float(res["bytes_min"].sum()) / n_launch / world  # N > 1: a rank scores 1/N of the slots of a launch
-        n_evals = float(res["n_evals"].sum()) / n_launch / world
+        split = world if (world > 1) else 1  # N > 1: a rank scores 1/N of the slots (or of the contact rows) of a launch
+        bytes_min = float(res["bytes_min"].sum()) / n_launch / split
+        n_evals = float(res["n_evals"].sum()) / n_launch / split
         achieved = bytes_min / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-        # WRITE_SIZE, separate passes; profiles/*_pmc_traffic.json): a committed measurement of THIS workload, or null
-        traffic = valu_busy = None
+        # the reference algorithm's streaming model B_ref (SURVEY 8(d)): (1 + C) 12 Z + C (12 S + 24 20 M + 50 136 N) + 2 20 M
+        C = float(res["n_candidates"].mean())
+        S = float(res["n_slice"].mean()) / max(C, 1.0)
+        b_ref = (1 + C) * 12.0 * prob.n_contacts + C * (12.0 * S + 24 * 20.0 * prob.n_sub_frags + 50 * 136.0 * prob.n_frags) + 40.0 * prob.n_sub_frags
+        # HBM bytes per launch of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+        # separate passes) of THIS workload, committed under profiles/ -- replayed from the file named below, not measured
+        # in this run (the counters need the profiler around the process)
+        traffic = valu_busy = traffic_src = None
         try:
             import glob
 
@@ -177,14 +268,15 @@ def main():
             if pmc and world == 1:
                 prof = json.load(open(pmc[-1]))["k_score_list"]
                 traffic = float(prof["traffic_bytes_per_launch"])
-                valu_busy = float(prof["VALUBusy_pct"]) / 100.0  # the bound that applies: fraction of cycles the VALUs issue
+                valu_busy = float(prof["VALUBusy_pct"]) / 100.0  # fraction of cycles the VALUs issue
+                traffic_src = "profiles/" + os.path.basename(pmc[-1])
         except Exception:
-            traffic = valu_busy = None
+            traffic = valu_busy = traffic_src = None
         out = {
             "metric": "MCMC moves/s (accepted+rejected) at fixed n_frags x nnz",
             "value": a.steps / elapsed,
             "unit": "moves/s",
-            "n_gpus": world,
+            "n_gpus": dist.get_world_size() if dist is not None else 1,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps,
@@ -195,22 +287,31 @@ def main():
             "data": "synthetic",
             "config": {"workload": "synthetic Hi-C %s (%d sub-frags), level 4, %d neighbours, nuisance sampling off" % (
                 prob_name(prob), prob.n_sub_frags, a.neighbours), "name": a.config, "seed": a.seed,
-                "parallelism": "1 GPU" if world == 1 else "batch slots split over %d ranks, all-gather of score records" % world,
+                "parallelism": "1 GPU" if world == 1 else (
+                    "batch slots split over %d ranks, all-gather of score records" % world if a.runner == "batch" else
+                    "contact rows split over %d ranks, all-reduce of exact partial sums per move" % world),
+                "timed_region": "candidate draw (host thread) + H2D + kernels + D2H of the result records",
+                "draw_us_per_move_alone": draw_us,
                 "candidates_scored_per_s": float(res["n_candidates"].sum()) * 24 / elapsed,
                 "term_evals_per_move": float(res["n_evals"].mean()), "moves_per_launch": a.steps / n_launch,
-                "batches": bstats, "maintained_likelihood_exact": exact_ok},
+                "batches": bstats, "maintained_likelihood_exact": exact_ok,
+                "nuisance_on": nuis,
+                "nuisance_on_moves_per_s": None if nuis is None else nuis.get("moves_per_s"),
+                "reference_equivalent_GBps": b_ref * (a.steps / elapsed) / 1e9,
+                "B_ref_bytes_per_move": b_ref},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "valu_busy_profiled": valu_busy, "kernel": "k_score_list", "avg_launch_ms": score_ms, "launches": int(n_launch),
+                         "traffic": traffic, "traffic_source": traffic_src, "valu_busy_profiled": valu_busy, "kernel": "k_score_list",
+                         "avg_launch_ms": score_ms, "launches": int(n_launch),
                          "algorithmic_bytes_per_launch": bytes_min,
                          "term_evals_per_launch": n_evals,
                          "term_evals_per_s": (n_evals / (score_ms * 1e-3)) if score_ms > 0 else 0.0,
                          "note": "B_min = sum_c[12 S_c + 20 m_c U + 8 U] + 68 n_touched per move (SURVEY 8(d)), summed over the moves "
-                                 "of a launch; the kernel is bound by VALU issue (VALUBusy 85 %, profiles/) of the exact f64 term "
-                                 "arithmetic on an L2-resident working set, not by HBM: DESIGN.md section 4.3"},
+                                 "of a launch; the working set of a launch is L2-resident and the kernel is bound by VALU issue of "
+                                 "the exact f64 term arithmetic, not by HBM: DESIGN.md section 4.3"},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(prob, frags, cands, a.cpu_budget)
+                out["cpu_baseline"] = cpu_baseline(prob, frags[a.warmup:], cands, a.cpu_budget)
             except Exception as e:  # the baseline is a report, never the product path
                 out["cpu_baseline"] = {"value": None, "unit": "moves/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)

@@ -95,6 +95,24 @@ int ig_step(ig_ctx* ctx, int32_t frag_a, const int32_t* cands, int32_t C, ig_mov
  * re-scored in the next batch, so the results are identical to n_moves calls of ig_step for every W. */
 int ig_step_batch(ig_ctx* ctx, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c,
                   ig_move_result* results);
+/* ---- the candidate draw (step 1 of step_sampler, CL:1403-1408: return_neighbours CL:3103-3141, candidates.sort()) ----
+ * Host code.  The reference draws with numpy's global legacy generator -- np.random.choice(xk, k, p=pk, replace=False), or
+ * np.random.choice(n_frags, k, replace=False) for a bin without hetero contacts -- and everything stochastic that follows
+ * continues that stream, so the draw is restated on a COPY of the MT19937 state: the caller passes key[624] and pos from
+ * np.random.get_state() and puts them back with set_state() (same lists, same generator state as numpy: tests/).
+ * Distributions (setup_distri_frags, CL:3053-3101): CSR over the level-L bins, bin i -> partners xk[indptr[i]..indptr[i+1])
+ * with float32 probabilities pk; an empty row = no hetero contact (the uniform draw).  Lists come out sorted, without the
+ * focal bin (quirk Q13) and without blacklisted bins, -1 padded to n_neighbours. */
+typedef struct ig_neighbours ig_neighbours;
+int ig_neighbours_create(const int64_t* indptr, const int32_t* xk, const float* pk, int32_t n_frags, const int32_t* blacklisted,
+                         int32_t n_blacklisted, ig_neighbours** out);
+void ig_neighbours_destroy(ig_neighbours* nb);
+int ig_neighbours_draw(ig_neighbours* nb, uint32_t* mt_key624, int32_t* mt_pos, const int32_t* frags, int32_t n_moves,
+                       int32_t n_neighbours, int32_t* cands_out);
+/* n_moves complete step_sampler calls: draw (on a host thread, ahead of the launches) + ig_step_batch.  cands_out
+ * [n_moves x n_neighbours] receives the drawn lists; the generator state is advanced past all n_moves draws. */
+int ig_step_batch_draw(ig_ctx* ctx, ig_neighbours* nb, uint32_t* mt_key624, int32_t* mt_pos, int32_t n_moves, const int32_t* frags,
+                       int32_t n_neighbours, int32_t* cands_out, ig_move_result* results);
 /* The same in steps, for a caller that splits the slots of a batch over several GPUs (one process per GPU, every rank
  * holds the full problem): upload the lists once; per batch every rank builds all W candidate-genome sets but slices and
  * scores only slots [slot_begin, slot_end); the slot-major score records (ig_batch_records: one device buffer, a fixed

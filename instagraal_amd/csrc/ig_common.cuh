@@ -35,6 +35,7 @@ static int fail(const char* fmt, ...)
     g_err = buf;
     return -1;
 }
+int ig_fail_msg(const char* msg) { return fail("%s", msg); } /* for ig_draw.cpp */
 #define HIPCK(x)                                                                                     \
     do {                                                                                             \
         hipError_t e_ = (x);                                                                         \

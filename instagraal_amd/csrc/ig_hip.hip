@@ -25,6 +25,8 @@
  * IG_NO_HOST_FLAG=1 (batch outcome by copy + synchronise instead of the polled mapped copy), IG_FULL_WGS (grid of k_full_nz),
  * IG_ABLATE (bit 1: every column of k_score_list through the checked path).
  */
+#include <thread>
+
 #include "ig_common.cuh"
 #include "ig_model.cuh"
 #include "ig_kernels_setup.cuh"
@@ -1017,6 +1019,43 @@ static int download_results(ig_ctx* c, int n_moves, ig_move_result* results)
     return 0;
 }
 
+/* the moves [0, n_moves) of the uploaded lists: speculative batches of up to Wmax moves (Wmax == 1: one move per launch
+ * sequence).  `ready(first, count)` is called before moves [first, first + count) are enqueued: the fused draw + step entry
+ * point waits there for its drawing thread and uploads the candidate lists drawn so far. */
+template <class Ready>
+static int run_moves(ig_ctx* c, int n_moves, int max_c, int Wmax, Ready ready)
+{
+    if (Wmax == 1) {
+        for (int i = 0; i < n_moves; i++) {
+            if (ready(i, 1)) return -1;
+            enqueue_move(c, i, max_c, -1, 2);
+            enqueue_apply(c, i, 0, 0);
+        }
+        return 0;
+    }
+    /* speculative batches: score W moves against the same state, commit the conflict-free prefix on the device,
+     * finish a winner that needs the exact delta pass with the one-move tail, continue after it */
+    /* The width follows the conflict rate: where few contigs are left (late in an assembly) nearly every move touches a
+     * contig an earlier move of the batch modified, and slots scored behind the first conflict are wasted work.  Moving
+     * average of the moves a batch got through (a batch that got through all of them counts double: the run was at
+     * least that long); the next batch is 1.5 x that, at most Wmax.  Results do not depend on the widths. */
+    static const int s_adaptive = getenv("IG_ADAPTIVE_W") ? atoi(getenv("IG_ADAPTIVE_W")) : 1;
+    if (c->w_ema <= 0.0 || c->w_ema > Wmax) c->w_ema = Wmax;
+    int done = 0;
+    while (done < n_moves) {
+        const int w_want = s_adaptive ? std::max(2, std::min(Wmax, (int)(1.5 * c->w_ema + 1.5))) : Wmax;
+        const int w_now = std::min(w_want, n_moves - done);
+        if (ready(done, w_now)) return -1;
+        enqueue_score(c, done, w_now, max_c, -1, 2);
+        int next = 0;
+        if (commit_loop(c, done, w_now, &next)) return -1;
+        if (w_now == w_want) /* a batch cut short by the end of the run says nothing */
+            c->w_ema = 0.6 * c->w_ema + 0.4 * (next >= w_now ? std::min(2.0 * w_now, (double)Wmax) : (double)next);
+        done += next;
+    }
+    return 0;
+}
+
 extern "C" int ig_step_batch(ig_ctx* c, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c,
                              ig_move_result* results)
 {
@@ -1028,32 +1067,65 @@ extern "C" int ig_step_batch(ig_ctx* c, int32_t n_moves, const int32_t* frags, c
     const int Wmax = c->init_links_inverse ? batch_width(c, max_c) : 1;
     if (ensure_move_buffers(c, std::max(8, (int)max_c), Wmax)) return -1;
     if (upload_moves(c, n_moves, frags, cands, max_c)) return -1;
-    if (Wmax == 1) {
-        for (int i = 0; i < n_moves; i++) {
-            enqueue_move(c, i, max_c, -1, 2);
-            enqueue_apply(c, i, 0, 0);
+    if (run_moves(c, n_moves, max_c, Wmax, [](int, int) { return 0; })) return -1;
+    return download_results(c, n_moves, results);
+}
+
+/* n_moves consecutive step_sampler calls INCLUDING their first step, the candidate draw (CL:1403-1408 -> return_neighbours
+ * CL:3103-3141): a host thread draws the lists of the moves ahead on the caller's copy of numpy's MT19937 state
+ * (ig_draw.cpp) while the launches of the moves in flight run; the lists are uploaded as they appear.  The draws do not
+ * depend on the genome, so the result is the same as drawing before each move.  cands_out [n_moves x n_neighbours]
+ * receives the lists (sorted, -1 padded). */
+extern "C" int ig_step_batch_draw(ig_ctx* c, ig_neighbours* nb, uint32_t* mt_key624, int32_t* mt_pos, int32_t n_moves,
+                                  const int32_t* frags, int32_t n_neighbours, int32_t* cands_out, ig_move_result* results)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (check_ready(c)) return -1;
+    if (n_moves <= 0) return 0;
+    if (!nb || !mt_key624 || !mt_pos || !cands_out) return fail("ig_step_batch_draw: NULL argument");
+    const int max_c = n_neighbours;
+    if (max_c < 1 || max_c > IG_MAX_CANDIDATES) return fail("ig_step_batch_draw: n_neighbours out of range");
+    if (c->world > 1) return fail("ig_step_batch_draw: this handle scores a contact shard (ig_set_shard %d/%d)", c->rank, c->world);
+    for (int i = 0; i < n_moves; i++)
+        if (frags[i] < 0 || frags[i] >= c->N) return fail("fragment %d out of range", frags[i]);
+    const int Wmax = c->init_links_inverse ? batch_width(c, max_c) : 1;
+    if (ensure_move_buffers(c, std::max(8, (int)max_c), Wmax)) return -1;
+    if (ensure_io(c, n_moves, max_c)) return -1;
+    HIPCK(hipMemcpyAsync(c->d_frags, frags, (size_t)n_moves * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    c->up_moves = n_moves;
+    c->up_max_c = max_c;
+    std::atomic<int> drawn(0), draw_rc(0);
+    std::thread drawer([&]() {
+        const int chunk = 32;
+        for (int i = 0; i < n_moves; i += chunk) {
+            const int n = std::min(chunk, n_moves - i);
+            if (ig_neighbours_draw(nb, mt_key624, mt_pos, frags + i, n, max_c, cands_out + (size_t)i * max_c)) {
+                draw_rc.store(-1, std::memory_order_release);
+                return;
+            }
+            drawn.store(i + n, std::memory_order_release);
         }
-    } else {
-        /* speculative batches: score W moves against the same state, commit the conflict-free prefix on the device,
-         * finish a winner that needs the exact delta pass with the one-move tail, continue after it */
-        /* The width follows the conflict rate: where few contigs are left (late in an assembly) nearly every move touches a
-         * contig an earlier move of the batch modified, and slots scored behind the first conflict are wasted work.  Moving
-         * average of the moves a batch got through (a batch that got through all of them counts double: the run was at
-         * least that long); the next batch is 1.5 x that, at most Wmax.  Results do not depend on the widths. */
-        static const int s_adaptive = getenv("IG_ADAPTIVE_W") ? atoi(getenv("IG_ADAPTIVE_W")) : 1;
-        if (c->w_ema <= 0.0 || c->w_ema > Wmax) c->w_ema = Wmax;
-        int done = 0;
-        while (done < n_moves) {
-            const int w_want = s_adaptive ? std::max(2, std::min(Wmax, (int)(1.5 * c->w_ema + 1.5))) : Wmax;
-            const int w_now = std::min(w_want, n_moves - done);
-            enqueue_score(c, done, w_now, max_c, -1, 2);
-            int next = 0;
-            if (commit_loop(c, done, w_now, &next)) return -1;
-            if (w_now == w_want) /* a batch cut short by the end of the run says nothing */
-                c->w_ema = 0.6 * c->w_ema + 0.4 * (next >= w_now ? std::min(2.0 * w_now, (double)Wmax) : (double)next);
-            done += next;
+    });
+    int uploaded = 0;
+    int rc = run_moves(c, n_moves, max_c, Wmax, [&](int first, int count) -> int {
+        int have;
+        while ((have = drawn.load(std::memory_order_acquire)) < first + count)
+            if (draw_rc.load(std::memory_order_acquire)) return fail("candidate draw failed (fragment out of the distributions' range)");
+        if (have > uploaded) { /* everything drawn so far: the later batches find their lists on the device already */
+            for (int i = uploaded; i < have; i++) {
+                int C = 0;
+                while (C < max_c && cands_out[(size_t)i * max_c + C] >= 0) C++;
+                if (validate_move(c, frags[i], cands_out + (size_t)i * max_c, C)) return -1;
+            }
+            HIPCK(hipMemcpyAsync(c->d_cands + (size_t)uploaded * max_c, cands_out + (size_t)uploaded * max_c,
+                                 (size_t)(have - uploaded) * max_c * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            uploaded = have;
         }
-    }
+        return 0;
+    });
+    drawer.join(); /* the generator state the caller puts back is the one after ALL draws, also on an error */
+    if (rc) return -1;
+    if (draw_rc.load()) return fail("candidate draw failed");
     return download_results(c, n_moves, results);
 }
 

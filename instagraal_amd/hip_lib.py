@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB_PATH = os.path.join(HERE, "libinstagraal_hip.so")
 SRC = os.path.join(HERE, "csrc", "ig_hip.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("ig_ops.cuh", "ig_common.cuh", "ig_model.cuh", "ig_kernels_setup.cuh",
+SRC_HOST = os.path.join(HERE, "csrc", "ig_draw.cpp")  # host-only part: the candidate draw
+DEPS = [SRC, SRC_HOST] + [os.path.join(HERE, "csrc", f) for f in ("ig_ops.cuh", "ig_common.cuh", "ig_model.cuh", "ig_kernels_setup.cuh",
                                                           "ig_kernels_score.cuh", "ig_kernels_commit.cuh")] + \
        [os.path.join(ROOT, "include", f) for f in ("ig_detmath.h", "ig_detmath_tables.h", "instagraal_hip.h")]
 
@@ -45,7 +46,7 @@ def build_lib(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in DEPS):
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-Wno-unused-result", "-Wno-unused-value", "-o", LIB_PATH, SRC]
+           "-Wno-unused-result", "-Wno-unused-value", "-pthread", "-o", LIB_PATH, SRC, SRC_HOST]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -88,6 +89,53 @@ def _ck(rc):
 
 def _p(a):
     return C.c_void_p(0) if a is None else C.c_void_p(a.ctypes.data)
+
+
+class Neighbours:
+    """The jump distributions of setup_distri_frags (CL:3053-3101) in the library's host memory + the draw of
+    return_neighbours (CL:3103-3141) on numpy's legacy MT19937 stream (csrc/ig_draw.cpp).  Needs no GPU."""
+
+    def __init__(self, indptr, xk, pk, n_frags, blacklisted=()):
+        self._h = C.c_void_p()
+        ip = np.ascontiguousarray(indptr, np.int64)
+        x = np.ascontiguousarray(xk, np.int32)
+        p = np.ascontiguousarray(pk, np.float32)
+        b = np.ascontiguousarray(list(blacklisted), np.int32)
+        assert ip.size == n_frags + 1 and x.size == p.size == ip[-1]
+        _ck(lib().ig_neighbours_create(_p(ip), _p(x), _p(p), C.c_int32(int(n_frags)), _p(b) if b.size else C.c_void_p(0),
+                                       C.c_int32(b.size), C.byref(self._h)))
+        self.n_frags = int(n_frags)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().ig_neighbours_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    @staticmethod
+    def take_numpy_state():
+        """(key[624] uint32 copy, pos, rest) of numpy's GLOBAL legacy generator"""
+        st = np.random.get_state()
+        assert st[0] == "MT19937"
+        return np.array(st[1], dtype=np.uint32, copy=True), int(st[2]), st[3:]
+
+    @staticmethod
+    def put_numpy_state(key, pos, rest):
+        np.random.set_state(("MT19937", key, int(pos)) + tuple(rest))
+
+    def draw(self, frags, n_neighbours):
+        """candidate lists of consecutive moves, consuming numpy's global generator exactly as successive
+        return_neighbours calls would -> (n, n_neighbours) int32, sorted, -1 padded"""
+        f = np.ascontiguousarray(frags, np.int32)
+        out = np.full((f.size, int(n_neighbours)), -1, np.int32)
+        key, pos, rest = self.take_numpy_state()
+        cpos = C.c_int32(pos)
+        rc = lib().ig_neighbours_draw(self._h, _p(key), C.byref(cpos), _p(f), C.c_int32(f.size), C.c_int32(int(n_neighbours)), _p(out))
+        self.put_numpy_state(key, cpos.value, rest)
+        _ck(rc)
+        return out
 
 
 def set_batch_width(w):
@@ -194,6 +242,20 @@ class Context:
         res = np.zeros(f.size, MOVE_RESULT_DTYPE)
         _ck(lib().ig_step_batch(self._h, C.c_int32(f.size), _p(f), _p(c), C.c_int32(c.shape[1]), _p(res)))
         return res
+
+    def step_batch_draw(self, neighbours, frags, n_neighbours):
+        """len(frags) complete step_sampler calls, candidate draw included (numpy's global generator is advanced exactly as
+        the reference's loop would) -> (results, candidate lists)"""
+        f = np.ascontiguousarray(frags, np.int32)
+        res = np.zeros(f.size, MOVE_RESULT_DTYPE)
+        cands = np.full((f.size, int(n_neighbours)), -1, np.int32)
+        key, pos, rest = Neighbours.take_numpy_state()
+        cpos = C.c_int32(pos)
+        rc = lib().ig_step_batch_draw(self._h, neighbours._h, _p(key), C.byref(cpos), C.c_int32(f.size), _p(f),
+                                      C.c_int32(int(n_neighbours)), _p(cands), _p(res))
+        Neighbours.put_numpy_state(key, cpos.value, rest)
+        _ck(rc)
+        return res, cands
 
     # ---- speculative batches in steps (slots of a batch split over several GPUs)
     def batch_max_width(self, max_c=5):

@@ -244,6 +244,16 @@ class sampler:  # noqa: N801 - the reference's class name
                 self.distri_frags[i] = dict(distri="ok", xk=np.array(xk), pk=pk)
             else:
                 self.distri_frags[i] = dict(distri=None)
+        # the same distributions as one CSR in the library's host memory: the draw of whole runs of moves happens there
+        # (hip_lib.Neighbours / csrc/ig_draw.cpp), on numpy's generator state, off the interpreter
+        n = int(self.n_frags)
+        lens = np.array([len(self.distri_frags[i]["xk"]) if self.distri_frags[i]["distri"] is not None else 0 for i in range(n)],
+                        dtype=np.int64)
+        ok = [i for i in range(n) if lens[i]]
+        nb_indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        nb_xk = np.concatenate([self.distri_frags[i]["xk"] for i in ok]).astype(np.int32) if ok else np.zeros(0, np.int32)
+        nb_pk = np.concatenate([self.distri_frags[i]["pk"] for i in ok]).astype(np.float32) if ok else np.zeros(0, np.float32)
+        self.neighbours = hip_lib.Neighbours(nb_indptr, nb_xk, nb_pk, n, self.id_frags_blacklisted)
 
     def return_neighbours(self, id_fA, delta0):  # CL:3103-3141
         ori_id = int(id_fA)  # id_d is the identity without repeats
@@ -301,6 +311,10 @@ class sampler:  # noqa: N801 - the reference's class name
     def draw_candidates(self, frags, n_neighbours):
         """Candidates of consecutive moves, consuming numpy's global RNG exactly as successive
         step_sampler calls would (state-independent: CL:3103-3141)."""
+        return self.neighbours.draw(frags, max(1, n_neighbours))
+
+    def draw_candidates_python(self, frags, n_neighbours):
+        """the same through return_neighbours, one numpy call per move (what draw_candidates is checked against)"""
         out = np.full((len(frags), max(1, n_neighbours)), -1, np.int32)
         for i, f in enumerate(frags):
             c = self._clean(f, self.return_neighbours(int(f), n_neighbours))
@@ -308,12 +322,15 @@ class sampler:  # noqa: N801 - the reference's class name
         return out
 
     def step_sampler_batch(self, frags, n_neighbours, candidates=None):
-        """len(frags) consecutive step_sampler calls with no host round trip; returns the structured
-        result array (fields o, dist, op_sampled, id_f_sampled, mean_len, n_contigs, ...)."""
+        """len(frags) consecutive step_sampler calls -- candidate draw included -- in ONE library call: a host thread draws
+        the lists of the moves ahead on numpy's generator state while the launches of the moves in flight run; returns the
+        structured result array (fields o, dist, op_sampled, id_f_sampled, mean_len, n_contigs, ...)."""
         frags = np.ascontiguousarray(frags, np.int32)
         if candidates is None:
-            candidates = self.draw_candidates(frags, n_neighbours)
-        res = self.ctx.step_batch(frags, candidates)
+            res, self.last_candidates = self.ctx.step_batch_draw(self.neighbours, frags, max(1, n_neighbours))
+        else:
+            res = self.ctx.step_batch(frags, candidates)
+            self.last_candidates = candidates
         last = res[-1]
         self.o = self.likelihood_t = float(last["o"])
         self.n_contigs = np.int32(last["n_contigs"])

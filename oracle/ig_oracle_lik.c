@@ -304,28 +304,77 @@ void igo_slice_sp_mat(const int32_t* dat, const int32_t* row, const int32_t* col
     int down_bound_fb = pos_fb + sub_len_fb;
     if (down_bound_fb > l_ctg_fb - 1) down_bound_fb = l_ctg_fb - 1;
 
+#define IGO_SLICE_KEEP(k, keep)                                                                                  \
+    do {                                                                                                          \
+        int fi_ = row[k], fj_ = col[k];                                                                           \
+        int c1_ = vect_id_c[fi_];                                                                                 \
+        (keep) = 0;                                                                                               \
+        if ((c1_ == id_ctg1) || (c1_ == id_ctg2)) {                                                               \
+            int c2_ = vect_id_c[fj_];                                                                             \
+            if ((c2_ == c1_) && (same_contigs == 1) && (is_circ == 0)) { /* KA:565-586 */                         \
+                int pos_fi = vect_pos[fi_], pos_fj = vect_pos[fj_];                                               \
+                int pos_x = pos_fi < pos_fj ? pos_fi : pos_fj;                                                    \
+                int pos_y = pos_fi < pos_fj ? pos_fj : pos_fi;                                                    \
+                int c_a = (pos_x <= down_bound_fa) && (pos_y >= up_bound_fa);                                     \
+                int c_b = (pos_y >= up_bound_fb) && (pos_x <= down_bound_fb);                                     \
+                (keep) = c_a || c_b;                                                                              \
+            } else if (((same_contigs == 0) && (c2_ == id_ctg1)) || (c2_ == id_ctg2)) { /* KA:587, precedence Q10 */ \
+                (keep) = 1;                                                                                       \
+            }                                                                                                     \
+        }                                                                                                         \
+    } while (0)
+
     int64_t n = counter[0];
-    for (int64_t k = 0; k < size_arr; k++) {
-        int fi = row[k], fj = col[k];
-        int c1 = vect_id_c[fi];
-        if (!((c1 == id_ctg1) || (c1 == id_ctg2))) continue;
-        int c2 = vect_id_c[fj];
-        int keep = 0;
-        if ((c2 == c1) && (same_contigs == 1) && (is_circ == 0)) { /* KA:565-586 */
-            int pos_fi = vect_pos[fi], pos_fj = vect_pos[fj];
-            int pos_x = pos_fi < pos_fj ? pos_fi : pos_fj;
-            int pos_y = pos_fi < pos_fj ? pos_fj : pos_fi;
-            int c_a = (pos_x <= down_bound_fa) && (pos_y >= up_bound_fa);
-            int c_b = (pos_y >= up_bound_fb) && (pos_x <= down_bound_fb);
-            keep = c_a || c_b;
-        } else if (((same_contigs == 0) && (c2 == id_ctg1)) || (c2 == id_ctg2)) { /* KA:587, precedence Q10 */
-            keep = 1;
+#ifdef _OPENMP
+    if (g_threads > 1 && size_arr > (1 << 16)) {
+        /* the same compaction in the same (COO) order on g_threads cores: count per chunk, prefix, fill */
+        const int T = g_threads;
+        int64_t* cnt = (int64_t*)calloc((size_t)T + 1, sizeof(int64_t));
+        const int64_t per = (size_arr + T - 1) / T;
+#pragma omp parallel num_threads(T)
+        {
+            const int t = omp_get_thread_num();
+            const int64_t b = (int64_t)t * per, e = (b + per < size_arr) ? b + per : size_arr;
+            int64_t c = 0;
+            for (int64_t k = b; k < e; k++) {
+                int keep;
+                IGO_SLICE_KEEP(k, keep);
+                c += keep;
+            }
+            cnt[t + 1] = c;
+#pragma omp barrier
+#pragma omp single
+            {
+                cnt[0] = n;
+                for (int q = 0; q < T; q++) cnt[q + 1] += cnt[q];
+            }
+            int64_t at = cnt[t];
+            for (int64_t k = b; k < e; k++) {
+                int keep;
+                IGO_SLICE_KEEP(k, keep);
+                if (keep) {
+                    if (dat[k] > 0) {
+                        sub_dat[at] = dat[k];
+                        sub_row[at] = row[k];
+                        sub_col[at] = col[k];
+                    }
+                    at++;
+                }
+            }
         }
+        counter[0] = (int32_t)cnt[T];
+        free(cnt);
+        return;
+    }
+#endif
+    for (int64_t k = 0; k < size_arr; k++) {
+        int keep;
+        IGO_SLICE_KEEP(k, keep);
         if (keep) {
             if (dat[k] > 0) {
                 sub_dat[n] = dat[k];
-                sub_row[n] = fi;
-                sub_col[n] = fj;
+                sub_row[n] = row[k];
+                sub_col[n] = col[k];
             }
             n++;
         }

@@ -52,8 +52,12 @@ def test_rippe_fit_matches_reference_host_functions():
     assert opti.estimate_max_dist_intra([50.0, 9.6, -1.5, 2.0, 3.0e5], 5e-3) == float(g["dmax"])
     assert opti.estimate_max_dist_intra_nuis([50.0, 9.6, -1.45, 2.0, 3.0e5], 5e-3, float(g["dmax"])) == float(g["dmax_nuis"])
     fit, y = opti.estimate_param_rippe(opti.peval(x, p) * 1.0, x)
-    assert np.array_equal(np.array(fit, dtype=np.float64), g["fit"])
-    assert np.array_equal(y, g["y_est"])
+    # the model has two identifiable parameters (slope and the amplitude A 0.53 kuhn^-3 (lm / kuhn)^slope) for the three
+    # numbers kuhn, lm, A: leastsq stops anywhere on that valley, and WHERE depends on the last bits of numpy's log (which
+    # vary with array alignment, i.e. with what was imported before) -- in the reference as well.  Pinned: slope, d, the curve.
+    fit = np.array(fit, dtype=np.float64)
+    assert abs(fit[2] - g["fit"][2]) < 1e-9 and fit[3] == g["fit"][3]
+    assert np.allclose(y, g["y_est"], rtol=1e-8, atol=0)
 
 
 def test_initial_rippe_estimation_matches_reference():
@@ -121,3 +125,83 @@ def test_synthetic_problem_is_well_formed():
     assert heads.sum() == s["id_c"].max() and np.all(s["start_bp"][heads] == 0)
     q = synth.make_problem(*synth.CONFIGS["small"])
     assert np.array_equal(p.coo_cnt, q.coo_cnt) and np.array_equal(p.coo_col, q.coo_col)  # seeded
+
+
+def _stub_sampler(level_csr, n_frags, blacklisted=()):
+    """the host half of the product sampler that needs no device: distributions + return_neighbours"""
+    from instagraal_amd.sampler import sampler as S
+
+    class Stub:
+        pass
+
+    st = Stub()
+    st.sub_sampled_sparse_matrix, st.n_frags, st.id_frags_blacklisted = level_csr, n_frags, list(blacklisted)
+    S.setup_distri_frags(st)
+    st._clean = lambda f, c: S._clean(st, f, c)
+    st.return_neighbours = lambda f, n: S.return_neighbours(st, f, n)
+    st.draw_candidates_python = lambda fr, n: S.draw_candidates_python(st, fr, n)
+    return st
+
+
+@pytest.mark.parametrize("n_neighbours", [1, 5, 9])
+def test_c_draw_equals_numpy_choice(n_neighbours):
+    """csrc/ig_draw.cpp restates RandomState.choice(replace=False) (with p: cumsum / searchsorted rounds; without: a
+    permutation) on numpy's MT19937 state: same candidate lists, same generator state afterwards as return_neighbours
+    (CL:3103-3141) through numpy itself -- including rows with fewer partners than requested (several rounds, duplicates),
+    zero probabilities, bins without any hetero contact (the uniform draw), blacklisted bins, and a pending cached
+    gaussian in the generator."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(12)
+    n = 400
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        kind = i % 8
+        k = 0 if kind == 0 else (int(rng.integers(1, 4)) if kind in (1, 2) else int(rng.integers(4, 60)))
+        for j in rng.choice(n, size=k, replace=False):
+            if j > i:
+                rows.append(i)
+                cols.append(int(j))
+                vals.append(int(rng.integers(1, 50)))
+    m = sp.coo_matrix((vals, (rows, cols)), shape=(n, n), dtype=np.int32).tocsr()
+    st = _stub_sampler(m, n, blacklisted=(5, 77, 200))
+    no_partner = [i for i in range(n) if st.distri_frags[i]["distri"] is None]
+    assert len(no_partner) >= 3
+    frags = rng.permutation(n).astype(np.int32)
+    for seed in (1, 2):
+        np.random.seed(seed)
+        np.random.normal()  # leaves a cached gaussian in the legacy generator: must survive the round trip
+        a = st.draw_candidates_python(frags, n_neighbours)
+        sa = np.random.get_state()
+        tail_a = np.random.normal(), np.random.rand()
+        np.random.seed(seed)
+        np.random.normal()
+        b = st.neighbours.draw(frags, n_neighbours)
+        sb = np.random.get_state()
+        tail_b = np.random.normal(), np.random.rand()
+        assert np.array_equal(a, b)
+        assert np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
+        assert tail_a == tail_b
+    # lists are sorted, distinct, without the focal bin and the blacklisted ones
+    for f, row in zip(frags, b):
+        c = row[row >= 0]
+        assert np.all(np.diff(c) > 0) and f not in c and not set(c) & {5, 77, 200}
+
+
+def test_c_draw_on_synthetic_problem_and_errors():
+    from instagraal_amd import hip_lib, synth
+
+    prob = synth.make_problem(*synth.CONFIGS["tiny"])
+    st = _stub_sampler(prob.sampler_kwargs()["sub_sampled_sparse_matrix"], prob.n_frags)
+    frags = np.resize(np.arange(prob.n_frags), 700).astype(np.int32)
+    np.random.seed(3)
+    a = st.draw_candidates_python(frags, 5)
+    sa = np.random.get_state()
+    np.random.seed(3)
+    b = st.neighbours.draw(frags, 5)
+    sb = np.random.get_state()
+    assert np.array_equal(a, b) and np.array_equal(sa[1], sb[1]) and sa[2] == sb[2]
+    with pytest.raises(hip_lib.HipError):
+        st.neighbours.draw(np.array([prob.n_frags], np.int32), 5)
+    with pytest.raises(hip_lib.HipError):
+        st.neighbours.draw(frags[:3], 17)

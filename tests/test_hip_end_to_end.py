@@ -110,3 +110,46 @@ def test_two_processes_batch_runner():
         assert "TWO_RANK_OK" in out
         return
     raise AssertionError(last)
+
+
+@pytest.mark.parametrize("runner", ["batch", "sharded"])
+def test_bench_starts_its_own_ranks(runner):
+    """`python bench.py --gpus 2` without a launcher: the script starts its two ranks itself (child processes; this rig has
+    one GPU, so IG_BENCH_ONE_DEVICE=1 puts both on cuda:0 with gloo collectives) and relays rank 0's JSON line; both ways
+    of splitting the chain (batch slots / contact rows) leave the maintained likelihood exact and report the world size."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, IG_BENCH_ONE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "small", "--steps", "60", "--warmup", "20",
+           "--no-cpu-baseline", "--nuisance-moves", "0", "--runner", runner]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 60 and out["value"] > 0
+    assert out["roofline"]["launches"] > 0
+    if runner == "batch":
+        assert out["config"]["maintained_likelihood_exact"] is True
+
+
+def test_bench_refuses_ranks_without_devices():
+    """more ranks than GPUs must not silently measure one GPU"""
+    import subprocess
+    import sys
+
+    import torch
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    n = torch.cuda.device_count() + 1
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("IG_BENCH_ONE_DEVICE", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--config", "tiny", "--steps", "5", "--warmup", "0",
+                        "--no-cpu-baseline", "--nuisance-moves", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
