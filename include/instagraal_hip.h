@@ -160,6 +160,12 @@ int ig_debug_last_sums(ig_ctx* ctx, int64_t* nz_hi, int64_t* nz_lo, int64_t* z_h
 int ig_debug_tables(ig_ctx* ctx, float* dist, int32_t* id_c, float* s_tot, int32_t* pos, int32_t* len);
 /* maintained exact sums {nz_hi, nz_lo, z_hi, z_lo, n_intra}; {n_contigs, next_cid, chosen c, k, slot, windowed} */
 int ig_debug_globals(ig_ctx* ctx, int64_t* sums5, int32_t* ints6);
+/* two-tier scoring of the batches (csrc/ig_kernels_screen.cuh): the hardware log2 / exp2 the screening bound leans on, measured
+ * over their whole domain {max |v_log_f32(s) - log2 s| / (2^-23 (|result| + 1)), max |v_exp_f32(y) - 2^y| / (2^-23 2^y)};
+ * and {largest |screened - exact| / bound, largest bound} of the runs under IG_SCREEN_VERIFY=1, {columns screened, columns
+ * scored exactly} */
+int ig_debug_transcendental_error(ig_ctx* ctx, double out2[2]);
+int ig_debug_screen_stats(ig_ctx* ctx, double out6[6]); /* ..., terms screened, terms scored exactly */
 /* 0 disables the reference's dropped-tail behaviour of eval_sub_likelihood (quirk Q5); default 1 */
 int ig_debug_set_tail_quirk(int on);
 

@@ -92,6 +92,8 @@ struct Glob {
     int valid_insert[12];
     int error;
     int stamp_ctr;
+    long long scr_cols, scr_cont; /* two-tier scoring: columns screened, columns scored exactly */
+    long long scr_terms, scr_terms_exact; /* ... and the (contact, column) terms in them */
 };
 
 /* one move slot of a batch (W = 1: the move in flight) */
@@ -102,6 +104,7 @@ struct MoveCtl {
     int superset0; /* candidate 0 was scored with every insert slot (its stale flags were not known yet) */
     int overflow;  /* the slice pool could not hold this slot: it is re-run at the head of the next batch */
     int n_dirty, pad;
+    int exact_chunk, pad2; /* two-tier scoring: entries per work item of the exact kernel (k_contend) */
     double ch_score;
     long long n_slice_tot, n_eval_tot, bytes_min;
     long long d_hi, d_lo; /* k_delta accumulator */
@@ -167,6 +170,18 @@ struct MoveBuf {
      * of slots are ONE block of memory (one all-gather per batch when the slots are split over GPUs): pre_at / cpre_at */
     char* rec;
     size_t rec_stride; /* bytes per slot */
+    /* two-tier scoring of a batch (ig_kernels_screen.cuh): screened sums + bounds per (candidate, column), the columns whose
+     * bound is void, the contender masks */
+    struct ScreenSum* scr; /* [..][NSLOT] */
+    unsigned* scr_void;    /* [..] bit k */
+    unsigned* cont;        /* [..] bit k: column k goes through the exact kernel */
+    /* two-tier scoring: the exact kernel's work list of a batch: eight interleaved sub-lists (k_contend), work[0..8) = their
+     * lengths, work[8..16) = the lengths they would have had if every slot had fitted, item j of sub-list x at work[16 + 8 j + x]:
+     * (chunk << 32 | cw << 12 | k << 4 | segment): entries [chunk * ch, (chunk + 1) * ch) of that segment of candidate cw's
+     * slice list under column k, ch = MoveCtl.exact_chunk of the slot (whole segments would leave the launch waiting for
+     * the few longest ones) */
+    unsigned long long* work;
+    int work_cap;
     int N, M, capC, capW;
 };
 /* layout of MoveBuf.part per candidate (int64 units) */
@@ -225,6 +240,9 @@ struct ig_ctx {
     unsigned timing_mask;
     struct ScoreConst* score_const; /* tables and constants k_score_list stages (parameter set 0) */
     struct ScoreConst* full_const;  /* the same for the parameter set a k_full_nz launch evaluates */
+    struct ScreenConst* screen_const; /* what k_screen stages (parameter set 0) */
+    double* screen_worst;             /* IG_SCREEN_VERIFY: {largest used fraction of a bound, largest bound} */
+    long long n_screen_cols, n_screen_cont; /* diagnostics of the verify mode */
     float* pz_tab;  /* P_z table of parameter set 0 (the model in use) */
     int pz_n;
     float* pz_tab1; /* and of set 1 (the nuisance step's test parameters) */
@@ -236,10 +254,12 @@ struct ig_ctx {
         std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
         double total_ms;
         long long n;
-    } timers[10];
+    } timers[12];
     long long n_batches, n_batch_committed, n_batch_pending, n_batch_predicted;
     int up_moves, up_max_c; /* the uploaded move lists */
     int own_begin, own_end; /* slots whose candidate genomes this handle built for the batch in flight */
+    int own_screened;       /* the batch in flight was scored in two tiers (1), or verified (2) */
+    int exact_grid;         /* two-tier scoring: blocks of the exact kernel's launch (follows what the last batches needed) */
     bool have_contacts, have_sub, have_state, have_init, have_params;
     bool init_links_inverse; /* initial prev / next are mutually inverse (k_commit_batch's de-duplication relies on it; else W = 1) */
 };

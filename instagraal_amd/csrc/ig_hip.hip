@@ -31,6 +31,7 @@
 #include "ig_model.cuh"
 #include "ig_kernels_setup.cuh"
 #include "ig_kernels_score.cuh"
+#include "ig_kernels_screen.cuh"
 #include "ig_kernels_commit.cuh"
 
 /* ================================================================== host side */
@@ -49,8 +50,8 @@ static int dalloc(T** p, size_t n)
         if (dalloc(&(p), (n))) return -1; \
     } while (0)
 
-enum { T_GATHER = 0, T_MUTATE, T_SCORE, T_FINALIZE, T_DELTA, T_APPLY, T_POST, T_COMMIT, T_SLICE, T_ARGMAX, T_COUNT };
-static const char* kTimerNames[T_COUNT] = {"gather", "mutate", "score", "finalize", "delta", "apply", "post", "commit", "slice", "argmax"};
+enum { T_GATHER = 0, T_MUTATE, T_SCORE, T_FINALIZE, T_DELTA, T_APPLY, T_POST, T_COMMIT, T_SLICE, T_ARGMAX, T_SCREEN, T_COUNT };
+static const char* kTimerNames[T_COUNT] = {"gather", "mutate", "score", "finalize", "delta", "apply", "post", "commit", "slice", "argmax", "screen"};
 
 struct TimedLaunch {
     ig_ctx* c;
@@ -135,12 +136,17 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->pz_tab = c->pz_tab1 = nullptr;
     c->score_const = nullptr;
     c->full_const = nullptr;
+    c->screen_const = nullptr;
+    c->screen_worst = nullptr;
+    c->n_screen_cols = c->n_screen_cont = 0;
     c->pz_n = c->pz_n1 = 0;
     c->timing_mask = 0xffff;
     c->timing = false;
     c->n_batches = c->n_batch_committed = c->n_batch_pending = c->n_batch_predicted = 0;
     c->up_moves = c->up_max_c = 0;
     c->own_begin = c->own_end = 0;
+    c->own_screened = 0;
+    c->exact_grid = 0;
     for (int i = 0; i < T_COUNT; i++) {
         c->timers[i].name = kTimerNames[i];
         c->timers[i].total_ms = 0;
@@ -204,6 +210,10 @@ static void free_move_buffers(ig_ctx* c)
     hipFree(m.ctl);
     hipFree(m.sinfo);
     hipFree(m.rec);
+    hipFree(m.scr);
+    hipFree(m.scr_void);
+    hipFree(m.cont);
+    hipFree(m.work);
     hipFree(c->own_tag);
     hipFree(c->own_idx);
     c->own_tag = c->own_idx = nullptr;
@@ -241,6 +251,8 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipFree(c->lgf_tab);
     hipFree(c->score_const);
     hipFree(c->full_const);
+    hipFree(c->screen_const);
+    hipFree(c->screen_worst);
     hipFree(c->glob);
     hipFree(c->d_results);
     hipFree(c->d_frags);
@@ -312,7 +324,7 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
             Zc = std::max<size_t>((size_t)atoll(e), (size_t)std::max<long long>(c->Z, 1) * (size_t)capC);
         m.packed = want_packed; /* IG_WIDE_LISTS=1 (tests) forces the 12-byte form */
         if (m.packed) {
-            DALLOC(m.sl_pk, Zc);
+            DALLOC(m.sl_pk, Zc + 8192); /* slack: k_screen's look-ahead loads run past the end of the last list */
         } else {
             DALLOC(m.sl_li, Zc);
             DALLOC(m.sl_lj, Zc);
@@ -333,6 +345,12 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
     DALLOC(m.sinfo, C * NSLOT);
     m.rec_stride = rec_bytes_per_slot(capC);
     DALLOC(m.rec, m.rec_stride * (size_t)capW);
+    DALLOC(m.scr, C * NSLOT);
+    DALLOC(m.scr_void, C);
+    DALLOC(m.cont, C);
+    m.work_cap = (int)std::min<size_t>((size_t)1 << 20, 4 * C * NSLOT * SLICE_SEG + 4096);
+    DALLOC(m.work, (size_t)m.work_cap + 32);
+    HIPCK(hipMemset(m.cont, 0xff, C * sizeof(unsigned)));
     DALLOC(c->own_tag, N);
     DALLOC(c->own_idx, N);
     HIPCK(hipMemset(c->own_tag, 0xff, N * sizeof(int)));
@@ -590,6 +608,8 @@ extern "C" int ig_set_params(ig_ctx* c, const float p[8], float mean_subfrag_kb,
             if (!c->score_const) DALLOC(c->score_const, 1);
             hipLaunchKernelGGL(k_build_score_const, dim3((LDS_PZ + 2 + 255) / 256), dim3(256), 0, c->stream, c->glob, PzTab{tab, n}, c->lgf_tab,
                                c->score_const, 0);
+            if (!c->screen_const) DALLOC(c->screen_const, 1);
+            hipLaunchKernelGGL(k_build_screen_const, dim3((LDS_PZ + 2 + 255) / 256), dim3(256), 0, c->stream, c->glob, PzTab{tab, n}, c->screen_const);
         }
     }
     if (which == 0) {
@@ -825,11 +845,49 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                                    g_tail_quirk, pz, w_begin);
                 hipEventRecord(c->ev_tail, c->stream2);
             }
+            /* two-tier scoring (batches on one handle, packed lists): every column through the float screening kernel, the exact
+             * kernel only for the columns that can still win (ig_kernels_screen.cuh).  IG_SCREEN=0: everything exact;
+             * IG_SCREEN_VERIFY=1: everything exact AND screened, the bound checked column by column. */
+            const int s_screen = getenv("IG_SCREEN") ? atoi(getenv("IG_SCREEN")) : 1; /* read per launch, like the next one */
+            const int verify = getenv("IG_SCREEN_VERIFY") ? atoi(getenv("IG_SCREEN_VERIFY")) : 0; /* read per launch: a test toggles it */
+            const bool screen = (s_screen || verify) && phase == 2 && W > 1 && c->world == 1 && c->mb.packed;
+            int contenders_only = 0;
+            if (screen) {
+                {
+                    TimedLaunch t(c, T_SCREEN);
+                    hipLaunchKernelGGL(k_screen, dim3(SLICE_SEG, NSLOT, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->screen_const, c->mb,
+                                       c->mb.scr, c->mb.scr_void, max_c, w_begin);
+                }
+                hipMemsetAsync(c->mb.work, 0, 16 * sizeof(unsigned long long), c->stream);
+                if (c->exact_grid <= 0) c->exact_grid = 32768;
+                c->exact_grid = std::min(c->exact_grid, c->mb.work_cap);
+                hipStreamWaitEvent(c->stream, c->ev_tail, 0); /* the contender test reads the exact tail sums (quirk Q5) */
+                hipLaunchKernelGGL(k_contend, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, c->mb.scr, c->mb.scr_void, c->mb.cont, w_begin,
+                                   getenv("IG_CONTEND_ALL") ? atoi(getenv("IG_CONTEND_ALL")) : 0, c->exact_grid,
+                                   getenv("IG_EXACT_CHUNK") ? std::max(256, atoi(getenv("IG_EXACT_CHUNK"))) : EXACT_CHUNK);
+                hipLaunchKernelGGL(k_worklist, dim3(nW), dim3(256), 0, c->stream, c->mb, c->mb.cont, w_begin, c->exact_grid);
+                contenders_only = verify ? 0 : 1;
+            }
+            c->own_screened = screen ? (verify ? 2 : 1) : 0;
             TimedLaunch t(c, T_SCORE);
             const int s_eb = SLICE_SEG; /* one workgroup per (segment, column, candidate) */
             const int s_abl = getenv("IG_ABLATE") ? atoi(getenv("IG_ABLATE")) : 0; /* read per launch: a test toggles it */
-            hipLaunchKernelGGL(k_score_list<LDS_COL_SMALL>, dim3(s_eb, NSLOT, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->score_const,
-                               c->mb, c->lgf_tab, pz, s_abl, max_c, w_begin);
+            if (contenders_only) {
+                /* the work list k_contend left; the grid follows what the previous batches needed (commit_loop), the workgroups
+                 * past the end of the list leave on their first load, a slot whose items do not fit is re-run */
+                hipLaunchKernelGGL(k_score_list<LDS_COL_SMALL>, dim3(c->exact_grid), dim3(SCORE_THREADS), 0, c->stream, c->score_const, c->mb,
+                                   c->lgf_tab, pz, s_abl, max_c, w_begin, 1);
+            } else {
+                hipLaunchKernelGGL(k_score_list<LDS_COL_SMALL>, dim3(s_eb, NSLOT, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->score_const,
+                                   c->mb, c->lgf_tab, pz, s_abl, max_c, w_begin, 0);
+            }
+            if (screen && verify) {
+                if (!c->screen_worst) {
+                    if (dalloc(&c->screen_worst, 2) == 0) hipMemsetAsync(c->screen_worst, 0, 2 * sizeof(double), c->stream);
+                }
+                hipLaunchKernelGGL(k_screen_verify, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, c->mb.scr, c->mb.scr_void, w_begin,
+                                   c->screen_worst);
+            }
         }
     }
     if (phase == 1 || phase == 2) {
@@ -840,7 +898,7 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
             else
                 hipStreamWaitEvent(c->stream, c->ev_tail, 0);
             TimedLaunch t(c, T_FINALIZE);
-            hipLaunchKernelGGL(k_records, dim3(max_c, nW), dim3(64), 0, c->stream, c->mb, w_begin);
+            hipLaunchKernelGGL(k_records, dim3(max_c, nW), dim3(64), 0, c->stream, c->mb, w_begin, c->own_screened ? 1 : 0);
             if (phase == 2 && W > 1 && c->world == 1) { /* batches: predicted windowed winners get their exact delta now */
                 static const int s_pred2 = getenv("IG_PREDICT_PASSES") ? atoi(getenv("IG_PREDICT_PASSES")) : 2;
                 if (s_pred2 >= 2) hipLaunchKernelGGL(k_predict, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, w_begin, 0);
@@ -948,6 +1006,8 @@ static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
         c->n_batch_committed += bo[0] - next;
         c->n_batch_predicted += bo[4];
         c->n_contigs_seen = bo[5];
+        if (c->own_screened == 1 && next == 0) /* first commit of this batch: size the exact kernel's next grid */
+            c->exact_grid = std::min(c->mb.work_cap, std::max(4096, (int)(1.25 * bo[6]) + 2048));
         next = bo[0];
         if (bo[1] >= 0) { /* slot bo[1] chose a windowed winner: delta + apply with the one-move kernels, then go on */
             enqueue_apply(c, done + bo[1], bo[1], 0);
@@ -1461,6 +1521,38 @@ extern "C" int ig_debug_tables(ig_ctx* c, float* dist, int32_t* id_c, float* s_t
         id_c[i] = cp[i].x;
         pos[i] = cp[i].y;
     }
+    return 0;
+}
+
+/* v_log_f32 / v_exp_f32 over their whole domain against the contract's double functions (the screening bound assumes
+ * both below SCR_KL = SCR_KE = 4 in these units): out[0], out[1] as k_transcendental_error defines them */
+extern "C" int ig_debug_transcendental_error(ig_ctx* c, double out2[2])
+{
+    HIPCK(hipSetDevice(c->device));
+    double* d;
+    DALLOC(d, 2);
+    HIPCK(hipMemsetAsync(d, 0, 2 * sizeof(double), c->stream));
+    hipLaunchKernelGGL(k_transcendental_error, dim3(256 * 16), dim3(256), 0, c->stream, d);
+    HIPCK(hipMemcpyAsync(out2, d, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    hipFree(d);
+    return 0;
+}
+
+/* {largest |screened - exact| / bound seen, largest bound} of the runs under IG_SCREEN_VERIFY=1; {columns screened, columns
+ * scored exactly} since the state was uploaded */
+extern "C" int ig_debug_screen_stats(ig_ctx* c, double out4[6])
+{
+    HIPCK(hipSetDevice(c->device));
+    HIPCK(hipStreamSynchronize(c->stream));
+    out4[0] = out4[1] = 0.0;
+    if (c->screen_worst) HIPCK(hipMemcpy(out4, c->screen_worst, 2 * sizeof(double), hipMemcpyDeviceToHost));
+    Glob hg;
+    HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));
+    out4[2] = (double)hg.scr_cols;
+    out4[3] = (double)hg.scr_cont;
+    out4[4] = (double)hg.scr_terms;
+    out4[5] = (double)hg.scr_terms_exact;
     return 0;
 }
 

@@ -582,6 +582,10 @@ __global__ void __launch_bounds__(64)
             batch_out[3] = n_cand;
             batch_out[4] = n_predicted;
             batch_out[5] = n_contigs;
+            int need = 0; /* two-tier scoring: work items the exact kernel's grid has to cover (8 x the longest sub-list, had every slot fitted) */
+            if (mb.work)
+                for (int x = 0; x < 8; x++) need = max(need, 8 * (int)mb.work[8 + x]);
+            batch_out[6] = need;
             /* the host polls this copy (mapped, coherent host memory): it learns the outcome while k_commit_batch is still
              * running and has the next launches queued behind it when it ends */
             if (host_out) {
@@ -591,6 +595,7 @@ __global__ void __launch_bounds__(64)
                 host_out[3] = n_cand;
                 host_out[4] = n_predicted;
                 host_out[5] = n_contigs;
+                host_out[6] = need;
                 __threadfence_system();
                 host_out[7] = seq;
             }

@@ -110,11 +110,18 @@ __global__ void __launch_bounds__(256)
         mc.pd_hi = mc.pd_lo = 0;
         mc.overflow = 0;
         mc.pad = 0;
+        mc.exact_chunk = 0;
+        mc.pad2 = 0;
         mb.ctl[w] = mc;
     }
     for (int i = t; i < C * P_STRIDE; i += blockDim.x) mb.part[(size_t)CW(w, 0) * P_STRIDE + i] = 0;
     for (int i = t; i < C * Q_STRIDE; i += blockDim.x) mb.qpart[(size_t)CW(w, 0) * Q_STRIDE + i] = 0;
     for (int i = t; i < C * IG_N_TMP_STRUCT; i += blockDim.x) mb.scores[(size_t)CW(w, 0) * IG_N_TMP_STRUCT + i] = 0.0;
+    for (int i = t; i < C * NSLOT * 2; i += blockDim.x) ((long long*)mb.scr)[(size_t)CW(w, 0) * NSLOT * 2 + i] = 0;
+    if (t < C) {
+        mb.scr_void[CW(w, t)] = 0;
+        mb.cont[CW(w, t)] = 0xffffffffu;
+    }
     if (t < C) {
         CandMeta m;
         const int B = cands[t];
@@ -764,24 +771,24 @@ struct ScoreLds {
     ColMeta cm[NCODE];
     long long red[2][SCORE_THREADS / 64];
 };
+/* one workgroup: segment blockIdx.x of the slice list of candidate (w, c), column k */
+/* one workgroup: entries [first, first + count) of segment `seg` of the slice list of candidate (w, c), under column k */
 template <int CAP>
-__global__ void __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(SCORE_WAVES)))
-    k_score_list(const ScoreConst* __restrict__ sc, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int ablate, int max_c,
-                 int w_begin)
+__device__ __forceinline__ void score_workgroup(ScoreLds<CAP>& L, const ScoreConst* __restrict__ sc, const MoveBuf& mb,
+                                                const double* __restrict__ lgf_tab, const PzTab& pz, int ablate, int w, int c, int k,
+                                                int seg, long long first, long long count)
 {
-    __shared__ ScoreLds<CAP> L;
     /* everything the early exits and the set-up need is loaded before the first branch: one round trip, not five */
-    const int w = w_begin + blockIdx.z / max_c, c = blockIdx.z % max_c;
-    const int k = blockIdx.y;
     const int cw = CW(w, c);
     const int C = mb.ctl[w].C;
     const int n_uniq = mb.meta[cw].n_uniq, m_loc = mb.meta[cw].m_loc;
-    const long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + blockIdx.x]; /* workgroup x streams segment x */
-    const long long off = mb.sloff[(size_t)cw * SLICE_SEG + blockIdx.x];
+    const long long n_seg = mb.part[(size_t)cw * P_STRIDE + P_CNT + seg];
+    const long long off = mb.sloff[(size_t)cw * SLICE_SEG + seg] + first;
+    const long long n = n_seg - first < count ? n_seg - first : count;
     const ig_params p = sc->par;
     const ig_hot hp = sc->hot;
     const float mean = sc->mean_kb;
-    if (c >= C || k > n_uniq || n == 0 || off < 0) return;
+    if (c >= C || k > n_uniq || n <= 0 || off < first) return;
     const int M = mb.M;
     const uint2* gcol = mb.coords + (size_t)(cw * NSLOT + k) * M;
     const bool staged = m_loc <= CAP;
@@ -831,6 +838,27 @@ __global__ void __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per
             atomic_add_ll(&part[P_NZ + 2 * k + 1], lo);
         }
     }
+}
+
+template <int CAP>
+__global__ void __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(SCORE_WAVES)))
+    k_score_list(const ScoreConst* __restrict__ sc, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int ablate, int max_c,
+                 int w_begin, int contenders_only)
+{
+    __shared__ ScoreLds<CAP> L;
+    if (!contenders_only) { /* every column: the grid is (segment, column, candidate), a workgroup streams a whole segment */
+        score_workgroup<CAP>(L, sc, mb, lgf_tab, pz, ablate, w_begin + blockIdx.z / max_c, blockIdx.z % max_c, blockIdx.y, blockIdx.x, 0,
+                             0x7fffffffffffffffLL);
+        return;
+    }
+    /* two-tier scoring: the block index is an index into the work list k_contend left (MoveBuf.work: eight interleaved
+     * sub-lists, their lengths in work[0..8), the items from work[16] on); a workgroup past the end of its sub-list leaves on its first (scalar) load */
+    if ((blockIdx.x >> 3) >= mb.work[blockIdx.x & 7]) return;
+    const unsigned long long e = mb.work[16 + blockIdx.x];
+    const int cw = (int)((e >> 12) & 0xfffffu), k = (int)((e >> 4) & 0xffu), seg = (int)(e & 0xfu);
+    const int w = cw / mb.capC;
+    const long long ch = mb.ctl[w].exact_chunk;
+    score_workgroup<CAP>(L, sc, mb, lgf_tab, pz, ablate, w, cw % mb.capC, k, seg, (long long)(e >> 32) * ch, ch);
 }
 
 /* k_full_nz: evaluate_likelihood_sparse (KA:4374-4488) over all contacts, exact sums -> out[0..1] (the from-scratch
@@ -1327,7 +1355,7 @@ __global__ void __launch_bounds__(256) k_tail(const long long* __restrict__ rowp
 }
 
 /* k_records: after k_score_list and k_tail: the slot-major records of the commit step */
-__global__ void __launch_bounds__(64) k_records(MoveBuf mb, int w_begin)
+__global__ void __launch_bounds__(64) k_records(MoveBuf mb, int w_begin, int contenders_only)
 {
     const int c = blockIdx.x, w = w_begin + blockIdx.y;
     if (c >= mb.ctl[w].C) return;
@@ -1345,7 +1373,9 @@ __global__ void __launch_bounds__(64) k_records(MoveBuf mb, int w_begin)
     __syncthreads();
     if (t < IG_N_TMP_STRUCT) {
         SlotPre r;
-        const int k = m.kidx[t];
+        int k = m.kidx[t];
+        /* two-tier scoring: a column that cannot win (k_contend) was not scored exactly: the decide step must not see it */
+        if (contenders_only && k > 0 && !((mb.cont[cw] >> k) & 1u)) k = -1;
         r.k = k > 0 ? k : 0;
         r.nz_hi = r.nz_lo = r.dz_hi = r.dz_lo = r.dni = 0;
         r.nz_d = r.nz_cut_d = 0.0;

@@ -1,0 +1,506 @@
+/* ig_kernels_screen.cuh -- two-tier scoring of a speculative batch.
+ *
+ * A batch needs the WINNER of every move and the winner's exact sums, not 105 exact scores per move: on the headline
+ * workload 5 of the 104 scored columns of a move lie within 8 of the best score and 8 within 128 (tools/score_gaps.py), the
+ * rest lose by thousands.  So every (contact, column) gets a cheap float evaluation of the same term with a RIGOROUS bound
+ * on its distance from the contract's exact term (k_screen); the columns that can still win -- upper bound of the score
+ * not below the best lower bound among the columns that are certainly scored -- are the contenders (k_contend), and only
+ * those (plus column 0, the current genome, of every candidate that has one) go through the exact k_score_list.  The decide
+ * step then sees the non-contenders as not scored.  The outcome -- winners, exact sums, genomes -- is the same as scoring
+ * everything exactly, provided the bound holds; IG_SCREEN_VERIFY=1 scores everything exactly as well and checks the bound
+ * column by column (tests), and the two hardware functions the bound leans on are checked over their whole domain
+ * (ig_debug_transcendental_error, tests/test_hip_screen.py).
+ *
+ * The screening term (linear contigs, one-log domain; anything else makes the column a contender unconditionally), f32,
+ * round to nearest, u = 2^-24; K_L, K_E = assumed error of v_log_f32 / v_exp_f32 in units of 2 u (|result|, 1) resp. 2 u result:
+ *     L  = v_log_f32(s)                     |L - log2 s|  <= K_L 2u (|L| + 1)
+ *     y  = fma(slope, L, la)                la = (float) log2(amp)
+ *     yy = in ? max(y, lv) : lv             lv = (float) log2(v_inter)
+ *     ex = v_exp_f32(yy)                    |ex - 2^yy|   <= K_E 2u 2^yy
+ *     m  = (float) ob * yy
+ *     t  = fma(m, (float) log10(2), -ex) + (float) pzc[d]
+ * against the contract's  ob * yy * log10(2) - ex + pzc  (- log10(ob!), which is the same in every column of a candidate
+ * and drops out of the score differences).  Propagating the roundings with K_L = K_E = 4:
+ *     |t - exact| <= u { ob (4 |yy| + 2.72 Cy) + ex (6.3 |yy| + 6.3 Cy + 10.1) + 3.1 pzc } + 2^-32,
+ *     Cy = |log2 amp| + |slope| + |log2 v_inter|.
+ * A workgroup accumulates sum(t) in double, sum(ob), sum(ex) and max |yy| and publishes its partial sum and bound as
+ * integers (units of 2^-20: integer atomics, deterministic totals). */
+#pragma once
+
+#define SCR_KL 4.0
+#define SCR_KE 4.0
+#define SCR_FIX 1048576.0 /* 2^20 */
+#ifndef EXACT_CHUNK
+#define EXACT_CHUNK 4096 /* entries per work item of the exact kernel in a two-tier batch */
+#endif
+
+struct alignas(16) ScreenConst {
+    float pzc[LDS_PZ + 2]; /* (float)(P_z log10 e) per rank distance; from the table's end on and for trans pairs: the trans level */
+    float slope, la, lv, d_max;
+    float cy;      /* |log2 amp| + |slope| + |log2 v_inter| (rounded up) */
+    float pzc_max; /* largest table entry */
+    int fast;      /* parameters in the one-log domain */
+    int pz_n;      /* length of the P_z table the exact path uses */
+};
+
+__global__ void k_build_screen_const(const Glob* g, PzTab pz, ScreenConst* out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const ig_params p = g->par[0];
+    const int pzn = min(pz.n, LDS_PZ);
+    if (i < LDS_PZ + 2) out->pzc[i] = (float)((double)(i < pzn ? pz.v[i] : p.v_inter) * IG_LOG_E_F);
+    if (i == 0) {
+        const ig_hot h = ig_hot_make(p, ig_tab());
+        out->slope = p.slope;
+        out->la = (float)h.log2_amp;
+        out->lv = (float)h.log2_v_inter;
+        out->d_max = h.d_max;
+        out->cy = (float)((__builtin_fabs(h.log2_amp) + __builtin_fabs(h.slope) + __builtin_fabs(h.log2_v_inter)) * 1.0001 + 1e-6);
+        float mx = (float)((double)p.v_inter * IG_LOG_E_F);
+        for (int q = 0; q < pzn; q++) mx = fmaxf(mx, (float)((double)pz.v[q] * IG_LOG_E_F));
+        out->pzc_max = mx * 1.0001f;
+        out->fast = h.fast;
+        out->pz_n = pz.n;
+    }
+}
+
+/* per (candidate, column): approximate slice sum and its bound (2^-20 units), and the columns whose bound is void */
+struct ScreenSum {
+    long long s_fix, b_fix;
+};
+
+#ifndef SCREEN_BATCH
+#define SCREEN_BATCH 4
+#endif
+struct alignas(16) ScreenLds {
+    float pzc[LDS_PZ + 2]; /* first member: copied with 16-byte vectors */
+    uint2 col[LDS_COL_SMALL];
+    ColMeta cm[NCODE];
+    double red_s[SCORE_THREADS / 64];
+    float red_e[SCORE_THREADS / 64], red_y[SCORE_THREADS / 64], red_o[SCORE_THREADS / 64];
+    unsigned red_bad[SCORE_THREADS / 64];
+};
+
+/* one screened term; MASKED: the lane's entry may lie past the end of the list (last, partly filled step) */
+template <bool STAGED, bool HAS_CUT, bool MASKED>
+__device__ __forceinline__ void screen_term(unsigned long long pk, bool live, const uint2* gcol, const ScreenLds& L, float slope, float la,
+                                            float lv, float d_max, float c10, unsigned cut, double& acc, float& exs, float& obs, float& ymax,
+                                            unsigned& bad)
+{
+    const unsigned lo = (unsigned)pk, hi = (unsigned)(pk >> 32);
+    bad |= MASKED ? (live ? hi : 0u) : hi; /* bits 8.. = the count: the largest count's leading bit survives the OR (checked at the end) */
+    const unsigned li = lo & 0xfffffu, lj = __builtin_amdgcn_alignbit(hi, lo, 20) & 0xfffffu, ob = hi >> 8;
+    const uint2 ai = STAGED ? L.col[li] : gcol[li];
+    const uint2 bj = STAGED ? L.col[lj] : gcol[lj];
+    /* packed lists: ranks below 2^20, the contig code in bits 28..30 -- for two different codes the difference of the
+     * words is at least 2^28 - 2^20: "same contig" is d < 2^27, and min(d, LDS_PZ) lands on the trans level by itself */
+    const unsigned d = abs_diff_u32(ai.y, bj.y);
+    const bool cis = d < (1u << 27);
+    const float sv = fabsf(__uint_as_float(ai.x) - __uint_as_float(bj.x));
+    const bool in = cis && (sv > 0.0f) && (sv < d_max);
+    const float pzc = L.pzc[min(d, (unsigned)LDS_PZ)];
+    const float lg2 = __builtin_amdgcn_logf(sv);
+    const float y = __builtin_fmaf(slope, lg2, la);
+    float ymx;
+    __asm__("v_max_f32 %0, %1, %2" : "=v"(ymx) : "v"(y), "v"(lv)); /* y is a number wherever it is used */
+    const float yy = in ? ymx : lv;
+    const float ex = __builtin_amdgcn_exp2f(yy);
+    const float obf = (float)ob; /* exact: packed lists hold counts below 2^24 */
+    const float m = obf * yy;
+    float t = __builtin_fmaf(m, c10, -ex) + pzc;
+    float exa = ex, oba = obf, yya = yy;
+    if (MASKED) {
+        t = live ? t : 0.0f;
+        exa = live ? ex : 0.0f;
+        oba = live ? obf : 0.0f;
+        yya = live ? yy : 0.0f;
+    }
+    acc += (double)t;
+    exs += exa;
+    obs += oba;
+    __asm__("v_max_f32 %0, %0, |%1|" : "+v"(ymax) : "v"(yya));
+    if (HAS_CUT) bad |= (cis && d >= cut && (!MASKED || live)) ? 0x80000000u : 0u; /* counts are below 2^24: bit 31 is free */
+}
+
+/* a wave streams steps of 64 x SCREEN_BATCH consecutive entries (steps wave, wave + 4, ...); the entries of the next step
+ * are loaded before this step's terms.  The lists live in a pool with slack behind its last entry (ensure_move_buffers):
+ * the look-ahead loads need no clamping; only the last, partly filled step of a wave masks its lanes. */
+template <bool STAGED, bool HAS_CUT>
+__device__ __forceinline__ void screen_loop(const unsigned long long* __restrict__ slp, unsigned n, const uint2* gcol, const ScreenLds& L,
+                                            float slope, float la_s, float lv_s, float d_max, unsigned cut, double& acc, float& exs, float& obs,
+                                            float& ymax, unsigned& bad)
+{
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned step = 64 * SCREEN_BATCH, stride = step * (SCORE_THREADS / 64);
+    const float c10 = (float)IG_LOG2_10_INV;
+    float la, lv; /* in vector registers once, not copied from scalar ones before every use */
+    __asm__ volatile("v_mov_b32 %0, %1" : "=v"(la) : "s"(la_s));
+    __asm__ volatile("v_mov_b32 %0, %1" : "=v"(lv) : "s"(lv_s));
+    const unsigned long long* ptr = slp + wave * step + lane;
+    unsigned long long nx[SCREEN_BATCH];
+#pragma unroll
+    for (int u = 0; u < SCREEN_BATCH; u++) nx[u] = ptr[u * 64];
+    unsigned s0 = wave * step; /* first entry of the wave's current step */
+    for (; s0 + step <= n; s0 += stride) { /* full steps */
+        unsigned long long pk[SCREEN_BATCH];
+#pragma unroll
+        for (int u = 0; u < SCREEN_BATCH; u++) pk[u] = nx[u];
+        ptr += stride;
+#pragma unroll
+        for (int u = 0; u < SCREEN_BATCH; u++) nx[u] = ptr[u * 64];
+#pragma unroll
+        for (int u = 0; u < SCREEN_BATCH; u++)
+            screen_term<STAGED, HAS_CUT, false>(pk[u], true, gcol, L, slope, la, lv, d_max, c10, cut, acc, exs, obs, ymax, bad);
+    }
+    if (s0 < n) { /* the partly filled step */
+        const unsigned long long safe = slp[0];
+#pragma unroll
+        for (int u = 0; u < SCREEN_BATCH; u++) {
+            const bool live = s0 + u * 64 + lane < n;
+            screen_term<STAGED, HAS_CUT, true>(live ? nx[u] : safe, live, gcol, L, slope, la, lv, d_max, c10, cut, acc, exs, obs, ymax, bad);
+        }
+    }
+}
+
+/* k_screen: one workgroup = (segment of the slice list, column k, candidate cw), as k_score_list */
+__global__ void __launch_bounds__(SCORE_THREADS)
+    k_screen(const ScreenConst* __restrict__ sc, MoveBuf mb, ScreenSum* __restrict__ scr, unsigned* __restrict__ scr_void, int max_c,
+             int w_begin)
+{
+    __shared__ ScreenLds L;
+    const int w = w_begin + blockIdx.z / max_c, c = blockIdx.z % max_c;
+    const int k = blockIdx.y;
+    const int cw = CW(w, c);
+    const int C = mb.ctl[w].C;
+    const int n_uniq = mb.meta[cw].n_uniq, m_loc = mb.meta[cw].m_loc;
+    const long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + blockIdx.x];
+    const long long off = mb.sloff[(size_t)cw * SLICE_SEG + blockIdx.x];
+    const float slope = sc->slope, la = sc->la, lv = sc->lv, d_max = sc->d_max, cy = sc->cy, pzc_max = sc->pzc_max;
+    const int fast = sc->fast, pz_n = sc->pz_n;
+    if (c >= C || k > n_uniq || n == 0 || off < 0) return;
+    const uint2* gcol = mb.coords + (size_t)(cw * NSLOT + k) * mb.M;
+    const bool staged = m_loc <= LDS_COL_SMALL;
+    {
+        const float4* src = (const float4*)sc->pzc;
+        float4* dst = (float4*)L.pzc;
+        for (int i = threadIdx.x; i < (LDS_PZ + 2) / 4; i += SCORE_THREADS) dst[i] = src[i];
+        if (threadIdx.x < (LDS_PZ + 2) % 4) L.pzc[(LDS_PZ + 2) / 4 * 4 + threadIdx.x] = sc->pzc[(LDS_PZ + 2) / 4 * 4 + threadIdx.x];
+    }
+    if (staged)
+        for (int i = threadIdx.x; i < m_loc; i += SCORE_THREADS) L.col[i] = gcol[i];
+    if (threadIdx.x < NCODE) L.cm[threadIdx.x] = mb.cmeta[(size_t)(cw * NSLOT + k) * NCODE + threadIdx.x];
+    __syncthreads();
+    unsigned circ_mask = 0;
+#pragma unroll
+    for (int q = 0; q < NCODE; q++) circ_mask |= (L.cm[q].stot != 0) ? (1u << q) : 0u;
+    if (circ_mask || !fast) { /* outside the screening term's domain: the column goes through the exact kernel */
+        if (threadIdx.x == 0) atomicOr(&scr_void[cw], 1u << k);
+        return;
+    }
+    double acc = 0.0;
+    float exs = 0.0f, ymax = 0.0f, obs = 0.0f;
+    unsigned bad = 0;
+    const unsigned cut = pz_n > LDS_PZ ? (unsigned)LDS_PZ : 0xffffffffu;
+    const unsigned long long* slp = mb.sl_pk + off;
+    if (pz_n > LDS_PZ) { /* a P_z table longer than its LDS copy: pairs beyond the copy void the column's bound */
+        if (staged) screen_loop<true, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
+        else screen_loop<false, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
+    } else {
+        if (staged) screen_loop<true, false>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
+        else screen_loop<false, false>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_down(acc, o, 64);
+        exs += __shfl_down(exs, o, 64);
+        obs += __shfl_down(obs, o, 64);
+        ymax = fmaxf(ymax, __shfl_down(ymax, o, 64));
+        bad |= __shfl_down(bad, o, 64);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+        L.red_s[wv] = acc;
+        L.red_e[wv] = exs;
+        L.red_o[wv] = obs;
+        L.red_y[wv] = ymax;
+        L.red_bad[wv] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S = 0.0, E = 0.0, O = 0.0, Y = 0.0;
+        unsigned B = 0;
+        for (int v = 0; v < SCORE_THREADS / 64; v++) {
+            S += L.red_s[v];
+            E += (double)L.red_e[v];
+            O += (double)L.red_o[v];
+            Y = __builtin_fmax(Y, (double)L.red_y[v]);
+            B |= L.red_bad[v];
+        }
+        const double u = 0x1p-24;
+        /* the bound of the header; sum(ob) and sum(ex) were accumulated in float by n / 256 additions per lane + the
+         * reduction (relative error below (n / 256 + 16) 2u), everything left out is covered by 1 % */
+        const double fa = 1.0 + 2.0 * u * ((double)n / SCORE_THREADS + 16.0) * 2.0;
+        const double bound = 1.01 * (u * fa * (O * (4.0 * Y + 2.72 * (double)cy) + E * (6.3 * Y + 6.3 * (double)cy + 10.1)) +
+                                     (double)n * (3.1 * u * (double)pzc_max + 0x1p-32));
+        /* The contract clamps a term to |t| < 2^20 before it is quantised (ig_quantize); the screening term does not, and it
+         * leaves log10(ob!) out.  Counts below 2^14 and |yy| <= 18 (P below 2^18) keep every exact term inside the clamp:
+         * |t| <= 2^14 18 log10(2) + 2^18 + log10(2^14 !) + pzc < 2^20.  Beyond: the column's bound is void. */
+        const bool in_clamp = ((B & 0x7fffffffu) >> 8) < (1u << 14) && Y <= 18.0 && (double)pzc_max < 1e5;
+        const bool ok = !(B & 0x80000000u) && in_clamp && (__builtin_fabs(S) < 1e15) && (bound < 1e12); /* false for NaN / inf as well */
+        if (!ok) {
+            atomicOr(&scr_void[cw], 1u << k);
+        } else {
+            atomic_add_ll(&scr[cw * NSLOT + k].s_fix, (long long)__builtin_rint(S * SCR_FIX));
+            atomic_add_ll(&scr[cw * NSLOT + k].b_fix, (long long)__builtin_ceil(bound * SCR_FIX) + 2); /* + the rounding of s_fix */
+        }
+    }
+}
+
+/* k_contend: one workgroup per move slot.  From the screened sums, the exact zero-pixel sums and the exact tail sums: an
+ * interval [lo, hi] for every scored (candidate, slot) that contains the score the decide step will compute; the
+ * contenders are the columns with hi >= the best lo among the columns that are scored whatever the stale insert flags turn
+ * out to be (candidate 0 of a slot w > 0 is screened with ALL block-insert slots, quirk Q4).  cont[cw]: bit k = column k
+ * goes through the exact kernel (bit 0, the current genome's column, with any other bit). */
+__global__ void __launch_bounds__(256) k_contend(Glob* g, MoveBuf mb, const ScreenSum* __restrict__ scr, const unsigned* __restrict__ scr_void,
+                                                 unsigned* __restrict__ cont, int w_begin, int force_all, int grid_cap, int chunk0)
+{
+    __shared__ double s_lo[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT], s_hi[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT];
+    __shared__ int s_kind[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT]; /* 0 not scored, 1 always scored, 2 depends on the flags, 3 void bound */
+    __shared__ double s_best[4];
+    __shared__ unsigned s_mask[IG_MAX_CANDIDATES];
+    const int w = w_begin + blockIdx.x, tid = threadIdx.x;
+    const MoveCtl& mc = mb.ctl[w];
+    const int C = mc.C, n = C * IG_N_TMP_STRUCT;
+    const ig_params p = g->par[0];
+    const double log_e = IG_LOG_E_F, n_tot_pxl = g->n_tot_pxl;
+    const long long z_hi = g->z_hi, z_lo = g->z_lo, n_intra = g->n_intra;
+    const double cur_nz = ig_acc_to_double(g->nz_hi, g->nz_lo);
+    if (tid < IG_MAX_CANDIDATES) s_mask[tid] = 0;
+    for (int i = tid; i < n; i += blockDim.x) {
+        const int c = i / IG_N_TMP_STRUCT, slot = i % IG_N_TMP_STRUCT;
+        const int cw = CW(w, c);
+        const CandMeta& m = mb.meta[cw];
+        const int k = m.kidx[slot];
+        int kind = 0;
+        double lo = 0.0, hi = 0.0;
+        if (k > 0) {
+            const bool sup = (c == 0) && mc.superset0 && (slot >= 12);
+            kind = sup ? 2 : 1;
+            const unsigned vd = scr_void[cw];
+            if (force_all || ((vd >> k) & 1u) || (vd & 1u)) {
+                kind = 3;
+            } else {
+                const long long* qp = mb.qpart + (size_t)cw * Q_STRIDE;
+                const ScreenSum a = scr[cw * NSLOT + k], b = scr[cw * NSLOT];
+                const double D = (double)(a.s_fix - b.s_fix) * (1.0 / SCR_FIX);
+                const double Bd = (double)(a.b_fix + b.b_fix) * (1.0 / SCR_FIX);
+                const long long dz_hi = qp[Q_Z + 2 * k] - qp[Q_Z], dz_lo = qp[Q_Z + 2 * k + 1] - qp[Q_Z + 1];
+                const long long dni = qp[Q_NI + k] - qp[Q_NI];
+                const double val_inter = -1.0 * log_e * (n_tot_pxl - (double)(n_intra + dni)) * p.v_inter;
+                const double val_intra = ig_acc_to_double(z_hi + dz_hi, z_lo + dz_lo) * log_e;
+                const double full = D + (val_intra + val_inter) + cur_nz;
+                const double tail = ig_acc_to_double(qp[Q_TAIL + 2 * k], qp[Q_TAIL + 2 * k + 1]);
+                const int r = (int)(slice_total(mb.part + (size_t)cw * P_STRIDE) % 64);
+                double vmin, vmax;
+                if (r == 0) {
+                    vmin = vmax = full;
+                } else if (sup) { /* its position in the list, hence whether the tail counts, depends on the flags (quirk Q5) */
+                    vmin = __builtin_fmin(full, full - tail);
+                    vmax = __builtin_fmax(full, full - tail);
+                } else {
+                    vmin = vmax = (k - 1 >= r) ? full - tail : full;
+                }
+                /* slack: the decide step assembles the score in double from the LIVE scalars (a shift common to all
+                 * columns of the move, up to roundings of numbers of this size) */
+                const double slack = 1e-3 + 1e-12 * (__builtin_fabs(cur_nz) + __builtin_fabs(val_intra) + __builtin_fabs(val_inter));
+                lo = vmin - Bd - slack;
+                hi = vmax + Bd + slack;
+                if (!(lo == lo) || !(hi == hi) || !(__builtin_fabs(lo) < 1e300) || !(__builtin_fabs(hi) < 1e300)) kind = 3;
+                /* an exact score of 0.0 counts as "not scored" in the argmax (CL:1435-1440): such a column bounds nothing */
+                else if (lo <= 0.0 && hi >= 0.0 && kind == 1) kind = 2;
+            }
+        }
+        s_kind[i] = kind;
+        s_lo[i] = lo;
+        s_hi[i] = hi;
+    }
+    __syncthreads();
+    double best = -IG_INF;
+    for (int i = tid; i < n; i += blockDim.x)
+        if (s_kind[i] == 1) best = __builtin_fmax(best, s_lo[i]);
+    for (int o = 32; o > 0; o >>= 1) best = __builtin_fmax(best, __shfl_down(best, o, 64));
+    if ((tid & 63) == 0) s_best[tid >> 6] = best;
+    __syncthreads();
+    best = __builtin_fmax(__builtin_fmax(s_best[0], s_best[1]), __builtin_fmax(s_best[2], s_best[3]));
+    for (int i = tid; i < n; i += blockDim.x) {
+        const int kind = s_kind[i];
+        if (kind == 0) continue;
+        if (kind == 3 || s_hi[i] >= best) {
+            const int c = i / IG_N_TMP_STRUCT, slot = i % IG_N_TMP_STRUCT;
+            atomicOr(&s_mask[c], (1u << mb.meta[CW(w, c)].kidx[slot]) | 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < C) cont[CW(w, tid)] = s_mask[tid];
+    /* what this slot will put on the exact kernel's work list (k_worklist): items of at most ch entries; ch is chosen so
+     * that a slot alone never needs more than half of the grid */
+    if (tid == 0) {
+        long long tot = 0;
+        for (int c = 0; c < C; c++) tot += slice_total(mb.part + (size_t)CW(w, c) * P_STRIDE) * __popc(s_mask[c]);
+        long long ch = chunk0;
+        while (tot / ch + (long long)C * NSLOT * SLICE_SEG > grid_cap / 2) ch *= 2;
+        mb.ctl[w].exact_chunk = (int)ch;
+    }
+    if (tid == 0) { /* diagnostics: columns screened / columns sent to the exact kernel (column 0 of a candidate included) */
+        long long cols = 0, cnt = 0;
+        long long tcols = 0, tcnt = 0;
+        for (int c = 0; c < C; c++) {
+            const long long Sc = slice_total(mb.part + (size_t)CW(w, c) * P_STRIDE);
+            cols += mb.meta[CW(w, c)].n_uniq + 1;
+            cnt += __popc(s_mask[c]);
+            tcols += Sc * (mb.meta[CW(w, c)].n_uniq + 1);
+            tcnt += Sc * __popc(s_mask[c]);
+        }
+        atomic_add_ll(&g->scr_cols, cols);
+        atomic_add_ll(&g->scr_cont, cnt);
+        atomic_add_ll(&g->scr_terms, tcols);
+        atomic_add_ll(&g->scr_terms_exact, tcnt);
+    }
+}
+
+/* k_worklist: the exact kernel's work list of a batch, one workgroup per slot (after k_contend).  Items of at most ch
+ * entries (MoveCtl.exact_chunk) of one segment under one contender column, in eight interleaved sub-lists: the items of
+ * segment s go to sub-list s % 8, item j of sub-list x sits at index 8 j + x -- the index is the exact kernel's block index,
+ * block b runs on XCD b % 8 (observed; a placement for speed, nothing depends on it), the XCD whose L2 k_screen just pulled
+ * that segment's lists through; the contender columns of a chunk are consecutive in their sub-list.  The slots take their
+ * places in slot order (every workgroup recomputes the counts of the slots before its own: a few hundred loads), so a slot
+ * fits or not regardless of the ones behind it: the slots that fit are a prefix of the batch, the first one always fits
+ * (k_contend's choice of ch), a slot that does not fit is flagged like a slot whose slice overflowed the pool -- the decide
+ * step stops before it and it is re-run.  grid_cap = the blocks the host launches the exact kernel with (sized from what
+ * the previous batches needed: launching the list's full capacity costs more in dispatch than the contenders cost to score). */
+__global__ void __launch_bounds__(256) k_worklist(MoveBuf mb, const unsigned* __restrict__ cont, int w_begin, int grid_cap)
+{
+    __shared__ int s_base[8], s_cnt[8], s_fit;
+    const int w = w_begin + blockIdx.x, tid = threadIdx.x;
+    auto items_of = [&](int ws, int c, int seg) -> int {
+        const long long ch = mb.ctl[ws].exact_chunk;
+        const long long n_seg = mb.part[(size_t)CW(ws, c) * P_STRIDE + P_CNT + seg];
+        return (int)((n_seg + ch - 1) / ch) * __popc(cont[CW(ws, c)]);
+    };
+    if (tid < 8) s_base[tid] = s_cnt[tid] = 0;
+    __syncthreads();
+    /* (slot, candidate, segment) units of the slots up to this one */
+    const int per = mb.capC * SLICE_SEG;
+    for (int u = tid; u < (blockIdx.x + 1) * per; u += blockDim.x) {
+        const int ws = w_begin + u / per, c = (u % per) / SLICE_SEG, seg = u % SLICE_SEG;
+        if (c >= mb.ctl[ws].C) continue;
+        const int it = items_of(ws, c, seg);
+        if (it) atomicAdd(ws == w ? &s_cnt[seg & 7] : &s_base[seg & 7], it);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        bool fit = true;
+        for (int x = 0; x < 8; x++) fit &= 8LL * (s_base[x] + s_cnt[x]) <= (long long)grid_cap;
+        s_fit = fit;
+        if (!fit) mb.ctl[w].overflow = 1;
+        for (int x = 0; x < 8; x++) {
+            if (fit) atomicMax(&mb.work[x], (unsigned long long)(s_base[x] + s_cnt[x])); /* the sub-lists end behind the last slot that fits */
+            atomicMax(&mb.work[8 + x], (unsigned long long)(s_base[x] + s_cnt[x])); /* what the grid would have to cover (the host sizes the next one) */
+        }
+    }
+    if (tid < 8) s_cnt[tid] = 0; /* now: the slot's append cursors */
+    __syncthreads();
+    if (!s_fit) return;
+    const int C = mb.ctl[w].C;
+    const long long ch = mb.ctl[w].exact_chunk;
+    for (int u = tid; u < C * SLICE_SEG; u += blockDim.x) {
+        const int c = u / SLICE_SEG, seg = u % SLICE_SEG;
+        const int cw = CW(w, c);
+        const long long n_seg = mb.part[(size_t)cw * P_STRIDE + P_CNT + seg];
+        const int nch = (int)((n_seg + ch - 1) / ch);
+        const unsigned mask = cont[cw];
+        if (!nch || !mask) continue;
+        const int x = seg & 7;
+        int j = s_base[x] + atomicAdd(&s_cnt[x], nch * __popc(mask));
+        for (int q = 0; q < nch; q++) {
+            unsigned m = mask;
+            while (m) {
+                const int k = __ffs(m) - 1;
+                m &= m - 1;
+                mb.work[16 + 8 * (size_t)(j++) + x] =
+                    ((unsigned long long)q << 32) | ((unsigned long long)cw << 12) | ((unsigned long long)k << 4) | (unsigned)seg;
+            }
+        }
+    }
+}
+
+/* IG_SCREEN_VERIFY=1: every column was scored exactly as well; check the bound column by column */
+__global__ void k_screen_verify(Glob* g, MoveBuf mb, const ScreenSum* __restrict__ scr, const unsigned* __restrict__ scr_void, int w_begin,
+                                double* worst)
+{
+    const int w = w_begin + blockIdx.x;
+    const MoveCtl& mc = mb.ctl[w];
+    for (int i = threadIdx.x; i < mc.C * NSLOT; i += blockDim.x) {
+        const int c = i / NSLOT, k = i % NSLOT;
+        const int cw = CW(w, c);
+        if (k == 0 || k > mb.meta[cw].n_uniq) continue;
+        const unsigned vd = scr_void[cw];
+        if (((vd >> k) & 1u) || (vd & 1u)) continue;
+        const long long* part = mb.part + (size_t)cw * P_STRIDE;
+        const double exact = ig_acc_to_double(part[P_NZ + 2 * k] - part[P_NZ], part[P_NZ + 2 * k + 1] - part[P_NZ + 1]);
+        const ScreenSum a = scr[cw * NSLOT + k], b = scr[cw * NSLOT];
+        const double D = (double)(a.s_fix - b.s_fix) * (1.0 / SCR_FIX);
+        const double Bd = (double)(a.b_fix + b.b_fix) * (1.0 / SCR_FIX);
+        const double err = __builtin_fabs(D - exact);
+        if (!(err <= Bd)) g->error = 7;
+        if (worst && Bd > 0) { /* largest used fraction of a bound, largest bound (diagnostics; races are harmless) */
+            if (err / Bd > worst[0]) worst[0] = err / Bd;
+            if (Bd > worst[1]) worst[1] = Bd;
+        }
+    }
+}
+
+/* The two hardware functions the bound leans on, over their whole domain: v_log_f32 on every positive normal float,
+ * v_exp_f32 on every float in [-150, 128), against the contract's double functions.
+ * out[0] = max |L - log2 s| / (2u (|L| + 1)), out[1] = max |E - 2^y| / (2u 2^y) over normal results (2u = 2^-23). */
+__global__ void k_transcendental_error(double* out)
+{
+    __shared__ double red[2][4];
+    const double* T = ig_tab();
+    double e_log = 0.0, e_exp = 0.0;
+    const unsigned long long tid = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x, nth = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long b = 0x00800000ull + tid; b < 0x7f800000ull; b += nth) {
+        const float s = __uint_as_float((unsigned)b);
+        const double L = (double)__builtin_amdgcn_logf(s);
+        const double ref = ig_log2_pos((double)s, T);
+        e_log = __builtin_fmax(e_log, __builtin_fabs(L - ref) / (0x1p-23 * (__builtin_fabs(L) + 1.0)));
+    }
+    /* y in [-126, 128): normal results; both signs of the float encoding */
+    for (unsigned long long b = tid; b < 0x43000000ull; b += nth) { /* +0 .. 128 */
+        const float y = __uint_as_float((unsigned)b);
+        const double E = (double)__builtin_amdgcn_exp2f(y), ref = ig_exp2((double)y, T);
+        e_exp = __builtin_fmax(e_exp, __builtin_fabs(E - ref) / (0x1p-23 * ref));
+    }
+    for (unsigned long long b = 0x80000000ull + tid; b <= 0xc2fc0000ull; b += nth) { /* -0 .. -126 */
+        const float y = __uint_as_float((unsigned)b);
+        const double E = (double)__builtin_amdgcn_exp2f(y), ref = ig_exp2((double)y, T);
+        e_exp = __builtin_fmax(e_exp, __builtin_fabs(E - ref) / (0x1p-23 * ref));
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        e_log = __builtin_fmax(e_log, __shfl_down(e_log, o, 64));
+        e_exp = __builtin_fmax(e_exp, __shfl_down(e_exp, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = e_log;
+        red[1][threadIdx.x >> 6] = e_exp;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int v = 1; v < (int)(blockDim.x >> 6); v++) {
+            red[0][0] = __builtin_fmax(red[0][0], red[0][v]);
+            red[1][0] = __builtin_fmax(red[1][0], red[1][v]);
+        }
+        /* doubles >= 0: the integer order of their bit patterns is their order */
+        atomicMax((unsigned long long*)&out[0], (unsigned long long)__double_as_longlong(red[0][0]));
+        atomicMax((unsigned long long*)&out[1], (unsigned long long)__double_as_longlong(red[1][0]));
+    }
+}

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(HERE, "libinstagraal_hip.so")
 SRC = os.path.join(HERE, "csrc", "ig_hip.hip")
 SRC_HOST = os.path.join(HERE, "csrc", "ig_draw.cpp")  # host-only part: the candidate draw
 DEPS = [SRC, SRC_HOST] + [os.path.join(HERE, "csrc", f) for f in ("ig_ops.cuh", "ig_common.cuh", "ig_model.cuh", "ig_kernels_setup.cuh",
-                                                          "ig_kernels_score.cuh", "ig_kernels_commit.cuh")] + \
+                                                          "ig_kernels_score.cuh", "ig_kernels_screen.cuh", "ig_kernels_commit.cuh")] + \
        [os.path.join(ROOT, "include", f) for f in ("ig_detmath.h", "ig_detmath_tables.h", "instagraal_hip.h")]
 
 N_TMP_STRUCT = 24
@@ -377,6 +377,18 @@ class Context:
                                      _p(ext_hi), _p(ext_lo), _p(n_slice), _p(n_uniq), _p(uniq)))
         a.update(ext_hi=ext_hi, ext_lo=ext_lo, n_slice=n_slice, n_uniq=n_uniq, uniq=uniq.reshape(n_cands, T))
         return a
+
+    def debug_transcendental_error(self):
+        o = np.zeros(2, np.float64)
+        _ck(lib().ig_debug_transcendental_error(self._h, _p(o)))
+        return float(o[0]), float(o[1])
+
+    def debug_screen_stats(self):
+        """(largest used fraction of a bound, largest bound) under IG_SCREEN_VERIFY=1; (columns screened, columns scored exactly,
+        terms screened, terms scored exactly)"""
+        o = np.zeros(6, np.float64)
+        _ck(lib().ig_debug_screen_stats(self._h, _p(o)))
+        return float(o[0]), float(o[1]), int(o[2]), int(o[3]), int(o[4]), int(o[5])
 
     def debug_globals(self):
         sums = np.zeros(5, np.int64)

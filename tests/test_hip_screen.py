@@ -1,0 +1,104 @@
+"""GPU tests of the two-tier scoring of the speculative batches (csrc/ig_kernels_screen.cuh): a float screening pass with a
+rigorous error bound per column decides which columns can still win; only those go through the exact kernel.
+
+* the two hardware functions the bound leans on (v_log_f32, v_exp_f32) over their WHOLE domain against the contract's
+  double functions: the bound assumes 4 units, the hardware must stay below 2;
+* IG_SCREEN_VERIFY=1 scores every column exactly as well and checks |screened - exact| <= bound for every column of every
+  move (device-side error 7 otherwise), while the decisions are taken from the contenders only, as in production;
+* the trajectories with and without screening are byte-identical (result records, genome, exact sums, stale flags)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(prob, frags, seed, env, monkeypatch, coo=False):
+    from instagraal_amd.sampler import sampler as hip_sampler
+
+    for k in ("IG_SCREEN", "IG_SCREEN_VERIFY"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    s = hip_sampler(**prob.sampler_kwargs(), device_id=0, coo=(prob.coo_row, prob.coo_col, prob.coo_cnt) if coo else None)
+    s.set_param_simu(prob.params)
+    s.eval_likelihood_init()
+    np.random.seed(seed)
+    cands = s.draw_candidates(frags, 5)
+    res = s.ctx.step_batch(frags, cands)
+    sums, _ = s.ctx.debug_globals()
+    _, _, limbs = s.ctx.full_likelihood(0)
+    assert [int(x) for x in sums[:5]] == [int(x) for x in limbs[:5]]
+    out = (res.tobytes(), s.gpu_vect_frags.copy_from_gpu().soa17().tobytes(), [int(x) for x in sums], [int(x) for x in s.ctx.valid_insert()])
+    stats = s.ctx.debug_screen_stats()
+    s.free_gpu()
+    return out, stats, res
+
+
+def test_hardware_log2_exp2_over_their_whole_domain():
+    from instagraal_amd import synth
+    from instagraal_amd.sampler import problem_to_context
+
+    ctx = problem_to_context(synth.make_problem(*synth.CONFIGS["tiny"]))
+    e_log, e_exp = ctx.debug_transcendental_error()
+    print("v_log_f32: %.3f units of 2^-23 (|L| + 1); v_exp_f32: %.3f units of 2^-23 2^y" % (e_log, e_exp))
+    assert 0 < e_log <= 2.0 and 0 < e_exp <= 2.0  # the bound is derived for 4
+    ctx.close()
+
+
+@pytest.mark.parametrize("cfg,n_moves", [("tiny", 300), ("small", 600), ("bigctg", 120), ("cfg2", 1500)])
+def test_screening_bound_holds_and_changes_nothing(cfg, n_moves, monkeypatch):
+    from instagraal_amd import synth
+
+    prob = synth.make_problem(*synth.CONFIGS[cfg])
+    np.random.seed(33)
+    frags = np.resize(np.random.permutation(prob.n_frags), n_moves).astype(np.int32)
+    exact, _, _ = _run(prob, frags, 7, {"IG_SCREEN": "0"}, monkeypatch)
+    verified, stats, _ = _run(prob, frags, 7, {"IG_SCREEN_VERIFY": "1"}, monkeypatch)  # raises on a violated bound (error 7)
+    screened, _, _ = _run(prob, frags, 7, {}, monkeypatch)
+    assert verified == exact
+    assert screened == exact
+    print(cfg, "largest used fraction of a bound %.3g, largest bound %.3g, columns screened %d, scored exactly %d, terms %d / %d" % stats)
+    assert 0 < stats[0] < 0.5  # the bound is rigorous, hence loose: the observed error uses a small part of it
+
+
+def test_screening_with_large_counts_and_other_parameters(monkeypatch):
+    """counts in the thousands (sums of ob and P in the millions per column: large bounds), and a parameter set outside the
+    one-log domain (slope 0: every column's bound is void, everything goes through the exact kernel)"""
+    import copy
+
+    import scipy.sparse as sp
+
+    from instagraal_amd import synth
+
+    prob = copy.deepcopy(synth.make_problem(*synth.CONFIGS["small"]))
+    cnt = prob.coo_cnt.copy()
+    cnt[::5] *= 70
+    cnt[::53] *= 500
+    prob.coo_cnt = cnt
+    M = prob.n_sub_frags
+    prob.sub_csr = sp.csr_matrix((cnt, (prob.coo_row, prob.coo_col)), shape=(M, M), dtype=np.int32)
+    prob.sub_csr.sort_indices()
+    np.random.seed(5)
+    frags = np.resize(np.random.permutation(prob.n_frags), 300).astype(np.int32)
+    for params in (prob.params, dict(prob.params, slope=0.0), dict(prob.params, slope=-0.7, v_inter=2e-4)):
+        prob.params = params
+        exact, _, _ = _run(prob, frags, 9, {"IG_SCREEN": "0"}, monkeypatch)
+        verified, stats, _ = _run(prob, frags, 9, {"IG_SCREEN_VERIFY": "1"}, monkeypatch)
+        screened, _, _ = _run(prob, frags, 9, {}, monkeypatch)
+        assert verified == exact and screened == exact
+        assert stats[0] < 0.5
+
+
+def test_screening_at_the_headline_shape(monkeypatch):
+    from instagraal_amd import synth
+
+    prob = synth.make_problem(*synth.CONFIGS["cfg3"])
+    np.random.seed(2)
+    frags = np.resize(np.random.permutation(prob.n_frags), 400).astype(np.int32)
+    exact, _, _ = _run(prob, frags, 3, {"IG_SCREEN": "0"}, monkeypatch, coo=True)
+    verified, stats, _ = _run(prob, frags, 3, {"IG_SCREEN_VERIFY": "1"}, monkeypatch, coo=True)
+    screened, _, _ = _run(prob, frags, 3, {}, monkeypatch, coo=True)
+    assert verified == exact and screened == exact
+    print("cfg3: largest used fraction of a bound %.3g, largest bound %.3g, columns screened %d, scored exactly %d, terms %d / %d" % stats)
+    assert stats[3] < 0.25 * stats[2]
+    assert 0 < stats[0] < 0.5
