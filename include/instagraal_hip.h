@@ -109,6 +109,13 @@ int ig_neighbours_create(const int64_t* indptr, const int32_t* xk, const float* 
 void ig_neighbours_destroy(ig_neighbours* nb);
 int ig_neighbours_draw(ig_neighbours* nb, uint32_t* mt_key624, int32_t* mt_pos, const int32_t* frags, int32_t n_moves,
                        int32_t n_neighbours, int32_t* cands_out);
+/* the same for a run of moves with nuisance sampling (instagraal.py:217-262, cycles > 4): per move the neighbour draw, then the
+ * three draws of step_nuisance_parameters (CL:2976-3028): choice(4), the STANDARD normal behind normal(0, sigma) -- numpy's
+ * legacy polar method with its one-value cache (has_gauss, gauss of get_state()) --, rand().  skip_normal_3: no normal is
+ * drawn for modifier 3 (the reference's branch for a non-positive sigma of the trans level). */
+int ig_neighbours_draw_nuisance(ig_neighbours* nb, uint32_t* mt_key624, int32_t* mt_pos, int32_t* has_gauss, double* gauss,
+                                const int32_t* frags, int32_t n_moves, int32_t n_neighbours, int32_t skip_normal_3, int32_t* cands_out,
+                                int32_t* id_modif_out, double* normal_out, double* uniform_out);
 /* n_moves complete step_sampler calls: draw (on a host thread, ahead of the launches) + ig_step_batch.  cands_out
  * [n_moves x n_neighbours] receives the drawn lists; the generator state is advanced past all n_moves draws. */
 int ig_step_batch_draw(ig_ctx* ctx, ig_neighbours* nb, uint32_t* mt_key624, int32_t* mt_pos, int32_t n_moves, const int32_t* frags,
@@ -126,6 +133,17 @@ int ig_batch_commit(ig_ctx* ctx, int32_t move0, int32_t W, int32_t* n_committed)
 int ig_batch_results(ig_ctx* ctx, int32_t n_moves, ig_move_result* results);
 int ig_set_batch_width(int w);                        /* W in 1..64 (default 24, env IG_BATCH_W); 1 = no speculation */
 int ig_batch_stats(ig_ctx* ctx, int64_t out4[4]);     /* {batches, moves committed in-batch, one-move tails, predicted deltas used} */
+
+/* ---- a move and the nuisance step behind it, in flight together (instagraal.py:217-262 for cycles > 4: step_sampler, then
+ * step_nuisance_parameters CL:2961-3051) ----------------------------------
+ * The nuisance step evaluates the full likelihood under its test parameters on the coordinates of the state BEFORE the move
+ * just applied (eval_likelihood_4_nuisance CL:1296-1344, quirk Q12) and needs only that move's score besides: its pass over
+ * all contacts runs next to the move.  ig_nuis_begin: asynchronous -- the move (score + apply) and, on a second stream, the
+ * pass under p_test (KA:91-100 order).  ig_nuis_end: waits for both; nz_test / z_test as ig_full_likelihood.  ig_nuis_accept:
+ * the test parameters of the last step become param_simu (maintained sums recomputed under them, CL:3032-3036). */
+int ig_nuis_begin(ig_ctx* ctx, int32_t frag_a, const int32_t* cands, int32_t C, const float p_test[8], float mean_subfrag_kb);
+int ig_nuis_end(ig_ctx* ctx, ig_move_result* out, double* nz_test, double* z_test, int64_t* limbs5);
+int ig_nuis_accept(ig_ctx* ctx);
 
 /* ---- bookkeeping -------------------------------------------------------- */
 int ig_renumber_contigs(ig_ctx* ctx, int32_t* n_contigs, float* mean_len, int32_t* max_id); /* CL:2715-2881 */

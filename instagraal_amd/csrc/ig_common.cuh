@@ -204,6 +204,14 @@ struct ig_ctx {
     bool own_stream;
     hipStream_t stream2;           /* k_tail next to k_score_list */
     hipEvent_t ev_slice, ev_tail;
+    hipStream_t stream3;           /* the nuisance step's full pass, next to the move it follows (ig_nuis_begin) */
+    hipEvent_t ev_main;            /* everything queued on the library stream before the step in flight */
+    hipEvent_t ev_gathered;        /* k_gather of the move in flight is done: tab_prev holds the state before that move */
+    long long* scratch_nuis;       /* 8 x int64 reduction scratch of that pass */
+    struct NuisHost* host_nuis;    /* pinned: its results and the move's */
+    bool nuis_in_flight;
+    ig_params nuis_test;           /* the test parameters of the step in flight */
+    float nuis_mean_kb;
     int N, M;
     long long Z;
     int max_count; /* largest contact count (packed slice entries need it below 2^24) */
@@ -216,6 +224,10 @@ struct ig_ctx {
     int2* cc; /* (col, count) */
     int* crow;    /* row of every contact (COO companion of cc: k_full_nz is contact-parallel) */
     int4* tabrec; /* k_pack_tab: (dist, s_tot, contig, rank) per sub-fragment */
+    /* the tiled copy of the contacts k_full_nz_tiled streams (ig_upload_contacts), nullptr: not built */
+    uint2* tiled_cc;
+    struct TileWork* tile_work;
+    int n_tile_work;
     int* init_prev;
     int* init_next;
     int* orientable;

@@ -17,6 +17,7 @@
  * tests/test_cpu_abi_and_host.py::test_c_draw_equals_numpy_choice compares lists and generator state with numpy itself.
  */
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -204,5 +205,57 @@ extern "C" int ig_neighbours_draw(ig_neighbours* nb, uint32_t* mt_key624, int32_
         draw_one(nb, mt, frags[i], n_neighbours, cands_out + (size_t)i * n_neighbours);
     }
     *mt_pos = mt.pos;
+    return 0;
+}
+
+/* The stream of a run of moves WITH nuisance sampling (the loop of instagraal.py:217-262 for cycles > 4): per move the
+ * neighbour draw, then the three draws of step_nuisance_parameters (CL:2976-3028) --
+ *     np.random.choice(4)           one 32-bit output & 3 (legacy masked rejection, range 3: never rejects)
+ *     np.random.normal(0, sigma)    legacy polar Box-Muller with its one-value cache (has_gauss, gauss of get_state());
+ *                                   returned here as the STANDARD normal g: the caller forms 0.0 + sigma * g as numpy does
+ *     np.random.rand()              the acceptance uniform
+ * -- whose consumption does not depend on the parameters being sampled (only `skip_normal_3`: the reference draws no normal
+ * for the trans-level proposal when its sigma is <= 0), so the whole stream of a run is drawn up front. */
+extern "C" int ig_neighbours_draw_nuisance(ig_neighbours* nb, uint32_t* mt_key624, int32_t* mt_pos, int32_t* has_gauss, double* gauss,
+                                           const int32_t* frags, int32_t n_moves, int32_t n_neighbours, int32_t skip_normal_3,
+                                           int32_t* cands_out, int32_t* id_modif_out, double* normal_out, double* uniform_out)
+{
+    if (!nb || !mt_key624 || !mt_pos || !has_gauss || !gauss || !frags || !cands_out || !id_modif_out || !normal_out || !uniform_out)
+        return ig_fail_msg("ig_neighbours_draw_nuisance: NULL argument");
+    if (n_neighbours < 1 || n_neighbours > IG_MAX_CANDIDATES) return ig_fail_msg("ig_neighbours_draw_nuisance: n_neighbours out of 1..16");
+    if (*mt_pos < 0 || *mt_pos > 624) return ig_fail_msg("ig_neighbours_draw_nuisance: MT19937 position out of range");
+    MT mt{mt_key624, *mt_pos};
+    int hg = *has_gauss;
+    double gz = *gauss;
+    for (int32_t i = 0; i < n_moves; i++) {
+        if (frags[i] < 0 || frags[i] >= nb->n_frags) return ig_fail_msg("ig_neighbours_draw_nuisance: fragment out of range");
+        draw_one(nb, mt, frags[i], n_neighbours, cands_out + (size_t)i * n_neighbours);
+        const int id = (int)(mt.next32() & 3u);
+        id_modif_out[i] = id;
+        double g = 0.0;
+        if (!(id == 3 && skip_normal_3)) {
+            if (hg) {
+                g = gz;
+                hg = 0;
+                gz = 0.0;
+            } else {
+                double f, x1, x2, r2;
+                do {
+                    x1 = 2.0 * mt.next_double() - 1.0;
+                    x2 = 2.0 * mt.next_double() - 1.0;
+                    r2 = x1 * x1 + x2 * x2;
+                } while (r2 >= 1.0 || r2 == 0.0);
+                f = std::sqrt(-2.0 * std::log(r2) / r2);
+                gz = f * x1;
+                hg = 1;
+                g = f * x2;
+            }
+        }
+        normal_out[i] = g;
+        uniform_out[i] = mt.next_double();
+    }
+    *mt_pos = mt.pos;
+    *has_gauss = hg;
+    *gauss = gz;
     return 0;
 }

@@ -123,6 +123,9 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->cc = nullptr;
     c->crow = nullptr;
     c->tabrec = nullptr;
+    c->tiled_cc = nullptr;
+    c->tile_work = nullptr;
+    c->n_tile_work = 0;
     c->init_prev = c->init_next = c->orientable = nullptr;
     c->black = nullptr;
     c->batch_out = nullptr;
@@ -156,10 +159,16 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->init_links_inverse = true;
     HIPCK(hipStreamCreate(&c->stream));
     HIPCK(hipStreamCreate(&c->stream2));
+    HIPCK(hipStreamCreate(&c->stream3));
+    HIPCK(hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
+    c->host_nuis = nullptr;
+    c->nuis_in_flight = false;
     HIPCK(hipEventCreateWithFlags(&c->ev_slice, hipEventDisableTiming));
     HIPCK(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
     DALLOC(c->glob, 1);
     DALLOC(c->scratch8, 8);
+    DALLOC(c->scratch_nuis, 8);
     HIPCK(hipMemset(c->glob, 0, sizeof(Glob)));
     DALLOC(c->lgf_tab, LGF_TAB);
     /* log10(ob!) table (KA:111-124, 251-270): the 15 float-factorial constants on the host, the rest on the device */
@@ -231,6 +240,12 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipStreamSynchronize(c->stream);
     hipStreamSynchronize(c->stream2);
     hipStreamDestroy(c->stream2);
+    hipStreamSynchronize(c->stream3);
+    hipStreamDestroy(c->stream3);
+    hipEventDestroy(c->ev_gathered);
+    hipEventDestroy(c->ev_main);
+    if (c->host_nuis) hipHostFree(c->host_nuis);
+    hipFree(c->scratch_nuis);
     hipEventDestroy(c->ev_slice);
     hipEventDestroy(c->ev_tail);
     if (c->host_bo) hipHostFree(c->host_bo);
@@ -244,6 +259,8 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipFree(c->cc);
     hipFree(c->crow);
     hipFree(c->tabrec);
+    hipFree(c->tiled_cc);
+    hipFree(c->tile_work);
     hipFree(c->init_prev);
     hipFree(c->init_next);
     hipFree(c->orientable);
@@ -288,14 +305,26 @@ extern "C" int ig_set_stream(ig_ctx* c, void* s)
 }
 
 /* the from-scratch likelihood of the non-zero pixels under tables `t` and parameter set `which` -> out[0..1] */
-static void launch_full_nz(ig_ctx* c, const Tables& t, int which, long long* out, PzTab pz)
+static void launch_full_nz(ig_ctx* c, const Tables& t, int which, long long* out, PzTab pz, hipStream_t stream = nullptr)
 {
     static int s_wgs = getenv("IG_FULL_WGS") ? atoi(getenv("IG_FULL_WGS")) : 8 * 256;
     if (c->Z <= 0) return;
-    hipLaunchKernelGGL(k_pack_tab, dim3((c->M + 255) / 256), dim3(256), 0, c->stream, t, c->M, c->tabrec);
+    if (!stream) stream = c->stream;
+    hipLaunchKernelGGL(k_pack_tab, dim3((c->M + 255) / 256), dim3(256), 0, stream, t, c->M, c->tabrec);
     /* the tables of this parameter set (k_score_list's own block is parameter set 0's) */
-    hipLaunchKernelGGL(k_build_score_const, dim3((LDS_PZ + 2 + 255) / 256), dim3(256), 0, c->stream, c->glob, pz, c->lgf_tab, c->full_const, which);
-    hipLaunchKernelGGL(k_full_nz, dim3(s_wgs), dim3(256), 0, c->stream, c->crow, c->cc, c->tabrec, t.len, c->full_const, c->lgf_tab,
+    hipLaunchKernelGGL(k_build_score_const, dim3((LDS_PZ + 2 + 255) / 256), dim3(256), 0, stream, c->glob, pz, c->lgf_tab, c->full_const, which);
+    static const int s_tiled = getenv("IG_FULL_TILED") ? atoi(getenv("IG_FULL_TILED")) : 1;
+    if (s_tiled && c->tiled_cc && c->n_tile_work > 0) {
+        /* next to a move (the nuisance step's pass, ig_nuis_begin): one workgroup per CU -- the request is padded beyond half
+         * of the LDS -- so that the move's own small workgroups find room on every CU instead of queueing behind this pass */
+        static const int s_pad = getenv("IG_FULL_LDS_PAD") ? atoi(getenv("IG_FULL_LDS_PAD")) : 100 * 1024;
+        const size_t lds = (stream != c->stream) ? std::max<size_t>(sizeof(FullTiledLds), (size_t)s_pad) : sizeof(FullTiledLds);
+        static const int s_thr = getenv("IG_FULL_THREADS") ? atoi(getenv("IG_FULL_THREADS")) : FULL_TILED_THREADS;
+        hipLaunchKernelGGL(k_full_nz_tiled, dim3(c->n_tile_work), dim3((stream != c->stream) ? s_thr : FULL_TILED_THREADS), lds, stream, c->tile_work, c->tiled_cc,
+                           c->tabrec, t.len, c->full_const, c->lgf_tab, c->M, pz.n, out);
+        return;
+    }
+    hipLaunchKernelGGL(k_full_nz, dim3(s_wgs), dim3(256), 0, stream, c->crow, c->cc, c->tabrec, t.len, c->full_const, c->lgf_tab,
                        (long long)c->Z, pz.n, out);
 }
 
@@ -413,6 +442,43 @@ extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* 
     if (Z) HIPCK(hipMemcpy(c->crow, row, (size_t)Z * sizeof(int), hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(c->rowptr, rp.data(), ((size_t)M + 1) * sizeof(long long), hipMemcpyHostToDevice));
     if (Z) HIPCK(hipMemcpy(c->cc, cc.data(), (size_t)Z * sizeof(int2), hipMemcpyHostToDevice));
+    /* the tiled copy for the from-scratch pass (k_full_nz_tiled): counting sort of the contacts by (row block, column block) */
+    hipFree(c->tiled_cc);
+    hipFree(c->tile_work);
+    c->tiled_cc = nullptr;
+    c->tile_work = nullptr;
+    c->n_tile_work = 0;
+    {
+        const int64_t nb = ((int64_t)M + FULL_TB - 1) / FULL_TB;
+        if (Z > 0 && nb <= 2048) {
+            static bool s_attr = false;
+            if (!s_attr) {
+                HIPCK(hipFuncSetAttribute((const void*)k_full_nz_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                s_attr = true;
+            }
+            std::vector<int64_t> tptr((size_t)(nb * nb) + 1, 0); /* contacts per tile -> first contact of a tile */
+            for (int64_t k = 0; k < Z; k++) tptr[(size_t)((row[k] / FULL_TB) * nb + col[k] / FULL_TB) + 1]++;
+            for (size_t i = 1; i < tptr.size(); i++) tptr[i] += tptr[i - 1];
+            std::vector<TileWork> work;
+            for (int64_t bi = 0; bi < nb; bi++)
+                for (int64_t bj = bi; bj < nb; bj++) {
+                    const int64_t b = tptr[(size_t)(bi * nb + bj)], e = tptr[(size_t)(bi * nb + bj) + 1];
+                    for (int64_t o = b; o < e; o += FULL_CHUNK)
+                        work.push_back(TileWork{(long long)o, (int)std::min<int64_t>(FULL_CHUNK, e - o), (int)bi, (int)bj, 0});
+                }
+            std::vector<uint2> tc((size_t)Z);
+            std::vector<int64_t> cur(tptr.begin(), tptr.end() - 1);
+            for (int64_t k = 0; k < Z; k++) {
+                const int64_t t = (row[k] / FULL_TB) * nb + col[k] / FULL_TB;
+                tc[(size_t)cur[(size_t)t]++] = make_uint2((unsigned)(row[k] % FULL_TB) | ((unsigned)(col[k] % FULL_TB) << 11), (unsigned)cnt[k]);
+            }
+            DALLOC(c->tiled_cc, (size_t)Z);
+            DALLOC(c->tile_work, work.size());
+            HIPCK(hipMemcpy(c->tiled_cc, tc.data(), (size_t)Z * sizeof(uint2), hipMemcpyHostToDevice));
+            HIPCK(hipMemcpy(c->tile_work, work.data(), work.size() * sizeof(TileWork), hipMemcpyHostToDevice));
+            c->n_tile_work = (int)work.size();
+        }
+    }
     c->Z = Z;
     c->M = M;
     c->max_count = max_count;
@@ -566,7 +632,7 @@ static int launch_recompute(ig_ctx* c)
                        c->black, c->glob, N);
     if (c->have_params && c->have_contacts) {
         launch_full_nz(c, c->tab, 0, scratch, PzTab{c->pz_tab, c->pz_n});
-        hipLaunchKernelGGL(k_full_zero, dim3(256), dim3(256), 0, c->stream, c->tab, c->glob, 0, M, scratch + 2);
+        hipLaunchKernelGGL(k_full_zero, dim3(128), dim3(256), 0, c->stream, c->tab, c->glob, 0, M, scratch + 2);
     }
     long long h[8];
     HIPCK(hipMemcpyAsync(h, scratch, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -748,7 +814,7 @@ extern "C" int ig_full_likelihood(ig_ctx* c, int which, int use_prev, double* nz
     /* which == 1 before any ig_set_params(.., 1): no table yet, every P_z is evaluated directly */
     const PzTab pz = which == 0 ? PzTab{c->pz_tab, c->pz_n} : PzTab{c->pz_tab1, c->pz_tab1 ? c->pz_n1 : 0};
     launch_full_nz(c, t, which, scratch, pz);
-    hipLaunchKernelGGL(k_full_zero, dim3(256), dim3(256), 0, c->stream, t, c->glob, which, c->M, scratch + 2);
+    hipLaunchKernelGGL(k_full_zero, dim3(128), dim3(256), 0, c->stream, t, c->glob, which, c->M, scratch + 2);
     long long h[8];
     HIPCK(hipMemcpyAsync(h, scratch, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
@@ -904,7 +970,7 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                 if (s_pred2 >= 2) hipLaunchKernelGGL(k_predict, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, w_begin, 0);
                 hipLaunchKernelGGL(k_predict, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, w_begin, 1);
                 hipLaunchKernelGGL(k_delta, dim3(DELTA_RB, 2, nW), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->tab_prev,
-                                   c->prev_touched, c->glob, c->mb, c->lgf_tab, pz, w_begin, 1);
+                                   c->prev_touched, c->glob, c->mb, c->lgf_tab, pz, w_begin, 1, 0);
             }
         }
     }
@@ -926,7 +992,7 @@ static void enqueue_apply(ig_ctx* c, int move, int w, int forced)
     {
         TimedLaunch t(c, T_DELTA);
         hipLaunchKernelGGL(k_delta, dim3(DELTA_RB, 2, 1), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->tab_prev,
-                           c->prev_touched, c->glob, c->mb, c->lgf_tab, pz, w, 0);
+                           c->prev_touched, c->glob, c->mb, c->lgf_tab, pz, w, 0, 0);
     }
     {
         TimedLaunch t(c, T_APPLY);
@@ -1360,6 +1426,159 @@ extern "C" int ig_step_finish(ig_ctx* c, ig_move_result* out, double* scores)
     HIPCK(hipGetLastError());
     drain_timers(c);
     if (out->error) return fail("device-side consistency failure %d", out->error);
+    return 0;
+}
+
+/* ---- a move and the nuisance step that follows it, in flight together (instagraal.py:217-262 for cycles > 4) ----------
+ * step_nuisance_parameters (CL:2961-3051) evaluates the full likelihood under its test parameters on the coordinates of the
+ * state BEFORE the move that was just applied (quirk Q12) and needs nothing else from that move but its score: the pass
+ * over all contacts does not have to wait for the move.  ig_nuis_begin enqueues the move (score + apply, library stream)
+ * and, on a second stream behind the move's k_gather (after which tab_prev is that earlier state), the full pass under
+ * p_test; ig_nuis_end waits for both; ig_nuis_accept makes the test parameters the model's. */
+struct NuisHost {
+    ig_move_result res;
+    long long sums[8];
+    int frag, cands[IG_MAX_CANDIDATES]; /* the move's lists: the asynchronous upload reads them after ig_nuis_begin returned */
+};
+__global__ void k_set_par(Glob* g, int which, ig_params p, float mean_kb)
+{
+    g->par[which] = p;
+    g->mean_kb = mean_kb;
+}
+/* tab_prev := the state before the move about to be scored (what k_gather does first thing; here ahead of it, so that the
+ * nuisance pass can start next to the move instead of behind its launches) */
+__global__ void k_catch_up(Tables tab, Tables tab_prev, const int* __restrict__ prev_touched, const Glob* g)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g->n_prev_touched; i += gridDim.x * blockDim.x) {
+        const int s = prev_touched[i];
+        tab_prev.dist[s] = tab.dist[s];
+        tab_prev.stot[s] = tab.stot[s];
+        tab_prev.cp[s] = tab.cp[s];
+        tab_prev.len[s] = tab.len[s];
+    }
+}
+
+extern "C" int ig_nuis_begin(ig_ctx* c, int32_t frag_a, const int32_t* cands, int32_t C, const float p_test[8], float mean_subfrag_kb)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (check_ready(c)) return -1;
+    if (c->world > 1) return fail("ig_nuis_begin: this handle scores a contact shard");
+    if (c->nuis_in_flight) return fail("ig_nuis_begin: the previous step was not ended (ig_nuis_end)");
+    if (validate_move(c, frag_a, cands, C)) return -1;
+    if (ensure_move_buffers(c, std::max(8, (int)C))) return -1;
+    if (ensure_io(c, 1, C)) return -1;
+    if (!c->host_nuis) HIPCK(hipHostMalloc((void**)&c->host_nuis, sizeof(NuisHost), hipHostMallocDefault));
+    if (!c->pz_tab1) DALLOC(c->pz_tab1, PZ_MAX);
+    c->host_nuis->frag = frag_a;
+    for (int i = 0; i < C; i++) c->host_nuis->cands[i] = cands[i];
+    HIPCK(hipMemcpyAsync(c->d_frags, &c->host_nuis->frag, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCK(hipMemcpyAsync(c->d_cands, c->host_nuis->cands, (size_t)C * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    c->nuis_in_flight = true;
+    /* the nuisance pass first (second stream), the move behind it (library stream): the pass is the longer of the two and
+     * would otherwise start only when the host is through with the move's dozen launches */
+    hipLaunchKernelGGL(k_catch_up, dim3(16), dim3(256), 0, c->stream, c->tab, c->tab_prev, c->prev_touched, c->glob);
+    HIPCK(hipEventRecord(c->ev_gathered, c->stream)); /* also: behind an accepted step's kernels (ig_nuis_accept), which read what the pass overwrites */
+    const ig_params hp = {p_test[0], p_test[1], p_test[2], p_test[3], p_test[4], p_test[5], p_test[6], p_test[7]};
+    c->nuis_test = hp;
+    c->nuis_mean_kb = mean_subfrag_kb;
+    const double need = (mean_subfrag_kb > 0) ? (double)p_test[5] / (double)mean_subfrag_kb + 2.0 : 0.0;
+    c->pz_n1 = (need > 0 && need < (double)PZ_MAX) ? (int)need : ((need >= (double)PZ_MAX) ? PZ_MAX : 0);
+    hipStream_t s3 = c->stream3;
+    HIPCK(hipStreamWaitEvent(s3, c->ev_gathered, 0));
+    hipLaunchKernelGGL(k_set_par, dim3(1), dim3(1), 0, s3, c->glob, 1, hp, mean_subfrag_kb);
+    if (c->pz_n1 > 0) hipLaunchKernelGGL(k_build_pz, dim3((c->pz_n1 + 255) / 256), dim3(256), 0, s3, c->glob, c->pz_tab1, c->pz_n1, 1);
+    HIPCK(hipMemsetAsync(c->scratch_nuis, 0, 8 * sizeof(long long), s3));
+    launch_full_nz(c, c->tab_prev, 1, c->scratch_nuis, PzTab{c->pz_tab1, c->pz_n1}, s3);
+    hipLaunchKernelGGL(k_full_zero, dim3(128), dim3(256), 0, s3, c->tab_prev, c->glob, 1, c->M, c->scratch_nuis + 2);
+    HIPCK(hipMemcpyAsync(c->host_nuis->sums, c->scratch_nuis, 8 * sizeof(long long), hipMemcpyDeviceToHost, s3));
+    /* the move */
+    enqueue_move(c, 0, C, -1, 2);
+    enqueue_apply(c, 0, 0, 0);
+    HIPCK(hipMemcpyAsync(&c->host_nuis->res, c->d_results, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ig_nuis_end(ig_ctx* c, ig_move_result* out, double* nz_test, double* z_test, int64_t* limbs5)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (!c->nuis_in_flight) return fail("ig_nuis_end: no step in flight");
+    c->nuis_in_flight = false;
+    HIPCK(hipStreamSynchronize(c->stream));
+    HIPCK(hipStreamSynchronize(c->stream3));
+    HIPCK(hipGetLastError());
+    drain_timers(c);
+    *out = c->host_nuis->res;
+    if (out->error) return fail("device-side consistency failure %d", out->error);
+    long long h[8];
+    memcpy(h, c->host_nuis->sums, sizeof h);
+    ig_acc_normalize((int64_t*)&h[0], (int64_t*)&h[1]);
+    ig_acc_normalize((int64_t*)&h[2], (int64_t*)&h[3]);
+    if (nz_test) *nz_test = ig_acc_to_double(h[0], h[1]);
+    if (z_test) { /* as ig_full_likelihood */
+        const double log_e = 0.43429448190325182;
+        double n_tot_pxl;
+        float v_inter;
+        const int vi_bits = (int)h[7];
+        memcpy(&n_tot_pxl, &h[5], sizeof n_tot_pxl);
+        memcpy(&v_inter, &vi_bits, sizeof v_inter);
+        *z_test = ig_acc_to_double(h[2], h[3]) * log_e + log_e * (n_tot_pxl - (double)h[4]) * -1.0 * (double)v_inter;
+    }
+    if (limbs5)
+        for (int i = 0; i < 5; i++) limbs5[i] = h[i];
+    return 0;
+}
+
+/* the accepted step's parameters become the model's (CL:3032-3036) without another pass over all contacts: the maintained
+ * exact sum under the new parameters on the CURRENT state = their full pass on the state before the last move (what the
+ * step just evaluated, quirk Q12) + that move's exact delta under them (k_delta over the touched contigs); the zero-pixel sum
+ * is recounted (O(M)) */
+__global__ void k_nuis_zero(MoveBuf mb, long long* scratch_z)
+{
+    mb.ctl[0].d_hi = mb.ctl[0].d_lo = 0;
+    for (int i = 0; i < 8; i++) scratch_z[i] = 0;
+}
+__global__ void k_nuis_promote(Glob* g, MoveBuf mb, const long long* __restrict__ full_sums, const long long* __restrict__ zero_sums)
+{
+    g->par[0] = g->par[1];
+    long long h = full_sums[0] + mb.ctl[0].d_hi, l = full_sums[1] + mb.ctl[0].d_lo;
+    ig_acc_normalize((int64_t*)&h, (int64_t*)&l);
+    g->nz_hi = h;
+    g->nz_lo = l;
+    h = zero_sums[0];
+    l = zero_sums[1];
+    ig_acc_normalize((int64_t*)&h, (int64_t*)&l);
+    g->z_hi = h;
+    g->z_lo = l;
+    if (zero_sums[2] != g->n_intra) g->error = 8; /* the pair count does not depend on the parameters */
+    mb.ctl[0].d_hi = mb.ctl[0].d_lo = 0;
+}
+
+extern "C" int ig_nuis_accept(ig_ctx* c)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (c->nuis_in_flight) return fail("ig_nuis_accept: end the step first (ig_nuis_end)");
+    static const int s_slow = getenv("IG_NUIS_SLOW_ACCEPT") ? atoi(getenv("IG_NUIS_SLOW_ACCEPT")) : 0;
+    if (s_slow) { /* the plain way: set the parameters, recompute everything */
+        const float p[8] = {c->nuis_test.kuhn, c->nuis_test.lm, c->nuis_test.c1, c->nuis_test.slope, c->nuis_test.d, c->nuis_test.d_max,
+                            c->nuis_test.fact, c->nuis_test.v_inter};
+        return ig_set_params(c, p, c->nuis_mean_kb, 0);
+    }
+    long long* zs = c->scratch8; /* the zero-pixel recount (the from-scratch passes' scratch is free between calls) */
+    hipLaunchKernelGGL(k_nuis_zero, dim3(1), dim3(1), 0, c->stream, c->mb, zs);
+    const PzTab pz1{c->pz_tab1, c->pz_n1};
+    /* the move's delta under the new parameters; contig membership of the partners as of BEFORE the move: tab_prev */
+    hipLaunchKernelGGL(k_delta, dim3(DELTA_RB, 2, 1), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab_prev, c->tab_prev,
+                       c->prev_touched, c->glob, c->mb, c->lgf_tab, pz1, 0, 2, 1);
+    hipLaunchKernelGGL(k_full_zero, dim3(128), dim3(256), 0, c->stream, c->tab, c->glob, 1, c->M, zs);
+    hipLaunchKernelGGL(k_nuis_promote, dim3(1), dim3(1), 0, c->stream, c->glob, c->mb, c->scratch_nuis, zs);
+    /* the tables of the model's parameter set: the test set's P_z table becomes the model's */
+    std::swap(c->pz_tab, c->pz_tab1);
+    std::swap(c->pz_n, c->pz_n1);
+    const PzTab pz0{c->pz_tab, c->pz_n};
+    hipLaunchKernelGGL(k_build_score_const, dim3((LDS_PZ + 2 + 255) / 256), dim3(256), 0, c->stream, c->glob, pz0, c->lgf_tab, c->score_const, 0);
+    hipLaunchKernelGGL(k_build_screen_const, dim3((LDS_PZ + 2 + 255) / 256), dim3(256), 0, c->stream, c->glob, pz0, c->screen_const);
+    HIPCK(hipGetLastError());
     return 0;
 }
 

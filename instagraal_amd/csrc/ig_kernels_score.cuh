@@ -1017,15 +1017,154 @@ __global__ void __launch_bounds__(256) k_full_nz(const int* __restrict__ crow, c
     }
 }
 
+/* k_full_nz_tiled: the same sum from a second, TILED copy of the contacts (built once at upload): the sub-fragments are cut
+ * into blocks of FULL_TB, tile (bi, bj) holds the contacts with row in block bi and column in block bj, a work item = up to
+ * FULL_CHUNK contacts of one tile.  A workgroup stages the 16-byte records (dist, s_tot, contig, rank) of the two blocks in
+ * LDS (2 x 32 KB) and streams its contacts -- 8 bytes each: (row | column << 11) inside the blocks, count -- so the two
+ * endpoint gathers per contact that bound k_full_nz (0.33 T random 16-byte gathers/s into L2) become LDS reads.  Same term,
+ * same exact integer sums (any order of the contacts gives the same total). */
+#define FULL_TB 2048
+#define FULL_CHUNK 16384
+#ifndef FULL_TILED_THREADS
+#define FULL_TILED_THREADS 1024
+#endif
+struct TileWork {
+    long long off; /* first contact of the item in the tiled array */
+    int n, bi, bj, pad;
+};
+struct FullTiledLds {
+    ScoreTables tab;
+    unsigned long long qtrans[LDS_LGF]; /* the quantised term of a trans pair with count ob (it depends on nothing else), + the rounding magic */
+    int4 rrec[FULL_TB], crec[FULL_TB];
+    long long red[2][FULL_TILED_THREADS / 64];
+};
+__global__ void __launch_bounds__(FULL_TILED_THREADS)
+    k_full_nz_tiled(const TileWork* __restrict__ work, const uint2* __restrict__ tc, const int4* __restrict__ rec, const int* __restrict__ len,
+                    const ScoreConst* __restrict__ sc, const double* __restrict__ lgf_tab, int M, int pz_n, long long* out)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    FullTiledLds& L = *(FullTiledLds*)lds_raw;
+    const TileWork wk = work[blockIdx.x];
+    {
+        const float4* src = (const float4*)&sc->tab;
+        float4* dst = (float4*)&L.tab;
+        for (int i = threadIdx.x; i < (int)(sizeof(ScoreTables) / 16); i += blockDim.x) dst[i] = src[i];
+    }
+    const bool diag = wk.bi == wk.bj;
+    for (int i = threadIdx.x; i < FULL_TB; i += blockDim.x) {
+        const int gi = wk.bi * FULL_TB + i, gj = wk.bj * FULL_TB + i;
+        L.rrec[i] = gi < M ? rec[gi] : make_int4(0, 0, -1, 0);
+        if (!diag) L.crec[i] = gj < M ? rec[gj] : make_int4(0, 0, -2, 0);
+    }
+    const ig_params p = sc->par;
+    const ig_hot hot = sc->hot;
+    const float mean = sc->mean_kb, d_max = hot.d_max;
+    const double lv = hot.log2_v_inter, slope = hot.slope, la = hot.log2_amp;
+    const unsigned cut = pz_n <= 0 ? 0u : (pz_n > LDS_PZ ? (unsigned)LDS_PZ : 0xffffffffu);
+    const bool checked = !hot.fast;
+    __syncthreads();
+    const double* T = L.tab.mt;
+    /* a trans pair's term is a function of its count alone -- the straight-line term below with the trans level for P and
+     * P_z: tabulated once per workgroup (same expression, same bits); most tiles hold trans pairs only */
+    if (threadIdx.x < LDS_LGF) {
+        const unsigned o_b = threadIdx.x;
+        const double ex = ig_exp2_core(lv, T), lg = lv * IG_LOG2_10_INV;
+        const double t = (ig_fma((double)o_b, lg, -ex) - L.tab.lgf[o_b]) + L.tab.pzc[LDS_PZ];
+        L.qtrans[o_b] = !(__builtin_fabs(t) < 524288.0) ? (unsigned long long)ig_quantize(t) + IG_QMAGIC_BITS : ig_d2u(ig_fma(t, IG_QSCALE, IG_QMAGIC));
+    }
+    __syncthreads();
+    const int4* cre = diag ? L.rrec : L.crec;
+    const uint2* src = tc + wk.off;
+    unsigned long long acc = 0, accl = 0;
+    /* the next two contacts of a lane are loaded before this pair's terms */
+    const int n = wk.n, nth = blockDim.x;
+    uint2 nx0 = src[min((int)threadIdx.x, n - 1)], nx1 = src[min((int)threadIdx.x + nth, n - 1)];
+    for (int e0 = threadIdx.x; e0 < n; e0 += 2 * nth) {
+        const uint2 v0 = nx0, v1 = nx1;
+        nx0 = src[min(e0 + 2 * nth, n - 1)];
+        nx1 = src[min(e0 + 3 * nth, n - 1)];
+        const int4 ri0 = L.rrec[v0.x & (FULL_TB - 1)], rj0 = cre[(v0.x >> 11) & (FULL_TB - 1)];
+        const int4 ri1 = L.rrec[v1.x & (FULL_TB - 1)], rj1 = cre[(v1.x >> 11) & (FULL_TB - 1)];
+        /* the whole wave on trans pairs with tabulated counts: no arithmetic at all */
+        const bool easy = (ri0.z != rj0.z) && (ri1.z != rj1.z) && (v0.y - 1u < (unsigned)(LDS_LGF - 1)) && (v1.y - 1u < (unsigned)(LDS_LGF - 1));
+        if (!checked && __all(easy)) {
+            const unsigned long long b0 = L.qtrans[v0.y], b1 = L.qtrans[v1.y];
+            if (e0 < n) {
+                acc += b0 - IG_QMAGIC_BITS;
+                accl += (unsigned)b0;
+            }
+            if (e0 + nth < n) {
+                acc += b1 - IG_QMAGIC_BITS;
+                accl += (unsigned)b1;
+            }
+            continue;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint2 v = u ? v1 : v0;
+            const int4 ri = u ? ri1 : ri0, rj = u ? rj1 : rj0;
+            const unsigned o_b = v.y;
+            const bool cis = ri.z == rj.z;
+            const unsigned d = abs_diff_u32((unsigned)ri.w, (unsigned)rj.w);
+            const float sv = fabsf(__int_as_float(ri.x) - __int_as_float(rj.x));
+            const bool in = cis && (sv > 0.0f) && (sv < d_max);
+            const double pzc = L.tab.pzc[cis ? min(d, (unsigned)LDS_PZ) : (unsigned)LDS_PZ];
+            const double lgf = L.tab.lgf[min(o_b, (unsigned)(LDS_LGF - 1))];
+            const double y = ig_fma(slope, ig_log2_pos((double)sv, T), la);
+            const double yy = in ? __builtin_fmax(y, lv) : lv;
+            const double ex = ig_exp2_core(yy, T);
+            const double lg = yy * IG_LOG2_10_INV;
+            const double t = (ig_fma((double)o_b, lg, -ex) - lgf) + pzc;
+            const bool rare = (o_b - 1u >= (unsigned)(LDS_LGF - 1)) || (cis && (d >= cut || __int_as_float(ri.y) != 0.0f)) || checked;
+            unsigned long long bits = ig_d2u(ig_fma(t, IG_QSCALE, IG_QMAGIC));
+            const bool big = !(__builtin_fabs(t) < 524288.0);
+            if (__any(big || rare)) {
+                if (rare)
+                    bits = (unsigned long long)full_q_general(p, mean, cis, sv, (int)d, __int_as_float(ri.y),
+                                                              len[min(wk.bi * FULL_TB + (int)(v.x & (FULL_TB - 1)), M - 1)], (int)o_b, lgf_tab) +
+                           IG_QMAGIC_BITS;
+                else if (big)
+                    bits = (unsigned long long)ig_quantize(t) + IG_QMAGIC_BITS;
+            }
+            if (e0 + u * nth < n) {
+                acc += bits - IG_QMAGIC_BITS;
+                accl += (unsigned)bits;
+            }
+        }
+    }
+    long long hi = ((long long)acc - (long long)accl) >> 32, lo = (long long)accl;
+    hi = wave_sum_ll(hi);
+    lo = wave_sum_ll(lo);
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) {
+        L.red[0][threadIdx.x >> 6] = hi;
+        L.red[1][threadIdx.x >> 6] = lo;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long h = 0, l = 0;
+        for (int v = 0; v < (int)(blockDim.x >> 6); v++) {
+            h += L.red[0][v];
+            l += L.red[1][v];
+        }
+        atomic_add_ll(&out[0], h);
+        atomic_add_ll(&out[1], l);
+    }
+}
+
 /* k_delta: exact update of the full likelihood when the winner's slice was windowed (KA:565-586 keeps only
  * pairs near A and B): sum over ALL pairs of the contig of (term under the winner - term under the current
  * genome).  Row-parallel with a per-wave compaction queue; two columns (current, winner). */
 __global__ void __launch_bounds__(SCORE_THREADS)
     k_delta(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, Tables tab_prev,
-            const int* __restrict__ prev_touched, Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int w, int predicted)
+            const int* __restrict__ prev_touched, Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int w, int predicted,
+            int which)
 {
-    /* predicted = 0: the chosen winner of slot w (one-move tail); 1: the predicted winners of slots w + blockIdx.z */
-    if (predicted) w += blockIdx.z;
+    /* predicted = 0: the chosen winner of slot w (one-move tail); 1: the predicted winners of slots w + blockIdx.z;
+     * 2: the winner of slot w AFTER it was applied, under parameter set `which` (an accepted nuisance step: the maintained
+     * sum under the new parameters = their full pass on the state before the move + this delta); the caller passes the
+     * tables of the state before the move as `tab` */
+    if (predicted == 1) w += blockIdx.z;
     /* tab_prev catches up with the last applied move before k_apply replaces the touched list (quirk Q12) */
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < (predicted ? 0 : g->n_prev_touched);
          i += gridDim.x * gridDim.y * blockDim.x) {
@@ -1039,14 +1178,14 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     __shared__ long long red[2][SCORE_THREADS / 64];
     __shared__ int q_li[SCORE_THREADS / 64][128], q_lj[SCORE_THREADS / 64][128], q_ob[SCORE_THREADS / 64][128];
     MoveCtl& mc = mb.ctl[w];
-    if (g->error || (predicted ? mc.pred < 0 : !mc.ch_windowed)) return;
-    const int c = predicted ? mc.pred_c : mc.ch_c;
+    if (g->error || (predicted == 1 ? mc.pred < 0 : (predicted == 0 && !mc.ch_windowed))) return;
+    const int c = predicted == 1 ? mc.pred_c : mc.ch_c;
     const int cw = CW(w, c);
     const CandMeta& m = mb.meta[cw];
     const int kk = blockIdx.y;
-    const int k = (kk == 0) ? 0 : (predicted ? mc.pred_k : mc.ch_k);
+    const int k = (kk == 0) ? 0 : (predicted == 1 ? mc.pred_k : mc.ch_k);
     const int M = mb.M, m_loc = m.m_loc;
-    const ig_params p = g->par[0];
+    const ig_params p = g->par[which];
     const ig_hot hot = ig_hot_make(p, ig_tab());
     const float mean = g->mean_kb;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1137,8 +1276,8 @@ __global__ void __launch_bounds__(SCORE_THREADS)
         if (hi | lo) {
             /* a predicted winner's delta goes straight into the records (candidate 0 of the slot): the decide step reads it there */
             CandPre& pc = cpre_at(mb, CW(w, 0));
-            atomic_add_ll(predicted ? &pc.pd_hi : &mc.d_hi, kk == 0 ? -hi : hi);
-            atomic_add_ll(predicted ? &pc.pd_lo : &mc.d_lo, kk == 0 ? -lo : lo);
+            atomic_add_ll(predicted == 1 ? &pc.pd_hi : &mc.d_hi, kk == 0 ? -hi : hi);
+            atomic_add_ll(predicted == 1 ? &pc.pd_lo : &mc.d_lo, kk == 0 ? -lo : lo);
         }
     }
 }

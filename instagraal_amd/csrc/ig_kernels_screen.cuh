@@ -56,11 +56,16 @@ __global__ void k_build_screen_const(const Glob* g, PzTab pz, ScreenConst* out)
         out->lv = (float)h.log2_v_inter;
         out->d_max = h.d_max;
         out->cy = (float)((__builtin_fabs(h.log2_amp) + __builtin_fabs(h.slope) + __builtin_fabs(h.log2_v_inter)) * 1.0001 + 1e-6);
-        float mx = (float)((double)p.v_inter * IG_LOG_E_F);
-        for (int q = 0; q < pzn; q++) mx = fmaxf(mx, (float)((double)pz.v[q] * IG_LOG_E_F));
-        out->pzc_max = mx * 1.0001f;
         out->fast = h.fast;
         out->pz_n = pz.n;
+    }
+    if (blockIdx.x == 0) { /* the largest table entry: one wave */
+        if (threadIdx.x < 64) {
+            float mx = (float)((double)p.v_inter * IG_LOG_E_F);
+            for (int q = threadIdx.x; q < pzn; q += 64) mx = fmaxf(mx, (float)((double)pz.v[q] * IG_LOG_E_F));
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
+            if (threadIdx.x == 0) out->pzc_max = mx * 1.0001f;
+        }
     }
 }
 

@@ -55,10 +55,19 @@ __global__ void k_full_zero(Tables t, const Glob* g, int which, int M, long long
     hi = wave_sum_ll(hi);
     lo = wave_sum_ll(lo);
     ni = wave_sum_ll(ni);
+    /* one triple of atomics per workgroup (a thousand waves on three addresses take longer than the sums) */
+    __shared__ long long red[3][16];
+    const int wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        atomic_add_ll(&out[0], hi);
-        atomic_add_ll(&out[1], lo);
-        atomic_add_ll(&out[2], ni);
+        red[0][wv] = hi;
+        red[1][wv] = lo;
+        red[2][wv] = ni;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        long long v = 0;
+        for (int q = 0; q < (int)(blockDim.x >> 6); q++) v += red[threadIdx.x][q];
+        if (v) atomic_add_ll(&out[threadIdx.x], v);
     }
     /* what the host needs next to the sums to form the zero-pixel likelihood: one copy back instead of two */
     if (blockIdx.x == 0 && threadIdx.x == 0) {

@@ -138,6 +138,28 @@ class Neighbours:
         return out
 
 
+def _neighbours_draw_nuisance(self, frags, n_neighbours, skip_normal_3=False):
+    """the generator stream of a run of moves with nuisance sampling: per move the candidate list, then choice(4), the
+    standard normal behind normal(0, sigma), rand() -- numpy's global generator is advanced exactly as the reference's loop
+    (step_sampler; step_nuisance_parameters) would -> (cands, id_modif, normal, uniform)"""
+    f = np.ascontiguousarray(frags, np.int32)
+    n = f.size
+    cands = np.full((n, int(n_neighbours)), -1, np.int32)
+    idm = np.zeros(n, np.int32)
+    g = np.zeros(n, np.float64)
+    u = np.zeros(n, np.float64)
+    key, pos, rest = self.take_numpy_state()
+    cpos, hg, gz = C.c_int32(pos), C.c_int32(int(rest[0])), C.c_double(float(rest[1]))
+    rc = lib().ig_neighbours_draw_nuisance(self._h, _p(key), C.byref(cpos), C.byref(hg), C.byref(gz), _p(f), C.c_int32(n),
+                                           C.c_int32(int(n_neighbours)), C.c_int32(int(bool(skip_normal_3))), _p(cands), _p(idm), _p(g), _p(u))
+    self.put_numpy_state(key, cpos.value, (hg.value, gz.value))
+    _ck(rc)
+    return cands, idm, g, u
+
+
+Neighbours.draw_nuisance = _neighbours_draw_nuisance
+
+
 def set_batch_width(w):
     """moves scored per launch by ``Context.step_batch`` (1 = one move at a time; results do not depend on it)"""
     _ck(lib().ig_set_batch_width(C.c_int(int(w))))
@@ -256,6 +278,21 @@ class Context:
         Neighbours.put_numpy_state(key, cpos.value, rest)
         _ck(rc)
         return res, cands
+
+    # ---- a move and the nuisance step behind it, in flight together
+    def nuis_begin(self, frag_a, cands, p_test8, mean_subfrag_kb):
+        c = np.ascontiguousarray(cands, np.int32)
+        p = np.ascontiguousarray(p_test8, np.float32)
+        _ck(lib().ig_nuis_begin(self._h, C.c_int32(int(frag_a)), _p(c), C.c_int32(c.size), _p(p), C.c_float(float(mean_subfrag_kb))))
+
+    def nuis_end(self):
+        res = MoveResult()
+        nz, z = C.c_double(), C.c_double()
+        _ck(lib().ig_nuis_end(self._h, C.byref(res), C.byref(nz), C.byref(z), C.c_void_p(0)))
+        return res, nz.value, z.value
+
+    def nuis_accept(self):
+        _ck(lib().ig_nuis_accept(self._h))
 
     # ---- speculative batches in steps (slots of a batch split over several GPUs)
     def batch_max_width(self, max_c=5):

@@ -362,27 +362,30 @@ class sampler:  # noqa: N801 - the reference's class name
     def temperature(self, t, n_step):  # CL:3163-3165
         return 1.0
 
-    def step_nuisance_parameters(self, dt, t, n_step):  # CL:2961-3051
-        curr_param = np.copy(self.param_simu)
+    def _sigmas(self, curr_param):  # CL:2970-2974
         kuhn, lm, c1, slope, d, d_max, fact, d_nuc = curr_param[0]
         self.sigma_fact = 10 ** (np.log10(fact) - 2)
         self.sigma_slope = 0.005
         self.sigma_d_max = 100
         self.sigma_d_nuc = 10 ** (np.log10(d_nuc) - 2)
         self.sigma_d = 10
-        id_modif = np.random.choice(4)
+
+    def _propose(self, curr_param, id_modif, normal):
+        """the test parameters of one nuisance step (CL:2979-3017).  ``normal(sigma)`` -> the value numpy's
+        ``np.random.normal(loc=0.0, scale=sigma)`` returns at this point of the stream (a Python float)."""
+        kuhn, lm, c1, slope, d, d_max, fact, d_nuc = curr_param[0]
         if id_modif == 0:
-            new_fact = fact + np.random.normal(loc=0.0, scale=self.sigma_fact)
+            new_fact = fact + normal(self.sigma_fact)
             new_d_max = opti.estimate_max_dist_intra_nuis([kuhn, lm, slope, d, new_fact], d_nuc, d_max)
             c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
             out = [(kuhn, lm, c1, slope, d, new_d_max, new_fact, d_nuc)]
         elif id_modif == 1:
-            new_slope = slope + np.random.normal(loc=0.0, scale=self.sigma_slope)
+            new_slope = slope + normal(self.sigma_slope)
             new_d_max = opti.estimate_max_dist_intra_nuis([kuhn, lm, new_slope, d, fact], d_nuc, d_max)
             c1 = np.float32((0.53 * np.power(lm / kuhn, new_slope)) * np.power(kuhn, -3))
             out = [(kuhn, lm, c1, new_slope, d, new_d_max, fact, d_nuc)]
         elif id_modif == 2:
-            new_d_max = d_max + np.random.normal(loc=0.0, scale=self.sigma_d_max)
+            new_d_max = d_max + normal(self.sigma_d_max)
             new_d_nuc = opti.peval(new_d_max, [kuhn, lm, slope, d, fact])  # 5 values where 4 are read (quirk Q12)
             c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
             out = [(kuhn, lm, c1, slope, d, new_d_max, fact, new_d_nuc)]
@@ -390,11 +393,17 @@ class sampler:  # noqa: N801 - the reference's class name
             if self.sigma_d_nuc <= 0:
                 new_d_nuc = d_nuc
             else:
-                new_d_nuc = d_nuc + np.random.normal(loc=0.0, scale=self.sigma_d_nuc)
+                new_d_nuc = d_nuc + normal(self.sigma_d_nuc)
             new_d_max = opti.estimate_max_dist_intra_nuis([kuhn, lm, slope, d, fact], new_d_nuc, d_max)
             c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
             out = [(kuhn, lm, c1, slope, d, new_d_max, fact, new_d_nuc)]
-        out = np.array(out, dtype=PARAM_DTYPE)
+        return np.array(out, dtype=PARAM_DTYPE)
+
+    def step_nuisance_parameters(self, dt, t, n_step):  # CL:2961-3051
+        curr_param = np.copy(self.param_simu)
+        self._sigmas(curr_param)
+        id_modif = np.random.choice(4)
+        out = self._propose(curr_param, id_modif, lambda sigma: np.random.normal(loc=0.0, scale=sigma))
         self.set_param_simu(out, 1)
         self.likelihood_nuis = self.eval_likelihood_4_nuisance()
         F_t = self.temperature(t, n_step)
@@ -408,6 +417,87 @@ class sampler:  # noqa: N801 - the reference's class name
         kuhn, lm, c1, slope, d, d_max, fact, d_nuc = self.param_simu[0]
         y_rippe = opti.peval(self.bins, [kuhn, lm, slope, d, fact]) if hasattr(self, "bins") else None
         return (fact, d, d_max, d_nuc, slope, self.likelihood_t, success, y_rippe)
+
+    def step_sampler_nuisance_batch(self, frags, n_neighbours, dt=None, t0=0, n_step=0):
+        """``for f in frags: step_sampler(f, n, dt); step_nuisance_parameters(dt, t, n_step)`` -- the loop of
+        instagraal.py:217-262 for cycles > 4 -- with the same results and the same generator stream, arranged for the GPU:
+
+        * the stream of the whole run is drawn up front in the library (candidate lists, choice(4), the standard normal
+          behind normal(0, sigma), the acceptance uniform: its consumption does not depend on the parameters);
+        * the nuisance step's pass over all contacts reads the state BEFORE the move (quirk Q12) and only needs the move's
+          score besides: it runs next to the move (``ig_nuis_begin`` / ``ig_nuis_end``);
+        * while both run, the host prepares the next step's proposal (the root finding for d_max, CL:2983) for the case
+          that this step is rejected.
+
+        -> (structured move results, list of the 8-tuples of step_nuisance_parameters with y_rippe = None)"""
+        frags = np.ascontiguousarray(frags, np.int32)
+        n = frags.size
+        res = np.zeros(n, hip_lib.MOVE_RESULT_DTYPE)
+        self._sigmas(np.copy(self.param_simu))
+        if n == 0 or self.sigma_d_nuc <= 0:  # the one case where the stream depends on the parameters: one step at a time
+            tuples = []
+            for i, f in enumerate(frags):
+                r = self.step_sampler(int(f), n_neighbours, dt)
+                for k in res.dtype.names:
+                    res[k][i] = getattr(self.last_result, k)
+                tuples.append(self.step_nuisance_parameters(dt, t0 + i, n_step))
+            return res, tuples
+        cands, id_modif, gauss, unif = self.neighbours.draw_nuisance(frags, max(1, n_neighbours))
+        tuples = []
+        mean_kb = self.mean_kb()
+
+        def proposal(i, params):
+            self._sigmas(params)
+            g = float(gauss[i])
+            return self._propose(params, int(id_modif[i]), lambda sigma: 0.0 + float(sigma) * g)
+
+        import time as _t
+
+        prof = self.nuis_profile = dict(begin=0.0, propose=0.0, wait=0.0, decide=0.0, accept=0.0)
+        curr = np.copy(self.param_simu)
+        out = proposal(0, curr)
+        names = res.dtype.names
+        for i in range(n):
+            ta = _t.perf_counter()
+            c = cands[i][cands[i] >= 0]
+            self.ctx.nuis_begin(int(frags[i]), c, [out[k][0] for k in PARAM_NAMES], mean_kb)
+            t1 = _t.perf_counter()
+            # while the GPU works: the next step's proposal for both outcomes of this one (the root finding for d_max is
+            # the expensive part of a step on the host)
+            nxt_rej = proposal(i + 1, curr) if i + 1 < n else None
+            nxt_acc = proposal(i + 1, out) if i + 1 < n else None
+            t2 = _t.perf_counter()
+            r, nz, z = self.ctx.nuis_end()
+            t3 = _t.perf_counter()
+            for k in names:
+                res[k][i] = getattr(r, k)
+            self.param_simu_test = out
+            self.likelihood_t = r.o
+            self.likelihood_nuis = np.array([nz]) + z
+            ratio = np.exp((self.likelihood_nuis - self.likelihood_t) / self.temperature(t0 + i, n_step))
+            success = 0
+            t4 = _t.perf_counter()
+            if ratio >= unif[i]:
+                success = 1
+                self.ctx.nuis_accept()
+                self.param_simu = out
+                self.likelihood_t = self.likelihood_nuis
+                curr = np.copy(out)
+            kuhn, lm, c1, slope, d, d_max, fact, d_nuc = self.param_simu[0]
+            tuples.append((fact, d, d_max, d_nuc, slope, self.likelihood_t, success, None))
+            out = nxt_acc if success else nxt_rej
+            t5 = _t.perf_counter()
+            prof["begin"] += t1 - ta
+            prof["propose"] += t2 - t1
+            prof["wait"] += t3 - t2
+            prof["decide"] += t4 - t3
+            prof["accept"] += t5 - t4
+        last = res[-1]
+        self.o = float(last["o"])
+        self.n_contigs = np.int32(last["n_contigs"])
+        self.mean_length_contigs = np.float32(last["mean_len"])
+        self.candidates = [int(x) for x in cands[-1] if x >= 0]
+        return res, tuples
 
     def free_gpu(self):  # CL:3167-3177
         self.ctx.close()

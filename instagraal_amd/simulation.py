@@ -202,13 +202,15 @@ class instagraal_class:
         for j in range(n_cycles):
             np.random.shuffle(list_frags)
             if self.sample_param and j > id_start_sample_param:
-                for id_frag in list_frags:
-                    self._record(id_frag, *sampler.step_sampler(id_frag, n_neighbours, self.dt))
-                    fact, d, d_max, d_nuc, slope, lik, success, _ = sampler.step_nuisance_parameters(self.dt, t, n_iter)
+                # step_sampler + step_nuisance_parameters per bin (IG:221-252), the two in flight together on the GPU
+                res, tuples = sampler.step_sampler_nuisance_batch(list_frags, n_neighbours, self.dt, t, n_iter)
+                for id_frag, r, (fact, d, d_max, d_nuc, slope, lik, success, _) in zip(list_frags, res, tuples):
+                    self._record(id_frag, float(r["o"]), float(r["dist"]), int(r["op_sampled"]), int(r["id_f_sampled"]),
+                                 np.float32(r["mean_len"]), int(r["n_contigs"]))
                     for k, v in (("fact", fact), ("d", d), ("d_max", d_max), ("d_nuc", d_nuc), ("slope", slope), ("success", success)):
                         self.collect[k].append(v)
                     self.collect_likelihood_nuisance.append(lik)
-                    t += 1
+                t += len(list_frags)
             else:  # no nuisance step between the moves: the whole cycle is one batch (same RNG stream, same results)
                 res = sampler.step_sampler_batch(list_frags, n_neighbours)
                 for id_frag, r in zip(list_frags, res):

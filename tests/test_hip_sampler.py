@@ -495,3 +495,69 @@ def test_errors_are_loud():
     c2 = hip_lib.Context(0)
     with pytest.raises(hip_lib.HipError):
         c2.step(0, [1])  # nothing uploaded
+
+
+def test_nuisance_batch_matches_golden_and_the_sequential_calls():
+    """step_sampler_nuisance_batch (the move and the nuisance step's pass over all contacts in flight together, the run's
+    generator stream drawn up front in the library) against the reference-driven golden trajectory -- return tuples, nuisance
+    tuples, generator state, genome -- and against the one-call-at-a-time methods on a larger problem."""
+    from instagraal_amd import synth
+    from instagraal_amd.sampler import sampler as hip_sampler
+
+    g = np.load(os.path.join(GOLDEN, "tiny_nuis_mode1.npz"))
+    prob = synth.make_problem(*synth.CONFIGS[str(g["config"])])
+    np.random.seed(int(g["seed"]))
+    s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
+    s.set_param_simu(prob.params)
+    s.bins = np.arange(1.0, 60.0, 1.0)
+    s.eval_likelihood_init()
+    frags = np.arange(0, s.n_new_frags)
+    np.random.shuffle(frags)
+    nuis_from, n = int(g["nuis_from"]), len(g["frag"])
+    assert np.array_equal(frags[:n], g["frag"])
+    res0 = s.step_sampler_batch(g["frag"][:nuis_from], 5)
+    res1, tuples = s.step_sampler_nuisance_batch(g["frag"][nuis_from:], 5, s.dt, nuis_from, n)
+    res = np.concatenate([res0, res1])
+    for t in range(n):
+        r = res[t]
+        got = [float(r["o"]), float(r["dist"]), float(r["op_sampled"]), float(r["id_f_sampled"]), float(np.float32(r["mean_len"])), float(r["n_contigs"])]
+        assert got == list(g["ret"][t]), (t, got, list(g["ret"][t]))
+    for k, q in enumerate(tuples):
+        got = [float(q[0]), float(q[1]), float(q[2]), float(q[3]), float(q[4]), float(np.ravel(q[5])[0]), float(q[6])]
+        assert got == list(g["nuis"][k]), (k, got, list(g["nuis"][k]))
+    assert np.array_equal(np.random.get_state()[1][:8], g["rng_after"])
+    assert np.array_equal(s.gpu_vect_frags.copy_from_gpu().soa17(), g["states"][-1])
+    s.free_gpu()
+
+    prob = synth.make_problem(*synth.CONFIGS["small"])
+    outs = []
+    for batch in (False, True):
+        np.random.seed(8)
+        s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
+        s.set_param_simu(prob.params)
+        s.bins = np.arange(1.0, 60.0, 1.0)
+        s.eval_likelihood_init()
+        frags = np.random.permutation(prob.n_frags)[:70]
+        np.random.normal()  # a cached gaussian in the generator at the start of the run
+        if batch:
+            res, tuples = s.step_sampler_nuisance_batch(frags, 5, s.dt, 0, 70)
+            rows = [(float(r["o"]), float(r["dist"]), int(r["op_sampled"]), int(r["id_f_sampled"]), int(r["n_contigs"])) for r in res]
+            nu = [tuple(float(np.ravel(x)[0]) for x in q[:7]) for q in tuples]
+        else:
+            rows, nu = [], []
+            for t, f in enumerate(frags):
+                r = s.step_sampler(int(f), 5, s.dt)
+                rows.append((float(r[0]), float(r[1]), int(r[2]), int(r[3]), int(r[5])))
+                q = s.step_nuisance_parameters(s.dt, t, 70)
+                nu.append(tuple(float(np.ravel(x)[0]) for x in q[:7]))
+        sums, _ = s.ctx.debug_globals()
+        _, _, limbs = s.ctx.full_likelihood(0)
+        assert [int(x) for x in sums[:5]] == [int(x) for x in limbs[:5]]
+        outs.append((rows, nu, s.gpu_vect_frags.copy_from_gpu().soa17(), np.random.get_state()[1][:6].copy(), np.random.get_state()[2:],
+                     [float(s.param_simu[k][0]) for k in ("fact", "slope", "d_max", "v_inter")]))
+        s.free_gpu()
+    assert outs[0][0] == outs[1][0]
+    assert outs[0][1] == outs[1][1]
+    assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3]) and outs[0][4] == outs[1][4]
+    assert outs[0][5] == outs[1][5]
+    assert sum(q[6] for q in outs[0][1]) > 0  # some steps were accepted: the accepted branch is covered

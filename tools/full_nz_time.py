@@ -3,7 +3,7 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import numpy as np
 
 from instagraal_amd import synth

@@ -1,5 +1,5 @@
 import sys, os, json, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import numpy as np
 from instagraal_amd import hip_lib, synth
 from instagraal_amd.sampler import sampler as hip_sampler

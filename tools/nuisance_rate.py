@@ -1,11 +1,12 @@
-"""moves/s of the reference-shaped loop WITH nuisance sampling (instagraal.py:217-262 for cycles > 4): one step_sampler and
-one step_nuisance_parameters (a full pass over all contacts under test parameters) per move.  Diagnostic, not the
-BASELINE metric."""
+"""moves/s of the loop WITH nuisance sampling (instagraal.py:217-262 for cycles > 4): one step_sampler and one
+step_nuisance_parameters (a full pass over all contacts under test parameters) per move, through
+sampler.step_sampler_nuisance_batch (the two in flight together) and through the one-call-at-a-time methods; with a
+breakdown of where the host waits.  Diagnostic, not the BASELINE metric.   python tools/nuisance_rate.py [cfg3] [moves]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import numpy as np
 
 from instagraal_amd import synth
@@ -19,13 +20,18 @@ s.set_param_simu(prob.params)
 s.bins = np.arange(1.0, 60.0, 1.0)
 s.eval_likelihood_init()
 np.random.seed(0)
-frags = np.random.permutation(prob.n_frags)[: n + 20]
-for f in frags[:20]:
-    s.step_sampler(int(f), 5, s.dt)
-    s.step_nuisance_parameters(s.dt, 0, n)
+frags = np.random.permutation(prob.n_frags)[: 2 * n + 40]
+s.step_sampler_nuisance_batch(frags[:20], 5, s.dt, 0, n)
 t0 = time.perf_counter()
+res, tup = s.step_sampler_nuisance_batch(frags[20:20 + n], 5, s.dt, 0, n)
+dt = time.perf_counter() - t0
+print("%s: %.0f moves/s through step_sampler_nuisance_batch (accept rate %.2f)" % (cfg, n / dt, np.mean([q[6] for q in tup])))
+if hasattr(s, "nuis_profile"):
+    tot = sum(s.nuis_profile.values())
+    print("   host time per move: " + ", ".join("%s %.0f us" % (k, 1e6 * v / n) for k, v in s.nuis_profile.items()) + " (sum %.0f us)" % (1e6 * tot / n))
 t_s = t_n = 0.0
-for t, f in enumerate(frags[20:]):
+rest = frags[20 + n:20 + n + min(n, 100)]
+for t, f in enumerate(rest):
     a = time.perf_counter()
     s.step_sampler(int(f), 5, s.dt)
     b = time.perf_counter()
@@ -33,6 +39,5 @@ for t, f in enumerate(frags[20:]):
     c = time.perf_counter()
     t_s += b - a
     t_n += c - b
-dt = time.perf_counter() - t0
-print("%s: %.0f moves/s with nuisance sampling (step_sampler %.0f us, step_nuisance_parameters %.0f us per move)" % (
-    cfg, n / dt, 1e6 * t_s / n, 1e6 * t_n / n))
+print("%s: %.0f moves/s one call at a time (step_sampler %.0f us, step_nuisance_parameters %.0f us per move)" % (
+    cfg, len(rest) / (t_s + t_n), 1e6 * t_s / len(rest), 1e6 * t_n / len(rest)))
