@@ -93,6 +93,7 @@ struct Glob {
     int error;
     int stamp_ctr;
     long long scr_cols, scr_cont; /* two-tier scoring: columns screened, columns scored exactly */
+    long long scr_void_cols; /* columns whose screening bound was void */
     long long scr_terms, scr_terms_exact; /* ... and the (contact, column) terms in them */
 };
 
@@ -174,7 +175,10 @@ struct MoveBuf {
      * bound is void, the contender masks */
     struct ScreenSum* scr; /* [..][NSLOT] */
     unsigned* scr_void;    /* [..] bit k */
-    unsigned* cont;        /* [..] bit k: column k goes through the exact kernel */
+    unsigned* scr_ub;      /* [..] bit k: the screened sum is an upper bound only (a ring on the window) */
+    unsigned* cont;        /* [..] bit k: column k can still win (k_contend) */
+    unsigned* ident;       /* [..] bit k: column k's genome IS the current genome on the window (its sums are column 0's: neither
+                            * screened nor scored) */
     /* two-tier scoring: the exact kernel's work list of a batch: eight interleaved sub-lists (k_contend), work[0..8) = their
      * lengths, work[8..16) = the lengths they would have had if every slot had fitted, item j of sub-list x at work[16 + 8 j + x]:
      * (chunk << 32 | cw << 12 | k << 4 | segment): entries [chunk * ch, (chunk + 1) * ch) of that segment of candidate cw's

@@ -221,7 +221,9 @@ static void free_move_buffers(ig_ctx* c)
     hipFree(m.rec);
     hipFree(m.scr);
     hipFree(m.scr_void);
+    hipFree(m.scr_ub);
     hipFree(m.cont);
+    hipFree(m.ident);
     hipFree(m.work);
     hipFree(c->own_tag);
     hipFree(c->own_idx);
@@ -376,7 +378,10 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
     DALLOC(m.rec, m.rec_stride * (size_t)capW);
     DALLOC(m.scr, C * NSLOT);
     DALLOC(m.scr_void, C);
+    DALLOC(m.scr_ub, C);
     DALLOC(m.cont, C);
+    DALLOC(m.ident, C);
+    HIPCK(hipMemset(m.ident, 0, C * sizeof(unsigned)));
     m.work_cap = (int)std::min<size_t>((size_t)1 << 20, 4 * C * NSLOT * SLICE_SEG + 4096);
     DALLOC(m.work, (size_t)m.work_cap + 32);
     HIPCK(hipMemset(m.cont, 0xff, C * sizeof(unsigned)));
@@ -922,13 +927,13 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                 {
                     TimedLaunch t(c, T_SCREEN);
                     hipLaunchKernelGGL(k_screen, dim3(SLICE_SEG, NSLOT, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->screen_const, c->mb,
-                                       c->mb.scr, c->mb.scr_void, max_c, w_begin);
+                                       c->mb.scr, c->mb.scr_void, c->mb.scr_ub, max_c, w_begin);
                 }
                 hipMemsetAsync(c->mb.work, 0, 16 * sizeof(unsigned long long), c->stream);
                 if (c->exact_grid <= 0) c->exact_grid = 32768;
                 c->exact_grid = std::min(c->exact_grid, c->mb.work_cap);
                 hipStreamWaitEvent(c->stream, c->ev_tail, 0); /* the contender test reads the exact tail sums (quirk Q5) */
-                hipLaunchKernelGGL(k_contend, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, c->mb.scr, c->mb.scr_void, c->mb.cont, w_begin,
+                hipLaunchKernelGGL(k_contend, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, c->mb.cont, w_begin,
                                    getenv("IG_CONTEND_ALL") ? atoi(getenv("IG_CONTEND_ALL")) : 0, c->exact_grid,
                                    getenv("IG_EXACT_CHUNK") ? std::max(256, atoi(getenv("IG_EXACT_CHUNK"))) : EXACT_CHUNK);
                 hipLaunchKernelGGL(k_worklist, dim3(nW), dim3(256), 0, c->stream, c->mb, c->mb.cont, w_begin, c->exact_grid);
@@ -951,7 +956,7 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                 if (!c->screen_worst) {
                     if (dalloc(&c->screen_worst, 2) == 0) hipMemsetAsync(c->screen_worst, 0, 2 * sizeof(double), c->stream);
                 }
-                hipLaunchKernelGGL(k_screen_verify, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, c->mb.scr, c->mb.scr_void, w_begin,
+                hipLaunchKernelGGL(k_screen_verify, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, w_begin,
                                    c->screen_worst);
             }
         }
@@ -1772,6 +1777,7 @@ extern "C" int ig_debug_screen_stats(ig_ctx* c, double out4[6])
     out4[3] = (double)hg.scr_cont;
     out4[4] = (double)hg.scr_terms;
     out4[5] = (double)hg.scr_terms_exact;
+    if (getenv("IG_SCREEN_STATS")) fprintf(stderr, "[screen] void columns %lld of %lld\n", hg.scr_void_cols, hg.scr_cols);
     return 0;
 }
 

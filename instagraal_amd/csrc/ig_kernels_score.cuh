@@ -120,7 +120,9 @@ __global__ void __launch_bounds__(256)
     for (int i = t; i < C * NSLOT * 2; i += blockDim.x) ((long long*)mb.scr)[(size_t)CW(w, 0) * NSLOT * 2 + i] = 0;
     if (t < C) {
         mb.scr_void[CW(w, t)] = 0;
+        mb.scr_ub[CW(w, t)] = 0;
         mb.cont[CW(w, t)] = 0xffffffffu;
+        mb.ident[CW(w, t)] = 0;
     }
     if (t < C) {
         CandMeta m;
@@ -1504,9 +1506,10 @@ __global__ void __launch_bounds__(64) k_records(MoveBuf mb, int w_begin, int con
     const int t = threadIdx.x;
     {
         const long long* part = mb.part + (size_t)cw * P_STRIDE;
-        if (t <= m.n_uniq) {
-            qp[Q_NZFULL + 2 * t] = part[P_NZ + 2 * t];
-            qp[Q_NZFULL + 2 * t + 1] = part[P_NZ + 2 * t + 1];
+        if (t <= m.n_uniq) { /* two-tier scoring: a column whose genome is the current one was not scored: its sums are column 0's */
+            const int src = (contenders_only && ((mb.ident[cw] >> t) & 1u)) ? 0 : t;
+            qp[Q_NZFULL + 2 * t] = part[P_NZ + 2 * src];
+            qp[Q_NZFULL + 2 * t + 1] = part[P_NZ + 2 * src + 1];
         }
     }
     __syncthreads();

@@ -39,6 +39,7 @@ struct alignas(16) ScreenConst {
     float slope, la, lv, d_max;
     float cy;      /* |log2 amp| + |slope| + |log2 v_inter| (rounded up) */
     float pzc_max; /* largest table entry */
+    float zc_ub;   /* upper bound of P_z log10(e) for a pair on a circular contig (< 0: none, the bound of such a column is void) */
     int fast;      /* parameters in the one-log domain */
     int pz_n;      /* length of the P_z table the exact path uses */
 };
@@ -58,6 +59,21 @@ __global__ void k_build_screen_const(const Glob* g, PzTab pz, ScreenConst* out)
         out->cy = (float)((__builtin_fabs(h.log2_amp) + __builtin_fabs(h.slope) + __builtin_fabs(h.log2_v_inter)) * 1.0001 + 1e-6);
         out->fast = h.fast;
         out->pz_n = pz.n;
+        /* Pairs on a CIRCULAR contig (a ring made by a candidate: KA:3588-3649) are evaluated with rippe_contacts_circ, which
+         * clamps BELOW with d_max (quirk Q6): P >= d_max, hundreds of contacts expected per pair -- such a column loses by
+         * orders of magnitude and only needs an UPPER bound to be ruled out:
+         *     ob log10 P - P <= max over P >= d_max            (concave: at P = max(d_max, ob / ln 10))
+         *     P_z = rippe_contacts_circ(d mean, len mean) <= max(kuhn^-3 fact n0^slope, d_max),  n0 = (lm / kuhn) mean / 2
+         * the second for slope < 0 (P decreasing in n = K s (S - s) / S, which is smallest, K mean (len - 1) / len >= n0, at
+         * rank distance 1); other slopes: no bound, the column is scored exactly. */
+        float zc = -1.0f;
+        if (h.fast && p.slope < 0.0f && p.kuhn > 0.0f && p.lm > 0.0f && g->mean_kb > 0.0f && p.d_max > 0.0f && p.d_max < 1e5f) { /* d_max < 1e5: the bound stays above the contract's clamp at -2^20 */
+            const double n0 = ((double)p.lm / (double)p.kuhn) * (double)g->mean_kb * 0.5;
+            const double pmax = ig_exp2(h.slope * ig_log2_pos(n0, ig_tab()), ig_tab()) * (double)p.fact / ((double)p.kuhn * p.kuhn * p.kuhn);
+            const double top = __builtin_fmax(__builtin_fmax(pmax, (double)p.d_max), (double)p.v_inter);
+            if (top < 1e30) zc = (float)(top * IG_LOG_E_F * 1.001);
+        }
+        out->zc_ub = zc;
     }
     if (blockIdx.x == 0) { /* the largest table entry: one wave */
         if (threadIdx.x < 64) {
@@ -87,10 +103,10 @@ struct alignas(16) ScreenLds {
 };
 
 /* one screened term; MASKED: the lane's entry may lie past the end of the list (last, partly filled step) */
-template <bool STAGED, bool HAS_CUT, bool MASKED>
+template <bool STAGED, bool HAS_CUT, bool MASKED, bool CIRC = false>
 __device__ __forceinline__ void screen_term(unsigned long long pk, bool live, const uint2* gcol, const ScreenLds& L, float slope, float la,
                                             float lv, float d_max, float c10, unsigned cut, double& acc, float& exs, float& obs, float& ymax,
-                                            unsigned& bad)
+                                            unsigned& bad, unsigned circ_mask = 0, float zc_ub = 0.0f)
 {
     const unsigned lo = (unsigned)pk, hi = (unsigned)(pk >> 32);
     bad |= MASKED ? (live ? hi : 0u) : hi; /* bits 8.. = the count: the largest count's leading bit survives the OR (checked at the end) */
@@ -114,6 +130,16 @@ __device__ __forceinline__ void screen_term(unsigned long long pk, bool live, co
     const float m = obf * yy;
     float t = __builtin_fmaf(m, c10, -ex) + pzc;
     float exa = ex, oba = obf, yya = yy;
+    if (CIRC) { /* a pair on a circular contig: an upper bound of its term (k_build_screen_const), nothing towards the error sums */
+        const bool ring = cis && ((circ_mask >> (ai.y >> 28)) & 1u);
+        const float em = fmaxf(d_max, 0.43429448f * obf);
+        const float lem = __builtin_amdgcn_logf(em) * c10;
+        const float ub = __builtin_fmaf(obf, lem, -em) + zc_ub + 1e-5f * (obf * fabsf(lem) + em);
+        t = ring ? ub : t;
+        exa = ring ? 0.0f : exa;
+        oba = ring ? 0.0f : oba;
+        yya = ring ? 0.0f : yya;
+    }
     if (MASKED) {
         t = live ? t : 0.0f;
         exa = live ? ex : 0.0f;
@@ -130,10 +156,10 @@ __device__ __forceinline__ void screen_term(unsigned long long pk, bool live, co
 /* a wave streams steps of 64 x SCREEN_BATCH consecutive entries (steps wave, wave + 4, ...); the entries of the next step
  * are loaded before this step's terms.  The lists live in a pool with slack behind its last entry (ensure_move_buffers):
  * the look-ahead loads need no clamping; only the last, partly filled step of a wave masks its lanes. */
-template <bool STAGED, bool HAS_CUT>
+template <bool STAGED, bool HAS_CUT, bool CIRC = false>
 __device__ __forceinline__ void screen_loop(const unsigned long long* __restrict__ slp, unsigned n, const uint2* gcol, const ScreenLds& L,
                                             float slope, float la_s, float lv_s, float d_max, unsigned cut, double& acc, float& exs, float& obs,
-                                            float& ymax, unsigned& bad)
+                                            float& ymax, unsigned& bad, unsigned circ_mask = 0, float zc_ub = 0.0f)
 {
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned step = 64 * SCREEN_BATCH, stride = step * (SCORE_THREADS / 64);
@@ -155,22 +181,23 @@ __device__ __forceinline__ void screen_loop(const unsigned long long* __restrict
         for (int u = 0; u < SCREEN_BATCH; u++) nx[u] = ptr[u * 64];
 #pragma unroll
         for (int u = 0; u < SCREEN_BATCH; u++)
-            screen_term<STAGED, HAS_CUT, false>(pk[u], true, gcol, L, slope, la, lv, d_max, c10, cut, acc, exs, obs, ymax, bad);
+            screen_term<STAGED, HAS_CUT, false, CIRC>(pk[u], true, gcol, L, slope, la, lv, d_max, c10, cut, acc, exs, obs, ymax, bad, circ_mask, zc_ub);
     }
     if (s0 < n) { /* the partly filled step */
         const unsigned long long safe = slp[0];
 #pragma unroll
         for (int u = 0; u < SCREEN_BATCH; u++) {
             const bool live = s0 + u * 64 + lane < n;
-            screen_term<STAGED, HAS_CUT, true>(live ? nx[u] : safe, live, gcol, L, slope, la, lv, d_max, c10, cut, acc, exs, obs, ymax, bad);
+            screen_term<STAGED, HAS_CUT, true, CIRC>(live ? nx[u] : safe, live, gcol, L, slope, la, lv, d_max, c10, cut, acc, exs, obs, ymax, bad, circ_mask,
+                                                     zc_ub);
         }
     }
 }
 
 /* k_screen: one workgroup = (segment of the slice list, column k, candidate cw), as k_score_list */
 __global__ void __launch_bounds__(SCORE_THREADS)
-    k_screen(const ScreenConst* __restrict__ sc, MoveBuf mb, ScreenSum* __restrict__ scr, unsigned* __restrict__ scr_void, int max_c,
-             int w_begin)
+    k_screen(const ScreenConst* __restrict__ sc, MoveBuf mb, ScreenSum* __restrict__ scr, unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub,
+             int max_c, int w_begin)
 {
     __shared__ ScreenLds L;
     const int w = w_begin + blockIdx.z / max_c, c = blockIdx.z % max_c;
@@ -182,7 +209,9 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     const long long off = mb.sloff[(size_t)cw * SLICE_SEG + blockIdx.x];
     const float slope = sc->slope, la = sc->la, lv = sc->lv, d_max = sc->d_max, cy = sc->cy, pzc_max = sc->pzc_max;
     const int fast = sc->fast, pz_n = sc->pz_n;
+    /* a column whose genome is the current genome on the window (k_mutate: nothing changed) has column 0's sums exactly */
     if (c >= C || k > n_uniq || n == 0 || off < 0) return;
+    if (k > 0 && mb.sinfo[cw * NSLOT + mb.meta[cw].uniq[k - 1]].x == 0) return;
     const uint2* gcol = mb.coords + (size_t)(cw * NSLOT + k) * mb.M;
     const bool staged = m_loc <= LDS_COL_SMALL;
     {
@@ -198,16 +227,24 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     unsigned circ_mask = 0;
 #pragma unroll
     for (int q = 0; q < NCODE; q++) circ_mask |= (L.cm[q].stot != 0) ? (1u << q) : 0u;
-    if (circ_mask || !fast) { /* outside the screening term's domain: the column goes through the exact kernel */
+    const float zc_ub = sc->zc_ub;
+    /* outside the screening term's domain: the column goes through the exact kernel.  A ring on the window (a candidate
+     * that closes a contig) is inside it as far as an UPPER bound goes -- all it takes to rule the column out; the current
+     * genome's own column (k = 0) needs both bounds */
+    if (!fast || (circ_mask && (zc_ub < 0.0f || k == 0))) {
         if (threadIdx.x == 0) atomicOr(&scr_void[cw], 1u << k);
         return;
     }
+    if (circ_mask && threadIdx.x == 0) atomicOr(&scr_ub[cw], 1u << k); /* every segment's workgroup: an empty one leaves before */
     double acc = 0.0;
     float exs = 0.0f, ymax = 0.0f, obs = 0.0f;
     unsigned bad = 0;
     const unsigned cut = pz_n > LDS_PZ ? (unsigned)LDS_PZ : 0xffffffffu;
     const unsigned long long* slp = mb.sl_pk + off;
-    if (pz_n > LDS_PZ) { /* a P_z table longer than its LDS copy: pairs beyond the copy void the column's bound */
+    if (circ_mask) {
+        if (staged) screen_loop<true, true, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad, circ_mask, zc_ub);
+        else screen_loop<false, true, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad, circ_mask, zc_ub);
+    } else if (pz_n > LDS_PZ) { /* a P_z table longer than its LDS copy: pairs beyond the copy void the column's bound */
         if (staged) screen_loop<true, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
         else screen_loop<false, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
     } else {
@@ -266,12 +303,12 @@ __global__ void __launch_bounds__(SCORE_THREADS)
  * out to be (candidate 0 of a slot w > 0 is screened with ALL block-insert slots, quirk Q4).  cont[cw]: bit k = column k
  * goes through the exact kernel (bit 0, the current genome's column, with any other bit). */
 __global__ void __launch_bounds__(256) k_contend(Glob* g, MoveBuf mb, const ScreenSum* __restrict__ scr, const unsigned* __restrict__ scr_void,
-                                                 unsigned* __restrict__ cont, int w_begin, int force_all, int grid_cap, int chunk0)
+                                                 const unsigned* __restrict__ scr_ub, unsigned* __restrict__ cont, int w_begin, int force_all, int grid_cap, int chunk0)
 {
     __shared__ double s_lo[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT], s_hi[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT];
     __shared__ int s_kind[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT]; /* 0 not scored, 1 always scored, 2 depends on the flags, 3 void bound */
     __shared__ double s_best[4];
-    __shared__ unsigned s_mask[IG_MAX_CANDIDATES];
+    __shared__ unsigned s_mask[IG_MAX_CANDIDATES], s_ident[IG_MAX_CANDIDATES];
     const int w = w_begin + blockIdx.x, tid = threadIdx.x;
     const MoveCtl& mc = mb.ctl[w];
     const int C = mc.C, n = C * IG_N_TMP_STRUCT;
@@ -279,7 +316,8 @@ __global__ void __launch_bounds__(256) k_contend(Glob* g, MoveBuf mb, const Scre
     const double log_e = IG_LOG_E_F, n_tot_pxl = g->n_tot_pxl;
     const long long z_hi = g->z_hi, z_lo = g->z_lo, n_intra = g->n_intra;
     const double cur_nz = ig_acc_to_double(g->nz_hi, g->nz_lo);
-    if (tid < IG_MAX_CANDIDATES) s_mask[tid] = 0;
+    if (tid < IG_MAX_CANDIDATES) s_mask[tid] = s_ident[tid] = 0;
+    __syncthreads();
     for (int i = tid; i < n; i += blockDim.x) {
         const int c = i / IG_N_TMP_STRUCT, slot = i % IG_N_TMP_STRUCT;
         const int cw = CW(w, c);
@@ -291,13 +329,15 @@ __global__ void __launch_bounds__(256) k_contend(Glob* g, MoveBuf mb, const Scre
             const bool sup = (c == 0) && mc.superset0 && (slot >= 12);
             kind = sup ? 2 : 1;
             const unsigned vd = scr_void[cw];
-            if (force_all || ((vd >> k) & 1u) || (vd & 1u)) {
+            const bool same = force_all != 1 && mb.sinfo[cw * NSLOT + slot].x == 0; /* the current genome again: nz - ext = 0 exactly */
+            if (same) atomicOr(&s_ident[c], 1u << k);
+            if (!same && (force_all == 1 || ((vd >> k) & 1u) || (vd & 1u))) {
                 kind = 3;
             } else {
                 const long long* qp = mb.qpart + (size_t)cw * Q_STRIDE;
                 const ScreenSum a = scr[cw * NSLOT + k], b = scr[cw * NSLOT];
-                const double D = (double)(a.s_fix - b.s_fix) * (1.0 / SCR_FIX);
-                const double Bd = (double)(a.b_fix + b.b_fix) * (1.0 / SCR_FIX);
+                const double D = same ? 0.0 : (double)(a.s_fix - b.s_fix) * (1.0 / SCR_FIX);
+                const double Bd = same ? 0.0 : (double)(a.b_fix + b.b_fix) * (1.0 / SCR_FIX);
                 const long long dz_hi = qp[Q_Z + 2 * k] - qp[Q_Z], dz_lo = qp[Q_Z + 2 * k + 1] - qp[Q_Z + 1];
                 const long long dni = qp[Q_NI + k] - qp[Q_NI];
                 const double val_inter = -1.0 * log_e * (n_tot_pxl - (double)(n_intra + dni)) * p.v_inter;
@@ -319,11 +359,17 @@ __global__ void __launch_bounds__(256) k_contend(Glob* g, MoveBuf mb, const Scre
                 const double slack = 1e-3 + 1e-12 * (__builtin_fabs(cur_nz) + __builtin_fabs(val_intra) + __builtin_fabs(val_inter));
                 lo = vmin - Bd - slack;
                 hi = vmax + Bd + slack;
+                if ((scr_ub[cw] >> k) & 1u) { /* a ring on the window: the screened sum is an upper bound only */
+                    lo = -1e299;
+                    if (kind == 1) kind = 2; /* bounds nothing */
+                }
                 if (!(lo == lo) || !(hi == hi) || !(__builtin_fabs(lo) < 1e300) || !(__builtin_fabs(hi) < 1e300)) kind = 3;
                 /* an exact score of 0.0 counts as "not scored" in the argmax (CL:1435-1440): such a column bounds nothing */
                 else if (lo <= 0.0 && hi >= 0.0 && kind == 1) kind = 2;
             }
         }
+        if (kind == 3 && force_all == 2) kind = 0; /* timing experiment only (IG_CONTEND_ALL=2): void columns dropped -- WRONG results */
+        if (kind == 3) atomic_add_ll(&g->scr_void_cols, 1);
         s_kind[i] = kind;
         s_lo[i] = lo;
         s_hi[i] = hi;
@@ -345,12 +391,15 @@ __global__ void __launch_bounds__(256) k_contend(Glob* g, MoveBuf mb, const Scre
         }
     }
     __syncthreads();
-    if (tid < C) cont[CW(w, tid)] = s_mask[tid];
+    if (tid < C) {
+        cont[CW(w, tid)] = s_mask[tid];
+        mb.ident[CW(w, tid)] = s_ident[tid];
+    }
     /* what this slot will put on the exact kernel's work list (k_worklist): items of at most ch entries; ch is chosen so
      * that a slot alone never needs more than half of the grid */
     if (tid == 0) {
         long long tot = 0;
-        for (int c = 0; c < C; c++) tot += slice_total(mb.part + (size_t)CW(w, c) * P_STRIDE) * __popc(s_mask[c]);
+        for (int c = 0; c < C; c++) tot += slice_total(mb.part + (size_t)CW(w, c) * P_STRIDE) * __popc(s_mask[c] & ~s_ident[c]);
         long long ch = chunk0;
         while (tot / ch + (long long)C * NSLOT * SLICE_SEG > grid_cap / 2) ch *= 2;
         mb.ctl[w].exact_chunk = (int)ch;
@@ -361,9 +410,9 @@ __global__ void __launch_bounds__(256) k_contend(Glob* g, MoveBuf mb, const Scre
         for (int c = 0; c < C; c++) {
             const long long Sc = slice_total(mb.part + (size_t)CW(w, c) * P_STRIDE);
             cols += mb.meta[CW(w, c)].n_uniq + 1;
-            cnt += __popc(s_mask[c]);
+            cnt += __popc(s_mask[c] & ~s_ident[c]);
             tcols += Sc * (mb.meta[CW(w, c)].n_uniq + 1);
-            tcnt += Sc * __popc(s_mask[c]);
+            tcnt += Sc * __popc(s_mask[c] & ~s_ident[c]);
         }
         atomic_add_ll(&g->scr_cols, cols);
         atomic_add_ll(&g->scr_cont, cnt);
@@ -389,7 +438,7 @@ __global__ void __launch_bounds__(256) k_worklist(MoveBuf mb, const unsigned* __
     auto items_of = [&](int ws, int c, int seg) -> int {
         const long long ch = mb.ctl[ws].exact_chunk;
         const long long n_seg = mb.part[(size_t)CW(ws, c) * P_STRIDE + P_CNT + seg];
-        return (int)((n_seg + ch - 1) / ch) * __popc(cont[CW(ws, c)]);
+        return (int)((n_seg + ch - 1) / ch) * __popc(cont[CW(ws, c)] & ~mb.ident[CW(ws, c)]);
     };
     if (tid < 8) s_base[tid] = s_cnt[tid] = 0;
     __syncthreads();
@@ -422,7 +471,7 @@ __global__ void __launch_bounds__(256) k_worklist(MoveBuf mb, const unsigned* __
         const int cw = CW(w, c);
         const long long n_seg = mb.part[(size_t)cw * P_STRIDE + P_CNT + seg];
         const int nch = (int)((n_seg + ch - 1) / ch);
-        const unsigned mask = cont[cw];
+        const unsigned mask = cont[cw] & ~mb.ident[cw];
         if (!nch || !mask) continue;
         const int x = seg & 7;
         int j = s_base[x] + atomicAdd(&s_cnt[x], nch * __popc(mask));
@@ -439,8 +488,8 @@ __global__ void __launch_bounds__(256) k_worklist(MoveBuf mb, const unsigned* __
 }
 
 /* IG_SCREEN_VERIFY=1: every column was scored exactly as well; check the bound column by column */
-__global__ void k_screen_verify(Glob* g, MoveBuf mb, const ScreenSum* __restrict__ scr, const unsigned* __restrict__ scr_void, int w_begin,
-                                double* worst)
+__global__ void k_screen_verify(Glob* g, MoveBuf mb, const ScreenSum* __restrict__ scr, const unsigned* __restrict__ scr_void,
+                                const unsigned* __restrict__ scr_ub, int w_begin, double* worst)
 {
     const int w = w_begin + blockIdx.x;
     const MoveCtl& mc = mb.ctl[w];
@@ -449,12 +498,16 @@ __global__ void k_screen_verify(Glob* g, MoveBuf mb, const ScreenSum* __restrict
         const int cw = CW(w, c);
         if (k == 0 || k > mb.meta[cw].n_uniq) continue;
         const unsigned vd = scr_void[cw];
-        if (((vd >> k) & 1u) || (vd & 1u)) continue;
+        if (((vd >> k) & 1u) || (vd & 1u) || ((mb.ident[cw] >> k) & 1u)) continue;
         const long long* part = mb.part + (size_t)cw * P_STRIDE;
         const double exact = ig_acc_to_double(part[P_NZ + 2 * k] - part[P_NZ], part[P_NZ + 2 * k + 1] - part[P_NZ + 1]);
         const ScreenSum a = scr[cw * NSLOT + k], b = scr[cw * NSLOT];
         const double D = (double)(a.s_fix - b.s_fix) * (1.0 / SCR_FIX);
         const double Bd = (double)(a.b_fix + b.b_fix) * (1.0 / SCR_FIX);
+        if ((scr_ub[cw] >> k) & 1u) { /* upper bound only */
+            if (!(exact <= D + Bd)) g->error = 7;
+            continue;
+        }
         const double err = __builtin_fabs(D - exact);
         if (!(err <= Bd)) g->error = 7;
         if (worst && Bd > 0) { /* largest used fraction of a bound, largest bound (diagnostics; races are harmless) */
