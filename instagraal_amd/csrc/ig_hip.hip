@@ -902,11 +902,15 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
             {
                 TimedLaunch t(c, T_SLICE);
                 hipLaunchKernelGGL(k_offsets, dim3(1), dim3(OFFSETS_THREADS), 0, c->stream, c->mb, W, w_begin, w_end);
+                /* a wave walks a row (a workgroup 4 rows at a time).  Measured at cfg3 (us per launch of 24 slots): 32 workgroups per
+                 * candidate 193, 64: 156, 96: 148, 128: 136, 256 with the chunks of a row dealt to several waves: 146 */
+                static const int s_rb = getenv("IG_SLICE_RB") ? atoi(getenv("IG_SLICE_RB")) : 0;
+                const int rb = s_rb > 0 ? s_rb : SLICE_RB;
                 if (c->mb.packed)
-                    hipLaunchKernelGGL(k_slice<true>, dim3(SLICE_RB, max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob,
+                    hipLaunchKernelGGL(k_slice<true>, dim3(rb, max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob,
                                        c->mb, c->rank, c->world, w_begin);
                 else
-                    hipLaunchKernelGGL(k_slice<false>, dim3(SLICE_RB, max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob,
+                    hipLaunchKernelGGL(k_slice<false>, dim3(rb, max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob,
                                        c->mb, c->rank, c->world, w_begin);
             }
             if (phase == 2) { /* the Q5 tail walk only needs the slice: second stream, next to k_score_list */

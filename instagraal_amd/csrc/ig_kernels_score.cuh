@@ -300,6 +300,7 @@ __device__ __forceinline__ void mutate_one(const State& st, const Tables& tab, c
             col[ls] = v;
             if (k == 0) {
                 subs[ls] = s;
+                mb.rowcnt[(size_t)cw * M + ls] = 0; /* k_slice adds the kept contacts of the row (several waves per row) */
                 /* upper bound of the slice segment this row appends to */
                 atomicAdd((unsigned long long*)&seg_bound[ls % SLICE_SEG], (unsigned long long)(rowptr[s + 1] - rowptr[s]));
             }
@@ -424,7 +425,9 @@ __global__ void __launch_bounds__(OFFSETS_THREADS) k_offsets(MoveBuf mb, int W, 
  * 8-byte loads, then one packed (contig, rank) gather each), the predicate is evaluated, and the kept ones
  * are appended to the candidate's list with ONE wave-aggregated atomic per batch (ballot + popcount ranks).
  * No sort afterwards: the reference sorted by row only to feed its shared-memory row cache (CL:1045-1050). */
-#define SLICE_RB 128
+#ifndef SLICE_RB
+#define SLICE_RB 128 /* workgroups (of 4 rows at a time) per candidate when nothing is known about the window sizes yet */
+#endif
 #define SLICE_UNROLL 4
 template <bool PACKED>
 __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
@@ -443,8 +446,12 @@ __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ row
     if (seg_off[0] < 0) return; /* slice pool exhausted (k_offsets flags all segments of a slot together) */
     const int* subs = mb.subs + (size_t)cw * M;
     int* rowcnt = mb.rowcnt + (size_t)cw * M;
+    /* work items = (row, j): wave j of a row takes the row's contact chunks j, j + J, ... (J waves per row: a row of thousands
+     * of contacts is a chain of dependent round trips per chunk, and the launch waits for the longest chain) */
     const int nrw = gridDim.x * 4;
-    for (int r = blockIdx.x * 4 + wv; r < m_loc; r += nrw) {
+    const int J = max(1, nrw / max(m_loc, 1));
+    for (int item = blockIdx.x * 4 + wv; item < m_loc * J; item += nrw) {
+        const int r = item % m_loc, j = item / m_loc;
         const long long off = seg_off[r % SLICE_SEG];
         int* sli = PACKED ? nullptr : mb.sl_li + off;
         int* slj = PACKED ? nullptr : mb.sl_lj + off;
@@ -457,7 +464,7 @@ __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ row
         int rc = 0;
         if (b != e) {
             const int2 cp1 = tab.cp[i];
-            for (long long q0 = b; q0 < e; q0 += 64 * SLICE_UNROLL) {
+            for (long long q0 = b + (long long)j * 64 * SLICE_UNROLL; q0 < e; q0 += (long long)J * 64 * SLICE_UNROLL) {
                 int2 v[SLICE_UNROLL], cp2[SLICE_UNROLL];
                 bool keep[SLICE_UNROLL];
                 unsigned long long mask[SLICE_UNROLL];
@@ -501,7 +508,7 @@ __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ row
                 }
             }
         }
-        if (lane == 0) rowcnt[r] = rc; /* every rank knows every row's count: the tail walk needs them */
+        if (lane == 0 && rc) atomicAdd(&rowcnt[r], rc); /* every rank knows every row's count: the tail walk needs them */
     }
 }
 
