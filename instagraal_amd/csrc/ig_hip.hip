@@ -930,7 +930,7 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
             if (screen) {
                 {
                     TimedLaunch t(c, T_SCREEN);
-                    hipLaunchKernelGGL(k_screen, dim3(SLICE_SEG, NSLOT, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->screen_const, c->mb,
+                    hipLaunchKernelGGL(k_screen, dim3(SLICE_SEG, (NSLOT + 1) / 2, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->screen_const, c->mb,
                                        c->mb.scr, c->mb.scr_void, c->mb.scr_ub, max_c, w_begin);
                 }
                 hipMemsetAsync(c->mb.work, 0, 16 * sizeof(unsigned long long), c->stream);

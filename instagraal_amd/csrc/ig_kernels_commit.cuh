@@ -339,9 +339,9 @@ __global__ void __launch_bounds__(64)
             }
             n_dirty += 2;
         }
-        /* Everything a decision reads is loaded ONE MOVE AHEAD (none of it depends on earlier decisions, only its
-         * interpretation does): while move w is decided from registers with wave shuffles only, the loads of move w + 1
-         * are in flight.  Moves with more than 5 candidates (> 2 score records per lane) take the unpipelined path. */
+        /* Everything a decision reads is loaded TWO MOVES AHEAD (none of it depends on earlier decisions, only its
+         * interpretation does): while move w is decided from registers with wave shuffles only, the loads of moves
+         * w + 1 and w + 2 are in flight.  Moves with more than 5 candidates (> 2 score records per lane) take the unpipelined path. */
         struct MoveData {
             int C, superset0;       /* uniform */
             CandPre cand;           /* lane c < C: candidate c */
@@ -384,10 +384,13 @@ __global__ void __launch_bounds__(64)
             return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
         };
         auto rld = [&](double v, int src) { return __longlong_as_double(rl64(__double_as_longlong(v), src)); };
+        /* two moves ahead: a decision takes about half a global-memory round trip */
         MoveData cur = load_move(w_start < W ? w_start : W - 1);
+        MoveData nxt = load_move(w_start + 1 < W ? w_start + 1 : W - 1);
         for (int w = w_start; w < W; w++) {
             const MoveData d = cur;
-            if (w + 1 < W) cur = load_move(w + 1);
+            cur = nxt;
+            if (w + 2 < W) nxt = load_move(w + 2);
             const int C = d.C;
             /* conflict with an earlier move of this batch?  slice pool overflow? */
             bool hitd = false;

@@ -22,7 +22,9 @@
  * against the contract's  ob * yy * log10(2) - ex + pzc  (- log10(ob!), which is the same in every column of a candidate
  * and drops out of the score differences).  Propagating the roundings with K_L = K_E = 4:
  *     |t - exact| <= u { ob (4 |yy| + 2.72 Cy) + ex (6.3 |yy| + 6.3 Cy + 10.1) + 3.1 pzc } + 2^-32,
- *     Cy = |log2 amp| + |slope| + |log2 v_inter|.
+ *     Cy = |log2 amp| + |slope| + |log2 v_inter|;
+ * two terms are added in float before they join the double sum (one more rounding, u (|t0| + |t1|)): the coefficients used
+ * are 4.4, 11.2 and 4.2.
  * A workgroup accumulates sum(t) in double, sum(ob), sum(ex) and max |yy| and publishes its partial sum and bound as
  * integers (units of 2^-20: integer atomics, deterministic totals). */
 #pragma once
@@ -103,7 +105,7 @@ struct alignas(16) ScreenLds {
 };
 
 /* one screened term; MASKED: the lane's entry may lie past the end of the list (last, partly filled step) */
-template <bool STAGED, bool HAS_CUT, bool MASKED, bool CIRC = false>
+template <bool STAGED, bool HAS_CUT, bool MASKED, bool CIRC = false, bool QUAD = false>
 __device__ __forceinline__ void screen_term(unsigned long long pk, bool live, const uint2* gcol, const ScreenLds& L, float slope, float la,
                                             float lv, float d_max, float c10, unsigned cut, double& acc, float& exs, float& obs, float& ymax,
                                             unsigned& bad, unsigned circ_mask = 0, float zc_ub = 0.0f)
@@ -115,8 +117,9 @@ __device__ __forceinline__ void screen_term(unsigned long long pk, bool live, co
     const uint2 bj = STAGED ? L.col[lj] : gcol[lj];
     /* packed lists: ranks below 2^20, the contig code in bits 28..30 -- for two different codes the difference of the
      * words is at least 2^28 - 2^20: "same contig" is d < 2^27, and min(d, LDS_PZ) lands on the trans level by itself */
-    const unsigned d = abs_diff_u32(ai.y, bj.y);
-    const bool cis = d < (1u << 27);
+    const unsigned dq = abs_diff_u32(ai.y, bj.y);
+    const bool cis = dq < (1u << 27);
+    const unsigned d = QUAD ? dq >> 2 : dq; /* QUAD: the staged column holds 4 x rank (screen_pair); across contigs d stays >= LDS_PZ */
     const float sv = fabsf(__uint_as_float(ai.x) - __uint_as_float(bj.x));
     const bool in = cis && (sv > 0.0f) && (sv < d_max);
     const float pzc = L.pzc[min(d, (unsigned)LDS_PZ)];
@@ -153,10 +156,46 @@ __device__ __forceinline__ void screen_term(unsigned long long pk, bool live, co
     if (HAS_CUT) bad |= (cis && d >= cut && (!MASKED || live)) ? 0x80000000u : 0u; /* counts are below 2^24: bit 31 is free */
 }
 
+/* two screened terms at once, for the common case (column staged in LDS, no ring on the window, P_z table inside its LDS
+ * copy, full step): the same term as screen_term, with the arithmetic on PAIRS (v_pk_add / v_pk_fma / v_pk_mul_f32: one
+ * instruction for both lanes' two terms).  The staged column holds the rank pre-multiplied by 4 (k_screen), so the byte
+ * offset into the P_z table is min(|4 rank_i - 4 rank_j|, 4 LDS_PZ) without a shift; the two terms are added in float before
+ * they join the double sum (one more rounding of the pair: in the bound's coefficients). */
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void screen_pair(unsigned long long pk0, unsigned long long pk1, const ScreenLds& L, float slope, float la, float lv,
+                                            float d_max, float c10, double& acc, f32x2& exs2, f32x2& obs2, float& ymax, unsigned& bad)
+{
+    const unsigned lo0 = (unsigned)pk0, hi0 = (unsigned)(pk0 >> 32), lo1 = (unsigned)pk1, hi1 = (unsigned)(pk1 >> 32);
+    bad |= hi0 | hi1;
+    const char* colb = (const char*)L.col;
+    const uint2 a0 = *(const uint2*)(colb + ((lo0 << 3) & 0x7ffff8u)), b0 = *(const uint2*)(colb + (__builtin_amdgcn_alignbit(hi0, lo0, 17) & 0x7ffff8u));
+    const uint2 a1 = *(const uint2*)(colb + ((lo1 << 3) & 0x7ffff8u)), b1 = *(const uint2*)(colb + (__builtin_amdgcn_alignbit(hi1, lo1, 17) & 0x7ffff8u));
+    const unsigned d0 = abs_diff_u32(a0.y, b0.y), d1 = abs_diff_u32(a1.y, b1.y); /* 4 x rank distance, or >= 2^28 - 2^22 across contigs */
+    const f32x2 sv = f32x2{__uint_as_float(a0.x), __uint_as_float(a1.x)} - f32x2{__uint_as_float(b0.x), __uint_as_float(b1.x)};
+    const bool in0 = (d0 < (1u << 27)) && (sv.x != 0.0f) && (fabsf(sv.x) < d_max);
+    const bool in1 = (d1 < (1u << 27)) && (sv.y != 0.0f) && (fabsf(sv.y) < d_max);
+    const char* pzb = (const char*)L.pzc;
+    const f32x2 pzc = {*(const float*)(pzb + min(d0, 4u * LDS_PZ)), *(const float*)(pzb + min(d1, 4u * LDS_PZ))};
+    const f32x2 lg2 = {__builtin_amdgcn_logf(fabsf(sv.x)), __builtin_amdgcn_logf(fabsf(sv.y))};
+    const f32x2 y = __builtin_elementwise_fma(f32x2{slope, slope}, lg2, f32x2{la, la});
+    float m0, m1;
+    __asm__("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(y.x), "v"(lv)); /* y is a number wherever it is used */
+    __asm__("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(y.y), "v"(lv));
+    const f32x2 yy = {in0 ? m0 : lv, in1 ? m1 : lv};
+    const f32x2 ex = {__builtin_amdgcn_exp2f(yy.x), __builtin_amdgcn_exp2f(yy.y)};
+    const f32x2 obf = {(float)(hi0 >> 8), (float)(hi1 >> 8)};
+    const f32x2 m = obf * yy;
+    const f32x2 t = __builtin_elementwise_fma(m, f32x2{c10, c10}, -ex) + pzc;
+    acc += (double)(t.x + t.y);
+    exs2 += ex;
+    obs2 += obf;
+    __asm__("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(ymax) : "v"(yy.x), "v"(yy.y));
+}
+
 /* a wave streams steps of 64 x SCREEN_BATCH consecutive entries (steps wave, wave + 4, ...); the entries of the next step
  * are loaded before this step's terms.  The lists live in a pool with slack behind its last entry (ensure_move_buffers):
  * the look-ahead loads need no clamping; only the last, partly filled step of a wave masks its lanes. */
-template <bool STAGED, bool HAS_CUT, bool CIRC = false>
+template <bool STAGED, bool HAS_CUT, bool CIRC = false, bool PAIRS = false, bool QUAD = PAIRS>
 __device__ __forceinline__ void screen_loop(const unsigned long long* __restrict__ slp, unsigned n, const uint2* gcol, const ScreenLds& L,
                                             float slope, float la_s, float lv_s, float d_max, unsigned cut, double& acc, float& exs, float& obs,
                                             float& ymax, unsigned& bad, unsigned circ_mask = 0, float zc_ub = 0.0f)
@@ -171,6 +210,7 @@ __device__ __forceinline__ void screen_loop(const unsigned long long* __restrict
     unsigned long long nx[SCREEN_BATCH];
 #pragma unroll
     for (int u = 0; u < SCREEN_BATCH; u++) nx[u] = ptr[u * 64];
+    f32x2 exs2 = {0.0f, 0.0f}, obs2 = {0.0f, 0.0f};
     unsigned s0 = wave * step; /* first entry of the wave's current step */
     for (; s0 + step <= n; s0 += stride) { /* full steps */
         unsigned long long pk[SCREEN_BATCH];
@@ -179,29 +219,36 @@ __device__ __forceinline__ void screen_loop(const unsigned long long* __restrict
         ptr += stride;
 #pragma unroll
         for (int u = 0; u < SCREEN_BATCH; u++) nx[u] = ptr[u * 64];
+        if (PAIRS) {
 #pragma unroll
-        for (int u = 0; u < SCREEN_BATCH; u++)
-            screen_term<STAGED, HAS_CUT, false, CIRC>(pk[u], true, gcol, L, slope, la, lv, d_max, c10, cut, acc, exs, obs, ymax, bad, circ_mask, zc_ub);
+            for (int u = 0; u < SCREEN_BATCH; u += 2) screen_pair(pk[u], pk[u + 1], L, slope, la, lv, d_max, c10, acc, exs2, obs2, ymax, bad);
+        } else {
+#pragma unroll
+            for (int u = 0; u < SCREEN_BATCH; u++)
+                screen_term<STAGED, HAS_CUT, false, CIRC, QUAD>(pk[u], true, gcol, L, slope, la, lv, d_max, c10, cut, acc, exs, obs, ymax, bad, circ_mask,
+                                                                  zc_ub);
+        }
+    }
+    if (PAIRS) {
+        exs += exs2.x + exs2.y;
+        obs += obs2.x + obs2.y;
     }
     if (s0 < n) { /* the partly filled step */
         const unsigned long long safe = slp[0];
 #pragma unroll
         for (int u = 0; u < SCREEN_BATCH; u++) {
             const bool live = s0 + u * 64 + lane < n;
-            screen_term<STAGED, HAS_CUT, true, CIRC>(live ? nx[u] : safe, live, gcol, L, slope, la, lv, d_max, c10, cut, acc, exs, obs, ymax, bad, circ_mask,
-                                                     zc_ub);
+            screen_term<STAGED, HAS_CUT, true, CIRC, QUAD>(live ? nx[u] : safe, live, gcol, L, slope, la, lv, d_max, c10, cut, acc, exs, obs, ymax, bad,
+                                                            circ_mask, zc_ub);
         }
     }
 }
 
-/* k_screen: one workgroup = (segment of the slice list, column k, candidate cw), as k_score_list */
-__global__ void __launch_bounds__(SCORE_THREADS)
-    k_screen(const ScreenConst* __restrict__ sc, MoveBuf mb, ScreenSum* __restrict__ scr, unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub,
-             int max_c, int w_begin)
+/* one column k of candidate (w, c) over segment blockIdx.x of its slice list: stage, stream, publish sum and bound.  Called by
+ * every thread of the workgroup (barriers inside). */
+__device__ __forceinline__ void screen_column(ScreenLds& L, const ScreenConst* __restrict__ sc, const MoveBuf& mb, ScreenSum* __restrict__ scr,
+                                              unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub, int w, int c, int k)
 {
-    __shared__ ScreenLds L;
-    const int w = w_begin + blockIdx.z / max_c, c = blockIdx.z % max_c;
-    const int k = blockIdx.y;
     const int cw = CW(w, c);
     const int C = mb.ctl[w].C;
     const int n_uniq = mb.meta[cw].n_uniq, m_loc = mb.meta[cw].m_loc;
@@ -220,9 +267,17 @@ __global__ void __launch_bounds__(SCORE_THREADS)
         for (int i = threadIdx.x; i < (LDS_PZ + 2) / 4; i += SCORE_THREADS) dst[i] = src[i];
         if (threadIdx.x < (LDS_PZ + 2) % 4) L.pzc[(LDS_PZ + 2) / 4 * 4 + threadIdx.x] = sc->pzc[(LDS_PZ + 2) / 4 * 4 + threadIdx.x];
     }
-    if (staged)
-        for (int i = threadIdx.x; i < m_loc; i += SCORE_THREADS) L.col[i] = gcol[i];
     if (threadIdx.x < NCODE) L.cm[threadIdx.x] = mb.cmeta[(size_t)(cw * NSLOT + k) * NCODE + threadIdx.x];
+    /* the common case -- staged column, P_z table inside its LDS copy -- takes the two-terms-at-a-time loop (screen_pair),
+     * which wants the ranks of the staged column pre-multiplied by 4 (ranks are below 2^20 in packed lists: no overlap with
+     * the contig code in bits 28..30) */
+    const bool pairs = staged && pz_n <= LDS_PZ;
+    if (staged)
+        for (int i = threadIdx.x; i < m_loc; i += SCORE_THREADS) {
+            uint2 v = gcol[i];
+            if (pairs) v.y = (v.y & 0xf0000000u) | ((v.y & 0x0fffffffu) << 2);
+            L.col[i] = v;
+        }
     __syncthreads();
     unsigned circ_mask = 0;
 #pragma unroll
@@ -242,8 +297,11 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     const unsigned cut = pz_n > LDS_PZ ? (unsigned)LDS_PZ : 0xffffffffu;
     const unsigned long long* slp = mb.sl_pk + off;
     if (circ_mask) {
-        if (staged) screen_loop<true, true, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad, circ_mask, zc_ub);
+        if (pairs) screen_loop<true, true, true, false, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad, circ_mask, zc_ub);
+        else if (staged) screen_loop<true, true, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad, circ_mask, zc_ub);
         else screen_loop<false, true, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad, circ_mask, zc_ub);
+    } else if (pairs) {
+        screen_loop<true, false, false, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
     } else if (pz_n > LDS_PZ) { /* a P_z table longer than its LDS copy: pairs beyond the copy void the column's bound */
         if (staged) screen_loop<true, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
         else screen_loop<false, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
@@ -281,8 +339,8 @@ __global__ void __launch_bounds__(SCORE_THREADS)
         /* the bound of the header; sum(ob) and sum(ex) were accumulated in float by n / 256 additions per lane + the
          * reduction (relative error below (n / 256 + 16) 2u), everything left out is covered by 1 % */
         const double fa = 1.0 + 2.0 * u * ((double)n / SCORE_THREADS + 16.0) * 2.0;
-        const double bound = 1.01 * (u * fa * (O * (4.0 * Y + 2.72 * (double)cy) + E * (6.3 * Y + 6.3 * (double)cy + 10.1)) +
-                                     (double)n * (3.1 * u * (double)pzc_max + 0x1p-32));
+        const double bound = 1.01 * (u * fa * (O * (4.4 * Y + 2.72 * (double)cy) + E * (6.3 * Y + 6.3 * (double)cy + 11.2)) +
+                                     (double)n * (4.2 * u * (double)pzc_max + 0x1p-32));
         /* The contract clamps a term to |t| < 2^20 before it is quantised (ig_quantize); the screening term does not, and it
          * leaves log10(ob!) out.  Counts below 2^14 and |yy| <= 18 (P below 2^18) keep every exact term inside the clamp:
          * |t| <= 2^14 18 log10(2) + 2^18 + log10(2^14 !) + pzc < 2^20.  Beyond: the column's bound is void. */
@@ -294,6 +352,215 @@ __global__ void __launch_bounds__(SCORE_THREADS)
             atomic_add_ll(&scr[cw * NSLOT + k].s_fix, (long long)__builtin_rint(S * SCR_FIX));
             atomic_add_ll(&scr[cw * NSLOT + k].b_fix, (long long)__builtin_ceil(bound * SCR_FIX) + 2); /* + the rounding of s_fix */
         }
+    }
+}
+
+/* k_screen: one workgroup = (segment of the slice list, TWO columns 2g and 2g + 1, candidate cw).  k_screen's traffic is the
+ * lists, re-read from L2 once per column (1.7 GB per launch at the headline shape: the L2 delivers little more): two plain
+ * columns -- staged, no ring, P_z table inside its LDS copy -- share one pass over the entries (screen_pair2: one unpack,
+ * two columns' terms); anything else takes the one-column routine, column by column. */
+struct alignas(16) ScreenLds2 {
+    ScreenLds one;            /* the one-column routine's block; its pzc table and col[] serve the pair loop as column A */
+    uint2 colB[LDS_COL_SMALL]; /* column B of the pair loop */
+    double red_s2[SCORE_THREADS / 64];
+    float red_e2[SCORE_THREADS / 64], red_y2[SCORE_THREADS / 64];
+};
+/* the arithmetic of screen_pair on precomputed LDS byte offsets (o = 8 x local index) for one column */
+__device__ __forceinline__ void screen_pair_col(unsigned oi0, unsigned oj0, unsigned oi1, unsigned oj1, f32x2 obf, const char* colb, const char* pzb,
+                                                float slope, float la, float lv, float d_max, float c10, double& acc, f32x2& exs2, float& ymax)
+{
+    const uint2 a0 = *(const uint2*)(colb + oi0), b0 = *(const uint2*)(colb + oj0);
+    const uint2 a1 = *(const uint2*)(colb + oi1), b1 = *(const uint2*)(colb + oj1);
+    const unsigned d0 = abs_diff_u32(a0.y, b0.y), d1 = abs_diff_u32(a1.y, b1.y);
+    const f32x2 sv = f32x2{__uint_as_float(a0.x), __uint_as_float(a1.x)} - f32x2{__uint_as_float(b0.x), __uint_as_float(b1.x)};
+    const bool in0 = (d0 < (1u << 27)) && (sv.x != 0.0f) && (fabsf(sv.x) < d_max);
+    const bool in1 = (d1 < (1u << 27)) && (sv.y != 0.0f) && (fabsf(sv.y) < d_max);
+    const f32x2 pzc = {*(const float*)(pzb + min(d0, 4u * LDS_PZ)), *(const float*)(pzb + min(d1, 4u * LDS_PZ))};
+    const f32x2 lg2 = {__builtin_amdgcn_logf(fabsf(sv.x)), __builtin_amdgcn_logf(fabsf(sv.y))};
+    const f32x2 y = __builtin_elementwise_fma(f32x2{slope, slope}, lg2, f32x2{la, la});
+    float m0, m1;
+    __asm__("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(y.x), "v"(lv));
+    __asm__("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(y.y), "v"(lv));
+    const f32x2 yy = {in0 ? m0 : lv, in1 ? m1 : lv};
+    const f32x2 ex = {__builtin_amdgcn_exp2f(yy.x), __builtin_amdgcn_exp2f(yy.y)};
+    const f32x2 m = obf * yy;
+    const f32x2 t = __builtin_elementwise_fma(m, f32x2{c10, c10}, -ex) + pzc;
+    acc += (double)(t.x + t.y);
+    exs2 += ex;
+    __asm__("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(ymax) : "v"(yy.x), "v"(yy.y));
+}
+/* publish one column's sum and bound (thread 0 of the workgroup, after the reduction) */
+__device__ __forceinline__ void screen_publish(const ScreenConst* __restrict__ sc, ScreenSum* __restrict__ scr, unsigned* __restrict__ scr_void,
+                                               int cw, int k, long long n, double S, double E, double O, double Y, unsigned B)
+{
+    const double u = 0x1p-24, cy = sc->cy, pzc_max = sc->pzc_max;
+    const double fa = 1.0 + 2.0 * u * ((double)n / SCORE_THREADS + 16.0) * 2.0;
+    const double bound = 1.01 * (u * fa * (O * (4.4 * Y + 2.72 * cy) + E * (6.3 * Y + 6.3 * cy + 11.2)) + (double)n * (4.2 * u * pzc_max + 0x1p-32));
+    const bool in_clamp = ((B & 0x7fffffffu) >> 8) < (1u << 14) && Y <= 18.0 && pzc_max < 1e5;
+    const bool ok = !(B & 0x80000000u) && in_clamp && (__builtin_fabs(S) < 1e15) && (bound < 1e12);
+    if (!ok) {
+        atomicOr(&scr_void[cw], 1u << k);
+    } else {
+        atomic_add_ll(&scr[cw * NSLOT + k].s_fix, (long long)__builtin_rint(S * SCR_FIX));
+        atomic_add_ll(&scr[cw * NSLOT + k].b_fix, (long long)__builtin_ceil(bound * SCR_FIX) + 2);
+    }
+}
+__global__ void __launch_bounds__(SCORE_THREADS)
+    k_screen(const ScreenConst* __restrict__ sc, MoveBuf mb, ScreenSum* __restrict__ scr, unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub,
+             int max_c, int w_begin)
+{
+    __shared__ ScreenLds2 L2;
+    ScreenLds& L = L2.one;
+    const int w = w_begin + blockIdx.z / max_c, c = blockIdx.z % max_c;
+    const int kA = 2 * blockIdx.y, kB = kA + 1;
+    const int cw = CW(w, c);
+    const int C = mb.ctl[w].C;
+    const int n_uniq = mb.meta[cw].n_uniq, m_loc = mb.meta[cw].m_loc;
+    const long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + blockIdx.x];
+    const long long off = mb.sloff[(size_t)cw * SLICE_SEG + blockIdx.x];
+    if (c >= C || kA > n_uniq || n == 0 || off < 0) return;
+    /* which of the two columns there is anything to do for (a column whose genome is the current one has column 0's sums) */
+    const bool doA = kA == 0 || mb.sinfo[cw * NSLOT + mb.meta[cw].uniq[kA - 1]].x != 0;
+    const bool doB = kB <= n_uniq && mb.sinfo[cw * NSLOT + mb.meta[cw].uniq[kB - 1]].x != 0;
+    const int pz_n = sc->pz_n;
+    bool plain = doA && doB && sc->fast && m_loc <= LDS_COL_SMALL && pz_n <= LDS_PZ;
+    if (plain) { /* no ring on either window */
+        const ColMeta* cmA = mb.cmeta + (size_t)(cw * NSLOT + kA) * NCODE;
+        const ColMeta* cmB = mb.cmeta + (size_t)(cw * NSLOT + kB) * NCODE;
+        for (int q = 0; q < NCODE; q++) plain &= (cmA[q].stot == 0) && (cmB[q].stot == 0);
+    }
+    if (!plain) {
+        if (doA) screen_column(L, sc, mb, scr, scr_void, scr_ub, w, c, kA);
+        if (doA && doB) __syncthreads(); /* the second column restages the LDS */
+        if (doB) screen_column(L, sc, mb, scr, scr_void, scr_ub, w, c, kB);
+        return;
+    }
+    const float slope = sc->slope, la_s = sc->la, lv_s = sc->lv, d_max = sc->d_max;
+    {
+        const float4* src = (const float4*)sc->pzc;
+        float4* dst = (float4*)L.pzc;
+        for (int i = threadIdx.x; i < (LDS_PZ + 2) / 4; i += SCORE_THREADS) dst[i] = src[i];
+        if (threadIdx.x < (LDS_PZ + 2) % 4) L.pzc[(LDS_PZ + 2) / 4 * 4 + threadIdx.x] = sc->pzc[(LDS_PZ + 2) / 4 * 4 + threadIdx.x];
+    }
+    {
+        const uint2* gA = mb.coords + (size_t)(cw * NSLOT + kA) * mb.M;
+        const uint2* gB = mb.coords + (size_t)(cw * NSLOT + kB) * mb.M;
+        for (int i = threadIdx.x; i < m_loc; i += SCORE_THREADS) { /* ranks x 4, see screen_pair */
+            uint2 va = gA[i], vb = gB[i];
+            va.y = (va.y & 0xf0000000u) | ((va.y & 0x0fffffffu) << 2);
+            vb.y = (vb.y & 0xf0000000u) | ((vb.y & 0x0fffffffu) << 2);
+            L.col[i] = va;
+            L2.colB[i] = vb;
+        }
+    }
+    __syncthreads();
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned step = 64 * SCREEN_BATCH, stride = step * (SCORE_THREADS / 64);
+    const float c10 = (float)IG_LOG2_10_INV;
+    float la, lv;
+    __asm__ volatile("v_mov_b32 %0, %1" : "=v"(la) : "s"(la_s));
+    __asm__ volatile("v_mov_b32 %0, %1" : "=v"(lv) : "s"(lv_s));
+    const unsigned long long* slp = mb.sl_pk + off;
+    const unsigned long long* ptr = slp + wave * step + lane;
+    const char* colA = (const char*)L.col;
+    const char* colBb = (const char*)L2.colB;
+    const char* pzb = (const char*)L.pzc;
+    double accA = 0.0, accB = 0.0;
+    f32x2 exsA = {0.0f, 0.0f}, exsB = {0.0f, 0.0f}, obs2 = {0.0f, 0.0f};
+    float ymaxA = 0.0f, ymaxB = 0.0f;
+    unsigned bad = 0;
+    unsigned long long nx[SCREEN_BATCH];
+#pragma unroll
+    for (int u = 0; u < SCREEN_BATCH; u++) nx[u] = ptr[u * 64];
+    unsigned s0 = wave * step;
+    const unsigned nn = (unsigned)n;
+    for (; s0 + step <= nn; s0 += stride) { /* full steps: both columns from one pass over the entries */
+        unsigned long long pk[SCREEN_BATCH];
+#pragma unroll
+        for (int u = 0; u < SCREEN_BATCH; u++) pk[u] = nx[u];
+        ptr += stride;
+#pragma unroll
+        for (int u = 0; u < SCREEN_BATCH; u++) nx[u] = ptr[u * 64];
+#pragma unroll
+        for (int u = 0; u < SCREEN_BATCH; u += 2) {
+            const unsigned lo0 = (unsigned)pk[u], hi0 = (unsigned)(pk[u] >> 32), lo1 = (unsigned)pk[u + 1], hi1 = (unsigned)(pk[u + 1] >> 32);
+            bad |= hi0 | hi1;
+            const unsigned oi0 = (lo0 << 3) & 0x7ffff8u, oj0 = __builtin_amdgcn_alignbit(hi0, lo0, 17) & 0x7ffff8u;
+            const unsigned oi1 = (lo1 << 3) & 0x7ffff8u, oj1 = __builtin_amdgcn_alignbit(hi1, lo1, 17) & 0x7ffff8u;
+            const f32x2 obf = {(float)(hi0 >> 8), (float)(hi1 >> 8)};
+            obs2 += obf;
+            screen_pair_col(oi0, oj0, oi1, oj1, obf, colA, pzb, slope, la, lv, d_max, c10, accA, exsA, ymaxA);
+            screen_pair_col(oi0, oj0, oi1, oj1, obf, colBb, pzb, slope, la, lv, d_max, c10, accB, exsB, ymaxB);
+        }
+    }
+    float exA = exsA.x + exsA.y, exB = exsB.x + exsB.y, obs = obs2.x + obs2.y;
+    if (s0 < nn) { /* the partly filled step: one term at a time, masked */
+        const unsigned long long safe = slp[0];
+        float obs_dummy = 0.0f;
+        unsigned bad_dummy = 0;
+#pragma unroll
+        for (int u = 0; u < SCREEN_BATCH; u++) {
+            const bool live = s0 + u * 64 + lane < nn;
+            const unsigned long long e = live ? nx[u] : safe;
+            screen_term<true, false, true, false, true>(e, live, nullptr, L, slope, la, lv, d_max, c10, 0xffffffffu, accA, exA, obs, ymaxA, bad);
+            /* column B: the same routine on a view of the block whose col[] is column B */
+            {
+                const unsigned lo = (unsigned)e, hi = (unsigned)(e >> 32);
+                const unsigned oi = (lo << 3) & 0x7ffff8u, oj = __builtin_amdgcn_alignbit(hi, lo, 17) & 0x7ffff8u;
+                const uint2 ai = *(const uint2*)(colBb + oi), bj = *(const uint2*)(colBb + oj);
+                const unsigned dq = abs_diff_u32(ai.y, bj.y);
+                const bool cis = dq < (1u << 27);
+                const float sv = fabsf(__uint_as_float(ai.x) - __uint_as_float(bj.x));
+                const bool in = cis && (sv > 0.0f) && (sv < d_max);
+                const float pzc = *(const float*)(pzb + min(dq, 4u * LDS_PZ));
+                const float y = __builtin_fmaf(slope, __builtin_amdgcn_logf(sv), la);
+                float ymx;
+                __asm__("v_max_f32 %0, %1, %2" : "=v"(ymx) : "v"(y), "v"(lv));
+                const float yy = in ? ymx : lv;
+                const float ex = __builtin_amdgcn_exp2f(yy);
+                const float t = __builtin_fmaf((float)(hi >> 8) * yy, c10, -ex) + pzc;
+                accB += (double)(live ? t : 0.0f);
+                exB += live ? ex : 0.0f;
+                const float yya = live ? yy : 0.0f;
+                __asm__("v_max_f32 %0, %0, |%1|" : "+v"(ymaxB) : "v"(yya));
+            }
+            (void)obs_dummy;
+            (void)bad_dummy;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        accA += __shfl_down(accA, o, 64);
+        accB += __shfl_down(accB, o, 64);
+        exA += __shfl_down(exA, o, 64);
+        exB += __shfl_down(exB, o, 64);
+        obs += __shfl_down(obs, o, 64);
+        ymaxA = fmaxf(ymaxA, __shfl_down(ymaxA, o, 64));
+        ymaxB = fmaxf(ymaxB, __shfl_down(ymaxB, o, 64));
+        bad |= __shfl_down(bad, o, 64);
+    }
+    if (lane == 0) {
+        L.red_s[wave] = accA;
+        L.red_e[wave] = exA;
+        L.red_o[wave] = obs;
+        L.red_y[wave] = ymaxA;
+        L.red_bad[wave] = bad;
+        L2.red_s2[wave] = accB;
+        L2.red_e2[wave] = exB;
+        L2.red_y2[wave] = ymaxB;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const bool isB = threadIdx.x == 1;
+        double S = 0.0, E = 0.0, O = 0.0, Y = 0.0;
+        unsigned B = 0;
+        for (int v = 0; v < SCORE_THREADS / 64; v++) {
+            S += isB ? L2.red_s2[v] : L.red_s[v];
+            E += (double)(isB ? L2.red_e2[v] : L.red_e[v]);
+            O += (double)L.red_o[v];
+            Y = __builtin_fmax(Y, (double)(isB ? L2.red_y2[v] : L.red_y[v]));
+            B |= L.red_bad[v];
+        }
+        screen_publish(sc, scr, scr_void, cw, isB ? kB : kA, n, S, E, O, Y, B);
     }
 }
 
