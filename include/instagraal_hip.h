@@ -133,6 +133,7 @@ int ig_batch_commit(ig_ctx* ctx, int32_t move0, int32_t W, int32_t* n_committed)
 int ig_batch_results(ig_ctx* ctx, int32_t n_moves, ig_move_result* results);
 int ig_set_batch_width(int w);                        /* W in 1..64 (default 24, env IG_BATCH_W); 1 = no speculation */
 int ig_batch_stats(ig_ctx* ctx, int64_t out4[4]);     /* {batches, moves committed in-batch, one-move tails, predicted deltas used} */
+int ig_scratch_bytes(ig_ctx* ctx, int64_t out3[3]);   /* move buffers: {per-window arrays, slice pool, per-slot records and lists} */
 
 /* ---- a move and the nuisance step behind it, in flight together (instagraal.py:217-262 for cycles > 4: step_sampler, then
  * step_nuisance_parameters CL:2961-3051) ----------------------------------

@@ -88,6 +88,8 @@ struct Glob {
     double n_tot_pxl;
     double lgf[15];
     int n_contigs, next_cid, n_black, N, M;
+    int max_L, max_SL; /* upper bounds of the longest contig in fragments / sub-fragments (exact after a recount, raised by every
+                        * committed move that changed the genome: its window's total) */
     int n_prev_touched;
     int valid_insert[12];
     int error;
@@ -187,6 +189,10 @@ struct MoveBuf {
     unsigned long long* work;
     int work_cap;
     int N, M, capC, capW;
+    /* strides of the per-window arrays above (Lloc .. loc: sN fragments, subs / rowcnt / coords: sM sub-fragments): the
+     * largest window the genome can produce right now -- two contigs of the current maximum length, with headroom -- not
+     * the whole genome; the host grows them when the maximum grows (ensure_window_buffers) */
+    int sN, sM;
 };
 /* layout of MoveBuf.part per candidate (int64 units) */
 #define P_NZ 0                 /* [NSLOT][2] slice sums per column k (k=0: current = "extract") */
@@ -275,6 +281,9 @@ struct ig_ctx {
     int up_moves, up_max_c; /* the uploaded move lists */
     int own_begin, own_end; /* slots whose candidate genomes this handle built for the batch in flight */
     int own_screened;       /* the batch in flight was scored in two tiers (1), or verified (2) */
+    int max_L, max_SL;      /* host copies of Glob.max_L / max_SL as of the last synchronisation */
+    bool full_windows;      /* window strides = the whole genome (runs of moves enqueued one at a time without a host round trip) */
+    int* host_max;          /* pinned: {max_L, max_SL} copied back with every one-move call's result */
     int exact_grid;         /* two-tier scoring: blocks of the exact kernel's launch (follows what the last batches needed) */
     bool have_contacts, have_sub, have_state, have_init, have_params;
     bool init_links_inverse; /* initial prev / next are mutually inverse (k_commit_batch's de-duplication relies on it; else W = 1) */

@@ -150,6 +150,9 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->own_begin = c->own_end = 0;
     c->own_screened = 0;
     c->exact_grid = 0;
+    c->max_L = c->max_SL = 0;
+    c->full_windows = false;
+    c->host_max = nullptr;
     for (int i = 0; i < T_COUNT; i++) {
         c->timers[i].name = kTimerNames[i];
         c->timers[i].total_ms = 0;
@@ -195,7 +198,8 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     return 0;
 }
 
-static void free_move_buffers(ig_ctx* c)
+/* the per-window arrays of the move buffers (strides sN / sM) */
+static void free_window_buffers(ig_ctx* c)
 {
     MoveBuf& m = c->mb;
     hipFree(m.Lloc);
@@ -203,12 +207,29 @@ static void free_move_buffers(ig_ctx* c)
     hipFree(m.slloc);
     hipFree(m.subs);
     hipFree(m.rowcnt);
+    hipFree(m.coords);
+    hipFree(m.loc);
+    m.Lloc = m.lbloc = m.slloc = m.subs = m.rowcnt = nullptr;
+    m.coords = nullptr;
+    m.loc = nullptr;
+    m.sN = m.sM = 0;
+}
+static void free_slice_pool(ig_ctx* c)
+{
+    MoveBuf& m = c->mb;
     hipFree(m.sl_li);
     hipFree(m.sl_lj);
     hipFree(m.sl_ob);
     hipFree(m.sl_pk);
-    hipFree(m.coords);
-    hipFree(m.loc);
+    m.sl_li = m.sl_lj = m.sl_ob = nullptr;
+    m.sl_pk = nullptr;
+    m.pool_cap = 0;
+}
+static void free_move_buffers(ig_ctx* c)
+{
+    MoveBuf& m = c->mb;
+    free_window_buffers(c);
+    free_slice_pool(c);
     hipFree(m.meta);
     hipFree(m.cmeta);
     hipFree(m.part);
@@ -251,6 +272,7 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipEventDestroy(c->ev_slice);
     hipEventDestroy(c->ev_tail);
     if (c->host_bo) hipHostFree(c->host_bo);
+    if (c->host_max) hipHostFree(c->host_max);
     drain_timers(c);
     free_move_buffers(c);
     hipFree(c->st_block);
@@ -330,43 +352,86 @@ static void launch_full_nz(ig_ctx* c, const Tables& t, int which, long long* out
                        (long long)c->Z, pz.n, out);
 }
 
+/* The per-window arrays are strided by the largest window the genome can produce NOW: a window is the contig of the focal
+ * bin plus the contig of a candidate, so twice the longest contig (Glob.max_L / max_SL: exact after a recount, raised by
+ * every committed move that changed the genome by its window's total -- a batch can at most double it) with headroom,
+ * not the whole genome: 12 MB instead of 0.84 GB per slot at the headline shape.  Grown when the bound grows. */
+static int ensure_window_buffers(ig_ctx* c)
+{
+    MoveBuf& m = c->mb;
+    if (!m.capC || !m.capW) return 0;
+    const int need_n = std::min(c->N, std::max(2 * c->max_L, 1)), need_m = std::min(c->M, std::max(2 * c->max_SL, 1));
+    static const int s_env_full = getenv("IG_FULL_WINDOWS") ? atoi(getenv("IG_FULL_WINDOWS")) : 0; /* strides = the whole genome */
+    const bool s_full = s_env_full || c->full_windows;
+    if (m.Lloc && (s_full ? (m.sN == c->N && m.sM == c->M) : (m.sN >= need_n && m.sM >= need_m))) return 0;
+    const int sN = s_full ? c->N : std::min(c->N, std::max(256, need_n + need_n / 2));
+    const int sM = s_full ? c->M : std::min(c->M, std::max(768, need_m + need_m / 2));
+    HIPCK(hipStreamSynchronize(c->stream));
+    free_window_buffers(c);
+    const size_t C = (size_t)m.capC * m.capW;
+    DALLOC(m.Lloc, C * sN);
+    DALLOC(m.lbloc, C * sN);
+    DALLOC(m.slloc, C * sN);
+    DALLOC(m.subs, C * sM);
+    DALLOC(m.rowcnt, C * sM);
+    DALLOC(m.coords, C * sM * NSLOT);
+    DALLOC(m.loc, C * NSLOT * NDYN * sN);
+    m.sN = sN;
+    m.sM = sM;
+    return 0;
+}
+
+/* the slice pool: room for the lists of a batch.  A slot whose lists do not fit behind the earlier ones is re-run; when
+ * the FIRST slot of a batch does not fit, the host grows the pool (grow_slice_pool) and repeats the batch.  The worst case
+ * of one slot is capC x Z entries (windows = the whole genome); it starts at 2 Z. */
+static int alloc_slice_pool(ig_ctx* c, size_t entries)
+{
+    MoveBuf& m = c->mb;
+    free_slice_pool(c);
+    if (m.packed) {
+        DALLOC(m.sl_pk, entries + 8192); /* slack: k_screen's look-ahead loads run past the end of the last list */
+    } else {
+        DALLOC(m.sl_li, entries);
+        DALLOC(m.sl_lj, entries);
+        DALLOC(m.sl_ob, entries);
+    }
+    m.pool_cap = (long long)entries;
+    return 0;
+}
+static size_t slice_pool_max(const ig_ctx* c) { return (size_t)std::max<long long>(c->Z, 1) * (size_t)std::max(c->mb.capC, 1); }
+static int grow_slice_pool(ig_ctx* c)
+{
+    const size_t mx = slice_pool_max(c);
+    if ((size_t)c->mb.pool_cap >= mx) return fail("the slice pool already holds the worst case of a move (%zu entries) and the move does not fit", mx);
+    HIPCK(hipStreamSynchronize(c->stream));
+    return alloc_slice_pool(c, std::min(mx, (size_t)c->mb.pool_cap * 4));
+}
+
 static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
 {
     const int want_packed = (!(getenv("IG_WIDE_LISTS") && atoi(getenv("IG_WIDE_LISTS"))) && c->M < (1 << 20) && c->max_count < (1 << 24)) ? 1 : 0;
-    if (c->mb.capC >= capC && c->mb.capW >= capW && c->mb.N == c->N && c->mb.M == c->M && c->mb.packed == want_packed &&
-        c->mb.pool_cap >= (long long)std::max<long long>(c->Z, 1) * std::max(capC, 1))
-        return 0;
+    if (c->mb.capC >= capC && c->mb.capW >= capW && c->mb.N == c->N && c->mb.M == c->M && c->mb.packed == want_packed)
+        return ensure_window_buffers(c);
     if (c->N == 0 || c->M == 0) return 0;
     capC = std::max(capC, c->mb.capC);
     capW = std::max(capW, c->mb.capW);
+    HIPCK(hipStreamSynchronize(c->stream));
     free_move_buffers(c);
     MoveBuf& m = c->mb;
-    const size_t N = c->N, M = c->M, C = (size_t)capC * capW;
-    DALLOC(m.Lloc, C * N);
-    DALLOC(m.lbloc, C * N);
-    DALLOC(m.slloc, C * N);
-    DALLOC(m.subs, C * M);
-    DALLOC(m.rowcnt, C * M);
+    const size_t N = c->N, C = (size_t)capC * capW;
+    m.N = c->N;
+    m.M = c->M;
+    m.capC = capC;
+    m.capW = capW;
+    m.packed = want_packed; /* IG_WIDE_LISTS=1 (tests) forces the 12-byte form */
     {
-        /* one slot never needs more than capC x Z entries; a batch shares the pool and the slots that do not fit
-         * are re-run (MoveCtl.overflow) */
-        size_t Zc = (size_t)std::max<long long>(c->Z, 1) * (size_t)std::max(capC, capW > 1 ? 16 : 1);
-        if (const char* e = getenv("IG_POOL_ENTRIES")) /* tests: a small pool forces the overflow / re-run path */
-            Zc = std::max<size_t>((size_t)atoll(e), (size_t)std::max<long long>(c->Z, 1) * (size_t)capC);
-        m.packed = want_packed; /* IG_WIDE_LISTS=1 (tests) forces the 12-byte form */
-        if (m.packed) {
-            DALLOC(m.sl_pk, Zc + 8192); /* slack: k_screen's look-ahead loads run past the end of the last list */
-        } else {
-            DALLOC(m.sl_li, Zc);
-            DALLOC(m.sl_lj, Zc);
-            DALLOC(m.sl_ob, Zc);
-        }
-        m.pool_cap = (long long)Zc;
+        size_t Zc = std::min(slice_pool_max(c), std::max<size_t>((size_t)1 << 22, 2 * (size_t)std::max<long long>(c->Z, 1))); /* 32 MB, or 2 Z */
+        if (const char* e = getenv("IG_POOL_ENTRIES")) /* tests: a small pool forces the overflow / re-run / growth paths */
+            Zc = std::max<size_t>((size_t)atoll(e), 1024);
+        if (alloc_slice_pool(c, Zc)) return -1;
     }
     DALLOC(m.slbound, C * SLICE_SEG);
     DALLOC(m.sloff, C * SLICE_SEG);
-    DALLOC(m.coords, C * M * NSLOT);
-    DALLOC(m.loc, C * NSLOT * NDYN * N);
     DALLOC(m.meta, C);
     DALLOC(m.cmeta, C * NSLOT * NCODE);
     DALLOC(m.part, C * P_STRIDE);
@@ -388,14 +453,14 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
     DALLOC(c->own_tag, N);
     DALLOC(c->own_idx, N);
     HIPCK(hipMemset(c->own_tag, 0xff, N * sizeof(int)));
-    DALLOC(c->batch_out, 8);
+    DALLOC(c->batch_out, 12);
     if (!c->host_bo && !(getenv("IG_NO_HOST_FLAG") && atoi(getenv("IG_NO_HOST_FLAG")))) {
         /* the batch outcome is also written to mapped host memory (commit_loop polls it); without it: copy + synchronise */
         int* hp = nullptr;
-        if (hipHostMalloc((void**)&hp, 8 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+        if (hipHostMalloc((void**)&hp, 12 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
             void* dp = nullptr;
             if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
-                memset(hp, 0, 8 * sizeof(int));
+                memset(hp, 0, 12 * sizeof(int));
                 c->host_bo = hp;
                 c->host_bo_dev = (int*)dp;
             } else {
@@ -408,11 +473,7 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
     HIPCK(hipMemset(m.cmeta, 0, C * NSLOT * NCODE * sizeof(ColMeta)));
     HIPCK(hipMemset(m.slbound, 0, C * SLICE_SEG * sizeof(long long)));
     HIPCK(hipMemset(m.ctl, 0, (size_t)capW * sizeof(MoveCtl)));
-    m.N = c->N;
-    m.M = c->M;
-    m.capC = capC;
-    m.capW = capW;
-    return 0;
+    return ensure_window_buffers(c);
 }
 
 extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* col, const int32_t* cnt, int64_t Z, int32_t M,
@@ -631,7 +692,8 @@ static int launch_recompute(ig_ctx* c)
     long long* scratch = c->scratch8; /* persistent: an allocation per call costs more than the small kernels */
     HIPCK(hipMemsetAsync(scratch, 0, 8 * sizeof(long long), c->stream));
     int* heads = (int*)(scratch + 6);
-    hipLaunchKernelGGL(k_count_heads, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->st, N, heads);
+    HIPCK(hipMemsetAsync(&c->glob->max_L, 0, 2 * sizeof(int), c->stream)); /* max_L, max_SL: recounted */
+    hipLaunchKernelGGL(k_count_heads, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->st, N, heads, c->glob);
     HIPCK(hipMemsetAsync(&c->glob->credit2_acc, 0, sizeof(long long), c->stream));
     hipLaunchKernelGGL(k_post, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->st, c->init_prev, c->init_next, c->orientable,
                        c->black, c->glob, N);
@@ -652,6 +714,8 @@ static int launch_recompute(ig_ctx* c)
     hg.z_lo = h[3];
     hg.n_intra = h[4];
     hg.n_contigs = ((int*)&h[6])[0];
+    c->max_L = hg.max_L;
+    c->max_SL = hg.max_SL;
     hg.credit2 = hg.credit2_acc;
     hg.credit2_acc = 0;
     hg.n_prev_touched = 0;
@@ -870,6 +934,23 @@ static int check_ready(ig_ctx* c)
 
 static int g_tail_quirk = 1;
 
+/* one-move calls: the bound on the longest contig comes back with the result (the window strides follow it) */
+static int queue_max_readback(ig_ctx* c)
+{
+    if (!c->host_max) {
+        HIPCK(hipHostMalloc((void**)&c->host_max, 2 * sizeof(int), hipHostMallocDefault));
+        c->host_max[0] = c->host_max[1] = 0;
+    }
+    HIPCK(hipMemcpyAsync(c->host_max, &c->glob->max_L, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+static void take_max_readback(ig_ctx* c)
+{
+    if (!c->host_max) return;
+    c->max_L = std::max(c->max_L, c->host_max[0]);
+    c->max_SL = std::max(c->max_SL, c->host_max[1]);
+}
+
 /* enqueue the scoring launches of W move slots (moves move0 .. move0+W-1 of the uploaded lists);
  * phase 0 = up to k_score_list (the sums that are all-reduced when sharded), 1 = the rest, 2 = both */
 static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot, int phase, int w_begin = 0, int w_end = -1)
@@ -1052,7 +1133,7 @@ static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
                                c->mb, c->init_prev, c->init_next, c->orientable, c->black, c->own_tag, c->own_idx,
                                c->prev_touched, c->d_results, done, w_now, next, c->batch_out);
         }
-        int bo[8];
+        int bo[12];
         if (c->host_bo) {
             /* spin on the mapped copy k_decide_batch writes; every so often make sure the stream is still alive (a fault
              * must not hang the host) and fall back to the device copy when the stream has drained without the flag */
@@ -1069,7 +1150,7 @@ static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
             }
             if (got) {
                 std::atomic_thread_fence(std::memory_order_acquire);
-                for (int i = 0; i < 8; i++) bo[i] = hb[i];
+                for (int i = 0; i < 12; i++) bo[i] = hb[i];
             } else {
                 HIPCK(hipMemcpy(bo, c->batch_out, sizeof bo, hipMemcpyDeviceToHost));
             }
@@ -1081,6 +1162,13 @@ static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
         c->n_batch_committed += bo[0] - next;
         c->n_batch_predicted += bo[4];
         c->n_contigs_seen = bo[5];
+        c->max_L = std::max(c->max_L, bo[8]);
+        c->max_SL = std::max(c->max_SL, bo[9]);
+        if (bo[2] && next == 0 && bo[0] == 0 && bo[1] < 0) { /* the batch's first slot did not fit the slice pool (1) or the exact
+                                                               * kernel's grid (2): the caller enlarges it and repeats the batch */
+            *next_out = -bo[2];
+            return 0;
+        }
         if (c->own_screened == 1 && next == 0) /* first commit of this batch: size the exact kernel's next grid */
             c->exact_grid = std::min(c->mb.work_cap, std::max(4096, (int)(1.25 * bo[6]) + 2048));
         next = bo[0];
@@ -1103,11 +1191,11 @@ static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
 
 static int g_batch_w = -1; /* moves scored per launch in ig_step_batch: env IG_BATCH_W, default 24; 1 = one move at a time */
 
-/* the per-slot work buffers are sized for the worst case (a window = the whole genome): keep them under ~64 GB */
+/* the per-slot window buffers (strides: three times the longest contig, at most the genome): keep them under ~64 GB */
 static int max_batch_width(ig_ctx* c, int max_c)
 {
-    const double per_slot = (double)std::max(8, max_c) *
-                            ((double)NSLOT * NDYN * c->N * 4.0 + (double)c->M * NSLOT * 8.0 + 3.0 * c->N * 4.0 + 2.0 * c->M * 4.0);
+    const double sN = std::min<double>(c->N, std::max(256.0, 3.0 * c->max_L)), sM = std::min<double>(c->M, std::max(768.0, 3.0 * c->max_SL));
+    const double per_slot = (double)std::max(8, max_c) * ((double)NSLOT * NDYN * sN * 4.0 + sM * NSLOT * 8.0 + 3.0 * sN * 4.0 + 2.0 * sM * 4.0);
     const int fit = (int)std::max(1.0, 64e9 / std::max(per_slot, 1.0));
     return std::min(fit, IG_MAX_BATCH);
 }
@@ -1146,9 +1234,12 @@ static int upload_moves(ig_ctx* c, int n_moves, const int32_t* frags, const int3
 static int download_results(ig_ctx* c, int n_moves, ig_move_result* results)
 {
     HIPCK(hipMemcpyAsync(results, c->d_results, (size_t)n_moves * sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
+    if (queue_max_readback(c)) return -1;
     HIPCK(hipStreamSynchronize(c->stream));
     HIPCK(hipGetLastError());
     drain_timers(c);
+    take_max_readback(c);
+    c->full_windows = false;
     for (int i = 0; i < n_moves; i++)
         if (results[i].error) return fail("device-side consistency failure %d at move %d", results[i].error, i);
     return 0;
@@ -1181,9 +1272,19 @@ static int run_moves(ig_ctx* c, int n_moves, int max_c, int Wmax, Ready ready)
         const int w_want = s_adaptive ? std::max(2, std::min(Wmax, (int)(1.5 * c->w_ema + 1.5))) : Wmax;
         const int w_now = std::min(w_want, n_moves - done);
         if (ready(done, w_now)) return -1;
+        if (ensure_window_buffers(c)) return -1; /* the longest contig may have grown */
         enqueue_score(c, done, w_now, max_c, -1, 2);
         int next = 0;
         if (commit_loop(c, done, w_now, &next)) return -1;
+        if (next < 0) { /* the first slot did not fit: more room, the same batch again (nothing was committed) */
+            if (next == -1) {
+                if (grow_slice_pool(c)) return -1;
+            } else {
+                if (c->exact_grid >= c->mb.work_cap) return fail("the exact kernel's work list cannot hold the first move of a batch");
+                c->exact_grid = std::min(c->mb.work_cap, c->exact_grid * 4);
+            }
+            continue;
+        }
         if (w_now == w_want) /* a batch cut short by the end of the run says nothing */
             c->w_ema = 0.6 * c->w_ema + 0.4 * (next >= w_now ? std::min(2.0 * w_now, (double)Wmax) : (double)next);
         done += next;
@@ -1200,6 +1301,7 @@ extern "C" int ig_step_batch(ig_ctx* c, int32_t n_moves, const int32_t* frags, c
     if (max_c < 1 || max_c > IG_MAX_CANDIDATES) return fail("ig_step_batch: max_c out of range");
     if (c->world > 1) return fail("ig_step_batch: this handle scores a contact shard (ig_set_shard %d/%d): use ig_step_begin / all-reduce / ig_step_finish", c->rank, c->world);
     const int Wmax = c->init_links_inverse ? batch_width(c, max_c) : 1;
+    c->full_windows = (Wmax == 1 && n_moves > 1); /* moves enqueued one behind the other: no host round trip to follow the contig lengths */
     if (ensure_move_buffers(c, std::max(8, (int)max_c), Wmax)) return -1;
     if (upload_moves(c, n_moves, frags, cands, max_c)) return -1;
     if (run_moves(c, n_moves, max_c, Wmax, [](int, int) { return 0; })) return -1;
@@ -1224,6 +1326,7 @@ extern "C" int ig_step_batch_draw(ig_ctx* c, ig_neighbours* nb, uint32_t* mt_key
     for (int i = 0; i < n_moves; i++)
         if (frags[i] < 0 || frags[i] >= c->N) return fail("fragment %d out of range", frags[i]);
     const int Wmax = c->init_links_inverse ? batch_width(c, max_c) : 1;
+    c->full_windows = (Wmax == 1 && n_moves > 1);
     if (ensure_move_buffers(c, std::max(8, (int)max_c), Wmax)) return -1;
     if (ensure_io(c, n_moves, max_c)) return -1;
     HIPCK(hipMemcpyAsync(c->d_frags, frags, (size_t)n_moves * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -1285,6 +1388,7 @@ extern "C" int ig_batch_score(ig_ctx* c, int32_t move0, int32_t W, int32_t slot_
     HIPCK(hipSetDevice(c->device));
     if (W < 1 || W > c->mb.capW || move0 < 0 || move0 + W > c->up_moves) return fail("ig_batch_score: batch out of range");
     if (slot_begin < 0 || slot_end > W || slot_begin > slot_end) return fail("ig_batch_score: slot range out of range");
+    if (ensure_window_buffers(c)) return -1; /* the longest contig may have grown */
     enqueue_score(c, move0, W, c->up_max_c, -1, 2, slot_begin, slot_end);
     HIPCK(hipGetLastError());
     return 0;
@@ -1304,6 +1408,15 @@ extern "C" int ig_batch_commit(ig_ctx* c, int32_t move0, int32_t W, int32_t* n_c
     if (W < 1 || W > c->mb.capW || move0 < 0 || move0 + W > c->up_moves) return fail("ig_batch_commit: batch out of range");
     int next = 0;
     if (commit_loop(c, move0, W, &next)) return -1;
+    if (next < 0) { /* the first slot did not fit the slice pool / the exact kernel's grid: more room, the caller scores the batch again */
+        if (next == -1) {
+            if (grow_slice_pool(c)) return -1;
+        } else {
+            if (c->exact_grid >= c->mb.work_cap) return fail("the exact kernel's work list cannot hold the first move of a batch");
+            c->exact_grid = std::min(c->mb.work_cap, c->exact_grid * 4);
+        }
+        next = 0;
+    }
     *n_committed = next;
     return 0;
 }
@@ -1318,6 +1431,19 @@ extern "C" int ig_batch_results(ig_ctx* c, int32_t n_moves, ig_move_result* resu
 extern "C" int ig_set_batch_width(int w)
 {
     g_batch_w = std::min(std::max(w, 1), IG_MAX_BATCH);
+    return 0;
+}
+
+/* bytes of the move buffers: {per-window arrays (strides sN, sM), slice pool, everything else sized by slots and candidates} */
+extern "C" int ig_scratch_bytes(ig_ctx* c, int64_t out3[3])
+{
+    const MoveBuf& m = c->mb;
+    const int64_t C = (int64_t)m.capC * m.capW;
+    out3[0] = C * ((int64_t)m.sN * 4 * 3 + (int64_t)m.sM * 4 * 2 + (int64_t)m.sM * NSLOT * 8 + (int64_t)NSLOT * NDYN * m.sN * 4);
+    out3[1] = m.pool_cap * (m.packed ? 8 : 12);
+    out3[2] = C * (int64_t)(SLICE_SEG * 16 + sizeof(CandMeta) + NSLOT * NCODE * sizeof(ColMeta) + (P_STRIDE + Q_STRIDE) * 8 + IG_N_TMP_STRUCT * 8 +
+                            NSLOT * 8 + NSLOT * 16 + 16) +
+              (int64_t)m.rec_stride * m.capW + (int64_t)m.work_cap * 8 + (int64_t)c->N * 8;
     return 0;
 }
 
@@ -1344,9 +1470,11 @@ extern "C" int ig_step(ig_ctx* c, int32_t frag_a, const int32_t* cands, int32_t 
     if (scores) HIPCK(hipMemcpyAsync(scores, c->mb.scores, (size_t)C * IG_N_TMP_STRUCT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     enqueue_apply(c, 0, 0, 0);
     HIPCK(hipMemcpyAsync(out, c->d_results, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
+    if (queue_max_readback(c)) return -1;
     HIPCK(hipStreamSynchronize(c->stream));
     HIPCK(hipGetLastError());
     drain_timers(c);
+    take_max_readback(c);
     if (out->error) return fail("device-side consistency failure %d", out->error);
     return 0;
 }
@@ -1384,9 +1512,11 @@ extern "C" int ig_apply(ig_ctx* c, int32_t frag_a, int32_t frag_b, int32_t op)
     enqueue_apply(c, 0, 0, 1);
     ig_move_result r;
     HIPCK(hipMemcpyAsync(&r, c->d_results, sizeof r, hipMemcpyDeviceToHost, c->stream));
+    if (queue_max_readback(c)) return -1;
     HIPCK(hipStreamSynchronize(c->stream));
     HIPCK(hipGetLastError());
     drain_timers(c);
+    take_max_readback(c);
     if (r.error) return fail("device-side consistency failure %d", r.error);
     return 0;
 }
@@ -1431,9 +1561,11 @@ extern "C" int ig_step_finish(ig_ctx* c, ig_move_result* out, double* scores)
     }
     enqueue_apply(c, 0, 0, 0);
     HIPCK(hipMemcpyAsync(out, c->d_results, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
+    if (queue_max_readback(c)) return -1;
     HIPCK(hipStreamSynchronize(c->stream));
     HIPCK(hipGetLastError());
     drain_timers(c);
+    take_max_readback(c);
     if (out->error) return fail("device-side consistency failure %d", out->error);
     return 0;
 }
@@ -1504,6 +1636,7 @@ extern "C" int ig_nuis_begin(ig_ctx* c, int32_t frag_a, const int32_t* cands, in
     enqueue_move(c, 0, C, -1, 2);
     enqueue_apply(c, 0, 0, 0);
     HIPCK(hipMemcpyAsync(&c->host_nuis->res, c->d_results, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
+    if (queue_max_readback(c)) return -1;
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -1517,6 +1650,7 @@ extern "C" int ig_nuis_end(ig_ctx* c, ig_move_result* out, double* nz_test, doub
     HIPCK(hipStreamSynchronize(c->stream3));
     HIPCK(hipGetLastError());
     drain_timers(c);
+    take_max_readback(c);
     *out = c->host_nuis->res;
     if (out->error) return fail("device-side consistency failure %d", out->error);
     long long h[8];
@@ -1666,11 +1800,12 @@ extern "C" int ig_debug_candidate_state(ig_ctx* c, int32_t cand, int32_t slot, i
     /* start from the live genome (internal ids), overlay the local window */
     std::vector<int> host(17 * n);
     HIPCK(hipMemcpy(host.data(), c->st_block, 17 * n * sizeof(int), hipMemcpyDeviceToHost));
-    std::vector<int> loc((size_t)NDYN * n), gid(n);
-    HIPCK(hipMemcpy(loc.data(), c->mb.loc + ((size_t)(cand * NSLOT + slot) * NDYN) * n, (size_t)NDYN * n * sizeof(int), hipMemcpyDeviceToHost));
-    HIPCK(hipMemcpy(gid.data(), c->mb.Lloc + (size_t)cand * n, n * sizeof(int), hipMemcpyDeviceToHost));
+    const size_t sn = (size_t)c->mb.sN; /* stride of the window arrays */
+    std::vector<int> loc((size_t)NDYN * sn), gid(sn);
+    HIPCK(hipMemcpy(loc.data(), c->mb.loc + ((size_t)(cand * NSLOT + slot) * NDYN) * sn, (size_t)NDYN * sn * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(gid.data(), c->mb.Lloc + (size_t)cand * sn, sn * sizeof(int), hipMemcpyDeviceToHost));
     for (int x = 0; x < m.n_loc; x++)
-        for (int k = 0; k < NDYN; k++) host[k * n + gid[x]] = loc[k * n + x];
+        for (int k = 0; k < NDYN; k++) host[k * n + gid[x]] = loc[k * sn + x];
     static const int dyn_src[NDYN] = {0, 1, 2, 3, 6, 8, 9, 10, 11, 12, 13};
     for (int k = 0; k < NDYN; k++) memcpy(soa + dyn_src[k] * n, &host[k * n], n * sizeof(int));
     memcpy(soa + 4 * n, &host[11 * n], n * sizeof(int));

@@ -151,7 +151,7 @@ __device__ void apply_winner(State st, Tables tab, Glob* g, const MoveBuf& mb, i
     const int c = mc.ch_c, slot = mc.ch_slot, k = mc.ch_k;
     const int cw = CW(w, c);
     const CandMeta& m = mb.meta[cw];
-    const int N = mb.N, M = mb.M;
+    const int N = mb.sN, M = mb.sM; /* strides of the window arrays */
     const int* base = mb.loc + ((size_t)(cw * NSLOT + slot) * NDYN) * N;
     const int* gid = mb.Lloc + (size_t)cw * N;
     int heads = 0;
@@ -189,6 +189,8 @@ __device__ void apply_winner(State st, Tables tab, Glob* g, const MoveBuf& mb, i
     }
     if (tid == 0) {
         const long long* qp = mb.qpart + (size_t)cw * Q_STRIDE;
+        atomicMax(&g->max_L, m.n_loc); /* no contig made by this move is longer than its window */
+        atomicMax(&g->max_SL, m.m_loc);
         g->n_prev_touched = m.m_loc;
         atomicAdd(&g->n_contigs, m.same ? -1 : -2);
         long long dh, dl;
@@ -327,7 +329,8 @@ __global__ void __launch_bounds__(64)
         const ig_params p = g->par[0];
         const double log_e = IG_LOG_E_F;
         const double n_tot_pxl = g->n_tot_pxl;
-        int n_dirty = 0, committed = w_start, pending = -1, n_cand = 0, n_predicted = 0;
+        int n_dirty = 0, committed = w_start, pending = -1, n_cand = 0, n_predicted = 0, stop_overflow = 0;
+        int max_L = g->max_L, max_SL = g->max_SL;
         if (w_start > 0) {
             n_dirty = dirty_buf[0];
             for (int q = lane; q < n_dirty; q += 64) dirty[q] = dirty_buf[1 + q];
@@ -395,7 +398,10 @@ __global__ void __launch_bounds__(64)
             /* conflict with an earlier move of this batch?  slice pool overflow? */
             bool hitd = false;
             for (int q = 0; q < n_dirty; q++) hitd |= (dirty[q] == d.cand.ctgA) | (dirty[q] == d.cand.ctgB);
-            if (err0 || rl(d.cand.overflow, 0) || __any(hitd && lane < C)) break;
+            if (err0 || rl(d.cand.overflow, 0) || __any(hitd && lane < C)) {
+                stop_overflow = err0 ? 0 : rl(d.cand.overflow, 0); /* 1: the slice pool, 2: the exact kernel's grid */
+                break;
+            }
             n_cand += C;
             /* scores (eval_all_likelihood_on_zero_2nd KA:4005-4027, eval_all_scores KA:4029-4046) with the live scalars */
             const double cur_nz = ig_acc_to_double(nz_hi, nz_lo);
@@ -542,6 +548,10 @@ __global__ void __launch_bounds__(64)
             n_intra += br.dni;
             n_contigs += br_heads - (b_same ? 1 : 2);
             next_cid += NFRESH;
+            if (br_changed) { /* no contig made by this move is longer than its window */
+                max_L = max(max_L, b_nloc);
+                max_SL = max(max_SL, rl(d.cand.m_loc, bc));
+            }
             {
                 const int sel = (bslot >= 12) ? bc : C - 1; /* the family of the winner re-ran get_bounds (CL:2125-2126) */
                 vmask = (unsigned)rl((int)d.cand.flag_mask, sel);
@@ -577,11 +587,15 @@ __global__ void __launch_bounds__(64)
             g->n_intra = n_intra;
             g->n_contigs = n_contigs;
             g->next_cid = next_cid;
+            g->max_L = max_L;
+            g->max_SL = max_SL;
             dirty_buf[0] = n_dirty;
             for (int q = 0; q < n_dirty; q++) dirty_buf[1 + q] = dirty[q];
             batch_out[0] = committed;
             batch_out[1] = pending;
-            batch_out[2] = 0;
+            batch_out[2] = (committed == w_start && pending < 0) ? stop_overflow : 0; /* nothing done because the first slot did not fit a pool */
+            batch_out[8] = max_L;
+            batch_out[9] = max_SL;
             batch_out[3] = n_cand;
             batch_out[4] = n_predicted;
             batch_out[5] = n_contigs;
@@ -594,7 +608,9 @@ __global__ void __launch_bounds__(64)
             if (host_out) {
                 host_out[0] = committed;
                 host_out[1] = pending;
-                host_out[2] = 0;
+                host_out[2] = (committed == w_start && pending < 0) ? stop_overflow : 0;
+                host_out[8] = max_L;
+                host_out[9] = max_SL;
                 host_out[3] = n_cand;
                 host_out[4] = n_predicted;
                 host_out[5] = n_contigs;
@@ -624,7 +640,7 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
     const int gsz = (committed - w_start >= 2) ? COMMIT_GROUP : COMMIT_THREADS;
     const int grp = tid / gsz, gtid = tid % gsz, ngrp = COMMIT_THREADS / gsz;
     /* ---------------------------------------------------------------- 2. apply */
-    const int N = mb.N, M = mb.M;
+    const int N = mb.sN, M = mb.sM; /* strides of the window arrays */
     auto winner_loc = [&](int w) -> const int* {
         const MoveCtl& mc = mb.ctl[w];
         return mb.loc + ((size_t)(CW(w, mc.ch_c) * NSLOT + mc.ch_slot) * NDYN) * N;

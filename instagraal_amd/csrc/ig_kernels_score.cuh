@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256)
     __shared__ int sh_cA[IG_MAX_BATCH], sh_LA[IG_MAX_BATCH], sh_C[IG_MAX_BATCH];
     __shared__ int sh_cB[IG_MAX_BATCH * IG_MAX_CANDIDATES];
     __shared__ int sh_flags[IG_MAX_CANDIDATES][12];
-    const int N = mb.N;
+    const int N = mb.N, sN = mb.sN;
     for (int i = threadIdx.x; i < W; i += blockDim.x) {
         const int A = frags_all[move0 + i];
         sh_cA[i] = st.cid[A];
@@ -76,8 +76,9 @@ __global__ void __launch_bounds__(256)
                 int slot = -1;
                 if (cf == cA) slot = pf;
                 else if (cf == sh_cB[w * IG_MAX_CANDIDATES + c]) slot = LA + pf;
-                if (slot >= 0) {
-                    const size_t o = (size_t)CW(w, c) * N + slot;
+                if (slot >= sN) g->error = 9; /* a window beyond the buffers' stride: the host's bound on the contig lengths failed */
+                else if (slot >= 0) {
+                    const size_t o = (size_t)CW(w, c) * sN + slot;
                     mb.Lloc[o] = f;
                     mb.lbloc[o] = lb;
                     mb.slloc[o] = sl;
@@ -151,6 +152,7 @@ __global__ void __launch_bounds__(256)
         m.windowed = m.same && (st.circ[A] == 0);
         /* a window that spans the whole contig keeps every pair: the slice is then the full contig */
         if (m.windowed && ((m.up_fa == 0 && m.down_fa == m.SLA - 1) || (m.up_fb == 0 && m.down_fb == m.SLA - 1))) m.windowed = 0;
+        if (m.n_loc > mb.sN || m.m_loc > mb.sM) g->error = 9; /* a window beyond the buffers' strides */
         bounds_scalar(st, g, A, B, m.pos_up, m.pos_down, m.flags);
         for (int i = 0; i < 12; i++) sh_flags[t][i] = m.flags[i];
         mb.meta[CW(w, t)] = m;
@@ -185,7 +187,8 @@ __device__ __forceinline__ void mutate_one(const State& st, const Tables& tab, c
     const CandMeta& m = mb.meta[cw];
     const int k = m.kidx[slot];
     if (k < 0) return;
-    const int N = mb.N, M = mb.M, n = m.n_loc;
+    const int N = mb.sN, M = mb.sM, n = m.n_loc; /* strides of the window arrays */
+    if (n > N || m.m_loc > M) return; /* k_gather flagged it */
     int* base = mb.loc + ((size_t)(cw * NSLOT + slot) * NDYN) * N;
     igd::Loc S;
     S.pos = base;
@@ -437,7 +440,7 @@ __global__ void __launch_bounds__(256) k_slice(const long long* __restrict__ row
     if (c >= mb.ctl[w].C) return;
     const int cw = CW(w, c);
     const CandMeta& m = mb.meta[cw];
-    const int M = mb.M, m_loc = m.m_loc;
+    const int M = mb.sM, m_loc = m.m_loc;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     __shared__ long long seg_off[SLICE_SEG];
@@ -798,7 +801,7 @@ __device__ __forceinline__ void score_workgroup(ScoreLds<CAP>& L, const ScoreCon
     const ig_hot hp = sc->hot;
     const float mean = sc->mean_kb;
     if (c >= C || k > n_uniq || n <= 0 || off < first) return;
-    const int M = mb.M;
+    const int M = mb.sM;
     const uint2* gcol = mb.coords + (size_t)(cw * NSLOT + k) * M;
     const bool staged = m_loc <= CAP;
     {
@@ -1193,7 +1196,7 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     const CandMeta& m = mb.meta[cw];
     const int kk = blockIdx.y;
     const int k = (kk == 0) ? 0 : (predicted == 1 ? mc.pred_k : mc.ch_k);
-    const int M = mb.M, m_loc = m.m_loc;
+    const int M = mb.sM, m_loc = m.m_loc;
     const ig_params p = g->par[which];
     const ig_hot hot = ig_hot_make(p, ig_tab());
     const float mean = g->mean_kb;
@@ -1388,7 +1391,7 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
     if (c >= mb.ctl[w].C) return;
     const int cw = CW(w, c);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int M = mb.M;
+    const int M = mb.sM; /* stride; the bisection below runs over the global sub-fragment ids [0, mb.M) */
     const ig_params p = g->par[0];
     const ig_hot hot = ig_hot_make(p, ig_tab());
     const float mean = g->mean_kb;
@@ -1406,7 +1409,7 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
     const long long Sc = slice_total(part);
     const int r = (int)(Sc % 64);
     if (!(tail_quirk && r > 0)) return;
-    int lo_t = 0, hi_t = M; /* count(lo_t) >= r, count(hi_t) < r */
+    int lo_t = 0, hi_t = mb.M; /* count(lo_t) >= r, count(hi_t) < r */
     while (hi_t - lo_t > 1) {
         const int mid = lo_t + (hi_t - lo_t) / 2;
         long long s = 0;

@@ -259,7 +259,7 @@ __device__ __forceinline__ void screen_column(ScreenLds& L, const ScreenConst* _
     /* a column whose genome is the current genome on the window (k_mutate: nothing changed) has column 0's sums exactly */
     if (c >= C || k > n_uniq || n == 0 || off < 0) return;
     if (k > 0 && mb.sinfo[cw * NSLOT + mb.meta[cw].uniq[k - 1]].x == 0) return;
-    const uint2* gcol = mb.coords + (size_t)(cw * NSLOT + k) * mb.M;
+    const uint2* gcol = mb.coords + (size_t)(cw * NSLOT + k) * mb.sM;
     const bool staged = m_loc <= LDS_COL_SMALL;
     {
         const float4* src = (const float4*)sc->pzc;
@@ -443,8 +443,8 @@ __global__ void __launch_bounds__(SCORE_THREADS)
         if (threadIdx.x < (LDS_PZ + 2) % 4) L.pzc[(LDS_PZ + 2) / 4 * 4 + threadIdx.x] = sc->pzc[(LDS_PZ + 2) / 4 * 4 + threadIdx.x];
     }
     {
-        const uint2* gA = mb.coords + (size_t)(cw * NSLOT + kA) * mb.M;
-        const uint2* gB = mb.coords + (size_t)(cw * NSLOT + kB) * mb.M;
+        const uint2* gA = mb.coords + (size_t)(cw * NSLOT + kA) * mb.sM;
+        const uint2* gB = mb.coords + (size_t)(cw * NSLOT + kB) * mb.sM;
         for (int i = threadIdx.x; i < m_loc; i += SCORE_THREADS) { /* ranks x 4, see screen_pair */
             uint2 va = gA[i], vb = gB[i];
             va.y = (va.y & 0xf0000000u) | ((va.y & 0x0fffffffu) << 2);
@@ -722,7 +722,7 @@ __global__ void __launch_bounds__(256) k_worklist(MoveBuf mb, const unsigned* __
         bool fit = true;
         for (int x = 0; x < 8; x++) fit &= 8LL * (s_base[x] + s_cnt[x]) <= (long long)grid_cap;
         s_fit = fit;
-        if (!fit) mb.ctl[w].overflow = 1;
+        if (!fit) mb.ctl[w].overflow = 2; /* 2: the exact kernel's grid (1: the slice pool, k_offsets) */
         for (int x = 0; x < 8; x++) {
             if (fit) atomicMax(&mb.work[x], (unsigned long long)(s_base[x] + s_cnt[x])); /* the sub-lists end behind the last slot that fits */
             atomicMax(&mb.work[8 + x], (unsigned long long)(s_base[x] + s_cnt[x])); /* what the grid would have to cover (the host sizes the next one) */

@@ -76,12 +76,21 @@ __global__ void k_full_zero(Tables t, const Glob* g, int which, int M, long long
     }
 }
 
-__global__ void k_count_heads(State st, int N, int* out)
+__global__ void k_count_heads(State st, int N, int* out, Glob* g)
 {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
     int h = (f < N && st.pos[f] == 0) ? 1 : 0;
+    int mL = (f < N) ? st.L[f] : 0, mS = (f < N) ? st.SL[f] : 0; /* longest contig, in fragments and in sub-fragments */
     h = wave_sum_i(h);
-    if ((threadIdx.x & 63) == 0 && h) atomicAdd(out, h);
+    for (int o = 32; o > 0; o >>= 1) {
+        mL = max(mL, __shfl_down(mL, o, 64));
+        mS = max(mS, __shfl_down(mS, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (h) atomicAdd(out, h);
+        atomicMax(&g->max_L, mL);
+        atomicMax(&g->max_SL, mS);
+    }
 }
 
 /* explode_genome (KA:409-426); internal contig id = fragment index (ori is NOT reset) */

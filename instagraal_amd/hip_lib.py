@@ -329,6 +329,12 @@ class Context:
         _ck(lib().ig_batch_stats(self._h, _p(o)))
         return dict(batches=int(o[0]), committed_in_batch=int(o[1]), one_move_tails=int(o[2]), predicted_deltas=int(o[3]))
 
+    def scratch_bytes(self):
+        """bytes of the move buffers: (per-window arrays, slice pool, the rest)"""
+        o = np.zeros(3, np.int64)
+        _ck(lib().ig_scratch_bytes(self._h, _p(o)))
+        return int(o[0]), int(o[1]), int(o[2])
+
     # ---- bookkeeping
     def renumber_contigs(self):
         n = C.c_int32()

@@ -122,6 +122,8 @@ def test_cfg5_properties():
             assert [int(x) for x in sums[:5]] == [int(x) for x in limbs[:5]], W
             outs.append((res.tobytes(), s.gpu_vect_frags.copy_from_gpu().soa17(), [int(x) for x in s.ctx.valid_insert()]))
             assert np.all(res["error"] == 0) and np.all(np.isfinite(res["o"]))
+            if W == 24:  # scratch of the batches: window-sized arrays + a pool of 2 Z entries, not the worst case of a genome-wide window
+                assert sum(s.ctx.scratch_bytes()) < 20e9, s.ctx.scratch_bytes()
             s.free_gpu()
             del s
     finally:

@@ -1,7 +1,12 @@
 """The oracle's restatement of the reference HOST logic against vectors captured from the
 reference's own sampler Python (tools/gen_golden.py): candidates and RNG stream, 24xC scores,
 chosen (op, frag_b), stale insert flags, return tuple, genome state, nuisance step.
-Bit-exact in both arithmetic modes."""
+Bit-exact in both arithmetic modes.
+
+Limit of these vectors: the kernels underneath the reference's host code are the oracle's own C functions
+(tools/fake_pycuda), so the goldens pin the host logic and the restatement's self-consistency, not the CUDA kernels (which
+cannot be compiled or run here; the reference's tests hold no golden for this path).  Independent of that restatement:
+test_rippe_against_reference_peval below (P(s) against the reference's optim_rippe_curve_update.peval)."""
 import glob
 import os
 
