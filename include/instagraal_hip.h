@@ -145,6 +145,16 @@ int ig_scratch_bytes(ig_ctx* ctx, int64_t out3[3]);   /* move buffers: {per-wind
 int ig_nuis_begin(ig_ctx* ctx, int32_t frag_a, const int32_t* cands, int32_t C, const float p_test[8], float mean_subfrag_kb);
 int ig_nuis_end(ig_ctx* ctx, ig_move_result* out, double* nz_test, double* z_test, int64_t* limbs5);
 int ig_nuis_accept(ig_ctx* ctx);
+/* The same for a RUN of (move, nuisance step) pairs -- the loop of instagraal.py:217-262 itself.  A rejected step changes
+ * nothing a move reads, so the moves behind it are scored ahead, in batches (width: env IG_NUIS_W, default: follows the run
+ * lengths, at most IG_NUIS_WMAX = 12): ig_nuis_run_begin uploads the lists of the run (as ig_batch_upload);
+ * ig_nuis_step_begin(move), move = 0, 1, ... in order: asynchronous -- the step's pass under p_test and the decision + apply
+ * of that ONE move from the batch it was scored in (a batch starting at `move` is scored first when there is none: first
+ * step, after an accepted step, after a conflict with an earlier move of the batch, batch used up); ig_nuis_end /
+ * ig_nuis_accept as above.  Results as one move and one step at a time.  Any other call that runs moves or changes state or
+ * param_simu ends the run. */
+int ig_nuis_run_begin(ig_ctx* ctx, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c);
+int ig_nuis_step_begin(ig_ctx* ctx, int32_t move, const float p_test[8], float mean_subfrag_kb);
 
 /* ---- bookkeeping -------------------------------------------------------- */
 int ig_renumber_contigs(ig_ctx* ctx, int32_t* n_contigs, float* mean_len, int32_t* max_id); /* CL:2715-2881 */
@@ -187,6 +197,7 @@ int ig_debug_transcendental_error(ig_ctx* ctx, double out2[2]);
 int ig_debug_screen_stats(ig_ctx* ctx, double out6[6]); /* ..., terms screened, terms scored exactly */
 /* 0 disables the reference's dropped-tail behaviour of eval_sub_likelihood (quirk Q5); default 1 */
 int ig_debug_set_tail_quirk(int on);
+int ig_debug_set_full_hist(int on); /* from-scratch pass: all-trans tiles from their count histograms (1, default) or contact by contact (0) */
 
 #ifdef __cplusplus
 }

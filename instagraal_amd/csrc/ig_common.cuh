@@ -220,6 +220,12 @@ struct ig_ctx {
     long long* scratch_nuis;       /* 8 x int64 reduction scratch of that pass */
     struct NuisHost* host_nuis;    /* pinned: its results and the move's */
     bool nuis_in_flight;
+    /* moves of a run of (move, nuisance step) pairs scored ahead in batches (ig_nuis_run_begin / ig_nuis_step_begin): the batch
+     * in the buffers starts at move spec_base, has spec_W slots of which [0, spec_next) are decided; spec_valid: its
+     * undecided slots were scored under the model's current parameters */
+    bool nuis_spec, spec_valid, spec_prev_pending;
+    int spec_base, spec_W, spec_next, spec_move, spec_slot;
+    double spec_ema;
     ig_params nuis_test;           /* the test parameters of the step in flight */
     float nuis_mean_kb;
     int N, M;
@@ -238,6 +244,7 @@ struct ig_ctx {
     uint2* tiled_cc;
     struct TileWork* tile_work;
     int n_tile_work;
+    unsigned *tile_hist, *tile_sig; /* count histograms of the off-diagonal tiles (static); contig signatures of the blocks (per pass) */
     int* init_prev;
     int* init_next;
     int* orientable;

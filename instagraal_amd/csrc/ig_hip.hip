@@ -285,6 +285,8 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipFree(c->tabrec);
     hipFree(c->tiled_cc);
     hipFree(c->tile_work);
+    hipFree(c->tile_hist);
+    hipFree(c->tile_sig);
     hipFree(c->init_prev);
     hipFree(c->init_next);
     hipFree(c->orientable);
@@ -329,23 +331,30 @@ extern "C" int ig_set_stream(ig_ctx* c, void* s)
 }
 
 /* the from-scratch likelihood of the non-zero pixels under tables `t` and parameter set `which` -> out[0..1] */
+static int g_full_hist = -1;
 static void launch_full_nz(ig_ctx* c, const Tables& t, int which, long long* out, PzTab pz, hipStream_t stream = nullptr)
 {
     static int s_wgs = getenv("IG_FULL_WGS") ? atoi(getenv("IG_FULL_WGS")) : 8 * 256;
     if (c->Z <= 0) return;
     if (!stream) stream = c->stream;
-    hipLaunchKernelGGL(k_pack_tab, dim3((c->M + 255) / 256), dim3(256), 0, stream, t, c->M, c->tabrec);
+    static const int s_tiled = getenv("IG_FULL_TILED") ? atoi(getenv("IG_FULL_TILED")) : 1;
+    if (g_full_hist < 0) g_full_hist = getenv("IG_FULL_HIST") ? atoi(getenv("IG_FULL_HIST")) : 1; /* 0: read every tile's contacts */
+    const int s_hist = g_full_hist;
+    const bool tiled = s_tiled && c->tiled_cc && c->n_tile_work > 0;
+    if (tiled)
+        hipLaunchKernelGGL(k_pack_tab_sig, dim3((c->M + FULL_TB - 1) / FULL_TB), dim3(256), 0, stream, t, c->M, c->tabrec, c->tile_sig, FULL_TB);
+    else
+        hipLaunchKernelGGL(k_pack_tab, dim3((c->M + 255) / 256), dim3(256), 0, stream, t, c->M, c->tabrec);
     /* the tables of this parameter set (k_score_list's own block is parameter set 0's) */
     hipLaunchKernelGGL(k_build_score_const, dim3((LDS_PZ + 2 + 255) / 256), dim3(256), 0, stream, c->glob, pz, c->lgf_tab, c->full_const, which);
-    static const int s_tiled = getenv("IG_FULL_TILED") ? atoi(getenv("IG_FULL_TILED")) : 1;
-    if (s_tiled && c->tiled_cc && c->n_tile_work > 0) {
+    if (tiled) {
         /* next to a move (the nuisance step's pass, ig_nuis_begin): one workgroup per CU -- the request is padded beyond half
          * of the LDS -- so that the move's own small workgroups find room on every CU instead of queueing behind this pass */
         static const int s_pad = getenv("IG_FULL_LDS_PAD") ? atoi(getenv("IG_FULL_LDS_PAD")) : 100 * 1024;
         const size_t lds = (stream != c->stream) ? std::max<size_t>(sizeof(FullTiledLds), (size_t)s_pad) : sizeof(FullTiledLds);
         static const int s_thr = getenv("IG_FULL_THREADS") ? atoi(getenv("IG_FULL_THREADS")) : FULL_TILED_THREADS;
         hipLaunchKernelGGL(k_full_nz_tiled, dim3(c->n_tile_work), dim3((stream != c->stream) ? s_thr : FULL_TILED_THREADS), lds, stream, c->tile_work, c->tiled_cc,
-                           c->tabrec, t.len, c->full_const, c->lgf_tab, c->M, pz.n, out);
+                           c->tabrec, t.len, c->full_const, c->lgf_tab, c->M, pz.n, out, s_hist ? c->tile_sig : nullptr, c->tile_hist);
         return;
     }
     hipLaunchKernelGGL(k_full_nz, dim3(s_wgs), dim3(256), 0, stream, c->crow, c->cc, c->tabrec, t.len, c->full_const, c->lgf_tab,
@@ -511,8 +520,12 @@ extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* 
     /* the tiled copy for the from-scratch pass (k_full_nz_tiled): counting sort of the contacts by (row block, column block) */
     hipFree(c->tiled_cc);
     hipFree(c->tile_work);
+    hipFree(c->tile_hist);
+    hipFree(c->tile_sig);
     c->tiled_cc = nullptr;
     c->tile_work = nullptr;
+    c->tile_hist = nullptr;
+    c->tile_sig = nullptr;
     c->n_tile_work = 0;
     {
         const int64_t nb = ((int64_t)M + FULL_TB - 1) / FULL_TB;
@@ -525,12 +538,33 @@ extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* 
             std::vector<int64_t> tptr((size_t)(nb * nb) + 1, 0); /* contacts per tile -> first contact of a tile */
             for (int64_t k = 0; k < Z; k++) tptr[(size_t)((row[k] / FULL_TB) * nb + col[k] / FULL_TB) + 1]++;
             for (size_t i = 1; i < tptr.size(); i++) tptr[i] += tptr[i - 1];
+            /* histogram of the counts of every off-diagonal tile (a tile that turns out to hold trans pairs only is summed
+             * from it, k_full_nz_tiled); -1: a count outside 1 .. TILE_HB-1 */
+            std::vector<int> tile_hist((size_t)(nb * nb), -1);
+            std::vector<unsigned> hist;
+            {
+                std::vector<char> bad((size_t)(nb * nb), 0);
+                for (int64_t k = 0; k < Z; k++)
+                    if (cnt[k] < 1 || cnt[k] >= TILE_HB) bad[(size_t)((row[k] / FULL_TB) * nb + col[k] / FULL_TB)] = 1;
+                int n_hist = 0;
+                for (int64_t bi = 0; bi < nb; bi++)
+                    for (int64_t bj = bi + 1; bj < nb; bj++) {
+                        const size_t t = (size_t)(bi * nb + bj);
+                        if (!bad[t] && tptr[t + 1] > tptr[t] && tptr[t + 1] - tptr[t] < (1LL << 31)) tile_hist[t] = n_hist++;
+                    }
+                hist.assign((size_t)std::max(n_hist, 1) * TILE_HB, 0u);
+                for (int64_t k = 0; k < Z; k++) {
+                    const int h = tile_hist[(size_t)((row[k] / FULL_TB) * nb + col[k] / FULL_TB)];
+                    if (h >= 0) hist[(size_t)h * TILE_HB + cnt[k]]++;
+                }
+            }
             std::vector<TileWork> work;
             for (int64_t bi = 0; bi < nb; bi++)
                 for (int64_t bj = bi; bj < nb; bj++) {
                     const int64_t b = tptr[(size_t)(bi * nb + bj)], e = tptr[(size_t)(bi * nb + bj) + 1];
+                    const int h = tile_hist[(size_t)(bi * nb + bj)];
                     for (int64_t o = b; o < e; o += FULL_CHUNK)
-                        work.push_back(TileWork{(long long)o, (int)std::min<int64_t>(FULL_CHUNK, e - o), (int)bi, (int)bj, 0});
+                        work.push_back(TileWork{(long long)o, (int)std::min<int64_t>(FULL_CHUNK, e - o), (int)bi, (int)bj, h < 0 ? -1 : 2 * h + (o == b ? 1 : 0)});
                 }
             std::vector<uint2> tc((size_t)Z);
             std::vector<int64_t> cur(tptr.begin(), tptr.end() - 1);
@@ -540,8 +574,11 @@ extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* 
             }
             DALLOC(c->tiled_cc, (size_t)Z);
             DALLOC(c->tile_work, work.size());
+            DALLOC(c->tile_hist, hist.size());
+            DALLOC(c->tile_sig, (size_t)nb * SIG_WORDS);
             HIPCK(hipMemcpy(c->tiled_cc, tc.data(), (size_t)Z * sizeof(uint2), hipMemcpyHostToDevice));
             HIPCK(hipMemcpy(c->tile_work, work.data(), work.size() * sizeof(TileWork), hipMemcpyHostToDevice));
+            HIPCK(hipMemcpy(c->tile_hist, hist.data(), hist.size() * sizeof(unsigned), hipMemcpyHostToDevice));
             c->n_tile_work = (int)work.size();
         }
     }
@@ -610,6 +647,7 @@ extern "C" int ig_upload_state(ig_ctx* c, const int32_t* soa, int32_t N)
     HIPCK(hipSetDevice(c->device));
     if (N <= 0) return fail("ig_upload_state: N <= 0");
     if (!c->have_sub) return fail("ig_upload_state: upload the sub-fragment table first");
+    c->nuis_spec = c->spec_valid = false;
     const size_t n = N;
     std::vector<int> host(17 * n);
     /* soa member order (KA:40-58): 0 pos 1 sub_pos 2 id_c 3 start_bp 4 len_bp 5 sub_len 6 circ 7 id 8 prev 9 next
@@ -727,6 +765,7 @@ extern "C" int ig_set_params(ig_ctx* c, const float p[8], float mean_subfrag_kb,
 {
     HIPCK(hipSetDevice(c->device));
     if (which != 0 && which != 1) return fail("ig_set_params: which must be 0 or 1");
+    if (which == 0) c->nuis_spec = c->spec_valid = false; /* moves scored ahead (ig_nuis_step_begin) were scored under the old set */
     HIPCK(hipStreamSynchronize(c->stream));
     ig_params hp = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]};
     HIPCK(hipMemcpy(&c->glob->par[which], &hp, sizeof hp, hipMemcpyHostToDevice));
@@ -847,6 +886,7 @@ extern "C" int ig_bomb(ig_ctx* c, const int32_t* shuffle)
     (void)shuffle; /* explode_genome writes id_c = shuffle[i] (KA:419); the renumbering that follows (CL:1948) erases it */
     HIPCK(hipSetDevice(c->device));
     if (!c->have_state) return fail("ig_bomb: no state");
+    c->nuis_spec = c->spec_valid = false;
     hipLaunchKernelGGL(k_explode, dim3((c->N + 255) / 256), dim3(256), 0, c->stream, c->st, c->N);
     int next = c->N;
     HIPCK(hipMemcpyAsync(&c->glob->next_cid, &next, sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -929,6 +969,7 @@ static int check_ready(ig_ctx* c)
 {
     if (!c->have_contacts || !c->have_sub || !c->have_state || !c->have_params)
         return fail("contacts, sub-fragment table, state and parameters must be uploaded before a move");
+    c->nuis_spec = c->spec_valid = false; /* every entry point that runs moves passes here: a run of ig_nuis_step_begin ends with it */
     return 0;
 }
 
@@ -1118,52 +1159,63 @@ static int validate_move(ig_ctx* c, int frag_a, const int32_t* cands, int C)
 }
 
 /* commit the scored batch [move0, move0 + w_now): k_commit_batch, the one-move tail for a windowed winner, resume */
+/* the decide + apply launches of the slots [next, w_now) of the batch at move `done` */
+static void launch_commit(ig_ctx* c, int done, int w_now, int next, int resumed_plain)
+{
+    TimedLaunch t(c, T_COMMIT);
+    hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(64), 0, c->stream, c->glob, c->mb, c->d_results, done, w_now, next, c->dirty_buf,
+                       c->batch_out, (volatile int*)c->host_bo_dev, ++c->bo_seq, resumed_plain);
+    if (c->own_begin > 0 || c->own_end < w_now)
+        hipLaunchKernelGGL(k_mutate_winners, dim3(2, w_now), dim3(256), 0, c->stream, c->st, c->tab, c->sub_tab, c->rowptr, c->glob,
+                           c->mb, PzTab{c->pz_tab, c->pz_n}, next, c->own_begin, c->own_end, c->batch_out);
+    hipLaunchKernelGGL(k_commit_batch, dim3(1), dim3(COMMIT_THREADS), 0, c->stream, c->st, c->tab, c->tab_prev, c->glob, c->mb,
+                       c->init_prev, c->init_next, c->orientable, c->black, c->own_tag, c->own_idx, c->prev_touched, c->d_results, done,
+                       w_now, next, c->batch_out);
+}
+
+/* what the last k_decide_batch launch reported (batch_out[0..12)), as soon as it is there: the kernel writes a copy to mapped,
+ * coherent host memory; the host spins on it, every so often makes sure the stream is still alive (a fault must not hang
+ * the host) and falls back to the device copy when the stream has drained without the flag */
+static int wait_commit(ig_ctx* c, int bo[12], bool first_of_batch, int next)
+{
+    if (c->host_bo) {
+        volatile int* hb = c->host_bo;
+        bool got = false;
+        for (unsigned spin = 0; !got; spin++) {
+            if (hb[7] == c->bo_seq) {
+                got = true;
+            } else if ((spin & 0xfff) == 0xfff) {
+                const hipError_t q = hipStreamQuery(c->stream);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) return fail("batch commit failed: %s", hipGetErrorString(q));
+            }
+        }
+        if (got) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            for (int i = 0; i < 12; i++) bo[i] = hb[i];
+        } else {
+            HIPCK(hipMemcpy(bo, c->batch_out, 12 * sizeof(int), hipMemcpyDeviceToHost));
+        }
+    } else {
+        HIPCK(hipMemcpyAsync(bo, c->batch_out, 12 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));
+    }
+    if (first_of_batch) c->n_batches++;
+    c->n_batch_committed += bo[0] - next;
+    c->n_batch_predicted += bo[4];
+    c->n_contigs_seen = bo[5];
+    c->max_L = std::max(c->max_L, bo[8]);
+    c->max_SL = std::max(c->max_SL, bo[9]);
+    return 0;
+}
+
 static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
 {
     int next = 0; /* slots [0, next) of this batch are committed */
     for (;;) {
-        {
-            TimedLaunch t(c, T_COMMIT);
-            hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(64), 0, c->stream, c->glob, c->mb, c->d_results, done, w_now, next,
-                               c->dirty_buf, c->batch_out, (volatile int*)c->host_bo_dev, ++c->bo_seq);
-            if (c->own_begin > 0 || c->own_end < w_now)
-                hipLaunchKernelGGL(k_mutate_winners, dim3(2, w_now), dim3(256), 0, c->stream, c->st, c->tab, c->sub_tab, c->rowptr,
-                                   c->glob, c->mb, PzTab{c->pz_tab, c->pz_n}, next, c->own_begin, c->own_end, c->batch_out);
-            hipLaunchKernelGGL(k_commit_batch, dim3(1), dim3(COMMIT_THREADS), 0, c->stream, c->st, c->tab, c->tab_prev, c->glob,
-                               c->mb, c->init_prev, c->init_next, c->orientable, c->black, c->own_tag, c->own_idx,
-                               c->prev_touched, c->d_results, done, w_now, next, c->batch_out);
-        }
+        launch_commit(c, done, w_now, next, 0);
         int bo[12];
-        if (c->host_bo) {
-            /* spin on the mapped copy k_decide_batch writes; every so often make sure the stream is still alive (a fault
-             * must not hang the host) and fall back to the device copy when the stream has drained without the flag */
-            volatile int* hb = c->host_bo;
-            bool got = false;
-            for (unsigned spin = 0; !got; spin++) {
-                if (hb[7] == c->bo_seq) {
-                    got = true;
-                } else if ((spin & 0xfff) == 0xfff) {
-                    const hipError_t q = hipStreamQuery(c->stream);
-                    if (q == hipSuccess) break;
-                    if (q != hipErrorNotReady) return fail("batch commit failed: %s", hipGetErrorString(q));
-                }
-            }
-            if (got) {
-                std::atomic_thread_fence(std::memory_order_acquire);
-                for (int i = 0; i < 12; i++) bo[i] = hb[i];
-            } else {
-                HIPCK(hipMemcpy(bo, c->batch_out, sizeof bo, hipMemcpyDeviceToHost));
-            }
-        } else {
-            HIPCK(hipMemcpyAsync(bo, c->batch_out, sizeof bo, hipMemcpyDeviceToHost, c->stream));
-            HIPCK(hipStreamSynchronize(c->stream));
-        }
-        if (next == 0) c->n_batches++;
-        c->n_batch_committed += bo[0] - next;
-        c->n_batch_predicted += bo[4];
-        c->n_contigs_seen = bo[5];
-        c->max_L = std::max(c->max_L, bo[8]);
-        c->max_SL = std::max(c->max_SL, bo[9]);
+        if (wait_commit(c, bo, next == 0, next)) return -1;
         if (bo[2] && next == 0 && bo[0] == 0 && bo[1] < 0) { /* the batch's first slot did not fit the slice pool (1) or the exact
                                                                * kernel's grid (2): the caller enlarges it and repeats the batch */
             *next_out = -bo[2];
@@ -1599,22 +1651,11 @@ __global__ void k_catch_up(Tables tab, Tables tab_prev, const int* __restrict__ 
     }
 }
 
-extern "C" int ig_nuis_begin(ig_ctx* c, int32_t frag_a, const int32_t* cands, int32_t C, const float p_test[8], float mean_subfrag_kb)
+/* tab_prev := the state before the move about to be decided, then (second stream) the full pass under p_test on it */
+static int enqueue_nuis_pass(ig_ctx* c, const float p_test[8], float mean_subfrag_kb)
 {
-    HIPCK(hipSetDevice(c->device));
-    if (check_ready(c)) return -1;
-    if (c->world > 1) return fail("ig_nuis_begin: this handle scores a contact shard");
-    if (c->nuis_in_flight) return fail("ig_nuis_begin: the previous step was not ended (ig_nuis_end)");
-    if (validate_move(c, frag_a, cands, C)) return -1;
-    if (ensure_move_buffers(c, std::max(8, (int)C))) return -1;
-    if (ensure_io(c, 1, C)) return -1;
     if (!c->host_nuis) HIPCK(hipHostMalloc((void**)&c->host_nuis, sizeof(NuisHost), hipHostMallocDefault));
     if (!c->pz_tab1) DALLOC(c->pz_tab1, PZ_MAX);
-    c->host_nuis->frag = frag_a;
-    for (int i = 0; i < C; i++) c->host_nuis->cands[i] = cands[i];
-    HIPCK(hipMemcpyAsync(c->d_frags, &c->host_nuis->frag, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCK(hipMemcpyAsync(c->d_cands, c->host_nuis->cands, (size_t)C * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    c->nuis_in_flight = true;
     /* the nuisance pass first (second stream), the move behind it (library stream): the pass is the longer of the two and
      * would otherwise start only when the host is through with the move's dozen launches */
     hipLaunchKernelGGL(k_catch_up, dim3(16), dim3(256), 0, c->stream, c->tab, c->tab_prev, c->prev_touched, c->glob);
@@ -1632,6 +1673,28 @@ extern "C" int ig_nuis_begin(ig_ctx* c, int32_t frag_a, const int32_t* cands, in
     launch_full_nz(c, c->tab_prev, 1, c->scratch_nuis, PzTab{c->pz_tab1, c->pz_n1}, s3);
     hipLaunchKernelGGL(k_full_zero, dim3(128), dim3(256), 0, s3, c->tab_prev, c->glob, 1, c->M, c->scratch_nuis + 2);
     HIPCK(hipMemcpyAsync(c->host_nuis->sums, c->scratch_nuis, 8 * sizeof(long long), hipMemcpyDeviceToHost, s3));
+    return 0;
+}
+
+extern "C" int ig_nuis_begin(ig_ctx* c, int32_t frag_a, const int32_t* cands, int32_t C, const float p_test[8], float mean_subfrag_kb)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (check_ready(c)) return -1;
+    if (c->world > 1) return fail("ig_nuis_begin: this handle scores a contact shard");
+    if (c->nuis_in_flight) return fail("ig_nuis_begin: the previous step was not ended (ig_nuis_end)");
+    if (validate_move(c, frag_a, cands, C)) return -1;
+    if (ensure_move_buffers(c, std::max(8, (int)C))) return -1;
+    if (ensure_io(c, 1, C)) return -1;
+    if (!c->host_nuis) HIPCK(hipHostMalloc((void**)&c->host_nuis, sizeof(NuisHost), hipHostMallocDefault));
+    c->host_nuis->frag = frag_a;
+    for (int i = 0; i < C; i++) c->host_nuis->cands[i] = cands[i];
+    HIPCK(hipMemcpyAsync(c->d_frags, &c->host_nuis->frag, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCK(hipMemcpyAsync(c->d_cands, c->host_nuis->cands, (size_t)C * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    c->nuis_in_flight = true;
+    c->nuis_spec = false;
+    c->spec_valid = false;
+    c->spec_slot = 0;
+    if (enqueue_nuis_pass(c, p_test, mean_subfrag_kb)) return -1;
     /* the move */
     enqueue_move(c, 0, C, -1, 2);
     enqueue_apply(c, 0, 0, 0);
@@ -1641,11 +1704,135 @@ extern "C" int ig_nuis_begin(ig_ctx* c, int32_t frag_a, const int32_t* cands, in
     return 0;
 }
 
+/* ---- the same for a RUN of (move, nuisance step) pairs, the moves scored ahead in speculative batches ----------------------
+ * A rejected nuisance step changes nothing a move reads, so the moves behind it can be scored before its outcome is
+ * known: ig_nuis_run_begin uploads the lists of the run; ig_nuis_step_begin(i) enqueues step i's pass, scores a batch of
+ * moves starting at i if move i has no valid scores yet (first step, after an accepted step, after a conflict, batch used
+ * up), and decides + applies move i ALONE from its records (k_decide_batch over one slot); ig_nuis_end / ig_nuis_accept as
+ * above.  An accepted step invalidates the slots scored ahead.  Same results as one move and one step at a time. */
+static int nuis_spec_width(ig_ctx* c)
+{
+    static const int s_w = getenv("IG_NUIS_W") ? atoi(getenv("IG_NUIS_W")) : 0; /* 0: follow the run lengths */
+    const int cap = std::min(c->mb.capW, IG_MAX_BATCH);
+    if (s_w > 0) return std::min(s_w, cap);
+    if (c->spec_ema <= 0.0) c->spec_ema = 3.0;
+    return std::max(1, std::min(cap, (int)(1.5 * c->spec_ema + 1.5)));
+}
+
+extern "C" int ig_nuis_run_begin(ig_ctx* c, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (check_ready(c)) return -1;
+    if (c->world > 1) return fail("ig_nuis_run_begin: this handle scores a contact shard");
+    if (c->nuis_in_flight) return fail("ig_nuis_run_begin: a step is in flight (ig_nuis_end)");
+    if (n_moves <= 0) return fail("ig_nuis_run_begin: no moves");
+    if (max_c < 1 || max_c > IG_MAX_CANDIDATES) return fail("ig_nuis_run_begin: max_c out of range");
+    static const int s_cap = getenv("IG_NUIS_WMAX") ? atoi(getenv("IG_NUIS_WMAX")) : 12;
+    const int Wmax = c->init_links_inverse ? std::max(1, std::min(s_cap, max_batch_width(c, max_c))) : 1;
+    if (ensure_move_buffers(c, std::max(8, (int)max_c), Wmax)) return -1;
+    if (upload_moves(c, n_moves, frags, cands, max_c)) return -1;
+    c->nuis_spec = true;
+    c->spec_valid = false;
+    c->spec_prev_pending = false;
+    c->spec_base = c->spec_W = c->spec_next = c->spec_move = c->spec_slot = 0;
+    c->full_windows = false;
+    return 0;
+}
+
+/* the slots scored ahead are of no use any more (accepted step, conflict, used up): the width of the next batch follows the
+ * number of moves the batches get through (one that got through all of its slots counts double: the run was at least that long) */
+static void nuis_spec_invalidate(ig_ctx* c)
+{
+    if (c->spec_valid && c->spec_W > 0) {
+        const double len = (c->spec_next >= c->spec_W) ? 2.0 * c->spec_W : (double)c->spec_next;
+        c->spec_ema = 0.7 * (c->spec_ema > 0 ? c->spec_ema : 3.0) + 0.3 * len;
+    }
+    c->spec_valid = false;
+}
+
+/* score a batch of moves starting at `move` */
+static int nuis_spec_score(ig_ctx* c, int move)
+{
+    nuis_spec_invalidate(c);
+    const int W = std::min(nuis_spec_width(c), c->up_moves - move);
+    if (ensure_window_buffers(c)) return -1; /* the longest contig may have grown */
+    enqueue_score(c, move, W, c->up_max_c, -1, 2);
+    c->spec_base = move;
+    c->spec_W = W;
+    c->spec_next = 0;
+    c->spec_valid = true;
+    c->spec_prev_pending = false;
+    return 0;
+}
+
+extern "C" int ig_nuis_step_begin(ig_ctx* c, int32_t move, const float p_test[8], float mean_subfrag_kb)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (!c->nuis_spec) return fail("ig_nuis_step_begin: no run (ig_nuis_run_begin)");
+    if (c->nuis_in_flight) return fail("ig_nuis_step_begin: the previous step was not ended (ig_nuis_end)");
+    if (move != c->spec_move || move >= c->up_moves) return fail("ig_nuis_step_begin: move %d, expected %d of %d", move, c->spec_move, c->up_moves);
+    c->nuis_in_flight = true;
+    if (enqueue_nuis_pass(c, p_test, mean_subfrag_kb)) return -1;
+    if (!c->spec_valid || c->spec_next >= c->spec_W || c->spec_base + c->spec_next != move) {
+        if (nuis_spec_score(c, move)) return -1;
+    }
+    launch_commit(c, c->spec_base, c->spec_next + 1, c->spec_next, c->spec_prev_pending ? 0 : 1);
+    HIPCK(hipGetLastError());
+    return 0;
+}
+
+/* the host half of a step of a run: the decision of move spec_move is in (or the slot has to be scored again) */
+static int nuis_spec_finish(ig_ctx* c)
+{
+    for (int attempt = 0;; attempt++) {
+        int bo[12];
+        const int w = c->spec_next;
+        if (wait_commit(c, bo, w == 0, w)) return -1;
+        if (c->own_screened == 1 && w == 0 && !(bo[2] && bo[0] == 0 && bo[1] < 0))
+            c->exact_grid = std::min(c->mb.work_cap, std::max(4096, (int)(1.25 * bo[6]) + 2048));
+        if (bo[0] == w + 1) {
+            c->spec_prev_pending = false;
+            break;
+        }
+        if (bo[1] == w) { /* a windowed winner without a predicted delta: the one-move tail */
+            enqueue_apply(c, c->spec_base + w, w, 0);
+            c->n_batch_pending++;
+            c->spec_prev_pending = true;
+            break;
+        }
+        /* not decided: a contig of the move was modified by an earlier move of the batch (w > 0), or the first slot did not
+         * fit the slice pool / the exact kernel's grid: score a batch from this move */
+        if (w == 0) {
+            if (bo[2] == 1) {
+                if (grow_slice_pool(c)) return -1;
+            } else if (bo[2] == 2) {
+                if (c->exact_grid >= c->mb.work_cap) return fail("the exact kernel's work list cannot hold the first move of a batch");
+                c->exact_grid = std::min(c->mb.work_cap, c->exact_grid * 4);
+            } else {
+                Glob hg;
+                HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));
+                return fail("device-side consistency failure %d at move %d of a run", hg.error, c->spec_move);
+            }
+            c->spec_valid = false; /* says nothing about run lengths */
+        }
+        if (attempt > 8) return fail("move %d of a run could not be decided", c->spec_move);
+        if (nuis_spec_score(c, c->spec_move)) return -1;
+        launch_commit(c, c->spec_base, 1, 0, 0);
+    }
+    c->spec_slot = c->spec_next;
+    HIPCK(hipMemcpyAsync(&c->host_nuis->res, c->d_results + c->spec_move, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
+    if (queue_max_readback(c)) return -1;
+    c->spec_next++;
+    c->spec_move++;
+    return 0;
+}
+
 extern "C" int ig_nuis_end(ig_ctx* c, ig_move_result* out, double* nz_test, double* z_test, int64_t* limbs5)
 {
     HIPCK(hipSetDevice(c->device));
     if (!c->nuis_in_flight) return fail("ig_nuis_end: no step in flight");
     c->nuis_in_flight = false;
+    if (c->nuis_spec && nuis_spec_finish(c)) return -1;
     HIPCK(hipStreamSynchronize(c->stream));
     HIPCK(hipStreamSynchronize(c->stream3));
     HIPCK(hipGetLastError());
@@ -1676,15 +1863,15 @@ extern "C" int ig_nuis_end(ig_ctx* c, ig_move_result* out, double* nz_test, doub
  * exact sum under the new parameters on the CURRENT state = their full pass on the state before the last move (what the
  * step just evaluated, quirk Q12) + that move's exact delta under them (k_delta over the touched contigs); the zero-pixel sum
  * is recounted (O(M)) */
-__global__ void k_nuis_zero(MoveBuf mb, long long* scratch_z)
+__global__ void k_nuis_zero(MoveBuf mb, long long* scratch_z, int w)
 {
-    mb.ctl[0].d_hi = mb.ctl[0].d_lo = 0;
+    mb.ctl[w].d_hi = mb.ctl[w].d_lo = 0;
     for (int i = 0; i < 8; i++) scratch_z[i] = 0;
 }
-__global__ void k_nuis_promote(Glob* g, MoveBuf mb, const long long* __restrict__ full_sums, const long long* __restrict__ zero_sums)
+__global__ void k_nuis_promote(Glob* g, MoveBuf mb, const long long* __restrict__ full_sums, const long long* __restrict__ zero_sums, int w)
 {
     g->par[0] = g->par[1];
-    long long h = full_sums[0] + mb.ctl[0].d_hi, l = full_sums[1] + mb.ctl[0].d_lo;
+    long long h = full_sums[0] + mb.ctl[w].d_hi, l = full_sums[1] + mb.ctl[w].d_lo;
     ig_acc_normalize((int64_t*)&h, (int64_t*)&l);
     g->nz_hi = h;
     g->nz_lo = l;
@@ -1694,7 +1881,7 @@ __global__ void k_nuis_promote(Glob* g, MoveBuf mb, const long long* __restrict_
     g->z_hi = h;
     g->z_lo = l;
     if (zero_sums[2] != g->n_intra) g->error = 8; /* the pair count does not depend on the parameters */
-    mb.ctl[0].d_hi = mb.ctl[0].d_lo = 0;
+    mb.ctl[w].d_hi = mb.ctl[w].d_lo = 0;
 }
 
 extern "C" int ig_nuis_accept(ig_ctx* c)
@@ -1705,16 +1892,22 @@ extern "C" int ig_nuis_accept(ig_ctx* c)
     if (s_slow) { /* the plain way: set the parameters, recompute everything */
         const float p[8] = {c->nuis_test.kuhn, c->nuis_test.lm, c->nuis_test.c1, c->nuis_test.slope, c->nuis_test.d, c->nuis_test.d_max,
                             c->nuis_test.fact, c->nuis_test.v_inter};
-        return ig_set_params(c, p, c->nuis_mean_kb, 0);
+        const bool run = c->nuis_spec;
+        nuis_spec_invalidate(c);
+        const int rc = ig_set_params(c, p, c->nuis_mean_kb, 0);
+        c->nuis_spec = run;
+        return rc;
     }
     long long* zs = c->scratch8; /* the zero-pixel recount (the from-scratch passes' scratch is free between calls) */
-    hipLaunchKernelGGL(k_nuis_zero, dim3(1), dim3(1), 0, c->stream, c->mb, zs);
+    const int w = c->spec_slot; /* the slot of the move just applied (0 unless it came out of a batch: ig_nuis_step_begin) */
+    nuis_spec_invalidate(c);    /* whatever was scored ahead was scored under the old parameters */
+    hipLaunchKernelGGL(k_nuis_zero, dim3(1), dim3(1), 0, c->stream, c->mb, zs, w);
     const PzTab pz1{c->pz_tab1, c->pz_n1};
     /* the move's delta under the new parameters; contig membership of the partners as of BEFORE the move: tab_prev */
     hipLaunchKernelGGL(k_delta, dim3(DELTA_RB, 2, 1), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab_prev, c->tab_prev,
-                       c->prev_touched, c->glob, c->mb, c->lgf_tab, pz1, 0, 2, 1);
+                       c->prev_touched, c->glob, c->mb, c->lgf_tab, pz1, w, 2, 1);
     hipLaunchKernelGGL(k_full_zero, dim3(128), dim3(256), 0, c->stream, c->tab, c->glob, 1, c->M, zs);
-    hipLaunchKernelGGL(k_nuis_promote, dim3(1), dim3(1), 0, c->stream, c->glob, c->mb, c->scratch_nuis, zs);
+    hipLaunchKernelGGL(k_nuis_promote, dim3(1), dim3(1), 0, c->stream, c->glob, c->mb, c->scratch_nuis, zs, w);
     /* the tables of the model's parameter set: the test set's P_z table becomes the model's */
     std::swap(c->pz_tab, c->pz_tab1);
     std::swap(c->pz_n, c->pz_n1);
@@ -1917,6 +2110,13 @@ extern "C" int ig_debug_screen_stats(ig_ctx* c, double out4[6])
     out4[4] = (double)hg.scr_terms;
     out4[5] = (double)hg.scr_terms_exact;
     if (getenv("IG_SCREEN_STATS")) fprintf(stderr, "[screen] void columns %lld of %lld\n", hg.scr_void_cols, hg.scr_cols);
+    return 0;
+}
+
+/* the from-scratch pass with (1, default) / without (0) the count histograms of the all-trans tiles: same sums */
+extern "C" int ig_debug_set_full_hist(int on)
+{
+    g_full_hist = on ? 1 : 0;
     return 0;
 }
 

@@ -310,10 +310,12 @@ __device__ __forceinline__ int credit2_view(V view, const int* ip, const int* in
  * registers while the current one is decided) */
 __global__ void __launch_bounds__(64)
     k_decide_batch(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out,
-                   volatile int* host_out, int seq)
+                   volatile int* host_out, int seq, int resumed_plain)
 {
     /* w_start > 0: slot w_start - 1 was the pending move, meanwhile applied by the one-move kernels; the rest of the batch
-     * is still valid wherever it does not touch a contig modified so far (dirty_buf carries the list across the calls) */
+     * is still valid wherever it does not touch a contig modified so far (dirty_buf carries the list across the calls).
+     * resumed_plain: slot w_start - 1 was committed by an earlier launch of this kernel (a batch decided one move per call,
+     * ig_nuis_step_begin): its contigs are on the list already */
     __shared__ int dirty[IG_MAX_BATCH * 2 + 2];
     const int tid = threadIdx.x, lane = tid & 63;
     {
@@ -334,13 +336,15 @@ __global__ void __launch_bounds__(64)
         if (w_start > 0) {
             n_dirty = dirty_buf[0];
             for (int q = lane; q < n_dirty; q += 64) dirty[q] = dirty_buf[1 + q];
-            const MoveCtl pm = mb.ctl[w_start - 1];
-            const CandMeta& m = mb.meta[CW(w_start - 1, pm.ch_c)];
-            if (lane == 0) {
-                dirty[n_dirty] = m.ctgA;
-                dirty[n_dirty + 1] = m.ctgB;
+            if (!resumed_plain) {
+                const MoveCtl pm = mb.ctl[w_start - 1];
+                const CandMeta& m = mb.meta[CW(w_start - 1, pm.ch_c)];
+                if (lane == 0) {
+                    dirty[n_dirty] = m.ctgA;
+                    dirty[n_dirty + 1] = m.ctgB;
+                }
+                n_dirty += 2;
             }
-            n_dirty += 2;
         }
         /* Everything a decision reads is loaded TWO MOVES AHEAD (none of it depends on earlier decisions, only its
          * interpretation does): while move w is decided from registers with wave shuffles only, the loads of moves

@@ -1040,29 +1040,77 @@ __global__ void __launch_bounds__(256) k_full_nz(const int* __restrict__ crow, c
 #ifndef FULL_TILED_THREADS
 #define FULL_TILED_THREADS 1024
 #endif
+#define TILE_HB 64 /* bins of a tile's histogram of counts */
 struct TileWork {
     long long off; /* first contact of the item in the tiled array */
-    int n, bi, bj, pad;
+    int n, bi, bj;
+    int hist; /* -1, or: 2 x (index of the tile's count histogram) + (1 for the first item of the tile): every count of the tile is in 1 .. TILE_HB-1 */
 };
 struct FullTiledLds {
     ScoreTables tab;
     unsigned long long qtrans[LDS_LGF]; /* the quantised term of a trans pair with count ob (it depends on nothing else), + the rounding magic */
     int4 rrec[FULL_TB], crec[FULL_TB];
     long long red[2][FULL_TILED_THREADS / 64];
+    int shared_contig; /* the two blocks' signatures intersect */
 };
 __global__ void __launch_bounds__(FULL_TILED_THREADS)
     k_full_nz_tiled(const TileWork* __restrict__ work, const uint2* __restrict__ tc, const int4* __restrict__ rec, const int* __restrict__ len,
-                    const ScoreConst* __restrict__ sc, const double* __restrict__ lgf_tab, int M, int pz_n, long long* out)
+                    const ScoreConst* __restrict__ sc, const double* __restrict__ lgf_tab, int M, int pz_n, long long* out,
+                    const unsigned* __restrict__ sig, const unsigned* __restrict__ hist)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     FullTiledLds& L = *(FullTiledLds*)lds_raw;
     const TileWork wk = work[blockIdx.x];
+    const bool diag = wk.bi == wk.bj;
+    /* A tile between two blocks that share no contig (disjoint signatures, k_pack_tab_sig) holds trans pairs only, and a
+     * trans pair's term is a function of its count alone: the tile's sum is its (static) histogram of counts times the
+     * table of those terms -- the first item of the tile adds it, the tile's contacts are not read at all. */
+    bool all_trans = false;
+    if (sig && wk.hist >= 0 && !diag && sc->hot.fast) {
+        unsigned both = 0;
+        for (int i = threadIdx.x; i < SIG_WORDS; i += blockDim.x) both |= sig[(size_t)wk.bi * SIG_WORDS + i] & sig[(size_t)wk.bj * SIG_WORDS + i];
+        if (threadIdx.x == 0) L.shared_contig = 0;
+        __syncthreads();
+        if (both) L.shared_contig = 1;
+        __syncthreads();
+        all_trans = !L.shared_contig;
+        if (all_trans && !(wk.hist & 1)) return;
+    }
     {
         const float4* src = (const float4*)&sc->tab;
         float4* dst = (float4*)&L.tab;
         for (int i = threadIdx.x; i < (int)(sizeof(ScoreTables) / 16); i += blockDim.x) dst[i] = src[i];
     }
-    const bool diag = wk.bi == wk.bj;
+    if (all_trans) {
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const ig_hot hot = sc->hot;
+            const double lv = hot.log2_v_inter;
+            const double* T = L.tab.mt;
+            const unsigned o_b = threadIdx.x;
+            long long hi = 0, lo = 0;
+            if (o_b >= 1 && o_b < TILE_HB) {
+                const double ex = ig_exp2_core(lv, T), lg = lv * IG_LOG2_10_INV;
+                const double t = (ig_fma((double)o_b, lg, -ex) - L.tab.lgf[o_b]) + L.tab.pzc[LDS_PZ];
+                const unsigned long long bits =
+                    !(__builtin_fabs(t) < 524288.0) ? (unsigned long long)ig_quantize(t) + IG_QMAGIC_BITS : ig_d2u(ig_fma(t, IG_QSCALE, IG_QMAGIC));
+                const long long q = (long long)(bits - IG_QMAGIC_BITS);
+                const unsigned long long ql = (unsigned)q;
+                const long long qh = (q - (long long)ql) >> 32;
+                const unsigned long long n = hist[(size_t)(wk.hist >> 1) * TILE_HB + o_b];
+                const unsigned long long pl = n * ql; /* < 2^63: a tile holds fewer than 2^31 contacts */
+                hi = (long long)n * qh + (long long)(pl >> 32);
+                lo = (long long)(pl & 0xffffffffull);
+            }
+            hi = wave_sum_ll(hi);
+            lo = wave_sum_ll(lo);
+            if (threadIdx.x == 0) {
+                atomic_add_ll(&out[0], hi);
+                atomic_add_ll(&out[1], lo);
+            }
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < FULL_TB; i += blockDim.x) {
         const int gi = wk.bi * FULL_TB + i, gj = wk.bj * FULL_TB + i;
         L.rrec[i] = gi < M ? rec[gi] : make_int4(0, 0, -1, 0);

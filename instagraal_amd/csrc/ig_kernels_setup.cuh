@@ -37,6 +37,27 @@ __global__ void k_pack_tab(Tables t, int M, int4* __restrict__ rec)
     rec[s] = make_int4(__float_as_int(t.dist[s]), __float_as_int(t.stot[s]), cp.x, cp.y);
 }
 
+/* the same, one workgroup per block of FULL_TB sub-fragments (the tiles of k_full_nz_tiled), which also leaves the block's
+ * SIGNATURE: bit (contig id mod 32 SIG_WORDS) of every contig with a sub-fragment in the block.  Two blocks whose signatures
+ * do not intersect share no contig: every contact between them is a trans pair. */
+#define SIG_WORDS 256
+__global__ void __launch_bounds__(256) k_pack_tab_sig(Tables t, int M, int4* __restrict__ rec, unsigned* __restrict__ sig, int tb)
+{
+    __shared__ unsigned lsig[SIG_WORDS];
+    for (int i = threadIdx.x; i < SIG_WORDS; i += blockDim.x) lsig[i] = 0;
+    __syncthreads();
+    const int s0 = blockIdx.x * tb;
+    for (int i = threadIdx.x; i < tb && s0 + i < M; i += blockDim.x) {
+        const int s = s0 + i;
+        const int2 cp = t.cp[s];
+        rec[s] = make_int4(__float_as_int(t.dist[s]), __float_as_int(t.stot[s]), cp.x, cp.y);
+        const unsigned h = (unsigned)cp.x & (32u * SIG_WORDS - 1u);
+        atomicOr(&lsig[h >> 5], 1u << (h & 31u));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SIG_WORDS; i += blockDim.x) sig[(size_t)blockIdx.x * SIG_WORDS + i] = lsig[i];
+}
+
 /* eval_likelihood_on_zero (KA:3850-3917) over all sub-fragments -> out[0..2] = hi, lo, n_intra */
 __global__ void k_full_zero(Tables t, const Glob* g, int which, int M, long long* out)
 {

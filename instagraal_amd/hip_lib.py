@@ -165,6 +165,12 @@ def set_batch_width(w):
     _ck(lib().ig_set_batch_width(C.c_int(int(w))))
 
 
+def debug_set_full_hist(on):
+    """from-scratch pass over all contacts: tiles of trans pairs only from their count histograms (default) or contact by
+    contact -- same exact sums (tests)"""
+    _ck(lib().ig_debug_set_full_hist(C.c_int(int(on))))
+
+
 class Context:
     """One handle per sampler (ig_create .. ig_destroy)."""
 
@@ -284,6 +290,17 @@ class Context:
         c = np.ascontiguousarray(cands, np.int32)
         p = np.ascontiguousarray(p_test8, np.float32)
         _ck(lib().ig_nuis_begin(self._h, C.c_int32(int(frag_a)), _p(c), C.c_int32(c.size), _p(p), C.c_float(float(mean_subfrag_kb))))
+
+    def nuis_run_begin(self, frags, cands):
+        """the lists of a run of (move, nuisance step) pairs: the moves are scored ahead in batches (ig_nuis_run_begin)"""
+        f = np.ascontiguousarray(frags, np.int32)
+        c = np.ascontiguousarray(cands, np.int32)
+        assert c.ndim == 2 and c.shape[0] == f.size
+        _ck(lib().ig_nuis_run_begin(self._h, C.c_int32(f.size), _p(f), _p(c), C.c_int32(c.shape[1])))
+
+    def nuis_step_begin(self, move, p_test8, mean_subfrag_kb):
+        p = np.ascontiguousarray(p_test8, np.float32)
+        _ck(lib().ig_nuis_step_begin(self._h, C.c_int32(int(move)), _p(p), C.c_float(float(mean_subfrag_kb))))
 
     def nuis_end(self):
         res = MoveResult()

@@ -407,7 +407,8 @@ class sampler:  # noqa: N801 - the reference's class name
         self.set_param_simu(out, 1)
         self.likelihood_nuis = self.eval_likelihood_4_nuisance()
         F_t = self.temperature(t, n_step)
-        ratio = np.exp((self.likelihood_nuis - self.likelihood_t) / F_t)
+        with np.errstate(over="ignore"):  # a much better likelihood at a low temperature: inf >= u, accepted
+            ratio = np.exp((self.likelihood_nuis - self.likelihood_t) / F_t)
         u = np.random.rand()
         success = 0
         if ratio >= u:
@@ -425,7 +426,9 @@ class sampler:  # noqa: N801 - the reference's class name
         * the stream of the whole run is drawn up front in the library (candidate lists, choice(4), the standard normal
           behind normal(0, sigma), the acceptance uniform: its consumption does not depend on the parameters);
         * the nuisance step's pass over all contacts reads the state BEFORE the move (quirk Q12) and only needs the move's
-          score besides: it runs next to the move (``ig_nuis_begin`` / ``ig_nuis_end``);
+          score besides: it runs next to the move (``ig_nuis_step_begin`` / ``ig_nuis_end``);
+        * a rejected step changes nothing a move reads: the moves are scored ahead in batches and decided one per step
+          (``ig_nuis_run_begin``); an accepted step discards what was scored ahead;
         * while both run, the host prepares the next step's proposal (the root finding for d_max, CL:2983) for the case
           that this step is rejected.
 
@@ -457,10 +460,10 @@ class sampler:  # noqa: N801 - the reference's class name
         curr = np.copy(self.param_simu)
         out = proposal(0, curr)
         names = res.dtype.names
+        self.ctx.nuis_run_begin(frags, cands)
         for i in range(n):
             ta = _t.perf_counter()
-            c = cands[i][cands[i] >= 0]
-            self.ctx.nuis_begin(int(frags[i]), c, [out[k][0] for k in PARAM_NAMES], mean_kb)
+            self.ctx.nuis_step_begin(i, [out[k][0] for k in PARAM_NAMES], mean_kb)
             t1 = _t.perf_counter()
             # while the GPU works: the next step's proposal for both outcomes of this one (the root finding for d_max is
             # the expensive part of a step on the host)
@@ -474,7 +477,8 @@ class sampler:  # noqa: N801 - the reference's class name
             self.param_simu_test = out
             self.likelihood_t = r.o
             self.likelihood_nuis = np.array([nz]) + z
-            ratio = np.exp((self.likelihood_nuis - self.likelihood_t) / self.temperature(t0 + i, n_step))
+            with np.errstate(over="ignore"):
+                ratio = np.exp((self.likelihood_nuis - self.likelihood_t) / self.temperature(t0 + i, n_step))
             success = 0
             t4 = _t.perf_counter()
             if ratio >= unif[i]:

@@ -50,6 +50,7 @@ def _valid_linear_contigs(state, n_check=200):
 def test_cfg2_live_oracle_then_properties():
     """BASELINE.json configs[1]: synthetic 5 k fragments / 2 M contacts."""
     from instagraal_amd import hip_lib, synth
+    from instagraal_amd.sampler import PARAM_NAMES
     from oracle import oracle_lib as ol
     from oracle.sampler_oracle import OracleSampler
 
@@ -87,6 +88,18 @@ def test_cfg2_live_oracle_then_properties():
             sums, _ = s.ctx.debug_globals()
             _, _, limbs = s.ctx.full_likelihood(0)
             assert [int(x) for x in sums[:5]] == [int(x) for x in limbs[:5]], W
+            if W == 24:
+                # the from-scratch pass sums the tiles of trans pairs only from their count histograms: same limbs contact
+                # by contact, under the model's parameters and under another set
+                p1 = dict(prob.params, slope=np.float32(-1.1), fact=np.float32(prob.params["fact"] * 1.7))
+                s.ctx.set_params([np.float32(p1[k]) for k in PARAM_NAMES], s.mean_kb(), 1)
+                _, _, limbs1 = s.ctx.full_likelihood(1)
+                hip_lib.debug_set_full_hist(0)
+                try:
+                    assert [int(x) for x in s.ctx.full_likelihood(0)[2]] == [int(x) for x in limbs]
+                    assert [int(x) for x in s.ctx.full_likelihood(1)[2]] == [int(x) for x in limbs1]
+                finally:
+                    hip_lib.debug_set_full_hist(1)
             outs.append((res.tobytes(), s.gpu_vect_frags.copy_from_gpu().soa17(), [int(x) for x in s.ctx.valid_insert()],
                          s.ctx.batch_stats()))
             s.free_gpu()

@@ -22,13 +22,18 @@ s.eval_likelihood_init()
 np.random.seed(0)
 frags = np.random.permutation(prob.n_frags)[: 2 * n + 40]
 s.step_sampler_nuisance_batch(frags[:20], 5, s.dt, 0, n)
+b0 = s.ctx.batch_stats()
 t0 = time.perf_counter()
 res, tup = s.step_sampler_nuisance_batch(frags[20:20 + n], 5, s.dt, 0, n)
 dt = time.perf_counter() - t0
 print("%s: %.0f moves/s through step_sampler_nuisance_batch (accept rate %.2f)" % (cfg, n / dt, np.mean([q[6] for q in tup])))
+b1 = s.ctx.batch_stats()
+print("   batches scored: %d for %d moves; one-move tails %d" % (b1["batches"] - b0["batches"], n, b1["one_move_tails"] - b0["one_move_tails"]))
 if hasattr(s, "nuis_profile"):
     tot = sum(s.nuis_profile.values())
     print("   host time per move: " + ", ".join("%s %.0f us" % (k, 1e6 * v / n) for k, v in s.nuis_profile.items()) + " (sum %.0f us)" % (1e6 * tot / n))
+if os.environ.get("NUIS_ONLY"):
+    sys.exit(0)
 t_s = t_n = 0.0
 rest = frags[20 + n:20 + n + min(n, 100)]
 for t, f in enumerate(rest):
