@@ -155,6 +155,11 @@ int ig_nuis_accept(ig_ctx* ctx);
  * param_simu ends the run. */
 int ig_nuis_run_begin(ig_ctx* ctx, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c);
 int ig_nuis_step_begin(ig_ctx* ctx, int32_t move, const float p_test[8], float mean_subfrag_kb);
+/* ig_nuis_end + the acceptance test (CL:3026-3036: exp((L_test - L_move) / temperature) >= u) + ig_nuis_accept + the next
+ * move's ig_nuis_step_begin (test parameters for both outcomes supplied) in one call; *accepted = 0 / 1, or 2: a close call
+ * (within 1e-9 relative), nothing decided or enqueued, the caller does it with its own exp(). */
+int ig_nuis_step_next(ig_ctx* ctx, double temperature, double u, const float p_next_rejected[8], const float p_next_accepted[8],
+                      float mean_subfrag_kb, int32_t has_next, ig_move_result* out, double* nz_test, double* z_test, int32_t* accepted);
 
 /* ---- bookkeeping -------------------------------------------------------- */
 int ig_renumber_contigs(ig_ctx* ctx, int32_t* n_contigs, float* mean_len, int32_t* max_id); /* CL:2715-2881 */
@@ -197,6 +202,7 @@ int ig_debug_transcendental_error(ig_ctx* ctx, double out2[2]);
 int ig_debug_screen_stats(ig_ctx* ctx, double out6[6]); /* ..., terms screened, terms scored exactly */
 /* 0 disables the reference's dropped-tail behaviour of eval_sub_likelihood (quirk Q5); default 1 */
 int ig_debug_set_tail_quirk(int on);
+int ig_debug_tile_trace(ig_ctx* ctx, int64_t* out4n, int64_t cap, int64_t* n_items); /* per-workgroup clocks of one from-scratch pass */
 int ig_debug_set_full_hist(int on); /* from-scratch pass: all-trans tiles from their count histograms (1, default) or contact by contact (0) */
 
 #ifdef __cplusplus

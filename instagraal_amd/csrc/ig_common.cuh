@@ -244,6 +244,10 @@ struct ig_ctx {
     uint2* tiled_cc;
     struct TileWork* tile_work;
     int n_tile_work;
+    long long* tile_trace; /* ig_debug_tile_trace */
+    int n_tile_static, n_tile_info; /* work items k_full_nz_tiled is launched over; off-diagonal tiles with a histogram */
+    struct TileInfo* tile_info;
+    int *tile_dyn, *tile_dyn_list;  /* {count, cursor} and the work items of the tiles whose contacts have to be read this pass */
     unsigned *tile_hist, *tile_sig; /* count histograms of the off-diagonal tiles (static); contig signatures of the blocks (per pass) */
     int* init_prev;
     int* init_next;

@@ -287,6 +287,9 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipFree(c->tile_work);
     hipFree(c->tile_hist);
     hipFree(c->tile_sig);
+    hipFree(c->tile_info);
+    hipFree(c->tile_dyn);
+    hipFree(c->tile_dyn_list);
     hipFree(c->init_prev);
     hipFree(c->init_next);
     hipFree(c->orientable);
@@ -331,34 +334,69 @@ extern "C" int ig_set_stream(ig_ctx* c, void* s)
 }
 
 /* the from-scratch likelihood of the non-zero pixels under tables `t` and parameter set `which` -> out[0..1] */
+__global__ void k_set_par(Glob* g, int which, ig_params p, float mean_kb)
+{
+    g->par[which] = p;
+    g->mean_kb = mean_kb;
+}
 static int g_full_hist = -1;
-static void launch_full_nz(ig_ctx* c, const Tables& t, int which, long long* out, PzTab pz, hipStream_t stream = nullptr)
+/* the from-scratch pass over all contacts under parameter set `which` -> out[0..1]; zero_out: the zero-pixel pass too
+ * (-> zero_out[0..5], k_full_zero).  p_host: the set's parameters, not yet on the device (a nuisance step's test set): the
+ * launches that would set them, build their tables and clear `out` (8 values) are part of the pass.
+ * Returns true when the zero-pixel pass was taken care of. */
+static bool launch_full_nz(ig_ctx* c, const Tables& t, int which, long long* out, PzTab pz, hipStream_t stream = nullptr,
+                           long long* zero_out = nullptr, const ig_params* p_host = nullptr, float mean_kb = 0.0f)
 {
     static int s_wgs = getenv("IG_FULL_WGS") ? atoi(getenv("IG_FULL_WGS")) : 8 * 256;
-    if (c->Z <= 0) return;
     if (!stream) stream = c->stream;
     static const int s_tiled = getenv("IG_FULL_TILED") ? atoi(getenv("IG_FULL_TILED")) : 1;
     if (g_full_hist < 0) g_full_hist = getenv("IG_FULL_HIST") ? atoi(getenv("IG_FULL_HIST")) : 1; /* 0: read every tile's contacts */
     const int s_hist = g_full_hist;
     const bool tiled = s_tiled && c->tiled_cc && c->n_tile_work > 0;
-    if (tiled)
-        hipLaunchKernelGGL(k_pack_tab_sig, dim3((c->M + FULL_TB - 1) / FULL_TB), dim3(256), 0, stream, t, c->M, c->tabrec, c->tile_sig, FULL_TB);
-    else
-        hipLaunchKernelGGL(k_pack_tab, dim3((c->M + 255) / 256), dim3(256), 0, stream, t, c->M, c->tabrec);
-    /* the tables of this parameter set (k_score_list's own block is parameter set 0's) */
-    hipLaunchKernelGGL(k_build_score_const, dim3((LDS_PZ + 2 + 255) / 256), dim3(256), 0, stream, c->glob, pz, c->lgf_tab, c->full_const, which);
+    const int n_pack = (c->M + FULL_TB - 1) / FULL_TB;
+    if (p_host && tiled) {
+        const int n_const = (std::max(std::max(pz.n, LDS_PZ + 2), std::max((int)IG_TAB_SIZE, LDS_LGF)) + 255) / 256;
+        hipLaunchKernelGGL(k_nuis_prepare, dim3(n_pack + n_const), dim3(256), 0, stream, c->glob, which, *p_host, mean_kb, (float*)pz.v, pz.n, c->lgf_tab,
+                           c->full_const, out, t, c->M, c->tabrec, c->tile_sig, FULL_TB, c->tile_dyn, n_pack);
+    } else {
+        if (p_host) {
+            hipLaunchKernelGGL(k_set_par, dim3(1), dim3(1), 0, stream, c->glob, which, *p_host, mean_kb);
+            if (pz.n > 0) hipLaunchKernelGGL(k_build_pz, dim3((pz.n + 255) / 256), dim3(256), 0, stream, c->glob, (float*)pz.v, pz.n, which);
+            hipMemsetAsync(out, 0, 8 * sizeof(long long), stream);
+        }
+        if (c->Z <= 0) return false;
+        if (tiled)
+            hipLaunchKernelGGL(k_pack_tab_sig, dim3(n_pack), dim3(256), 0, stream, t, c->M, c->tabrec, c->tile_sig, FULL_TB, c->tile_dyn);
+        else
+            hipLaunchKernelGGL(k_pack_tab, dim3((c->M + 255) / 256), dim3(256), 0, stream, t, c->M, c->tabrec);
+        /* the tables of this parameter set (k_score_list's own block is parameter set 0's) */
+        hipLaunchKernelGGL(k_build_score_const, dim3((LDS_PZ + 2 + 255) / 256), dim3(256), 0, stream, c->glob, pz, c->lgf_tab, c->full_const, which);
+    }
     if (tiled) {
-        /* next to a move (the nuisance step's pass, ig_nuis_begin): one workgroup per CU -- the request is padded beyond half
-         * of the LDS -- so that the move's own small workgroups find room on every CU instead of queueing behind this pass */
-        static const int s_pad = getenv("IG_FULL_LDS_PAD") ? atoi(getenv("IG_FULL_LDS_PAD")) : 100 * 1024;
-        const size_t lds = (stream != c->stream) ? std::max<size_t>(sizeof(FullTiledLds), (size_t)s_pad) : sizeof(FullTiledLds);
-        static const int s_thr = getenv("IG_FULL_THREADS") ? atoi(getenv("IG_FULL_THREADS")) : FULL_TILED_THREADS;
-        hipLaunchKernelGGL(k_full_nz_tiled, dim3(c->n_tile_work), dim3((stream != c->stream) ? s_thr : FULL_TILED_THREADS), lds, stream, c->tile_work, c->tiled_cc,
-                           c->tabrec, t.len, c->full_const, c->lgf_tab, c->M, pz.n, out, s_hist ? c->tile_sig : nullptr, c->tile_hist);
-        return;
+        /* the off-diagonal tiles: summed from their count histograms where the two blocks share no contig, else put on the
+         * list; in the same launch (blocks behind those of the tiles) the zero-pixel pass */
+        const int per = TILE_TRANS_THREADS / 64;
+        const int n_trans = (c->n_tile_info + per - 1) / per, n_zero = zero_out ? 32 : 0;
+        if (n_trans + n_zero > 0)
+            hipLaunchKernelGGL(k_tile_trans, dim3(n_trans + n_zero), dim3(TILE_TRANS_THREADS), 0, stream, c->tile_info, c->n_tile_info, c->tile_sig,
+                               c->tile_hist, c->full_const, (TileDyn*)c->tile_dyn, c->tile_dyn_list, s_hist, out, n_trans, t, c->glob, which,
+                               c->M, zero_out);
+        /* persistent workgroups over the static items and then the list */
+        /* two per CU; next to a move (the nuisance step's pass, on its own stream) one per CU: persistent workgroups that took
+         * every wave slot would keep the move's kernels waiting until the pass is over (k_decide_batch: 70 instead of 12 us),
+         * and the pass is bound by its arithmetic, not by its occupancy */
+        static const int s_grid = getenv("IG_FULL_GRID") ? atoi(getenv("IG_FULL_GRID")) : 512;
+        static const int s_grid_side = getenv("IG_FULL_GRID_SIDE") ? atoi(getenv("IG_FULL_GRID_SIDE")) : 256;
+        const int grid = std::min(c->n_tile_work, stream != c->stream ? s_grid_side : s_grid);
+        if (grid > 0)
+            hipLaunchKernelGGL(k_full_nz_tiled, dim3(grid), dim3(FULL_TILED_THREADS), sizeof(FullTiledLds), stream, c->tile_work, c->tiled_cc,
+                               c->tabrec, t.len, c->full_const, c->lgf_tab, c->M, pz.n, out, c->n_tile_static, (TileDyn*)c->tile_dyn,
+                               c->tile_dyn_list, c->tile_trace);
+        return zero_out != nullptr;
     }
     hipLaunchKernelGGL(k_full_nz, dim3(s_wgs), dim3(256), 0, stream, c->crow, c->cc, c->tabrec, t.len, c->full_const, c->lgf_tab,
                        (long long)c->Z, pz.n, out);
+    return false;
 }
 
 /* The per-window arrays are strided by the largest window the genome can produce NOW: a window is the contig of the focal
@@ -522,6 +560,12 @@ extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* 
     hipFree(c->tile_work);
     hipFree(c->tile_hist);
     hipFree(c->tile_sig);
+    hipFree(c->tile_info);
+    hipFree(c->tile_dyn);
+    hipFree(c->tile_dyn_list);
+    c->tile_info = nullptr;
+    c->tile_dyn = nullptr;
+    c->tile_dyn_list = nullptr;
     c->tiled_cc = nullptr;
     c->tile_work = nullptr;
     c->tile_hist = nullptr;
@@ -539,33 +583,44 @@ extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* 
             for (int64_t k = 0; k < Z; k++) tptr[(size_t)((row[k] / FULL_TB) * nb + col[k] / FULL_TB) + 1]++;
             for (size_t i = 1; i < tptr.size(); i++) tptr[i] += tptr[i - 1];
             /* histogram of the counts of every off-diagonal tile (a tile that turns out to hold trans pairs only is summed
-             * from it, k_full_nz_tiled); -1: a count outside 1 .. TILE_HB-1 */
+             * from it, k_tile_trans); tiles with a count outside 1 .. TILE_HB-1 have none: their items are static, like the
+             * diagonal tiles' */
             std::vector<int> tile_hist((size_t)(nb * nb), -1);
             std::vector<unsigned> hist;
+            std::vector<TileInfo> tiles;
             {
                 std::vector<char> bad((size_t)(nb * nb), 0);
                 for (int64_t k = 0; k < Z; k++)
                     if (cnt[k] < 1 || cnt[k] >= TILE_HB) bad[(size_t)((row[k] / FULL_TB) * nb + col[k] / FULL_TB)] = 1;
-                int n_hist = 0;
                 for (int64_t bi = 0; bi < nb; bi++)
                     for (int64_t bj = bi + 1; bj < nb; bj++) {
                         const size_t t = (size_t)(bi * nb + bj);
-                        if (!bad[t] && tptr[t + 1] > tptr[t] && tptr[t + 1] - tptr[t] < (1LL << 31)) tile_hist[t] = n_hist++;
+                        if (!bad[t] && tptr[t + 1] > tptr[t] && tptr[t + 1] - tptr[t] < (1LL << 31)) {
+                            tile_hist[t] = (int)tiles.size();
+                            tiles.push_back(TileInfo{(int)bi, (int)bj, 0, 0});
+                        }
                     }
-                hist.assign((size_t)std::max(n_hist, 1) * TILE_HB, 0u);
+                hist.assign(std::max<size_t>(tiles.size(), 1) * TILE_HB, 0u);
                 for (int64_t k = 0; k < Z; k++) {
                     const int h = tile_hist[(size_t)((row[k] / FULL_TB) * nb + col[k] / FULL_TB)];
                     if (h >= 0) hist[(size_t)h * TILE_HB + cnt[k]]++;
                 }
             }
+            /* work items: the static ones first (k_full_nz_tiled's grid), then those of the tiles with a histogram */
             std::vector<TileWork> work;
-            for (int64_t bi = 0; bi < nb; bi++)
-                for (int64_t bj = bi; bj < nb; bj++) {
-                    const int64_t b = tptr[(size_t)(bi * nb + bj)], e = tptr[(size_t)(bi * nb + bj) + 1];
-                    const int h = tile_hist[(size_t)(bi * nb + bj)];
-                    for (int64_t o = b; o < e; o += FULL_CHUNK)
-                        work.push_back(TileWork{(long long)o, (int)std::min<int64_t>(FULL_CHUNK, e - o), (int)bi, (int)bj, h < 0 ? -1 : 2 * h + (o == b ? 1 : 0)});
-                }
+            for (int pass = 0; pass < 2; pass++) {
+                for (int64_t bi = 0; bi < nb; bi++)
+                    for (int64_t bj = bi; bj < nb; bj++) {
+                        const int64_t b = tptr[(size_t)(bi * nb + bj)], e = tptr[(size_t)(bi * nb + bj) + 1];
+                        const int h = tile_hist[(size_t)(bi * nb + bj)];
+                        if ((h >= 0) != (pass == 1)) continue;
+                        if (h >= 0) tiles[(size_t)h].first_item = (int)work.size();
+                        for (int64_t o = b; o < e; o += FULL_CHUNK)
+                            work.push_back(TileWork{(long long)o, (int)std::min<int64_t>(FULL_CHUNK, e - o), (int)bi, (int)bj, 0});
+                        if (h >= 0) tiles[(size_t)h].n_items = (int)work.size() - tiles[(size_t)h].first_item;
+                    }
+                if (pass == 0) c->n_tile_static = (int)work.size();
+            }
             std::vector<uint2> tc((size_t)Z);
             std::vector<int64_t> cur(tptr.begin(), tptr.end() - 1);
             for (int64_t k = 0; k < Z; k++) {
@@ -576,9 +631,14 @@ extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* 
             DALLOC(c->tile_work, work.size());
             DALLOC(c->tile_hist, hist.size());
             DALLOC(c->tile_sig, (size_t)nb * SIG_WORDS);
+            DALLOC(c->tile_info, std::max<size_t>(tiles.size(), 1));
+            DALLOC(c->tile_dyn, 2);
+            DALLOC(c->tile_dyn_list, std::max<size_t>(work.size() - (size_t)c->n_tile_static, 1));
             HIPCK(hipMemcpy(c->tiled_cc, tc.data(), (size_t)Z * sizeof(uint2), hipMemcpyHostToDevice));
             HIPCK(hipMemcpy(c->tile_work, work.data(), work.size() * sizeof(TileWork), hipMemcpyHostToDevice));
             HIPCK(hipMemcpy(c->tile_hist, hist.data(), hist.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+            if (!tiles.empty()) HIPCK(hipMemcpy(c->tile_info, tiles.data(), tiles.size() * sizeof(TileInfo), hipMemcpyHostToDevice));
+            c->n_tile_info = (int)tiles.size();
             c->n_tile_work = (int)work.size();
         }
     }
@@ -922,8 +982,8 @@ extern "C" int ig_full_likelihood(ig_ctx* c, int which, int use_prev, double* nz
     Tables& t = use_prev ? c->tab_prev : c->tab;
     /* which == 1 before any ig_set_params(.., 1): no table yet, every P_z is evaluated directly */
     const PzTab pz = which == 0 ? PzTab{c->pz_tab, c->pz_n} : PzTab{c->pz_tab1, c->pz_tab1 ? c->pz_n1 : 0};
-    launch_full_nz(c, t, which, scratch, pz);
-    hipLaunchKernelGGL(k_full_zero, dim3(128), dim3(256), 0, c->stream, t, c->glob, which, c->M, scratch + 2);
+    if (!launch_full_nz(c, t, which, scratch, pz, nullptr, scratch + 2))
+        hipLaunchKernelGGL(k_full_zero, dim3(128), dim3(256), 0, c->stream, t, c->glob, which, c->M, scratch + 2);
     long long h[8];
     HIPCK(hipMemcpyAsync(h, scratch, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
@@ -1633,11 +1693,6 @@ struct NuisHost {
     long long sums[8];
     int frag, cands[IG_MAX_CANDIDATES]; /* the move's lists: the asynchronous upload reads them after ig_nuis_begin returned */
 };
-__global__ void k_set_par(Glob* g, int which, ig_params p, float mean_kb)
-{
-    g->par[which] = p;
-    g->mean_kb = mean_kb;
-}
 /* tab_prev := the state before the move about to be scored (what k_gather does first thing; here ahead of it, so that the
  * nuisance pass can start next to the move instead of behind its launches) */
 __global__ void k_catch_up(Tables tab, Tables tab_prev, const int* __restrict__ prev_touched, const Glob* g)
@@ -1667,11 +1722,8 @@ static int enqueue_nuis_pass(ig_ctx* c, const float p_test[8], float mean_subfra
     c->pz_n1 = (need > 0 && need < (double)PZ_MAX) ? (int)need : ((need >= (double)PZ_MAX) ? PZ_MAX : 0);
     hipStream_t s3 = c->stream3;
     HIPCK(hipStreamWaitEvent(s3, c->ev_gathered, 0));
-    hipLaunchKernelGGL(k_set_par, dim3(1), dim3(1), 0, s3, c->glob, 1, hp, mean_subfrag_kb);
-    if (c->pz_n1 > 0) hipLaunchKernelGGL(k_build_pz, dim3((c->pz_n1 + 255) / 256), dim3(256), 0, s3, c->glob, c->pz_tab1, c->pz_n1, 1);
-    HIPCK(hipMemsetAsync(c->scratch_nuis, 0, 8 * sizeof(long long), s3));
-    launch_full_nz(c, c->tab_prev, 1, c->scratch_nuis, PzTab{c->pz_tab1, c->pz_n1}, s3);
-    hipLaunchKernelGGL(k_full_zero, dim3(128), dim3(256), 0, s3, c->tab_prev, c->glob, 1, c->M, c->scratch_nuis + 2);
+    if (!launch_full_nz(c, c->tab_prev, 1, c->scratch_nuis, PzTab{c->pz_tab1, c->pz_n1}, s3, c->scratch_nuis + 2, &hp, mean_subfrag_kb))
+        hipLaunchKernelGGL(k_full_zero, dim3(128), dim3(256), 0, s3, c->tab_prev, c->glob, 1, c->M, c->scratch_nuis + 2);
     HIPCK(hipMemcpyAsync(c->host_nuis->sums, c->scratch_nuis, 8 * sizeof(long long), hipMemcpyDeviceToHost, s3));
     return 0;
 }
@@ -1777,6 +1829,9 @@ extern "C" int ig_nuis_step_begin(ig_ctx* c, int32_t move, const float p_test[8]
         if (nuis_spec_score(c, move)) return -1;
     }
     launch_commit(c, c->spec_base, c->spec_next + 1, c->spec_next, c->spec_prev_pending ? 0 : 1);
+    /* the result record on its way as soon as the move is applied (copied again in the rare cases ig_nuis_end has to redo the move) */
+    HIPCK(hipMemcpyAsync(&c->host_nuis->res, c->d_results + move, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
+    if (queue_max_readback(c)) return -1;
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -1784,6 +1839,7 @@ extern "C" int ig_nuis_step_begin(ig_ctx* c, int32_t move, const float p_test[8]
 /* the host half of a step of a run: the decision of move spec_move is in (or the slot has to be scored again) */
 static int nuis_spec_finish(ig_ctx* c)
 {
+    bool redone = false;
     for (int attempt = 0;; attempt++) {
         int bo[12];
         const int w = c->spec_next;
@@ -1798,6 +1854,7 @@ static int nuis_spec_finish(ig_ctx* c)
             enqueue_apply(c, c->spec_base + w, w, 0);
             c->n_batch_pending++;
             c->spec_prev_pending = true;
+            redone = true;
             break;
         }
         /* not decided: a contig of the move was modified by an earlier move of the batch (w > 0), or the first slot did not
@@ -1818,10 +1875,13 @@ static int nuis_spec_finish(ig_ctx* c)
         if (attempt > 8) return fail("move %d of a run could not be decided", c->spec_move);
         if (nuis_spec_score(c, c->spec_move)) return -1;
         launch_commit(c, c->spec_base, 1, 0, 0);
+        redone = true;
     }
     c->spec_slot = c->spec_next;
-    HIPCK(hipMemcpyAsync(&c->host_nuis->res, c->d_results + c->spec_move, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
-    if (queue_max_readback(c)) return -1;
+    if (redone) {
+        HIPCK(hipMemcpyAsync(&c->host_nuis->res, c->d_results + c->spec_move, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
+        if (queue_max_readback(c)) return -1;
+    }
     c->spec_next++;
     c->spec_move++;
     return 0;
@@ -1915,6 +1975,33 @@ extern "C" int ig_nuis_accept(ig_ctx* c)
     hipLaunchKernelGGL(k_build_score_const, dim3((LDS_PZ + 2 + 255) / 256), dim3(256), 0, c->stream, c->glob, pz0, c->lgf_tab, c->score_const, 0);
     hipLaunchKernelGGL(k_build_screen_const, dim3((LDS_PZ + 2 + 255) / 256), dim3(256), 0, c->stream, c->glob, pz0, c->screen_const);
     HIPCK(hipGetLastError());
+    return 0;
+}
+
+/* ig_nuis_end, the Metropolis decision of step_nuisance_parameters (CL:3026-3036: ratio = exp((L_test - L_move) / T) >= u),
+ * ig_nuis_accept and the next move's ig_nuis_step_begin in ONE call: between the end of a step's kernels and the first
+ * launch of the next step there is no host code but this.  The caller supplies the next step's test parameters for both
+ * outcomes (they are prepared while this step's kernels run).  *accepted: 0 / 1, or 2 when exp() lands within 1e-9
+ * relative of u -- then nothing was decided or enqueued and the caller goes on with its own arithmetic (ig_nuis_accept,
+ * ig_nuis_step_begin). */
+extern "C" int ig_nuis_step_next(ig_ctx* c, double temperature, double u, const float p_next_rejected[8], const float p_next_accepted[8],
+                                 float mean_subfrag_kb, int32_t has_next, ig_move_result* out, double* nz_test, double* z_test, int32_t* accepted)
+{
+    if (!c->nuis_spec) return fail("ig_nuis_step_next: no run (ig_nuis_run_begin)");
+    double nz = 0.0, z = 0.0;
+    if (ig_nuis_end(c, out, &nz, &z, nullptr)) return -1;
+    if (nz_test) *nz_test = nz;
+    if (z_test) *z_test = z;
+    const double ratio = exp(((nz + z) - out->o) / temperature);
+    int acc;
+    if (ratio != ratio) acc = 0; /* NaN >= u is false */
+    else if (ratio >= u * (1.0 + 1e-9)) acc = 1;
+    else if (ratio <= u * (1.0 - 1e-9)) acc = 0;
+    else acc = 2;
+    *accepted = acc;
+    if (acc == 2) return 0;
+    if (acc == 1 && ig_nuis_accept(c)) return -1;
+    if (has_next) return ig_nuis_step_begin(c, c->spec_move, acc ? p_next_accepted : p_next_rejected, mean_subfrag_kb);
     return 0;
 }
 
@@ -2111,6 +2198,26 @@ extern "C" int ig_debug_screen_stats(ig_ctx* c, double out4[6])
     out4[5] = (double)hg.scr_terms_exact;
     if (getenv("IG_SCREEN_STATS")) fprintf(stderr, "[screen] void columns %lld of %lld\n", hg.scr_void_cols, hg.scr_cols);
     return 0;
+}
+
+/* one from-scratch pass with every workgroup of k_full_nz_tiled leaving {start, end (100 MHz clock), XCC_ID << 32 | HW_ID, contacts}:
+ * out [4 x n]; n_items receives the number of workgroups */
+extern "C" int ig_debug_tile_trace(ig_ctx* c, int64_t* out, int64_t cap, int64_t* n_items)
+{
+    HIPCK(hipSetDevice(c->device));
+    *n_items = c->n_tile_work;
+    if (!out || cap < c->n_tile_work) return 0;
+    long long* d = nullptr;
+    DALLOC(d, (size_t)4 * c->n_tile_work);
+    HIPCK(hipMemset(d, 0, (size_t)32 * c->n_tile_work));
+    *n_items = std::min(c->n_tile_work, 4096);
+    c->tile_trace = d;
+    double nz;
+    const int rc = ig_full_likelihood(c, 0, 0, &nz, nullptr, nullptr);
+    c->tile_trace = nullptr;
+    if (!rc) HIPCK(hipMemcpy(out, d, (size_t)32 * c->n_tile_work, hipMemcpyDeviceToHost));
+    hipFree(d);
+    return rc;
 }
 
 /* the from-scratch pass with (1, default) / without (0) the count histograms of the all-trans tiles: same sums */

@@ -1031,90 +1031,164 @@ __global__ void __launch_bounds__(256) k_full_nz(const int* __restrict__ crow, c
 
 /* k_full_nz_tiled: the same sum from a second, TILED copy of the contacts (built once at upload): the sub-fragments are cut
  * into blocks of FULL_TB, tile (bi, bj) holds the contacts with row in block bi and column in block bj, a work item = up to
- * FULL_CHUNK contacts of one tile.  A workgroup stages the 16-byte records (dist, s_tot, contig, rank) of the two blocks in
- * LDS (2 x 32 KB) and streams its contacts -- 8 bytes each: (row | column << 11) inside the blocks, count -- so the two
+ * FULL_CHUNK contacts of one tile.  A workgroup stages (dist, rank, contig) of the two blocks' sub-fragments in LDS
+ * (2 x 24 KB) and streams its contacts -- 8 bytes each: (row | column << 11) inside the blocks, count -- so the two
  * endpoint gathers per contact that bound k_full_nz (0.33 T random 16-byte gathers/s into L2) become LDS reads.  Same term,
- * same exact integer sums (any order of the contacts gives the same total). */
+ * same exact integer sums (any order of the contacts gives the same total).
+ *
+ * Most contacts are never read: a trans pair's term is a function of its count alone, so the sum of a tile between two
+ * blocks that share no contig is its (static) histogram of counts times the table of those terms.  k_tile_trans decides
+ * that per off-diagonal tile from the blocks' contig signatures (k_pack_tab_sig) and either adds the histogram's sum or
+ * puts the tile's work items on a list; k_full_nz_tiled is launched over the STATIC items (diagonal tiles, tiles with a
+ * count beyond the histogram) and every workgroup goes on with items from that list until it is empty. */
 #define FULL_TB 2048
+#ifndef FULL_CHUNK
 #define FULL_CHUNK 16384
+#endif
 #ifndef FULL_TILED_THREADS
 #define FULL_TILED_THREADS 1024
 #endif
 #define TILE_HB 64 /* bins of a tile's histogram of counts */
 struct TileWork {
     long long off; /* first contact of the item in the tiled array */
-    int n, bi, bj;
-    int hist; /* -1, or: 2 x (index of the tile's count histogram) + (1 for the first item of the tile): every count of the tile is in 1 .. TILE_HB-1 */
+    int n, bi, bj, pad;
+};
+struct TileInfo { /* an off-diagonal tile whose counts are all in 1 .. TILE_HB-1 */
+    int bi, bj, first_item, n_items;
+};
+struct TileDyn {
+    int count, next; /* items on the list (k_tile_trans), items taken (k_full_nz_tiled); zeroed by k_pack_tab_sig */
 };
 struct FullTiledLds {
     ScoreTables tab;
     unsigned long long qtrans[LDS_LGF]; /* the quantised term of a trans pair with count ob (it depends on nothing else), + the rounding magic */
-    int4 rrec[FULL_TB], crec[FULL_TB];
+    /* per sub-fragment of the row / column block: (dist, rank | circular contig << 31) and the contig id -- 12 bytes, so that
+     * two workgroups fit the LDS of a CU */
+    uint2 rrec[FULL_TB], crec[FULL_TB];
+    int rctg[FULL_TB], cctg[FULL_TB];
     long long red[2][FULL_TILED_THREADS / 64];
-    int shared_contig; /* the two blocks' signatures intersect */
+    int next_item;
 };
-__global__ void __launch_bounds__(FULL_TILED_THREADS)
+
+/* the quantised trans term of count o_b (+ the rounding magic): the straight-line term of the kernels below with the trans
+ * level for P and P_z -- same expression, same bits */
+__device__ __forceinline__ unsigned long long trans_term_bits(unsigned o_b, double lv, const double* T, const double* lgf, double pzc_trans)
+{
+    const double ex = ig_exp2_core(lv, T), lg = lv * IG_LOG2_10_INV;
+    const double t = (ig_fma((double)o_b, lg, -ex) - lgf[o_b]) + pzc_trans;
+    return !(__builtin_fabs(t) < 524288.0) ? (unsigned long long)ig_quantize(t) + IG_QMAGIC_BITS : ig_d2u(ig_fma(t, IG_QSCALE, IG_QMAGIC));
+}
+
+/* one wave per off-diagonal tile with a histogram (blocks [0, n_trans_blocks)); the blocks behind them, if any, are the
+ * zero-pixel pass over all sub-fragments (k_full_zero's job: it needs nothing from the tiles and would otherwise be one more
+ * launch behind k_full_nz_tiled) */
+#define TILE_TRANS_THREADS 1024 /* a tile per wave; few, large workgroups: every workgroup ends in a pair of atomics on the same two words */
+__global__ void __launch_bounds__(TILE_TRANS_THREADS) k_tile_trans(const TileInfo* __restrict__ tiles, int n_tiles, const unsigned* __restrict__ sig,
+                                                    const unsigned* __restrict__ hist, const ScoreConst* __restrict__ sc, TileDyn* dyn,
+                                                    int* __restrict__ dyn_list, int use_hist, long long* out, int n_trans_blocks, Tables zt,
+                                                    const Glob* g, int which, int M, long long* zero_out)
+{
+    if ((int)blockIdx.x >= n_trans_blocks) {
+        full_zero_block(zt, g, which, M, zero_out, (int)blockIdx.x - n_trans_blocks, (int)gridDim.x - n_trans_blocks);
+        return;
+    }
+    __shared__ long long red[2][TILE_TRANS_THREADS / 64];
+    __shared__ unsigned long long qt[TILE_HB];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int t = blockIdx.x * (TILE_TRANS_THREADS / 64) + wv;
+    /* everything is requested before anything is looked at: tile, signatures, histogram bin; the table of trans terms by
+     * the first wave meanwhile */
+    TileInfo ti = {0, 0, 0, 0};
+    unsigned both = 0;
+    unsigned long long n = 0;
+    if (t < n_tiles) {
+        ti = tiles[t];
+        n = hist[(size_t)t * TILE_HB + lane];
+        for (int i = lane; i < SIG_WORDS; i += 64) both |= sig[(size_t)ti.bi * SIG_WORDS + i] & sig[(size_t)ti.bj * SIG_WORDS + i];
+    }
+    const bool fast = sc->hot.fast;
+    if (threadIdx.x < TILE_HB)
+        qt[threadIdx.x] = threadIdx.x ? trans_term_bits(threadIdx.x, sc->hot.log2_v_inter, sc->tab.mt, sc->tab.lgf, sc->tab.pzc[LDS_PZ]) : IG_QMAGIC_BITS;
+    __syncthreads();
+    long long hi = 0, lo = 0;
+    if (t < n_tiles) {
+        if (__any(both != 0u) || !use_hist || !fast) { /* a contig in both blocks (or its alias): read the contacts */
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&dyn->count, ti.n_items);
+            base = __shfl(base, 0, 64);
+            for (int i = lane; i < ti.n_items; i += 64) dyn_list[base + i] = ti.first_item + i;
+        } else if (lane >= 1) {
+            const long long q = (long long)(qt[lane] - IG_QMAGIC_BITS);
+            const unsigned long long ql = (unsigned)q;
+            const long long qh = (q - (long long)ql) >> 32;
+            const unsigned long long pl = n * ql; /* < 2^63: a tile holds fewer than 2^31 contacts */
+            hi = (long long)n * qh + (long long)(pl >> 32);
+            lo = (long long)(pl & 0xffffffffull);
+        }
+    }
+    hi = wave_sum_ll(hi);
+    lo = wave_sum_ll(lo);
+    if (lane == 0) {
+        red[0][wv] = hi;
+        red[1][wv] = lo;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        hi = lo = 0;
+        for (int q = 0; q < TILE_TRANS_THREADS / 64; q++) {
+            hi += red[0][q];
+            lo += red[1][q];
+        }
+        if (hi | lo) {
+            atomic_add_ll(&out[0], hi);
+            atomic_add_ll(&out[1], lo);
+        }
+    }
+}
+
+/* everything a nuisance step's pass needs before its tiles, in ONE launch (k_set_par + k_build_pz + the scratch memset +
+ * k_pack_tab_sig + k_build_score_const were five, each a few microseconds of work behind a launch gap): the test parameters
+ * come from the host, so nothing here waits for anything else.  Blocks [0, n_pack): the records and signatures of a block
+ * of sub-fragments; the blocks behind: P_z table and score constants of the set (same expressions as k_build_pz and
+ * k_build_score_const). */
+__global__ void __launch_bounds__(256) k_nuis_prepare(Glob* g, int which, ig_params p, float mean_kb, float* __restrict__ pz, int pz_n,
+                                                      const double* __restrict__ lgf_tab, ScoreConst* out, long long* scratch8, Tables t,
+                                                      int M, int4* __restrict__ rec, unsigned* __restrict__ sig, int tb, int* dyn2, int n_pack)
+{
+    if ((int)blockIdx.x < n_pack) {
+        pack_tab_sig_block(t, M, rec, sig, tb, dyn2);
+        return;
+    }
+    const int i = ((int)blockIdx.x - n_pack) * blockDim.x + threadIdx.x;
+    const float s_z = (float)i * mean_kb;
+    const float pzv = (i < pz_n && s_z < p.d_max) ? ig_rippe(s_z, p, ig_tab()) : p.v_inter;
+    if (i < pz_n) pz[i] = pzv;
+    if (i < IG_TAB_SIZE) out->tab.mt[i] = ig_tab()[i];
+    if (i < LDS_PZ + 2) out->tab.pzc[i] = (double)(i < min(pz_n, LDS_PZ) ? pzv : p.v_inter) * IG_LOG_E_F;
+    if (i < LDS_LGF) out->tab.lgf[i] = lgf_tab[i];
+    if (i == 0) {
+        out->hot = ig_hot_make(p, ig_tab());
+        out->par = p;
+        out->mean_kb = mean_kb;
+        g->par[which] = p;
+        g->mean_kb = mean_kb;
+        for (int q = 0; q < 8; q++) scratch8[q] = 0;
+    }
+}
+
+__global__ void __launch_bounds__(FULL_TILED_THREADS, 8) /* 8 waves per SIMD: two workgroups per CU need <= 80 SGPRs (112 admit 6 waves) */
     k_full_nz_tiled(const TileWork* __restrict__ work, const uint2* __restrict__ tc, const int4* __restrict__ rec, const int* __restrict__ len,
-                    const ScoreConst* __restrict__ sc, const double* __restrict__ lgf_tab, int M, int pz_n, long long* out,
-                    const unsigned* __restrict__ sig, const unsigned* __restrict__ hist)
+                    const ScoreConst* __restrict__ sc, const double* __restrict__ lgf_tab, int M, int pz_n, long long* out, int n_static,
+                    TileDyn* dyn, const int* __restrict__ dyn_list, long long* trace)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     FullTiledLds& L = *(FullTiledLds*)lds_raw;
-    const TileWork wk = work[blockIdx.x];
-    const bool diag = wk.bi == wk.bj;
-    /* A tile between two blocks that share no contig (disjoint signatures, k_pack_tab_sig) holds trans pairs only, and a
-     * trans pair's term is a function of its count alone: the tile's sum is its (static) histogram of counts times the
-     * table of those terms -- the first item of the tile adds it, the tile's contacts are not read at all. */
-    bool all_trans = false;
-    if (sig && wk.hist >= 0 && !diag && sc->hot.fast) {
-        unsigned both = 0;
-        for (int i = threadIdx.x; i < SIG_WORDS; i += blockDim.x) both |= sig[(size_t)wk.bi * SIG_WORDS + i] & sig[(size_t)wk.bj * SIG_WORDS + i];
-        if (threadIdx.x == 0) L.shared_contig = 0;
-        __syncthreads();
-        if (both) L.shared_contig = 1;
-        __syncthreads();
-        all_trans = !L.shared_contig;
-        if (all_trans && !(wk.hist & 1)) return;
-    }
+    long long t_start = 0;
+    if (trace && threadIdx.x == 0) t_start = (long long)wall_clock64(); /* ig_debug_tile_trace */
     {
         const float4* src = (const float4*)&sc->tab;
         float4* dst = (float4*)&L.tab;
         for (int i = threadIdx.x; i < (int)(sizeof(ScoreTables) / 16); i += blockDim.x) dst[i] = src[i];
-    }
-    if (all_trans) {
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            const ig_hot hot = sc->hot;
-            const double lv = hot.log2_v_inter;
-            const double* T = L.tab.mt;
-            const unsigned o_b = threadIdx.x;
-            long long hi = 0, lo = 0;
-            if (o_b >= 1 && o_b < TILE_HB) {
-                const double ex = ig_exp2_core(lv, T), lg = lv * IG_LOG2_10_INV;
-                const double t = (ig_fma((double)o_b, lg, -ex) - L.tab.lgf[o_b]) + L.tab.pzc[LDS_PZ];
-                const unsigned long long bits =
-                    !(__builtin_fabs(t) < 524288.0) ? (unsigned long long)ig_quantize(t) + IG_QMAGIC_BITS : ig_d2u(ig_fma(t, IG_QSCALE, IG_QMAGIC));
-                const long long q = (long long)(bits - IG_QMAGIC_BITS);
-                const unsigned long long ql = (unsigned)q;
-                const long long qh = (q - (long long)ql) >> 32;
-                const unsigned long long n = hist[(size_t)(wk.hist >> 1) * TILE_HB + o_b];
-                const unsigned long long pl = n * ql; /* < 2^63: a tile holds fewer than 2^31 contacts */
-                hi = (long long)n * qh + (long long)(pl >> 32);
-                lo = (long long)(pl & 0xffffffffull);
-            }
-            hi = wave_sum_ll(hi);
-            lo = wave_sum_ll(lo);
-            if (threadIdx.x == 0) {
-                atomic_add_ll(&out[0], hi);
-                atomic_add_ll(&out[1], lo);
-            }
-        }
-        return;
-    }
-    for (int i = threadIdx.x; i < FULL_TB; i += blockDim.x) {
-        const int gi = wk.bi * FULL_TB + i, gj = wk.bj * FULL_TB + i;
-        L.rrec[i] = gi < M ? rec[gi] : make_int4(0, 0, -1, 0);
-        if (!diag) L.crec[i] = gj < M ? rec[gj] : make_int4(0, 0, -2, 0);
     }
     const ig_params p = sc->par;
     const ig_hot hot = sc->hot;
@@ -1124,73 +1198,123 @@ __global__ void __launch_bounds__(FULL_TILED_THREADS)
     const bool checked = !hot.fast;
     __syncthreads();
     const double* T = L.tab.mt;
-    /* a trans pair's term is a function of its count alone -- the straight-line term below with the trans level for P and
-     * P_z: tabulated once per workgroup (same expression, same bits); most tiles hold trans pairs only */
-    if (threadIdx.x < LDS_LGF) {
-        const unsigned o_b = threadIdx.x;
-        const double ex = ig_exp2_core(lv, T), lg = lv * IG_LOG2_10_INV;
-        const double t = (ig_fma((double)o_b, lg, -ex) - L.tab.lgf[o_b]) + L.tab.pzc[LDS_PZ];
-        L.qtrans[o_b] = !(__builtin_fabs(t) < 524288.0) ? (unsigned long long)ig_quantize(t) + IG_QMAGIC_BITS : ig_d2u(ig_fma(t, IG_QSCALE, IG_QMAGIC));
-    }
-    __syncthreads();
-    const int4* cre = diag ? L.rrec : L.crec;
-    const uint2* src = tc + wk.off;
+    if (threadIdx.x < LDS_LGF) L.qtrans[threadIdx.x] = trans_term_bits(threadIdx.x, lv, T, L.tab.lgf, L.tab.pzc[LDS_PZ]);
     unsigned long long acc = 0, accl = 0;
-    /* the next two contacts of a lane are loaded before this pair's terms */
-    const int n = wk.n, nth = blockDim.x;
-    uint2 nx0 = src[min((int)threadIdx.x, n - 1)], nx1 = src[min((int)threadIdx.x + nth, n - 1)];
-    for (int e0 = threadIdx.x; e0 < n; e0 += 2 * nth) {
-        const uint2 v0 = nx0, v1 = nx1;
-        nx0 = src[min(e0 + 2 * nth, n - 1)];
-        nx1 = src[min(e0 + 3 * nth, n - 1)];
-        const int4 ri0 = L.rrec[v0.x & (FULL_TB - 1)], rj0 = cre[(v0.x >> 11) & (FULL_TB - 1)];
-        const int4 ri1 = L.rrec[v1.x & (FULL_TB - 1)], rj1 = cre[(v1.x >> 11) & (FULL_TB - 1)];
-        /* the whole wave on trans pairs with tabulated counts: no arithmetic at all */
-        const bool easy = (ri0.z != rj0.z) && (ri1.z != rj1.z) && (v0.y - 1u < (unsigned)(LDS_LGF - 1)) && (v1.y - 1u < (unsigned)(LDS_LGF - 1));
-        if (!checked && __all(easy)) {
-            const unsigned long long b0 = L.qtrans[v0.y], b1 = L.qtrans[v1.y];
-            if (e0 < n) {
-                acc += b0 - IG_QMAGIC_BITS;
-                accl += (unsigned)b0;
-            }
-            if (e0 + nth < n) {
-                acc += b1 - IG_QMAGIC_BITS;
-                accl += (unsigned)b1;
-            }
-            continue;
+    int n_items = 0, n_contacts = 0;
+    const int nth = blockDim.x;
+    /* persistent workgroups over ONE sequence of items: the static ones, then the list of k_tile_trans; a workgroup starts
+     * with item blockIdx.x and takes the next free one when it is through (dispatching a workgroup per item left the last
+     * third of the launch to a quarter of the CUs) */
+    for (int seq = (int)blockIdx.x;;) {
+        int it;
+        if (seq < n_static) {
+            it = seq;
+        } else {
+            if (seq - n_static >= dyn->count) break;
+            it = dyn_list[seq - n_static];
         }
+        const TileWork wk = work[it];
+        const bool diag = wk.bi == wk.bj;
+        n_items++;
+        n_contacts += wk.n;
+        /* the first two contacts of a lane are on their way while the blocks are staged */
+        const uint2* src = tc + wk.off;
+        const int n = wk.n;
+        uint2 nx0 = src[min((int)threadIdx.x, n - 1)], nx1 = src[min((int)threadIdx.x + nth, n - 1)];
+        for (int i = threadIdx.x; i < FULL_TB; i += nth) {
+            const int gi = wk.bi * FULL_TB + i, gj = wk.bj * FULL_TB + i;
+            const int4 a = gi < M ? rec[gi] : make_int4(0, 0, -1, 0);
+            L.rrec[i] = make_uint2((unsigned)a.x, (unsigned)a.w | (__int_as_float(a.y) != 0.0f ? 0x80000000u : 0u));
+            L.rctg[i] = a.z;
+            if (!diag) {
+                const int4 b = gj < M ? rec[gj] : make_int4(0, 0, -2, 0);
+                L.crec[i] = make_uint2((unsigned)b.x, (unsigned)b.w | (__int_as_float(b.y) != 0.0f ? 0x80000000u : 0u));
+                L.cctg[i] = b.z;
+            }
+        }
+        __syncthreads();
+        const uint2* cre = diag ? L.rrec : L.crec;
+        const int* cct = diag ? L.rctg : L.cctg;
+        for (int e0 = threadIdx.x; e0 < n; e0 += 2 * nth) {
+            const uint2 v0 = nx0, v1 = nx1;
+            nx0 = src[min(e0 + 2 * nth, n - 1)];
+            nx1 = src[min(e0 + 3 * nth, n - 1)];
+            /* .x dist, .y s_tot != 0 (a circular contig: the long way), .z contig, .w rank */
+            auto record = [](uint2 r, int ctg) { return make_int4((int)r.x, (int)(r.y >> 31), ctg, (int)(r.y & 0x7fffffffu)); };
+            const int4 ri0 = record(L.rrec[v0.x & (FULL_TB - 1)], L.rctg[v0.x & (FULL_TB - 1)]);
+            const int4 rj0 = record(cre[(v0.x >> 11) & (FULL_TB - 1)], cct[(v0.x >> 11) & (FULL_TB - 1)]);
+            const int4 ri1 = record(L.rrec[v1.x & (FULL_TB - 1)], L.rctg[v1.x & (FULL_TB - 1)]);
+            const int4 rj1 = record(cre[(v1.x >> 11) & (FULL_TB - 1)], cct[(v1.x >> 11) & (FULL_TB - 1)]);
+            /* the whole wave on trans pairs with tabulated counts: no arithmetic at all */
+            const bool easy = (ri0.z != rj0.z) && (ri1.z != rj1.z) && (v0.y - 1u < (unsigned)(LDS_LGF - 1)) && (v1.y - 1u < (unsigned)(LDS_LGF - 1));
+            if (!checked && __all(easy)) {
+                const unsigned long long b0 = L.qtrans[v0.y], b1 = L.qtrans[v1.y];
+                if (e0 < n) {
+                    acc += b0 - IG_QMAGIC_BITS;
+                    accl += (unsigned)b0;
+                }
+                if (e0 + nth < n) {
+                    acc += b1 - IG_QMAGIC_BITS;
+                    accl += (unsigned)b1;
+                }
+                continue;
+            }
+            /* both terms in one straight line (the two dependent chains interleave), ONE branch for whatever needs the long way */
+            double t[2];
+            unsigned long long bits[2];
+            bool rare[2], cisv[2];
+            unsigned dv[2];
+            float svv[2];
+            bool fix = false;
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const uint2 v = u ? v1 : v0;
-            const int4 ri = u ? ri1 : ri0, rj = u ? rj1 : rj0;
-            const unsigned o_b = v.y;
-            const bool cis = ri.z == rj.z;
-            const unsigned d = abs_diff_u32((unsigned)ri.w, (unsigned)rj.w);
-            const float sv = fabsf(__int_as_float(ri.x) - __int_as_float(rj.x));
-            const bool in = cis && (sv > 0.0f) && (sv < d_max);
-            const double pzc = L.tab.pzc[cis ? min(d, (unsigned)LDS_PZ) : (unsigned)LDS_PZ];
-            const double lgf = L.tab.lgf[min(o_b, (unsigned)(LDS_LGF - 1))];
-            const double y = ig_fma(slope, ig_log2_pos((double)sv, T), la);
-            const double yy = in ? __builtin_fmax(y, lv) : lv;
-            const double ex = ig_exp2_core(yy, T);
-            const double lg = yy * IG_LOG2_10_INV;
-            const double t = (ig_fma((double)o_b, lg, -ex) - lgf) + pzc;
-            const bool rare = (o_b - 1u >= (unsigned)(LDS_LGF - 1)) || (cis && (d >= cut || __int_as_float(ri.y) != 0.0f)) || checked;
-            unsigned long long bits = ig_d2u(ig_fma(t, IG_QSCALE, IG_QMAGIC));
-            const bool big = !(__builtin_fabs(t) < 524288.0);
-            if (__any(big || rare)) {
-                if (rare)
-                    bits = (unsigned long long)full_q_general(p, mean, cis, sv, (int)d, __int_as_float(ri.y),
-                                                              len[min(wk.bi * FULL_TB + (int)(v.x & (FULL_TB - 1)), M - 1)], (int)o_b, lgf_tab) +
-                           IG_QMAGIC_BITS;
-                else if (big)
-                    bits = (unsigned long long)ig_quantize(t) + IG_QMAGIC_BITS;
+            for (int u = 0; u < 2; u++) {
+                const uint2 v = u ? v1 : v0;
+                const int4 ri = u ? ri1 : ri0, rj = u ? rj1 : rj0;
+                const unsigned o_b = v.y;
+                const bool cis = ri.z == rj.z;
+                const unsigned d = abs_diff_u32((unsigned)ri.w, (unsigned)rj.w);
+                const float sv = fabsf(__int_as_float(ri.x) - __int_as_float(rj.x));
+                const bool in = cis & (sv > 0.0f) & (sv < d_max);
+                const double pzc = L.tab.pzc[cis ? min(d, (unsigned)LDS_PZ) : (unsigned)LDS_PZ];
+                const double lgf = L.tab.lgf[min(o_b, (unsigned)(LDS_LGF - 1))];
+                const double y = ig_fma(slope, ig_log2_pos((double)sv, T), la);
+                const double yy = in ? __builtin_fmax(y, lv) : lv;
+                const double ex = ig_exp2_core(yy, T);
+                const double lg = yy * IG_LOG2_10_INV;
+                t[u] = (ig_fma((double)o_b, lg, -ex) - lgf) + pzc;
+                rare[u] = (o_b - 1u >= (unsigned)(LDS_LGF - 1)) | (cis & ((d >= cut) | (ri.y != 0))) | checked;
+                bits[u] = ig_d2u(ig_fma(t[u], IG_QSCALE, IG_QMAGIC));
+                fix |= rare[u] | !(__builtin_fabs(t[u]) < 524288.0);
+                cisv[u] = cis;
+                dv[u] = d;
+                svv[u] = sv;
             }
-            if (e0 + u * nth < n) {
-                acc += bits - IG_QMAGIC_BITS;
-                accl += (unsigned)bits;
+            if (__any(fix)) {
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint2 v = u ? v1 : v0;
+                    const int4 ri = u ? ri1 : ri0;
+                    if (rare[u]) {
+                        const int gi = min(wk.bi * FULL_TB + (int)(v.x & (FULL_TB - 1)), M - 1);
+                        bits[u] = (unsigned long long)full_q_general(p, mean, cisv[u], svv[u], (int)dv[u], ri.y ? __int_as_float(rec[gi].y) : 0.0f,
+                                                                     len[gi], (int)v.y, lgf_tab) +
+                                  IG_QMAGIC_BITS;
+                    } else if (!(__builtin_fabs(t[u]) < 524288.0)) {
+                        bits[u] = (unsigned long long)ig_quantize(t[u]) + IG_QMAGIC_BITS;
+                    }
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (e0 + u * nth < n) {
+                    acc += bits[u] - IG_QMAGIC_BITS;
+                    accl += (unsigned)bits[u];
+                }
         }
+        __syncthreads(); /* everybody is through with the staged blocks */
+        if (threadIdx.x == 0) L.next_item = (int)gridDim.x + atomicAdd(&dyn->next, 1);
+        __syncthreads();
+        seq = L.next_item;
     }
     long long hi = ((long long)acc - (long long)accl) >> 32, lo = (long long)accl;
     hi = wave_sum_ll(hi);
@@ -1209,6 +1333,15 @@ __global__ void __launch_bounds__(FULL_TILED_THREADS)
         }
         atomic_add_ll(&out[0], h);
         atomic_add_ll(&out[1], l);
+        if (trace) { /* start, end (100 MHz clock), XCC_ID << 32 | HW_ID, items << 32 | contacts */
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            trace[4 * (size_t)blockIdx.x] = t_start;
+            trace[4 * (size_t)blockIdx.x + 1] = (long long)wall_clock64();
+            trace[4 * (size_t)blockIdx.x + 2] = (long long)(((unsigned long long)xcc << 32) | hw);
+            trace[4 * (size_t)blockIdx.x + 3] = ((long long)n_items << 32) | (long long)n_contacts;
+        }
     }
 }
 

@@ -41,9 +41,10 @@ __global__ void k_pack_tab(Tables t, int M, int4* __restrict__ rec)
  * SIGNATURE: bit (contig id mod 32 SIG_WORDS) of every contig with a sub-fragment in the block.  Two blocks whose signatures
  * do not intersect share no contig: every contact between them is a trans pair. */
 #define SIG_WORDS 256
-__global__ void __launch_bounds__(256) k_pack_tab_sig(Tables t, int M, int4* __restrict__ rec, unsigned* __restrict__ sig, int tb)
+__device__ __forceinline__ void pack_tab_sig_block(const Tables& t, int M, int4* __restrict__ rec, unsigned* __restrict__ sig, int tb, int* dyn2)
 {
     __shared__ unsigned lsig[SIG_WORDS];
+    if (blockIdx.x == 0 && threadIdx.x == 0) dyn2[0] = dyn2[1] = 0; /* the list of tiles to read (k_tile_trans) and its cursor */
     for (int i = threadIdx.x; i < SIG_WORDS; i += blockDim.x) lsig[i] = 0;
     __syncthreads();
     const int s0 = blockIdx.x * tb;
@@ -57,14 +58,18 @@ __global__ void __launch_bounds__(256) k_pack_tab_sig(Tables t, int M, int4* __r
     __syncthreads();
     for (int i = threadIdx.x; i < SIG_WORDS; i += blockDim.x) sig[(size_t)blockIdx.x * SIG_WORDS + i] = lsig[i];
 }
+__global__ void __launch_bounds__(256) k_pack_tab_sig(Tables t, int M, int4* __restrict__ rec, unsigned* __restrict__ sig, int tb, int* dyn2)
+{
+    pack_tab_sig_block(t, M, rec, sig, tb, dyn2);
+}
 
 /* eval_likelihood_on_zero (KA:3850-3917) over all sub-fragments -> out[0..2] = hi, lo, n_intra */
-__global__ void k_full_zero(Tables t, const Glob* g, int which, int M, long long* out)
+__device__ __forceinline__ void full_zero_block(const Tables& t, const Glob* g, int which, int M, long long* out, int block, int n_blocks)
 {
     const ig_params p = g->par[which];
     const float mean = g->mean_kb;
     long long hi = 0, lo = 0, ni = 0;
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < M; s += gridDim.x * blockDim.x) {
+    for (int s = block * blockDim.x + threadIdx.x; s < M; s += n_blocks * blockDim.x) {
         const int pos = t.cp[s].y, len = t.len[s];
         if (pos == 0) ni += ((long long)len * (long long)(len - 1)) / 2;
         if (pos > 0) {
@@ -91,11 +96,12 @@ __global__ void k_full_zero(Tables t, const Glob* g, int which, int M, long long
         if (v) atomic_add_ll(&out[threadIdx.x], v);
     }
     /* what the host needs next to the sums to form the zero-pixel likelihood: one copy back instead of two */
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (block == 0 && threadIdx.x == 0) {
         out[3] = __double_as_longlong(g->n_tot_pxl);
         out[5] = (long long)__float_as_int(g->par[which].v_inter);
     }
 }
+__global__ void k_full_zero(Tables t, const Glob* g, int which, int M, long long* out) { full_zero_block(t, g, which, M, out, blockIdx.x, gridDim.x); }
 
 __global__ void k_count_heads(State st, int N, int* out, Glob* g)
 {

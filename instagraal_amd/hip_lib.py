@@ -302,6 +302,18 @@ class Context:
         p = np.ascontiguousarray(p_test8, np.float32)
         _ck(lib().ig_nuis_step_begin(self._h, C.c_int32(int(move)), _p(p), C.c_float(float(mean_subfrag_kb))))
 
+    def nuis_step_next(self, temperature, u, p_next_rejected, p_next_accepted, mean_subfrag_kb, has_next):
+        """end of the step in flight + acceptance test + promotion + begin of the next step (ig_nuis_step_next)
+        -> (move result, nz_test, z_test, accepted: 0 / 1 / 2 = undecided)"""
+        res = MoveResult()
+        nz, z, acc = C.c_double(), C.c_double(), C.c_int32()
+        pr = np.ascontiguousarray(p_next_rejected, np.float32)
+        pa = np.ascontiguousarray(p_next_accepted, np.float32)
+        _ck(lib().ig_nuis_step_next(self._h, C.c_double(float(temperature)), C.c_double(float(u)), _p(pr), _p(pa),
+                                    C.c_float(float(mean_subfrag_kb)), C.c_int32(int(has_next)), C.byref(res), C.byref(nz), C.byref(z),
+                                    C.byref(acc)))
+        return res, nz.value, z.value, acc.value
+
     def nuis_end(self):
         res = MoveResult()
         nz, z = C.c_double(), C.c_double()
@@ -340,6 +352,14 @@ class Context:
         res = np.zeros(int(n_moves), MOVE_RESULT_DTYPE)
         _ck(lib().ig_batch_results(self._h, C.c_int32(int(n_moves)), _p(res)))
         return res
+
+    def debug_tile_trace(self):
+        """one from-scratch pass -> (n, 4) int64: start, end (100 MHz clock), XCC_ID << 32 | HW_ID, contacts of every workgroup"""
+        n = C.c_int64()
+        _ck(lib().ig_debug_tile_trace(self._h, C.c_void_p(0), C.c_int64(0), C.byref(n)))
+        out = np.zeros((n.value, 4), np.int64)
+        _ck(lib().ig_debug_tile_trace(self._h, _p(out), C.c_int64(n.value), C.byref(n)))
+        return out
 
     def batch_stats(self):
         o = np.zeros(4, np.int64)

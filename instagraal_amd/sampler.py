@@ -429,8 +429,9 @@ class sampler:  # noqa: N801 - the reference's class name
           score besides: it runs next to the move (``ig_nuis_step_begin`` / ``ig_nuis_end``);
         * a rejected step changes nothing a move reads: the moves are scored ahead in batches and decided one per step
           (``ig_nuis_run_begin``); an accepted step discards what was scored ahead;
-        * while both run, the host prepares the next step's proposal (the root finding for d_max, CL:2983) for the case
-          that this step is rejected.
+        * while both run, the host prepares the next step's proposal (the root finding for d_max, CL:2983) for both
+          outcomes of this one; the acceptance test itself and the first launches of the next step are one library call
+          (``ig_nuis_step_next``), so that no Python runs between two steps' kernels.
 
         -> (structured move results, list of the 8-tuples of step_nuisance_parameters with y_rippe = None)"""
         frags = np.ascontiguousarray(frags, np.int32)
@@ -456,46 +457,48 @@ class sampler:  # noqa: N801 - the reference's class name
 
         import time as _t
 
-        prof = self.nuis_profile = dict(begin=0.0, propose=0.0, wait=0.0, decide=0.0, accept=0.0)
+        prof = self.nuis_profile = dict(propose=0.0, step=0.0, book=0.0)
         curr = np.copy(self.param_simu)
         out = proposal(0, curr)
         names = res.dtype.names
+        p8 = lambda q: [q[k][0] for k in PARAM_NAMES]
         self.ctx.nuis_run_begin(frags, cands)
+        self.ctx.nuis_step_begin(0, p8(out), mean_kb)
         for i in range(n):
             ta = _t.perf_counter()
-            self.ctx.nuis_step_begin(i, [out[k][0] for k in PARAM_NAMES], mean_kb)
+            # while the GPU works on step i: the next step's proposal for both outcomes of this one (the root finding for
+            # d_max is the expensive part of a step on the host)
+            has_next = i + 1 < n
+            nxt_rej = proposal(i + 1, curr) if has_next else out
+            nxt_acc = proposal(i + 1, out) if has_next else out
             t1 = _t.perf_counter()
-            # while the GPU works: the next step's proposal for both outcomes of this one (the root finding for d_max is
-            # the expensive part of a step on the host)
-            nxt_rej = proposal(i + 1, curr) if i + 1 < n else None
-            nxt_acc = proposal(i + 1, out) if i + 1 < n else None
+            # end of step i, the acceptance test, the promotion and the first launches of step i + 1 in one call
+            r, nz, z, success = self.ctx.nuis_step_next(self.temperature(t0 + i, n_step), unif[i], p8(nxt_rej), p8(nxt_acc), mean_kb, has_next)
             t2 = _t.perf_counter()
-            r, nz, z = self.ctx.nuis_end()
-            t3 = _t.perf_counter()
-            for k in names:
-                res[k][i] = getattr(r, k)
             self.param_simu_test = out
             self.likelihood_t = r.o
             self.likelihood_nuis = np.array([nz]) + z
-            with np.errstate(over="ignore"):
-                ratio = np.exp((self.likelihood_nuis - self.likelihood_t) / self.temperature(t0 + i, n_step))
-            success = 0
-            t4 = _t.perf_counter()
-            if ratio >= unif[i]:
-                success = 1
-                self.ctx.nuis_accept()
+            if success == 2:  # exp() within 1e-9 of u: the reference's own arithmetic decides
+                with np.errstate(over="ignore"):
+                    ratio = np.exp((self.likelihood_nuis - self.likelihood_t) / self.temperature(t0 + i, n_step))
+                success = 1 if ratio >= unif[i] else 0
+                if success:
+                    self.ctx.nuis_accept()
+                if has_next:
+                    self.ctx.nuis_step_begin(i + 1, p8(nxt_acc if success else nxt_rej), mean_kb)
+            for k in names:
+                res[k][i] = getattr(r, k)
+            if success:
                 self.param_simu = out
                 self.likelihood_t = self.likelihood_nuis
                 curr = np.copy(out)
             kuhn, lm, c1, slope, d, d_max, fact, d_nuc = self.param_simu[0]
             tuples.append((fact, d, d_max, d_nuc, slope, self.likelihood_t, success, None))
             out = nxt_acc if success else nxt_rej
-            t5 = _t.perf_counter()
-            prof["begin"] += t1 - ta
-            prof["propose"] += t2 - t1
-            prof["wait"] += t3 - t2
-            prof["decide"] += t4 - t3
-            prof["accept"] += t5 - t4
+            t3 = _t.perf_counter()
+            prof["propose"] += t1 - ta
+            prof["step"] += t2 - t1
+            prof["book"] += t3 - t2
         last = res[-1]
         self.o = float(last["o"])
         self.n_contigs = np.int32(last["n_contigs"])

@@ -9,3 +9,4 @@ timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_nu -o run -- python3 $R/tools/
 python3 $R/tools/rocprof_stats.py $(find /tmp/prof_nu -name "*.db" | head -1) $R/gpurun_out/${TAG}_nuis_kernel_stats.csv \
   "rocprofv3 --kernel-trace -- python3 tools/nuisance_rate.py cfg3 600 (620 moves + nuisance steps, one MI355X); aggregated by tools/rocprof_stats.py"
 grep -v "Warning\|ratio =" /tmp/nu.log | tail -4
+python3 $R/tools/rocprof_timeline.py $(find /tmp/prof_nu -name "*.db" | head -1) 90 > $R/gpurun_out/${TAG}_nuis_timeline.txt
