@@ -203,6 +203,7 @@ int ig_debug_screen_stats(ig_ctx* ctx, double out6[6]); /* ..., terms screened, 
 /* 0 disables the reference's dropped-tail behaviour of eval_sub_likelihood (quirk Q5); default 1 */
 int ig_debug_set_tail_quirk(int on);
 int ig_debug_tile_trace(ig_ctx* ctx, int64_t* out4n, int64_t cap, int64_t* n_items); /* per-workgroup clocks of one from-scratch pass */
+int ig_debug_nuis_wait(ig_ctx* ctx, double* seconds); /* time ig_nuis_end has waited for the device */
 int ig_debug_set_full_hist(int on); /* from-scratch pass: all-trans tiles from their count histograms (1, default) or contact by contact (0) */
 
 #ifdef __cplusplus

@@ -25,6 +25,7 @@
  * IG_NO_HOST_FLAG=1 (batch outcome by copy + synchronise instead of the polled mapped copy), IG_FULL_WGS (grid of k_full_nz),
  * IG_ABLATE (bit 1: every column of k_score_list through the checked path).
  */
+#include <chrono>
 #include <thread>
 
 #include "ig_common.cuh"
@@ -1892,9 +1893,11 @@ extern "C" int ig_nuis_end(ig_ctx* c, ig_move_result* out, double* nz_test, doub
     HIPCK(hipSetDevice(c->device));
     if (!c->nuis_in_flight) return fail("ig_nuis_end: no step in flight");
     c->nuis_in_flight = false;
+    const auto w0 = std::chrono::steady_clock::now();
     if (c->nuis_spec && nuis_spec_finish(c)) return -1;
     HIPCK(hipStreamSynchronize(c->stream));
     HIPCK(hipStreamSynchronize(c->stream3));
+    c->nuis_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count(); /* ig_debug_nuis_wait */
     HIPCK(hipGetLastError());
     drain_timers(c);
     take_max_readback(c);
@@ -1981,7 +1984,8 @@ extern "C" int ig_nuis_accept(ig_ctx* c)
 /* ig_nuis_end, the Metropolis decision of step_nuisance_parameters (CL:3026-3036: ratio = exp((L_test - L_move) / T) >= u),
  * ig_nuis_accept and the next move's ig_nuis_step_begin in ONE call: between the end of a step's kernels and the first
  * launch of the next step there is no host code but this.  The caller supplies the next step's test parameters for both
- * outcomes (they are prepared while this step's kernels run).  *accepted: 0 / 1, or 2 when exp() lands within 1e-9
+ * outcomes (they are prepared while this step's kernels run; one of them may be NULL: then, on that outcome, the next step is
+ * left to the caller's ig_nuis_step_begin -- the promotion's kernels run meanwhile).  *accepted: 0 / 1, or 2 when exp() lands within 1e-9
  * relative of u -- then nothing was decided or enqueued and the caller goes on with its own arithmetic (ig_nuis_accept,
  * ig_nuis_step_begin). */
 extern "C" int ig_nuis_step_next(ig_ctx* c, double temperature, double u, const float p_next_rejected[8], const float p_next_accepted[8],
@@ -2001,7 +2005,8 @@ extern "C" int ig_nuis_step_next(ig_ctx* c, double temperature, double u, const 
     *accepted = acc;
     if (acc == 2) return 0;
     if (acc == 1 && ig_nuis_accept(c)) return -1;
-    if (has_next) return ig_nuis_step_begin(c, c->spec_move, acc ? p_next_accepted : p_next_rejected, mean_subfrag_kb);
+    const float* p_next = acc ? p_next_accepted : p_next_rejected;
+    if (has_next && p_next) return ig_nuis_step_begin(c, c->spec_move, p_next, mean_subfrag_kb);
     return 0;
 }
 
@@ -2218,6 +2223,13 @@ extern "C" int ig_debug_tile_trace(ig_ctx* c, int64_t* out, int64_t cap, int64_t
     if (!rc) HIPCK(hipMemcpy(out, d, (size_t)32 * c->n_tile_work, hipMemcpyDeviceToHost));
     hipFree(d);
     return rc;
+}
+
+/* seconds ig_nuis_end (also inside ig_nuis_step_next) has spent waiting for the device since the handle was created */
+extern "C" int ig_debug_nuis_wait(ig_ctx* c, double* seconds)
+{
+    *seconds = c->nuis_wait_s;
+    return 0;
 }
 
 /* the from-scratch pass with (1, default) / without (0) the count histograms of the all-trans tiles: same sums */

@@ -307,8 +307,8 @@ class Context:
         -> (move result, nz_test, z_test, accepted: 0 / 1 / 2 = undecided)"""
         res = MoveResult()
         nz, z, acc = C.c_double(), C.c_double(), C.c_int32()
-        pr = np.ascontiguousarray(p_next_rejected, np.float32)
-        pa = np.ascontiguousarray(p_next_accepted, np.float32)
+        pr = None if p_next_rejected is None else np.ascontiguousarray(p_next_rejected, np.float32)
+        pa = None if p_next_accepted is None else np.ascontiguousarray(p_next_accepted, np.float32)
         _ck(lib().ig_nuis_step_next(self._h, C.c_double(float(temperature)), C.c_double(float(u)), _p(pr), _p(pa),
                                     C.c_float(float(mean_subfrag_kb)), C.c_int32(int(has_next)), C.byref(res), C.byref(nz), C.byref(z),
                                     C.byref(acc)))
@@ -360,6 +360,11 @@ class Context:
         out = np.zeros((n.value, 4), np.int64)
         _ck(lib().ig_debug_tile_trace(self._h, _p(out), C.c_int64(n.value), C.byref(n)))
         return out
+
+    def debug_nuis_wait(self):
+        s = C.c_double()
+        _ck(lib().ig_debug_nuis_wait(self._h, C.byref(s)))
+        return s.value
 
     def batch_stats(self):
         o = np.zeros(4, np.int64)

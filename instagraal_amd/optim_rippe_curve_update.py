@@ -55,11 +55,44 @@ def residual_4_max_dist(x, p):
     return np.abs(y - A * _rippe_shape(x, kuhn, lm, slope, dd))
 
 
-def _solve(p, val_inter, s0):
+def _solve_fsolve(p, val_inter, s0):
     kuhn, lm, slope, dd, A = p
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)
         return fsolve(residual_4_max_dist, s0, args=([kuhn, lm, slope, dd, A, val_inter]))[0]
+
+
+try:  # MINPACK's hybrd as scipy.optimize.fsolve reaches it (scipy/optimize/_minpack_py.py, _root_hybr)
+    from scipy.optimize import _minpack as _minpack_ext
+
+    _hybrd = _minpack_ext._hybrd
+except Exception:  # pragma: no cover - another scipy: the public function
+    _hybrd = None
+
+
+def _solve(p, val_inter, s0):
+    """``fsolve(residual_4_max_dist, s0, args=...)[0]`` without fsolve's Python layers: this root is found twice per nuisance
+    step, on the critical path of the host.  Same MINPACK routine, same arguments (xtol, maxfev, band, the forward-difference
+    step from the dtype of the residual on the caller's s0, factor), the same residual with its parameter-only factors
+    computed once -- same iterates, same bits (tests/test_cpu_abi_and_host.py compares the two on a grid)."""
+    if _hybrd is None:
+        return _solve_fsolve(p, val_inter, s0)
+    kuhn, lm, slope, dd, A = p
+    c0 = 0.53 * (kuhn ** -3.0)
+    c1 = dd - 2
+
+    def residual(x):
+        if x.size != 1 or x[0] != x[0]:
+            x[np.isnan(x)] = 0
+        u = lm * np.abs(x) / kuhn
+        return np.abs(val_inter - A * (c0 * np.power(u, slope) * np.exp(c1 / (np.power(u, 2) + dd))))
+
+    x0 = np.asarray(s0).flatten()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        res = np.atleast_1d(residual(x0[:1]))  # fsolve's shape check: one evaluation on the caller's (possibly float32) s0
+        dt = res.dtype if np.issubdtype(res.dtype, np.inexact) else np.dtype(float)
+        return _hybrd(residual, x0, (), 1, 1.49012e-08, 200 * (x0.size + 1), -10, -10, np.finfo(dt).eps, 100, None)[0][0]
 
 
 def estimate_max_dist_intra(p, val_inter):

@@ -466,15 +466,19 @@ class sampler:  # noqa: N801 - the reference's class name
         self.ctx.nuis_step_begin(0, p8(out), mean_kb)
         for i in range(n):
             ta = _t.perf_counter()
-            # while the GPU works on step i: the next step's proposal for both outcomes of this one (the root finding for
-            # d_max is the expensive part of a step on the host)
+            # while the GPU works on step i: the next step's proposal for the case that this one is rejected (the root finding
+            # for d_max is the expensive part of a step on the host); the one for the other case only if it comes to that --
+            # the kernels of the promotion run while it is computed
             has_next = i + 1 < n
             nxt_rej = proposal(i + 1, curr) if has_next else out
-            nxt_acc = proposal(i + 1, out) if has_next else out
+            nxt_acc = None
             t1 = _t.perf_counter()
-            # end of step i, the acceptance test, the promotion and the first launches of step i + 1 in one call
-            r, nz, z, success = self.ctx.nuis_step_next(self.temperature(t0 + i, n_step), unif[i], p8(nxt_rej), p8(nxt_acc), mean_kb, has_next)
+            # end of step i, the acceptance test, the promotion and (rejected) the first launches of step i + 1 in one call
+            r, nz, z, success = self.ctx.nuis_step_next(self.temperature(t0 + i, n_step), unif[i], p8(nxt_rej), None, mean_kb, has_next)
             t2 = _t.perf_counter()
+            if success == 1 and has_next:
+                nxt_acc = proposal(i + 1, out)
+                self.ctx.nuis_step_begin(i + 1, p8(nxt_acc), mean_kb)
             self.param_simu_test = out
             self.likelihood_t = r.o
             self.likelihood_nuis = np.array([nz]) + z
@@ -485,6 +489,8 @@ class sampler:  # noqa: N801 - the reference's class name
                 if success:
                     self.ctx.nuis_accept()
                 if has_next:
+                    if success:
+                        nxt_acc = proposal(i + 1, out)
                     self.ctx.nuis_step_begin(i + 1, p8(nxt_acc if success else nxt_rej), mean_kb)
             for k in names:
                 res[k][i] = getattr(r, k)
@@ -494,7 +500,8 @@ class sampler:  # noqa: N801 - the reference's class name
                 curr = np.copy(out)
             kuhn, lm, c1, slope, d, d_max, fact, d_nuc = self.param_simu[0]
             tuples.append((fact, d, d_max, d_nuc, slope, self.likelihood_t, success, None))
-            out = nxt_acc if success else nxt_rej
+            if has_next:
+                out = nxt_acc if success else nxt_rej
             t3 = _t.perf_counter()
             prof["propose"] += t1 - ta
             prof["step"] += t2 - t1

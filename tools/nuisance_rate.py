@@ -23,11 +23,13 @@ np.random.seed(0)
 frags = np.random.permutation(prob.n_frags)[: 2 * n + 40]
 s.step_sampler_nuisance_batch(frags[:20], 5, s.dt, 0, n)
 b0 = s.ctx.batch_stats()
+w0 = s.ctx.debug_nuis_wait()
 t0 = time.perf_counter()
 res, tup = s.step_sampler_nuisance_batch(frags[20:20 + n], 5, s.dt, 0, n)
 dt = time.perf_counter() - t0
 print("%s: %.0f moves/s through step_sampler_nuisance_batch (accept rate %.2f)" % (cfg, n / dt, np.mean([q[6] for q in tup])))
 b1 = s.ctx.batch_stats()
+print("   of the library call: %.0f us per move waiting for the device" % (1e6 * (s.ctx.debug_nuis_wait() - w0) / n))
 print("   batches scored: %d for %d moves; one-move tails %d" % (b1["batches"] - b0["batches"], n, b1["one_move_tails"] - b0["one_move_tails"]))
 if hasattr(s, "nuis_profile"):
     tot = sum(s.nuis_profile.values())
