@@ -220,6 +220,7 @@ struct ig_ctx {
     long long* scratch_nuis;       /* 8 x int64 reduction scratch of that pass */
     struct NuisHost* host_nuis;    /* pinned: its results and the move's */
     bool nuis_in_flight;
+    bool nuis_caught_up; /* tab_prev is the state before the next move already and ev_gathered recorded (ig_nuis_step_next) */
     double nuis_wait_s; /* time ig_nuis_end spent waiting for the device (ig_debug_nuis_wait) */
     /* moves of a run of (move, nuisance step) pairs scored ahead in batches (ig_nuis_run_begin / ig_nuis_step_begin): the batch
      * in the buffers starts at move spec_base, has spec_W slots of which [0, spec_next) are decided; spec_valid: its

@@ -1030,6 +1030,7 @@ static int check_ready(ig_ctx* c)
 {
     if (!c->have_contacts || !c->have_sub || !c->have_state || !c->have_params)
         return fail("contacts, sub-fragment table, state and parameters must be uploaded before a move");
+    c->nuis_caught_up = false;
     c->nuis_spec = c->spec_valid = false; /* every entry point that runs moves passes here: a run of ig_nuis_step_begin ends with it */
     return 0;
 }
@@ -1714,8 +1715,11 @@ static int enqueue_nuis_pass(ig_ctx* c, const float p_test[8], float mean_subfra
     if (!c->pz_tab1) DALLOC(c->pz_tab1, PZ_MAX);
     /* the nuisance pass first (second stream), the move behind it (library stream): the pass is the longer of the two and
      * would otherwise start only when the host is through with the move's dozen launches */
-    hipLaunchKernelGGL(k_catch_up, dim3(16), dim3(256), 0, c->stream, c->tab, c->tab_prev, c->prev_touched, c->glob);
-    HIPCK(hipEventRecord(c->ev_gathered, c->stream)); /* also: behind an accepted step's kernels (ig_nuis_accept), which read what the pass overwrites */
+    if (!c->nuis_caught_up) {
+        hipLaunchKernelGGL(k_catch_up, dim3(16), dim3(256), 0, c->stream, c->tab, c->tab_prev, c->prev_touched, c->glob);
+        HIPCK(hipEventRecord(c->ev_gathered, c->stream)); /* also: behind an accepted step's kernels (ig_nuis_accept), which read what the pass overwrites */
+    }
+    c->nuis_caught_up = false;
     const ig_params hp = {p_test[0], p_test[1], p_test[2], p_test[3], p_test[4], p_test[5], p_test[6], p_test[7]};
     c->nuis_test = hp;
     c->nuis_mean_kb = mean_subfrag_kb;
@@ -2007,6 +2011,15 @@ extern "C" int ig_nuis_step_next(ig_ctx* c, double temperature, double u, const 
     if (acc == 1 && ig_nuis_accept(c)) return -1;
     const float* p_next = acc ? p_next_accepted : p_next_rejected;
     if (has_next && p_next) return ig_nuis_step_begin(c, c->spec_move, p_next, mean_subfrag_kb);
+    /* the caller has yet to work out the next test parameters; what is certain is that the moves ahead have to be scored
+     * under the parameters just promoted: that needs nothing from the caller, and runs while it computes */
+    if (has_next && acc == 1 && c->spec_move < c->up_moves) {
+        /* (first what the pass of the next step waits for, or it would queue behind the scoring launches) */
+        hipLaunchKernelGGL(k_catch_up, dim3(16), dim3(256), 0, c->stream, c->tab, c->tab_prev, c->prev_touched, c->glob);
+        HIPCK(hipEventRecord(c->ev_gathered, c->stream));
+        c->nuis_caught_up = true;
+        if (nuis_spec_score(c, c->spec_move)) return -1;
+    }
     return 0;
 }
 
