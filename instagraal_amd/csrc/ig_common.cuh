@@ -208,6 +208,15 @@ struct MoveBuf {
 #define Q_TAIL (NSLOT * 5)     /* [NSLOT][2] sum of the last S_c mod 64 sliced contacts' terms (quirk Q5) */
 #define Q_STRIDE (NSLOT * 7)
 
+/* a nuisance step's results on the host (pinned, mapped where possible) */
+struct NuisHost {
+    ig_move_result res;
+    long long sums[8];
+    int frag, cands[IG_MAX_CANDIDATES]; /* the move's lists: the asynchronous upload reads them after ig_nuis_begin returned */
+    int max_L, max_SL;                  /* Glob.max_L / max_SL as of the move */
+    volatile int res_seq, sums_seq;     /* written last, by the kernel that wrote the record (k_commit_batch) / the sums (k_full_nz_tiled) */
+};
+
 struct ig_ctx {
     int device;
     hipStream_t stream;
@@ -219,6 +228,9 @@ struct ig_ctx {
     hipEvent_t ev_gathered;        /* k_gather of the move in flight is done: tab_prev holds the state before that move */
     long long* scratch_nuis;       /* 8 x int64 reduction scratch of that pass */
     struct NuisHost* host_nuis;    /* pinned: its results and the move's */
+    struct NuisHost *host_nuis_dev, *pub_sums; /* its device address when mapped; set while a pass that publishes its sums is enqueued */
+    int res_seq, sums_seq;         /* launch numbers the flags in host_nuis are compared with */
+    bool nuis_pub_res, nuis_pub_sums; /* the step in flight publishes its record / its sums itself */
     bool nuis_in_flight;
     bool nuis_caught_up; /* tab_prev is the state before the next move already and ev_gathered recorded (ig_nuis_step_next) */
     double nuis_wait_s; /* time ig_nuis_end spent waiting for the device (ig_debug_nuis_wait) */

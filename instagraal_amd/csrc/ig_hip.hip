@@ -167,6 +167,7 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     HIPCK(hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming));
     HIPCK(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
     c->host_nuis = nullptr;
+    c->host_nuis_dev = nullptr;
     c->nuis_in_flight = false;
     HIPCK(hipEventCreateWithFlags(&c->ev_slice, hipEventDisableTiming));
     HIPCK(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
@@ -392,7 +393,8 @@ static bool launch_full_nz(ig_ctx* c, const Tables& t, int which, long long* out
         if (grid > 0)
             hipLaunchKernelGGL(k_full_nz_tiled, dim3(grid), dim3(FULL_TILED_THREADS), sizeof(FullTiledLds), stream, c->tile_work, c->tiled_cc,
                                c->tabrec, t.len, c->full_const, c->lgf_tab, c->M, pz.n, out, c->n_tile_static, (TileDyn*)c->tile_dyn,
-                               c->tile_dyn_list, c->tile_trace);
+                               c->tile_dyn_list, c->tile_trace, (zero_out && c->pub_sums) ? c->pub_sums : nullptr, ++c->sums_seq);
+        if (zero_out && c->pub_sums) c->nuis_pub_sums = true;
         return zero_out != nullptr;
     }
     hipLaunchKernelGGL(k_full_nz, dim3(s_wgs), dim3(256), 0, stream, c->crow, c->cc, c->tabrec, t.len, c->full_const, c->lgf_tab,
@@ -633,7 +635,7 @@ extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* 
             DALLOC(c->tile_hist, hist.size());
             DALLOC(c->tile_sig, (size_t)nb * SIG_WORDS);
             DALLOC(c->tile_info, std::max<size_t>(tiles.size(), 1));
-            DALLOC(c->tile_dyn, 2);
+            DALLOC(c->tile_dyn, 4);
             DALLOC(c->tile_dyn_list, std::max<size_t>(work.size() - (size_t)c->n_tile_static, 1));
             HIPCK(hipMemcpy(c->tiled_cc, tc.data(), (size_t)Z * sizeof(uint2), hipMemcpyHostToDevice));
             HIPCK(hipMemcpy(c->tile_work, work.data(), work.size() * sizeof(TileWork), hipMemcpyHostToDevice));
@@ -1222,7 +1224,7 @@ static int validate_move(ig_ctx* c, int frag_a, const int32_t* cands, int C)
 
 /* commit the scored batch [move0, move0 + w_now): k_commit_batch, the one-move tail for a windowed winner, resume */
 /* the decide + apply launches of the slots [next, w_now) of the batch at move `done` */
-static void launch_commit(ig_ctx* c, int done, int w_now, int next, int resumed_plain)
+static void launch_commit(ig_ctx* c, int done, int w_now, int next, int resumed_plain, bool publish = false)
 {
     TimedLaunch t(c, T_COMMIT);
     hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(64), 0, c->stream, c->glob, c->mb, c->d_results, done, w_now, next, c->dirty_buf,
@@ -1232,7 +1234,7 @@ static void launch_commit(ig_ctx* c, int done, int w_now, int next, int resumed_
                            c->mb, PzTab{c->pz_tab, c->pz_n}, next, c->own_begin, c->own_end, c->batch_out);
     hipLaunchKernelGGL(k_commit_batch, dim3(1), dim3(COMMIT_THREADS), 0, c->stream, c->st, c->tab, c->tab_prev, c->glob, c->mb,
                        c->init_prev, c->init_next, c->orientable, c->black, c->own_tag, c->own_idx, c->prev_touched, c->d_results, done,
-                       w_now, next, c->batch_out);
+                       w_now, next, c->batch_out, publish ? c->host_nuis_dev : nullptr, publish ? ++c->res_seq : 0);
 }
 
 /* what the last k_decide_batch launch reported (batch_out[0..12)), as soon as it is there: the kernel writes a copy to mapped,
@@ -1690,11 +1692,6 @@ extern "C" int ig_step_finish(ig_ctx* c, ig_move_result* out, double* scores)
  * over all contacts does not have to wait for the move.  ig_nuis_begin enqueues the move (score + apply, library stream)
  * and, on a second stream behind the move's k_gather (after which tab_prev is that earlier state), the full pass under
  * p_test; ig_nuis_end waits for both; ig_nuis_accept makes the test parameters the model's. */
-struct NuisHost {
-    ig_move_result res;
-    long long sums[8];
-    int frag, cands[IG_MAX_CANDIDATES]; /* the move's lists: the asynchronous upload reads them after ig_nuis_begin returned */
-};
 /* tab_prev := the state before the move about to be scored (what k_gather does first thing; here ahead of it, so that the
  * nuisance pass can start next to the move instead of behind its launches) */
 __global__ void k_catch_up(Tables tab, Tables tab_prev, const int* __restrict__ prev_touched, const Glob* g)
@@ -1708,10 +1705,42 @@ __global__ void k_catch_up(Tables tab, Tables tab_prev, const int* __restrict__ 
     }
 }
 
+/* pinned and mapped: the kernels write a step's results there themselves and raise a flag (no copy, no stream synchronisation) */
+static int ensure_host_nuis(ig_ctx* c)
+{
+    if (c->host_nuis) return 0;
+    NuisHost* hp = nullptr;
+    if (hipHostMalloc((void**)&hp, sizeof(NuisHost), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+        void* dp = nullptr;
+        memset(hp, 0, sizeof(NuisHost));
+        c->host_nuis = hp;
+        if (!(getenv("IG_NO_HOST_FLAG") && atoi(getenv("IG_NO_HOST_FLAG"))) && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess)
+            c->host_nuis_dev = (NuisHost*)dp;
+        (void)hipGetLastError();
+        return 0;
+    }
+    (void)hipGetLastError();
+    HIPCK(hipHostMalloc((void**)&c->host_nuis, sizeof(NuisHost), hipHostMallocDefault));
+    memset(c->host_nuis, 0, sizeof(NuisHost));
+    return 0;
+}
+
+/* spin until *flag == seq (written by a kernel into mapped host memory) or `stream` has drained; true: the flag is there */
+static bool wait_host_flag(volatile int* flag, int seq, hipStream_t stream)
+{
+    for (unsigned spin = 0;; spin++) {
+        if (*flag == seq) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return true;
+        }
+        if ((spin & 0xfff) == 0xfff && hipStreamQuery(stream) != hipErrorNotReady) return *flag == seq;
+    }
+}
+
 /* tab_prev := the state before the move about to be decided, then (second stream) the full pass under p_test on it */
 static int enqueue_nuis_pass(ig_ctx* c, const float p_test[8], float mean_subfrag_kb)
 {
-    if (!c->host_nuis) HIPCK(hipHostMalloc((void**)&c->host_nuis, sizeof(NuisHost), hipHostMallocDefault));
+    if (ensure_host_nuis(c)) return -1;
     if (!c->pz_tab1) DALLOC(c->pz_tab1, PZ_MAX);
     /* the nuisance pass first (second stream), the move behind it (library stream): the pass is the longer of the two and
      * would otherwise start only when the host is through with the move's dozen launches */
@@ -1727,9 +1756,12 @@ static int enqueue_nuis_pass(ig_ctx* c, const float p_test[8], float mean_subfra
     c->pz_n1 = (need > 0 && need < (double)PZ_MAX) ? (int)need : ((need >= (double)PZ_MAX) ? PZ_MAX : 0);
     hipStream_t s3 = c->stream3;
     HIPCK(hipStreamWaitEvent(s3, c->ev_gathered, 0));
-    if (!launch_full_nz(c, c->tab_prev, 1, c->scratch_nuis, PzTab{c->pz_tab1, c->pz_n1}, s3, c->scratch_nuis + 2, &hp, mean_subfrag_kb))
-        hipLaunchKernelGGL(k_full_zero, dim3(128), dim3(256), 0, s3, c->tab_prev, c->glob, 1, c->M, c->scratch_nuis + 2);
-    HIPCK(hipMemcpyAsync(c->host_nuis->sums, c->scratch_nuis, 8 * sizeof(long long), hipMemcpyDeviceToHost, s3));
+    c->nuis_pub_sums = false;
+    c->pub_sums = (c->nuis_spec && c->host_nuis_dev) ? c->host_nuis_dev : nullptr; /* launch_full_nz: the tiled kernel's last workgroup publishes */
+    const bool zero_done = launch_full_nz(c, c->tab_prev, 1, c->scratch_nuis, PzTab{c->pz_tab1, c->pz_n1}, s3, c->scratch_nuis + 2, &hp, mean_subfrag_kb);
+    c->pub_sums = nullptr;
+    if (!zero_done) hipLaunchKernelGGL(k_full_zero, dim3(128), dim3(256), 0, s3, c->tab_prev, c->glob, 1, c->M, c->scratch_nuis + 2);
+    if (!c->nuis_pub_sums) HIPCK(hipMemcpyAsync(c->host_nuis->sums, c->scratch_nuis, 8 * sizeof(long long), hipMemcpyDeviceToHost, s3));
     return 0;
 }
 
@@ -1742,7 +1774,7 @@ extern "C" int ig_nuis_begin(ig_ctx* c, int32_t frag_a, const int32_t* cands, in
     if (validate_move(c, frag_a, cands, C)) return -1;
     if (ensure_move_buffers(c, std::max(8, (int)C))) return -1;
     if (ensure_io(c, 1, C)) return -1;
-    if (!c->host_nuis) HIPCK(hipHostMalloc((void**)&c->host_nuis, sizeof(NuisHost), hipHostMallocDefault));
+    if (ensure_host_nuis(c)) return -1;
     c->host_nuis->frag = frag_a;
     for (int i = 0; i < C; i++) c->host_nuis->cands[i] = cands[i];
     HIPCK(hipMemcpyAsync(c->d_frags, &c->host_nuis->frag, sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -1833,10 +1865,14 @@ extern "C" int ig_nuis_step_begin(ig_ctx* c, int32_t move, const float p_test[8]
     if (!c->spec_valid || c->spec_next >= c->spec_W || c->spec_base + c->spec_next != move) {
         if (nuis_spec_score(c, move)) return -1;
     }
-    launch_commit(c, c->spec_base, c->spec_next + 1, c->spec_next, c->spec_prev_pending ? 0 : 1);
-    /* the result record on its way as soon as the move is applied (copied again in the rare cases ig_nuis_end has to redo the move) */
-    HIPCK(hipMemcpyAsync(&c->host_nuis->res, c->d_results + move, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
-    if (queue_max_readback(c)) return -1;
+    /* the result record reaches the host as soon as the move is applied: written by k_commit_batch itself where the host
+     * memory is mapped, else copied (and copied in the rare cases ig_nuis_end has to redo the move) */
+    c->nuis_pub_res = c->host_nuis_dev != nullptr;
+    launch_commit(c, c->spec_base, c->spec_next + 1, c->spec_next, c->spec_prev_pending ? 0 : 1, c->nuis_pub_res);
+    if (!c->nuis_pub_res) {
+        HIPCK(hipMemcpyAsync(&c->host_nuis->res, c->d_results + move, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
+        if (queue_max_readback(c)) return -1;
+    }
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -1884,6 +1920,7 @@ static int nuis_spec_finish(ig_ctx* c)
     }
     c->spec_slot = c->spec_next;
     if (redone) {
+        c->nuis_pub_res = false;
         HIPCK(hipMemcpyAsync(&c->host_nuis->res, c->d_results + c->spec_move, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
         if (queue_max_readback(c)) return -1;
     }
@@ -1899,16 +1936,29 @@ extern "C" int ig_nuis_end(ig_ctx* c, ig_move_result* out, double* nz_test, doub
     c->nuis_in_flight = false;
     const auto w0 = std::chrono::steady_clock::now();
     if (c->nuis_spec && nuis_spec_finish(c)) return -1;
-    HIPCK(hipStreamSynchronize(c->stream));
-    HIPCK(hipStreamSynchronize(c->stream3));
+    if (c->nuis_spec && c->nuis_pub_res && wait_host_flag(&c->host_nuis->res_seq, c->res_seq, c->stream)) {
+        c->max_L = std::max(c->max_L, c->host_nuis->max_L);
+        c->max_SL = std::max(c->max_SL, c->host_nuis->max_SL);
+    } else {
+        if (c->nuis_spec && c->nuis_pub_res) { /* no flag although the stream has drained: fetch the record the plain way */
+            HIPCK(hipMemcpyAsync(&c->host_nuis->res, c->d_results + c->spec_move - 1, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
+            if (queue_max_readback(c)) return -1;
+        }
+        HIPCK(hipStreamSynchronize(c->stream));
+        take_max_readback(c);
+    }
+    if (!(c->nuis_spec && c->nuis_pub_sums && wait_host_flag(&c->host_nuis->sums_seq, c->sums_seq, c->stream3))) {
+        if (c->nuis_spec && c->nuis_pub_sums)
+            HIPCK(hipMemcpyAsync(c->host_nuis->sums, c->scratch_nuis, 8 * sizeof(long long), hipMemcpyDeviceToHost, c->stream3));
+        HIPCK(hipStreamSynchronize(c->stream3));
+    }
     c->nuis_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count(); /* ig_debug_nuis_wait */
     HIPCK(hipGetLastError());
     drain_timers(c);
-    take_max_readback(c);
     *out = c->host_nuis->res;
     if (out->error) return fail("device-side consistency failure %d", out->error);
     long long h[8];
-    memcpy(h, c->host_nuis->sums, sizeof h);
+    memcpy(h, (const void*)c->host_nuis->sums, sizeof h);
     ig_acc_normalize((int64_t*)&h[0], (int64_t*)&h[1]);
     ig_acc_normalize((int64_t*)&h[2], (int64_t*)&h[3]);
     if (nz_test) *nz_test = ig_acc_to_double(h[0], h[1]);

@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(64)
 __global__ void __launch_bounds__(COMMIT_THREADS)
     k_commit_batch(State st, Tables tab, Tables tab_prev, Glob* g, MoveBuf mb, const int* __restrict__ ip, const int* __restrict__ in,
                    const int* __restrict__ orientable, const unsigned char* __restrict__ black, int* own_tag, int* own_idx,
-                   int* prev_touched, ig_move_result* res, int move0, int W, int w_start, const int* batch_out)
+                   int* prev_touched, ig_move_result* res, int move0, int W, int w_start, const int* batch_out, NuisHost* hn, int hn_seq)
 {
     __shared__ long long sh_delta[IG_MAX_BATCH];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -808,6 +808,16 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
         }
         g->credit2 = c2;
         g->stamp_ctr = tag_base + W + 2;
+    }
+    if (hn) { /* the last committed move's record straight to the (mapped) host memory, then the flag the host spins on */
+        __syncthreads();
+        if (tid == 0) {
+            hn->res = res[move0 + committed - 1];
+            hn->max_L = g->max_L;
+            hn->max_SL = g->max_SL;
+            __threadfence_system();
+            hn->res_seq = hn_seq;
+        }
     }
 }
 

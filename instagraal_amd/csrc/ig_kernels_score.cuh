@@ -1057,7 +1057,7 @@ struct TileInfo { /* an off-diagonal tile whose counts are all in 1 .. TILE_HB-1
     int bi, bj, first_item, n_items;
 };
 struct TileDyn {
-    int count, next; /* items on the list (k_tile_trans), items taken (k_full_nz_tiled); zeroed by k_pack_tab_sig */
+    int count, next, done, pad; /* items on the list (k_tile_trans), items taken, workgroups through (k_full_nz_tiled); zeroed by k_pack_tab_sig */
 };
 struct FullTiledLds {
     ScoreTables tab;
@@ -1179,7 +1179,7 @@ __global__ void __launch_bounds__(256) k_nuis_prepare(Glob* g, int which, ig_par
 __global__ void __launch_bounds__(FULL_TILED_THREADS, 8) /* 8 waves per SIMD: two workgroups per CU need <= 80 SGPRs (112 admit 6 waves) */
     k_full_nz_tiled(const TileWork* __restrict__ work, const uint2* __restrict__ tc, const int4* __restrict__ rec, const int* __restrict__ len,
                     const ScoreConst* __restrict__ sc, const double* __restrict__ lgf_tab, int M, int pz_n, long long* out, int n_static,
-                    TileDyn* dyn, const int* __restrict__ dyn_list, long long* trace)
+                    TileDyn* dyn, const int* __restrict__ dyn_list, long long* trace, NuisHost* hn, int hn_seq)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     FullTiledLds& L = *(FullTiledLds*)lds_raw;
@@ -1333,6 +1333,15 @@ __global__ void __launch_bounds__(FULL_TILED_THREADS, 8) /* 8 waves per SIMD: tw
         }
         atomic_add_ll(&out[0], h);
         atomic_add_ll(&out[1], l);
+        if (hn) { /* the last workgroup through: all eight sums (out[2..] are k_tile_trans's) straight to the mapped host memory */
+            __threadfence();
+            if (atomicAdd(&dyn->done, 1) == (int)gridDim.x - 1) {
+                __threadfence();
+                for (int q = 0; q < 8; q++) hn->sums[q] = __hip_atomic_load(&out[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence_system();
+                hn->sums_seq = hn_seq;
+            }
+        }
         if (trace) { /* start, end (100 MHz clock), XCC_ID << 32 | HW_ID, items << 32 | contacts */
             unsigned hw, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));

@@ -44,7 +44,7 @@ __global__ void k_pack_tab(Tables t, int M, int4* __restrict__ rec)
 __device__ __forceinline__ void pack_tab_sig_block(const Tables& t, int M, int4* __restrict__ rec, unsigned* __restrict__ sig, int tb, int* dyn2)
 {
     __shared__ unsigned lsig[SIG_WORDS];
-    if (blockIdx.x == 0 && threadIdx.x == 0) dyn2[0] = dyn2[1] = 0; /* the list of tiles to read (k_tile_trans) and its cursor */
+    if (blockIdx.x == 0 && threadIdx.x == 0) dyn2[0] = dyn2[1] = dyn2[2] = 0; /* the list of tiles to read (k_tile_trans), its cursor, the workgroups through */
     for (int i = threadIdx.x; i < SIG_WORDS; i += blockDim.x) lsig[i] = 0;
     __syncthreads();
     const int s0 = blockIdx.x * tb;
