@@ -226,12 +226,14 @@ struct ig_ctx {
     hipStream_t stream3;           /* the nuisance step's full pass, next to the move it follows (ig_nuis_begin) */
     hipEvent_t ev_main;            /* everything queued on the library stream before the step in flight */
     hipEvent_t ev_gathered;        /* k_gather of the move in flight is done: tab_prev holds the state before that move */
+    long long* scratch_accept;     /* ig_nuis_accept's accumulators (zero between calls) */
     long long* scratch_nuis;       /* 8 x int64 reduction scratch of that pass */
     struct NuisHost* host_nuis;    /* pinned: its results and the move's */
     struct NuisHost *host_nuis_dev, *pub_sums; /* its device address when mapped; set while a pass that publishes its sums is enqueued */
     int res_seq, sums_seq;         /* launch numbers the flags in host_nuis are compared with */
     bool nuis_pub_res, nuis_pub_sums; /* the step in flight publishes its record / its sums itself */
     bool nuis_in_flight;
+    bool no_predict;     /* enqueue_score: no k_predict / predicted k_delta for this batch */
     bool nuis_caught_up; /* tab_prev is the state before the next move already and ev_gathered recorded (ig_nuis_step_next) */
     double nuis_wait_s; /* time ig_nuis_end spent waiting for the device (ig_debug_nuis_wait) */
     /* moves of a run of (move, nuisance step) pairs scored ahead in batches (ig_nuis_run_begin / ig_nuis_step_begin): the batch

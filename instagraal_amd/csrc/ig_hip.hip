@@ -270,6 +270,7 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipEventDestroy(c->ev_gathered);
     hipEventDestroy(c->ev_main);
     if (c->host_nuis) hipHostFree(c->host_nuis);
+    hipFree(c->scratch_accept);
     hipFree(c->scratch_nuis);
     hipEventDestroy(c->ev_slice);
     hipEventDestroy(c->ev_tail);
@@ -1119,7 +1120,6 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                     hipLaunchKernelGGL(k_screen, dim3(SLICE_SEG, (NSLOT + 1) / 2, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->screen_const, c->mb,
                                        c->mb.scr, c->mb.scr_void, c->mb.scr_ub, max_c, w_begin);
                 }
-                hipMemsetAsync(c->mb.work, 0, 16 * sizeof(unsigned long long), c->stream);
                 if (c->exact_grid <= 0) c->exact_grid = 32768;
                 c->exact_grid = std::min(c->exact_grid, c->mb.work_cap);
                 hipStreamWaitEvent(c->stream, c->ev_tail, 0); /* the contender test reads the exact tail sums (quirk Q5) */
@@ -1160,7 +1160,9 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                 hipStreamWaitEvent(c->stream, c->ev_tail, 0);
             TimedLaunch t(c, T_FINALIZE);
             hipLaunchKernelGGL(k_records, dim3(max_c, nW), dim3(64), 0, c->stream, c->mb, w_begin, c->own_screened ? 1 : 0);
-            if (phase == 2 && W > 1 && c->world == 1) { /* batches: predicted windowed winners get their exact delta now */
+            /* batches: predicted windowed winners get their exact delta now (not those decided one move per call, ig_nuis_step_begin:
+             * a pause costs them nothing they would not wait for anyway) */
+            if (phase == 2 && W > 1 && c->world == 1 && !c->no_predict) {
                 static const int s_pred2 = getenv("IG_PREDICT_PASSES") ? atoi(getenv("IG_PREDICT_PASSES")) : 2;
                 if (s_pred2 >= 2) hipLaunchKernelGGL(k_predict, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, w_begin, 0);
                 hipLaunchKernelGGL(k_predict, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, w_begin, 1);
@@ -1845,7 +1847,10 @@ static int nuis_spec_score(ig_ctx* c, int move)
     nuis_spec_invalidate(c);
     const int W = std::min(nuis_spec_width(c), c->up_moves - move);
     if (ensure_window_buffers(c)) return -1; /* the longest contig may have grown */
+    static const int s_nopred = getenv("IG_NUIS_PREDICT") ? !atoi(getenv("IG_NUIS_PREDICT")) : 1;
+    c->no_predict = s_nopred != 0;
     enqueue_score(c, move, W, c->up_max_c, -1, 2);
+    c->no_predict = false;
     c->spec_base = move;
     c->spec_W = W;
     c->spec_next = 0;
@@ -1980,25 +1985,29 @@ extern "C" int ig_nuis_end(ig_ctx* c, ig_move_result* out, double* nz_test, doub
  * exact sum under the new parameters on the CURRENT state = their full pass on the state before the last move (what the
  * step just evaluated, quirk Q12) + that move's exact delta under them (k_delta over the touched contigs); the zero-pixel sum
  * is recounted (O(M)) */
-__global__ void k_nuis_zero(MoveBuf mb, long long* scratch_z, int w)
+/* acc8: {zero-pixel hi, lo, pair count (k_full_zero), .., .., .., the move's delta hi, lo (k_delta)} -- all zero between two
+ * accepted steps: the promotion clears what it has read.  One launch: thread 0 of block 0 promotes (parameters, maintained
+ * sums), every block builds its share of the model's score / screening constants from the SAME parameters (set 1: what set 0
+ * is being overwritten with), i.e. k_build_score_const and k_build_screen_const for the promoted set. */
+__global__ void __launch_bounds__(256) k_nuis_promote(Glob* g, const long long* __restrict__ full_sums, long long* acc8, PzTab pz,
+                                                      const double* __restrict__ lgf_tab, ScoreConst* score_const, ScreenConst* screen_const)
 {
-    mb.ctl[w].d_hi = mb.ctl[w].d_lo = 0;
-    for (int i = 0; i < 8; i++) scratch_z[i] = 0;
-}
-__global__ void k_nuis_promote(Glob* g, MoveBuf mb, const long long* __restrict__ full_sums, const long long* __restrict__ zero_sums, int w)
-{
-    g->par[0] = g->par[1];
-    long long h = full_sums[0] + mb.ctl[w].d_hi, l = full_sums[1] + mb.ctl[w].d_lo;
-    ig_acc_normalize((int64_t*)&h, (int64_t*)&l);
-    g->nz_hi = h;
-    g->nz_lo = l;
-    h = zero_sums[0];
-    l = zero_sums[1];
-    ig_acc_normalize((int64_t*)&h, (int64_t*)&l);
-    g->z_hi = h;
-    g->z_lo = l;
-    if (zero_sums[2] != g->n_intra) g->error = 8; /* the pair count does not depend on the parameters */
-    mb.ctl[w].d_hi = mb.ctl[w].d_lo = 0;
+    build_score_const_block(g, pz, lgf_tab, score_const, 1);
+    build_screen_const_block(g, pz, screen_const, 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g->par[0] = g->par[1];
+        long long h = full_sums[0] + acc8[6], l = full_sums[1] + acc8[7];
+        ig_acc_normalize((int64_t*)&h, (int64_t*)&l);
+        g->nz_hi = h;
+        g->nz_lo = l;
+        h = acc8[0];
+        l = acc8[1];
+        ig_acc_normalize((int64_t*)&h, (int64_t*)&l);
+        g->z_hi = h;
+        g->z_lo = l;
+        if (acc8[2] != g->n_intra) g->error = 8; /* the pair count does not depend on the parameters */
+        for (int q = 0; q < 8; q++) acc8[q] = 0;
+    }
 }
 
 extern "C" int ig_nuis_accept(ig_ctx* c)
@@ -2015,22 +2024,24 @@ extern "C" int ig_nuis_accept(ig_ctx* c)
         c->nuis_spec = run;
         return rc;
     }
-    long long* zs = c->scratch8; /* the zero-pixel recount (the from-scratch passes' scratch is free between calls) */
+    if (!c->scratch_accept) {
+        DALLOC(c->scratch_accept, 8);
+        HIPCK(hipMemset(c->scratch_accept, 0, 8 * sizeof(long long)));
+    }
+    long long* acc8 = c->scratch_accept;
     const int w = c->spec_slot; /* the slot of the move just applied (0 unless it came out of a batch: ig_nuis_step_begin) */
     nuis_spec_invalidate(c);    /* whatever was scored ahead was scored under the old parameters */
-    hipLaunchKernelGGL(k_nuis_zero, dim3(1), dim3(1), 0, c->stream, c->mb, zs, w);
     const PzTab pz1{c->pz_tab1, c->pz_n1};
     /* the move's delta under the new parameters; contig membership of the partners as of BEFORE the move: tab_prev */
     hipLaunchKernelGGL(k_delta, dim3(DELTA_RB, 2, 1), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab_prev, c->tab_prev,
-                       c->prev_touched, c->glob, c->mb, c->lgf_tab, pz1, w, 2, 1);
-    hipLaunchKernelGGL(k_full_zero, dim3(128), dim3(256), 0, c->stream, c->tab, c->glob, 1, c->M, zs);
-    hipLaunchKernelGGL(k_nuis_promote, dim3(1), dim3(1), 0, c->stream, c->glob, c->mb, c->scratch_nuis, zs, w);
-    /* the tables of the model's parameter set: the test set's P_z table becomes the model's */
+                       c->prev_touched, c->glob, c->mb, c->lgf_tab, pz1, w, 2, 1, acc8 + 6);
+    hipLaunchKernelGGL(k_full_zero, dim3(128), dim3(256), 0, c->stream, c->tab, c->glob, 1, c->M, acc8);
+    /* the promotion, and the tables of the model's parameter set: the test set's P_z table becomes the model's */
     std::swap(c->pz_tab, c->pz_tab1);
     std::swap(c->pz_n, c->pz_n1);
     const PzTab pz0{c->pz_tab, c->pz_n};
-    hipLaunchKernelGGL(k_build_score_const, dim3((LDS_PZ + 2 + 255) / 256), dim3(256), 0, c->stream, c->glob, pz0, c->lgf_tab, c->score_const, 0);
-    hipLaunchKernelGGL(k_build_screen_const, dim3((LDS_PZ + 2 + 255) / 256), dim3(256), 0, c->stream, c->glob, pz0, c->screen_const);
+    hipLaunchKernelGGL(k_nuis_promote, dim3((LDS_PZ + 2 + 255) / 256), dim3(256), 0, c->stream, c->glob, c->scratch_nuis, acc8, pz0, c->lgf_tab,
+                       c->score_const, c->screen_const);
     HIPCK(hipGetLastError());
     return 0;
 }

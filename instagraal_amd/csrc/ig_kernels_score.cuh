@@ -89,6 +89,7 @@ __global__ void __launch_bounds__(256)
     const int w = blockIdx.x;
     if (w >= W) return;
     const int t = threadIdx.x;
+    if (w == 0 && t < 16 && mb.work) mb.work[t] = 0; /* the exact kernel's work list: lengths and needs of the sub-lists (k_worklist) */
     const int A = frags_all[move0 + w];
     const int* cands = cands_all + (size_t)(move0 + w) * max_c;
     const int C = sh_C[w];
@@ -761,7 +762,7 @@ struct ScoreConst {
     float mean_kb;
 };
 static_assert(sizeof(ScoreTables) % 16 == 0, "copied as 16-byte vectors");
-__global__ void k_build_score_const(const Glob* g, PzTab pz, const double* __restrict__ lgf_tab, ScoreConst* out, int which)
+__device__ __forceinline__ void build_score_const_block(const Glob* g, PzTab pz, const double* __restrict__ lgf_tab, ScoreConst* out, int which)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const ig_params p = g->par[which];
@@ -774,6 +775,10 @@ __global__ void k_build_score_const(const Glob* g, PzTab pz, const double* __res
         out->par = p;
         out->mean_kb = g->mean_kb;
     }
+}
+__global__ void k_build_score_const(const Glob* g, PzTab pz, const double* __restrict__ lgf_tab, ScoreConst* out, int which)
+{
+    build_score_const_block(g, pz, lgf_tab, out, which);
 }
 
 template <int CAP>
@@ -1360,7 +1365,7 @@ __global__ void __launch_bounds__(FULL_TILED_THREADS, 8) /* 8 waves per SIMD: tw
 __global__ void __launch_bounds__(SCORE_THREADS)
     k_delta(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, Tables tab_prev,
             const int* __restrict__ prev_touched, Glob* g, MoveBuf mb, const double* __restrict__ lgf_tab, PzTab pz, int w, int predicted,
-            int which)
+            int which, long long* acc2 = nullptr)
 {
     /* predicted = 0: the chosen winner of slot w (one-move tail); 1: the predicted winners of slots w + blockIdx.z;
      * 2: the winner of slot w AFTER it was applied, under parameter set `which` (an accepted nuisance step: the maintained
@@ -1478,8 +1483,9 @@ __global__ void __launch_bounds__(SCORE_THREADS)
         if (hi | lo) {
             /* a predicted winner's delta goes straight into the records (candidate 0 of the slot): the decide step reads it there */
             CandPre& pc = cpre_at(mb, CW(w, 0));
-            atomic_add_ll(predicted == 1 ? &pc.pd_hi : &mc.d_hi, kk == 0 ? -hi : hi);
-            atomic_add_ll(predicted == 1 ? &pc.pd_lo : &mc.d_lo, kk == 0 ? -lo : lo);
+            /* (an accepted nuisance step's delta, predicted == 2: into the caller's accumulators) */
+            atomic_add_ll(acc2 ? &acc2[0] : (predicted == 1 ? &pc.pd_hi : &mc.d_hi), kk == 0 ? -hi : hi);
+            atomic_add_ll(acc2 ? &acc2[1] : (predicted == 1 ? &pc.pd_lo : &mc.d_lo), kk == 0 ? -lo : lo);
         }
     }
 }

@@ -46,10 +46,10 @@ struct alignas(16) ScreenConst {
     int pz_n;      /* length of the P_z table the exact path uses */
 };
 
-__global__ void k_build_screen_const(const Glob* g, PzTab pz, ScreenConst* out)
+__device__ __forceinline__ void build_screen_const_block(const Glob* g, PzTab pz, ScreenConst* out, int which)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const ig_params p = g->par[0];
+    const ig_params p = g->par[which];
     const int pzn = min(pz.n, LDS_PZ);
     if (i < LDS_PZ + 2) out->pzc[i] = (float)((double)(i < pzn ? pz.v[i] : p.v_inter) * IG_LOG_E_F);
     if (i == 0) {
@@ -86,6 +86,7 @@ __global__ void k_build_screen_const(const Glob* g, PzTab pz, ScreenConst* out)
         }
     }
 }
+__global__ void k_build_screen_const(const Glob* g, PzTab pz, ScreenConst* out) { build_screen_const_block(g, pz, out, 0); }
 
 /* per (candidate, column): approximate slice sum and its bound (2^-20 units), and the columns whose bound is void */
 struct ScreenSum {
