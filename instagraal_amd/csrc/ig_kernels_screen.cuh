@@ -406,7 +406,10 @@ __device__ __forceinline__ void screen_publish(const ScreenConst* __restrict__ s
         atomic_add_ll(&scr[cw * NSLOT + k].b_fix, (long long)__builtin_ceil(bound * SCR_FIX) + 2);
     }
 }
-__global__ void __launch_bounds__(SCORE_THREADS)
+#ifndef SCREEN_MIN_WAVES
+#define SCREEN_MIN_WAVES 7 /* seven workgroups per CU (what the LDS admits) need <= 96 SGPRs (106 admit six) */
+#endif
+__global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
     k_screen(const ScreenConst* __restrict__ sc, MoveBuf mb, ScreenSum* __restrict__ scr, unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub,
              int max_c, int w_begin)
 {
