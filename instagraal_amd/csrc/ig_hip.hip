@@ -1801,13 +1801,21 @@ extern "C" int ig_nuis_begin(ig_ctx* c, int32_t frag_a, const int32_t* cands, in
  * moves starting at i if move i has no valid scores yet (first step, after an accepted step, after a conflict, batch used
  * up), and decides + applies move i ALONE from its records (k_decide_batch over one slot); ig_nuis_end / ig_nuis_accept as
  * above.  An accepted step invalidates the slots scored ahead.  Same results as one move and one step at a time. */
+static int g_nuis_w = -1; /* moves scored ahead per launch in a run of ig_nuis_step_begin: env IG_NUIS_W, ig_set_nuis_width; 0: follow the run lengths */
 static int nuis_spec_width(ig_ctx* c)
 {
-    static const int s_w = getenv("IG_NUIS_W") ? atoi(getenv("IG_NUIS_W")) : 0; /* 0: follow the run lengths */
+    if (g_nuis_w < 0) g_nuis_w = getenv("IG_NUIS_W") ? std::max(0, atoi(getenv("IG_NUIS_W"))) : 0;
+    const int s_w = g_nuis_w;
     const int cap = std::min(c->mb.capW, IG_MAX_BATCH);
     if (s_w > 0) return std::min(s_w, cap);
     if (c->spec_ema <= 0.0) c->spec_ema = 3.0;
     return std::max(1, std::min(cap, (int)(1.5 * c->spec_ema + 1.5)));
+}
+
+extern "C" int ig_set_nuis_width(int w)
+{
+    g_nuis_w = std::max(0, w);
+    return 0;
 }
 
 extern "C" int ig_nuis_run_begin(ig_ctx* c, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c)
@@ -1819,7 +1827,8 @@ extern "C" int ig_nuis_run_begin(ig_ctx* c, int32_t n_moves, const int32_t* frag
     if (n_moves <= 0) return fail("ig_nuis_run_begin: no moves");
     if (max_c < 1 || max_c > IG_MAX_CANDIDATES) return fail("ig_nuis_run_begin: max_c out of range");
     static const int s_cap = getenv("IG_NUIS_WMAX") ? atoi(getenv("IG_NUIS_WMAX")) : 12;
-    const int Wmax = c->init_links_inverse ? std::max(1, std::min(s_cap, max_batch_width(c, max_c))) : 1;
+    if (g_nuis_w < 0) g_nuis_w = getenv("IG_NUIS_W") ? std::max(0, atoi(getenv("IG_NUIS_W"))) : 0;
+    const int Wmax = c->init_links_inverse ? std::max(1, std::min(std::max(s_cap, g_nuis_w), max_batch_width(c, max_c))) : 1;
     if (ensure_move_buffers(c, std::max(8, (int)max_c), Wmax)) return -1;
     if (upload_moves(c, n_moves, frags, cands, max_c)) return -1;
     c->nuis_spec = true;

@@ -165,6 +165,11 @@ def set_batch_width(w):
     _ck(lib().ig_set_batch_width(C.c_int(int(w))))
 
 
+def set_nuis_width(w):
+    """moves scored ahead per launch by the nuisance-on loop (``Context.nuis_step_begin``); 0 = follow the run lengths"""
+    _ck(lib().ig_set_nuis_width(C.c_int(int(w))))
+
+
 def debug_set_full_hist(on):
     """from-scratch pass over all contacts: tiles of trans pairs only from their count histograms (default) or contact by
     contact -- same exact sums (tests)"""

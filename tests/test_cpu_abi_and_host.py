@@ -60,6 +60,35 @@ def test_rippe_fit_matches_reference_host_functions():
     assert np.allclose(y, g["y_est"], rtol=1e-8, atol=0)
 
 
+def test_root_finding_fast_path_is_fsolve():
+    """estimate_max_dist_intra_nuis is solved twice per nuisance step on the host's critical path: ``_solve`` reaches MINPACK's
+    hybrd without fsolve's Python layers.  Same routine, same arguments, same residual: the very same root, bit for bit, as
+    ``fsolve(residual_4_max_dist, ...)`` (what the reference calls, optim_rippe_curve_update.py:137-149) -- float32 and float
+    inputs (the dtype of the start value sets the step of the forward differences), NaN and negative starts included."""
+    from instagraal_amd import optim_rippe_curve_update as opti
+    from instagraal_amd import synth
+
+    if opti._hybrd is None:
+        pytest.skip("this scipy does not expose _minpack._hybrd: the public fsolve is used")
+    p = synth.rippe_params(1.8)
+    rng = np.random.RandomState(0)
+    for it in range(600):
+        cast = (lambda v: np.float32(v)) if it % 2 == 0 else (lambda v: float(v))
+        kuhn, lm, d = cast(p["kuhn"]), cast(p["lm"]), cast(p["d"])
+        slope = cast(p["slope"] + rng.normal(0, 0.05))
+        fact = cast(p["fact"] * np.exp(rng.normal(0, 0.3)))
+        d_nuc = cast(p["v_inter"] * np.exp(rng.normal(0, 0.5)))
+        s0 = cast(p["d_max"] * np.exp(rng.normal(0, 0.3)))
+        if it % 97 == 0:
+            s0 = cast(np.nan)
+        if it % 101 == 0:
+            s0 = cast(-300.0)
+        a = opti._solve_fsolve([kuhn, lm, slope, d, fact], d_nuc, s0)
+        b = opti._solve([kuhn, lm, slope, d, fact], d_nuc, s0)
+        assert type(a) is type(b)
+        assert a == b or (a != a and b != b), (it, a, b)
+
+
 def test_initial_rippe_estimation_matches_reference():
     """the host part of estimate_parameters_rippe (CL:2239-2341) against the reference's own method
     driven as simu_single does (tools/gen_golden.py::estimate_golden): same bins, same binned means, same fit."""

@@ -531,9 +531,14 @@ def test_nuisance_batch_matches_golden_and_the_sequential_calls():
     assert np.array_equal(s.gpu_vect_frags.copy_from_gpu().soa17(), g["states"][-1])
     s.free_gpu()
 
+    from instagraal_amd import hip_lib
+
     prob = synth.make_problem(*synth.CONFIGS["small"])
     outs = []
-    for batch in (False, True):
+    # one call at a time; the run with the moves scored ahead in batches of 1 / 3 / 12 / a width that follows the run lengths
+    for batch in (False, 1, 3, 12, 0):
+        if batch is not False:
+            hip_lib.set_nuis_width(batch)
         np.random.seed(8)
         s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
         s.set_param_simu(prob.params)
@@ -541,7 +546,7 @@ def test_nuisance_batch_matches_golden_and_the_sequential_calls():
         s.eval_likelihood_init()
         frags = np.random.permutation(prob.n_frags)[:70]
         np.random.normal()  # a cached gaussian in the generator at the start of the run
-        if batch:
+        if batch is not False:
             res, tuples = s.step_sampler_nuisance_batch(frags, 5, s.dt, 0, 70)
             rows = [(float(r["o"]), float(r["dist"]), int(r["op_sampled"]), int(r["id_f_sampled"]), int(r["n_contigs"])) for r in res]
             nu = [tuple(float(np.ravel(x)[0]) for x in q[:7]) for q in tuples]
@@ -558,8 +563,41 @@ def test_nuisance_batch_matches_golden_and_the_sequential_calls():
         outs.append((rows, nu, s.gpu_vect_frags.copy_from_gpu().soa17(), np.random.get_state()[1][:6].copy(), np.random.get_state()[2:],
                      [float(s.param_simu[k][0]) for k in ("fact", "slope", "d_max", "v_inter")]))
         s.free_gpu()
-    assert outs[0][0] == outs[1][0]
-    assert outs[0][1] == outs[1][1]
-    assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3]) and outs[0][4] == outs[1][4]
-    assert outs[0][5] == outs[1][5]
-    assert sum(q[6] for q in outs[0][1]) > 0  # some steps were accepted: the accepted branch is covered
+    hip_lib.set_nuis_width(0)
+    for o in outs[1:]:
+        assert outs[0][0] == o[0]
+        assert outs[0][1] == o[1]
+        assert np.array_equal(outs[0][2], o[2]) and np.array_equal(outs[0][3], o[3]) and outs[0][4] == o[4]
+        assert outs[0][5] == o[5]
+    assert 0 < sum(q[6] for q in outs[0][1]) < 70  # steps were accepted and rejected: both branches are covered
+
+
+def test_nuisance_run_entry_points_refuse_misuse():
+    """ig_nuis_run_begin / ig_nuis_step_begin / ig_nuis_step_next: moves in order only, one step in flight, no run after
+    another entry point has changed the genome."""
+    from instagraal_amd import hip_lib, synth
+    from instagraal_amd.sampler import PARAM_NAMES, problem_to_context
+
+    prob = synth.make_problem(*synth.CONFIGS["tiny"])
+    ctx = problem_to_context(prob)
+    p8 = [np.float32(prob.params[k]) for k in PARAM_NAMES]
+    frags = np.arange(6, dtype=np.int32)
+    cands = np.array([[(f + 7 + 3 * q) % prob.n_frags for q in range(3)] for f in frags], np.int32)
+    with pytest.raises(hip_lib.HipError, match="no run"):
+        ctx.nuis_step_begin(0, p8, prob.mean_subfrag_kb)
+    ctx.nuis_run_begin(frags, cands)
+    with pytest.raises(hip_lib.HipError, match="expected 0"):
+        ctx.nuis_step_begin(1, p8, prob.mean_subfrag_kb)
+    ctx.nuis_step_begin(0, p8, prob.mean_subfrag_kb)
+    with pytest.raises(hip_lib.HipError, match="not ended"):
+        ctx.nuis_step_begin(1, p8, prob.mean_subfrag_kb)
+    r, nz, z, acc = ctx.nuis_step_next(1e6, float("inf"), p8, None, prob.mean_subfrag_kb, True)  # no finite ratio reaches u = inf: rejected
+    assert acc == 0 and r.error == 0 and np.isfinite(nz + z)
+    r, nz, z, acc = ctx.nuis_step_next(1e6, 0.0, None, None, prob.mean_subfrag_kb, True)  # u = 0: accepted; no parameters for the next step
+    assert acc == 1
+    ctx.nuis_step_begin(2, p8, prob.mean_subfrag_kb)  # ... so the caller begins it
+    ctx.nuis_end()
+    ctx.step(int(frags[3]), cands[3])  # any other move ends the run
+    with pytest.raises(hip_lib.HipError, match="no run"):
+        ctx.nuis_step_begin(3, p8, prob.mean_subfrag_kb)
+    ctx.close()
