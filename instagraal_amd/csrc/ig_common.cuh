@@ -276,6 +276,7 @@ struct ig_ctx {
     int* batch_out; /* committed moves, pending slot, (unused), candidates, predicted deltas used, contigs */
     int *host_bo, *host_bo_dev; /* the same in mapped host memory (+ [7] = sequence number of the decide launch), and its device address */
     int bo_seq;
+    int last_stop; /* what the last decided batch stopped at: 0 a conflict / its end, 1 the slice pool, 2 the exact kernel's grid */
     int n_contigs_seen; /* contigs after the last batch (0: none yet): picks k_mutate's launch shape */
     double w_ema; /* moving average of the moves a batch gets through: sets the width of the next one */
     int* dirty_buf; /* [1 + 2 * IG_MAX_BATCH + 2] contigs modified by the committed moves of the batch in flight */

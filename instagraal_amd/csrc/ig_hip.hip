@@ -1272,6 +1272,7 @@ static int wait_commit(ig_ctx* c, int bo[12], bool first_of_batch, int next)
     c->n_contigs_seen = bo[5];
     c->max_L = std::max(c->max_L, bo[8]);
     c->max_SL = std::max(c->max_SL, bo[9]);
+    c->last_stop = bo[10];
     return 0;
 }
 
@@ -1403,8 +1404,14 @@ static int run_moves(ig_ctx* c, int n_moves, int max_c, int Wmax, Ready ready)
             }
             continue;
         }
-        if (w_now == w_want) /* a batch cut short by the end of the run says nothing */
+        if (next < w_now && c->last_stop == 1 && (size_t)c->mb.pool_cap < slice_pool_max(c)) {
+            /* cut short by the slice pool, not by a conflict: twice the room for the batches to come (the pool starts at 2 Z
+             * entries; small problems with long contigs need more than that for 24 slots) */
+            HIPCK(hipStreamSynchronize(c->stream));
+            if (alloc_slice_pool(c, std::min(slice_pool_max(c), (size_t)c->mb.pool_cap * 2))) return -1;
+        } else if (w_now == w_want) { /* a batch cut short by the end of the run says nothing */
             c->w_ema = 0.6 * c->w_ema + 0.4 * (next >= w_now ? std::min(2.0 * w_now, (double)Wmax) : (double)next);
+        }
         done += next;
     }
     return 0;
@@ -1534,6 +1541,9 @@ extern "C" int ig_batch_commit(ig_ctx* c, int32_t move0, int32_t W, int32_t* n_c
             c->exact_grid = std::min(c->mb.work_cap, c->exact_grid * 4);
         }
         next = 0;
+    } else if (next < W && c->last_stop == 1 && (size_t)c->mb.pool_cap < slice_pool_max(c)) { /* cut short by the slice pool: more room for the batches to come */
+        HIPCK(hipStreamSynchronize(c->stream));
+        if (alloc_slice_pool(c, std::min(slice_pool_max(c), (size_t)c->mb.pool_cap * 2))) return -1;
     }
     *n_committed = next;
     return 0;

@@ -600,6 +600,7 @@ __global__ void __launch_bounds__(64)
             batch_out[2] = (committed == w_start && pending < 0) ? stop_overflow : 0; /* nothing done because the first slot did not fit a pool */
             batch_out[8] = max_L;
             batch_out[9] = max_SL;
+            batch_out[10] = stop_overflow; /* what the batch stopped at, if a pool: the host makes more room for the next ones */
             batch_out[3] = n_cand;
             batch_out[4] = n_predicted;
             batch_out[5] = n_contigs;
@@ -615,6 +616,7 @@ __global__ void __launch_bounds__(64)
                 host_out[2] = (committed == w_start && pending < 0) ? stop_overflow : 0;
                 host_out[8] = max_L;
                 host_out[9] = max_SL;
+                host_out[10] = stop_overflow;
                 host_out[3] = n_cand;
                 host_out[4] = n_predicted;
                 host_out[5] = n_contigs;

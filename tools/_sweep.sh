@@ -1,4 +1,4 @@
-for v in "IG_NUIS_W=1" "IG_NUIS_W=2" "IG_NUIS_W=3" "IG_NUIS_W=4" "IG_NUIS_W=6" "IG_NUIS_W=8"; do
-echo "== $v"
-env $v NUIS_ONLY=1 python tools/nuisance_rate.py cfg3 600 2>&1 | grep "moves/s\|batches"
+for i in 1 2; do
+python bench.py --config cfg2 --no-cpu-baseline --nuisance-moves 0 2>&1 | tail -1 | cut -c1-120
+IG_HIP_LIB=$GRAFT_REPO_ROOT/tune_nolb.so python bench.py --config cfg2 --no-cpu-baseline --nuisance-moves 0 2>&1 | tail -1 | cut -c1-120
 done
