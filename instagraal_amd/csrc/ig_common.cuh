@@ -233,6 +233,7 @@ struct ig_ctx {
     int res_seq, sums_seq;         /* launch numbers the flags in host_nuis are compared with */
     bool nuis_pub_res, nuis_pub_sums; /* the step in flight publishes its record / its sums itself */
     bool nuis_in_flight;
+    bool tail_fused;     /* the batch in flight: the Q5 tail walk ran inside the screening kernel's launch (no second stream, no events) */
     bool no_predict;     /* enqueue_score: no k_predict / predicted k_delta for this batch */
     bool nuis_caught_up; /* tab_prev is the state before the next move already and ev_gathered recorded (ig_nuis_step_next) */
     double nuis_wait_s; /* time ig_nuis_end spent waiting for the device (ig_debug_nuis_wait) */

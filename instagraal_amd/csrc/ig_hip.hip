@@ -1100,29 +1100,39 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                     hipLaunchKernelGGL(k_slice<false>, dim3(rb, max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob,
                                        c->mb, c->rank, c->world, w_begin);
             }
-            if (phase == 2) { /* the Q5 tail walk only needs the slice: second stream, next to k_score_list */
+            /* two-tier scoring (batches on one handle, packed lists): every column through the float screening kernel, the exact
+             * kernel only for the columns that can still win (ig_kernels_screen.cuh).  IG_SCREEN=0: everything exact;
+             * IG_SCREEN_VERIFY=1: everything exact AND screened, the bound checked column by column. */
+            const int s_screen = getenv("IG_SCREEN") ? atoi(getenv("IG_SCREEN")) : 1; /* read per launch, like the next one */
+            const int verify = getenv("IG_SCREEN_VERIFY") ? atoi(getenv("IG_SCREEN_VERIFY")) : 0; /* read per launch: a test toggles it */
+            static const int s_screen_min_w = getenv("IG_SCREEN_MIN_W") ? atoi(getenv("IG_SCREEN_MIN_W")) : 2;
+            const bool screen = (s_screen || verify) && phase == 2 && W >= s_screen_min_w && W > 1 && c->world == 1 && c->mb.packed;
+            /* the Q5 tail walk only needs the slice: in the screening kernel's launch (k_screen_tail), else on a second stream
+             * next to k_score_list */
+            static const int s_fuse = getenv("IG_FUSE_TAIL") ? atoi(getenv("IG_FUSE_TAIL")) : 1;
+            c->tail_fused = screen && s_fuse;
+            if (phase == 2 && !c->tail_fused) {
                 hipEventRecord(c->ev_slice, c->stream);
                 hipStreamWaitEvent(c->stream2, c->ev_slice, 0);
                 hipLaunchKernelGGL(k_tail, dim3(max_c, nW), dim3(256), 0, c->stream2, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->lgf_tab,
                                    g_tail_quirk, pz, w_begin);
                 hipEventRecord(c->ev_tail, c->stream2);
             }
-            /* two-tier scoring (batches on one handle, packed lists): every column through the float screening kernel, the exact
-             * kernel only for the columns that can still win (ig_kernels_screen.cuh).  IG_SCREEN=0: everything exact;
-             * IG_SCREEN_VERIFY=1: everything exact AND screened, the bound checked column by column. */
-            const int s_screen = getenv("IG_SCREEN") ? atoi(getenv("IG_SCREEN")) : 1; /* read per launch, like the next one */
-            const int verify = getenv("IG_SCREEN_VERIFY") ? atoi(getenv("IG_SCREEN_VERIFY")) : 0; /* read per launch: a test toggles it */
-            const bool screen = (s_screen || verify) && phase == 2 && W > 1 && c->world == 1 && c->mb.packed;
             int contenders_only = 0;
             if (screen) {
                 {
                     TimedLaunch t(c, T_SCREEN);
-                    hipLaunchKernelGGL(k_screen, dim3(SLICE_SEG, (NSLOT + 1) / 2, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->screen_const, c->mb,
-                                       c->mb.scr, c->mb.scr_void, c->mb.scr_ub, max_c, w_begin);
+                    if (c->tail_fused)
+                        hipLaunchKernelGGL(k_screen_tail, dim3(max_c * nW + SLICE_SEG * ((NSLOT + 1) / 2) * max_c * nW), dim3(SCORE_THREADS), 0, c->stream,
+                                           c->screen_const, c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, max_c, w_begin, max_c * nW, c->rowptr, c->cc,
+                                           c->tab, c->glob, c->lgf_tab, g_tail_quirk, pz);
+                    else
+                        hipLaunchKernelGGL(k_screen, dim3(SLICE_SEG, (NSLOT + 1) / 2, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->screen_const,
+                                           c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, max_c, w_begin);
                 }
                 if (c->exact_grid <= 0) c->exact_grid = 32768;
                 c->exact_grid = std::min(c->exact_grid, c->mb.work_cap);
-                hipStreamWaitEvent(c->stream, c->ev_tail, 0); /* the contender test reads the exact tail sums (quirk Q5) */
+                if (!c->tail_fused) hipStreamWaitEvent(c->stream, c->ev_tail, 0); /* the contender test reads the exact tail sums (quirk Q5) */
                 hipLaunchKernelGGL(k_contend, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, c->mb.cont, w_begin,
                                    getenv("IG_CONTEND_ALL") ? atoi(getenv("IG_CONTEND_ALL")) : 0, c->exact_grid,
                                    getenv("IG_EXACT_CHUNK") ? std::max(256, atoi(getenv("IG_EXACT_CHUNK"))) : EXACT_CHUNK);
@@ -1156,7 +1166,7 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
             if (phase == 1) /* after the all-reduce of the list lengths (contact shards): no overlap */
                 hipLaunchKernelGGL(k_tail, dim3(max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->lgf_tab,
                                    g_tail_quirk, pz, w_begin);
-            else
+            else if (!c->tail_fused)
                 hipStreamWaitEvent(c->stream, c->ev_tail, 0);
             TimedLaunch t(c, T_FINALIZE);
             hipLaunchKernelGGL(k_records, dim3(max_c, nW), dim3(64), 0, c->stream, c->mb, w_begin, c->own_screened ? 1 : 0);

@@ -316,7 +316,12 @@ __global__ void __launch_bounds__(64)
      * is still valid wherever it does not touch a contig modified so far (dirty_buf carries the list across the calls).
      * resumed_plain: slot w_start - 1 was committed by an earlier launch of this kernel (a batch decided one move per call,
      * ig_nuis_step_begin): its contigs are on the list already */
-    __shared__ int dirty[IG_MAX_BATCH * 2 + 2];
+    /* the contigs modified so far: entry q lives in lane q % 64 (register q / 64) -- the test of a move against the list is a
+     * handful of compares and a ballot per candidate instead of a walk over an LDS array (it was a third of a decision) */
+    constexpr int ND = (IG_MAX_BATCH * 2 + 2 + 63) / 64;
+    int dirty[ND];
+#pragma unroll
+    for (int j = 0; j < ND; j++) dirty[j] = -2; /* no contig has this id */
     const int tid = threadIdx.x, lane = tid & 63;
     {
         /* ------------------------------------------------------------ 1. decide */
@@ -335,13 +340,16 @@ __global__ void __launch_bounds__(64)
         int max_L = g->max_L, max_SL = g->max_SL;
         if (w_start > 0) {
             n_dirty = dirty_buf[0];
-            for (int q = lane; q < n_dirty; q += 64) dirty[q] = dirty_buf[1 + q];
+#pragma unroll
+            for (int j = 0; j < ND; j++)
+                if (lane + 64 * j < n_dirty) dirty[j] = dirty_buf[1 + lane + 64 * j];
             if (!resumed_plain) {
                 const MoveCtl pm = mb.ctl[w_start - 1];
                 const CandMeta& m = mb.meta[CW(w_start - 1, pm.ch_c)];
-                if (lane == 0) {
-                    dirty[n_dirty] = m.ctgA;
-                    dirty[n_dirty + 1] = m.ctgB;
+#pragma unroll
+                for (int j = 0; j < ND; j++) {
+                    if (lane + 64 * j == n_dirty) dirty[j] = m.ctgA;
+                    if (lane + 64 * j == n_dirty + 1) dirty[j] = m.ctgB;
                 }
                 n_dirty += 2;
             }
@@ -401,8 +409,12 @@ __global__ void __launch_bounds__(64)
             const int C = d.C;
             /* conflict with an earlier move of this batch?  slice pool overflow? */
             bool hitd = false;
-            for (int q = 0; q < n_dirty; q++) hitd |= (dirty[q] == d.cand.ctgA) | (dirty[q] == d.cand.ctgB);
-            if (err0 || rl(d.cand.overflow, 0) || __any(hitd && lane < C)) {
+            for (int cq = 0; cq < C; cq++) { /* candidate cq's two contigs against every lane's entries */
+                const int qa = rl(d.cand.ctgA, cq), qb = rl(d.cand.ctgB, cq);
+#pragma unroll
+                for (int j = 0; j < ND; j++) hitd |= (dirty[j] == qa) | (dirty[j] == qb);
+            }
+            if (err0 || rl(d.cand.overflow, 0) || __any(hitd)) {
                 stop_overflow = err0 ? 0 : rl(d.cand.overflow, 0); /* 1: the slice pool, 2: the exact kernel's grid */
                 break;
             }
@@ -575,14 +587,20 @@ __global__ void __launch_bounds__(64)
                 r.error = err0;
                 r.pad = 0;
                 res[move0 + w] = r;
-                if (br_changed) {
-                    dirty[n_dirty] = b_cA;
-                    dirty[n_dirty + 1] = b_cB;
-                }
             }
-            if (br_changed) n_dirty += 2;
+            if (br_changed) {
+#pragma unroll
+                for (int j = 0; j < ND; j++) {
+                    if (lane + 64 * j == n_dirty) dirty[j] = b_cA;
+                    if (lane + 64 * j == n_dirty + 1) dirty[j] = b_cB;
+                }
+                n_dirty += 2;
+            }
             committed = w + 1;
         }
+#pragma unroll
+        for (int j = 0; j < ND; j++)
+            if (lane + 64 * j < n_dirty) dirty_buf[1 + lane + 64 * j] = dirty[j];
         if (lane == 0) {
             g->nz_hi = nz_hi;
             g->nz_lo = nz_lo;
@@ -594,7 +612,6 @@ __global__ void __launch_bounds__(64)
             g->max_L = max_L;
             g->max_SL = max_SL;
             dirty_buf[0] = n_dirty;
-            for (int q = 0; q < n_dirty; q++) dirty_buf[1 + q] = dirty[q];
             batch_out[0] = committed;
             batch_out[1] = pending;
             batch_out[2] = (committed == w_start && pending < 0) ? stop_overflow : 0; /* nothing done because the first slot did not fit a pool */

@@ -1581,12 +1581,12 @@ __global__ void __launch_bounds__(256) k_predict(Glob* g, MoveBuf mb, int w_begi
  * a column at list position >= r never receives those contacts; which columns that applies to is decided
  * when the uniq list is known (k_scores / k_commit_batch). */
 __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, Glob* g, MoveBuf mb,
-                              const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int w_begin)
+                              const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int w_begin, int c, int w_rel)
 {
     __shared__ int t_li[64], t_lj[64], t_ob[64], t_rows[64];
     __shared__ int sh_n_rows, sh_n_tail, sh_cnt;
     __shared__ long long sh_red[4];
-    const int c = blockIdx.x, w = w_begin + blockIdx.y;
+    const int w = w_begin + w_rel;
     if (c >= mb.ctl[w].C) return;
     const int cw = CW(w, c);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1701,7 +1701,7 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
 __global__ void __launch_bounds__(256) k_tail(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, Glob* g,
                                               MoveBuf mb, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int w_begin)
 {
-    prefinal_tail(rowptr, cc, tab, g, mb, lgf_tab, tail_quirk, pz, w_begin);
+    prefinal_tail(rowptr, cc, tab, g, mb, lgf_tab, tail_quirk, pz, w_begin, blockIdx.x, blockIdx.y);
 }
 
 /* k_records: after k_score_list and k_tail: the slot-major records of the commit step */

@@ -245,16 +245,16 @@ __device__ __forceinline__ void screen_loop(const unsigned long long* __restrict
     }
 }
 
-/* one column k of candidate (w, c) over segment blockIdx.x of its slice list: stage, stream, publish sum and bound.  Called by
+/* one column k of candidate (w, c) over segment `seg` of its slice list: stage, stream, publish sum and bound.  Called by
  * every thread of the workgroup (barriers inside). */
 __device__ __forceinline__ void screen_column(ScreenLds& L, const ScreenConst* __restrict__ sc, const MoveBuf& mb, ScreenSum* __restrict__ scr,
-                                              unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub, int w, int c, int k)
+                                              unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub, int w, int c, int k, int seg)
 {
     const int cw = CW(w, c);
     const int C = mb.ctl[w].C;
     const int n_uniq = mb.meta[cw].n_uniq, m_loc = mb.meta[cw].m_loc;
-    const long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + blockIdx.x];
-    const long long off = mb.sloff[(size_t)cw * SLICE_SEG + blockIdx.x];
+    const long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + seg];
+    const long long off = mb.sloff[(size_t)cw * SLICE_SEG + seg];
     const float slope = sc->slope, la = sc->la, lv = sc->lv, d_max = sc->d_max, cy = sc->cy, pzc_max = sc->pzc_max;
     const int fast = sc->fast, pz_n = sc->pz_n;
     /* a column whose genome is the current genome on the window (k_mutate: nothing changed) has column 0's sums exactly */
@@ -406,22 +406,20 @@ __device__ __forceinline__ void screen_publish(const ScreenConst* __restrict__ s
         atomic_add_ll(&scr[cw * NSLOT + k].b_fix, (long long)__builtin_ceil(bound * SCR_FIX) + 2);
     }
 }
-#ifndef SCREEN_MIN_WAVES
-#define SCREEN_MIN_WAVES 7 /* seven workgroups per CU (what the LDS admits) need <= 96 SGPRs (106 admit six) */
-#endif
-__global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
-    k_screen(const ScreenConst* __restrict__ sc, MoveBuf mb, ScreenSum* __restrict__ scr, unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub,
-             int max_c, int w_begin)
+/* one workgroup of the screening pass: segment `seg` of the slice list of candidate zc (= slot * max_c + c), columns 2 ypair, 2 ypair + 1 */
+__device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc, const MoveBuf& mb, ScreenSum* __restrict__ scr,
+                                             unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub, int max_c, int w_begin, int seg, int ypair,
+                                             int zc)
 {
     __shared__ ScreenLds2 L2;
     ScreenLds& L = L2.one;
-    const int w = w_begin + blockIdx.z / max_c, c = blockIdx.z % max_c;
-    const int kA = 2 * blockIdx.y, kB = kA + 1;
+    const int w = w_begin + zc / max_c, c = zc % max_c;
+    const int kA = 2 * ypair, kB = kA + 1;
     const int cw = CW(w, c);
     const int C = mb.ctl[w].C;
     const int n_uniq = mb.meta[cw].n_uniq, m_loc = mb.meta[cw].m_loc;
-    const long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + blockIdx.x];
-    const long long off = mb.sloff[(size_t)cw * SLICE_SEG + blockIdx.x];
+    const long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + seg];
+    const long long off = mb.sloff[(size_t)cw * SLICE_SEG + seg];
     if (c >= C || kA > n_uniq || n == 0 || off < 0) return;
     /* which of the two columns there is anything to do for (a column whose genome is the current one has column 0's sums) */
     const bool doA = kA == 0 || mb.sinfo[cw * NSLOT + mb.meta[cw].uniq[kA - 1]].x != 0;
@@ -434,9 +432,9 @@ __global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
         for (int q = 0; q < NCODE; q++) plain &= (cmA[q].stot == 0) && (cmB[q].stot == 0);
     }
     if (!plain) {
-        if (doA) screen_column(L, sc, mb, scr, scr_void, scr_ub, w, c, kA);
+        if (doA) screen_column(L, sc, mb, scr, scr_void, scr_ub, w, c, kA, seg);
         if (doA && doB) __syncthreads(); /* the second column restages the LDS */
-        if (doB) screen_column(L, sc, mb, scr, scr_void, scr_ub, w, c, kB);
+        if (doB) screen_column(L, sc, mb, scr, scr_void, scr_ub, w, c, kB, seg);
         return;
     }
     const float slope = sc->slope, la_s = sc->la, lv_s = sc->lv, d_max = sc->d_max;
@@ -566,6 +564,35 @@ __global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
         }
         screen_publish(sc, scr, scr_void, cw, isB ? kB : kA, n, S, E, O, Y, B);
     }
+}
+#ifndef SCREEN_MIN_WAVES
+#define SCREEN_MIN_WAVES 7 /* seven workgroups per CU (what the LDS admits) need <= 96 SGPRs (106 admit six) */
+#endif
+__global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
+    k_screen(const ScreenConst* __restrict__ sc, MoveBuf mb, ScreenSum* __restrict__ scr, unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub,
+             int max_c, int w_begin)
+{
+    screen_block(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+/* k_screen and k_tail in ONE launch.  The Q5 tail walk (prefinal_tail: one workgroup per candidate, a chain of dependent
+ * loads of ~80 us) needs the slice lists only and used to run on a second stream next to k_screen: the event record / wait
+ * pairs that ordered the two streams cost ~10 us of idle queue each, three times per batch.  Here the first n_tail
+ * workgroups of a 1-D grid are the tail walks (dispatched first, done long before the screening workgroups are), the rest
+ * the (segment, column pair, candidate) workgroups of k_screen in the same order as its 3-D grid (block -> XCD affinity of a
+ * segment is kept: n_tail shifts every segment by the same amount). */
+__global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
+    k_screen_tail(const ScreenConst* __restrict__ sc, MoveBuf mb, ScreenSum* __restrict__ scr, unsigned* __restrict__ scr_void,
+                  unsigned* __restrict__ scr_ub, int max_c, int w_begin, int n_tail, const long long* __restrict__ rowptr,
+                  const int2* __restrict__ cc, Tables tab, Glob* g, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz)
+{
+    const int b = (int)blockIdx.x;
+    if (b < n_tail) {
+        prefinal_tail(rowptr, cc, tab, g, mb, lgf_tab, tail_quirk, pz, w_begin, b % max_c, b / max_c);
+        return;
+    }
+    const int s = b - n_tail, ny = (NSLOT + 1) / 2;
+    screen_block(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, s % SLICE_SEG, (s / SLICE_SEG) % ny, s / (SLICE_SEG * ny));
 }
 
 /* k_contend: one workgroup per move slot.  From the screened sums, the exact zero-pixel sums and the exact tail sums: an
