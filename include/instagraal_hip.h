@@ -182,6 +182,7 @@ int ig_step_finish(ig_ctx* ctx, ig_move_result* out, double* scores_or_null);
  * with hipEvents on the library's stream; name in {"score","mutate","gather","finalize","apply","post"} */
 int ig_kernel_time_ms(ig_ctx* ctx, const char* name, double* avg_ms, int64_t* n_launches);
 int ig_reset_timers(ig_ctx* ctx, int enable);
+int ig_set_timer_sampling(ig_ctx* ctx, int every); /* hipEvent pairs around every n-th launch only (an event record costs ~6 us of idle queue) */
 
 /* ---- debug ABI (kernel-granularity parity tests) ------------------------ */
 /* evaluate the model on arrays: ex = rippe(s), exc = rippe_circ(s, s_tot), term, quantised term */

@@ -289,6 +289,7 @@ struct ig_ctx {
     int cands_cap;
     int* prev_touched;
     unsigned timing_mask;
+    int timing_every; /* ig_set_timer_sampling */
     struct ScoreConst* score_const; /* tables and constants k_score_list stages (parameter set 0) */
     struct ScoreConst* full_const;  /* the same for the parameter set a k_full_nz launch evaluates */
     struct ScreenConst* screen_const; /* what k_screen stages (parameter set 0) */
@@ -305,6 +306,7 @@ struct ig_ctx {
         std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
         double total_ms;
         long long n;
+        long long seen; /* launches since the timers were reset (timing_every) */
     } timers[12];
     long long n_batches, n_batch_committed, n_batch_pending, n_batch_predicted;
     int up_moves, up_max_c; /* the uploaded move lists */

@@ -414,6 +414,9 @@ class Context:
     def reset_timers(self, enable=True):
         _ck(lib().ig_reset_timers(self._h, C.c_int(int(enable))))
 
+    def set_timer_sampling(self, every):
+        _ck(lib().ig_set_timer_sampling(self._h, C.c_int(int(every))))
+
     def kernel_time_ms(self, name):
         avg = C.c_double()
         n = C.c_int64()
