@@ -1096,12 +1096,13 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                  * candidate 193, 64: 156, 96: 148, 128: 136, 256 with the chunks of a row dealt to several waves: 146 */
                 static const int s_rb = getenv("IG_SLICE_RB") ? atoi(getenv("IG_SLICE_RB")) : 0;
                 const int rb = s_rb > 0 ? s_rb : SLICE_RB;
+                static const int s_share = getenv("IG_SLICE_SHARE") ? atoi(getenv("IG_SLICE_SHARE")) : 1; /* A's rows once per move */
                 if (c->mb.packed)
-                    hipLaunchKernelGGL(k_slice<true>, dim3(rb, max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob,
-                                       c->mb, c->rank, c->world, w_begin);
+                    hipLaunchKernelGGL(k_slice<true>, dim3(rb, max_c + 1, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->rank,
+                                       c->world, w_begin, s_share);
                 else
-                    hipLaunchKernelGGL(k_slice<false>, dim3(rb, max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob,
-                                       c->mb, c->rank, c->world, w_begin);
+                    hipLaunchKernelGGL(k_slice<false>, dim3(rb, max_c + 1, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->rank,
+                                       c->world, w_begin, s_share);
             }
             /* two-tier scoring (batches on one handle, packed lists): every column through the float screening kernel, the exact
              * kernel only for the columns that can still win (ig_kernels_screen.cuh).  IG_SCREEN=0: everything exact;

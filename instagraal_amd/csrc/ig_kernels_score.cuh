@@ -436,45 +436,70 @@ __global__ void __launch_bounds__(OFFSETS_THREADS) k_offsets(MoveBuf mb, int W, 
 #ifndef SLICE_MIN_WAVES
 #define SLICE_MIN_WAVES 8 /* eight workgroups per CU need <= 80 SGPRs (81 admit seven: MI355X_MICROARCH.md, residency) */
 #endif
+/* grid: (workgroups, candidates + 1, slots).  The rows of the focal contig A are the same for every candidate of a move whose
+ * partner lies in another contig, and so are the contacts read from them and the partners' records gathered: the last plane
+ * walks A's rows ONCE for all those candidates (a contact inside A goes to every list, one into B_c to candidate c's), the
+ * candidates' planes walk the rows of B_c only (all rows where A and B_c are one contig: the windowed predicate of
+ * KA:565-586 is the candidate's own).  40 % fewer (row, contact chunk) chains per move at five candidates.
+ * Measured and dropped: several shared planes (slower), the cursors one per 128-byte line (no change), write-through / non-temporal
+ * list stores (no change / slower), one workgroup per (segment, slot) with the cursors in LDS (190 us: too few chains in
+ * flight), counting pass + writing pass without atomics (178 us: the rows are read twice). */
 template <bool PACKED>
 __global__ void __launch_bounds__(256, SLICE_MIN_WAVES) k_slice(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
-                                               Glob* g, MoveBuf mb, int rank, int world, int w_begin)
+                                                                 Glob* g, MoveBuf mb, int rank, int world, int w_begin, int share_rows)
 {
-    const int c = blockIdx.y, w = w_begin + blockIdx.z;
-    if (c >= mb.ctl[w].C) return;
-    const int cw = CW(w, c);
-    const CandMeta& m = mb.meta[cw];
-    const int M = mb.sM, m_loc = m.m_loc;
+    const int w = w_begin + blockIdx.z, C = mb.ctl[w].C;
+    const bool shared_plane = (blockIdx.y == gridDim.y - 1);
+    __shared__ long long seg_off[IG_MAX_CANDIDATES][SLICE_SEG];
+    __shared__ int s_cw[IG_MAX_CANDIDATES], s_ctgB[IG_MAX_CANDIDATES], s_nc;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    __shared__ long long seg_off[SLICE_SEG];
-    if (threadIdx.x < SLICE_SEG) seg_off[threadIdx.x] = mb.sloff[(size_t)cw * SLICE_SEG + threadIdx.x];
+    if (threadIdx.x == 0) {
+        int nc = 0;
+        if (shared_plane) {
+            if (share_rows)
+                for (int c = 0; c < C; c++)
+                    if (!mb.meta[CW(w, c)].same) {
+                        s_cw[nc] = CW(w, c);
+                        s_ctgB[nc++] = mb.meta[CW(w, c)].ctgB;
+                    }
+        } else if ((int)blockIdx.y < C) {
+            s_cw[0] = CW(w, blockIdx.y);
+            s_ctgB[0] = mb.meta[s_cw[0]].ctgB;
+            nc = 1;
+        }
+        s_nc = nc;
+    }
     __syncthreads();
-    if (seg_off[0] < 0) return; /* slice pool exhausted (k_offsets flags all segments of a slot together) */
-    const int* subs = mb.subs + (size_t)cw * M;
-    int* rowcnt = mb.rowcnt + (size_t)cw * M;
+    const int nc = s_nc;
+    if (nc == 0) return;
+    for (int i = threadIdx.x; i < nc * SLICE_SEG; i += blockDim.x) seg_off[i / SLICE_SEG][i % SLICE_SEG] = mb.sloff[(size_t)s_cw[i / SLICE_SEG] * SLICE_SEG + i % SLICE_SEG];
+    __syncthreads();
+    if (seg_off[0][0] < 0) return; /* slice pool exhausted (k_offsets flags all segments of a slot together) */
+    const int cw0 = s_cw[0];
+    const CandMeta& m = mb.meta[cw0];
+    const int M = mb.sM;
+    /* the rows this plane walks: A's (shared plane), B's (a candidate in another contig, A's being walked by the shared plane), all */
+    const bool own_all = !shared_plane && (m.same || !share_rows);
+    const int row_lo = (shared_plane || own_all) ? 0 : m.SLA;
+    const int n_rows = shared_plane ? m.SLA : (m.m_loc - row_lo);
+    const int ctgA = m.ctgA, SLA = m.SLA;
+    const int* subs = mb.subs + (size_t)cw0 * M;
     /* work items = (row, j): wave j of a row takes the row's contact chunks j, j + J, ... (J waves per row: a row of thousands
      * of contacts is a chain of dependent round trips per chunk, and the launch waits for the longest chain) */
     const int nrw = gridDim.x * 4;
-    const int J = max(1, nrw / max(m_loc, 1));
-    for (int item = blockIdx.x * 4 + wv; item < m_loc * J; item += nrw) {
-        const int r = item % m_loc, j = item / m_loc;
-        const long long off = seg_off[r % SLICE_SEG];
-        int* sli = PACKED ? nullptr : mb.sl_li + off;
-        int* slj = PACKED ? nullptr : mb.sl_lj + off;
-        int* slo = PACKED ? nullptr : mb.sl_ob + off;
-        unsigned long long* slp = PACKED ? mb.sl_pk + off : nullptr;
-        unsigned long long* cursor = (unsigned long long*)(mb.part + (size_t)cw * P_STRIDE + P_CNT + r % SLICE_SEG);
+    const int J = max(1, nrw / max(n_rows, 1));
+    for (int item = blockIdx.x * 4 + wv; item < n_rows * J; item += nrw) {
+        const int r = row_lo + item % n_rows, j = item / n_rows;
+        const int seg = r % SLICE_SEG;
         const int i = subs[r];
         const long long b = rowptr[i], e = rowptr[i + 1];
         const bool mine = (world <= 1) || ((r % world) == rank);
-        int rc = 0;
+        int rc = 0; /* lane k: contacts of this row kept for candidate k */
         if (b != e) {
             const int2 cp1 = tab.cp[i];
             for (long long q0 = b + (long long)j * 64 * SLICE_UNROLL; q0 < e; q0 += (long long)J * 64 * SLICE_UNROLL) {
                 int2 v[SLICE_UNROLL], cp2[SLICE_UNROLL];
-                bool keep[SLICE_UNROLL];
-                unsigned long long mask[SLICE_UNROLL];
 #pragma unroll
                 for (int u = 0; u < SLICE_UNROLL; u++) {
                     const long long qi = q0 + u * 64 + lane;
@@ -482,40 +507,46 @@ __global__ void __launch_bounds__(256, SLICE_MIN_WAVES) k_slice(const long long*
                 }
 #pragma unroll
                 for (int u = 0; u < SLICE_UNROLL; u++) cp2[u] = (v[u].x >= 0) ? tab.cp[v[u].x] : make_int2(-1, -1);
-                int add = 0;
+                for (int k = 0; k < nc; k++) {
+                    bool keep[SLICE_UNROLL];
+                    unsigned long long mask[SLICE_UNROLL];
+                    int add = 0;
+                    const int ctgB = s_ctgB[k];
 #pragma unroll
-                for (int u = 0; u < SLICE_UNROLL; u++) {
-                    keep[u] = (v[u].x >= 0) && slice_keep(m, cp1.x, cp2[u].x, cp1.y, cp2[u].y, v[u].y, false);
-                    mask[u] = __ballot(keep[u]);
-                    add += __popcll(mask[u]);
-                }
-                if (add) {
-                    rc += add;
-                    if (mine) {
-                        unsigned long long base = 0;
-                        if (lane == 0) base = atomicAdd(cursor, (unsigned long long)add);
-                        base = __shfl(base, 0, 64);
-                        int o2 = 0;
+                    for (int u = 0; u < SLICE_UNROLL; u++) {
+                        if (own_all) keep[u] = (v[u].x >= 0) && slice_keep(m, cp1.x, cp2[u].x, cp1.y, cp2[u].y, v[u].y, false);
+                        else keep[u] = (v[u].x >= 0) && (v[u].y > 0) && ((cp2[u].x == ctgA) || (cp2[u].x == ctgB)); /* slice_keep, two contigs */
+                        mask[u] = __ballot(keep[u]);
+                        add += __popcll(mask[u]);
+                    }
+                    if (!add) continue;
+                    rc += (lane == k) ? add : 0;
+                    if (!mine) continue;
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd((unsigned long long*)(mb.part + (size_t)s_cw[k] * P_STRIDE + P_CNT + seg), (unsigned long long)add);
+                    base = __shfl(base, 0, 64);
+                    const long long off = seg_off[k][seg];
+                    int o2 = 0;
 #pragma unroll
-                        for (int u = 0; u < SLICE_UNROLL; u++) {
-                            if (keep[u]) {
-                                const long long at = (long long)base + o2 + __popcll(mask[u] & lt_mask);
-                                const int lj = ((m.same || cp2[u].x == m.ctgA) ? 0 : m.SLA) + cp2[u].y;
-                                if (PACKED) {
-                                    slp[at] = (unsigned long long)r | ((unsigned long long)lj << 20) | ((unsigned long long)v[u].y << 40);
-                                } else {
-                                    sli[at] = r;
-                                    slj[at] = lj;
-                                    slo[at] = v[u].y;
-                                }
+                    for (int u = 0; u < SLICE_UNROLL; u++) {
+                        if (keep[u]) {
+                            const long long at = off + (long long)base + o2 + __popcll(mask[u] & lt_mask);
+                            const int lj = ((m.same || cp2[u].x == ctgA) ? 0 : SLA) + cp2[u].y;
+                            if (PACKED) {
+                                mb.sl_pk[at] = (unsigned long long)r | ((unsigned long long)lj << 20) | ((unsigned long long)v[u].y << 40);
+                            } else {
+                                mb.sl_li[at] = r;
+                                mb.sl_lj[at] = lj;
+                                mb.sl_ob[at] = v[u].y;
                             }
-                            o2 += __popcll(mask[u]);
                         }
+                        o2 += __popcll(mask[u]);
                     }
                 }
             }
         }
-        if (lane == 0 && rc) atomicAdd(&rowcnt[r], rc); /* every rank knows every row's count: the tail walk needs them */
+        /* every rank knows every row's count: the tail walk needs them */
+        if (lane < nc && rc) atomicAdd(&mb.rowcnt[(size_t)s_cw[lane] * M + r], rc);
     }
 }
 

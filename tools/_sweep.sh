@@ -1,5 +1,5 @@
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-rm -rf /tmp/prof_kt
-timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_kt -o run -- python3 $R/bench.py --no-cpu-baseline --nuisance-moves 0 --steps 1000 --warmup 100 > /tmp/kt.log 2>&1
-python3 $R/tools/rocprof_timeline.py $(find /tmp/prof_kt -name "*.db" | head -1) 36 > $R/gpurun_out/r02k_batch_timeline.txt
+for v in "IG_SLICE_SHARED_PLANES=1" "IG_SLICE_SHARED_PLANES=2" "IG_SLICE_SHARED_PLANES=3" "IG_SLICE_SHARED_PLANES=5" "IG_SLICE_SHARED_PLANES=2 IG_SLICE_RB=96" "IG_SLICE_SHARED_PLANES=4 IG_SLICE_RB=64"; do
+echo "== $v"
+env $v python bench.py --no-cpu-baseline --nuisance-moves 0 2>&1 | tail -1 | cut -c77-100
+env $v python tools/kernel_times.py cfg3 1500 2>&1 | grep "slice"
+done
