@@ -153,6 +153,7 @@ int ig_nuis_accept(ig_ctx* ctx);
  * step, after an accepted step, after a conflict with an earlier move of the batch, batch used up); ig_nuis_end /
  * ig_nuis_accept as above.  Results as one move and one step at a time.  Any other call that runs moves or changes state or
  * param_simu ends the run. */
+int ig_links_inverse(ig_ctx* ctx); /* 1: speculative batches (ig_step_batch with W > 1, ig_batch_*, ig_nuis_run_begin) are available for this initial genome */
 int ig_set_nuis_width(int w); /* moves scored ahead per launch: 0 = follow the run lengths (default, env IG_NUIS_W); results do not depend on it */
 int ig_nuis_run_begin(ig_ctx* ctx, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c);
 int ig_nuis_step_begin(ig_ctx* ctx, int32_t move, const float p_test[8], float mean_subfrag_kb);

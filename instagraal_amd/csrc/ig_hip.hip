@@ -1516,7 +1516,9 @@ extern "C" int ig_batch_upload(ig_ctx* c, int32_t n_moves, const int32_t* frags,
     if (max_w < 1 || max_w > max_batch_width(c, max_c))
         return fail("ig_batch_upload: batch width %d out of 1..%d (ig_batch_max_width)", max_w, max_batch_width(c, max_c));
     if (c->world > 1) return fail("ig_batch_upload: contact shards (ig_set_shard) and slot splitting are exclusive");
-    if (!c->init_links_inverse && max_w > 1) return fail("ig_batch_upload: the initial prev / next arrays are not mutually inverse: batches of one move only");
+    /* k_commit_batch counts every genome-distance credit exactly once by a rule on mutually inverse initial links -- also for a
+     * batch of one move */
+    if (!c->init_links_inverse) return fail("ig_batch_upload: the initial prev / next arrays are not mutually inverse: ig_step / ig_step_batch only");
     if (max_c < 1 || max_c > IG_MAX_CANDIDATES) return fail("ig_batch_upload: max_c out of range");
     if (ensure_move_buffers(c, std::max(8, (int)max_c), max_w)) return -1;
     return upload_moves(c, n_moves, frags, cands, max_c);
@@ -1836,6 +1838,10 @@ static int nuis_spec_width(ig_ctx* c)
     return std::max(1, std::min(cap, (int)(1.5 * c->spec_ema + 1.5)));
 }
 
+/* 1: the initial prev / next arrays (ig_upload_state / ig_set_initial_genome) are mutually inverse -- what the batch commit's
+ * genome-distance bookkeeping relies on; 0: moves are applied one at a time */
+extern "C" int ig_links_inverse(ig_ctx* c) { return c->init_links_inverse ? 1 : 0; }
+
 extern "C" int ig_set_nuis_width(int w)
 {
     g_nuis_w = std::max(0, w);
@@ -1850,9 +1856,10 @@ extern "C" int ig_nuis_run_begin(ig_ctx* c, int32_t n_moves, const int32_t* frag
     if (c->nuis_in_flight) return fail("ig_nuis_run_begin: a step is in flight (ig_nuis_end)");
     if (n_moves <= 0) return fail("ig_nuis_run_begin: no moves");
     if (max_c < 1 || max_c > IG_MAX_CANDIDATES) return fail("ig_nuis_run_begin: max_c out of range");
+    if (!c->init_links_inverse) return fail("ig_nuis_run_begin: the initial prev / next arrays are not mutually inverse (ig_links_inverse): ig_nuis_begin, one pair at a time");
     static const int s_cap = getenv("IG_NUIS_WMAX") ? atoi(getenv("IG_NUIS_WMAX")) : 12;
     if (g_nuis_w < 0) g_nuis_w = getenv("IG_NUIS_W") ? std::max(0, atoi(getenv("IG_NUIS_W"))) : 0;
-    const int Wmax = c->init_links_inverse ? std::max(1, std::min(std::max(s_cap, g_nuis_w), max_batch_width(c, max_c))) : 1;
+    const int Wmax = std::max(1, std::min(std::max(s_cap, g_nuis_w), max_batch_width(c, max_c)));
     if (ensure_move_buffers(c, std::max(8, (int)max_c), Wmax)) return -1;
     if (upload_moves(c, n_moves, frags, cands, max_c)) return -1;
     c->nuis_spec = true;

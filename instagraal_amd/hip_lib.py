@@ -296,6 +296,9 @@ class Context:
         p = np.ascontiguousarray(p_test8, np.float32)
         _ck(lib().ig_nuis_begin(self._h, C.c_int32(int(frag_a)), _p(c), C.c_int32(c.size), _p(p), C.c_float(float(mean_subfrag_kb))))
 
+    def links_inverse(self):
+        return bool(lib().ig_links_inverse(self._h))
+
     def nuis_run_begin(self, frags, cands):
         """the lists of a run of (move, nuisance step) pairs: the moves are scored ahead in batches (ig_nuis_run_begin)"""
         f = np.ascontiguousarray(frags, np.int32)

@@ -438,7 +438,9 @@ class sampler:  # noqa: N801 - the reference's class name
         n = frags.size
         res = np.zeros(n, hip_lib.MOVE_RESULT_DTYPE)
         self._sigmas(np.copy(self.param_simu))
-        if n == 0 or self.sigma_d_nuc <= 0:  # the one case where the stream depends on the parameters: one step at a time
+        # one step at a time: the one case where the stream depends on the parameters; an initial genome whose prev / next
+        # links are not mutually inverse (the batch commit's bookkeeping needs that)
+        if n == 0 or self.sigma_d_nuc <= 0 or not self.ctx.links_inverse():
             tuples = []
             for i, f in enumerate(frags):
                 r = self.step_sampler(int(f), n_neighbours, dt)

@@ -601,3 +601,50 @@ def test_nuisance_run_entry_points_refuse_misuse():
     with pytest.raises(hip_lib.HipError, match="no run"):
         ctx.nuis_step_begin(3, p8, prob.mean_subfrag_kb)
     ctx.close()
+
+
+def test_initial_links_not_mutually_inverse_use_the_one_move_path():
+    """The batch commit counts every genome-distance credit once by a rule on mutually inverse initial prev / next links
+    (true of any genome the loader builds).  With other initial links the library applies one move at a time, refuses the
+    batch entry points, and the batched methods of the sampler still return what the one-call-at-a-time methods return."""
+    from instagraal_amd import hip_lib, synth
+    from instagraal_amd.sampler import sampler as hip_sampler
+
+    prob = synth.make_problem(*synth.CONFIGS["tiny"])
+    outs = []
+    for batch in (False, True):
+        np.random.seed(11)
+        s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
+        s.set_param_simu(prob.params)
+        s.bins = np.arange(1.0, 60.0, 1.0)
+        s.eval_likelihood_init()
+        assert s.ctx.links_inverse()
+        nxt = np.copy(s.np_init_next)
+        a, b = np.nonzero(nxt >= 0)[0][:2]
+        nxt[a], nxt[b] = nxt[b], nxt[a]  # next(prev(x)) != x for two fragments
+        s.ctx.set_initial_genome(s.np_init_prev, nxt, s.np_init_orientable, s.id_frags_blacklisted)
+        assert not s.ctx.links_inverse()
+        frags = np.random.permutation(prob.n_frags)[:30]
+        if batch:
+            with pytest.raises(hip_lib.HipError, match="not mutually inverse"):
+                s.ctx.nuis_run_begin(frags[:4].astype(np.int32), np.zeros((4, 5), np.int32))
+            with pytest.raises(hip_lib.HipError, match="not mutually inverse"):
+                s.ctx.batch_upload(frags[:4].astype(np.int32), np.zeros((4, 5), np.int32), 1)
+            res = s.step_sampler_batch(frags[:15], 5)
+            rows = [(float(r["o"]), float(r["dist"]), int(r["op_sampled"]), int(r["id_f_sampled"]), int(r["n_contigs"])) for r in res]
+            res, tuples = s.step_sampler_nuisance_batch(frags[15:], 5, s.dt, 0, 15)
+            rows += [(float(r["o"]), float(r["dist"]), int(r["op_sampled"]), int(r["id_f_sampled"]), int(r["n_contigs"])) for r in res]
+            nu = [tuple(float(np.ravel(x)[0]) for x in q[:7]) for q in tuples]
+        else:
+            rows, nu = [], []
+            for t, f in enumerate(frags):
+                r = s.step_sampler(int(f), 5, s.dt)
+                rows.append((float(r[0]), float(r[1]), int(r[2]), int(r[3]), int(r[5])))
+                if t >= 15:
+                    q = s.step_nuisance_parameters(s.dt, t - 15, 15)
+                    nu.append(tuple(float(np.ravel(x)[0]) for x in q[:7]))
+        outs.append((rows, nu, s.gpu_vect_frags.copy_from_gpu().soa17()))
+        s.free_gpu()
+    assert outs[0][0] == outs[1][0]
+    assert outs[0][1] == outs[1][1]
+    assert np.array_equal(outs[0][2], outs[1][2])

@@ -11,14 +11,14 @@ import sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 tag = sys.argv[1]
 outdir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
-KERNELS = {"k_screen": "_Z8k_screen", "k_score_list": "_Z12k_score_list", "k_slice": "_Z7k_slice", "k_tail": "_Z6k_tail",
+KERNELS = {"k_screen": ("_Z13k_screen_tail", "_Z8k_screen"), "k_score_list": "_Z12k_score_list", "k_slice": "_Z7k_slice", "k_tail": "_Z6k_tail",
            "k_full_nz_tiled": "_Z15k_full_nz_tiled", "k_decide_batch": "_Z14k_decide_batch", "k_mutate": "_Z8k_mutate"}
 merged = {}
 for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "%s_pmc_pass*.json" % tag))):
     d = json.load(open(f))
     for name, ctrs in d.items():
         for short, prefix in KERNELS.items():
-            if name.startswith(prefix):
+            if name.startswith(prefix if isinstance(prefix, tuple) else (prefix,)):
                 e = merged.setdefault(short, {})
                 for c, v in ctrs.items():
                     e[c] = v["avg"]

@@ -15,5 +15,5 @@ for CT in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ
   i=$((i+1))
   rm -rf /tmp/pmc$i
   timeout 300 rocprofv3 --pmc $CT -d /tmp/pmc$i -o run -- python3 $R/bench.py --no-cpu-baseline --nuisance-moves 0 --steps 300 --warmup 50 > /tmp/pmc$i.log 2>&1
-  python3 $R/tools/rocprof_pmc.py $(find /tmp/pmc$i -name "*.db" | head -1) $R/gpurun_out/${TAG}_pmc_pass$i.json | grep -i "score_list\|commit_batch\|k_slice" | cut -c1-300
+  python3 $R/tools/rocprof_pmc.py $(find /tmp/pmc$i -name "*.db" | head -1) $R/gpurun_out/${TAG}_pmc_pass$i.json | grep -i "score_list\|k_screen\|k_slice" | cut -c1-300
 done
