@@ -1083,10 +1083,14 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
              * commit step applies from the other ranks' slots */
             c->own_begin = w_begin;
             c->own_end = w_end;
-            if (nW > 0)
-                /* long contigs (late in an assembly: windows of thousands of sub-fragments): twice the threads per candidate genome */
-                hipLaunchKernelGGL(k_mutate, dim3(NSLOT, max_c, nW), dim3((c->n_contigs_seen > 0 && c->N / c->n_contigs_seen >= 150) ? 512 : 256), 0, c->stream, c->st, c->tab, c->sub_tab, c->rowptr,
+            if (nW > 0) {
+                /* long contigs (late in an assembly: windows of thousands of sub-fragments): more threads per candidate genome */
+                static const int s_mt = getenv("IG_MUTATE_THREADS") ? atoi(getenv("IG_MUTATE_THREADS")) : 0;
+                const int mean_len = c->n_contigs_seen > 0 ? c->N / c->n_contigs_seen : 0;
+                const int mutate_threads = s_mt > 0 ? s_mt : (mean_len >= 600 ? 1024 : (mean_len >= 150 ? 512 : 256));
+                hipLaunchKernelGGL(k_mutate, dim3(NSLOT, max_c, nW), dim3(mutate_threads), 0, c->stream, c->st, c->tab, c->sub_tab, c->rowptr,
                                    c->glob, c->mb, pz, w_begin);
+            }
         }
         if (force_slot < 0 && nW > 0) {
             {
