@@ -1184,7 +1184,8 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                 static const int s_pred2 = getenv("IG_PREDICT_PASSES") ? atoi(getenv("IG_PREDICT_PASSES")) : 2;
                 if (s_pred2 >= 2) hipLaunchKernelGGL(k_predict, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, w_begin, 0);
                 hipLaunchKernelGGL(k_predict, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, w_begin, 1);
-                hipLaunchKernelGGL(k_delta, dim3(DELTA_RB, 2, nW), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->tab_prev,
+                static const int s_drb = getenv("IG_DELTA_RB") ? atoi(getenv("IG_DELTA_RB")) : DELTA_RB;
+                hipLaunchKernelGGL(k_delta, dim3(s_drb, 2, nW), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->tab_prev,
                                    c->prev_touched, c->glob, c->mb, c->lgf_tab, pz, w_begin, 1, 0);
             }
         }
