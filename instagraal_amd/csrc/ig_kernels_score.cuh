@@ -1272,6 +1272,7 @@ __global__ void __launch_bounds__(FULL_TILED_THREADS, 8) /* 8 waves per SIMD: tw
             }
         }
         __syncthreads();
+        if (threadIdx.x == 0) L.next_item = (int)gridDim.x + atomicAdd(&dyn->next, 1); /* the item after this one: its number is on its way while this one is summed */
         const uint2* cre = diag ? L.rrec : L.crec;
         const int* cct = diag ? L.rctg : L.cctg;
         for (int e0 = threadIdx.x; e0 < n; e0 += 2 * nth) {
@@ -1350,9 +1351,7 @@ __global__ void __launch_bounds__(FULL_TILED_THREADS, 8) /* 8 waves per SIMD: tw
                     accl += (unsigned)bits[u];
                 }
         }
-        __syncthreads(); /* everybody is through with the staged blocks */
-        if (threadIdx.x == 0) L.next_item = (int)gridDim.x + atomicAdd(&dyn->next, 1);
-        __syncthreads();
+        __syncthreads(); /* everybody is through with the staged blocks (and the next item's number, requested at the start of this one, is there) */
         seq = L.next_item;
     }
     long long hi = ((long long)acc - (long long)accl) >> 32, lo = (long long)accl;
