@@ -339,6 +339,53 @@ def test_headline_size_properties():
         assert np.array_equal(f["start_bp"][order], np.concatenate([[0], np.cumsum(f["len_bp"][order])[:-1]]))
 
 
+def test_headline_size_nuisance_run_equals_the_sequential_calls():
+    """The loop with nuisance sampling at BASELINE.json's headline shape: ``step_sampler_nuisance_batch`` (moves scored ahead
+    in batches across rejected steps, the pass over all 50 M contacts from tile histograms and a persistent tiled kernel,
+    results through mapped host memory, the acceptance test in the library) against ``step_sampler`` +
+    ``step_nuisance_parameters`` one call at a time (every column scored exactly, the plain from-scratch entry point):
+    result records, nuisance tuples, parameters, generator state, genome; accepted and rejected steps, moves that conflict
+    with an earlier move of their batch, winners that need the one-move tail."""
+    from instagraal_amd import synth
+    from instagraal_amd.sampler import sampler as hip_sampler
+
+    prob = synth.make_problem(*synth.CONFIGS["cfg3"])
+    n = 90
+    outs = []
+    for batch in (True, False):
+        np.random.seed(21)
+        s = hip_sampler(**prob.sampler_kwargs(), device_id=0, coo=(prob.coo_row, prob.coo_col, prob.coo_cnt))
+        s.set_param_simu(prob.params)
+        s.bins = np.arange(1.0, 60.0, 1.0)
+        s.eval_likelihood_init()
+        frags = np.random.permutation(prob.n_frags)[:n]
+        if batch:
+            b0 = s.ctx.batch_stats()
+            res, tuples = s.step_sampler_nuisance_batch(frags, 5, s.dt, 0, n)
+            b1 = s.ctx.batch_stats()
+            assert b1["batches"] - b0["batches"] < n  # moves were scored ahead
+            rows = [(float(r["o"]), float(r["dist"]), int(r["op_sampled"]), int(r["id_f_sampled"]), int(r["n_contigs"])) for r in res]
+            nu = [tuple(float(np.ravel(x)[0]) for x in q[:7]) for q in tuples]
+        else:
+            rows, nu = [], []
+            for t, f in enumerate(frags):
+                r = s.step_sampler(int(f), 5, s.dt)
+                rows.append((float(r[0]), float(r[1]), int(r[2]), int(r[3]), int(r[5])))
+                q = s.step_nuisance_parameters(s.dt, t, n)
+                nu.append(tuple(float(np.ravel(x)[0]) for x in q[:7]))
+        sums, _ = s.ctx.debug_globals()
+        _, _, limbs = s.ctx.full_likelihood(0)
+        assert [int(x) for x in sums[:5]] == [int(x) for x in limbs[:5]]
+        outs.append((rows, nu, s.gpu_vect_frags.copy_from_gpu().soa17(), np.random.get_state()[1][:6].copy(),
+                     [float(s.param_simu[k][0]) for k in ("fact", "slope", "d_max", "v_inter")]))
+        s.free_gpu()
+        del s
+    assert outs[0][0] == outs[1][0]
+    assert outs[0][1] == outs[1][1]
+    assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3]) and outs[0][4] == outs[1][4]
+    assert 0 < sum(q[6] for q in outs[0][1]) < n
+
+
 def test_estimate_parameters_rippe_matches_reference_golden():
     """SURVEY 8(f) f2 end to end: estimate_parameters_rippe (CL:2239-2372) on the GPU sampler against the reference's own
     method over the oracle kernels.  NOT bit for bit: the least-squares fit is ill-conditioned in the reference itself
