@@ -147,7 +147,7 @@ int ig_nuis_end(ig_ctx* ctx, ig_move_result* out, double* nz_test, double* z_tes
 int ig_nuis_accept(ig_ctx* ctx);
 /* The same for a RUN of (move, nuisance step) pairs -- the loop of instagraal.py:217-262 itself.  A rejected step changes
  * nothing a move reads, so the moves behind it are scored ahead, in batches (width: env IG_NUIS_W, default: follows the run
- * lengths, at most IG_NUIS_WMAX = 12): ig_nuis_run_begin uploads the lists of the run (as ig_batch_upload);
+ * lengths, at most IG_NUIS_WMAX = 24): ig_nuis_run_begin uploads the lists of the run (as ig_batch_upload);
  * ig_nuis_step_begin(move), move = 0, 1, ... in order: asynchronous -- the step's pass under p_test and the decision + apply
  * of that ONE move from the batch it was scored in (a batch starting at `move` is scored first when there is none: first
  * step, after an accepted step, after a conflict with an earlier move of the batch, batch used up); ig_nuis_end /

@@ -233,8 +233,10 @@ struct ig_ctx {
     int res_seq, sums_seq;         /* launch numbers the flags in host_nuis are compared with */
     bool nuis_pub_res, nuis_pub_sums; /* the step in flight publishes its record / its sums itself */
     bool nuis_in_flight;
+    bool side_busy;      /* launch_full_nz on a side stream: the library stream is busy with a batch (one workgroup per CU for the pass) */
     bool tail_fused;     /* the batch in flight: the Q5 tail walk ran inside the screening kernel's launch (no second stream, no events) */
     bool no_predict;     /* enqueue_score: no k_predict / predicted k_delta for this batch */
+    bool main_drained;   /* nothing is queued on the library stream (end of a run's step, until something is enqueued there) */
     bool nuis_caught_up; /* tab_prev is the state before the next move already and ev_gathered recorded (ig_nuis_step_next) */
     double nuis_wait_s; /* time ig_nuis_end spent waiting for the device (ig_debug_nuis_wait) */
     /* moves of a run of (move, nuisance step) pairs scored ahead in batches (ig_nuis_run_begin / ig_nuis_step_begin): the batch

@@ -154,6 +154,7 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->n_screen_cols = c->n_screen_cont = 0;
     c->pz_n = c->pz_n1 = 0;
     c->timing_mask = 0xffff;
+    c->side_busy = true;
     c->timing_every = 1;
     c->timing = false;
     c->n_batches = c->n_batch_committed = c->n_batch_pending = c->n_batch_predicted = 0;
@@ -400,7 +401,7 @@ static bool launch_full_nz(ig_ctx* c, const Tables& t, int which, long long* out
          * and the pass is bound by its arithmetic, not by its occupancy */
         static const int s_grid = getenv("IG_FULL_GRID") ? atoi(getenv("IG_FULL_GRID")) : 512;
         static const int s_grid_side = getenv("IG_FULL_GRID_SIDE") ? atoi(getenv("IG_FULL_GRID_SIDE")) : 256;
-        const int grid = std::min(c->n_tile_work, stream != c->stream ? s_grid_side : s_grid);
+        const int grid = std::min(c->n_tile_work, (stream != c->stream && c->side_busy) ? s_grid_side : s_grid);
         if (grid > 0)
             hipLaunchKernelGGL(k_full_nz_tiled, dim3(grid), dim3(FULL_TILED_THREADS), sizeof(FullTiledLds), stream, c->tile_work, c->tiled_cc,
                                c->tabrec, t.len, c->full_const, c->lgf_tab, c->M, pz.n, out, c->n_tile_static, (TileDyn*)c->tile_dyn,
@@ -1044,6 +1045,7 @@ static int check_ready(ig_ctx* c)
     if (!c->have_contacts || !c->have_sub || !c->have_state || !c->have_params)
         return fail("contacts, sub-fragment table, state and parameters must be uploaded before a move");
     c->nuis_caught_up = false;
+    c->main_drained = false;
     c->nuis_spec = c->spec_valid = false; /* every entry point that runs moves passes here: a run of ig_nuis_step_begin ends with it */
     return 0;
 }
@@ -1784,18 +1786,31 @@ static int enqueue_nuis_pass(ig_ctx* c, const float p_test[8], float mean_subfra
     if (!c->pz_tab1) DALLOC(c->pz_tab1, PZ_MAX);
     /* the nuisance pass first (second stream), the move behind it (library stream): the pass is the longer of the two and
      * would otherwise start only when the host is through with the move's dozen launches */
+    hipStream_t s3 = c->stream3;
+    bool on_side = false;
     if (!c->nuis_caught_up) {
-        hipLaunchKernelGGL(k_catch_up, dim3(16), dim3(256), 0, c->stream, c->tab, c->tab_prev, c->prev_touched, c->glob);
-        HIPCK(hipEventRecord(c->ev_gathered, c->stream)); /* also: behind an accepted step's kernels (ig_nuis_accept), which read what the pass overwrites */
+        if (c->main_drained) {
+            /* nothing is queued on the library stream (the previous step's results are on the host, nothing was promoted since):
+             * the catch-up runs at the head of the pass's own stream -- an event from the library stream to this one costs ~15 us
+             * of idle queue at the start of every step -- and the library stream's next kernels, which replace what it reads,
+             * wait for IT (that wait is not on the step's critical path) */
+            hipLaunchKernelGGL(k_catch_up, dim3(16), dim3(256), 0, s3, c->tab, c->tab_prev, c->prev_touched, c->glob);
+            HIPCK(hipEventRecord(c->ev_main, s3));
+            HIPCK(hipStreamWaitEvent(c->stream, c->ev_main, 0));
+            on_side = true;
+        } else {
+            hipLaunchKernelGGL(k_catch_up, dim3(16), dim3(256), 0, c->stream, c->tab, c->tab_prev, c->prev_touched, c->glob);
+            HIPCK(hipEventRecord(c->ev_gathered, c->stream)); /* also: behind an accepted step's kernels (ig_nuis_accept), which read what the pass overwrites */
+        }
     }
     c->nuis_caught_up = false;
+    c->main_drained = false;
     const ig_params hp = {p_test[0], p_test[1], p_test[2], p_test[3], p_test[4], p_test[5], p_test[6], p_test[7]};
     c->nuis_test = hp;
     c->nuis_mean_kb = mean_subfrag_kb;
     const double need = (mean_subfrag_kb > 0) ? (double)p_test[5] / (double)mean_subfrag_kb + 2.0 : 0.0;
     c->pz_n1 = (need > 0 && need < (double)PZ_MAX) ? (int)need : ((need >= (double)PZ_MAX) ? PZ_MAX : 0);
-    hipStream_t s3 = c->stream3;
-    HIPCK(hipStreamWaitEvent(s3, c->ev_gathered, 0));
+    if (!on_side) HIPCK(hipStreamWaitEvent(s3, c->ev_gathered, 0));
     c->nuis_pub_sums = false;
     c->pub_sums = (c->nuis_spec && c->host_nuis_dev) ? c->host_nuis_dev : nullptr; /* launch_full_nz: the tiled kernel's last workgroup publishes */
     const bool zero_done = launch_full_nz(c, c->tab_prev, 1, c->scratch_nuis, PzTab{c->pz_tab1, c->pz_n1}, s3, c->scratch_nuis + 2, &hp, mean_subfrag_kb);
@@ -1869,7 +1884,7 @@ extern "C" int ig_nuis_run_begin(ig_ctx* c, int32_t n_moves, const int32_t* frag
     if (n_moves <= 0) return fail("ig_nuis_run_begin: no moves");
     if (max_c < 1 || max_c > IG_MAX_CANDIDATES) return fail("ig_nuis_run_begin: max_c out of range");
     if (!c->init_links_inverse) return fail("ig_nuis_run_begin: the initial prev / next arrays are not mutually inverse (ig_links_inverse): ig_nuis_begin, one pair at a time");
-    static const int s_cap = getenv("IG_NUIS_WMAX") ? atoi(getenv("IG_NUIS_WMAX")) : 12;
+    static const int s_cap = getenv("IG_NUIS_WMAX") ? atoi(getenv("IG_NUIS_WMAX")) : 24;
     if (g_nuis_w < 0) g_nuis_w = getenv("IG_NUIS_W") ? std::max(0, atoi(getenv("IG_NUIS_W"))) : 0;
     const int Wmax = std::max(1, std::min(std::max(s_cap, g_nuis_w), max_batch_width(c, max_c)));
     if (ensure_move_buffers(c, std::max(8, (int)max_c), Wmax)) return -1;
@@ -1918,8 +1933,13 @@ extern "C" int ig_nuis_step_begin(ig_ctx* c, int32_t move, const float p_test[8]
     if (c->nuis_in_flight) return fail("ig_nuis_step_begin: the previous step was not ended (ig_nuis_end)");
     if (move != c->spec_move || move >= c->up_moves) return fail("ig_nuis_step_begin: move %d, expected %d of %d", move, c->spec_move, c->up_moves);
     c->nuis_in_flight = true;
+    /* a batch is scored in this step (or still being scored: right after an accepted step): the pass leaves half of every CU
+     * to it; else it takes the machine (all that runs next to it is one decision and one apply) */
+    const bool rescore = !c->spec_valid || c->spec_next >= c->spec_W || c->spec_base + c->spec_next != move;
+    c->side_busy = rescore || c->spec_next == 0;
     if (enqueue_nuis_pass(c, p_test, mean_subfrag_kb)) return -1;
-    if (!c->spec_valid || c->spec_next >= c->spec_W || c->spec_base + c->spec_next != move) {
+    c->side_busy = true;
+    if (rescore) {
         if (nuis_spec_score(c, move)) return -1;
     }
     /* the result record reaches the host as soon as the move is applied: written by k_commit_batch itself where the host
@@ -2012,6 +2032,7 @@ extern "C" int ig_nuis_end(ig_ctx* c, ig_move_result* out, double* nz_test, doub
     c->nuis_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count(); /* ig_debug_nuis_wait */
     HIPCK(hipGetLastError());
     drain_timers(c);
+    c->main_drained = c->nuis_spec; /* a run's step: its last kernel on the library stream has delivered (or the stream was synchronised) */
     *out = c->host_nuis->res;
     if (out->error) return fail("device-side consistency failure %d", out->error);
     long long h[8];
@@ -2081,6 +2102,7 @@ extern "C" int ig_nuis_accept(ig_ctx* c)
         HIPCK(hipMemset(c->scratch_accept, 0, 8 * sizeof(long long)));
     }
     long long* acc8 = c->scratch_accept;
+    c->main_drained = false;
     const int w = c->spec_slot; /* the slot of the move just applied (0 unless it came out of a batch: ig_nuis_step_begin) */
     nuis_spec_invalidate(c);    /* whatever was scored ahead was scored under the old parameters */
     const PzTab pz1{c->pz_tab1, c->pz_n1};
