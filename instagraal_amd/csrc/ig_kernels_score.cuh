@@ -1638,19 +1638,53 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
     const long long Sc = slice_total(part);
     const int r = (int)(Sc % 64);
     if (!(tail_quirk && r > 0)) return;
-    int lo_t = 0, hi_t = mb.M; /* count(lo_t) >= r, count(hi_t) < r */
-    while (hi_t - lo_t > 1) {
-        const int mid = lo_t + (hi_t - lo_t) / 2;
-        long long s = 0;
-        for (int ls = tid; ls < m.m_loc; ls += blockDim.x)
-            if (subs[ls] >= mid) s += rowcnt[ls];
-        s = wave_sum_ll(s);
-        if (lane == 0) sh_red[wv] = s;
+    /* T = the largest sub-fragment id with (kept contacts in rows of id >= T) >= r.  Radix descent, 8 bits of the id per pass over
+     * the window's rows (histogram of the kept contacts by id, suffix sums from the top): 3 passes at M = 150 k where a
+     * bisection on the id took 18 -- on windows of thousands of rows this walk is the longest chain of the launch. */
+    __shared__ int hist[256];
+    int lo_t = 0, bits = 0; /* invariant: count(id >= lo_t) >= r > count(id >= lo_t + 2^bits) =: n_above */
+    while ((1 << bits) < mb.M) bits++;
+    int n_above = 0;
+    while (bits > 0) {
+        const int sh = max(bits - 8, 0), nb = 1 << (bits - sh);
+        for (int b = tid; b < nb; b += blockDim.x) hist[b] = 0;
         __syncthreads();
-        const long long tot = sh_red[0] + sh_red[1] + sh_red[2] + sh_red[3];
+        for (int ls = tid; ls < m.m_loc; ls += blockDim.x) {
+            const int d = subs[ls] - lo_t, n = rowcnt[ls];
+            if (n > 0 && d >= 0 && (d >> bits) == 0) atomicAdd(&hist[d >> sh], n);
+        }
         __syncthreads();
-        if (tot >= r) lo_t = mid;
-        else hi_t = mid;
+        /* the highest bin b with n_above + (bins b .. nb-1) >= r: wave 0, four bins per lane, suffix sums across the lanes */
+        if (wv == 0) {
+            int h[4], mine = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                h[q] = (4 * lane + q < nb) ? hist[4 * lane + q] : 0;
+                mine += h[q];
+            }
+            int suf = mine; /* inclusive suffix sum over lanes >= lane */
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_down(suf, off, 64);
+                if (lane + off < 64) suf += o;
+            }
+            const unsigned long long ok = __ballot(n_above + suf >= r);
+            const int top = 63 - __builtin_clzll(ok); /* ok != 0: lane 0's suffix is the whole range, count(id >= lo_t) >= r */
+            if (lane == top) {
+                int acc = n_above + suf - mine, b = 3; /* contacts above this lane's bins */
+                for (; b > 0; b--) {
+                    if (acc + h[b] >= r) break;
+                    acc += h[b];
+                }
+                hist[0] = 4 * lane + b; /* the bin, and the contacts above it */
+                hist[1] = acc;
+            }
+        }
+        __syncthreads();
+        const int b = hist[0];
+        n_above = hist[1];
+        __syncthreads();
+        lo_t += b << sh;
+        bits = sh;
     }
     const int T = lo_t;
     if (tid == 0) {
