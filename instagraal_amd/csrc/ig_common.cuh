@@ -188,6 +188,7 @@ struct MoveBuf {
      * the few longest ones) */
     unsigned long long* work;
     int work_cap;
+    int* slot_items; /* [capW][8] work items a slot puts on each of the eight sub-lists (k_contend -> k_worklist) */
     int N, M, capC, capW;
     /* strides of the per-window arrays above (Lloc .. loc: sN fragments, subs / rowcnt / coords: sM sub-fragments): the
      * largest window the genome can produce right now -- two contigs of the current maximum length, with headroom -- not

@@ -259,6 +259,7 @@ static void free_move_buffers(ig_ctx* c)
     hipFree(m.cont);
     hipFree(m.ident);
     hipFree(m.work);
+    hipFree(m.slot_items);
     hipFree(c->own_tag);
     hipFree(c->own_idx);
     c->own_tag = c->own_idx = nullptr;
@@ -511,6 +512,7 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
     HIPCK(hipMemset(m.ident, 0, C * sizeof(unsigned)));
     m.work_cap = (int)std::min<size_t>((size_t)1 << 20, 4 * C * NSLOT * SLICE_SEG + 4096);
     DALLOC(m.work, (size_t)m.work_cap + 32);
+    DALLOC(m.slot_items, (size_t)capW * 8);
     HIPCK(hipMemset(m.cont, 0xff, C * sizeof(unsigned)));
     DALLOC(c->own_tag, N);
     DALLOC(c->own_idx, N);

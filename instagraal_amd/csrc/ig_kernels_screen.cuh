@@ -701,7 +701,23 @@ __global__ void __launch_bounds__(256) k_contend(Glob* g, MoveBuf mb, const Scre
         long long ch = chunk0;
         while (tot / ch + (long long)C * NSLOT * SLICE_SEG > grid_cap / 2) ch *= 2;
         mb.ctl[w].exact_chunk = (int)ch;
+        s_kind[0] = (int)ch; /* (the intervals are done with) */
     }
+    /* ... and how many items that is per sub-list (segment s -> sub-list s % 8): k_worklist places the slots in order from these */
+    __shared__ int s_items[8];
+    if (tid < 8) s_items[tid] = 0;
+    __syncthreads();
+    {
+        const long long ch = s_kind[0];
+        for (int u = tid; u < C * SLICE_SEG; u += blockDim.x) {
+            const int c = u / SLICE_SEG, seg = u % SLICE_SEG;
+            const long long n_seg = mb.part[(size_t)CW(w, c) * P_STRIDE + P_CNT + seg];
+            const int it = (int)((n_seg + ch - 1) / ch) * __popc(s_mask[c] & ~s_ident[c]);
+            if (it) atomicAdd(&s_items[seg & 7], it);
+        }
+    }
+    __syncthreads();
+    if (tid < 8) mb.slot_items[w * 8 + tid] = s_items[tid];
     if (tid == 0) { /* diagnostics: columns screened / columns sent to the exact kernel (column 0 of a candidate included) */
         long long cols = 0, cnt = 0;
         long long tcols = 0, tcnt = 0;
@@ -724,7 +740,7 @@ __global__ void __launch_bounds__(256) k_contend(Glob* g, MoveBuf mb, const Scre
  * segment s go to sub-list s % 8, item j of sub-list x sits at index 8 j + x -- the index is the exact kernel's block index,
  * block b runs on XCD b % 8 (observed; a placement for speed, nothing depends on it), the XCD whose L2 k_screen just pulled
  * that segment's lists through; the contender columns of a chunk are consecutive in their sub-list.  The slots take their
- * places in slot order (every workgroup recomputes the counts of the slots before its own: a few hundred loads), so a slot
+ * places in slot order (the counts per slot and sub-list come from k_contend), so a slot
  * fits or not regardless of the ones behind it: the slots that fit are a prefix of the batch, the first one always fits
  * (k_contend's choice of ch), a slot that does not fit is flagged like a slot whose slice overflowed the pool -- the decide
  * step stops before it and it is re-run.  grid_cap = the blocks the host launches the exact kernel with (sized from what
@@ -733,20 +749,12 @@ __global__ void __launch_bounds__(256) k_worklist(MoveBuf mb, const unsigned* __
 {
     __shared__ int s_base[8], s_cnt[8], s_fit;
     const int w = w_begin + blockIdx.x, tid = threadIdx.x;
-    auto items_of = [&](int ws, int c, int seg) -> int {
-        const long long ch = mb.ctl[ws].exact_chunk;
-        const long long n_seg = mb.part[(size_t)CW(ws, c) * P_STRIDE + P_CNT + seg];
-        return (int)((n_seg + ch - 1) / ch) * __popc(cont[CW(ws, c)] & ~mb.ident[CW(ws, c)]);
-    };
-    if (tid < 8) s_base[tid] = s_cnt[tid] = 0;
-    __syncthreads();
-    /* (slot, candidate, segment) units of the slots up to this one */
-    const int per = mb.capC * SLICE_SEG;
-    for (int u = tid; u < (blockIdx.x + 1) * per; u += blockDim.x) {
-        const int ws = w_begin + u / per, c = (u % per) / SLICE_SEG, seg = u % SLICE_SEG;
-        if (c >= mb.ctl[ws].C) continue;
-        const int it = items_of(ws, c, seg);
-        if (it) atomicAdd(ws == w ? &s_cnt[seg & 7] : &s_base[seg & 7], it);
+    /* the items of the slots before this one, per sub-list (k_contend counted them) */
+    if (tid < 8) {
+        int base = 0;
+        for (int ws = w_begin; ws < w; ws++) base += mb.slot_items[ws * 8 + tid];
+        s_base[tid] = base;
+        s_cnt[tid] = mb.slot_items[w * 8 + tid];
     }
     __syncthreads();
     if (tid == 0) {
