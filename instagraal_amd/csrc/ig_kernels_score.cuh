@@ -177,6 +177,9 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+#ifndef MUT_LDS_N
+#define MUT_LDS_N 384 /* fragments of a window mutated in LDS (14 arrays x 4 bytes each: 21 KB) */
+#endif
 /* one workgroup = one candidate genome (slot `slot` of candidate c of move slot w) on the local window */
 __device__ __forceinline__ void mutate_one(const State& st, const Tables& tab, const SubTab* __restrict__ sub,
                                            const long long* __restrict__ rowptr, Glob* g, const MoveBuf& mb, const PzTab& pz, int slot,
@@ -191,24 +194,36 @@ __device__ __forceinline__ void mutate_one(const State& st, const Tables& tab, c
     const int N = mb.sN, M = mb.sM, n = m.n_loc; /* strides of the window arrays */
     if (n > N || m.m_loc > M) return; /* k_gather flagged it */
     int* base = mb.loc + ((size_t)(cw * NSLOT + slot) * NDYN) * N;
+    /* Windows of up to MUT_LDS_N fragments are mutated in LDS and written out once: the operator chain is a dozen dependent
+     * phases over the 13 arrays, each a global-memory round trip when they live in the window buffers. */
+    __shared__ int s_loc[(NDYN + 3) * MUT_LDS_N];
+    const bool in_lds = n <= MUT_LDS_N;
+    int* wb = in_lds ? s_loc : base;
+    const size_t ws = in_lds ? (size_t)MUT_LDS_N : (size_t)N;
     igd::Loc S;
-    S.pos = base;
-    S.spos = base + (size_t)N;
-    S.cid = base + (size_t)2 * N;
-    S.sbp = base + (size_t)3 * N;
-    S.circ = base + (size_t)4 * N;
-    S.prev = base + (size_t)5 * N;
-    S.next = base + (size_t)6 * N;
-    S.L = base + (size_t)7 * N;
-    S.SL = base + (size_t)8 * N;
-    S.LB = base + (size_t)9 * N;
-    S.ori = base + (size_t)10 * N;
-    S.gid = mb.Lloc + (size_t)cw * N;
-    S.lb = mb.lbloc + (size_t)cw * N;
-    S.sl = mb.slloc + (size_t)cw * N;
+    S.pos = wb;
+    S.spos = wb + ws;
+    S.cid = wb + 2 * ws;
+    S.sbp = wb + 3 * ws;
+    S.circ = wb + 4 * ws;
+    S.prev = wb + 5 * ws;
+    S.next = wb + 6 * ws;
+    S.L = wb + 7 * ws;
+    S.SL = wb + 8 * ws;
+    S.LB = wb + 9 * ws;
+    S.ori = wb + 10 * ws;
+    const int* g_gid = mb.Lloc + (size_t)cw * N;
+    S.gid = in_lds ? (const int*)(s_loc + 11 * MUT_LDS_N) : g_gid;
+    S.lb = in_lds ? (const int*)(s_loc + 12 * MUT_LDS_N) : (mb.lbloc + (size_t)cw * N);
+    S.sl = in_lds ? (const int*)(s_loc + 13 * MUT_LDS_N) : (mb.slloc + (size_t)cw * N);
     S.n = n;
     for (int x = threadIdx.x; x < n; x += blockDim.x) {
-        const int f = S.gid[x];
+        const int f = g_gid[x];
+        if (in_lds) {
+            s_loc[11 * MUT_LDS_N + x] = f;
+            s_loc[12 * MUT_LDS_N + x] = mb.lbloc[(size_t)cw * N + x];
+            s_loc[13 * MUT_LDS_N + x] = mb.slloc[(size_t)cw * N + x];
+        }
         S.pos[x] = st.pos[f];
         S.spos[x] = st.spos[f];
         S.cid[x] = st.cid[f];
@@ -256,6 +271,10 @@ __device__ __forceinline__ void mutate_one(const State& st, const Tables& tab, c
                   (S.circ[x] != st.circ[f]) | (S.prev[x] != st.prev[f]) | (S.next[x] != st.next[f]) | (S.L[x] != st.L[f]) |
                   (S.SL[x] != st.SL[f]) | (S.LB[x] != st.LB[f]) | (S.ori[x] != st.ori[f]);
             hd += (S.pos[x] == 0);
+            if (in_lds) { /* the candidate genome to where the commit step (and ig_debug_candidate_state) read it */
+#pragma unroll
+                for (int a = 0; a < NDYN; a++) base[(size_t)a * N + x] = s_loc[a * MUT_LDS_N + x];
+            }
         }
         __shared__ int sh_ch, sh_hd;
         if (threadIdx.x == 0) {
