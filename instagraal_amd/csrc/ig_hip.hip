@@ -1112,12 +1112,13 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                 static const int s_rb = getenv("IG_SLICE_RB") ? atoi(getenv("IG_SLICE_RB")) : 0;
                 const int rb = s_rb > 0 ? s_rb : SLICE_RB;
                 static const int s_share = getenv("IG_SLICE_SHARE") ? atoi(getenv("IG_SLICE_SHARE")) : 1; /* A's rows once per move */
+                static const int s_maxj = getenv("IG_SLICE_J") ? std::max(1, atoi(getenv("IG_SLICE_J"))) : 1 << 20;
                 if (c->mb.packed)
                     hipLaunchKernelGGL(k_slice<true>, dim3(rb, max_c + 1, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->rank,
-                                       c->world, w_begin, s_share);
+                                       c->world, w_begin, s_share, s_maxj);
                 else
                     hipLaunchKernelGGL(k_slice<false>, dim3(rb, max_c + 1, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->rank,
-                                       c->world, w_begin, s_share);
+                                       c->world, w_begin, s_share, s_maxj);
             }
             /* two-tier scoring (batches on one handle, packed lists): every column through the float screening kernel, the exact
              * kernel only for the columns that can still win (ig_kernels_screen.cuh).  IG_SCREEN=0: everything exact;

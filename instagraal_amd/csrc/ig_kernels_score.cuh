@@ -451,7 +451,9 @@ __global__ void __launch_bounds__(OFFSETS_THREADS) k_offsets(MoveBuf mb, int W, 
 #ifndef SLICE_RB
 #define SLICE_RB 128 /* workgroups (of 4 rows at a time) per candidate when nothing is known about the window sizes yet */
 #endif
+#ifndef SLICE_UNROLL
 #define SLICE_UNROLL 4
+#endif
 #ifndef SLICE_MIN_WAVES
 #define SLICE_MIN_WAVES 8 /* eight workgroups per CU need <= 80 SGPRs (81 admit seven: MI355X_MICROARCH.md, residency) */
 #endif
@@ -465,26 +467,45 @@ __global__ void __launch_bounds__(OFFSETS_THREADS) k_offsets(MoveBuf mb, int W, 
  * flight), counting pass + writing pass without atomics (178 us: the rows are read twice). */
 template <bool PACKED>
 __global__ void __launch_bounds__(256, SLICE_MIN_WAVES) k_slice(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
-                                                                 Glob* g, MoveBuf mb, int rank, int world, int w_begin, int share_rows)
+                                                                 Glob* g, MoveBuf mb, int rank, int world, int w_begin, int share_rows, int max_j)
 {
-    const int w = w_begin + blockIdx.z, C = mb.ctl[w].C;
+    const int w = w_begin + blockIdx.z;
     const bool shared_plane = (blockIdx.y == gridDim.y - 1);
     __shared__ long long seg_off[IG_MAX_CANDIDATES][SLICE_SEG];
-    __shared__ int s_cw[IG_MAX_CANDIDATES], s_ctgB[IG_MAX_CANDIDATES], s_nc;
+    __shared__ int s_cw[IG_MAX_CANDIDATES], s_ctgB[IG_MAX_CANDIDATES], s_idx[IG_MAX_CANDIDATES], s_nc;
+    __shared__ int a_same[IG_MAX_CANDIDATES], a_ctgB[IG_MAX_CANDIDATES], a_SLA, a_ctgA, a_mloc[IG_MAX_CANDIDATES];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    /* ONE round trip for everything the prologue needs (this launch is tens of thousands of short waves: every dependent load in
+     * front of the rows counts): the slot's candidate count, the few fields of every candidate's window, every list start */
+    const int C = mb.ctl[w].C;
+    const int capC = min(mb.capC, IG_MAX_CANDIDATES);
+    if ((int)threadIdx.x < capC) {
+        const CandMeta& mt = mb.meta[CW(w, threadIdx.x)]; /* (entries behind the slot's last candidate: stale but in bounds, not used) */
+        a_same[threadIdx.x] = mt.same;
+        a_ctgB[threadIdx.x] = mt.ctgB;
+        a_mloc[threadIdx.x] = mt.m_loc;
+        if (threadIdx.x == 0) {
+            a_SLA = mt.SLA; /* the focal contig is every candidate's */
+            a_ctgA = mt.ctgA;
+        }
+    }
+    for (int i = threadIdx.x; i < capC * SLICE_SEG; i += blockDim.x) seg_off[i / SLICE_SEG][i % SLICE_SEG] = mb.sloff[(size_t)CW(w, i / SLICE_SEG) * SLICE_SEG + i % SLICE_SEG];
+    __syncthreads();
     if (threadIdx.x == 0) {
         int nc = 0;
         if (shared_plane) {
             if (share_rows)
                 for (int c = 0; c < C; c++)
-                    if (!mb.meta[CW(w, c)].same) {
+                    if (!a_same[c]) {
+                        s_idx[nc] = c;
                         s_cw[nc] = CW(w, c);
-                        s_ctgB[nc++] = mb.meta[CW(w, c)].ctgB;
+                        s_ctgB[nc++] = a_ctgB[c];
                     }
         } else if ((int)blockIdx.y < C) {
+            s_idx[0] = blockIdx.y;
             s_cw[0] = CW(w, blockIdx.y);
-            s_ctgB[0] = mb.meta[s_cw[0]].ctgB;
+            s_ctgB[0] = a_ctgB[blockIdx.y];
             nc = 1;
         }
         s_nc = nc;
@@ -492,31 +513,30 @@ __global__ void __launch_bounds__(256, SLICE_MIN_WAVES) k_slice(const long long*
     __syncthreads();
     const int nc = s_nc;
     if (nc == 0) return;
-    for (int i = threadIdx.x; i < nc * SLICE_SEG; i += blockDim.x) seg_off[i / SLICE_SEG][i % SLICE_SEG] = mb.sloff[(size_t)s_cw[i / SLICE_SEG] * SLICE_SEG + i % SLICE_SEG];
-    __syncthreads();
     if (seg_off[0][0] < 0) return; /* slice pool exhausted (k_offsets flags all segments of a slot together) */
-    const int cw0 = s_cw[0];
-    const CandMeta& m = mb.meta[cw0];
+    const int cw0 = s_cw[0], c0 = s_idx[0];
+    const CandMeta& m = mb.meta[cw0]; /* only the windowed predicate of a candidate in A's own contig reads it */
     const int M = mb.sM;
+    const bool m_same = a_same[c0] != 0;
     /* the rows this plane walks: A's (shared plane), B's (a candidate in another contig, A's being walked by the shared plane), all */
-    const bool own_all = !shared_plane && (m.same || !share_rows);
-    const int row_lo = (shared_plane || own_all) ? 0 : m.SLA;
-    const int n_rows = shared_plane ? m.SLA : (m.m_loc - row_lo);
-    const int ctgA = m.ctgA, SLA = m.SLA;
+    const bool own_all = !shared_plane && (m_same || !share_rows);
+    const int SLA = a_SLA, ctgA = a_ctgA;
+    const int row_lo = (shared_plane || own_all) ? 0 : SLA;
+    const int n_rows = shared_plane ? SLA : (a_mloc[c0] - row_lo);
     const int* subs = mb.subs + (size_t)cw0 * M;
     /* work items = (row, j): wave j of a row takes the row's contact chunks j, j + J, ... (J waves per row: a row of thousands
      * of contacts is a chain of dependent round trips per chunk, and the launch waits for the longest chain) */
     const int nrw = gridDim.x * 4;
-    const int J = max(1, nrw / max(n_rows, 1));
+    const int J = min(max_j, max(1, nrw / max(n_rows, 1)));
     for (int item = blockIdx.x * 4 + wv; item < n_rows * J; item += nrw) {
         const int r = row_lo + item % n_rows, j = item / n_rows;
         const int seg = r % SLICE_SEG;
         const int i = subs[r];
         const long long b = rowptr[i], e = rowptr[i + 1];
+        const int2 cp1 = tab.cp[i]; /* with the row's bounds: one round trip */
         const bool mine = (world <= 1) || ((r % world) == rank);
         int rc = 0; /* lane k: contacts of this row kept for candidate k */
         if (b != e) {
-            const int2 cp1 = tab.cp[i];
             for (long long q0 = b + (long long)j * 64 * SLICE_UNROLL; q0 < e; q0 += (long long)J * 64 * SLICE_UNROLL) {
                 int2 v[SLICE_UNROLL], cp2[SLICE_UNROLL];
 #pragma unroll
@@ -544,13 +564,13 @@ __global__ void __launch_bounds__(256, SLICE_MIN_WAVES) k_slice(const long long*
                     unsigned long long base = 0;
                     if (lane == 0) base = atomicAdd((unsigned long long*)(mb.part + (size_t)s_cw[k] * P_STRIDE + P_CNT + seg), (unsigned long long)add);
                     base = __shfl(base, 0, 64);
-                    const long long off = seg_off[k][seg];
+                    const long long off = seg_off[s_idx[k]][seg];
                     int o2 = 0;
 #pragma unroll
                     for (int u = 0; u < SLICE_UNROLL; u++) {
                         if (keep[u]) {
                             const long long at = off + (long long)base + o2 + __popcll(mask[u] & lt_mask);
-                            const int lj = ((m.same || cp2[u].x == ctgA) ? 0 : SLA) + cp2[u].y;
+                            const int lj = ((m_same || cp2[u].x == ctgA) ? 0 : SLA) + cp2[u].y;
                             if (PACKED) {
                                 mb.sl_pk[at] = (unsigned long long)r | ((unsigned long long)lj << 20) | ((unsigned long long)v[u].y << 40);
                             } else {
