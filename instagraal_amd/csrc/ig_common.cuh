@@ -267,6 +267,7 @@ struct ig_ctx {
     long long* tile_trace; /* ig_debug_tile_trace */
     int n_tile_static, n_tile_info; /* work items k_full_nz_tiled is launched over; off-diagonal tiles with a histogram */
     struct TileInfo* tile_info;
+    long long* tile_partial;        /* k_tile_trans: one (hi, lo) pair per workgroup, summed by k_full_nz_tiled */
     int *tile_dyn, *tile_dyn_list;  /* {count, cursor} and the work items of the tiles whose contacts have to be read this pass */
     unsigned *tile_hist, *tile_sig; /* count histograms of the off-diagonal tiles (static); contig signatures of the blocks (per pass) */
     int* init_prev;

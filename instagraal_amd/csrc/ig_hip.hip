@@ -305,6 +305,7 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipFree(c->tile_info);
     hipFree(c->tile_dyn);
     hipFree(c->tile_dyn_list);
+    hipFree(c->tile_partial);
     hipFree(c->init_prev);
     hipFree(c->init_next);
     hipFree(c->orientable);
@@ -391,11 +392,11 @@ static bool launch_full_nz(ig_ctx* c, const Tables& t, int which, long long* out
         /* the off-diagonal tiles: summed from their count histograms where the two blocks share no contig, else put on the
          * list; in the same launch (blocks behind those of the tiles) the zero-pixel pass */
         const int per = TILE_TRANS_THREADS / 64;
-        const int n_trans = (c->n_tile_info + per - 1) / per, n_zero = zero_out ? 32 : 0;
+        const int n_trans = (c->n_tile_info + per - 1) / per, n_zero = zero_out ? std::min(256, std::max(32, c->M / 4096)) : 0; /* the zero-pixel pass: ~4 sub-fragments per thread */
         if (n_trans + n_zero > 0)
             hipLaunchKernelGGL(k_tile_trans, dim3(n_trans + n_zero), dim3(TILE_TRANS_THREADS), 0, stream, c->tile_info, c->n_tile_info, c->tile_sig,
-                               c->tile_hist, c->full_const, (TileDyn*)c->tile_dyn, c->tile_dyn_list, s_hist, out, n_trans, t, c->glob, which,
-                               c->M, zero_out);
+                               c->tile_hist, c->full_const, (TileDyn*)c->tile_dyn, c->tile_dyn_list, s_hist, c->tile_partial, n_trans, t, c->glob,
+                               which, c->M, zero_out);
         /* persistent workgroups over the static items and then the list */
         /* two per CU; next to a move (the nuisance step's pass, on its own stream) one per CU: persistent workgroups that took
          * every wave slot would keep the move's kernels waiting until the pass is over (k_decide_batch: 70 instead of 12 us),
@@ -406,7 +407,8 @@ static bool launch_full_nz(ig_ctx* c, const Tables& t, int which, long long* out
         if (grid > 0)
             hipLaunchKernelGGL(k_full_nz_tiled, dim3(grid), dim3(FULL_TILED_THREADS), sizeof(FullTiledLds), stream, c->tile_work, c->tiled_cc,
                                c->tabrec, t.len, c->full_const, c->lgf_tab, c->M, pz.n, out, c->n_tile_static, (TileDyn*)c->tile_dyn,
-                               c->tile_dyn_list, c->tile_trace, (zero_out && c->pub_sums) ? c->pub_sums : nullptr, ++c->sums_seq);
+                               c->tile_dyn_list, c->tile_trace, (zero_out && c->pub_sums) ? c->pub_sums : nullptr, ++c->sums_seq, c->tile_partial,
+                               n_trans);
         if (zero_out && c->pub_sums) c->nuis_pub_sums = true;
         return zero_out != nullptr;
     }
@@ -580,6 +582,8 @@ extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* 
     hipFree(c->tile_info);
     hipFree(c->tile_dyn);
     hipFree(c->tile_dyn_list);
+    hipFree(c->tile_partial);
+    c->tile_partial = nullptr;
     c->tile_info = nullptr;
     c->tile_dyn = nullptr;
     c->tile_dyn_list = nullptr;
@@ -647,9 +651,10 @@ extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* 
             DALLOC(c->tiled_cc, (size_t)Z);
             DALLOC(c->tile_work, work.size());
             DALLOC(c->tile_hist, hist.size());
-            DALLOC(c->tile_sig, (size_t)nb * SIG_WORDS);
+            DALLOC(c->tile_sig, (size_t)nb * (SIG_WORDS + SIG_FOLD));
             DALLOC(c->tile_info, std::max<size_t>(tiles.size(), 1));
             DALLOC(c->tile_dyn, 4);
+            DALLOC(c->tile_partial, 2 * ((tiles.size() + TILE_TRANS_THREADS / 64 - 1) / (TILE_TRANS_THREADS / 64) + 1));
             DALLOC(c->tile_dyn_list, std::max<size_t>(work.size() - (size_t)c->n_tile_static, 1));
             HIPCK(hipMemcpy(c->tiled_cc, tc.data(), (size_t)Z * sizeof(uint2), hipMemcpyHostToDevice));
             HIPCK(hipMemcpy(c->tile_work, work.data(), work.size() * sizeof(TileWork), hipMemcpyHostToDevice));

@@ -828,13 +828,27 @@ struct ScoreTables {
     double pzc[LDS_PZ + 2];  /* P_z * log10(e) per rank distance; from the table's end on (and for trans pairs): the trans level */
     double lgf[LDS_LGF];     /* log10(ob!) */
 };
+#define TILE_HB 64 /* bins of a tile's histogram of counts (k_full_nz_tiled) */
 struct ScoreConst {
     ScoreTables tab;
     ig_hot hot;
     ig_params par;
     float mean_kb;
+    unsigned long long qtrans[TILE_HB]; /* the quantised term of a trans pair with count ob (+ the rounding magic): k_tile_trans */
 };
 static_assert(sizeof(ScoreTables) % 16 == 0, "copied as 16-byte vectors");
+/* the quantised trans term of count o_b (+ the rounding magic): the straight-line term of the kernels below with the trans
+ * level for P and P_z -- same expression, same bits */
+__device__ __forceinline__ unsigned long long trans_term_bits(unsigned o_b, double lv, const double* T, const double* lgf, double pzc_trans)
+{
+    const double ex = ig_exp2_core(lv, T), lg = lv * IG_LOG2_10_INV;
+    const double t = (ig_fma((double)o_b, lg, -ex) - lgf[o_b]) + pzc_trans;
+    return !(__builtin_fabs(t) < 524288.0) ? (unsigned long long)ig_quantize(t) + IG_QMAGIC_BITS : ig_d2u(ig_fma(t, IG_QSCALE, IG_QMAGIC));
+}
+
+/* one wave per off-diagonal tile with a histogram (the last n_trans_blocks blocks); the blocks in front of them, if any, are the
+ * zero-pixel pass over all sub-fragments (k_full_zero's job: it needs nothing from the tiles and would otherwise be one more
+ * launch behind k_full_nz_tiled) */
 __device__ __forceinline__ void build_score_const_block(const Glob* g, PzTab pz, const double* __restrict__ lgf_tab, ScoreConst* out, int which)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -847,6 +861,10 @@ __device__ __forceinline__ void build_score_const_block(const Glob* g, PzTab pz,
         out->hot = ig_hot_make(p, ig_tab());
         out->par = p;
         out->mean_kb = g->mean_kb;
+    }
+    if (i < TILE_HB) { /* from the sources of the table entries it reads (they are being written by other threads) */
+        const ig_hot h = ig_hot_make(p, ig_tab());
+        out->qtrans[i] = i ? trans_term_bits((unsigned)i, h.log2_v_inter, ig_tab(), lgf_tab, (double)p.v_inter * IG_LOG_E_F) : IG_QMAGIC_BITS;
     }
 }
 __global__ void k_build_score_const(const Glob* g, PzTab pz, const double* __restrict__ lgf_tab, ScoreConst* out, int which)
@@ -1126,7 +1144,6 @@ __global__ void __launch_bounds__(256) k_full_nz(const int* __restrict__ crow, c
 #ifndef FULL_TILED_THREADS
 #define FULL_TILED_THREADS 1024
 #endif
-#define TILE_HB 64 /* bins of a tile's histogram of counts */
 struct TileWork {
     long long off; /* first contact of the item in the tiled array */
     int n, bi, bj, pad;
@@ -1148,32 +1165,23 @@ struct FullTiledLds {
     int next_item;
 };
 
-/* the quantised trans term of count o_b (+ the rounding magic): the straight-line term of the kernels below with the trans
- * level for P and P_z -- same expression, same bits */
-__device__ __forceinline__ unsigned long long trans_term_bits(unsigned o_b, double lv, const double* T, const double* lgf, double pzc_trans)
-{
-    const double ex = ig_exp2_core(lv, T), lg = lv * IG_LOG2_10_INV;
-    const double t = (ig_fma((double)o_b, lg, -ex) - lgf[o_b]) + pzc_trans;
-    return !(__builtin_fabs(t) < 524288.0) ? (unsigned long long)ig_quantize(t) + IG_QMAGIC_BITS : ig_d2u(ig_fma(t, IG_QSCALE, IG_QMAGIC));
-}
-
-/* one wave per off-diagonal tile with a histogram (blocks [0, n_trans_blocks)); the blocks behind them, if any, are the
- * zero-pixel pass over all sub-fragments (k_full_zero's job: it needs nothing from the tiles and would otherwise be one more
- * launch behind k_full_nz_tiled) */
 #define TILE_TRANS_THREADS 1024 /* a tile per wave; few, large workgroups: every workgroup ends in a pair of atomics on the same two words */
 __global__ void __launch_bounds__(TILE_TRANS_THREADS) k_tile_trans(const TileInfo* __restrict__ tiles, int n_tiles, const unsigned* __restrict__ sig,
                                                     const unsigned* __restrict__ hist, const ScoreConst* __restrict__ sc, TileDyn* dyn,
-                                                    int* __restrict__ dyn_list, int use_hist, long long* out, int n_trans_blocks, Tables zt,
+                                                    int* __restrict__ dyn_list, int use_hist, long long* partial, int n_trans_blocks, Tables zt,
                                                     const Glob* g, int which, int M, long long* zero_out)
 {
-    if ((int)blockIdx.x >= n_trans_blocks) {
-        full_zero_block(zt, g, which, M, zero_out, (int)blockIdx.x - n_trans_blocks, (int)gridDim.x - n_trans_blocks);
+    const unsigned* fold = sig + (size_t)((M + FULL_TB - 1) / FULL_TB) * SIG_WORDS; /* the folded signatures (k_pack_tab_sig) */
+    /* the zero-pixel blocks first: they are the longer ones (dispatched first, they run next to the tiles' instead of behind them) */
+    const int n_zero_blocks = (int)gridDim.x - n_trans_blocks;
+    if ((int)blockIdx.x < n_zero_blocks) {
+        full_zero_block(zt, g, which, M, zero_out, (int)blockIdx.x, n_zero_blocks);
         return;
     }
+    const int tb = (int)blockIdx.x - n_zero_blocks; /* this workgroup's number among the tiles' */
     __shared__ long long red[2][TILE_TRANS_THREADS / 64];
-    __shared__ unsigned long long qt[TILE_HB];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int t = blockIdx.x * (TILE_TRANS_THREADS / 64) + wv;
+    const int t = tb * (TILE_TRANS_THREADS / 64) + wv;
     /* everything is requested before anything is looked at: tile, signatures, histogram bin; the table of trans terms by
      * the first wave meanwhile */
     TileInfo ti = {0, 0, 0, 0};
@@ -1182,12 +1190,14 @@ __global__ void __launch_bounds__(TILE_TRANS_THREADS) k_tile_trans(const TileInf
     if (t < n_tiles) {
         ti = tiles[t];
         n = hist[(size_t)t * TILE_HB + lane];
-        for (int i = lane; i < SIG_WORDS; i += 64) both |= sig[(size_t)ti.bi * SIG_WORDS + i] & sig[(size_t)ti.bj * SIG_WORDS + i];
+        if (lane < SIG_FOLD) both = fold[(size_t)ti.bi * SIG_FOLD + lane] & fold[(size_t)ti.bj * SIG_FOLD + lane];
+        if (__any(both != 0u)) { /* the folded signatures intersect: the full ones decide */
+            both = 0;
+            for (int i = lane; i < SIG_WORDS; i += 64) both |= sig[(size_t)ti.bi * SIG_WORDS + i] & sig[(size_t)ti.bj * SIG_WORDS + i];
+        }
     }
     const bool fast = sc->hot.fast;
-    if (threadIdx.x < TILE_HB)
-        qt[threadIdx.x] = threadIdx.x ? trans_term_bits(threadIdx.x, sc->hot.log2_v_inter, sc->tab.mt, sc->tab.lgf, sc->tab.pzc[LDS_PZ]) : IG_QMAGIC_BITS;
-    __syncthreads();
+    const unsigned long long qt_lane = sc->qtrans[lane]; /* the table of trans terms of this parameter set (k_build_score_const) */
     long long hi = 0, lo = 0;
     if (t < n_tiles) {
         if (__any(both != 0u) || !use_hist || !fast) { /* a contig in both blocks (or its alias): read the contacts */
@@ -1196,7 +1206,7 @@ __global__ void __launch_bounds__(TILE_TRANS_THREADS) k_tile_trans(const TileInf
             base = __shfl(base, 0, 64);
             for (int i = lane; i < ti.n_items; i += 64) dyn_list[base + i] = ti.first_item + i;
         } else if (lane >= 1) {
-            const long long q = (long long)(qt[lane] - IG_QMAGIC_BITS);
+            const long long q = (long long)(qt_lane - IG_QMAGIC_BITS);
             const unsigned long long ql = (unsigned)q;
             const long long qh = (q - (long long)ql) >> 32;
             const unsigned long long pl = n * ql; /* < 2^63: a tile holds fewer than 2^31 contacts */
@@ -1217,10 +1227,10 @@ __global__ void __launch_bounds__(TILE_TRANS_THREADS) k_tile_trans(const TileInf
             hi += red[0][q];
             lo += red[1][q];
         }
-        if (hi | lo) {
-            atomic_add_ll(&out[0], hi);
-            atomic_add_ll(&out[1], lo);
-        }
+        /* one pair of words per workgroup, summed by the first workgroup of k_full_nz_tiled: thousands of workgroups adding to
+         * the same two words with atomics took 36 ns each, one after the other (97 us at 43 k tiles) */
+        partial[2 * (size_t)tb] = hi;
+        partial[2 * (size_t)tb + 1] = lo;
     }
 }
 
@@ -1252,12 +1262,17 @@ __global__ void __launch_bounds__(256) k_nuis_prepare(Glob* g, int which, ig_par
         g->mean_kb = mean_kb;
         for (int q = 0; q < 8; q++) scratch8[q] = 0;
     }
+    if (i < TILE_HB) {
+        const ig_hot h = ig_hot_make(p, ig_tab());
+        out->qtrans[i] = i ? trans_term_bits((unsigned)i, h.log2_v_inter, ig_tab(), lgf_tab, (double)p.v_inter * IG_LOG_E_F) : IG_QMAGIC_BITS;
+    }
 }
 
 __global__ void __launch_bounds__(FULL_TILED_THREADS, 8) /* 8 waves per SIMD: two workgroups per CU need <= 80 SGPRs (112 admit 6 waves) */
     k_full_nz_tiled(const TileWork* __restrict__ work, const uint2* __restrict__ tc, const int4* __restrict__ rec, const int* __restrict__ len,
                     const ScoreConst* __restrict__ sc, const double* __restrict__ lgf_tab, int M, int pz_n, long long* out, int n_static,
-                    TileDyn* dyn, const int* __restrict__ dyn_list, long long* trace, NuisHost* hn, int hn_seq)
+                    TileDyn* dyn, const int* __restrict__ dyn_list, long long* trace, NuisHost* hn, int hn_seq,
+                    const long long* __restrict__ partial, int n_partial)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     FullTiledLds& L = *(FullTiledLds*)lds_raw;
@@ -1394,6 +1409,11 @@ __global__ void __launch_bounds__(FULL_TILED_THREADS, 8) /* 8 waves per SIMD: tw
         seq = L.next_item;
     }
     long long hi = ((long long)acc - (long long)accl) >> 32, lo = (long long)accl;
+    if (blockIdx.x == 0) /* the histogram sums of the tiles that were not read (k_tile_trans, one pair per workgroup) */
+        for (int i = threadIdx.x; i < n_partial; i += blockDim.x) {
+            hi += partial[2 * (size_t)i];
+            lo += partial[2 * (size_t)i + 1];
+        }
     hi = wave_sum_ll(hi);
     lo = wave_sum_ll(lo);
     const int lane = threadIdx.x & 63;

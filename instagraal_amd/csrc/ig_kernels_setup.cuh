@@ -41,8 +41,10 @@ __global__ void k_pack_tab(Tables t, int M, int4* __restrict__ rec)
  * SIGNATURE: bit (contig id mod 32 SIG_WORDS) of every contig with a sub-fragment in the block.  Two blocks whose signatures
  * do not intersect share no contig: every contact between them is a trans pair. */
 #define SIG_WORDS 256
+#define SIG_FOLD 32
 __device__ __forceinline__ void pack_tab_sig_block(const Tables& t, int M, int4* __restrict__ rec, unsigned* __restrict__ sig, int tb, int* dyn2)
 {
+    const int gridDim_blocks = (M + tb - 1) / tb; /* blocks of sub-fragments (k_nuis_prepare's grid holds other blocks too) */
     __shared__ unsigned lsig[SIG_WORDS];
     if (blockIdx.x == 0 && threadIdx.x == 0) dyn2[0] = dyn2[1] = dyn2[2] = 0; /* the list of tiles to read (k_tile_trans), its cursor, the workgroups through */
     for (int i = threadIdx.x; i < SIG_WORDS; i += blockDim.x) lsig[i] = 0;
@@ -57,6 +59,13 @@ __device__ __forceinline__ void pack_tab_sig_block(const Tables& t, int M, int4*
     }
     __syncthreads();
     for (int i = threadIdx.x; i < SIG_WORDS; i += blockDim.x) sig[(size_t)blockIdx.x * SIG_WORDS + i] = lsig[i];
+    /* behind the signatures of all blocks: the same folded to SIG_FOLD words (bit h mod 32 SIG_FOLD) -- two blocks whose folded
+     * signatures do not intersect do not intersect at all, and most pairs are told apart by these 128 bytes */
+    if (threadIdx.x < SIG_FOLD) {
+        unsigned f = 0;
+        for (int j = threadIdx.x; j < SIG_WORDS; j += SIG_FOLD) f |= lsig[j];
+        sig[(size_t)gridDim_blocks * SIG_WORDS + (size_t)blockIdx.x * SIG_FOLD + threadIdx.x] = f;
+    }
 }
 __global__ void __launch_bounds__(256) k_pack_tab_sig(Tables t, int M, int4* __restrict__ rec, unsigned* __restrict__ sig, int tb, int* dyn2)
 {
