@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(OFFSETS_THREADS) k_offsets(MoveBuf mb, int W, 
 #define SLICE_MIN_WAVES 8 /* eight workgroups per CU need <= 80 SGPRs (81 admit seven: MI355X_MICROARCH.md, residency) */
 #endif
 /* grid: (workgroups, candidates + 1, slots).  The rows of the focal contig A are the same for every candidate of a move whose
- * partner lies in another contig, and so are the contacts read from them and the partners' records gathered: the last plane
+ * partner lies in another contig, and so are the contacts read from them and the partners' records gathered: the first plane
  * walks A's rows ONCE for all those candidates (a contact inside A goes to every list, one into B_c to candidate c's), the
  * candidates' planes walk the rows of B_c only (all rows where A and B_c are one contig: the windowed predicate of
  * KA:565-586 is the candidate's own).  40 % fewer (row, contact chunk) chains per move at five candidates.
@@ -470,7 +470,8 @@ __global__ void __launch_bounds__(256, SLICE_MIN_WAVES) k_slice(const long long*
                                                                  Glob* g, MoveBuf mb, int rank, int world, int w_begin, int share_rows, int max_j)
 {
     const int w = w_begin + blockIdx.z;
-    const bool shared_plane = (blockIdx.y == gridDim.y - 1);
+    const bool shared_plane = (blockIdx.y == 0); /* first: its waves write every kept contact once per candidate */
+    const int cand_plane = (int)blockIdx.y - 1;
     __shared__ long long seg_off[IG_MAX_CANDIDATES][SLICE_SEG];
     __shared__ int s_cw[IG_MAX_CANDIDATES], s_ctgB[IG_MAX_CANDIDATES], s_idx[IG_MAX_CANDIDATES], s_nc;
     __shared__ int a_same[IG_MAX_CANDIDATES], a_ctgB[IG_MAX_CANDIDATES], a_SLA, a_ctgA, a_mloc[IG_MAX_CANDIDATES];
@@ -502,10 +503,10 @@ __global__ void __launch_bounds__(256, SLICE_MIN_WAVES) k_slice(const long long*
                         s_cw[nc] = CW(w, c);
                         s_ctgB[nc++] = a_ctgB[c];
                     }
-        } else if ((int)blockIdx.y < C) {
-            s_idx[0] = blockIdx.y;
-            s_cw[0] = CW(w, blockIdx.y);
-            s_ctgB[0] = a_ctgB[blockIdx.y];
+        } else if (cand_plane < C) {
+            s_idx[0] = cand_plane;
+            s_cw[0] = CW(w, cand_plane);
+            s_ctgB[0] = a_ctgB[cand_plane];
             nc = 1;
         }
         s_nc = nc;
