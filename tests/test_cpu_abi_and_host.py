@@ -60,6 +60,24 @@ def test_rippe_fit_matches_reference_host_functions():
     assert np.allclose(y, g["y_est"], rtol=1e-8, atol=0)
 
 
+def test_draw_unit_under_address_and_ub_sanitizers(tmp_path):
+    """csrc/ig_draw.cpp is the one host-only translation unit of the library (the candidate draw on numpy's generator
+    stream): built here with g++ -fsanitize=address,undefined together with tests/sanitize/draw_harness.cpp (random jump
+    distributions incl. empty and short rows, zero weights, blacklisted bins; invariants of every draw; the error paths) and
+    run.  GPU AddressSanitizer is not available on the target pool: this is where the sanitizers can run."""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "draw_asan")
+    src = [os.path.join(ROOT, "instagraal_amd", "csrc", "ig_draw.cpp"), os.path.join(ROOT, "tests", "sanitize", "draw_harness.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-fno-omit-frame-pointer"] + src + ["-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "draw harness ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_root_finding_fast_path_is_fsolve():
     """estimate_max_dist_intra_nuis is solved twice per nuisance step on the host's critical path: ``_solve`` reaches MINPACK's
     hybrd without fsolve's Python layers.  Same routine, same arguments, same residual: the very same root, bit for bit, as
