@@ -312,8 +312,11 @@ struct ig_ctx {
         long long n;
         long long seen; /* launches since the timers were reset (timing_every) */
     } timers[12];
+    std::vector<hipEvent_t> ev_pool; /* recycled timer events */
     long long n_batches, n_batch_committed, n_batch_pending, n_batch_predicted;
     int up_moves, up_max_c; /* the uploaded move lists */
+    void* h_stage;          /* pinned staging of lists and result records (ensure_io) */
+    size_t h_stage_bytes;
     int own_begin, own_end; /* slots whose candidate genomes this handle built for the batch in flight */
     int own_screened;       /* the batch in flight was scored in two tiers (1), or verified (2) */
     int max_L, max_SL;      /* host copies of Glob.max_L / max_SL as of the last synchronisation */

@@ -70,9 +70,16 @@ struct TimedLaunch {
         if (c->timing && !((c->timing_mask >> id) & 1u)) return;
         /* every timing_every-th launch only: an event record between two kernels of a stream costs ~6 us of idle queue */
         if (c->timing && c->timing_every > 1 && (c->timers[id].seen++ % c->timing_every) != 0) return;
-        if (c->timing) {
-            hipEventCreate(&a);
-            hipEventCreate(&b);
+        if (c->timing) { /* events are recycled (drain_timers): creating a pair costs microseconds the timed call should not pay */
+            if (c->ev_pool.size() >= 2) {
+                a = c->ev_pool.back();
+                c->ev_pool.pop_back();
+                b = c->ev_pool.back();
+                c->ev_pool.pop_back();
+            } else {
+                hipEventCreate(&a);
+                hipEventCreate(&b);
+            }
             hipEventRecord(a, c->stream);
         }
     }
@@ -94,8 +101,8 @@ static void drain_timers(ig_ctx* c)
                 c->timers[i].total_ms += ms;
                 c->timers[i].n++;
             }
-            hipEventDestroy(pr.first);
-            hipEventDestroy(pr.second);
+            c->ev_pool.push_back(pr.first);
+            c->ev_pool.push_back(pr.second);
         }
         c->timers[i].ev.clear();
     }
@@ -282,6 +289,8 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipEventDestroy(c->ev_gathered);
     hipEventDestroy(c->ev_main);
     if (c->host_nuis) hipHostFree(c->host_nuis);
+    if (c->h_stage) hipHostFree(c->h_stage);
+    for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
     hipFree(c->scratch_accept);
     hipFree(c->scratch_nuis);
     hipEventDestroy(c->ev_slice);
@@ -1032,6 +1041,17 @@ extern "C" int ig_full_likelihood(ig_ctx* c, int which, int use_prev, double* nz
 
 static int ensure_io(ig_ctx* c, int n_moves, int max_c)
 {
+    /* pinned staging of the lists and the result records: copies from / to the caller's pageable arrays block the host for
+     * 10-20 us each, which is a tenth of a call of one batch */
+    const size_t need = (size_t)n_moves * (sizeof(int) + (size_t)IG_MAX_CANDIDATES * sizeof(int) + sizeof(ig_move_result));
+    if (c->h_stage_bytes < need) {
+        if (c->h_stage) hipHostFree(c->h_stage);
+        c->h_stage = nullptr;
+        c->h_stage_bytes = 0;
+        const size_t want = std::max(need, (size_t)1 << 16);
+        if (hipHostMalloc((void**)&c->h_stage, want, hipHostMallocDefault) == hipSuccess) c->h_stage_bytes = want;
+        else (void)hipGetLastError(); /* no pinned memory: the copies go through the caller's arrays */
+    }
     if (c->results_cap < n_moves) {
         hipFree(c->d_results);
         hipFree(c->d_frags);
@@ -1388,11 +1408,18 @@ static int upload_moves(ig_ctx* c, int n_moves, const int32_t* frags, const int3
 
 static int download_results(ig_ctx* c, int n_moves, ig_move_result* results)
 {
-    HIPCK(hipMemcpyAsync(results, c->d_results, (size_t)n_moves * sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
+    const size_t bytes = (size_t)n_moves * sizeof(ig_move_result);
+    ig_move_result* stage = (c->h_stage && c->h_stage_bytes >= bytes) ? (ig_move_result*)c->h_stage : nullptr;
+    HIPCK(hipMemcpyAsync(stage ? stage : results, c->d_results, bytes, hipMemcpyDeviceToHost, c->stream));
     if (queue_max_readback(c)) return -1;
     HIPCK(hipStreamSynchronize(c->stream));
+    if (stage) memcpy(results, stage, bytes);
     HIPCK(hipGetLastError());
-    drain_timers(c);
+    {
+        size_t pending = 0; /* timer events are read when the times are asked for (ig_kernel_time_ms), not inside every call */
+        for (int i = 0; i < T_COUNT; i++) pending += c->timers[i].ev.size();
+        if (pending > 4096) drain_timers(c);
+    }
     take_max_readback(c);
     c->full_windows = false;
     for (int i = 0; i < n_moves; i++)
@@ -1490,21 +1517,36 @@ extern "C" int ig_step_batch_draw(ig_ctx* c, ig_neighbours* nb, uint32_t* mt_key
     c->full_windows = (Wmax == 1 && n_moves > 1);
     if (ensure_move_buffers(c, std::max(8, (int)max_c), Wmax)) return -1;
     if (ensure_io(c, n_moves, max_c)) return -1;
-    HIPCK(hipMemcpyAsync(c->d_frags, frags, (size_t)n_moves * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    /* the lists go to the device from pinned staging (layout of h_stage: result records, fragments, candidates) */
+    int* st_frags = nullptr;
+    int* st_cands = nullptr;
+    if (c->h_stage) {
+        st_frags = (int*)((char*)c->h_stage + (size_t)n_moves * sizeof(ig_move_result));
+        st_cands = st_frags + n_moves;
+        memcpy(st_frags, frags, (size_t)n_moves * sizeof(int));
+    }
+    HIPCK(hipMemcpyAsync(c->d_frags, st_frags ? st_frags : frags, (size_t)n_moves * sizeof(int), hipMemcpyHostToDevice, c->stream));
     c->up_moves = n_moves;
     c->up_max_c = max_c;
     std::atomic<int> drawn(0), draw_rc(0);
-    std::thread drawer([&]() {
-        const int chunk = 32;
-        for (int i = 0; i < n_moves; i += chunk) {
-            const int n = std::min(chunk, n_moves - i);
-            if (ig_neighbours_draw(nb, mt_key624, mt_pos, frags + i, n, max_c, cands_out + (size_t)i * max_c)) {
-                draw_rc.store(-1, std::memory_order_release);
-                return;
+    /* the lists of the first moves are drawn here (a call of one batch -- the usual benchmark call is 20 moves -- then needs
+     * no thread at all: creating and joining one costs as much as drawing 30 lists), the rest on a thread, ahead of the launches */
+    const int chunk = 32;
+    const int inline_n = std::min(n_moves, chunk);
+    if (ig_neighbours_draw(nb, mt_key624, mt_pos, frags, inline_n, max_c, cands_out)) return fail("candidate draw failed (fragment out of the distributions' range)");
+    drawn.store(inline_n, std::memory_order_release);
+    std::thread drawer;
+    if (n_moves > inline_n)
+        drawer = std::thread([&]() {
+            for (int i = inline_n; i < n_moves; i += chunk) {
+                const int n = std::min(chunk, n_moves - i);
+                if (ig_neighbours_draw(nb, mt_key624, mt_pos, frags + i, n, max_c, cands_out + (size_t)i * max_c)) {
+                    draw_rc.store(-1, std::memory_order_release);
+                    return;
+                }
+                drawn.store(i + n, std::memory_order_release);
             }
-            drawn.store(i + n, std::memory_order_release);
-        }
-    });
+        });
     int uploaded = 0;
     int rc = run_moves(c, n_moves, max_c, Wmax, [&](int first, int count) -> int {
         int have;
@@ -1516,12 +1558,18 @@ extern "C" int ig_step_batch_draw(ig_ctx* c, ig_neighbours* nb, uint32_t* mt_key
                 while (C < max_c && cands_out[(size_t)i * max_c + C] >= 0) C++;
                 if (validate_move(c, frags[i], cands_out + (size_t)i * max_c, C)) return -1;
             }
-            HIPCK(hipMemcpyAsync(c->d_cands + (size_t)uploaded * max_c, cands_out + (size_t)uploaded * max_c,
-                                 (size_t)(have - uploaded) * max_c * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            const int* src = cands_out + (size_t)uploaded * max_c;
+            if (st_cands) {
+                memcpy(st_cands + (size_t)uploaded * max_c, src, (size_t)(have - uploaded) * max_c * sizeof(int));
+                src = st_cands + (size_t)uploaded * max_c;
+            }
+            HIPCK(hipMemcpyAsync(c->d_cands + (size_t)uploaded * max_c, src, (size_t)(have - uploaded) * max_c * sizeof(int),
+                                 hipMemcpyHostToDevice, c->stream));
             uploaded = have;
         }
         return 0;
     });
+    if (drawer.joinable())
     drawer.join(); /* the generator state the caller puts back is the one after ALL draws, also on an error */
     if (rc) return -1;
     if (draw_rc.load()) return fail("candidate draw failed");
@@ -2188,6 +2236,11 @@ extern "C" int ig_reset_timers(ig_ctx* c, int enable)
     }
     c->timing = enable != 0;
     c->timing_mask = enable > 1 ? (unsigned)(enable >> 1) : 0xffffu; /* enable = 1 | (mask << 1) */
+    while (enable && c->ev_pool.size() < 16) { /* the first timed launches find their events ready */
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) break;
+        c->ev_pool.push_back(e);
+    }
     for (int i = 0; i < T_COUNT; i++) c->timers[i].seen = 0;
     return 0;
 }
