@@ -3,12 +3,17 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one move = one complete ``step_sampler`` call (CL:1401-1465): the candidate draw (return_neighbours,
-CL:3103-3141, on numpy's generator stream), one focal bin, <= 5 partner bins, up to 5 x 24 candidate genomes scored, argmax
-applied.  Workload at N=1: BASELINE.json configs[2] (synthetic 50 k bins / 50 M contacts, the configuration the metric is
+A "step" is one pass of the path over one BATCH of moves: ``--moves-per-step`` (default 24, the speculative batch width
+the library scores per launch of its kernels) consecutive ``step_sampler`` calls (CL:1401-1465), each one the candidate
+draw (return_neighbours, CL:3103-3141, on numpy's generator stream), one focal bin, <= 5 partner bins, up to 5 x 24
+candidate genomes scored, argmax applied.  ``value`` is MOVES per second (BASELINE.json's metric) = K x moves-per-step /
+elapsed; ``ms_per_step`` is per batch; ``config.moves_timed`` says how many moves the timed region held.  (Rounds 1 and
+early 2 counted one move as a step, so the driver's ``--steps 20`` timed ONE launch of 20 moves, 0.7 ms: a sample of
+the call overhead, not of the path.)  Workload at N=1: BASELINE.json configs[2] (synthetic 50 k bins / 50 M contacts, the configuration the metric is
 quoted on).  The problem (contacts, genome state, jump distributions) is resident before the timed region; the timed
-region covers K consecutive moves END TO END: draw of the candidate lists (host thread, ahead of the launches), their
-H2D, every kernel, the D2H of the K result records.  ``ig_step_batch_draw`` scores the moves W at a time against one
+region covers the K x moves-per-step consecutive moves END TO END, issued as ONE ``step_sampler_batch`` call (the way
+``full_em`` issues a cycle): draw of the candidate lists (host thread, ahead of the launches), their
+H2D, every kernel, the D2H of the result records.  ``ig_step_batch_draw`` scores the moves W at a time against one
 state and commits them in order on the device ("speculative batches": results identical to K single calls,
 tests/test_hip_sampler.py), so one launch of the dominant kernel covers several moves.
 
@@ -122,8 +127,9 @@ def spawn_workers(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=84, help="timed batches of --moves-per-step moves")
+    ap.add_argument("--warmup", type=int, default=8, help="untimed batches before them")
+    ap.add_argument("--moves-per-step", type=int, default=24, help="moves (step_sampler calls) per step")
     ap.add_argument("--config", default="cfg3", help="synthetic shape: cfg2 | cfg3 | cfg5 | small | tiny")
     ap.add_argument("--neighbours", type=int, default=5)
     ap.add_argument("--seed", type=int, default=0)
@@ -183,7 +189,9 @@ def main():
 
     # trajectory: a shuffled cycle prefix; the candidate lists are drawn INSIDE the timed region, as step_sampler does
     np.random.seed(a.seed)
-    n_total = a.warmup + a.steps
+    mps = max(1, a.moves_per_step)
+    n_warm, n_moves = a.warmup * mps, a.steps * mps
+    n_total = n_warm + n_moves
     order = np.arange(prob.n_frags)
     np.random.shuffle(order)
     frags = np.resize(order, n_total).astype(np.int32)
@@ -202,8 +210,8 @@ def main():
         cands = s.draw_candidates(fr, a.neighbours)  # every rank draws the same lists from the same generator state
         return runner.run(fr, cands), cands
 
-    if a.warmup:
-        run(frags[: a.warmup])
+    if n_warm:
+        run(frags[:n_warm])
     # hipEvent pairs around the two scoring kernels (k_screen, k_score_list) on the library's stream, every 4th launch: an event
     # record between two kernels of a stream costs ~6 us of idle queue, four of them per batch were 4 % of the timed region
     s.ctx.set_timer_sampling(4)
@@ -213,7 +221,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res, cands = run(frags[a.warmup:])
+    res, cands = run(frags[n_warm:])
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -239,8 +247,8 @@ def main():
     # the draw alone, for the record (it ran on a host thread next to the launches above)
     st = np.random.get_state()
     t0 = time.perf_counter()
-    s.draw_candidates(frags[a.warmup:], a.neighbours)
-    draw_us = 1e6 * (time.perf_counter() - t0) / a.steps
+    s.draw_candidates(frags[n_warm:], a.neighbours)
+    draw_us = 1e6 * (time.perf_counter() - t0) / n_moves
     np.random.set_state(st)
 
     # self-check: the incrementally maintained exact likelihood equals a from-scratch recomputation
@@ -287,7 +295,7 @@ def main():
             traffic = valu_busy = traffic_src = None
         out = {
             "metric": "MCMC moves/s (accepted+rejected) at fixed n_frags x nnz",
-            "value": a.steps / elapsed,
+            "value": n_moves / elapsed,
             "unit": "moves/s",
             "n_gpus": dist.get_world_size() if dist is not None else 1,
             "steps": a.steps,
@@ -300,17 +308,19 @@ def main():
             "data": "synthetic",
             "config": {"workload": "synthetic Hi-C %s (%d sub-frags), level 4, %d neighbours, nuisance sampling off" % (
                 prob_name(prob), prob.n_sub_frags, a.neighbours), "name": a.config, "seed": a.seed,
+                "step": "one batch of %d moves (step_sampler calls)" % mps, "moves_per_step": mps, "moves_timed": n_moves,
+                "moves_warmup": n_warm,
                 "parallelism": "1 GPU" if world == 1 else (
                     "batch slots split over %d ranks, all-gather of score records" % world if a.runner == "batch" else
                     "contact rows split over %d ranks, all-reduce of exact partial sums per move" % world),
                 "timed_region": "candidate draw (host thread) + H2D + kernels + D2H of the result records",
                 "draw_us_per_move_alone": draw_us,
-                "candidates_scored_per_s": float(res["n_candidates"].sum()) * 24 / elapsed,
-                "term_evals_per_move": float(res["n_evals"].mean()), "moves_per_launch": a.steps / n_launch,
+                "candidates_scored_per_s": float(res["n_candidates"].sum()) * 24 / elapsed,  # 24 mutations per candidate
+                "term_evals_per_move": float(res["n_evals"].mean()), "moves_per_launch": n_moves / n_launch,
                 "batches": bstats, "maintained_likelihood_exact": exact_ok,
                 "nuisance_on": nuis,
                 "nuisance_on_moves_per_s": None if nuis is None else nuis.get("moves_per_s"),
-                "reference_equivalent_GBps": b_ref * (a.steps / elapsed) / 1e9,
+                "reference_equivalent_GBps": b_ref * (n_moves / elapsed) / 1e9,
                 "B_ref_bytes_per_move": b_ref},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": traffic_src, "valu_busy_profiled": valu_busy, "kernel": dom_name,
@@ -327,7 +337,7 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(prob, frags[a.warmup:], cands, a.cpu_budget)
+                out["cpu_baseline"] = cpu_baseline(prob, frags[n_warm:], cands, a.cpu_budget)
             except Exception as e:  # the baseline is a report, never the product path
                 out["cpu_baseline"] = {"value": None, "unit": "moves/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)

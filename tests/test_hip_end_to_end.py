@@ -125,7 +125,7 @@ def test_bench_starts_its_own_ranks(runner):
     env = dict(os.environ, IG_BENCH_ONE_DEVICE="1")
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "small", "--steps", "60", "--warmup", "20",
-           "--no-cpu-baseline", "--nuisance-moves", "0", "--runner", runner]
+           "--moves-per-step", "1", "--no-cpu-baseline", "--nuisance-moves", "0", "--runner", runner]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -150,6 +150,6 @@ def test_bench_refuses_ranks_without_devices():
     env.pop("WORLD_SIZE", None)
     env.pop("IG_BENCH_ONE_DEVICE", None)
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--config", "tiny", "--steps", "5", "--warmup", "0",
-                        "--no-cpu-baseline", "--nuisance-moves", "0"], env=env, capture_output=True, text=True, timeout=300)
+                        "--moves-per-step", "1", "--no-cpu-baseline", "--nuisance-moves", "0"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

@@ -24,7 +24,7 @@ for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "%s_pmc_pass*.json" %
                     e[c] = v["avg"]
                     e.setdefault("launches", v["launches"])
 out = {"command": "tools/profile_round.sh %s: rocprofv3 --pmc <one group per pass> -- python3 bench.py --no-cpu-baseline --nuisance-moves 0 "
-                  "--steps 300 --warmup 50 (cfg3, one MI355X, W = 24 moves per launch)" % tag,
+                  "--steps 12 --warmup 2 (12 batches of 24 moves; cfg3, one MI355X, W = 24 moves per launch)" % tag,
        "note": "FETCH_SIZE / WRITE_SIZE are KB per dispatch (separate passes). traffic_bytes_per_launch = 2 x FETCH_SIZE (gfx950 "
                "correction of MI355X_MICROARCH.md, calibrated in round 1 on k_full_nz) + WRITE_SIZE.  Instruction counts are per "
                "dispatch and per counter instance as rocprofv3 reports them."}
