@@ -338,6 +338,7 @@ __global__ void __launch_bounds__(64)
         const double n_tot_pxl = g->n_tot_pxl;
         int n_dirty = 0, committed = w_start, pending = -1, n_cand = 0, n_predicted = 0, stop_overflow = 0;
         int max_L = g->max_L, max_SL = g->max_SL;
+        const float n_frags_f = (float)g->N; /* not inside the loop: a load there waits for the prefetches issued before it */
         if (w_start > 0) {
             n_dirty = dirty_buf[0];
 #pragma unroll
@@ -354,9 +355,9 @@ __global__ void __launch_bounds__(64)
                 n_dirty += 2;
             }
         }
-        /* Everything a decision reads is loaded TWO MOVES AHEAD (none of it depends on earlier decisions, only its
+        /* Everything a decision reads is loaded THREE MOVES AHEAD (none of it depends on earlier decisions, only its
          * interpretation does): while move w is decided from registers with wave shuffles only, the loads of moves
-         * w + 1 and w + 2 are in flight.  Moves with more than 5 candidates (> 2 score records per lane) take the unpipelined path. */
+         * w + 1 .. w + 3 are in flight.  Moves with more than 5 candidates (> 2 score records per lane) take the unpipelined path. */
         struct MoveData {
             int C, superset0;       /* uniform */
             CandPre cand;           /* lane c < C: candidate c */
@@ -371,25 +372,19 @@ __global__ void __launch_bounds__(64)
             MoveData d;
             d.C = __builtin_amdgcn_readlane(all_C, w);
             d.superset0 = __builtin_amdgcn_readlane(all_sup, w);
+            /* NOTHING here may touch a loaded value or load under a condition: either makes the wave wait for the data at
+             * once (lanes past the end load a valid entry instead and are never read: every use below is under c < C or
+             * i < C * IG_N_TMP_STRUCT) */
             d.cand = cpre_at(mb, CW(w, lane < d.C ? lane : 0));
-            if (lane >= d.C) {
-                d.cand.ctgA = d.cand.ctgB = -1;
-                d.cand.m_loc = 0;
-            }
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const int i = lane + 64 * j;
-                d.rec[j].k = 0;
-                d.e_ext_d[j] = 0.0;
-                d.e_r[j] = d.e_base[j] = 0;
-                if (i < d.C * IG_N_TMP_STRUCT) {
-                    const int cw = CW(w, i / IG_N_TMP_STRUCT);
-                    d.rec[j] = pre_at(mb, cw, i % IG_N_TMP_STRUCT);
-                    const CandPre& cp = cpre_at(mb, cw);
-                    d.e_ext_d[j] = cp.ext_d;
-                    d.e_r[j] = cp.r;
-                    d.e_base[j] = cp.base_cnt;
-                }
+                const int i = max(min(lane + 64 * j, d.C * IG_N_TMP_STRUCT - 1), 0);
+                const int cw = CW(w, i / IG_N_TMP_STRUCT);
+                d.rec[j] = pre_at(mb, cw, i % IG_N_TMP_STRUCT);
+                const CandPre& cp = cpre_at(mb, cw);
+                d.e_ext_d[j] = cp.ext_d;
+                d.e_r[j] = cp.r;
+                d.e_base[j] = cp.base_cnt;
             }
             return d;
         };
@@ -399,13 +394,8 @@ __global__ void __launch_bounds__(64)
             return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
         };
         auto rld = [&](double v, int src) { return __longlong_as_double(rl64(__double_as_longlong(v), src)); };
-        /* two moves ahead: a decision takes about half a global-memory round trip */
-        MoveData cur = load_move(w_start < W ? w_start : W - 1);
-        MoveData nxt = load_move(w_start + 1 < W ? w_start + 1 : W - 1);
-        for (int w = w_start; w < W; w++) {
-            const MoveData d = cur;
-            cur = nxt;
-            if (w + 2 < W) nxt = load_move(w + 2);
+        /* one decision: false = the batch stops before (conflict, pool) or at (pending) move w */
+        auto decide_one = [&](const int w, const MoveData& d) -> bool {
             const int C = d.C;
             /* conflict with an earlier move of this batch?  slice pool overflow? */
             bool hitd = false;
@@ -416,7 +406,7 @@ __global__ void __launch_bounds__(64)
             }
             if (err0 || rl(d.cand.overflow, 0) || __any(hitd)) {
                 stop_overflow = err0 ? 0 : rl(d.cand.overflow, 0); /* 1: the slice pool, 2: the exact kernel's grid */
-                break;
+                return false;
             }
             n_cand += C;
             /* scores (eval_all_likelihood_on_zero_2nd KA:4005-4027, eval_all_scores KA:4029-4046) with the live scalars */
@@ -496,13 +486,21 @@ __global__ void __launch_bounds__(64)
                 br.k = rl(mine.k, owner);
                 br.info = (unsigned)rl((int)mine.info, owner);
                 bests = rld((bj == 0) ? sc[0] : sc[1], owner);
-            } else {
-                br = pre_at(mb, CW(w, bc), bslot);
+            } else { /* through readlane as well: a load still pending at the join would make every move wait for all prefetches */
+                const SlotPre ld = pre_at(mb, CW(w, bc), bslot);
+                br.nz_hi = rl64(ld.nz_hi, 0);
+                br.nz_lo = rl64(ld.nz_lo, 0);
+                br.dz_hi = rl64(ld.dz_hi, 0);
+                br.dz_lo = rl64(ld.dz_lo, 0);
+                br.dni = rl64(ld.dni, 0);
+                br.k = rl(ld.k, 0);
+                br.info = (unsigned)rl((int)ld.info, 0);
                 double sv = 0.0;
 #pragma unroll
                 for (int j = 2; j < NJ; j++) sv = (bj == j) ? sc[j] : sv;
                 bests = rld(sv, owner);
             }
+            if (n == 0) br.k = 0; /* a move without candidates: nothing was scored (error 3 below) */
             const int b_sw = rl(d.cand.same_windowed, bc), b_B = rl(d.cand.B, bc), b_nloc = rl(d.cand.n_loc, bc);
             const int windowed = (b_sw >> 1) & 1, b_same = b_sw & 1;
             const int b_cA = rl(d.cand.ctgA, bc), b_cB = rl(d.cand.ctgB, bc);
@@ -546,7 +544,7 @@ __global__ void __launch_bounds__(64)
             }
             if (is_pending) { /* needs k_delta: hand this move to the one-move tail */
                 pending = w;
-                break;
+                return false;
             }
             /* commit: scalars (exact), stale-flag state (quirk Q4), fresh ids */
             if (have_delta) {
@@ -576,7 +574,7 @@ __global__ void __launch_bounds__(64)
                 ig_move_result r;
                 r.o = bests;
                 r.dist = 0.0; /* step 2 */
-                r.mean_len = (double)((float)g->N / (float)n_contigs);
+                r.mean_len = (double)(n_frags_f / (float)n_contigs);
                 r.op_sampled = bslot;
                 r.id_f_sampled = b_B;
                 r.n_contigs = n_contigs;
@@ -597,6 +595,19 @@ __global__ void __launch_bounds__(64)
                 n_dirty += 2;
             }
             committed = w + 1;
+            return true;
+        };
+        /* three moves in flight, each in its OWN registers (a rotation `cur = nxt` made the compiler wait for every
+         * outstanding load at the top of each iteration: one memory round trip per decision) */
+        auto clampw = [&](int w) { return w < W ? w : W - 1; };
+        MoveData d0 = load_move(clampw(w_start)), d1 = load_move(clampw(w_start + 1)), d2 = load_move(clampw(w_start + 2));
+        for (int w = w_start; w < W; w += 3) {
+            if (!decide_one(w, d0)) break;
+            d0 = load_move(clampw(w + 3));
+            if (w + 1 >= W || !decide_one(w + 1, d1)) break;
+            d1 = load_move(clampw(w + 4));
+            if (w + 2 >= W || !decide_one(w + 2, d2)) break;
+            d2 = load_move(clampw(w + 5));
         }
 #pragma unroll
         for (int j = 0; j < ND; j++)
