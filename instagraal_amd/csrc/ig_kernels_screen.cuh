@@ -172,7 +172,10 @@ __device__ __forceinline__ void screen_pair(unsigned long long pk0, unsigned lon
     const uint2 a0 = *(const uint2*)(colb + ((lo0 << 3) & 0x7ffff8u)), b0 = *(const uint2*)(colb + (__builtin_amdgcn_alignbit(hi0, lo0, 17) & 0x7ffff8u));
     const uint2 a1 = *(const uint2*)(colb + ((lo1 << 3) & 0x7ffff8u)), b1 = *(const uint2*)(colb + (__builtin_amdgcn_alignbit(hi1, lo1, 17) & 0x7ffff8u));
     const unsigned d0 = abs_diff_u32(a0.y, b0.y), d1 = abs_diff_u32(a1.y, b1.y); /* 4 x rank distance, or >= 2^28 - 2^22 across contigs */
-    const f32x2 sv = f32x2{__uint_as_float(a0.x), __uint_as_float(a1.x)} - f32x2{__uint_as_float(b0.x), __uint_as_float(b1.x)};
+    /* two scalar subtractions: a packed one needs {a0.x, a1.x} in a register pair, i.e. two v_mov per v_pk_add */
+    f32x2 sv;
+    __asm__("v_sub_f32 %0, %1, %2" : "=v"(sv.x) : "v"(__uint_as_float(a0.x)), "v"(__uint_as_float(b0.x)));
+    __asm__("v_sub_f32 %0, %1, %2" : "=v"(sv.y) : "v"(__uint_as_float(a1.x)), "v"(__uint_as_float(b1.x)));
     const bool in0 = (d0 < (1u << 27)) && (sv.x != 0.0f) && (fabsf(sv.x) < d_max);
     const bool in1 = (d1 < (1u << 27)) && (sv.y != 0.0f) && (fabsf(sv.y) < d_max);
     const char* pzb = (const char*)L.pzc;
@@ -187,7 +190,9 @@ __device__ __forceinline__ void screen_pair(unsigned long long pk0, unsigned lon
     const f32x2 obf = {(float)(hi0 >> 8), (float)(hi1 >> 8)};
     const f32x2 m = obf * yy;
     const f32x2 t = __builtin_elementwise_fma(m, f32x2{c10, c10}, -ex) + pzc;
-    acc += (double)(t.x + t.y);
+    float tsum;
+    __asm__("v_add_f32 %0, %1, %2" : "=v"(tsum) : "v"(t.x), "v"(t.y));
+    acc += (double)tsum;
     exs2 += ex;
     obs2 += obf;
     __asm__("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(ymax) : "v"(yy.x), "v"(yy.y));
@@ -373,7 +378,9 @@ __device__ __forceinline__ void screen_pair_col(unsigned oi0, unsigned oj0, unsi
     const uint2 a0 = *(const uint2*)(colb + oi0), b0 = *(const uint2*)(colb + oj0);
     const uint2 a1 = *(const uint2*)(colb + oi1), b1 = *(const uint2*)(colb + oj1);
     const unsigned d0 = abs_diff_u32(a0.y, b0.y), d1 = abs_diff_u32(a1.y, b1.y);
-    const f32x2 sv = f32x2{__uint_as_float(a0.x), __uint_as_float(a1.x)} - f32x2{__uint_as_float(b0.x), __uint_as_float(b1.x)};
+    f32x2 sv; /* scalar subtractions, see screen_pair */
+    __asm__("v_sub_f32 %0, %1, %2" : "=v"(sv.x) : "v"(__uint_as_float(a0.x)), "v"(__uint_as_float(b0.x)));
+    __asm__("v_sub_f32 %0, %1, %2" : "=v"(sv.y) : "v"(__uint_as_float(a1.x)), "v"(__uint_as_float(b1.x)));
     const bool in0 = (d0 < (1u << 27)) && (sv.x != 0.0f) && (fabsf(sv.x) < d_max);
     const bool in1 = (d1 < (1u << 27)) && (sv.y != 0.0f) && (fabsf(sv.y) < d_max);
     const f32x2 pzc = {*(const float*)(pzb + min(d0, 4u * LDS_PZ)), *(const float*)(pzb + min(d1, 4u * LDS_PZ))};
@@ -386,7 +393,9 @@ __device__ __forceinline__ void screen_pair_col(unsigned oi0, unsigned oj0, unsi
     const f32x2 ex = {__builtin_amdgcn_exp2f(yy.x), __builtin_amdgcn_exp2f(yy.y)};
     const f32x2 m = obf * yy;
     const f32x2 t = __builtin_elementwise_fma(m, f32x2{c10, c10}, -ex) + pzc;
-    acc += (double)(t.x + t.y);
+    float tsum; /* (kept scalar: the vectoriser pairs it with the other column's sum through three v_mov) */
+    __asm__("v_add_f32 %0, %1, %2" : "=v"(tsum) : "v"(t.x), "v"(t.y));
+    acc += (double)tsum;
     exs2 += ex;
     __asm__("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(ymax) : "v"(yy.x), "v"(yy.y));
 }
@@ -477,19 +486,17 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
     unsigned s0 = wave * step;
     const unsigned nn = (unsigned)n;
     for (; s0 + step <= nn; s0 += stride) { /* full steps: both columns from one pass over the entries */
-        unsigned long long pk[SCREEN_BATCH];
-#pragma unroll
-        for (int u = 0; u < SCREEN_BATCH; u++) pk[u] = nx[u];
         ptr += stride;
 #pragma unroll
-        for (int u = 0; u < SCREEN_BATCH; u++) nx[u] = ptr[u * 64];
-#pragma unroll
         for (int u = 0; u < SCREEN_BATCH; u += 2) {
-            const unsigned lo0 = (unsigned)pk[u], hi0 = (unsigned)(pk[u] >> 32), lo1 = (unsigned)pk[u + 1], hi1 = (unsigned)(pk[u + 1] >> 32);
+            const unsigned lo0 = (unsigned)nx[u], hi0 = (unsigned)(nx[u] >> 32), lo1 = (unsigned)nx[u + 1], hi1 = (unsigned)(nx[u + 1] >> 32);
             bad |= hi0 | hi1;
             const unsigned oi0 = (lo0 << 3) & 0x7ffff8u, oj0 = __builtin_amdgcn_alignbit(hi0, lo0, 17) & 0x7ffff8u;
             const unsigned oi1 = (lo1 << 3) & 0x7ffff8u, oj1 = __builtin_amdgcn_alignbit(hi1, lo1, 17) & 0x7ffff8u;
             const f32x2 obf = {(float)(hi0 >> 8), (float)(hi1 >> 8)};
+            /* unpacked: the next step's entries straight into the same registers (no copy of the look-ahead) */
+            nx[u] = ptr[u * 64];
+            nx[u + 1] = ptr[(u + 1) * 64];
             obs2 += obf;
             screen_pair_col(oi0, oj0, oi1, oj1, obf, colA, pzb, slope, la, lv, d_max, c10, accA, exsA, ymaxA);
             screen_pair_col(oi0, oj0, oi1, oj1, obf, colBb, pzb, slope, la, lv, d_max, c10, accB, exsB, ymaxB);
