@@ -10,6 +10,7 @@ import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 tag = sys.argv[1]
+cfg = os.environ.get("CONFIG", "cfg3")  # the shape tools/profile_round.sh was run with
 outdir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
 KERNELS = {"k_screen": ("_Z13k_screen_tail", "_Z8k_screen"), "k_score_list": "_Z12k_score_list", "k_slice": "_Z7k_slice", "k_tail": "_Z6k_tail",
            "k_full_nz_tiled": "_Z15k_full_nz_tiled", "k_decide_batch": "_Z14k_decide_batch", "k_mutate": "_Z8k_mutate"}
@@ -24,7 +25,7 @@ for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "%s_pmc_pass*.json" %
                     e[c] = v["avg"]
                     e.setdefault("launches", v["launches"])
 out = {"command": "tools/profile_round.sh %s: rocprofv3 --pmc <one group per pass> -- python3 bench.py --no-cpu-baseline --nuisance-moves 0 "
-                  "--steps 12 --warmup 2 (12 batches of 24 moves; cfg3, one MI355X, W = 24 moves per launch)" % tag,
+                  "--config %s --steps 12 --warmup 2 (12 batches of 24 moves; one MI355X, W = 24 moves per launch)" % (tag, cfg),
        "note": "FETCH_SIZE / WRITE_SIZE are KB per dispatch (separate passes). traffic_bytes_per_launch = 2 x FETCH_SIZE (gfx950 "
                "correction of MI355X_MICROARCH.md, calibrated in round 1 on k_full_nz) + WRITE_SIZE.  Instruction counts are per "
                "dispatch and per counter instance as rocprofv3 reports them."}
@@ -45,6 +46,6 @@ for short, e in merged.items():
         if k_in in e:
             r[k_out] = e[k_in]
     out[short] = r
-path = os.path.join(outdir, "%s_cfg3_pmc_traffic.json" % tag)
+path = os.path.join(outdir, "%s_%s_pmc_traffic.json" % (tag, cfg))
 json.dump(out, open(path, "w"), indent=1)
 print("wrote", path, {k: round(v.get("traffic_bytes_per_launch", 0) / 1e6, 1) for k, v in out.items() if isinstance(v, dict)})

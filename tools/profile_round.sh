@@ -2,18 +2,19 @@
 # Profiles of one round on the GPU box: kernel trace stats + PMC passes (separate runs), summaries into gpurun_out/.
 # usage: bash tools/profile_round.sh <tag>      (run through gpurun; copy gpurun_out/<tag>_* into profiles/)
 TAG=${1:-rXX}
+CFG=${CONFIG:-cfg3}   # CONFIG=cfg5 bash tools/profile_round.sh <tag>: the human-scale shape
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_kt
-timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_kt -o run -- python3 $R/bench.py --no-cpu-baseline --nuisance-moves 0 --steps 42 --warmup 4 > /tmp/kt.log 2>&1
-python3 $R/tools/rocprof_stats.py $(find /tmp/prof_kt -name "*.db" | head -1) $R/gpurun_out/${TAG}_cfg3_kernel_stats.csv \
-  "rocprofv3 --kernel-trace -- python3 bench.py --no-cpu-baseline --steps 42 --warmup 4 (cfg3, one MI355X); aggregated by tools/rocprof_stats.py"
+timeout 600 rocprofv3 --kernel-trace -d /tmp/prof_kt -o run -- python3 $R/bench.py --config $CFG --no-cpu-baseline --nuisance-moves 0 --steps 42 --warmup 4 > /tmp/kt.log 2>&1
+python3 $R/tools/rocprof_stats.py $(find /tmp/prof_kt -name "*.db" | head -1) $R/gpurun_out/${TAG}_${CFG}_kernel_stats.csv \
+  "rocprofv3 --kernel-trace -- python3 bench.py --config $CFG --no-cpu-baseline --steps 42 --warmup 4 (one MI355X); aggregated by tools/rocprof_stats.py"
 tail -1 /tmp/kt.log | cut -c1-400
 [ -n "$SKIP_PMC" ] && exit 0
 i=0
 for CT in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "VALUBusy VALUUtilization LdsUtil LdsBankConflict" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   rm -rf /tmp/pmc$i
-  timeout 300 rocprofv3 --pmc $CT -d /tmp/pmc$i -o run -- python3 $R/bench.py --no-cpu-baseline --nuisance-moves 0 --steps 12 --warmup 2 > /tmp/pmc$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $CT -d /tmp/pmc$i -o run -- python3 $R/bench.py --config $CFG --no-cpu-baseline --nuisance-moves 0 --steps 12 --warmup 2 > /tmp/pmc$i.log 2>&1
   python3 $R/tools/rocprof_pmc.py $(find /tmp/pmc$i -name "*.db" | head -1) $R/gpurun_out/${TAG}_pmc_pass$i.json | grep -i "score_list\|k_screen\|k_slice" | cut -c1-300
 done
