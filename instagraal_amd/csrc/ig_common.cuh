@@ -157,6 +157,7 @@ struct MoveBuf {
     /* a candidate's slice list is kept in SLICE_SEG segments (local row r -> segment r % SLICE_SEG): one append cursor
      * per segment instead of one per candidate (same-address atomics were k_slice's bottleneck), and workgroup x of
      * k_score_list streams exactly segment x */
+    unsigned* touched;  /* ig_ctx.touched_bits */
     long long* slbound; /* [..][SLICE_SEG] upper bound of a segment = contacts in its rows */
     long long* sloff;   /* [..][SLICE_SEG] start of the segment in the pool, -1 = does not fit (k_offsets) */
     long long pool_cap;
@@ -292,6 +293,9 @@ struct ig_ctx {
     int* d_cands;
     int cands_cap;
     int* prev_touched;
+    unsigned* touched_bits; /* 2 x one bit per sub-fragment: in a window of the batch being sliced (set by k_gather, read by k_slice; the
+                             * other half is cleared by the same k_gather for the next batch) */
+    int touched_flip;
     unsigned timing_mask;
     int timing_every; /* ig_set_timer_sampling */
     struct ScoreConst* score_const; /* tables and constants k_score_list stages (parameter set 0) */

@@ -328,6 +328,7 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipFree(c->d_results);
     hipFree(c->d_frags);
     hipFree(c->d_cands);
+    hipFree(c->touched_bits);
     hipFree(c->prev_touched);
     hipFree(c->pz_tab);
     hipFree(c->scratch8);
@@ -711,6 +712,9 @@ extern "C" int ig_upload_subfrag_table(ig_ctx* c, const float* xyzw, int32_t M)
     }
     hipFree(c->prev_touched);
     DALLOC(c->prev_touched, (size_t)M);
+    hipFree(c->touched_bits);
+    DALLOC(c->touched_bits, 2 * ((size_t)(M + 31) / 32 + 1));
+    HIPCK(hipMemset(c->touched_bits, 0, 2 * ((size_t)(M + 31) / 32 + 1) * sizeof(unsigned)));
     c->M = M;
     c->have_sub = true;
     return 0;
@@ -1108,10 +1112,13 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
     const int gN = std::max((N + 255) / 256, W);
     const PzTab pz{c->pz_tab, c->pz_n};
     if (phase == 0 || phase == 2) {
+        const int n_tw = (c->M + 31) / 32 + 1;
+        c->touched_flip ^= 1;
+        c->mb.touched = c->touched_bits + (size_t)c->touched_flip * n_tw;
         {
             TimedLaunch t(c, T_GATHER);
             hipLaunchKernelGGL(k_gather, dim3(gN), dim3(256), 0, c->stream, c->st, c->glob, c->mb, c->d_cands, c->d_frags, move0, W, max_c,
-                               c->tab, c->tab_prev, c->prev_touched, force_slot);
+                               c->tab, c->tab_prev, c->prev_touched, force_slot, c->touched_bits + (size_t)(c->touched_flip ^ 1) * n_tw, n_tw);
         }
         {
             TimedLaunch t(c, T_MUTATE);

@@ -38,8 +38,13 @@ __device__ inline int build_uniq(int* u, bool first, int LA, int LB, const int* 
  * superset list and the commit step selects the actual one. */
 __global__ void __launch_bounds__(256)
     k_gather(State st, Glob* g, MoveBuf mb, const int* __restrict__ cands_all, const int* __restrict__ frags_all, int move0, int W,
-             int max_c, Tables tab, Tables tab_prev, const int* __restrict__ prev_touched, int force_slot)
+             int max_c, Tables tab, Tables tab_prev, const int* __restrict__ prev_touched, int force_slot, unsigned* touched_next,
+             int n_touched_words)
 {
+    /* the sub-fragments of this batch's windows, one bit each (mb.touched: set below by the fragments that drop themselves into
+     * a window, read by k_slice in front of its gather of the partner's (contig, rank)); two bitmaps take turns: the one the
+     * NEXT batch sets is cleared here */
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_touched_words; i += gridDim.x * blockDim.x) touched_next[i] = 0u;
     /* tab_prev := coordinates before the LAST applied move (eval_likelihood_4_nuisance reads tables that
      * were filled before the move was applied, CL:1296-1344 / quirk Q12): catch up the entries that move touched */
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g->n_prev_touched; i += gridDim.x * blockDim.x) {
@@ -70,6 +75,8 @@ __global__ void __launch_bounds__(256)
     if (f < N) {
         const int cf = st.cid[f], pf = st.pos[f];
         const int lb = st.lb[f], sl = st.sl[f];
+        const int sf = st.sub_first[f]; /* (with the others: not a round trip of its own for the fragments that need it) */
+        bool in_window = false;
         for (int w = 0; w < W; w++) {
             const int cA = sh_cA[w], LA = sh_LA[w], C = sh_C[w];
             for (int c = 0; c < C; c++) {
@@ -82,7 +89,16 @@ __global__ void __launch_bounds__(256)
                     mb.Lloc[o] = f;
                     mb.lbloc[o] = lb;
                     mb.slloc[o] = sl;
+                    in_window = true;
                 }
+            }
+        }
+        if (in_window) { /* its sub-fragments (consecutive ids): one or two words */
+            for (int s0 = sf; s0 < sf + sl;) {
+                const int wd = s0 >> 5, hi = min(sf + sl, (wd + 1) << 5); /* [s0, hi) lies in word wd */
+                const unsigned bits = (hi - s0 >= 32) ? 0xffffffffu : (((1u << (hi - s0)) - 1u) << (s0 & 31));
+                atomicOr(&mb.touched[wd], bits);
+                s0 = hi;
             }
         }
     }
@@ -546,7 +562,10 @@ __global__ void __launch_bounds__(256, SLICE_MIN_WAVES) k_slice(const long long*
                     v[u] = (qi < e) ? cc[qi] : make_int2(-1, 0);
                 }
 #pragma unroll
-                for (int u = 0; u < SLICE_UNROLL; u++) cp2[u] = (v[u].x >= 0) ? tab.cp[v[u].x] : make_int2(-1, -1);
+                for (int u = 0; u < SLICE_UNROLL; u++) { /* a kept partner lies in a window of the batch: one bit (75 KB at 600 k sub-fragments) in front of the 8-byte gather */
+                    const bool hit = (v[u].x >= 0) && ((mb.touched[v[u].x >> 5] >> (v[u].x & 31)) & 1u);
+                    cp2[u] = hit ? tab.cp[v[u].x] : make_int2(-1, -1);
+                }
                 for (int k = 0; k < nc; k++) {
                     bool keep[SLICE_UNROLL];
                     unsigned long long mask[SLICE_UNROLL];
