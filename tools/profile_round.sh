@@ -14,6 +14,7 @@ tail -1 /tmp/kt.log | cut -c1-400
 i=0
 for CT in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "VALUBusy VALUUtilization LdsUtil LdsBankConflict" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
+  [ -n "$TRAFFIC_ONLY" ] && [ $i -gt 2 ] && [ $i -ne 4 ] && continue   # FETCH_SIZE, WRITE_SIZE, VALUBusy only
   rm -rf /tmp/pmc$i
   timeout 600 rocprofv3 --pmc $CT -d /tmp/pmc$i -o run -- python3 $R/bench.py --config $CFG --no-cpu-baseline --nuisance-moves 0 --steps 12 --warmup 2 > /tmp/pmc$i.log 2>&1
   python3 $R/tools/rocprof_pmc.py $(find /tmp/pmc$i -name "*.db" | head -1) $R/gpurun_out/${TAG}_pmc_pass$i.json | grep -i "score_list\|k_screen\|k_slice" | cut -c1-300
