@@ -148,6 +148,7 @@ struct MoveBuf {
     int* slloc;     /* [..][N] */
     int* subs;      /* [..][M] global sub-frag id of local sub index */
     int* rowcnt;    /* [..][M] sliced contacts per local row */
+    int4* rowbe;    /* [..][M] the local row's CSR range {begin lo, begin hi, length, global sub-frag id}: k_slice starts from it (one round trip instead of subs -> rowptr) */
     int* sl_li;     /* slice pool: candidate cw's list starts at slice_offset(w, c): local row index, */
     int* sl_lj;     /*           local column index, */
     int* sl_ob;     /*           observed count (order = arrival, sums are order-free) */

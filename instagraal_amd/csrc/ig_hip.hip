@@ -227,9 +227,11 @@ static void free_window_buffers(ig_ctx* c)
     hipFree(m.slloc);
     hipFree(m.subs);
     hipFree(m.rowcnt);
+    hipFree(m.rowbe);
     hipFree(m.coords);
     hipFree(m.loc);
     m.Lloc = m.lbloc = m.slloc = m.subs = m.rowcnt = nullptr;
+    m.rowbe = nullptr;
     m.coords = nullptr;
     m.loc = nullptr;
     m.sN = m.sM = 0;
@@ -449,6 +451,7 @@ static int ensure_window_buffers(ig_ctx* c)
     DALLOC(m.slloc, C * sN);
     DALLOC(m.subs, C * sM);
     DALLOC(m.rowcnt, C * sM);
+    DALLOC(m.rowbe, C * sM);
     DALLOC(m.coords, C * sM * NSLOT);
     DALLOC(m.loc, C * NSLOT * NDYN * sN);
     m.sN = sN;

@@ -340,8 +340,10 @@ __device__ __forceinline__ void mutate_one(const State& st, const Tables& tab, c
             if (k == 0) {
                 subs[ls] = s;
                 mb.rowcnt[(size_t)cw * M + ls] = 0; /* k_slice adds the kept contacts of the row (several waves per row) */
-                /* upper bound of the slice segment this row appends to */
-                atomicAdd((unsigned long long*)&seg_bound[ls % SLICE_SEG], (unsigned long long)(rowptr[s + 1] - rowptr[s]));
+                /* upper bound of the slice segment this row appends to; the row's range for k_slice */
+                const long long rb = rowptr[s], re = rowptr[s + 1];
+                atomicAdd((unsigned long long*)&seg_bound[ls % SLICE_SEG], (unsigned long long)(re - rb));
+                mb.rowbe[(size_t)cw * M + ls] = make_int4((int)(unsigned)rb, (int)(rb >> 32), (int)(re - rb), s);
             }
             if (npos == 0) ni += ((long long)SLc * (long long)(SLc - 1)) / 2;
             if (npos > 0) {
@@ -540,7 +542,8 @@ __global__ void __launch_bounds__(256, SLICE_MIN_WAVES) k_slice(const long long*
     const int SLA = a_SLA, ctgA = a_ctgA;
     const int row_lo = (shared_plane || own_all) ? 0 : SLA;
     const int n_rows = shared_plane ? SLA : (a_mloc[c0] - row_lo);
-    const int* subs = mb.subs + (size_t)cw0 * M;
+    const int4* rowbe = mb.rowbe + (size_t)cw0 * M;
+    const int ctgB0 = s_ctgB[0];
     /* work items = (row, j): wave j of a row takes the row's contact chunks j, j + J, ... (J waves per row: a row of thousands
      * of contacts is a chain of dependent round trips per chunk, and the launch waits for the longest chain) */
     const int nrw = gridDim.x * 4;
@@ -548,9 +551,12 @@ __global__ void __launch_bounds__(256, SLICE_MIN_WAVES) k_slice(const long long*
     for (int item = blockIdx.x * 4 + wv; item < n_rows * J; item += nrw) {
         const int r = row_lo + item % n_rows, j = item / n_rows;
         const int seg = r % SLICE_SEG;
-        const int i = subs[r];
-        const long long b = rowptr[i], e = rowptr[i + 1];
-        const int2 cp1 = tab.cp[i]; /* with the row's bounds: one round trip */
+        /* the row's range, written by k_mutate next to the window's sub-fragment list: ONE round trip in front of the contacts;
+         * its (contig, rank) follows from its place in the window (A's sub-fragments first, by rank, then B's) */
+        const int4 be = rowbe[r];
+        const long long b = (long long)(unsigned)be.x | ((long long)be.y << 32), e = b + be.z;
+        const bool in_a = m_same || r < SLA;
+        const int2 cp1 = make_int2(in_a ? ctgA : ctgB0, in_a ? r : r - SLA);
         const bool mine = (world <= 1) || ((r % world) == rank);
         int rc = 0; /* lane k: contacts of this row kept for candidate k */
         if (b != e) {
