@@ -137,6 +137,34 @@ def test_bench_starts_its_own_ranks(runner):
         assert out["config"]["maintained_likelihood_exact"] is True
 
 
+def test_bench_line_contract_one_gpu():
+    """`python bench.py --steps K --warmup W` on one GPU: one JSON line, a step is one batch of 24 moves (value in moves/s over
+    24 K moves), the roofline and CPU-baseline objects present, the maintained likelihood exact after the run"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "small", "--steps", "4", "--warmup", "1", "--cpu-budget", "2",
+                        "--nuisance-moves", "20"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 4 and out["warmup"] == 1 and out["unit"] == "moves/s" and out["higher_is_better"] is True
+    assert out["config"]["moves_per_step"] == 24 and out["config"]["moves_timed"] == 96
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 24.0) < 1e-6 * 24.0  # value = moves / s, ms_per_step per batch
+    assert out["vs_baseline"] is None and out["config"]["maintained_likelihood_exact"] is True
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["launches"] >= 4 and 0.0 < r["frac"] < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = out["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "moves/s" and c["value"] > 0 and c["cores"] >= 1
+    assert out["config"]["nuisance_on_moves_per_s"] > 0
+
+
 def test_bench_refuses_ranks_without_devices():
     """more ranks than GPUs must not silently measure one GPU"""
     import subprocess
