@@ -291,6 +291,23 @@ __device__ __forceinline__ int credit2_view(V view, const int* ip, const int* in
     return c2;
 }
 
+/* one step of a wave-wide argmax (larger score wins, the lower index among equals): every lane combines its pair with the one a
+ * DPP move brings (row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143); a lane the move does not reach keeps its
+ * own pair (the `old` operand), which the combination leaves as it is */
+template <int DPP_CTRL, int ROW_MASK>
+__device__ __forceinline__ void wave_argmax_step(double& v, int& i)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, DPP_CTRL, ROW_MASK, 0xf, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, DPP_CTRL, ROW_MASK, 0xf, false);
+    const int oi = __builtin_amdgcn_update_dpp(i, i, DPP_CTRL, ROW_MASK, 0xf, false);
+    const double ov = __hiloint2double(ohi, olo);
+    if (ov > v || (ov == v && oi < i)) {
+        v = ov;
+        i = oi;
+    }
+}
+
 /* k_commit_batch: the sequential half of a batch, one workgroup.
  *
  * 1. DECIDE (wave 0, no barriers): for w = 0, 1, ...: stop if a contig of move w was modified by an earlier move of
@@ -462,15 +479,16 @@ __global__ void __launch_bounds__(64)
                     }
                 }
             }
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ov = __shfl_xor(bestv, off, 64);
-                const int oi = __shfl_xor(best, off, 64);
-                if (ov > bestv || (ov == bestv && oi < best)) {
-                    bestv = ov;
-                    best = oi;
-                }
-            }
-            best = rl(best, 0);
+            /* (score, index) reduced into lane 63 with DPP moves: row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then lane 15 of
+             * rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2, 3 -- six steps of three moves each instead of six rounds of three
+             * ds_bpermute (a quarter of a decision's time: one wave cannot hide an LDS round trip) */
+            wave_argmax_step<0x111, 0xf>(bestv, best);
+            wave_argmax_step<0x112, 0xf>(bestv, best);
+            wave_argmax_step<0x114, 0xf>(bestv, best);
+            wave_argmax_step<0x118, 0xf>(bestv, best);
+            wave_argmax_step<0x142, 0xa>(bestv, best);
+            wave_argmax_step<0x143, 0xc>(bestv, best);
+            best = rl(best, 63);
             if (best >= n) best = 0;
             const int bc = best / IG_N_TMP_STRUCT, bslot = best % IG_N_TMP_STRUCT;
             const int owner = best & 63, bj = best >> 6; /* the lane and register that hold the winner's record */
