@@ -338,6 +338,12 @@ __device__ __forceinline__ SlotPre& pre_at(const MoveBuf& mb, int cw, int slot)
     const int w = cw / mb.capC, c = cw % mb.capC;
     return ((SlotPre*)(mb.rec + (size_t)w * mb.rec_stride))[c * IG_N_TMP_STRUCT + slot];
 }
+/* the same by (slot w, entry i = c * IG_N_TMP_STRUCT + column) / (slot w, candidate c): no division by the runtime capC */
+__device__ __forceinline__ SlotPre& pre_w(const MoveBuf& mb, int w, int i) { return ((SlotPre*)(mb.rec + (size_t)w * mb.rec_stride))[i]; }
+__device__ __forceinline__ CandPre& cpre_w(const MoveBuf& mb, int w, int c)
+{
+    return ((CandPre*)(mb.rec + (size_t)w * mb.rec_stride + (size_t)mb.capC * IG_N_TMP_STRUCT * sizeof(SlotPre)))[c];
+}
 __device__ __forceinline__ CandPre& cpre_at(const MoveBuf& mb, int cw)
 {
     const int w = cw / mb.capC, c = cw % mb.capC;

@@ -392,13 +392,12 @@ __global__ void __launch_bounds__(64)
             /* NOTHING here may touch a loaded value or load under a condition: either makes the wave wait for the data at
              * once (lanes past the end load a valid entry instead and are never read: every use below is under c < C or
              * i < C * IG_N_TMP_STRUCT) */
-            d.cand = cpre_at(mb, CW(w, lane < d.C ? lane : 0));
+            d.cand = cpre_w(mb, w, lane < d.C ? lane : 0);
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const int i = max(min(lane + 64 * j, d.C * IG_N_TMP_STRUCT - 1), 0);
-                const int cw = CW(w, i / IG_N_TMP_STRUCT);
-                d.rec[j] = pre_at(mb, cw, i % IG_N_TMP_STRUCT);
-                const CandPre& cp = cpre_at(mb, cw);
+                d.rec[j] = pre_w(mb, w, i); /* (the records of a slot are one array, entry i = candidate * IG_N_TMP_STRUCT + column) */
+                const CandPre& cp = cpre_w(mb, w, i / IG_N_TMP_STRUCT);
                 d.e_ext_d[j] = cp.ext_d;
                 d.e_r[j] = cp.r;
                 d.e_base[j] = cp.base_cnt;
@@ -467,9 +466,8 @@ __global__ void __launch_bounds__(64)
                     const int i = lane + 64 * j;
                     double v = 0.0;
                     if (i < n) {
-                        const int cw = CW(w, i / IG_N_TMP_STRUCT);
-                        const CandPre cp = cpre_at(mb, cw);
-                        v = score_of(i, pre_at(mb, cw, i % IG_N_TMP_STRUCT), cp.ext_d, cp.r, cp.base_cnt);
+                        const CandPre cp = cpre_w(mb, w, i / IG_N_TMP_STRUCT);
+                        v = score_of(i, pre_w(mb, w, i), cp.ext_d, cp.r, cp.base_cnt);
                     }
                     sc[j] = v;
                     const double ok = (v == 0.0) ? -IG_INF : v;
@@ -505,7 +503,7 @@ __global__ void __launch_bounds__(64)
                 br.info = (unsigned)rl((int)mine.info, owner);
                 bests = rld((bj == 0) ? sc[0] : sc[1], owner);
             } else { /* through readlane as well: a load still pending at the join would make every move wait for all prefetches */
-                const SlotPre ld = pre_at(mb, CW(w, bc), bslot);
+                const SlotPre ld = pre_w(mb, w, best);
                 br.nz_hi = rl64(ld.nz_hi, 0);
                 br.nz_lo = rl64(ld.nz_lo, 0);
                 br.dz_hi = rl64(ld.dz_hi, 0);
