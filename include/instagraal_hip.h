@@ -162,6 +162,13 @@ int ig_nuis_step_begin(ig_ctx* ctx, int32_t move, const float p_test[8], float m
  * (within 1e-9 relative), nothing decided or enqueued, the caller does it with its own exp(). */
 int ig_nuis_step_next(ig_ctx* ctx, double temperature, double u, const float p_next_rejected[8], const float p_next_accepted[8],
                       float mean_subfrag_kb, int32_t has_next, ig_move_result* out, double* nz_test, double* z_test, int32_t* accepted);
+/* The steps of a run decide their Metropolis test (CL:3026-3036) from a SCREENED pass where they can: the change of the
+ * likelihood between the model's and the test parameters, term by term in float with a rigorous bound
+ * (csrc/ig_kernels_nuis.cuh); a step whose whole interval lies below T ln u is rejected without the exact pass (its *nz_test is
+ * then the interval's midpoint: eval_likelihood_4_nuisance's value is only read inside the method, CL:3023-3036), every other
+ * step runs the exact pass as well.  0 = the exact pass on every step (env IG_NUIS_SCREEN); env IG_NUIS_SCREEN_VERIFY=1: both
+ * on every step, the bound checked. */
+int ig_set_nuis_screen(int on);
 
 /* ---- bookkeeping -------------------------------------------------------- */
 int ig_renumber_contigs(ig_ctx* ctx, int32_t* n_contigs, float* mean_len, int32_t* max_id); /* CL:2715-2881 */
@@ -207,6 +214,12 @@ int ig_debug_screen_stats(ig_ctx* ctx, double out6[6]); /* ..., terms screened, 
 int ig_debug_set_tail_quirk(int on);
 int ig_debug_tile_trace(ig_ctx* ctx, int64_t* out4n, int64_t cap, int64_t* n_items); /* per-workgroup clocks of one from-scratch pass */
 int ig_debug_nuis_wait(ig_ctx* ctx, double* seconds); /* time ig_nuis_end has waited for the device */
+/* per-workgroup clocks of one screened nuisance pass under p_test (8 words per workgroup; see ig_hip.hip) and its output words */
+int ig_debug_diff_trace(ig_ctx* ctx, const float p_test[8], float mean_subfrag_kb, int64_t* out8n, int64_t cap, int64_t* n, int64_t* sums8);
+/* the screened nuisance pass: {steps screened, rejected from the interval alone, exact passes behind a screened one, void,
+ * largest bound, largest |screened - exact| / bound seen, sum of the bounds, steps whose interval did not decide, void because of
+ * {the parameter pair, a contact, a workgroup's sums, a move record that did not come from the batch commit}} */
+int ig_debug_nuis_screen_stats(ig_ctx* ctx, double out12[12]);
 int ig_debug_set_full_hist(int on); /* from-scratch pass: all-trans tiles from their count histograms (1, default) or contact by contact (0) */
 
 #ifdef __cplusplus

@@ -111,6 +111,7 @@ struct MoveCtl {
     double ch_score;
     long long n_slice_tot, n_eval_tot, bytes_min;
     long long d_hi, d_lo; /* k_delta accumulator */
+    long long nzb_hi, nzb_lo; /* the maintained exact sum when this move was decided, i.e. of the state before it (k_decide_batch) */
     /* the predicted winner (k_predict: scores under the batch-start scalars), when it is a windowed candidate that changes
      * the genome, and its exact full-contig delta, computed before the decisions so that the batch need not pause for it */
     int pred, pred_c, pred_k, pred_pad; /* pred = c * 24 + slot, or -1 */
@@ -191,6 +192,10 @@ struct MoveBuf {
     unsigned long long* work;
     int work_cap;
     int* slot_items; /* [capW][8] work items a slot puts on each of the eight sub-lists (k_contend -> k_worklist) */
+    /* set while the parameter-dependent half of slots scored EARLIER is redone (enqueue_score, par_only): {n, contig ids modified by
+     * the moves of this batch committed meanwhile}.  The Q5 tail walk is the one scoring step that reads the live tables: it
+     * skips a slot whose contigs are on the list (the decide step stops in front of such a slot anyway) */
+    const int* stale;
     int N, M, capC, capW;
     /* strides of the per-window arrays above (Lloc .. loc: sN fragments, subs / rowcnt / coords: sM sub-fragments): the
      * largest window the genome can produce right now -- two contigs of the current maximum length, with headroom -- not
@@ -218,6 +223,11 @@ struct NuisHost {
     int frag, cands[IG_MAX_CANDIDATES]; /* the move's lists: the asynchronous upload reads them after ig_nuis_begin returned */
     int max_L, max_SL;                  /* Glob.max_L / max_SL as of the move */
     volatile int res_seq, sums_seq;     /* written last, by the kernel that wrote the record (k_commit_batch) / the sums (k_full_nz_tiled) */
+    /* the screened pass (ig_kernels_nuis.cuh): its sums {exact limbs of the all-trans tiles' change, screened sum and bound in
+     * 2^-20 units, void flags, contacts read}; the maintained exact sum as of BEFORE the move of the record (k_commit_batch) */
+    long long diff[8];
+    long long nzb[2];
+    volatile int diff_seq;
 };
 
 struct ig_ctx {
@@ -235,6 +245,15 @@ struct ig_ctx {
     struct NuisHost *host_nuis_dev, *pub_sums; /* its device address when mapped; set while a pass that publishes its sums is enqueued */
     int res_seq, sums_seq;         /* launch numbers the flags in host_nuis are compared with */
     bool nuis_pub_res, nuis_pub_sums; /* the step in flight publishes its record / its sums itself */
+    /* the Metropolis test from a screened pass over the parameter DIFFERENCE (ig_kernels_nuis.cuh) */
+    struct DiffConst* diff_const;
+    long long* scratch_diff;      /* its 8 output words */
+    long long* tile_partial0;     /* k_tile_trans: the histogram sums under the model's current set */
+    int diff_seq;
+    bool nuis_diff;               /* the step in flight ran the screened pass (the exact one only if it does not decide) */
+    bool nuis_exact_queued;       /* ... and the exact pass behind it already (verify mode) */
+    bool nuis_screen_rejected;    /* the last ig_nuis_end: rejected from the screened interval, no exact pass */
+    double nscr[12];               /* statistics: steps screened, rejected from the interval, exact passes, void, largest bound, largest used fraction, sum of bounds */
     bool nuis_in_flight;
     bool side_busy;      /* launch_full_nz on a side stream: the library stream is busy with a batch (one workgroup per CU for the pass) */
     bool tail_fused;     /* the batch in flight: the Q5 tail walk ran inside the screening kernel's launch (no second stream, no events) */
@@ -247,7 +266,11 @@ struct ig_ctx {
      * undecided slots were scored under the model's current parameters */
     bool nuis_spec, spec_valid, spec_prev_pending;
     int spec_base, spec_W, spec_next, spec_move, spec_slot;
-    double spec_ema;
+    /* the parameter-dependent half (screening, exact kernel, records) of the batch's slots [spec_par_begin, spec_par_end) is
+     * valid; the structural half (windows, candidate genomes, slice lists) of all spec_W slots: an accepted step only voids
+     * the former (ig_kernels: k_rescore_prepare) */
+    int spec_par_begin, spec_par_end;
+    double spec_ema, spec_struct_ema; /* moves decided per parameter scoring / per structural batch: set the widths */
     ig_params nuis_test;           /* the test parameters of the step in flight */
     float nuis_mean_kb;
     int N, M;
@@ -267,6 +290,7 @@ struct ig_ctx {
     struct TileWork* tile_work;
     int n_tile_work;
     long long* tile_trace; /* ig_debug_tile_trace */
+    long long* diff_trace; /* ig_debug_diff_trace */
     int n_tile_static, n_tile_info; /* work items k_full_nz_tiled is launched over; off-diagonal tiles with a histogram */
     struct TileInfo* tile_info;
     long long* tile_partial;        /* k_tile_trans: one (hi, lo) pair per workgroup, summed by k_full_nz_tiled */

@@ -199,9 +199,11 @@ extern "C" int ig_neighbours_draw(ig_neighbours* nb, uint32_t* mt_key624, int32_
     if (!nb || !mt_key624 || !mt_pos || !frags || !cands_out) return ig_fail_msg("ig_neighbours_draw: NULL argument");
     if (n_neighbours < 1 || n_neighbours > IG_MAX_CANDIDATES) return ig_fail_msg("ig_neighbours_draw: n_neighbours out of 1..16");
     if (*mt_pos < 0 || *mt_pos > 624) return ig_fail_msg("ig_neighbours_draw: MT19937 position out of range");
+    /* every fragment is checked before the first draw: an error leaves the caller's generator state (key AND position) untouched */
+    for (int32_t i = 0; i < n_moves; i++)
+        if (frags[i] < 0 || frags[i] >= nb->n_frags) return ig_fail_msg("ig_neighbours_draw: fragment out of range");
     MT mt{mt_key624, *mt_pos};
     for (int32_t i = 0; i < n_moves; i++) {
-        if (frags[i] < 0 || frags[i] >= nb->n_frags) return ig_fail_msg("ig_neighbours_draw: fragment out of range");
         draw_one(nb, mt, frags[i], n_neighbours, cands_out + (size_t)i * n_neighbours);
     }
     *mt_pos = mt.pos;
@@ -224,11 +226,12 @@ extern "C" int ig_neighbours_draw_nuisance(ig_neighbours* nb, uint32_t* mt_key62
         return ig_fail_msg("ig_neighbours_draw_nuisance: NULL argument");
     if (n_neighbours < 1 || n_neighbours > IG_MAX_CANDIDATES) return ig_fail_msg("ig_neighbours_draw_nuisance: n_neighbours out of 1..16");
     if (*mt_pos < 0 || *mt_pos > 624) return ig_fail_msg("ig_neighbours_draw_nuisance: MT19937 position out of range");
+    for (int32_t i = 0; i < n_moves; i++) /* before the first draw: an error leaves the caller's generator state untouched */
+        if (frags[i] < 0 || frags[i] >= nb->n_frags) return ig_fail_msg("ig_neighbours_draw_nuisance: fragment out of range");
     MT mt{mt_key624, *mt_pos};
     int hg = *has_gauss;
     double gz = *gauss;
     for (int32_t i = 0; i < n_moves; i++) {
-        if (frags[i] < 0 || frags[i] >= nb->n_frags) return ig_fail_msg("ig_neighbours_draw_nuisance: fragment out of range");
         draw_one(nb, mt, frags[i], n_neighbours, cands_out + (size_t)i * n_neighbours);
         const int id = (int)(mt.next32() & 3u);
         id_modif_out[i] = id;

@@ -41,6 +41,7 @@
 #include "ig_kernels_score.cuh"
 #include "ig_kernels_screen.cuh"
 #include "ig_kernels_commit.cuh"
+#include "ig_kernels_nuis.cuh"
 
 /* ================================================================== host side */
 
@@ -58,14 +59,15 @@ static int dalloc(T** p, size_t n)
         if (dalloc(&(p), (n))) return -1; \
     } while (0)
 
-enum { T_GATHER = 0, T_MUTATE, T_SCORE, T_FINALIZE, T_DELTA, T_APPLY, T_POST, T_COMMIT, T_SLICE, T_ARGMAX, T_SCREEN, T_COUNT };
-static const char* kTimerNames[T_COUNT] = {"gather", "mutate", "score", "finalize", "delta", "apply", "post", "commit", "slice", "argmax", "screen"};
+enum { T_GATHER = 0, T_MUTATE, T_SCORE, T_FINALIZE, T_DELTA, T_APPLY, T_POST, T_COMMIT, T_SLICE, T_ARGMAX, T_SCREEN, T_DIFF, T_COUNT };
+static const char* kTimerNames[T_COUNT] = {"gather", "mutate", "score", "finalize", "delta", "apply", "post", "commit", "slice", "argmax", "screen", "diff"};
 
 struct TimedLaunch {
     ig_ctx* c;
     int id;
     hipEvent_t a, b;
-    TimedLaunch(ig_ctx* ctx, int which) : c(ctx), id(which), a(nullptr), b(nullptr)
+    hipStream_t st;
+    TimedLaunch(ig_ctx* ctx, int which, hipStream_t stream = nullptr) : c(ctx), id(which), a(nullptr), b(nullptr), st(stream ? stream : ctx->stream)
     {
         if (c->timing && !((c->timing_mask >> id) & 1u)) return;
         /* every timing_every-th launch only: an event record between two kernels of a stream costs ~6 us of idle queue */
@@ -80,13 +82,13 @@ struct TimedLaunch {
                 hipEventCreate(&a);
                 hipEventCreate(&b);
             }
-            hipEventRecord(a, c->stream);
+            hipEventRecord(a, st);
         }
     }
     ~TimedLaunch()
     {
         if (c->timing && a) {
-            hipEventRecord(b, c->stream);
+            hipEventRecord(b, st);
             c->timers[id].ev.emplace_back(a, b);
         }
     }
@@ -143,6 +145,7 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->tiled_cc = nullptr;
     c->tile_work = nullptr;
     c->n_tile_work = 0;
+    c->tile_trace = c->diff_trace = nullptr;
     c->init_prev = c->init_next = c->orientable = nullptr;
     c->black = nullptr;
     c->batch_out = nullptr;
@@ -187,6 +190,12 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->host_nuis = nullptr;
     c->host_nuis_dev = nullptr;
     c->nuis_in_flight = false;
+    c->diff_const = nullptr;
+    c->scratch_diff = nullptr;
+    c->tile_partial0 = nullptr;
+    c->diff_seq = 0;
+    c->nuis_diff = c->nuis_exact_queued = c->nuis_screen_rejected = false;
+    for (double& v : c->nscr) v = 0.0;
     HIPCK(hipEventCreateWithFlags(&c->ev_slice, hipEventDisableTiming));
     HIPCK(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
     DALLOC(c->glob, 1);
@@ -317,6 +326,9 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipFree(c->tile_dyn);
     hipFree(c->tile_dyn_list);
     hipFree(c->tile_partial);
+    hipFree(c->tile_partial0);
+    hipFree(c->diff_const);
+    hipFree(c->scratch_diff);
     hipFree(c->init_prev);
     hipFree(c->init_next);
     hipFree(c->orientable);
@@ -596,6 +608,8 @@ extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* 
     hipFree(c->tile_dyn);
     hipFree(c->tile_dyn_list);
     hipFree(c->tile_partial);
+    hipFree(c->tile_partial0);
+    c->tile_partial0 = nullptr;
     c->tile_partial = nullptr;
     c->tile_info = nullptr;
     c->tile_dyn = nullptr;
@@ -668,6 +682,7 @@ extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* 
             DALLOC(c->tile_info, std::max<size_t>(tiles.size(), 1));
             DALLOC(c->tile_dyn, 4);
             DALLOC(c->tile_partial, 2 * ((tiles.size() + TILE_TRANS_THREADS / 64 - 1) / (TILE_TRANS_THREADS / 64) + 1));
+            DALLOC(c->tile_partial0, 2 * ((tiles.size() + TILE_TRANS_THREADS / 64 - 1) / (TILE_TRANS_THREADS / 64) + 1));
             DALLOC(c->tile_dyn_list, std::max<size_t>(work.size() - (size_t)c->n_tile_static, 1));
             HIPCK(hipMemcpy(c->tiled_cc, tc.data(), (size_t)Z * sizeof(uint2), hipMemcpyHostToDevice));
             HIPCK(hipMemcpy(c->tile_work, work.data(), work.size() * sizeof(TileWork), hipMemcpyHostToDevice));
@@ -1086,6 +1101,14 @@ static int check_ready(ig_ctx* c)
 
 static int g_tail_quirk = 1;
 
+/* two-tier scoring: the smallest grid of the exact kernel a batch may be launched with.  k_contend cuts a slot's work into items
+ * so that the slot alone needs at most half of the grid; whatever the item size there is up to one partly filled item per
+ * (candidate, column, list segment): max_c x NSLOT x SLICE_SEG of them (2 000 at 5 candidates, 6 400 at 16) */
+static int exact_grid_floor(const ig_ctx* c, int max_c)
+{
+    return std::min(c->mb.work_cap, std::max(4096, 2 * std::max(max_c, 1) * NSLOT * SLICE_SEG + 2048));
+}
+
 /* one-move calls: the bound on the longest contig comes back with the result (the window strides follow it) */
 static int queue_max_readback(ig_ctx* c)
 {
@@ -1105,25 +1128,104 @@ static void take_max_readback(ig_ctx* c)
 
 /* enqueue the scoring launches of W move slots (moves move0 .. move0+W-1 of the uploaded lists);
  * phase 0 = up to k_score_list (the sums that are all-reduced when sharded), 1 = the rest, 2 = both */
-static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot, int phase, int w_begin = 0, int w_end = -1)
+/* k_rescore_prepare: slots whose structural half (windows, candidate genomes, columns, slice lists) stands but whose
+ * parameter-dependent half has to be (re)done -- the parameters changed (an accepted nuisance step), or the slots were only
+ * gathered / mutated / sliced so far: accumulators back to zero, the zero-pixel sums of every column under the model's
+ * current P_z table (what k_mutate left, KA:3919-4002, from the columns it wrote) */
+__global__ void __launch_bounds__(256) k_rescore_prepare(Glob* g, MoveBuf mb, PzTab pz, int w_begin)
+{
+    const int slot = blockIdx.x, c = blockIdx.y, w = w_begin + blockIdx.z, t = threadIdx.x;
+    MoveCtl& mc = mb.ctl[w];
+    if (c >= mc.C) return;
+    const int cw = CW(w, c);
+    if (slot == 0) { /* once per candidate */
+        for (int i = t; i < NSLOT * 2; i += blockDim.x) mb.part[(size_t)cw * P_STRIDE + P_NZ + i] = 0;
+        for (int i = t; i < NSLOT * 2; i += blockDim.x) {
+            mb.qpart[(size_t)cw * Q_STRIDE + Q_NZFULL + i] = 0;
+            mb.qpart[(size_t)cw * Q_STRIDE + Q_TAIL + i] = 0;
+            ((long long*)mb.scr)[(size_t)cw * NSLOT * 2 + i] = 0;
+        }
+        if (t == 0) {
+            mb.scr_void[cw] = 0;
+            mb.scr_ub[cw] = 0;
+            mb.cont[cw] = 0xffffffffu;
+            mb.ident[cw] = 0;
+            if (c == 0) {
+                mc.exact_chunk = 0;
+                if (mc.overflow == 2) mc.overflow = 0; /* the exact kernel's grid is dealt out again (the slice pool's verdict, 1, stands) */
+                mc.pred = -1;
+                mc.pred_pad = -1;
+                mc.pd_hi = mc.pd_lo = 0;
+                if (blockIdx.z == 0 && mb.work)
+                    for (int q = 0; q < 16; q++) mb.work[q] = 0;
+            }
+        }
+    }
+    const CandMeta& m = mb.meta[cw];
+    const int k = m.kidx[slot];
+    if (k < 0 || m.m_loc > mb.sM) return;
+    const ig_params p = g->par[0];
+    const float mean = g->mean_kb;
+    const uint2* col = mb.coords + (size_t)(cw * NSLOT + k) * mb.sM;
+    const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
+    long long hi = 0, lo = 0;
+    for (int ls = t; ls < m.m_loc; ls += blockDim.x) {
+        const uint2 v = col[ls];
+        const int npos = (int)(v.y & 0x0fffffffu), code = (int)(v.y >> 28);
+        if (npos > 0) {
+            const long long q2 = zero_q(p, npos, cm[code].len, cm[code].stot, mean, pz.v, pz.n);
+            hi += q2 >> 32;
+            lo += (long long)(unsigned int)q2;
+        }
+    }
+    __shared__ long long red[2][4];
+    hi = wave_sum_ll(hi);
+    lo = wave_sum_ll(lo);
+    if ((t & 63) == 0) {
+        red[0][t >> 6] = hi;
+        red[1][t >> 6] = lo;
+    }
+    __syncthreads();
+    if (t == 0) {
+        long long* q = mb.qpart + (size_t)cw * Q_STRIDE;
+        q[Q_Z + 2 * k] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        q[Q_Z + 2 * k + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+/* par_begin / par_end: the slots whose PARAMETER-DEPENDENT half (tail walk, screening, contenders, exact kernel, records) is
+ * done by this call (default: all of [w_begin, w_end)); par_only: nothing but that half, on slots gathered, mutated and
+ * sliced by an earlier call (the runs of (move, nuisance step) pairs: the structural half of a batch survives an accepted
+ * step, and is scored in pieces that follow the run lengths) */
+static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot, int phase, int w_begin = 0, int w_end = -1, int par_begin = -1,
+                          int par_end = -1, bool par_only = false)
 {
     /* slots [w_begin, w_end) are sliced and scored here (multi-GPU: the other ranks score the rest and the slot-major
      * records are all-gathered); the candidate genomes of EVERY slot are built on every rank, the commit step needs them */
     if (w_end < 0) w_end = W;
     const int nW = w_end - w_begin;
+    const int pb = par_begin < 0 ? w_begin : par_begin, pe = par_end < 0 ? w_end : par_end;
+    const int nWp = pe - pb;
+    struct StaleGuard { /* the kernels launched below see the list of contigs modified since these slots were gathered */
+        ig_ctx* c;
+        StaleGuard(ig_ctx* ctx, bool on) : c(ctx) { c->mb.stale = on ? c->dirty_buf : nullptr; }
+        ~StaleGuard() { c->mb.stale = nullptr; }
+    } stale_guard(c, par_only && pb > 0);
     const int N = c->N;
     const int gN = std::max((N + 255) / 256, W);
     const PzTab pz{c->pz_tab, c->pz_n};
     if (phase == 0 || phase == 2) {
         const int n_tw = (c->M + 31) / 32 + 1;
-        c->touched_flip ^= 1;
-        c->mb.touched = c->touched_bits + (size_t)c->touched_flip * n_tw;
-        {
+        if (!par_only) {
+            c->touched_flip ^= 1;
+            c->mb.touched = c->touched_bits + (size_t)c->touched_flip * n_tw;
+        }
+        if (!par_only) {
             TimedLaunch t(c, T_GATHER);
             hipLaunchKernelGGL(k_gather, dim3(gN), dim3(256), 0, c->stream, c->st, c->glob, c->mb, c->d_cands, c->d_frags, move0, W, max_c,
                                c->tab, c->tab_prev, c->prev_touched, force_slot, c->touched_bits + (size_t)(c->touched_flip ^ 1) * n_tw, n_tw);
         }
-        {
+        if (!par_only) {
             TimedLaunch t(c, T_MUTATE);
             /* slots split over GPUs: only the own slots' candidate genomes are built here; k_mutate_winners rebuilds what the
              * commit step applies from the other ranks' slots */
@@ -1139,7 +1241,7 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
             }
         }
         if (force_slot < 0 && nW > 0) {
-            {
+            if (!par_only) {
                 TimedLaunch t(c, T_SLICE);
                 hipLaunchKernelGGL(k_offsets, dim3(1), dim3(OFFSETS_THREADS), 0, c->stream, c->mb, W, w_begin, w_end);
                 /* a wave walks a row (a workgroup 4 rows at a time).  Measured at cfg3 (us per launch of 24 slots): 32 workgroups per
@@ -1155,6 +1257,9 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                     hipLaunchKernelGGL(k_slice<false>, dim3(rb, max_c + 1, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->rank,
                                        c->world, w_begin, s_share, s_maxj);
             }
+            if (par_only && nWp > 0)
+                hipLaunchKernelGGL(k_rescore_prepare, dim3(NSLOT, max_c, nWp), dim3(256), 0, c->stream, c->glob, c->mb, pz, pb);
+            if (nWp > 0) {
             /* two-tier scoring (batches on one handle, packed lists): every column through the float screening kernel, the exact
              * kernel only for the columns that can still win (ig_kernels_screen.cuh).  IG_SCREEN=0: everything exact;
              * IG_SCREEN_VERIFY=1: everything exact AND screened, the bound checked column by column. */
@@ -1169,8 +1274,8 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
             if (phase == 2 && !c->tail_fused) {
                 hipEventRecord(c->ev_slice, c->stream);
                 hipStreamWaitEvent(c->stream2, c->ev_slice, 0);
-                hipLaunchKernelGGL(k_tail, dim3(max_c, nW), dim3(256), 0, c->stream2, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->lgf_tab,
-                                   g_tail_quirk, pz, w_begin);
+                hipLaunchKernelGGL(k_tail, dim3(max_c, nWp), dim3(256), 0, c->stream2, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->lgf_tab,
+                                   g_tail_quirk, pz, pb);
                 hipEventRecord(c->ev_tail, c->stream2);
             }
             int contenders_only = 0;
@@ -1178,20 +1283,20 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                 {
                     TimedLaunch t(c, T_SCREEN);
                     if (c->tail_fused)
-                        hipLaunchKernelGGL(k_screen_tail, dim3(max_c * nW + SLICE_SEG * ((NSLOT + 1) / 2) * max_c * nW), dim3(SCORE_THREADS), 0, c->stream,
-                                           c->screen_const, c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, max_c, w_begin, max_c * nW, c->rowptr, c->cc,
+                        hipLaunchKernelGGL(k_screen_tail, dim3(max_c * nWp + SLICE_SEG * ((NSLOT + 1) / 2) * max_c * nWp), dim3(SCORE_THREADS), 0, c->stream,
+                                           c->screen_const, c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, max_c, pb, max_c * nWp, c->rowptr, c->cc,
                                            c->tab, c->glob, c->lgf_tab, g_tail_quirk, pz);
                     else
-                        hipLaunchKernelGGL(k_screen, dim3(SLICE_SEG, (NSLOT + 1) / 2, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->screen_const,
-                                           c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, max_c, w_begin);
+                        hipLaunchKernelGGL(k_screen, dim3(SLICE_SEG, (NSLOT + 1) / 2, max_c * nWp), dim3(SCORE_THREADS), 0, c->stream, c->screen_const,
+                                           c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, max_c, pb);
                 }
                 if (c->exact_grid <= 0) c->exact_grid = 32768;
-                c->exact_grid = std::min(c->exact_grid, c->mb.work_cap);
+                c->exact_grid = std::max(std::min(c->exact_grid, c->mb.work_cap), exact_grid_floor(c, max_c));
                 if (!c->tail_fused) hipStreamWaitEvent(c->stream, c->ev_tail, 0); /* the contender test reads the exact tail sums (quirk Q5) */
-                hipLaunchKernelGGL(k_contend, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, c->mb.cont, w_begin,
+                hipLaunchKernelGGL(k_contend, dim3(nWp), dim3(256), 0, c->stream, c->glob, c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, c->mb.cont, pb,
                                    getenv("IG_CONTEND_ALL") ? atoi(getenv("IG_CONTEND_ALL")) : 0, c->exact_grid,
                                    getenv("IG_EXACT_CHUNK") ? std::max(256, atoi(getenv("IG_EXACT_CHUNK"))) : EXACT_CHUNK);
-                hipLaunchKernelGGL(k_worklist, dim3(nW), dim3(256), 0, c->stream, c->mb, c->mb.cont, w_begin, c->exact_grid);
+                hipLaunchKernelGGL(k_worklist, dim3(nWp), dim3(256), 0, c->stream, c->mb, c->mb.cont, pb, c->exact_grid);
                 contenders_only = verify ? 0 : 1;
             }
             c->own_screened = screen ? (verify ? 2 : 1) : 0;
@@ -1202,38 +1307,39 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                 /* the work list k_contend left; the grid follows what the previous batches needed (commit_loop), the workgroups
                  * past the end of the list leave on their first load, a slot whose items do not fit is re-run */
                 hipLaunchKernelGGL(k_score_list<LDS_COL_SMALL>, dim3(c->exact_grid), dim3(SCORE_THREADS), 0, c->stream, c->score_const, c->mb,
-                                   c->lgf_tab, pz, s_abl, max_c, w_begin, 1);
+                                   c->lgf_tab, pz, s_abl, max_c, pb, 1);
             } else {
-                hipLaunchKernelGGL(k_score_list<LDS_COL_SMALL>, dim3(s_eb, NSLOT, max_c * nW), dim3(SCORE_THREADS), 0, c->stream, c->score_const,
-                                   c->mb, c->lgf_tab, pz, s_abl, max_c, w_begin, 0);
+                hipLaunchKernelGGL(k_score_list<LDS_COL_SMALL>, dim3(s_eb, NSLOT, max_c * nWp), dim3(SCORE_THREADS), 0, c->stream, c->score_const,
+                                   c->mb, c->lgf_tab, pz, s_abl, max_c, pb, 0);
             }
             if (screen && verify) {
                 if (!c->screen_worst) {
                     if (dalloc(&c->screen_worst, 2) == 0) hipMemsetAsync(c->screen_worst, 0, 2 * sizeof(double), c->stream);
                 }
-                hipLaunchKernelGGL(k_screen_verify, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, w_begin,
+                hipLaunchKernelGGL(k_screen_verify, dim3(nWp), dim3(256), 0, c->stream, c->glob, c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, pb,
                                    c->screen_worst);
+            }
             }
         }
     }
     if (phase == 1 || phase == 2) {
-        if (force_slot < 0 && nW > 0) {
+        if (force_slot < 0 && nWp > 0) {
             if (phase == 1) /* after the all-reduce of the list lengths (contact shards): no overlap */
-                hipLaunchKernelGGL(k_tail, dim3(max_c, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->lgf_tab,
-                                   g_tail_quirk, pz, w_begin);
+                hipLaunchKernelGGL(k_tail, dim3(max_c, nWp), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->lgf_tab,
+                                   g_tail_quirk, pz, pb);
             else if (!c->tail_fused)
                 hipStreamWaitEvent(c->stream, c->ev_tail, 0);
             TimedLaunch t(c, T_FINALIZE);
-            hipLaunchKernelGGL(k_records, dim3(max_c, nW), dim3(64), 0, c->stream, c->mb, w_begin, c->own_screened ? 1 : 0);
+            hipLaunchKernelGGL(k_records, dim3(max_c, nWp), dim3(64), 0, c->stream, c->mb, pb, c->own_screened ? 1 : 0);
             /* batches: predicted windowed winners get their exact delta now (not those decided one move per call, ig_nuis_step_begin:
              * a pause costs them nothing they would not wait for anyway) */
             if (phase == 2 && W > 1 && c->world == 1 && !c->no_predict) {
                 static const int s_pred2 = getenv("IG_PREDICT_PASSES") ? atoi(getenv("IG_PREDICT_PASSES")) : 2;
-                if (s_pred2 >= 2) hipLaunchKernelGGL(k_predict, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, w_begin, 0);
-                hipLaunchKernelGGL(k_predict, dim3(nW), dim3(256), 0, c->stream, c->glob, c->mb, w_begin, 1);
+                if (s_pred2 >= 2) hipLaunchKernelGGL(k_predict, dim3(nWp), dim3(256), 0, c->stream, c->glob, c->mb, pb, 0);
+                hipLaunchKernelGGL(k_predict, dim3(nWp), dim3(256), 0, c->stream, c->glob, c->mb, pb, 1);
                 static const int s_drb = getenv("IG_DELTA_RB") ? atoi(getenv("IG_DELTA_RB")) : DELTA_RB;
-                hipLaunchKernelGGL(k_delta, dim3(s_drb, 2, nW), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->tab_prev,
-                                   c->prev_touched, c->glob, c->mb, c->lgf_tab, pz, w_begin, 1, 0);
+                hipLaunchKernelGGL(k_delta, dim3(s_drb, 2, nWp), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->tab_prev,
+                                   c->prev_touched, c->glob, c->mb, c->lgf_tab, pz, pb, 1, 0);
             }
         }
     }
@@ -1248,7 +1354,7 @@ static void enqueue_choose(ig_ctx* c, int w, int force_slot)
 }
 
 /* one-move tail: exact delta, apply, genome distance, result record */
-static void enqueue_apply(ig_ctx* c, int move, int w, int forced)
+static void enqueue_apply(ig_ctx* c, int move, int w, int forced, bool log_dirty = false)
 {
     const int N = c->N;
     const PzTab pz{c->pz_tab, c->pz_n};
@@ -1268,7 +1374,7 @@ static void enqueue_apply(ig_ctx* c, int move, int w, int forced)
     }
     {
         TimedLaunch t(c, T_COMMIT);
-        hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, c->stream, c->glob, c->mb, c->d_results, move, w);
+        hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, c->stream, c->glob, c->mb, c->d_results, move, w, log_dirty ? c->dirty_buf : (int*)nullptr);
     }
 }
 
@@ -1355,7 +1461,7 @@ static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
             return 0;
         }
         if (c->own_screened == 1 && next == 0) /* first commit of this batch: size the exact kernel's next grid */
-            c->exact_grid = std::min(c->mb.work_cap, std::max(4096, (int)(1.25 * bo[6]) + 2048));
+            c->exact_grid = std::min(c->mb.work_cap, std::max(exact_grid_floor(c, c->up_max_c), (int)(1.25 * bo[6]) + 2048));
         next = bo[0];
         if (bo[1] >= 0) { /* slot bo[1] chose a windowed winner: delta + apply with the one-move kernels, then go on */
             enqueue_apply(c, done + bo[1], bo[1], 0);
@@ -1845,6 +1951,73 @@ static bool wait_host_flag(volatile int* flag, int seq, hipStream_t stream)
     }
 }
 
+/* ---- the Metropolis test from a screened pass (ig_kernels_nuis.cuh) ------------------------------------------------------
+ * IG_NUIS_SCREEN=0: every step through the exact pass, as before; IG_NUIS_SCREEN_VERIFY=1: both, the bound checked on the host */
+static int g_nuis_screen = -1, g_nuis_screen_verify = -1;
+static bool nuis_screen_usable(ig_ctx* c)
+{
+    if (g_nuis_screen < 0) g_nuis_screen = getenv("IG_NUIS_SCREEN") ? atoi(getenv("IG_NUIS_SCREEN")) : 1;
+    g_nuis_screen_verify = getenv("IG_NUIS_SCREEN_VERIFY") ? atoi(getenv("IG_NUIS_SCREEN_VERIFY")) : 0; /* read per step: a test toggles it */
+    static const int s_tiled = getenv("IG_FULL_TILED") ? atoi(getenv("IG_FULL_TILED")) : 1;
+    return (g_nuis_screen || g_nuis_screen_verify) && c->nuis_spec && c->host_nuis_dev && s_tiled && c->tiled_cc && c->n_tile_work > 0 &&
+           c->score_const && c->screen_const && c->pz_tab && g_full_hist != 0;
+}
+extern "C" int ig_set_nuis_screen(int on)
+{
+    g_nuis_screen = on ? 1 : 0;
+    return 0;
+}
+
+/* the exact tiles kernel over the list the step's k_tile_trans left (tables, signatures, constants of the test set are in place) */
+static void launch_nuis_exact_tiles(ig_ctx* c, hipStream_t s3)
+{
+    static const int s_grid = getenv("IG_FULL_GRID") ? atoi(getenv("IG_FULL_GRID")) : 512;
+    const int per = TILE_TRANS_THREADS / 64;
+    const int n_trans = (c->n_tile_info + per - 1) / per;
+    const int grid = std::min(c->n_tile_work, s_grid);
+    hipLaunchKernelGGL(k_full_nz_tiled, dim3(grid), dim3(FULL_TILED_THREADS), sizeof(FullTiledLds), s3, c->tile_work, c->tiled_cc, c->tabrec,
+                       c->tab_prev.len, c->full_const, c->lgf_tab, c->M, c->pz_n1, c->scratch_nuis, c->n_tile_static, (TileDyn*)c->tile_dyn,
+                       c->tile_dyn_list, (long long*)nullptr, c->host_nuis_dev, ++c->sums_seq, c->tile_partial, n_trans);
+    c->nuis_pub_sums = true;
+}
+
+static int launch_nuis_diff(ig_ctx* c, const ig_params& hp, float mean_kb, hipStream_t s3)
+{
+    if (!c->diff_const) {
+        DALLOC(c->diff_const, 1);
+        DALLOC(c->scratch_diff, 8);
+        HIPCK(hipFuncSetAttribute((const void*)k_full_diff_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DiffLds)));
+    }
+    const Tables& t = c->tab_prev;
+    const int n_pack = (c->M + FULL_TB - 1) / FULL_TB;
+    const int n_const = (std::max(std::max(c->pz_n1, LDS_PZ + 2), std::max((int)IG_TAB_SIZE, LDS_LGF)) + 255) / 256;
+    hipLaunchKernelGGL(k_nuis_prepare, dim3(n_pack + n_const), dim3(256), 0, s3, c->glob, 1, hp, mean_kb, c->pz_tab1, c->pz_n1, c->lgf_tab, c->full_const,
+                       c->scratch_nuis, t, c->M, c->tabrec, c->tile_sig, FULL_TB, c->tile_dyn, n_pack, c->score_const, c->pz_n, c->diff_const,
+                       c->scratch_diff, c->screen_const);
+    const int per = TILE_TRANS_THREADS / 64;
+    const int n_trans = (c->n_tile_info + per - 1) / per, n_zero = std::min(256, std::max(32, c->M / 4096));
+    hipLaunchKernelGGL(k_tile_trans, dim3(n_trans + n_zero), dim3(TILE_TRANS_THREADS), 0, s3, c->tile_info, c->n_tile_info, c->tile_sig, c->tile_hist,
+                       c->full_const, (TileDyn*)c->tile_dyn, c->tile_dyn_list, 1, c->tile_partial, n_trans, t, c->glob, 1, c->M, c->scratch_nuis + 2,
+                       c->score_const, c->tile_partial0);
+    static const int s_grid = getenv("IG_FULL_GRID") ? atoi(getenv("IG_FULL_GRID")) : 512;
+    static const int s_grid_side = getenv("IG_FULL_GRID_SIDE") ? atoi(getenv("IG_FULL_GRID_SIDE")) : 256;
+    const int grid = std::min(c->n_tile_work, c->side_busy ? s_grid_side : s_grid);
+    {
+        TimedLaunch tl(c, T_DIFF, s3);
+        hipLaunchKernelGGL(k_full_diff_tiled, dim3(grid), dim3(DIFF_THREADS), sizeof(DiffLds), s3, c->tile_work, c->tiled_cc, c->tabrec, c->diff_const,
+                           c->M, c->scratch_diff, c->n_tile_static, (TileDyn*)c->tile_dyn, c->tile_dyn_list, c->host_nuis_dev, ++c->diff_seq,
+                           c->tile_partial, c->tile_partial0, n_trans, c->scratch_nuis, c->diff_trace);
+    }
+    c->nuis_diff = true;
+    c->nuis_exact_queued = false;
+    c->nuis_pub_sums = false;
+    if (g_nuis_screen_verify) { /* the exact pass behind it, unconditionally */
+        launch_nuis_exact_tiles(c, s3);
+        c->nuis_exact_queued = true;
+    }
+    return 0;
+}
+
 /* tab_prev := the state before the move about to be decided, then (second stream) the full pass under p_test on it */
 static int enqueue_nuis_pass(ig_ctx* c, const float p_test[8], float mean_subfrag_kb)
 {
@@ -1878,6 +2051,9 @@ static int enqueue_nuis_pass(ig_ctx* c, const float p_test[8], float mean_subfra
     c->pz_n1 = (need > 0 && need < (double)PZ_MAX) ? (int)need : ((need >= (double)PZ_MAX) ? PZ_MAX : 0);
     if (!on_side) HIPCK(hipStreamWaitEvent(s3, c->ev_gathered, 0));
     c->nuis_pub_sums = false;
+    c->nuis_diff = false;
+    c->nuis_screen_rejected = false;
+    if (nuis_screen_usable(c)) return launch_nuis_diff(c, hp, mean_subfrag_kb, s3);
     c->pub_sums = (c->nuis_spec && c->host_nuis_dev) ? c->host_nuis_dev : nullptr; /* launch_full_nz: the tiled kernel's last workgroup publishes */
     const bool zero_done = launch_full_nz(c, c->tab_prev, 1, c->scratch_nuis, PzTab{c->pz_tab1, c->pz_n1}, s3, c->scratch_nuis + 2, &hp, mean_subfrag_kb);
     c->pub_sums = nullptr;
@@ -1959,36 +2135,85 @@ extern "C" int ig_nuis_run_begin(ig_ctx* c, int32_t n_moves, const int32_t* frag
     c->spec_valid = false;
     c->spec_prev_pending = false;
     c->spec_base = c->spec_W = c->spec_next = c->spec_move = c->spec_slot = 0;
+    c->spec_par_begin = c->spec_par_end = 0;
     c->full_windows = false;
     return 0;
 }
 
-/* the slots scored ahead are of no use any more (accepted step, conflict, used up): the width of the next batch follows the
- * number of moves the batches get through (one that got through all of its slots counts double: the run was at least that long) */
+/* Widths.  The PARAMETER width (slots screened / scored per launch) follows the number of moves decided between two accepted
+ * steps; the STRUCTURAL width (slots gathered, mutated and sliced per launch) the number of moves a batch gets through before
+ * a conflict -- an accepted step voids only the former.  IG_NUIS_W / ig_set_nuis_width fixes both (tests). */
+static int nuis_struct_width(ig_ctx* c)
+{
+    const int cap = std::min(c->mb.capW, IG_MAX_BATCH);
+    if (g_nuis_w > 0) return std::min(g_nuis_w, cap);
+    static const int s_keep = getenv("IG_NUIS_KEEP") ? atoi(getenv("IG_NUIS_KEEP")) : 1; /* 0: the structural half is redone with every scoring (as before) */
+    if (!s_keep) return nuis_spec_width(c);
+    if (c->spec_struct_ema <= 0.0) c->spec_struct_ema = cap;
+    return std::max(nuis_spec_width(c), std::min(cap, (int)(1.5 * c->spec_struct_ema + 1.5)));
+}
+
+/* the parameter-dependent scores ahead are of no use any more (accepted step) */
+static void nuis_par_invalidate(ig_ctx* c)
+{
+    if (c->spec_valid && c->spec_par_end > c->spec_par_begin) {
+        const int used = c->spec_next - c->spec_par_begin, had = c->spec_par_end - c->spec_par_begin;
+        if (used >= 0) { /* a piece used up counts double: the run was at least that long */
+            const double len = (used >= had) ? 2.0 * had : (double)used;
+            c->spec_ema = 0.7 * (c->spec_ema > 0 ? c->spec_ema : 3.0) + 0.3 * len;
+        }
+    }
+    c->spec_par_begin = c->spec_par_end = c->spec_next;
+}
+
+/* the batch in the buffers is of no use any more (conflict, used up, a run's end) */
 static void nuis_spec_invalidate(ig_ctx* c)
 {
     if (c->spec_valid && c->spec_W > 0) {
         const double len = (c->spec_next >= c->spec_W) ? 2.0 * c->spec_W : (double)c->spec_next;
-        c->spec_ema = 0.7 * (c->spec_ema > 0 ? c->spec_ema : 3.0) + 0.3 * len;
+        c->spec_struct_ema = 0.7 * (c->spec_struct_ema > 0 ? c->spec_struct_ema : (double)c->spec_W) + 0.3 * len;
+        nuis_par_invalidate(c);
     }
     c->spec_valid = false;
 }
 
-/* score a batch of moves starting at `move` */
+/* score a batch of moves starting at `move`: the structural half of all its slots, the parameter half of the first ones */
 static int nuis_spec_score(ig_ctx* c, int move)
 {
     nuis_spec_invalidate(c);
-    const int W = std::min(nuis_spec_width(c), c->up_moves - move);
+    const int W = std::min(nuis_struct_width(c), c->up_moves - move);
+    const int r = std::min(nuis_spec_width(c), W);
     if (ensure_window_buffers(c)) return -1; /* the longest contig may have grown */
     static const int s_nopred = getenv("IG_NUIS_PREDICT") ? !atoi(getenv("IG_NUIS_PREDICT")) : 1;
     c->no_predict = s_nopred != 0;
-    enqueue_score(c, move, W, c->up_max_c, -1, 2);
+    enqueue_score(c, move, W, c->up_max_c, -1, 2, 0, W, 0, r, false);
     c->no_predict = false;
     c->spec_base = move;
     c->spec_W = W;
     c->spec_next = 0;
+    c->spec_par_begin = 0;
+    c->spec_par_end = r;
     c->spec_valid = true;
     c->spec_prev_pending = false;
+    return 0;
+}
+
+/* the structural half of the batch stands (no conflict so far, slots left): the parameter half of the next slots -- after an
+ * accepted step (new parameters), or because the piece scored before is used up */
+static bool nuis_spec_can_rescore(const ig_ctx* c, int move)
+{
+    return c->spec_valid && c->spec_next < c->spec_W && c->spec_base + c->spec_next == move;
+}
+static int nuis_spec_rescore(ig_ctx* c)
+{
+    nuis_par_invalidate(c);
+    const int pb = c->spec_next, pe = std::min(c->spec_W, pb + nuis_spec_width(c));
+    static const int s_nopred = getenv("IG_NUIS_PREDICT") ? !atoi(getenv("IG_NUIS_PREDICT")) : 1;
+    c->no_predict = s_nopred != 0;
+    enqueue_score(c, c->spec_base, c->spec_W, c->up_max_c, -1, 2, 0, c->spec_W, pb, pe, true);
+    c->no_predict = false;
+    c->spec_par_begin = pb;
+    c->spec_par_end = pe;
     return 0;
 }
 
@@ -2001,12 +2226,15 @@ extern "C" int ig_nuis_step_begin(ig_ctx* c, int32_t move, const float p_test[8]
     c->nuis_in_flight = true;
     /* a batch is scored in this step (or still being scored: right after an accepted step): the pass leaves half of every CU
      * to it; else it takes the machine (all that runs next to it is one decision and one apply) */
-    const bool rescore = !c->spec_valid || c->spec_next >= c->spec_W || c->spec_base + c->spec_next != move;
-    c->side_busy = rescore || c->spec_next == 0;
+    const bool restruct = !nuis_spec_can_rescore(c, move);
+    const bool repar = !restruct && c->spec_next >= c->spec_par_end; /* the piece scored under the current parameters is used up */
+    c->side_busy = restruct || repar || c->spec_next == c->spec_par_begin;
     if (enqueue_nuis_pass(c, p_test, mean_subfrag_kb)) return -1;
     c->side_busy = true;
-    if (rescore) {
+    if (restruct) {
         if (nuis_spec_score(c, move)) return -1;
+    } else if (repar) {
+        if (nuis_spec_rescore(c)) return -1;
     }
     /* the result record reaches the host as soon as the move is applied: written by k_commit_batch itself where the host
      * memory is mapped, else copied (and copied in the rare cases ig_nuis_end has to redo the move) */
@@ -2027,17 +2255,17 @@ static int nuis_spec_finish(ig_ctx* c)
     for (int attempt = 0;; attempt++) {
         int bo[12];
         const int w = c->spec_next;
-        if (wait_commit(c, bo, w == 0, w)) return -1;
-        if (c->own_screened == 1 && w == 0 && !(bo[2] && bo[0] == 0 && bo[1] < 0))
-            c->exact_grid = std::min(c->mb.work_cap, std::max(4096, (int)(1.25 * bo[6]) + 2048));
+        if (wait_commit(c, bo, w == c->spec_par_begin, w)) return -1;
+        if (c->own_screened == 1 && w == c->spec_par_begin && !(bo[2] && bo[0] == 0 && bo[1] < 0))
+            c->exact_grid = std::min(c->mb.work_cap, std::max(exact_grid_floor(c, c->up_max_c), (int)(1.25 * bo[6]) + 2048));
         if (bo[0] == w + 1) {
             c->spec_prev_pending = false;
             break;
         }
         if (bo[1] == w) { /* a windowed winner without a predicted delta: the one-move tail */
-            enqueue_apply(c, c->spec_base + w, w, 0);
+            enqueue_apply(c, c->spec_base + w, w, 0, true); /* (its contigs onto the batch's list of modified ones) */
             c->n_batch_pending++;
-            c->spec_prev_pending = true;
+            c->spec_prev_pending = false;
             redone = true;
             break;
         }
@@ -2072,16 +2300,36 @@ static int nuis_spec_finish(ig_ctx* c)
     return 0;
 }
 
-extern "C" int ig_nuis_end(ig_ctx* c, ig_move_result* out, double* nz_test, double* z_test, int64_t* limbs5)
+/* z of a pass from its eight sums (as ig_full_likelihood) */
+static double nuis_z_from_sums(const long long h_in[8])
+{
+    long long h[8];
+    memcpy(h, h_in, sizeof h);
+    ig_acc_normalize((int64_t*)&h[2], (int64_t*)&h[3]);
+    const double log_e = 0.43429448190325182;
+    double n_tot_pxl;
+    float v_inter;
+    const int vi_bits = (int)h[7];
+    memcpy(&n_tot_pxl, &h[5], sizeof n_tot_pxl);
+    memcpy(&v_inter, &vi_bits, sizeof v_inter);
+    return ig_acc_to_double(h[2], h[3]) * log_e + log_e * (n_tot_pxl - (double)h[4]) * -1.0 * (double)v_inter;
+}
+
+/* Tu = {temperature, u} of the Metropolis test when the caller is ig_nuis_step_next: a step whose screened interval lies
+ * below T ln u is rejected without the exact pass (nuis_screen_rejected; *nz_test is then the interval's midpoint) */
+static int nuis_end_impl(ig_ctx* c, ig_move_result* out, double* nz_test, double* z_test, int64_t* limbs5, const double* Tu)
 {
     HIPCK(hipSetDevice(c->device));
     if (!c->nuis_in_flight) return fail("ig_nuis_end: no step in flight");
     c->nuis_in_flight = false;
+    c->nuis_screen_rejected = false;
     const auto w0 = std::chrono::steady_clock::now();
     if (c->nuis_spec && nuis_spec_finish(c)) return -1;
+    bool have_nzb = false;
     if (c->nuis_spec && c->nuis_pub_res && wait_host_flag(&c->host_nuis->res_seq, c->res_seq, c->stream)) {
         c->max_L = std::max(c->max_L, c->host_nuis->max_L);
         c->max_SL = std::max(c->max_SL, c->host_nuis->max_SL);
+        have_nzb = true; /* the record came from k_commit_batch, with the maintained sum of the state before the move */
     } else {
         if (c->nuis_spec && c->nuis_pub_res) { /* no flag although the stream has drained: fetch the record the plain way */
             HIPCK(hipMemcpyAsync(&c->host_nuis->res, c->d_results + c->spec_move - 1, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
@@ -2089,6 +2337,60 @@ extern "C" int ig_nuis_end(ig_ctx* c, ig_move_result* out, double* nz_test, doub
         }
         HIPCK(hipStreamSynchronize(c->stream));
         take_max_readback(c);
+    }
+    /* the screened pass: decide from its interval where that is possible */
+    bool scr_valid = false;
+    double scr_mid = 0.0, scr_B = 0.0;
+    if (c->nuis_diff) {
+        NuisHost* hn = c->host_nuis;
+        if (!wait_host_flag(&hn->diff_seq, c->diff_seq, c->stream3)) {
+            HIPCK(hipStreamSynchronize(c->stream3));
+            HIPCK(hipMemcpy((void*)hn->diff, c->scratch_diff, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+            HIPCK(hipMemcpy((void*)hn->sums, c->scratch_nuis, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+        }
+        long long d[8];
+        memcpy(d, (const void*)hn->diff, sizeof d);
+        c->nscr[0] += 1.0;
+        bool reject = false;
+        if (d[4] != 0 || d[3] <= 0 || !have_nzb) {
+            c->nscr[3] += 1.0; /* void: outside the screening term's domain, or the move did not come out of the batch commit */
+            if (d[4] & 1) c->nscr[8] += 1.0;  /* ... the parameter pair (one-log domain, size of the proposal) */
+            if (d[4] & 2) c->nscr[9] += 1.0;  /* ... a contact (ring, count, rank distance beyond the tables) */
+            if (d[4] & 4) c->nscr[10] += 1.0; /* ... a workgroup's sums (|log2 s|, |y|, not a number) */
+            if (!have_nzb) c->nscr[11] += 1.0;
+        } else {
+            long long hi = hn->nzb[0] + d[0], lo = hn->nzb[1] + d[1];
+            ig_acc_normalize((int64_t*)&hi, (int64_t*)&lo);
+            const double base = ig_acc_to_double(hi, lo);
+            scr_mid = base + (double)d[2] * (1.0 / DIFF_FIX);
+            scr_B = (double)d[3] * (1.0 / DIFF_FIX) + 1e-6 + 1e-14 * (__builtin_fabs(base) + __builtin_fabs(hn->res.o)); /* + the double roundings here */
+            scr_valid = true;
+            c->nscr[4] = std::max(c->nscr[4], scr_B);
+            c->nscr[6] += scr_B;
+            if (Tu && Tu[0] > 0.0 && Tu[1] > 0.0 && !g_nuis_screen_verify) {
+                const double z = nuis_z_from_sums((const long long*)hn->sums);
+                const double x_hi = (((scr_mid + scr_B) + z) - hn->res.o) / Tu[0];
+                reject = exp(x_hi) <= Tu[1] * (1.0 - 1e-9); /* exp is monotone: every L_test in the interval gives a ratio below u */
+            }
+            if (!reject) c->nscr[7] += 1.0;
+        }
+        if (reject) {
+            c->nscr[1] += 1.0;
+            c->nuis_screen_rejected = true;
+            c->nuis_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+            HIPCK(hipGetLastError());
+            drain_timers(c);
+            c->main_drained = c->nuis_spec;
+            *out = hn->res;
+            if (out->error) return fail("device-side consistency failure %d", out->error);
+            if (nz_test) *nz_test = scr_mid;
+            if (z_test) *z_test = nuis_z_from_sums((const long long*)hn->sums);
+            if (limbs5)
+                for (int i = 0; i < 5; i++) limbs5[i] = 0;
+            return 0;
+        }
+        c->nscr[2] += 1.0;
+        if (!c->nuis_exact_queued) launch_nuis_exact_tiles(c, c->stream3); /* the exact pass over the same list of tiles */
     }
     if (!(c->nuis_spec && c->nuis_pub_sums && wait_host_flag(&c->host_nuis->sums_seq, c->sums_seq, c->stream3))) {
         if (c->nuis_spec && c->nuis_pub_sums)
@@ -2101,6 +2403,15 @@ extern "C" int ig_nuis_end(ig_ctx* c, ig_move_result* out, double* nz_test, doub
     c->main_drained = c->nuis_spec; /* a run's step: its last kernel on the library stream has delivered (or the stream was synchronised) */
     *out = c->host_nuis->res;
     if (out->error) return fail("device-side consistency failure %d", out->error);
+    if (scr_valid) { /* the exact pass ran as well: how much of the bound did the screened sum use?  (verify mode: the check) */
+        long long e[2] = {c->host_nuis->sums[0], c->host_nuis->sums[1]};
+        ig_acc_normalize((int64_t*)&e[0], (int64_t*)&e[1]);
+        const double err = __builtin_fabs(scr_mid - ig_acc_to_double(e[0], e[1]));
+        if (scr_B > 0.0) c->nscr[5] = std::max(c->nscr[5], err / scr_B);
+        static const int s_nocheck = getenv("IG_NUIS_SCREEN_NOCHECK") ? atoi(getenv("IG_NUIS_SCREEN_NOCHECK")) : 0; /* tuning builds that compute garbage */
+        if (!(err <= scr_B) && !s_nocheck)
+            return fail("screened nuisance pass: |screened - exact| = %.6g exceeds its bound %.6g (move %d)", err, scr_B, c->spec_move - 1);
+    }
     long long h[8];
     memcpy(h, (const void*)c->host_nuis->sums, sizeof h);
     ig_acc_normalize((int64_t*)&h[0], (int64_t*)&h[1]);
@@ -2117,6 +2428,19 @@ extern "C" int ig_nuis_end(ig_ctx* c, ig_move_result* out, double* nz_test, doub
     }
     if (limbs5)
         for (int i = 0; i < 5; i++) limbs5[i] = h[i];
+    return 0;
+}
+
+extern "C" int ig_nuis_end(ig_ctx* c, ig_move_result* out, double* nz_test, double* z_test, int64_t* limbs5)
+{
+    return nuis_end_impl(c, out, nz_test, z_test, limbs5, nullptr);
+}
+
+/* {steps screened, rejected from the interval alone, exact passes behind a screened one, void, largest bound, largest used
+ * fraction of a bound (where the exact pass ran), sum of the bounds, steps whose interval did not decide} since the handle was made */
+extern "C" int ig_debug_nuis_screen_stats(ig_ctx* c, double out12[12])
+{
+    for (int i = 0; i < 12; i++) out12[i] = c->nscr[i];
     return 0;
 }
 
@@ -2170,7 +2494,11 @@ extern "C" int ig_nuis_accept(ig_ctx* c)
     long long* acc8 = c->scratch_accept;
     c->main_drained = false;
     const int w = c->spec_slot; /* the slot of the move just applied (0 unless it came out of a batch: ig_nuis_step_begin) */
-    nuis_spec_invalidate(c);    /* whatever was scored ahead was scored under the old parameters */
+    /* whatever was scored ahead was scored under the old parameters -- but only its parameter-dependent half: windows, candidate
+     * genomes, columns and slice lists of the batch's remaining slots stand (IG_NUIS_KEEP=0: redone as well) */
+    static const int s_keep = getenv("IG_NUIS_KEEP") ? atoi(getenv("IG_NUIS_KEEP")) : 1;
+    if (s_keep && c->nuis_spec) nuis_par_invalidate(c);
+    else nuis_spec_invalidate(c);
     const PzTab pz1{c->pz_tab1, c->pz_n1};
     /* the move's delta under the new parameters; contig membership of the partners as of BEFORE the move: tab_prev */
     hipLaunchKernelGGL(k_delta, dim3(DELTA_RB, 2, 1), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab_prev, c->tab_prev,
@@ -2198,12 +2526,14 @@ extern "C" int ig_nuis_step_next(ig_ctx* c, double temperature, double u, const 
 {
     if (!c->nuis_spec) return fail("ig_nuis_step_next: no run (ig_nuis_run_begin)");
     double nz = 0.0, z = 0.0;
-    if (ig_nuis_end(c, out, &nz, &z, nullptr)) return -1;
+    const double Tu[2] = {temperature, u};
+    if (nuis_end_impl(c, out, &nz, &z, nullptr, Tu)) return -1;
     if (nz_test) *nz_test = nz;
     if (z_test) *z_test = z;
     const double ratio = exp(((nz + z) - out->o) / temperature);
     int acc;
-    if (ratio != ratio) acc = 0; /* NaN >= u is false */
+    if (c->nuis_screen_rejected) acc = 0; /* every L_test of the screened interval gives a ratio below u */
+    else if (ratio != ratio) acc = 0; /* NaN >= u is false */
     else if (ratio >= u * (1.0 + 1e-9)) acc = 1;
     else if (ratio <= u * (1.0 - 1e-9)) acc = 0;
     else acc = 2;
@@ -2219,7 +2549,11 @@ extern "C" int ig_nuis_step_next(ig_ctx* c, double temperature, double u, const 
         hipLaunchKernelGGL(k_catch_up, dim3(16), dim3(256), 0, c->stream, c->tab, c->tab_prev, c->prev_touched, c->glob);
         HIPCK(hipEventRecord(c->ev_gathered, c->stream));
         c->nuis_caught_up = true;
-        if (nuis_spec_score(c, c->spec_move)) return -1;
+        if (nuis_spec_can_rescore(c, c->spec_move)) {
+            if (nuis_spec_rescore(c)) return -1;
+        } else if (nuis_spec_score(c, c->spec_move)) {
+            return -1;
+        }
     }
     return 0;
 }
@@ -2448,6 +2782,41 @@ extern "C" int ig_debug_tile_trace(ig_ctx* c, int64_t* out, int64_t cap, int64_t
     const int rc = ig_full_likelihood(c, 0, 0, &nz, nullptr, nullptr);
     c->tile_trace = nullptr;
     if (!rc) HIPCK(hipMemcpy(out, d, (size_t)32 * c->n_tile_work, hipMemcpyDeviceToHost));
+    hipFree(d);
+    return rc;
+}
+
+/* one screened nuisance pass (csrc/ig_kernels_nuis.cuh) under test parameters p_test on the tables of the state before the last
+ * move, every workgroup leaving {start, end (100 MHz clock), XCC_ID << 32 | HW_ID, items << 32 | contacts, ticks until its blocks
+ * were staged, ticks in its contact loops, 0, 0}: out [8 x n]; *n receives the number of workgroups; sums8 the pass's eight output
+ * words */
+extern "C" int ig_debug_diff_trace(ig_ctx* c, const float p_test[8], float mean_subfrag_kb, int64_t* out, int64_t cap, int64_t* n, int64_t* sums8)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (!c->tiled_cc || c->n_tile_work <= 0 || !c->score_const || !c->screen_const || !c->pz_tab) return fail("ig_debug_diff_trace: no tiled contacts / parameters");
+    const int grid = std::min(c->n_tile_work, 512);
+    *n = grid;
+    if (!out || cap < grid) return 0;
+    HIPCK(hipStreamSynchronize(c->stream));
+    HIPCK(hipStreamSynchronize(c->stream3));
+    if (ensure_host_nuis(c)) return -1;
+    if (!c->pz_tab1) DALLOC(c->pz_tab1, PZ_MAX);
+    const double need = (mean_subfrag_kb > 0) ? (double)p_test[5] / (double)mean_subfrag_kb + 2.0 : 0.0;
+    c->pz_n1 = (need > 0 && need < (double)PZ_MAX) ? (int)need : ((need >= (double)PZ_MAX) ? PZ_MAX : 0);
+    const ig_params hp = {p_test[0], p_test[1], p_test[2], p_test[3], p_test[4], p_test[5], p_test[6], p_test[7]};
+    long long* d = nullptr;
+    DALLOC(d, (size_t)8 * grid);
+    HIPCK(hipMemset(d, 0, (size_t)64 * grid));
+    c->diff_trace = d;
+    const bool sb = c->side_busy;
+    c->side_busy = false;
+    const int rc = launch_nuis_diff(c, hp, mean_subfrag_kb, c->stream3);
+    c->side_busy = sb;
+    c->diff_trace = nullptr;
+    c->nuis_diff = false;
+    HIPCK(hipStreamSynchronize(c->stream3));
+    if (!rc) HIPCK(hipMemcpy(out, d, (size_t)64 * grid, hipMemcpyDeviceToHost));
+    if (!rc && sums8) HIPCK(hipMemcpy(sums8, c->scratch_diff, 8 * sizeof(long long), hipMemcpyDeviceToHost));
     hipFree(d);
     return rc;
 }

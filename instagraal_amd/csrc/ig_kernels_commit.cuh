@@ -247,8 +247,20 @@ __device__ __forceinline__ void write_result(Glob* g, const MoveBuf& mb, int w, 
     *out = r;
 }
 
-__global__ void k_commit(Glob* g, MoveBuf mb, ig_move_result* res, int move, int w)
+__global__ void k_commit(Glob* g, MoveBuf mb, ig_move_result* res, int move, int w, int* dirty)
 {
+    /* dirty (a move of a batch finished with the one-move kernels, decided one move per call: ig_nuis_step_begin): its contigs
+     * onto the batch's list of modified contigs, as k_decide_batch does for the moves it commits itself */
+    if (dirty) {
+        const MoveCtl& mc = mb.ctl[w];
+        const CandMeta& m = mb.meta[CW(w, mc.ch_c)];
+        const int n = dirty[0];
+        if (n + 2 <= 2 * IG_MAX_BATCH + 2) {
+            dirty[1 + n] = m.ctgA;
+            dirty[2 + n] = m.ctgB;
+            dirty[0] = n + 2;
+        }
+    }
     g->next_cid += NFRESH;
     g->credit2 = g->credit2_acc;
     g->credit2_acc = 0;
@@ -335,6 +347,9 @@ __global__ void __launch_bounds__(64)
      * ig_nuis_step_begin): its contigs are on the list already */
     /* the contigs modified so far: entry q lives in lane q % 64 (register q / 64) -- the test of a move against the list is a
      * handful of compares and a ballot per candidate instead of a walk over an LDS array (it was a third of a decision) */
+    /* one wave, often next to a pass that fills the machine (the nuisance step's, on its own stream): first in line for its
+     * SIMD's issue slots (it took 70 us instead of 12 next to the persistent tiles kernel) */
+    __builtin_amdgcn_s_setprio(3);
     constexpr int ND = (IG_MAX_BATCH * 2 + 2 + 63) / 64;
     int dirty[ND];
 #pragma unroll
@@ -554,6 +569,8 @@ __global__ void __launch_bounds__(64)
                 o.bytes_min = by;
                 o.d_hi = 0;
                 o.d_lo = 0;
+                o.nzb_hi = nz_hi; /* the state this move was scored against (the nuisance step's screened pass starts from it) */
+                o.nzb_lo = nz_lo;
                 o.n_dirty = br_changed;
                 o.pad = (int)vmask; /* the stale flags this move was scored under */
                 if (br.k <= 0) g->error = 3; /* an unscored slot won: cannot happen */
@@ -859,6 +876,8 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
         __syncthreads();
         if (tid == 0) {
             hn->res = res[move0 + committed - 1];
+            hn->nzb[0] = mb.ctl[committed - 1].nzb_hi;
+            hn->nzb[1] = mb.ctl[committed - 1].nzb_lo;
             hn->max_L = g->max_L;
             hn->max_SL = g->max_SL;
             __threadfence_system();

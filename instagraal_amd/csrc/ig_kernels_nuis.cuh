@@ -1,0 +1,435 @@
+/* ig_kernels_nuis.cuh -- the nuisance step's Metropolis test (CL:2961-3051, 1296-1344) decided from a SCREENED pass.
+ *
+ * step_nuisance_parameters evaluates the full likelihood under its test parameters on the state before the last move and
+ * accepts iff exp((L_test - L_move) / T) >= u.  The exact pass (k_full_nz_tiled) costs ~90 us at the headline shape; once
+ * the chain has settled most steps are rejected, and |L_test - L_move - T ln u| is in the tens to hundreds, so a float
+ * evaluation of L_test itself (bound ~1000: sum(ob), sum(P) ~ 1e8 at u = 6e-8) decides only half of them
+ * (tools/nuis_margins.py).  What is screened here is the DIFFERENCE
+ *
+ *     D = sum over the contacts read this pass of [ t(theta_test) - t(theta_cur) ],
+ *
+ * whose float error scales with the size of the proposal (1 % steps), not with the terms: L_test = L_cur(state before the
+ * move; exact, the maintained sum) + (exact integer difference of the all-trans tiles' histogram sums) + D +- B, B ~ 10..50.
+ * A step whose interval lies entirely below T ln u is rejected without the exact pass; anything else (accepted, undecided,
+ * bound void) runs the exact pass as before -- an accepted step needs the exact sum for the promotion anyway.  The returned
+ * 8-tuple is unchanged (CL:3038-3051 returns likelihood_t, which a rejected step leaves alone).
+ *
+ * The term (ig_term_hot, linear contigs, one-log domain), per contact with count ob, distance s, rank distance d:
+ *     y = slope log2 s + la,   yy = in ? max(y, lv) : lv,   t = ob yy log10(2) - 2^yy - log10(ob!) + pzc[d]
+ * and its difference between two parameter sets (c = current, t = test; the log-factorial cancels):
+ *     dt = ob log10(2) dyy - 2^yy_c (2^dyy - 1) + (pzc_t[d] - pzc_c[d]),   dyy = yy_t - yy_c.
+ * Three classes of contacts, told apart with a guard band G >= the float error of y around the clamp levels:
+ *     A  in range under both sets and y_c > max(lv_c, lv_t) + G + DY:  neither clamps, dyy = dslope L + dla  (small, accurate)
+ *     B  out of range under both, or y_c < min(lv_c, lv_t) - G - DY:    both at their level: dyy = lv_t - lv_c and
+ *        2^yy_t - 2^yy_c = v_inter_t - v_inter_c are constants of the step (any size: a d_max proposal moves the level by tens of percent)
+ *     C  anything else (a thin shell around the clamp levels / between the two d_max): both terms evaluated in full;
+ *        full-size error, accounted term by term.
+ * DY = |dslope| LB + |dla| bounds |dy| over |log2 s| <= LB = 24 (checked at the end: a larger |L| voids the pass).
+ * 2^x - 1 for |x| <= 1/4 is a degree-6 polynomial in x ln 2 (truncation 5e-9 relative).
+ *
+ * Error budget, u = 2^-24, v_log_f32 / v_exp_f32 within K = 2 units of 2u (|result| + 1) resp. 2u result (measured over
+ * their whole domain: 0.98 / 0.71, tests/test_hip_screen.py fails above 2):
+ *     e(L) <= 4u (|L| + 1);  e(y_c) <= 5.25 u (|y_c| + Cy),  Cy = |la| + |slope| + |lv|;
+ *     e(dyy): A  u [ |dslope| (5 |L| + 4) + |dla| + |dy| ],  B  2 u |dlv|            =: u G
+ *     ob log10(2) dyy:  u log10(2) ob (G + 3 DX),  DX = max(DY, |dlv|)                 (rounding of ob log10(2), fma, pair add)
+ *     2^yy_c (2^dyy - 1) =: dex:  |dex| (4u + ln2 5.25 u (|yy| + Cy))  [v_exp_f32 and the error of its argument]
+ *                                 + |dex| 9 u [polynomial, products]  +  2^yy_c 0.84 u G  [sensitivity to e(dyy)]
+ *     final adds (DIFF_BATCH terms are added in float before they join the double sum), table conversion:
+ *                                 u ((2 + DIFF_BATCH) (log10(2) ob DX + |dex|) + (3 + DIFF_BATCH) |dpzc|)
+ *     the contract itself: two quantisations (2^-32 each) and its double roundings (4e-15 of the magnitudes)
+ * accumulated per workgroup from sum(ob), sum|dex|, sum|dex||yy|, sum 2^yy_c, max|L|, max|yy| and, for class C, a direct
+ * per-term bound.  IG_NUIS_SCREEN_VERIFY=1 runs the exact pass on every step as well and checks |screened - exact| <= B on
+ * the host (tests/test_hip_nuis_screen.py). */
+#pragma once
+
+#ifndef DIFF_THREADS
+#define DIFF_THREADS 512 /* two workgroups per CU (their LDS), four waves per SIMD: room for DIFF_BATCH x 2 contacts in flight per thread */
+#endif
+#ifndef DIFF_BATCH
+#define DIFF_BATCH 8
+#endif
+#define DIFF_X0 0.25f
+#define DIFF_LB 24.0f
+#define DIFF_FIX 1048576.0 /* 2^20: sums and bounds are published as integers (deterministic totals) */
+
+struct alignas(16) DiffConst {
+    float dpzc[LDS_PZ + 2]; /* (pzc_t - pzc_c)[d], the last entries: the trans level's */
+    float slope_c, la_c, lv_c, dslope, dla, dlv;
+    float slope_t, la_t, lv_t, dmax_c, dmax_t;
+    float dmin, dmax2;    /* min / max of the two d_max */
+    float hi_thr, lo_thr; /* class A above, class B below */
+    float cy;             /* max over the two sets of |la| + |slope| + |lv| (rounded up) */
+    float a_dslope, a_dla, a_dlv, dy_max; /* magnitudes (rounded up); DY */
+    float dex_b;          /* v_inter_t - v_inter_c: class B's 2^yy_t - 2^yy_c */
+    float pzc_abs_max;    /* largest |pzc| of either set */
+    unsigned cut;         /* rank distances from here on are not in the tables' LDS copies (a longer table: the pass is void if one occurs) */
+    int ok;               /* both sets in the one-log domain, DY and |dlv| within DIFF_X0 */
+};
+
+/* built by the blocks of k_nuis_prepare that build the test set's tables: thread i of that range */
+__device__ __forceinline__ void build_diff_const(int i, const Glob* g, const ig_params pt, float mean_kb, float pzv_t, int pz_n_t,
+                                                 const ScoreConst* __restrict__ sc0, int pz_n_c, DiffConst* out, const ScreenConst* __restrict__ scr0)
+{
+    const ig_params pc = g->par[0];
+    if (i < LDS_PZ + 2) {
+        const double t = (double)(i < min(pz_n_t, LDS_PZ) ? pzv_t : pt.v_inter) * IG_LOG_E_F;
+        out->dpzc[i] = (float)(t - sc0->tab.pzc[i]);
+    }
+    if (i == 0) {
+        const ig_hot hc = ig_hot_make(pc, ig_tab()), ht = ig_hot_make(pt, ig_tab());
+        const double dslope = ht.slope - hc.slope, dla = ht.log2_amp - hc.log2_amp, dlv = ht.log2_v_inter - hc.log2_v_inter;
+        out->slope_c = (float)hc.slope;
+        out->la_c = (float)hc.log2_amp;
+        out->lv_c = (float)hc.log2_v_inter;
+        out->slope_t = (float)ht.slope;
+        out->la_t = (float)ht.log2_amp;
+        out->lv_t = (float)ht.log2_v_inter;
+        out->dslope = (float)dslope;
+        out->dla = (float)dla;
+        out->dlv = (float)dlv;
+        out->dmax_c = hc.d_max;
+        out->dmax_t = ht.d_max;
+        out->dmin = fminf(hc.d_max, ht.d_max);
+        out->dmax2 = fmaxf(hc.d_max, ht.d_max);
+        const double up = 1.0 + 0x1p-20;
+        const double cyc = __builtin_fabs(hc.log2_amp) + __builtin_fabs(hc.slope) + __builtin_fabs(hc.log2_v_inter);
+        const double cyt = __builtin_fabs(ht.log2_amp) + __builtin_fabs(ht.slope) + __builtin_fabs(ht.log2_v_inter);
+        const double cy = __builtin_fmax(cyc, cyt) * up + 1e-6;
+        out->cy = (float)(cy * up);
+        const double a_ds = __builtin_fabs(dslope) * up, a_dl = __builtin_fabs(dla) * up, a_dv = __builtin_fabs(dlv) * up;
+        const double dy_max = (a_ds * (double)DIFF_LB + a_dl) * up;
+        out->a_dslope = (float)(a_ds * up);
+        out->a_dla = (float)(a_dl * up);
+        out->a_dlv = (float)(a_dv * up);
+        out->dy_max = (float)(dy_max * up);
+        out->dex_b = (float)((double)pt.v_inter - (double)pc.v_inter);
+        /* guard band: the float error of y (5.25 u (|y| + Cy), |y| <= 18 or the pass is void) and of y + dy, with room */
+        const double guard = 8.0 * 0x1p-24 * (19.0 + cy) + 1e-6;
+        out->hi_thr = (float)((__builtin_fmax(hc.log2_v_inter, ht.log2_v_inter) + guard + dy_max) + 1e-6 * (1.0 + cy));
+        out->lo_thr = (float)((__builtin_fmin(hc.log2_v_inter, ht.log2_v_inter) - guard - dy_max) - 1e-6 * (1.0 + cy));
+        out->cut = (pz_n_c > LDS_PZ || pz_n_t > LDS_PZ) ? (unsigned)LDS_PZ : 0xffffffffu;
+        out->ok = (hc.fast && ht.fast && pc.slope < 0.0f && pt.slope < 0.0f && dy_max <= (double)DIFF_X0 && a_dv <= 64.0 && cy < 200.0 &&
+                   pz_n_c > 0 && pz_n_t > 0 && scr0->pzc_max < 1e5f)
+                      ? 1
+                      : 0;
+    }
+    if (i == 1) { /* the largest |pzc| of either set (only a 4e-15 slack on the contract's own double roundings hangs on it):
+                   * the model's from its screening constants, the test set's from its largest entry -- P_z decreases with the
+                   * rank distance for slope < 0 (other slopes: the pass is void, see ok above), entry 0 is the trans level */
+        const float p1 = (mean_kb < pt.d_max) ? ig_rippe(mean_kb, pt, ig_tab()) : pt.v_inter;
+        const double mx = __builtin_fmax((double)scr0->pzc_max, (double)fmaxf(p1, pt.v_inter) * IG_LOG_E_F);
+        out->pzc_abs_max = (float)(mx * 1.001 + 1e-30);
+    }
+}
+
+struct DiffLds {
+    float dpzc[LDS_PZ + 2];
+    uint2 rrec[FULL_TB], crec[FULL_TB];
+    int rctg[FULL_TB], cctg[FULL_TB];
+    double red_s[DIFF_THREADS / 64];
+    float red_f[6][DIFF_THREADS / 64];
+    unsigned red_bad[DIFF_THREADS / 64];
+    int next_item;
+};
+
+/* out8: [0],[1] exact integer limbs (hist sums under the test set minus under the current set), [2] s_fix, [3] b_fix,
+ * [4] void flags, [5] contacts read */
+/* The pass is a stream of 8-byte contacts (160 MB at the headline shape) against two staged blocks: what bounds it is the
+ * number of loads in flight (Little's law: 2 per thread of 2 x 1024-thread workgroups per CU moved 1.9 TB/s, 85 us -- as long as
+ * the exact double-precision pass), so a thread keeps DIFF_BATCH contacts being summed and DIFF_BATCH more on their way. */
+__global__ void __launch_bounds__(DIFF_THREADS)
+    k_full_diff_tiled(const TileWork* __restrict__ work, const uint2* __restrict__ tc, const int4* __restrict__ rec, const DiffConst* __restrict__ dc,
+                      int M, long long* out8, int n_static, TileDyn* dyn, const int* __restrict__ dyn_list, NuisHost* hn, int hn_seq,
+                      const long long* __restrict__ partial_t, const long long* __restrict__ partial_c, int n_partial,
+                      const long long* __restrict__ zero_sums, long long* trace)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    DiffLds& L = *(DiffLds*)lds_raw;
+    /* trace (ig_debug_diff_trace): per workgroup {start, end (100 MHz clock), XCC_ID << 32 | HW_ID, items << 32 | contacts, ticks
+     * between an item's start and its blocks being staged, ticks in the contact loops} */
+    long long t_start = 0, t_stage = 0, t_loop = 0, t_mark = 0;
+    int n_items = 0;
+    if (trace && threadIdx.x == 0) t_start = (long long)wall_clock64();
+    __shared__ float s_pmx[DIFF_THREADS / 64];
+    {
+        float mx = 0.0f; /* the largest |dpzc| (the bound's table-conversion term) while the table goes to LDS */
+        for (int i = threadIdx.x; i < LDS_PZ + 2; i += blockDim.x) {
+            const float v = dc->dpzc[i];
+            L.dpzc[i] = v;
+            mx = fmaxf(mx, fabsf(v));
+        }
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
+        if ((threadIdx.x & 63) == 0) s_pmx[threadIdx.x >> 6] = mx;
+    }
+    const float slope_c = dc->slope_c, la_c = dc->la_c, lv_c = dc->lv_c, dslope = dc->dslope, dla = dc->dla, dlv = dc->dlv;
+    const float dmin = dc->dmin, dmax2 = dc->dmax2, hi_thr = dc->hi_thr, lo_thr = dc->lo_thr, dex_b = dc->dex_b;
+    /* (class C's constants as well: its branch is taken by most waves -- one lane near a clamp level is enough -- and must not
+     * start with a round trip to memory) */
+    const float slope_t = dc->slope_t, la_t = dc->la_t, lv_t = dc->lv_t, dmax_c = dc->dmax_c, dmax_t = dc->dmax_t, cy_f = dc->cy;
+    const unsigned cut = dc->cut;
+    const int ok = dc->ok;
+    const float c10 = (float)IG_LOG2_10_INV, ln2 = 0.69314718f;
+    double acc = 0.0;
+    float s_ob = 0.0f, s_dex = 0.0f, s_dexy = 0.0f, s_ex = 0.0f, l_max = 0.0f, y_max = 0.0f, b_c = 0.0f;
+    unsigned bad = ok ? 0u : 1u;
+    long long n_read = 0;
+    const int nth = blockDim.x;
+    __syncthreads();
+    for (int seq = (int)blockIdx.x; ok;) {
+        int it;
+        if (seq < n_static) {
+            it = seq;
+        } else {
+            if (seq - n_static >= dyn->count) break;
+            it = dyn_list[seq - n_static];
+        }
+        const TileWork wk = work[it];
+        const bool diag = wk.bi == wk.bj;
+        const uint2* src = tc + wk.off;
+        const int n = wk.n;
+        n_read += (threadIdx.x == 0) ? n : 0;
+        n_items++;
+        if (trace && threadIdx.x == 0) t_mark = (long long)wall_clock64();
+        uint2 nx[DIFF_BATCH];
+#pragma unroll
+        for (int q = 0; q < DIFF_BATCH; q++) nx[q] = src[min((int)threadIdx.x + q * nth, n - 1)];
+#if !(defined(DIFF_ABLATE) && (DIFF_ABLATE & 4)) /* tuning builds: no staging */
+        for (int i = threadIdx.x; i < FULL_TB; i += nth) {
+            const int gi = wk.bi * FULL_TB + i, gj = wk.bj * FULL_TB + i;
+            const int4 a = gi < M ? rec[gi] : make_int4(0, 0, -1, 0);
+            L.rrec[i] = make_uint2((unsigned)a.x, (unsigned)a.w | (__int_as_float(a.y) != 0.0f ? 0x80000000u : 0u));
+            L.rctg[i] = a.z;
+            if (!diag) {
+                const int4 b = gj < M ? rec[gj] : make_int4(0, 0, -2, 0);
+                L.crec[i] = make_uint2((unsigned)b.x, (unsigned)b.w | (__int_as_float(b.y) != 0.0f ? 0x80000000u : 0u));
+                L.cctg[i] = b.z;
+            }
+        }
+#endif
+        __syncthreads();
+        if (trace && threadIdx.x == 0) {
+            const long long now = (long long)wall_clock64();
+            t_stage += now - t_mark;
+            t_mark = now;
+        }
+        if (threadIdx.x == 0) L.next_item = (int)gridDim.x + atomicAdd(&dyn->next, 1);
+        const uint2* cre = diag ? L.rrec : L.crec;
+        const int* cct = diag ? L.rctg : L.cctg;
+#if defined(DIFF_ABLATE) && (DIFF_ABLATE & 8) /* tuning builds: the contacts are only read */
+        for (int e0 = threadIdx.x; e0 < n; e0 += DIFF_BATCH * nth) {
+            uint2 vv[DIFF_BATCH];
+#pragma unroll
+            for (int q = 0; q < DIFF_BATCH; q++) vv[q] = nx[q];
+#pragma unroll
+            for (int q = 0; q < DIFF_BATCH; q++) nx[q] = src[min(e0 + (DIFF_BATCH + q) * nth, n - 1)];
+#pragma unroll
+            for (int q = 0; q < DIFF_BATCH; q++) s_ob += (float)(vv[q].x ^ vv[q].y);
+        }
+#else
+        for (int e0 = threadIdx.x; e0 < n; e0 += DIFF_BATCH * nth) {
+            uint2 vv[DIFF_BATCH];
+#pragma unroll
+            for (int q = 0; q < DIFF_BATCH; q++) vv[q] = nx[q];
+#pragma unroll
+            for (int q = 0; q < DIFF_BATCH; q++) nx[q] = src[min(e0 + (DIFF_BATCH + q) * nth, n - 1)];
+            float dt[DIFF_BATCH];
+#pragma unroll
+            for (int q = 0; q < DIFF_BATCH; q++) {
+                const uint2 v = vv[q];
+                const bool live = e0 + q * nth < n;
+                const unsigned li = v.x & (FULL_TB - 1), lj = (v.x >> 11) & (FULL_TB - 1);
+#if defined(DIFF_ABLATE) && (DIFF_ABLATE & 2) /* tuning builds: no LDS gathers */
+                const uint2 ri = make_uint2(__float_as_uint((float)li), li), rj = make_uint2(__float_as_uint((float)lj * 1.5f), lj);
+                const bool cis = (li ^ lj) & 1;
+#else
+                const uint2 ri = L.rrec[li], rj = cre[lj];
+                const bool cis = L.rctg[li] == cct[lj];
+#endif
+                const unsigned d = abs_diff_u32(ri.y & 0x7fffffffu, rj.y & 0x7fffffffu);
+                const float sv = fabsf(__uint_as_float(ri.x) - __uint_as_float(rj.x));
+#if defined(DIFF_ABLATE) && (DIFF_ABLATE & 1) /* tuning builds: no transcendental functions */
+                const float lg = sv * 0.001f;
+#else
+                const float lg = __builtin_amdgcn_logf(sv);
+#endif
+                const float y = __builtin_fmaf(slope_c, lg, la_c);
+                const float dy = __builtin_fmaf(dslope, lg, dla);
+                const bool pos = cis && (sv > 0.0f);
+                const bool both_in = pos && (sv < dmin), any_in = pos && (sv < dmax2);
+                const bool A = both_in && (y > hi_thr);
+                const bool B = !any_in || (y < lo_thr);
+                float yy = A ? y : lv_c;
+                const float dyy = A ? dy : dlv;
+                float ex = __builtin_amdgcn_exp2f(yy);
+                const float z = dyy * ln2;
+                float e = __builtin_fmaf(z, 1.0f / 720.0f, 1.0f / 120.0f);
+                e = __builtin_fmaf(z, e, 1.0f / 24.0f);
+                e = __builtin_fmaf(z, e, 1.0f / 6.0f);
+                e = __builtin_fmaf(z, e, 0.5f);
+                e = __builtin_fmaf(z, e, 1.0f);
+                float dex = A ? ex * (z * e) : dex_b;
+                const float obf = (float)v.y;
+                const float m = obf * c10;
+                const float pz = L.dpzc[cis ? min(d, (unsigned)LDS_PZ) : (unsigned)LDS_PZ];
+                float t = __builtin_fmaf(m, dyy, -dex) + pz;
+                bad |= (live && ((cis && (((ri.y | rj.y) >> 31) || d >= cut)) || (v.y - 1u >= 16383u))) ? 2u : 0u;
+                float obacc = obf, lacc = A ? fabsf(lg) : 0.0f;
+                if (__any(live && !(A || B))) {
+                    if (!(A || B)) { /* class C: both terms in full */
+                        const bool in_c = pos && (sv < dmax_c), in_t = pos && (sv < dmax_t);
+                        const float yt0 = __builtin_fmaf(slope_t, lg, la_t);
+                        const float yc = in_c ? fmaxf(y, lv_c) : lv_c, yt = in_t ? fmaxf(yt0, lv_t) : lv_t;
+                        const float exc = __builtin_amdgcn_exp2f(yc), ext = __builtin_amdgcn_exp2f(yt);
+                        t = __builtin_fmaf(m, yt - yc, -(ext - exc)) + pz;
+                        const float ya = fabsf(yc) + fabsf(yt), ym = fmaxf(fabsf(yc), fabsf(yt));
+                        const float bc = m * (11.0f * ya + 11.0f * cy_f) + (exc + ext) * (8.0f + 3.7f * (ym + cy_f)) + 4.0f * fabsf(pz);
+                        b_c += live ? bc : 0.0f;
+                        y_max = fmaxf(y_max, live ? ym : 0.0f);
+                        obacc = 0.0f;
+                        lacc = 0.0f;
+                        dex = 0.0f;
+                        ex = 0.0f;
+                        yy = 0.0f;
+                    }
+                }
+                if (!live) {
+                    t = 0.0f;
+                    obacc = 0.0f;
+                    lacc = 0.0f;
+                    dex = 0.0f;
+                    ex = 0.0f;
+                    yy = 0.0f;
+                }
+                dt[q] = t;
+                s_ob += obacc;
+                s_dex += fabsf(dex);
+                s_dexy = __builtin_fmaf(fabsf(dex), fabsf(yy), s_dexy);
+                s_ex += ex;
+                l_max = fmaxf(l_max, lacc);
+                y_max = fmaxf(y_max, fabsf(yy));
+            }
+            float ts = 0.0f; /* a few float additions before the double one: u sum|dt| of them, inside T3's 3 |dex| + ... */
+#pragma unroll
+            for (int q = 0; q < DIFF_BATCH; q++) ts += dt[q];
+            acc += (double)ts;
+        }
+#endif
+        __syncthreads();
+        if (trace && threadIdx.x == 0) t_loop += (long long)wall_clock64() - t_mark;
+        seq = L.next_item;
+    }
+    /* ---- the workgroup's sum and bound */
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_down(acc, o, 64);
+        s_ob += __shfl_down(s_ob, o, 64);
+        s_dex += __shfl_down(s_dex, o, 64);
+        s_dexy += __shfl_down(s_dexy, o, 64);
+        s_ex += __shfl_down(s_ex, o, 64);
+        b_c += __shfl_down(b_c, o, 64);
+        l_max = fmaxf(l_max, __shfl_down(l_max, o, 64));
+        y_max = fmaxf(y_max, __shfl_down(y_max, o, 64));
+        bad |= __shfl_down(bad, o, 64);
+        n_read += __shfl_down(n_read, o, 64);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+        L.red_s[wv] = acc;
+        L.red_f[0][wv] = s_ob;
+        L.red_f[1][wv] = s_dex;
+        L.red_f[2][wv] = s_dexy;
+        L.red_f[3][wv] = s_ex;
+        L.red_f[4][wv] = b_c;
+        L.red_f[5][wv] = fmaxf(l_max, 0.0f);
+        L.red_bad[wv] = bad;
+    }
+    /* y_max rides in a second step (six float slots): through lane 0's registers of wave 0 below */
+    __shared__ float s_ymax[FULL_TILED_THREADS / 64];
+    __shared__ long long s_nread[FULL_TILED_THREADS / 64];
+    if (lane == 0) {
+        s_ymax[wv] = y_max;
+        s_nread[wv] = n_read;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S = 0.0, Sob = 0.0, Sdex = 0.0, Sdexy = 0.0, Sex = 0.0, Bc = 0.0, Lm = 0.0, Ym = 0.0;
+        unsigned Bd = 0;
+        long long n = 0;
+        for (int v = 0; v < (int)(blockDim.x >> 6); v++) {
+            S += L.red_s[v];
+            Sob += (double)L.red_f[0][v];
+            Sdex += (double)L.red_f[1][v];
+            Sdexy += (double)L.red_f[2][v];
+            Sex += (double)L.red_f[3][v];
+            Bc += (double)L.red_f[4][v];
+            Lm = __builtin_fmax(Lm, (double)L.red_f[5][v]);
+            Ym = __builtin_fmax(Ym, (double)s_ymax[v]);
+            Bd |= L.red_bad[v];
+            n += s_nread[v];
+        }
+        if (ok && n > 0) {
+            const double u = 0x1p-24, c10d = IG_LOG2_10_INV;
+            const double cy = dc->cy, a_ds = dc->a_dslope, a_dl = dc->a_dla, a_dv = dc->a_dlv, DY = dc->dy_max;
+            const double DX = __builtin_fmax(DY, a_dv);
+            const double G = 1.05 * __builtin_fmax(a_ds * (5.0 * Lm + 4.0) + a_dl + DY, 2.0 * a_dv);
+            double pmx = 0.0; /* largest |dpzc| */
+            for (int q = 0; q < (int)(blockDim.x >> 6); q++) pmx = __builtin_fmax(pmx, (double)s_pmx[q]);
+            const double nn = (double)n;
+            const double fa = 1.0 + 2.0 * u * (nn / (double)blockDim.x + 32.0) * 2.0; /* the float accumulators' own roundings */
+            const double T1 = u * c10d * Sob * (G + 3.0 * DX);
+            const double T2 = u * (13.0 * Sdex + 3.68 * (Sdexy + cy * Sdex) + 0.84 * G * Sex);
+            const double T3 = u * ((2.0 + DIFF_BATCH) * c10d * Sob * DX + (2.0 + DIFF_BATCH) * Sdex + (3.0 + DIFF_BATCH) * nn * pmx);
+            const double T4 = nn * 0x1p-31 + 4e-15 * (Sob * (Ym + 5.0) + 2.6 * Sex + nn * (double)dc->pzc_abs_max);
+            const double bound = 1.01 * fa * (T1 + T2 + T3 + u * Bc) + T4 + 2.0 / DIFF_FIX;
+            /* outside the screening term's domain: |L| beyond the bound DY was derived for, |yy| beyond the contract's clamp
+             * (|t| < 2^20 needs P < 2^18 and counts < 2^14), anything not a number */
+            if (!(Lm <= (double)DIFF_LB) || !(Ym <= 17.5) || !(__builtin_fabs(S) < 1e15) || !(bound < 1e12)) Bd |= 4u;
+            atomic_add_ll(&out8[2], (long long)__builtin_rint(S * DIFF_FIX));
+            atomic_add_ll(&out8[3], (long long)__builtin_ceil(bound * DIFF_FIX));
+            atomic_add_ll(&out8[5], n);
+        }
+        if (Bd) atomicOr((unsigned long long*)&out8[4], (unsigned long long)Bd);
+    }
+    /* the all-trans tiles: exact integer histogram sums under the test set minus under the current set (k_tile_trans) */
+    if (blockIdx.x == 0 && ok) {
+        long long hi = 0, lo = 0;
+        for (int i = threadIdx.x; i < n_partial; i += blockDim.x) {
+            hi += partial_t[2 * (size_t)i] - partial_c[2 * (size_t)i];
+            lo += partial_t[2 * (size_t)i + 1] - partial_c[2 * (size_t)i + 1];
+        }
+        hi = wave_sum_ll(hi);
+        lo = wave_sum_ll(lo);
+        if (lane == 0 && (hi | lo)) {
+            atomic_add_ll(&out8[0], hi);
+            atomic_add_ll(&out8[1], lo);
+        }
+    }
+    /* the last workgroup through: the cursors back for the exact pass that may follow over the same list, the sums to the
+     * (mapped) host memory, then the flag */
+    __syncthreads(); /* (block 0: every wave's share of the histogram sums is out) */
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&dyn->done, 1) == (int)gridDim.x - 1) {
+            __threadfence();
+            dyn->next = 0;
+            dyn->done = 0;
+            if (hn) {
+                for (int q = 0; q < 8; q++) hn->diff[q] = __hip_atomic_load(&out8[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int q = 0; q < 8; q++) hn->sums[q] = __hip_atomic_load(&zero_sums[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence_system();
+                hn->diff_seq = hn_seq;
+            }
+        }
+        if (trace) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            long long* tr = trace + 8 * (size_t)blockIdx.x;
+            tr[0] = t_start;
+            tr[1] = (long long)wall_clock64();
+            tr[2] = (long long)(((unsigned long long)xcc << 32) | hw);
+            tr[3] = ((long long)n_items << 32) | (n_read & 0xffffffffLL);
+            tr[4] = t_stage;
+            tr[5] = t_loop;
+        }
+    }
+}

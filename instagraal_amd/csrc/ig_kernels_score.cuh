@@ -1195,8 +1195,11 @@ struct FullTiledLds {
 __global__ void __launch_bounds__(TILE_TRANS_THREADS) k_tile_trans(const TileInfo* __restrict__ tiles, int n_tiles, const unsigned* __restrict__ sig,
                                                     const unsigned* __restrict__ hist, const ScoreConst* __restrict__ sc, TileDyn* dyn,
                                                     int* __restrict__ dyn_list, int use_hist, long long* partial, int n_trans_blocks, Tables zt,
-                                                    const Glob* g, int which, int M, long long* zero_out)
+                                                    const Glob* g, int which, int M, long long* zero_out,
+                                                    const ScoreConst* __restrict__ sc0 = nullptr, long long* partial0 = nullptr)
 {
+    /* sc0 / partial0 (the screened nuisance pass, ig_kernels_nuis.cuh): the same histogram sums under a second parameter set
+     * (the model's current one) -> partial0: the difference of the two is the exact change of the all-trans tiles' share */
     const unsigned* fold = sig + (size_t)((M + FULL_TB - 1) / FULL_TB) * SIG_WORDS; /* the folded signatures (k_pack_tab_sig) */
     /* the zero-pixel blocks first: they are the longer ones (dispatched first, they run next to the tiles' instead of behind them) */
     const int n_zero_blocks = (int)gridDim.x - n_trans_blocks;
@@ -1224,7 +1227,8 @@ __global__ void __launch_bounds__(TILE_TRANS_THREADS) k_tile_trans(const TileInf
     }
     const bool fast = sc->hot.fast;
     const unsigned long long qt_lane = sc->qtrans[lane]; /* the table of trans terms of this parameter set (k_build_score_const) */
-    long long hi = 0, lo = 0;
+    const unsigned long long q0_lane = sc0 ? sc0->qtrans[lane] : IG_QMAGIC_BITS;
+    long long hi = 0, lo = 0, hi0 = 0, lo0 = 0;
     if (t < n_tiles) {
         if (__any(both != 0u) || !use_hist || !fast) { /* a contig in both blocks (or its alias): read the contacts */
             int base = 0;
@@ -1238,25 +1242,46 @@ __global__ void __launch_bounds__(TILE_TRANS_THREADS) k_tile_trans(const TileInf
             const unsigned long long pl = n * ql; /* < 2^63: a tile holds fewer than 2^31 contacts */
             hi = (long long)n * qh + (long long)(pl >> 32);
             lo = (long long)(pl & 0xffffffffull);
+            if (sc0) {
+                const long long q0 = (long long)(q0_lane - IG_QMAGIC_BITS);
+                const unsigned long long ql0 = (unsigned)q0;
+                const long long qh0 = (q0 - (long long)ql0) >> 32;
+                const unsigned long long pl0 = n * ql0;
+                hi0 = (long long)n * qh0 + (long long)(pl0 >> 32);
+                lo0 = (long long)(pl0 & 0xffffffffull);
+            }
         }
     }
     hi = wave_sum_ll(hi);
     lo = wave_sum_ll(lo);
+    __shared__ long long red0[2][TILE_TRANS_THREADS / 64];
+    if (sc0) {
+        hi0 = wave_sum_ll(hi0);
+        lo0 = wave_sum_ll(lo0);
+    }
     if (lane == 0) {
         red[0][wv] = hi;
         red[1][wv] = lo;
+        red0[0][wv] = hi0;
+        red0[1][wv] = lo0;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        hi = lo = 0;
+        hi = lo = hi0 = lo0 = 0;
         for (int q = 0; q < TILE_TRANS_THREADS / 64; q++) {
             hi += red[0][q];
             lo += red[1][q];
+            hi0 += red0[0][q];
+            lo0 += red0[1][q];
         }
         /* one pair of words per workgroup, summed by the first workgroup of k_full_nz_tiled: thousands of workgroups adding to
          * the same two words with atomics took 36 ns each, one after the other (97 us at 43 k tiles) */
         partial[2 * (size_t)tb] = hi;
         partial[2 * (size_t)tb + 1] = lo;
+        if (partial0) {
+            partial0[2 * (size_t)tb] = hi0;
+            partial0[2 * (size_t)tb + 1] = lo0;
+        }
     }
 }
 
@@ -1265,9 +1290,15 @@ __global__ void __launch_bounds__(TILE_TRANS_THREADS) k_tile_trans(const TileInf
  * come from the host, so nothing here waits for anything else.  Blocks [0, n_pack): the records and signatures of a block
  * of sub-fragments; the blocks behind: P_z table and score constants of the set (same expressions as k_build_pz and
  * k_build_score_const). */
+struct DiffConst;
+struct ScreenConst;
+__device__ __forceinline__ void build_diff_const(int i, const Glob* g, const ig_params pt, float mean_kb, float pzv_t, int pz_n_t,
+                                                 const ScoreConst* __restrict__ sc0, int pz_n_c, DiffConst* out, const ScreenConst* __restrict__ scr0);
 __global__ void __launch_bounds__(256) k_nuis_prepare(Glob* g, int which, ig_params p, float mean_kb, float* __restrict__ pz, int pz_n,
                                                       const double* __restrict__ lgf_tab, ScoreConst* out, long long* scratch8, Tables t,
-                                                      int M, int4* __restrict__ rec, unsigned* __restrict__ sig, int tb, int* dyn2, int n_pack)
+                                                      int M, int4* __restrict__ rec, unsigned* __restrict__ sig, int tb, int* dyn2, int n_pack,
+                                                      const ScoreConst* __restrict__ sc0 = nullptr, int pz_n0 = 0, DiffConst* dc = nullptr,
+                                                      long long* diff8 = nullptr, const ScreenConst* __restrict__ scr0 = nullptr)
 {
     if ((int)blockIdx.x < n_pack) {
         pack_tab_sig_block(t, M, rec, sig, tb, dyn2);
@@ -1287,11 +1318,14 @@ __global__ void __launch_bounds__(256) k_nuis_prepare(Glob* g, int which, ig_par
         g->par[which] = p;
         g->mean_kb = mean_kb;
         for (int q = 0; q < 8; q++) scratch8[q] = 0;
+        if (diff8)
+            for (int q = 0; q < 8; q++) diff8[q] = 0;
     }
     if (i < TILE_HB) {
         const ig_hot h = ig_hot_make(p, ig_tab());
         out->qtrans[i] = i ? trans_term_bits((unsigned)i, h.log2_v_inter, ig_tab(), lgf_tab, (double)p.v_inter * IG_LOG_E_F) : IG_QMAGIC_BITS;
     }
+    if (dc) build_diff_const(i, g, p, mean_kb, pzv, pz_n, sc0, pz_n0, dc, scr0); /* the screened pass (ig_kernels_nuis.cuh) */
 }
 
 __global__ void __launch_bounds__(FULL_TILED_THREADS, 8) /* 8 waves per SIMD: two workgroups per CU need <= 80 SGPRs (112 admit 6 waves) */
@@ -1720,6 +1754,12 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
         qp[Q_TAIL + 2 * k + 1] = 0;
     }
     __syncthreads();
+    if (mb.stale) { /* scored earlier, re-evaluated now: not if a move committed meanwhile modified one of its contigs (MoveBuf.stale) */
+        const int nd = mb.stale[0];
+        int hit = 0;
+        for (int q = tid; q < nd; q += blockDim.x) hit |= (mb.stale[1 + q] == m.ctgA) | (mb.stale[1 + q] == m.ctgB);
+        if (__syncthreads_or(hit)) return;
+    }
     const long long Sc = slice_total(part);
     const int r = (int)(Sc % 64);
     if (!(tail_quirk && r > 0)) return;

@@ -705,8 +705,11 @@ __global__ void __launch_bounds__(256) k_contend(Glob* g, MoveBuf mb, const Scre
     if (tid == 0) {
         long long tot = 0;
         for (int c = 0; c < C; c++) tot += slice_total(mb.part + (size_t)CW(w, c) * P_STRIDE) * __popc(s_mask[c] & ~s_ident[c]);
-        long long ch = chunk0;
-        while (tot / ch + (long long)C * NSLOT * SLICE_SEG > grid_cap / 2) ch *= 2;
+        /* (the constant part -- at most one partly filled item per (candidate, column, segment) -- does not shrink with ch: the
+         * host keeps grid_cap above twice that for the widest move (exact_grid_floor); should it ever not be, the loop ends at
+         * whole segments, k_worklist flags the slot (overflow 2) and the host enlarges the grid) */
+        long long ch = chunk0 > 0 ? chunk0 : EXACT_CHUNK;
+        while (ch < (1LL << 40) && tot / ch + (long long)C * NSLOT * SLICE_SEG > grid_cap / 2) ch *= 2;
         mb.ctl[w].exact_chunk = (int)ch;
         s_kind[0] = (int)ch; /* (the intervals are done with) */
     }

@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(HERE, "libinstagraal_hip.so")
 SRC = os.path.join(HERE, "csrc", "ig_hip.hip")
 SRC_HOST = os.path.join(HERE, "csrc", "ig_draw.cpp")  # host-only part: the candidate draw
 DEPS = [SRC, SRC_HOST] + [os.path.join(HERE, "csrc", f) for f in ("ig_ops.cuh", "ig_common.cuh", "ig_model.cuh", "ig_kernels_setup.cuh",
-                                                          "ig_kernels_score.cuh", "ig_kernels_screen.cuh", "ig_kernels_commit.cuh")] + \
+                                                          "ig_kernels_score.cuh", "ig_kernels_screen.cuh", "ig_kernels_commit.cuh",
+                                                          "ig_kernels_nuis.cuh")] + \
        [os.path.join(ROOT, "include", f) for f in ("ig_detmath.h", "ig_detmath_tables.h", "instagraal_hip.h")]
 
 N_TMP_STRUCT = 24
@@ -168,6 +169,11 @@ def set_batch_width(w):
 def set_nuis_width(w):
     """moves scored ahead per launch by the nuisance-on loop (``Context.nuis_step_begin``); 0 = follow the run lengths"""
     _ck(lib().ig_set_nuis_width(C.c_int(int(w))))
+
+
+def set_nuis_screen(on):
+    """the Metropolis test of the nuisance steps from the screened pass where it decides (default), or always from the exact one"""
+    _ck(lib().ig_set_nuis_screen(C.c_int(int(on))))
 
 
 def debug_set_full_hist(on):
@@ -369,10 +375,30 @@ class Context:
         _ck(lib().ig_debug_tile_trace(self._h, _p(out), C.c_int64(n.value), C.byref(n)))
         return out
 
+    def debug_diff_trace(self, p_test8, mean_subfrag_kb):
+        """one screened nuisance pass under p_test -> ((n, 8) int64 per-workgroup clocks, the pass's 8 output words)"""
+        p = np.ascontiguousarray(p_test8, np.float32)
+        n = C.c_int64()
+        _ck(lib().ig_debug_diff_trace(self._h, _p(p), C.c_float(float(mean_subfrag_kb)), C.c_void_p(0), C.c_int64(0), C.byref(n), C.c_void_p(0)))
+        out = np.zeros((n.value, 8), np.int64)
+        sums = np.zeros(8, np.int64)
+        _ck(lib().ig_debug_diff_trace(self._h, _p(p), C.c_float(float(mean_subfrag_kb)), _p(out), C.c_int64(n.value), C.byref(n), _p(sums)))
+        return out, sums
+
     def debug_nuis_wait(self):
         s = C.c_double()
         _ck(lib().ig_debug_nuis_wait(self._h, C.byref(s)))
         return s.value
+
+    def debug_nuis_screen_stats(self):
+        """the screened nuisance pass (csrc/ig_kernels_nuis.cuh): steps screened, rejected from the interval alone, exact passes
+        run behind a screened one, void, largest bound, largest |screened - exact| / bound, mean bound, undecided"""
+        o = np.zeros(12, np.float64)
+        _ck(lib().ig_debug_nuis_screen_stats(self._h, _p(o)))
+        n = max(o[0] - o[3], 1.0)
+        return dict(screened=int(o[0]), rejected_screened=int(o[1]), exact_passes=int(o[2]), void=int(o[3]), largest_bound=float(o[4]),
+                    largest_used_fraction=float(o[5]), mean_bound=float(o[6] / n), undecided=int(o[7]),
+                    void_why=dict(parameters=int(o[8]), contact=int(o[9]), sums=int(o[10]), no_record=int(o[11])))
 
     def batch_stats(self):
         o = np.zeros(4, np.int64)

@@ -104,6 +104,7 @@ class BatchRunner:
         self._bufs = None
         self._key = None
         self._stream = None
+        self._into_tensor = None  # all_gather_into_tensor (RCCL) or all_gather of a list (gloo): _exchange
         self.batches = 0
         self._ema = float(self.width)  # moves a batch gets through, moving average: sets the next width (as ig_step_batch)
 
@@ -130,9 +131,16 @@ class BatchRunner:
         chunk = per * b
         out = t[: self.world * chunk]
         mine = out[self.rank * chunk:(self.rank + 1) * chunk].clone()
-        try:
+        # which collective is decided up front from the backend, never by catching a failure: on RCCL a failed collective
+        # poisons the communicator, and a fallback would hide the first real error.  gloo (the CPU / one-device test rigs) has
+        # no all_gather_into_tensor; the in-process stand-ins of the tests implement what they are asked for.
+        if self._into_tensor is None:
+            get_backend = getattr(self.dist, "get_backend", None)
+            backend = str(get_backend()).lower() if get_backend is not None else ""
+            self._into_tensor = hasattr(self.dist, "all_gather_into_tensor") and backend != "gloo"
+        if self._into_tensor:
             self.dist.all_gather_into_tensor(out, mine)
-        except (RuntimeError, AttributeError, NotImplementedError):
+        else:
             parts = [out[r * chunk:(r + 1) * chunk] for r in range(self.world)]
             self.dist.all_gather(parts, mine)
 

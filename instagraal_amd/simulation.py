@@ -238,8 +238,19 @@ class instagraal_class:
 
 
 def run_instagraal(hic_folder, reference_fa, output_folder=None, level=4, cycles=100, coverage_std=1, neighborhood=5, device=0,
-                   circular=False, bomb=False, pyramid_only=False):
-    """IG:502-581 (defaults of cli/main.py: level 4, 100 cycles, 5 neighbours, 1 std)."""
+                   circular=False, bomb=False, pyramid_only=False, save_pickle=False, save_matrix=False, simple=False):
+    """IG:502-581 (defaults of cli/main.py: level 4, 100 cycles, 5 neighbours, 1 std).  The three trailing switches of the
+    reference's signature (IG:512-514) are accepted: ``save_pickle`` dumps the run object to ``graal.pkl`` as the reference
+    tries to (IG:589-594: a warning when it cannot be pickled -- device handles here, h5py handles there); ``save_matrix``
+    asks for the matplotlib contact-map previews of ``display_current_matrix`` (IG:279-284), which are outside this path
+    (SURVEY 2a): ignored with a warning; ``simple`` calls ``instagraal_class.simple_start``, a method the reference does not
+    define (IG:582 raises AttributeError): refused."""
+    import warnings
+
+    if simple and not pyramid_only:
+        raise NotImplementedError("simple=True: the reference calls instagraal_class.simple_start (instagraal.py:582), which it does not define")
+    if save_matrix:
+        warnings.warn("save_matrix: the per-cycle contact-map previews (instagraal.py:279-284, matplotlib) are not part of this path; ignored")
     name = os.path.basename(os.path.normpath(str(hic_folder)))
     if pyramid_only:
         root = str(output_folder) if output_folder is not None else os.path.join(os.getcwd(), "results")
@@ -251,10 +262,20 @@ def run_instagraal(hic_folder, reference_fa, output_folder=None, level=4, cycles
     if circular:
         # IG:569-570: the flag is applied to the loader's arrays AFTER the sampler copied them to the device, i.e. it
         # has no effect on the run in the reference either (quirk Q14).  Accepted and applied the same (ineffective) way.
-        import warnings
-
         warnings.warn("--circular has no effect on the assembly (as in the reference: instagraal.py:569-570 sets the flag "
                       "after the sampler copied the fragment arrays)")
         p2.simulation.level.S_o_A_frags["circ"] += 1
     p2.full_em(n_cycles=cycles, n_neighbours=neighborhood, bomb=bomb, id_start_sample_param=4)
+    if save_pickle:  # IG:589-594
+        import pickle
+
+        try:
+            with open("graal.pkl", "wb") as h:
+                pickle.dump(p2, h)
+        except Exception as e:  # ctypes handles do not pickle (the reference: h5py handles)
+            warnings.warn("could not pickle the run state: %s" % (e,))
+            try:
+                os.remove("graal.pkl")
+            except OSError:
+                pass
     return p2

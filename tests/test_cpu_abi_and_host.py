@@ -55,9 +55,10 @@ def test_rippe_fit_matches_reference_host_functions():
     # the model has two identifiable parameters (slope and the amplitude A 0.53 kuhn^-3 (lm / kuhn)^slope) for the three
     # numbers kuhn, lm, A: leastsq stops anywhere on that valley, and WHERE depends on the last bits of numpy's log (which
     # vary with array alignment, i.e. with what was imported before) -- in the reference as well.  Pinned: slope, d, the curve.
+    # (the fixture holds just that, in a form tools/gen_golden.py regenerates bit for bit)
     fit = np.array(fit, dtype=np.float64)
-    assert abs(fit[2] - g["fit"][2]) < 1e-9 and fit[3] == g["fit"][3]
-    assert np.allclose(y, g["y_est"], rtol=1e-8, atol=0)
+    assert abs(fit[2] - float(g["fit_slope"])) < 2e-8 and fit[3] == float(g["fit_d"])
+    assert np.allclose(y, g["y_est"].astype(np.float64), rtol=1e-6, atol=0)
 
 
 def test_draw_unit_under_address_and_ub_sanitizers(tmp_path):
@@ -252,3 +253,15 @@ def test_c_draw_on_synthetic_problem_and_errors():
         st.neighbours.draw(np.array([prob.n_frags], np.int32), 5)
     with pytest.raises(hip_lib.HipError):
         st.neighbours.draw(frags[:3], 17)
+    # an out-of-range fragment BEHIND valid ones: nothing is drawn, numpy's generator is exactly where it was
+    np.random.seed(11)
+    before = np.random.get_state()
+    bad = np.array([3, 9, prob.n_frags + 4, 1], np.int32)
+    with pytest.raises(hip_lib.HipError):
+        st.neighbours.draw(bad, 5)
+    after = np.random.get_state()
+    assert np.array_equal(before[1], after[1]) and before[2:] == after[2:]
+    with pytest.raises(hip_lib.HipError):
+        st.neighbours.draw_nuisance(bad, 5)
+    after = np.random.get_state()
+    assert np.array_equal(before[1], after[1]) and before[2:] == after[2:]

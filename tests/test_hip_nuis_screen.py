@@ -1,0 +1,110 @@
+"""GPU tests of the screened nuisance pass (csrc/ig_kernels_nuis.cuh): the Metropolis test of step_nuisance_parameters
+(CL:3023-3036) decided from a float evaluation of the likelihood CHANGE between the model's and the test parameters with a
+rigorous bound; the exact pass only where the interval does not decide.
+
+* IG_NUIS_SCREEN_VERIFY=1 runs both passes on every step and fails the call when |screened - exact| exceeds the bound;
+* the run with screening, the run without (every step through the exact pass) and the verified run return the same move
+  records, the same 8-tuples (fact, d, d_max, d_nuc, slope, likelihood_t, success), the same parameters, genome, generator
+  state and maintained exact sums;
+* over a long settled run most steps are decided by the screened pass alone."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(prob, n, seed, mode, monkeypatch, coo=False, params=None, warm=0):
+    """mode: 'exact' (screening off), 'screened' (default), 'verify'"""
+    from instagraal_amd import hip_lib
+    from instagraal_amd.sampler import sampler as hip_sampler
+
+    monkeypatch.delenv("IG_NUIS_SCREEN_VERIFY", raising=False)
+    if mode == "verify":
+        monkeypatch.setenv("IG_NUIS_SCREEN_VERIFY", "1")
+    hip_lib.set_nuis_screen(mode != "exact")
+    try:
+        np.random.seed(seed)
+        s = hip_sampler(**prob.sampler_kwargs(), device_id=0, coo=(prob.coo_row, prob.coo_col, prob.coo_cnt) if coo else None)
+        s.set_param_simu(prob.params if params is None else params)
+        s.bins = np.arange(1.0, 60.0, 1.0)
+        s.eval_likelihood_init()
+        frags = np.resize(np.random.permutation(prob.n_frags), n + warm)
+        if warm:
+            s.step_sampler_nuisance_batch(frags[:warm], 5, s.dt, 0, n + warm)
+        res, tuples = s.step_sampler_nuisance_batch(frags[warm:], 5, s.dt, warm, n + warm)
+        rows = res[["o", "dist", "op_sampled", "id_f_sampled", "n_contigs"]].tobytes()
+        nu = [tuple(float(np.ravel(x)[0]) for x in q[:7]) for q in tuples]
+        sums, _ = s.ctx.debug_globals()
+        _, _, limbs = s.ctx.full_likelihood(0)
+        assert [int(x) for x in sums[:5]] == [int(x) for x in limbs[:5]]
+        out = (rows, nu, s.gpu_vect_frags.copy_from_gpu().soa17().tobytes(), np.random.get_state()[1][:8].tobytes(),
+               [float(s.param_simu[k][0]) for k in ("fact", "slope", "d_max", "v_inter")])
+        stats = s.ctx.debug_nuis_screen_stats()
+        s.free_gpu()
+        return out, stats
+    finally:
+        hip_lib.set_nuis_screen(1)
+
+
+@pytest.mark.parametrize("cfg,n", [("tiny", 250), ("small", 400), ("cfg2", 500)])
+def test_screened_pass_bound_holds_and_changes_nothing(cfg, n, monkeypatch):
+    from instagraal_amd import synth
+
+    prob = synth.make_problem(*synth.CONFIGS[cfg])
+    exact, st0 = _run(prob, n, 5, "exact", monkeypatch)
+    verified, st1 = _run(prob, n, 5, "verify", monkeypatch)  # raises when a bound is violated
+    screened, st2 = _run(prob, n, 5, "screened", monkeypatch)
+    assert st0["screened"] == 0
+    assert verified == exact
+    assert screened == exact
+    print(cfg, "verify:", st1, "\n    screened:", st2)
+    assert st1["screened"] > 0.9 * n and st1["largest_used_fraction"] < 0.5  # rigorous, hence loose
+    assert st2["rejected_screened"] > 0  # steps were decided without the exact pass
+    assert 0 < sum(q[6] for q in exact[1]) < n  # accepted and rejected steps
+
+
+def test_screened_pass_other_parameters_and_large_counts(monkeypatch):
+    """parameter sets at the edges of the screening term's domain (slope 0: not in the one-log domain, the pass is void and
+    every step takes the exact pass; a shallow slope with a low trans level), and counts in the thousands"""
+    import copy
+
+    import scipy.sparse as sp
+
+    from instagraal_amd import synth
+
+    prob = copy.deepcopy(synth.make_problem(*synth.CONFIGS["small"]))
+    cnt = prob.coo_cnt.copy()
+    cnt[::5] *= 70
+    cnt[::53] *= 500
+    prob.coo_cnt = cnt
+    M = prob.n_sub_frags
+    prob.sub_csr = sp.csr_matrix((cnt, (prob.coo_row, prob.coo_col)), shape=(M, M), dtype=np.int32)
+    prob.sub_csr.sort_indices()
+    for params in (prob.params, dict(prob.params, slope=-0.7, v_inter=2e-4), dict(prob.params, slope=-2.4)):
+        exact, _ = _run(prob, 200, 9, "exact", monkeypatch, params=params)
+        verified, st = _run(prob, 200, 9, "verify", monkeypatch, params=params)
+        screened, _ = _run(prob, 200, 9, "screened", monkeypatch, params=params)
+        assert verified == exact and screened == exact
+        print(params["slope"], st)
+        assert st["largest_used_fraction"] < 0.5
+
+
+def test_screened_pass_at_the_headline_shape(monkeypatch):
+    """cfg3 (50 k bins / 50 M contacts): verify mode over the first steps (large proposals, decisive tests) and, behind a
+    warm-up that lets the chain settle, over steps whose tests are close calls"""
+    from instagraal_amd import synth
+
+    prob = synth.make_problem(*synth.CONFIGS["cfg3"])
+    exact, _ = _run(prob, 300, 3, "exact", monkeypatch, coo=True)
+    verified, st = _run(prob, 300, 3, "verify", monkeypatch, coo=True)
+    screened, st2 = _run(prob, 300, 3, "screened", monkeypatch, coo=True)
+    assert verified == exact and screened == exact
+    print("cfg3 verify:", st, "\n     screened:", st2)
+    assert st["largest_used_fraction"] < 0.5
+    assert st2["rejected_screened"] > 0.3 * st2["screened"]
+    # settled: 2 400 steps of warm-up, then 300 verified ones
+    verified, st = _run(prob, 300, 4, "verify", monkeypatch, coo=True, warm=2400)
+    screened, st2 = _run(prob, 300, 4, "screened", monkeypatch, coo=True, warm=2400)
+    assert verified == screened
+    print("cfg3 settled verify:", st, "\n     screened:", st2)
+    assert st["largest_used_fraction"] < 0.5

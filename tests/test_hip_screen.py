@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run(prob, frags, seed, env, monkeypatch, coo=False):
+def _run(prob, frags, seed, env, monkeypatch, coo=False, n_neighbours=5, second_call=0):
     from instagraal_amd.sampler import sampler as hip_sampler
 
     for k in ("IG_SCREEN", "IG_SCREEN_VERIFY"):
@@ -23,8 +23,12 @@ def _run(prob, frags, seed, env, monkeypatch, coo=False):
     s.set_param_simu(prob.params)
     s.eval_likelihood_init()
     np.random.seed(seed)
-    cands = s.draw_candidates(frags, 5)
-    res = s.ctx.step_batch(frags, cands)
+    cands = s.draw_candidates(frags, n_neighbours)
+    if second_call:  # a long call, then a short one: the exact kernel's grid is sized from the batches before (down to its floor)
+        res = np.concatenate([s.ctx.step_batch(frags[:-second_call], cands[:-second_call]),
+                              s.ctx.step_batch(frags[-second_call:], cands[-second_call:])])
+    else:
+        res = s.ctx.step_batch(frags, cands)
     sums, _ = s.ctx.debug_globals()
     _, _, limbs = s.ctx.full_likelihood(0)
     assert [int(x) for x in sums[:5]] == [int(x) for x in limbs[:5]]
@@ -102,3 +106,30 @@ def test_screening_at_the_headline_shape(monkeypatch):
     print("cfg3: largest used fraction of a bound %.3g, largest bound %.3g, columns screened %d, scored exactly %d, terms %d / %d" % stats)
     assert stats[3] < 0.25 * stats[2]
     assert 0 < stats[0] < 0.5
+
+
+@pytest.mark.parametrize("n_neighbours", [1, 6, 9, 16])
+@pytest.mark.parametrize("cfg,n_moves", [("tiny", 160), ("small", 330)])
+def test_other_candidate_counts(cfg, n_moves, n_neighbours, monkeypatch):
+    """--neighborhood other than 5 (up to IG_MAX_CANDIDATES = 16): the decide wave's extra-record loads (more than 128 score
+    records per move), k_contend / k_worklist sizing (a move alone may need 16 x 25 x 16 partly filled work items: the exact
+    kernel's grid has a floor that follows the candidate count) and the capC = max(8, max_c) buffers.  Screened == verified ==
+    exact == one move at a time, byte for byte; the run ends in a short second call (narrow batch, grid at its floor)."""
+    from instagraal_amd import hip_lib, synth
+
+    prob = synth.make_problem(*synth.CONFIGS[cfg])
+    np.random.seed(41)
+    frags = np.resize(np.random.permutation(prob.n_frags), n_moves).astype(np.int32)
+    kw = dict(n_neighbours=n_neighbours, second_call=7)
+    exact, _, res = _run(prob, frags, 7, {"IG_SCREEN": "0"}, monkeypatch, **kw)
+    assert res["n_candidates"].max() <= n_neighbours and (n_neighbours <= 5 or res["n_candidates"].max() > 5)  # the wide path is taken
+    verified, stats, _ = _run(prob, frags, 7, {"IG_SCREEN_VERIFY": "1"}, monkeypatch, **kw)
+    screened, _, _ = _run(prob, frags, 7, {}, monkeypatch, **kw)
+    assert verified == exact and screened == exact
+    try:
+        hip_lib.set_batch_width(1)
+        single, _, _ = _run(prob, frags, 7, {}, monkeypatch, **kw)
+    finally:
+        hip_lib.set_batch_width(24)
+    assert single == exact
+    print(cfg, n_neighbours, "candidates per move: max %d, mean %.2f" % (res["n_candidates"].max(), res["n_candidates"].mean()))

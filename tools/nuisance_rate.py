@@ -31,9 +31,20 @@ print("%s: %.0f moves/s through step_sampler_nuisance_batch (accept rate %.2f)" 
 b1 = s.ctx.batch_stats()
 print("   of the library call: %.0f us per move waiting for the device" % (1e6 * (s.ctx.debug_nuis_wait() - w0) / n))
 print("   batches scored: %d for %d moves; one-move tails %d" % (b1["batches"] - b0["batches"], n, b1["one_move_tails"] - b0["one_move_tails"]))
+print("   screened pass:", s.ctx.debug_nuis_screen_stats())
 if hasattr(s, "nuis_profile"):
     tot = sum(s.nuis_profile.values())
     print("   host time per move: " + ", ".join("%s %.0f us" % (k, 1e6 * v / n) for k, v in s.nuis_profile.items()) + " (sum %.0f us)" % (1e6 * tot / n))
+if os.environ.get("NUIS_LONG"):  # the rate as the chain settles: chunks of 600 moves
+    for k in range(int(os.environ["NUIS_LONG"])):
+        fr = np.random.permutation(prob.n_frags)[:600]
+        w0 = s.ctx.debug_nuis_wait()
+        t0 = time.perf_counter()
+        res, tup = s.step_sampler_nuisance_batch(fr, 5, s.dt, 0, 600)
+        dt = time.perf_counter() - t0
+        print("   chunk %d: %.0f moves/s, accept %.2f, device wait %.0f us/move, host %s, %s" % (
+            k, 600 / dt, np.mean([q[6] for q in tup]), 1e6 * (s.ctx.debug_nuis_wait() - w0) / 600,
+            ", ".join("%s %.0f" % (a, 1e6 * v / 600) for a, v in s.nuis_profile.items()), s.ctx.debug_nuis_screen_stats()), flush=True)
 if os.environ.get("NUIS_ONLY"):
     sys.exit(0)
 t_s = t_n = 0.0
