@@ -272,6 +272,7 @@ struct ig_ctx {
     int spec_par_begin, spec_par_end;
     double spec_ema, spec_struct_ema; /* moves decided per parameter scoring / per structural batch: set the widths */
     ig_params nuis_test;           /* the test parameters of the step in flight */
+    ig_params par_model;           /* host copy of the model's parameters (set 0): ig_set_params, ig_nuis_accept */
     float nuis_mean_kb;
     int N, M;
     long long Z;

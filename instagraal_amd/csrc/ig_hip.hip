@@ -663,8 +663,10 @@ extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* 
                         const int h = tile_hist[(size_t)(bi * nb + bj)];
                         if ((h >= 0) != (pass == 1)) continue;
                         if (h >= 0) tiles[(size_t)h].first_item = (int)work.size();
+                        const size_t first = work.size();
                         for (int64_t o = b; o < e; o += FULL_CHUNK)
                             work.push_back(TileWork{(long long)o, (int)std::min<int64_t>(FULL_CHUNK, e - o), (int)bi, (int)bj, 0});
+                        for (size_t q = first; q < work.size(); q++) work[q].pad = (int)(work.size() - 1 - q); /* items of this tile behind this one */
                         if (h >= 0) tiles[(size_t)h].n_items = (int)work.size() - tiles[(size_t)h].first_item;
                     }
                 if (pass == 0) c->n_tile_static = (int)work.size();
@@ -881,6 +883,7 @@ extern "C" int ig_set_params(ig_ctx* c, const float p[8], float mean_subfrag_kb,
     if (which == 0) c->nuis_spec = c->spec_valid = false; /* moves scored ahead (ig_nuis_step_begin) were scored under the old set */
     HIPCK(hipStreamSynchronize(c->stream));
     ig_params hp = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]};
+    if (which == 0) c->par_model = hp;
     HIPCK(hipMemcpy(&c->glob->par[which], &hp, sizeof hp, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(&c->glob->mean_kb, &mean_subfrag_kb, sizeof(float), hipMemcpyHostToDevice));
     {
@@ -1981,19 +1984,22 @@ static void launch_nuis_exact_tiles(ig_ctx* c, hipStream_t s3)
     c->nuis_pub_sums = true;
 }
 
-static int launch_nuis_diff(ig_ctx* c, const ig_params& hp, float mean_kb, hipStream_t s3)
+static int launch_nuis_diff(ig_ctx* c, const ig_params& hp, float mean_kb, hipStream_t s3, bool fuse_catch = false)
 {
     if (!c->diff_const) {
         DALLOC(c->diff_const, 1);
         DALLOC(c->scratch_diff, 8);
-        HIPCK(hipFuncSetAttribute((const void*)k_full_diff_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DiffLds)));
+        HIPCK(hipFuncSetAttribute((const void*)k_full_diff_tiled<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DiffLds)));
+        HIPCK(hipFuncSetAttribute((const void*)k_full_diff_tiled<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DiffLds)));
     }
     const Tables& t = c->tab_prev;
     const int n_pack = (c->M + FULL_TB - 1) / FULL_TB;
     const int n_const = (std::max(std::max(c->pz_n1, LDS_PZ + 2), std::max((int)IG_TAB_SIZE, LDS_LGF)) + 255) / 256;
     hipLaunchKernelGGL(k_nuis_prepare, dim3(n_pack + n_const), dim3(256), 0, s3, c->glob, 1, hp, mean_kb, c->pz_tab1, c->pz_n1, c->lgf_tab, c->full_const,
                        c->scratch_nuis, t, c->M, c->tabrec, c->tile_sig, FULL_TB, c->tile_dyn, n_pack, c->score_const, c->pz_n, c->diff_const,
-                       c->scratch_diff, c->screen_const);
+                       c->scratch_diff, c->screen_const, fuse_catch ? c->tab : Tables{nullptr, nullptr, nullptr, nullptr}, c->prev_touched);
+    /* the library stream's next kernels replace what the catch-up reads: they wait for it (not for the pass behind it) */
+    if (fuse_catch) HIPCK(hipEventRecord(c->ev_main, s3));
     const int per = TILE_TRANS_THREADS / 64;
     const int n_trans = (c->n_tile_info + per - 1) / per, n_zero = std::min(256, std::max(32, c->M / 4096));
     hipLaunchKernelGGL(k_tile_trans, dim3(n_trans + n_zero), dim3(TILE_TRANS_THREADS), 0, s3, c->tile_info, c->n_tile_info, c->tile_sig, c->tile_hist,
@@ -2004,10 +2010,20 @@ static int launch_nuis_diff(ig_ctx* c, const ig_params& hp, float mean_kb, hipSt
     const int grid = std::min(c->n_tile_work, c->side_busy ? s_grid_side : s_grid);
     {
         TimedLaunch tl(c, T_DIFF, s3);
-        hipLaunchKernelGGL(k_full_diff_tiled, dim3(grid), dim3(DIFF_THREADS), sizeof(DiffLds), s3, c->tile_work, c->tiled_cc, c->tabrec, c->diff_const,
-                           c->M, c->scratch_diff, c->n_tile_static, (TileDyn*)c->tile_dyn, c->tile_dyn_list, c->host_nuis_dev, ++c->diff_seq,
-                           c->tile_partial, c->tile_partial0, n_trans, c->scratch_nuis, c->diff_trace);
+        /* a proposal that leaves slope and amplitude alone (d_max, trans level): the kernel without transcendental functions; the
+         * device has the last word (DiffConst.zdy: the other kernel's pass comes out void) */
+        const bool zdy = hp.slope == c->par_model.slope && hp.c1 == c->par_model.c1 && hp.fact == c->par_model.fact;
+        ++c->diff_seq;
+        if (zdy)
+            hipLaunchKernelGGL(k_full_diff_tiled<true>, dim3(grid), dim3(DIFF_THREADS), sizeof(DiffLds), s3, c->tile_work, c->tiled_cc, c->tabrec,
+                               c->diff_const, c->M, c->scratch_diff, c->n_tile_static, (TileDyn*)c->tile_dyn, c->tile_dyn_list, c->host_nuis_dev,
+                               c->diff_seq, c->tile_partial, c->tile_partial0, n_trans, c->scratch_nuis, c->diff_trace);
+        else
+            hipLaunchKernelGGL(k_full_diff_tiled<false>, dim3(grid), dim3(DIFF_THREADS), sizeof(DiffLds), s3, c->tile_work, c->tiled_cc, c->tabrec,
+                               c->diff_const, c->M, c->scratch_diff, c->n_tile_static, (TileDyn*)c->tile_dyn, c->tile_dyn_list, c->host_nuis_dev,
+                               c->diff_seq, c->tile_partial, c->tile_partial0, n_trans, c->scratch_nuis, c->diff_trace);
     }
+    if (fuse_catch) HIPCK(hipStreamWaitEvent(c->stream, c->ev_main, 0));
     c->nuis_diff = true;
     c->nuis_exact_queued = false;
     c->nuis_pub_sums = false;
@@ -2026,9 +2042,12 @@ static int enqueue_nuis_pass(ig_ctx* c, const float p_test[8], float mean_subfra
     /* the nuisance pass first (second stream), the move behind it (library stream): the pass is the longer of the two and
      * would otherwise start only when the host is through with the move's dozen launches */
     hipStream_t s3 = c->stream3;
-    bool on_side = false;
+    bool on_side = false, fuse_catch = false;
+    const bool use_diff = nuis_screen_usable(c);
     if (!c->nuis_caught_up) {
-        if (c->main_drained) {
+        if (c->main_drained && use_diff) {
+            fuse_catch = on_side = true; /* the screened pass's first launch does it (k_nuis_prepare), see launch_nuis_diff */
+        } else if (c->main_drained) {
             /* nothing is queued on the library stream (the previous step's results are on the host, nothing was promoted since):
              * the catch-up runs at the head of the pass's own stream -- an event from the library stream to this one costs ~15 us
              * of idle queue at the start of every step -- and the library stream's next kernels, which replace what it reads,
@@ -2053,7 +2072,7 @@ static int enqueue_nuis_pass(ig_ctx* c, const float p_test[8], float mean_subfra
     c->nuis_pub_sums = false;
     c->nuis_diff = false;
     c->nuis_screen_rejected = false;
-    if (nuis_screen_usable(c)) return launch_nuis_diff(c, hp, mean_subfrag_kb, s3);
+    if (use_diff) return launch_nuis_diff(c, hp, mean_subfrag_kb, s3, fuse_catch);
     c->pub_sums = (c->nuis_spec && c->host_nuis_dev) ? c->host_nuis_dev : nullptr; /* launch_full_nz: the tiled kernel's last workgroup publishes */
     const bool zero_done = launch_full_nz(c, c->tab_prev, 1, c->scratch_nuis, PzTab{c->pz_tab1, c->pz_n1}, s3, c->scratch_nuis + 2, &hp, mean_subfrag_kb);
     c->pub_sums = nullptr;
@@ -2505,6 +2524,7 @@ extern "C" int ig_nuis_accept(ig_ctx* c)
                        c->prev_touched, c->glob, c->mb, c->lgf_tab, pz1, w, 2, 1, acc8 + 6);
     hipLaunchKernelGGL(k_full_zero, dim3(128), dim3(256), 0, c->stream, c->tab, c->glob, 1, c->M, acc8);
     /* the promotion, and the tables of the model's parameter set: the test set's P_z table becomes the model's */
+    c->par_model = c->nuis_test;
     std::swap(c->pz_tab, c->pz_tab1);
     std::swap(c->pz_n, c->pz_n1);
     const PzTab pz0{c->pz_tab, c->pz_n};

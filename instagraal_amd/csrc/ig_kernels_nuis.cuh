@@ -18,14 +18,17 @@
  *     y = slope log2 s + la,   yy = in ? max(y, lv) : lv,   t = ob yy log10(2) - 2^yy - log10(ob!) + pzc[d]
  * and its difference between two parameter sets (c = current, t = test; the log-factorial cancels):
  *     dt = ob log10(2) dyy - 2^yy_c (2^dyy - 1) + (pzc_t[d] - pzc_c[d]),   dyy = yy_t - yy_c.
- * Three classes of contacts, told apart with a guard band G >= the float error of y around the clamp levels:
- *     A  in range under both sets and y_c > max(lv_c, lv_t) + G + DY:  neither clamps, dyy = dslope L + dla  (small, accurate)
- *     B  out of range under both, or y_c < min(lv_c, lv_t) - G - DY:    both at their level: dyy = lv_t - lv_c and
+ * Three classes of contacts.  The model's slope is negative (else the pass is void), so y is a decreasing function of s and
+ * the classes are intervals of s, told apart by two thresholds computed once per step in double (rounded to the safe side):
+ *     A  in range under both sets and y_c >= max(lv_c, lv_t) + DY (s < thrA):  neither clamps, dyy = dslope L + dla  (small, accurate)
+ *     B  out of range under both, or y_c <= min(lv_c, lv_t) - DY (s >= thrB):   both at their level: dyy = lv_t - lv_c and
  *        2^yy_t - 2^yy_c = v_inter_t - v_inter_c are constants of the step (any size: a d_max proposal moves the level by tens of percent)
  *     C  anything else (a thin shell around the clamp levels / between the two d_max): both terms evaluated in full;
  *        full-size error, accounted term by term.
  * DY = |dslope| LB + |dla| bounds |dy| over |log2 s| <= LB = 24 (checked at the end: a larger |L| voids the pass).
  * 2^x - 1 for |x| <= 1/4 is a degree-6 polynomial in x ln 2 (truncation 5e-9 relative).
+ * A proposal that leaves slope and amplitude alone (the d_max and trans-level proposals, CL:2996-3017: half of the steps) has
+ * dyy = 0 EXACTLY in class A: its term there is the table difference dpzc[d] -- no logarithm, no exponential (template ZDY).
  *
  * Error budget, u = 2^-24, v_log_f32 / v_exp_f32 within K = 2 units of 2u (|result| + 1) resp. 2u result (measured over
  * their whole domain: 0.98 / 0.71, tests/test_hip_screen.py fails above 2):
@@ -57,7 +60,9 @@ struct alignas(16) DiffConst {
     float slope_c, la_c, lv_c, dslope, dla, dlv;
     float slope_t, la_t, lv_t, dmax_c, dmax_t;
     float dmin, dmax2;    /* min / max of the two d_max */
-    float hi_thr, lo_thr; /* class A above, class B below */
+    float thr_a, thr_b;   /* class A: 0 < s < thr_a (cis); class B: s >= thr_b, or not cis, or s == 0 */
+    float s17;            /* s >= s17  <=>  y <= 17 (class A terms of the ZDY kernel: the contract's clamp is out of reach) */
+    int zdy;              /* dslope == 0 and dla == 0 exactly */
     float cy;             /* max over the two sets of |la| + |slope| + |lv| (rounded up) */
     float a_dslope, a_dla, a_dlv, dy_max; /* magnitudes (rounded up); DY */
     float dex_b;          /* v_inter_t - v_inter_c: class B's 2^yy_t - 2^yy_c */
@@ -103,10 +108,19 @@ __device__ __forceinline__ void build_diff_const(int i, const Glob* g, const ig_
         out->a_dlv = (float)(a_dv * up);
         out->dy_max = (float)(dy_max * up);
         out->dex_b = (float)((double)pt.v_inter - (double)pc.v_inter);
-        /* guard band: the float error of y (5.25 u (|y| + Cy), |y| <= 18 or the pass is void) and of y + dy, with room */
-        const double guard = 8.0 * 0x1p-24 * (19.0 + cy) + 1e-6;
-        out->hi_thr = (float)((__builtin_fmax(hc.log2_v_inter, ht.log2_v_inter) + guard + dy_max) + 1e-6 * (1.0 + cy));
-        out->lo_thr = (float)((__builtin_fmin(hc.log2_v_inter, ht.log2_v_inter) - guard - dy_max) - 1e-6 * (1.0 + cy));
+        /* y_c(s) = slope_c log2 s + la_c decreases with s (slope_c < 0, see ok): y_c >= HI <=> s <= 2^((HI - la_c) / slope_c).  HI / LO
+         * leave room for the test set's y = y_c + dy (|dy| <= DY) and for the last bits of the contract's own evaluation */
+        const double hi = __builtin_fmax(hc.log2_v_inter, ht.log2_v_inter) + dy_max + 1e-6 * (1.0 + cy);
+        const double lo = __builtin_fmin(hc.log2_v_inter, ht.log2_v_inter) - dy_max - 1e-6 * (1.0 + cy);
+        auto s_of = [&](double level) { /* the s at which y_c reaches `level` */
+            const double e = (level - hc.log2_amp) / (hc.slope < 0.0 ? hc.slope : -1.0);
+            return ig_exp2(__builtin_fmin(__builtin_fmax(e, -140.0), 120.0), ig_tab());
+        };
+        const float s_a = (float)(s_of(hi) * (1.0 - 1e-6)), s_b = (float)(s_of(lo) * (1.0 + 1e-6));
+        out->thr_a = fminf(fminf(hc.d_max, ht.d_max), s_a);
+        out->thr_b = fminf(fmaxf(hc.d_max, ht.d_max), __uint_as_float(__float_as_uint(s_b) + 1u)); /* s > s_b: the next float up */
+        out->s17 = (float)(s_of(17.0) * (1.0 + 1e-6));
+        out->zdy = (dslope == 0.0 && dla == 0.0) ? 1 : 0;
         out->cut = (pz_n_c > LDS_PZ || pz_n_t > LDS_PZ) ? (unsigned)LDS_PZ : 0xffffffffu;
         out->ok = (hc.fast && ht.fast && pc.slope < 0.0f && pt.slope < 0.0f && dy_max <= (double)DIFF_X0 && a_dv <= 64.0 && cy < 200.0 &&
                    pz_n_c > 0 && pz_n_t > 0 && scr0->pzc_max < 1e5f)
@@ -129,15 +143,15 @@ struct DiffLds {
     double red_s[DIFF_THREADS / 64];
     float red_f[6][DIFF_THREADS / 64];
     unsigned red_bad[DIFF_THREADS / 64];
-    int next_item;
 };
 
 /* out8: [0],[1] exact integer limbs (hist sums under the test set minus under the current set), [2] s_fix, [3] b_fix,
  * [4] void flags, [5] contacts read */
-/* The pass is a stream of 8-byte contacts (160 MB at the headline shape) against two staged blocks: what bounds it is the
- * number of loads in flight (Little's law: 2 per thread of 2 x 1024-thread workgroups per CU moved 1.9 TB/s, 85 us -- as long as
- * the exact double-precision pass), so a thread keeps DIFF_BATCH contacts being summed and DIFF_BATCH more on their way. */
-__global__ void __launch_bounds__(DIFF_THREADS)
+/* The pass is a stream of 8-byte contacts (160 MB at the headline shape) against two staged blocks; a thread keeps DIFF_BATCH
+ * contacts being summed and DIFF_BATCH more on their way, a workgroup takes an even share of the pass as a few contiguous runs
+ * (TileRuns, ig_kernels_score.cuh).  ZDY: the proposal leaves slope and amplitude alone (DiffConst.zdy). */
+template <bool ZDY>
+__global__ void __launch_bounds__(DIFF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) /* two workgroups per CU: at most 128 VGPRs */
     k_full_diff_tiled(const TileWork* __restrict__ work, const uint2* __restrict__ tc, const int4* __restrict__ rec, const DiffConst* __restrict__ dc,
                       int M, long long* out8, int n_static, TileDyn* dyn, const int* __restrict__ dyn_list, NuisHost* hn, int hn_seq,
                       const long long* __restrict__ partial_t, const long long* __restrict__ partial_c, int n_partial,
@@ -145,11 +159,12 @@ __global__ void __launch_bounds__(DIFF_THREADS)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     DiffLds& L = *(DiffLds*)lds_raw;
-    /* trace (ig_debug_diff_trace): per workgroup {start, end (100 MHz clock), XCC_ID << 32 | HW_ID, items << 32 | contacts, ticks
-     * between an item's start and its blocks being staged, ticks in the contact loops} */
+    /* trace (ig_debug_diff_trace): per workgroup {start, end (100 MHz clock), XCC_ID << 32 | HW_ID, runs << 32 | contacts, ticks
+     * between a run's start and its blocks being staged, ticks in the contact loops} */
     long long t_start = 0, t_stage = 0, t_loop = 0, t_mark = 0;
     int n_items = 0;
     if (trace && threadIdx.x == 0) t_start = (long long)wall_clock64();
+    const int dyn_count = dyn->count; /* (requested with the constants below: one round trip less in front of the first contacts) */
     __shared__ float s_pmx[DIFF_THREADS / 64];
     {
         float mx = 0.0f; /* the largest |dpzc| (the bound's table-conversion term) while the table goes to LDS */
@@ -162,28 +177,25 @@ __global__ void __launch_bounds__(DIFF_THREADS)
         if ((threadIdx.x & 63) == 0) s_pmx[threadIdx.x >> 6] = mx;
     }
     const float slope_c = dc->slope_c, la_c = dc->la_c, lv_c = dc->lv_c, dslope = dc->dslope, dla = dc->dla, dlv = dc->dlv;
-    const float dmin = dc->dmin, dmax2 = dc->dmax2, hi_thr = dc->hi_thr, lo_thr = dc->lo_thr, dex_b = dc->dex_b;
-    /* (class C's constants as well: its branch is taken by most waves -- one lane near a clamp level is enough -- and must not
+    const float thr_a = dc->thr_a, thr_b = dc->thr_b, dex_b = dc->dex_b;
+    /* (class C's constants as well: its branch is taken by many waves -- one lane between the thresholds is enough -- and must not
      * start with a round trip to memory) */
     const float slope_t = dc->slope_t, la_t = dc->la_t, lv_t = dc->lv_t, dmax_c = dc->dmax_c, dmax_t = dc->dmax_t, cy_f = dc->cy;
     const unsigned cut = dc->cut;
-    const int ok = dc->ok;
+    const int ok = dc->ok && (dc->zdy != 0) == ZDY;
     const float c10 = (float)IG_LOG2_10_INV, ln2 = 0.69314718f;
     double acc = 0.0;
-    float s_ob = 0.0f, s_dex = 0.0f, s_dexy = 0.0f, s_ex = 0.0f, l_max = 0.0f, y_max = 0.0f, b_c = 0.0f;
+    /* sum(ob) where a term depends on it; sum |dex|; sum |dex| |yy|; sum 2^yy_c (ZDY: contacts in class B); max |L| (ZDY: min s in
+     * class A, negated); max |yy|; class C's direct bound; sum(ob) over everything */
+    float s_ob = 0.0f, s_dex = 0.0f, s_dexy = 0.0f, s_ex = 0.0f, l_max = ZDY ? -3.0e38f : 0.0f, y_max = 0.0f, b_c = 0.0f, s_oball = 0.0f;
     unsigned bad = ok ? 0u : 1u;
     long long n_read = 0;
     const int nth = blockDim.x;
     __syncthreads();
-    for (int seq = (int)blockIdx.x; ok;) {
-        int it;
-        if (seq < n_static) {
-            it = seq;
-        } else {
-            if (seq - n_static >= dyn->count) break;
-            it = dyn_list[seq - n_static];
-        }
-        const TileWork wk = work[it];
+    TileRuns runs(work, dyn_list, n_static, ok ? dyn_count : -n_static); /* this workgroup's share of the pass; nothing when the pass is void */
+    TileRun wk;
+    int st_bi = -1, st_bj = -1;
+    while (runs.next(wk)) {
         const bool diag = wk.bi == wk.bj;
         const uint2* src = tc + wk.off;
         const int n = wk.n;
@@ -193,39 +205,32 @@ __global__ void __launch_bounds__(DIFF_THREADS)
         uint2 nx[DIFF_BATCH];
 #pragma unroll
         for (int q = 0; q < DIFF_BATCH; q++) nx[q] = src[min((int)threadIdx.x + q * nth, n - 1)];
+        if (st_bi != wk.bi || st_bj != wk.bj) {
+            __syncthreads(); /* everybody is through with the blocks of the run before */
 #if !(defined(DIFF_ABLATE) && (DIFF_ABLATE & 4)) /* tuning builds: no staging */
-        for (int i = threadIdx.x; i < FULL_TB; i += nth) {
-            const int gi = wk.bi * FULL_TB + i, gj = wk.bj * FULL_TB + i;
-            const int4 a = gi < M ? rec[gi] : make_int4(0, 0, -1, 0);
-            L.rrec[i] = make_uint2((unsigned)a.x, (unsigned)a.w | (__int_as_float(a.y) != 0.0f ? 0x80000000u : 0u));
-            L.rctg[i] = a.z;
-            if (!diag) {
-                const int4 b = gj < M ? rec[gj] : make_int4(0, 0, -2, 0);
-                L.crec[i] = make_uint2((unsigned)b.x, (unsigned)b.w | (__int_as_float(b.y) != 0.0f ? 0x80000000u : 0u));
-                L.cctg[i] = b.z;
+            for (int i = threadIdx.x; i < FULL_TB; i += nth) {
+                const int gi = wk.bi * FULL_TB + i, gj = wk.bj * FULL_TB + i;
+                const int4 a = gi < M ? rec[gi] : make_int4(0, 0, -1, 0);
+                L.rrec[i] = make_uint2((unsigned)a.x, (unsigned)a.w | (__int_as_float(a.y) != 0.0f ? 0x80000000u : 0u));
+                L.rctg[i] = a.z;
+                if (!diag) {
+                    const int4 b = gj < M ? rec[gj] : make_int4(0, 0, -2, 0);
+                    L.crec[i] = make_uint2((unsigned)b.x, (unsigned)b.w | (__int_as_float(b.y) != 0.0f ? 0x80000000u : 0u));
+                    L.cctg[i] = b.z;
+                }
             }
-        }
 #endif
-        __syncthreads();
+            __syncthreads();
+            st_bi = wk.bi;
+            st_bj = wk.bj;
+        }
         if (trace && threadIdx.x == 0) {
             const long long now = (long long)wall_clock64();
             t_stage += now - t_mark;
             t_mark = now;
         }
-        if (threadIdx.x == 0) L.next_item = (int)gridDim.x + atomicAdd(&dyn->next, 1);
         const uint2* cre = diag ? L.rrec : L.crec;
         const int* cct = diag ? L.rctg : L.cctg;
-#if defined(DIFF_ABLATE) && (DIFF_ABLATE & 8) /* tuning builds: the contacts are only read */
-        for (int e0 = threadIdx.x; e0 < n; e0 += DIFF_BATCH * nth) {
-            uint2 vv[DIFF_BATCH];
-#pragma unroll
-            for (int q = 0; q < DIFF_BATCH; q++) vv[q] = nx[q];
-#pragma unroll
-            for (int q = 0; q < DIFF_BATCH; q++) nx[q] = src[min(e0 + (DIFF_BATCH + q) * nth, n - 1)];
-#pragma unroll
-            for (int q = 0; q < DIFF_BATCH; q++) s_ob += (float)(vv[q].x ^ vv[q].y);
-        }
-#else
         for (int e0 = threadIdx.x; e0 < n; e0 += DIFF_BATCH * nth) {
             uint2 vv[DIFF_BATCH];
 #pragma unroll
@@ -247,35 +252,50 @@ __global__ void __launch_bounds__(DIFF_THREADS)
 #endif
                 const unsigned d = abs_diff_u32(ri.y & 0x7fffffffu, rj.y & 0x7fffffffu);
                 const float sv = fabsf(__uint_as_float(ri.x) - __uint_as_float(rj.x));
-#if defined(DIFF_ABLATE) && (DIFF_ABLATE & 1) /* tuning builds: no transcendental functions */
-                const float lg = sv * 0.001f;
-#else
-                const float lg = __builtin_amdgcn_logf(sv);
-#endif
-                const float y = __builtin_fmaf(slope_c, lg, la_c);
-                const float dy = __builtin_fmaf(dslope, lg, dla);
                 const bool pos = cis && (sv > 0.0f);
-                const bool both_in = pos && (sv < dmin), any_in = pos && (sv < dmax2);
-                const bool A = both_in && (y > hi_thr);
-                const bool B = !any_in || (y < lo_thr);
-                float yy = A ? y : lv_c;
-                const float dyy = A ? dy : dlv;
-                float ex = __builtin_amdgcn_exp2f(yy);
-                const float z = dyy * ln2;
-                float e = __builtin_fmaf(z, 1.0f / 720.0f, 1.0f / 120.0f);
-                e = __builtin_fmaf(z, e, 1.0f / 24.0f);
-                e = __builtin_fmaf(z, e, 1.0f / 6.0f);
-                e = __builtin_fmaf(z, e, 0.5f);
-                e = __builtin_fmaf(z, e, 1.0f);
-                float dex = A ? ex * (z * e) : dex_b;
+                const bool A = pos && (sv < thr_a);
+                const bool B = !pos || (sv >= thr_b);
                 const float obf = (float)v.y;
                 const float m = obf * c10;
                 const float pz = L.dpzc[cis ? min(d, (unsigned)LDS_PZ) : (unsigned)LDS_PZ];
-                float t = __builtin_fmaf(m, dyy, -dex) + pz;
                 bad |= (live && ((cis && (((ri.y | rj.y) >> 31) || d >= cut)) || (v.y - 1u >= 16383u))) ? 2u : 0u;
-                float obacc = obf, lacc = A ? fabsf(lg) : 0.0f;
+                float t, obacc, dexa, exa, yya, lacc;
+                if (ZDY) { /* class A: the table difference alone; class B: constants of the step */
+                    t = A ? pz : __builtin_fmaf(m, dlv, -dex_b) + pz;
+                    obacc = A ? 0.0f : obf;
+                    dexa = 0.0f;
+                    exa = A ? 0.0f : 1.0f; /* counts class B */
+                    yya = 0.0f;
+                    lacc = A ? -sv : -3.0e38f; /* max of -s = -(min s) over class A: y <= 17 there iff min s >= s17 */
+                } else {
+#if defined(DIFF_ABLATE) && (DIFF_ABLATE & 1) /* tuning builds: no transcendental functions */
+                    const float lg = sv * 0.001f;
+#else
+                    const float lg = __builtin_amdgcn_logf(sv);
+#endif
+                    const float y = __builtin_fmaf(slope_c, lg, la_c);
+                    const float dy = __builtin_fmaf(dslope, lg, dla);
+                    const float yy = A ? y : lv_c;
+                    const float dyy = A ? dy : dlv;
+                    const float ex = __builtin_amdgcn_exp2f(yy);
+                    const float z = dyy * ln2;
+                    float e = __builtin_fmaf(z, 1.0f / 720.0f, 1.0f / 120.0f);
+                    e = __builtin_fmaf(z, e, 1.0f / 24.0f);
+                    e = __builtin_fmaf(z, e, 1.0f / 6.0f);
+                    e = __builtin_fmaf(z, e, 0.5f);
+                    e = __builtin_fmaf(z, e, 1.0f);
+                    const float dex = A ? ex * (z * e) : dex_b;
+                    t = __builtin_fmaf(m, dyy, -dex) + pz;
+                    obacc = obf;
+                    dexa = fabsf(dex);
+                    exa = ex;
+                    yya = fabsf(yy);
+                    lacc = A ? fabsf(lg) : 0.0f;
+                }
                 if (__any(live && !(A || B))) {
                     if (!(A || B)) { /* class C: both terms in full */
+                        const float lg = __builtin_amdgcn_logf(sv);
+                        const float y = __builtin_fmaf(slope_c, lg, la_c);
                         const bool in_c = pos && (sv < dmax_c), in_t = pos && (sv < dmax_t);
                         const float yt0 = __builtin_fmaf(slope_t, lg, la_t);
                         const float yc = in_c ? fmaxf(y, lv_c) : lv_c, yt = in_t ? fmaxf(yt0, lv_t) : lv_t;
@@ -286,42 +306,43 @@ __global__ void __launch_bounds__(DIFF_THREADS)
                         b_c += live ? bc : 0.0f;
                         y_max = fmaxf(y_max, live ? ym : 0.0f);
                         obacc = 0.0f;
-                        lacc = 0.0f;
-                        dex = 0.0f;
-                        ex = 0.0f;
-                        yy = 0.0f;
+                        dexa = 0.0f;
+                        exa = 0.0f;
+                        yya = 0.0f;
+                        lacc = ZDY ? -3.0e38f : 0.0f;
                     }
                 }
                 if (!live) {
                     t = 0.0f;
                     obacc = 0.0f;
-                    lacc = 0.0f;
-                    dex = 0.0f;
-                    ex = 0.0f;
-                    yy = 0.0f;
+                    dexa = 0.0f;
+                    exa = 0.0f;
+                    yya = 0.0f;
+                    lacc = ZDY ? -3.0e38f : 0.0f;
                 }
                 dt[q] = t;
                 s_ob += obacc;
-                s_dex += fabsf(dex);
-                s_dexy = __builtin_fmaf(fabsf(dex), fabsf(yy), s_dexy);
-                s_ex += ex;
+                s_oball += live ? obf : 0.0f;
+                s_ex += exa;
                 l_max = fmaxf(l_max, lacc);
-                y_max = fmaxf(y_max, fabsf(yy));
+                if (!ZDY) {
+                    s_dex += dexa;
+                    s_dexy = __builtin_fmaf(dexa, yya, s_dexy);
+                    y_max = fmaxf(y_max, yya);
+                }
             }
-            float ts = 0.0f; /* a few float additions before the double one: u sum|dt| of them, inside T3's 3 |dex| + ... */
+            float ts = 0.0f; /* a few float additions before the double one: u sum|dt| of them, in the bound's "final adds" */
 #pragma unroll
             for (int q = 0; q < DIFF_BATCH; q++) ts += dt[q];
             acc += (double)ts;
         }
-#endif
-        __syncthreads();
         if (trace && threadIdx.x == 0) t_loop += (long long)wall_clock64() - t_mark;
-        seq = L.next_item;
     }
     /* ---- the workgroup's sum and bound */
     for (int o = 32; o > 0; o >>= 1) {
         acc += __shfl_down(acc, o, 64);
         s_ob += __shfl_down(s_ob, o, 64);
+        s_oball += __shfl_down(s_oball, o, 64);
         s_dex += __shfl_down(s_dex, o, 64);
         s_dexy += __shfl_down(s_dexy, o, 64);
         s_ex += __shfl_down(s_ex, o, 64);
@@ -332,6 +353,9 @@ __global__ void __launch_bounds__(DIFF_THREADS)
         n_read += __shfl_down(n_read, o, 64);
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ float s_ymax[DIFF_THREADS / 64], s_oba[DIFF_THREADS / 64];
+    __shared__ long long s_nread[DIFF_THREADS / 64];
+    __syncthreads(); /* (the staged blocks' last readers are through: red_* do not overlap them, but keep the phases apart) */
     if (lane == 0) {
         L.red_s[wv] = acc;
         L.red_f[0][wv] = s_ob;
@@ -339,19 +363,15 @@ __global__ void __launch_bounds__(DIFF_THREADS)
         L.red_f[2][wv] = s_dexy;
         L.red_f[3][wv] = s_ex;
         L.red_f[4][wv] = b_c;
-        L.red_f[5][wv] = fmaxf(l_max, 0.0f);
+        L.red_f[5][wv] = l_max;
         L.red_bad[wv] = bad;
-    }
-    /* y_max rides in a second step (six float slots): through lane 0's registers of wave 0 below */
-    __shared__ float s_ymax[FULL_TILED_THREADS / 64];
-    __shared__ long long s_nread[FULL_TILED_THREADS / 64];
-    if (lane == 0) {
         s_ymax[wv] = y_max;
+        s_oba[wv] = s_oball;
         s_nread[wv] = n_read;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double S = 0.0, Sob = 0.0, Sdex = 0.0, Sdexy = 0.0, Sex = 0.0, Bc = 0.0, Lm = 0.0, Ym = 0.0;
+        double S = 0.0, Sob = 0.0, Sdex = 0.0, Sdexy = 0.0, Sex = 0.0, Bc = 0.0, Lm = -3.0e38, Ym = 0.0, Soa = 0.0;
         unsigned Bd = 0;
         long long n = 0;
         for (int v = 0; v < (int)(blockDim.x >> 6); v++) {
@@ -363,22 +383,33 @@ __global__ void __launch_bounds__(DIFF_THREADS)
             Bc += (double)L.red_f[4][v];
             Lm = __builtin_fmax(Lm, (double)L.red_f[5][v]);
             Ym = __builtin_fmax(Ym, (double)s_ymax[v]);
+            Soa += (double)s_oba[v];
             Bd |= L.red_bad[v];
             n += s_nread[v];
         }
         if (ok && n > 0) {
             const double u = 0x1p-24, c10d = IG_LOG2_10_INV;
             const double cy = dc->cy, a_ds = dc->a_dslope, a_dl = dc->a_dla, a_dv = dc->a_dlv, DY = dc->dy_max;
-            const double DX = __builtin_fmax(DY, a_dv);
-            const double G = 1.05 * __builtin_fmax(a_ds * (5.0 * Lm + 4.0) + a_dl + DY, 2.0 * a_dv);
-            double pmx = 0.0; /* largest |dpzc| */
-            for (int q = 0; q < (int)(blockDim.x >> 6); q++) pmx = __builtin_fmax(pmx, (double)s_pmx[q]);
             const double nn = (double)n;
             const double fa = 1.0 + 2.0 * u * (nn / (double)blockDim.x + 32.0) * 2.0; /* the float accumulators' own roundings */
+            double pmx = 0.0; /* largest |dpzc| */
+            for (int q = 0; q < (int)(blockDim.x >> 6); q++) pmx = __builtin_fmax(pmx, (double)s_pmx[q]);
+            if (ZDY) { /* class A: dt = dpzc[d] (a table conversion); class B: constants; what was counted in s_ex is class B's size */
+                const double dexb = __builtin_fabs((double)dc->dex_b);
+                Sdex = Sex * dexb * (1.0 + 0x1p-20);
+                Sdexy = Sdex * __builtin_fabs((double)dc->lv_c);
+                /* the contract's own double roundings need sum 2^yy_c: below 2^17 per contact (checked: min s of class A against s17) */
+                Sex = nn * 131072.0;
+                if (!(-Lm >= (double)dc->s17)) Bd |= 4u; /* (no class A contact: Lm = -3e38, fine) */
+                Ym = __builtin_fmax(Ym, 17.0); /* (class C's own maximum stands) */
+                Lm = 0.0;
+            }
+            const double DX = __builtin_fmax(DY, a_dv);
+            const double G = 1.05 * __builtin_fmax(a_ds * (5.0 * Lm + 4.0) + a_dl + DY, 2.0 * a_dv);
             const double T1 = u * c10d * Sob * (G + 3.0 * DX);
-            const double T2 = u * (13.0 * Sdex + 3.68 * (Sdexy + cy * Sdex) + 0.84 * G * Sex);
+            const double T2 = ZDY ? u * 13.0 * Sdex : u * (13.0 * Sdex + 3.68 * (Sdexy + cy * Sdex) + 0.84 * G * Sex);
             const double T3 = u * ((2.0 + DIFF_BATCH) * c10d * Sob * DX + (2.0 + DIFF_BATCH) * Sdex + (3.0 + DIFF_BATCH) * nn * pmx);
-            const double T4 = nn * 0x1p-31 + 4e-15 * (Sob * (Ym + 5.0) + 2.6 * Sex + nn * (double)dc->pzc_abs_max);
+            const double T4 = nn * 0x1p-31 + 4e-15 * (Soa * (Ym + 5.0) + 2.6 * Sex + nn * (double)dc->pzc_abs_max);
             const double bound = 1.01 * fa * (T1 + T2 + T3 + u * Bc) + T4 + 2.0 / DIFF_FIX;
             /* outside the screening term's domain: |L| beyond the bound DY was derived for, |yy| beyond the contract's clamp
              * (|t| < 2^20 needs P < 2^18 and counts < 2^14), anything not a number */
@@ -403,14 +434,13 @@ __global__ void __launch_bounds__(DIFF_THREADS)
             atomic_add_ll(&out8[1], lo);
         }
     }
-    /* the last workgroup through: the cursors back for the exact pass that may follow over the same list, the sums to the
+    /* the last workgroup through: the counter back for the exact pass that may follow over the same list, the sums to the
      * (mapped) host memory, then the flag */
     __syncthreads(); /* (block 0: every wave's share of the histogram sums is out) */
     if (threadIdx.x == 0) {
         __threadfence();
         if (atomicAdd(&dyn->done, 1) == (int)gridDim.x - 1) {
             __threadfence();
-            dyn->next = 0;
             dyn->done = 0;
             if (hn) {
                 for (int q = 0; q < 8; q++) hn->diff[q] = __hip_atomic_load(&out8[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

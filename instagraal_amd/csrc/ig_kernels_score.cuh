@@ -1165,14 +1165,15 @@ __global__ void __launch_bounds__(256) k_full_nz(const int* __restrict__ crow, c
  * count beyond the histogram) and every workgroup goes on with items from that list until it is empty. */
 #define FULL_TB 2048
 #ifndef FULL_CHUNK
-#define FULL_CHUNK 16384
+#define FULL_CHUNK 4096 /* contacts per work item: the granularity of the even split of a pass over its workgroups (tile_runs) */
 #endif
 #ifndef FULL_TILED_THREADS
 #define FULL_TILED_THREADS 1024
 #endif
 struct TileWork {
     long long off; /* first contact of the item in the tiled array */
-    int n, bi, bj, pad;
+    int n, bi, bj;
+    int pad; /* items of the same tile behind this one (they follow it in the array, and their contacts its contacts in memory) */
 };
 struct TileInfo { /* an off-diagonal tile whose counts are all in 1 .. TILE_HB-1 */
     int bi, bj, first_item, n_items;
@@ -1180,6 +1181,46 @@ struct TileInfo { /* an off-diagonal tile whose counts are all in 1 .. TILE_HB-1
 struct TileDyn {
     int count, next, done, pad; /* items on the list (k_tile_trans), items taken, workgroups through (k_full_nz_tiled); zeroed by k_pack_tab_sig */
 };
+/* The work of a pass = the sequence of items [static ones: work[0 .. n_static)] [the list k_tile_trans left: dyn_list[0 .. count)];
+ * workgroup b of G takes positions [b T / G, (b + 1) T / G) of it.  The items of a tile are consecutive in the sequence AND in
+ * memory, so a workgroup's share is a handful of RUNS -- contiguous contact ranges of one tile each: it stages a tile's blocks
+ * once and streams the run.  (Until round 3: items of 16 384 contacts handed out one at a time to persistent workgroups
+ * through an atomic cursor, the blocks staged again for every item: 10 us of staging per workgroup and a launch that ended
+ * 25 us after its median workgroup, tools/tile_trace.py.) */
+struct TileRun {
+    long long off;
+    int n, bi, bj;
+};
+struct TileRuns {
+    const TileWork* work;
+    const int* dyn_list;
+    int n_static, p, pe;
+    __device__ __forceinline__ TileRuns(const TileWork* w, const int* dl, int ns, int n_dyn) : work(w), dyn_list(dl), n_static(ns)
+    {
+        const long long T = (long long)ns + n_dyn;
+        p = (int)((long long)blockIdx.x * T / gridDim.x);
+        pe = (int)((long long)(blockIdx.x + 1) * T / gridDim.x);
+    }
+    __device__ __forceinline__ int item(int q) const { return q < n_static ? q : dyn_list[q - n_static]; }
+    __device__ __forceinline__ bool next(TileRun& r)
+    {
+        if (p >= pe) return false;
+        /* two dependent loads per run, whatever its length: the first item says how many items of its tile follow it (they sit
+         * behind it in `work`, and -- static part or list -- at the positions behind p), the last one where the run ends */
+        const int it0 = item(p);
+        const TileWork w0 = work[it0];
+        int k = min(pe - p, w0.pad + 1);
+        if (p < n_static) k = min(k, n_static - p);
+        const TileWork wl = work[it0 + k - 1];
+        r.off = w0.off;
+        r.n = (int)(wl.off - w0.off) + wl.n;
+        r.bi = w0.bi;
+        r.bj = w0.bj;
+        p += k;
+        return true;
+    }
+};
+
 struct FullTiledLds {
     ScoreTables tab;
     unsigned long long qtrans[LDS_LGF]; /* the quantised term of a trans pair with count ob (it depends on nothing else), + the rounding magic */
@@ -1298,9 +1339,25 @@ __global__ void __launch_bounds__(256) k_nuis_prepare(Glob* g, int which, ig_par
                                                       const double* __restrict__ lgf_tab, ScoreConst* out, long long* scratch8, Tables t,
                                                       int M, int4* __restrict__ rec, unsigned* __restrict__ sig, int tb, int* dyn2, int n_pack,
                                                       const ScoreConst* __restrict__ sc0 = nullptr, int pz_n0 = 0, DiffConst* dc = nullptr,
-                                                      long long* diff8 = nullptr, const ScreenConst* __restrict__ scr0 = nullptr)
+                                                      long long* diff8 = nullptr, const ScreenConst* __restrict__ scr0 = nullptr,
+                                                      Tables live = Tables{nullptr, nullptr, nullptr, nullptr}, const int* __restrict__ prev_touched = nullptr)
 {
     if ((int)blockIdx.x < n_pack) {
+        if (live.dist) { /* tab_prev := the state before the move about to be decided (k_catch_up's job, one launch and one stream
+                          * event less at the head of every step): each block of sub-fragments takes the touched entries of its own
+                          * range before it packs them */
+            const int s0 = (int)blockIdx.x * tb, s1 = s0 + tb, n = g->n_prev_touched;
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int s = prev_touched[i];
+                if (s >= s0 && s < s1) {
+                    t.dist[s] = live.dist[s];
+                    t.stot[s] = live.stot[s];
+                    t.cp[s] = live.cp[s];
+                    t.len[s] = live.len[s];
+                }
+            }
+            __syncthreads();
+        }
         pack_tab_sig_block(t, M, rec, sig, tb, dyn2);
         return;
     }
@@ -1355,18 +1412,11 @@ __global__ void __launch_bounds__(FULL_TILED_THREADS, 8) /* 8 waves per SIMD: tw
     unsigned long long acc = 0, accl = 0;
     int n_items = 0, n_contacts = 0;
     const int nth = blockDim.x;
-    /* persistent workgroups over ONE sequence of items: the static ones, then the list of k_tile_trans; a workgroup starts
-     * with item blockIdx.x and takes the next free one when it is through (dispatching a workgroup per item left the last
-     * third of the launch to a quarter of the CUs) */
-    for (int seq = (int)blockIdx.x;;) {
-        int it;
-        if (seq < n_static) {
-            it = seq;
-        } else {
-            if (seq - n_static >= dyn->count) break;
-            it = dyn_list[seq - n_static];
-        }
-        const TileWork wk = work[it];
+    /* this workgroup's share of the pass: runs of contacts of one tile each (tile_runs) */
+    TileRuns runs(work, dyn_list, n_static, dyn->count);
+    TileRun wk;
+    int st_bi = -1, st_bj = -1;
+    while (runs.next(wk)) {
         const bool diag = wk.bi == wk.bj;
         n_items++;
         n_contacts += wk.n;
@@ -1374,19 +1424,23 @@ __global__ void __launch_bounds__(FULL_TILED_THREADS, 8) /* 8 waves per SIMD: tw
         const uint2* src = tc + wk.off;
         const int n = wk.n;
         uint2 nx0 = src[min((int)threadIdx.x, n - 1)], nx1 = src[min((int)threadIdx.x + nth, n - 1)];
-        for (int i = threadIdx.x; i < FULL_TB; i += nth) {
-            const int gi = wk.bi * FULL_TB + i, gj = wk.bj * FULL_TB + i;
-            const int4 a = gi < M ? rec[gi] : make_int4(0, 0, -1, 0);
-            L.rrec[i] = make_uint2((unsigned)a.x, (unsigned)a.w | (__int_as_float(a.y) != 0.0f ? 0x80000000u : 0u));
-            L.rctg[i] = a.z;
-            if (!diag) {
-                const int4 b = gj < M ? rec[gj] : make_int4(0, 0, -2, 0);
-                L.crec[i] = make_uint2((unsigned)b.x, (unsigned)b.w | (__int_as_float(b.y) != 0.0f ? 0x80000000u : 0u));
-                L.cctg[i] = b.z;
+        if (st_bi != wk.bi || st_bj != wk.bj) {
+            __syncthreads(); /* everybody is through with the blocks of the run before */
+            for (int i = threadIdx.x; i < FULL_TB; i += nth) {
+                const int gi = wk.bi * FULL_TB + i, gj = wk.bj * FULL_TB + i;
+                const int4 a = gi < M ? rec[gi] : make_int4(0, 0, -1, 0);
+                L.rrec[i] = make_uint2((unsigned)a.x, (unsigned)a.w | (__int_as_float(a.y) != 0.0f ? 0x80000000u : 0u));
+                L.rctg[i] = a.z;
+                if (!diag) {
+                    const int4 b = gj < M ? rec[gj] : make_int4(0, 0, -2, 0);
+                    L.crec[i] = make_uint2((unsigned)b.x, (unsigned)b.w | (__int_as_float(b.y) != 0.0f ? 0x80000000u : 0u));
+                    L.cctg[i] = b.z;
+                }
             }
+            __syncthreads();
+            st_bi = wk.bi;
+            st_bj = wk.bj;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) L.next_item = (int)gridDim.x + atomicAdd(&dyn->next, 1); /* the item after this one: its number is on its way while this one is summed */
         const uint2* cre = diag ? L.rrec : L.crec;
         const int* cct = diag ? L.rctg : L.cctg;
         for (int e0 = threadIdx.x; e0 < n; e0 += 2 * nth) {
@@ -1465,8 +1519,6 @@ __global__ void __launch_bounds__(FULL_TILED_THREADS, 8) /* 8 waves per SIMD: tw
                     accl += (unsigned)bits[u];
                 }
         }
-        __syncthreads(); /* everybody is through with the staged blocks (and the next item's number, requested at the start of this one, is there) */
-        seq = L.next_item;
     }
     long long hi = ((long long)acc - (long long)accl) >> 32, lo = (long long)accl;
     if (blockIdx.x == 0) /* the histogram sums of the tiles that were not read (k_tile_trans, one pair per workgroup) */
