@@ -2005,7 +2005,11 @@ static int launch_nuis_diff(ig_ctx* c, const ig_params& hp, float mean_kb, hipSt
     hipLaunchKernelGGL(k_tile_trans, dim3(n_trans + n_zero), dim3(TILE_TRANS_THREADS), 0, s3, c->tile_info, c->n_tile_info, c->tile_sig, c->tile_hist,
                        c->full_const, (TileDyn*)c->tile_dyn, c->tile_dyn_list, 1, c->tile_partial, n_trans, t, c->glob, 1, c->M, c->scratch_nuis + 2,
                        c->score_const, c->tile_partial0);
-    static const int s_grid = getenv("IG_FULL_GRID") ? atoi(getenv("IG_FULL_GRID")) : 512;
+    /* two workgroups per CU less two: the one-wave kernels of the move next to the pass (decide, commit) find a SIMD with registers
+     * to spare at once (the stream workgroups take all 512 VGPRs of a SIMD between them).  (Measured and dropped: k_tile_trans's
+     * blocks as the head of this kernel's grid, the stream workgroups waiting for them in front of the list: 95 - 112 us instead of
+     * 11 + 68 - 84 -- 400 head blocks with this kernel's footprint hold the machine before the first contact is read.) */
+    static const int s_grid = getenv("IG_FULL_GRID") ? atoi(getenv("IG_FULL_GRID")) : 510;
     static const int s_grid_side = getenv("IG_FULL_GRID_SIDE") ? atoi(getenv("IG_FULL_GRID_SIDE")) : 256;
     const int grid = std::min(c->n_tile_work, c->side_busy ? s_grid_side : s_grid);
     {
@@ -2567,13 +2571,15 @@ extern "C" int ig_nuis_step_next(ig_ctx* c, double temperature, double u, const 
     if (has_next && acc == 1 && c->spec_move < c->up_moves) {
         /* (first what the pass of the next step waits for, or it would queue behind the scoring launches) */
         hipLaunchKernelGGL(k_catch_up, dim3(16), dim3(256), 0, c->stream, c->tab, c->tab_prev, c->prev_touched, c->glob);
-        HIPCK(hipEventRecord(c->ev_gathered, c->stream));
+        static const int s_serial = getenv("IG_NUIS_SERIAL") ? atoi(getenv("IG_NUIS_SERIAL")) : 0; /* the next pass behind the scoring launches, not next to them */
+        if (!s_serial) HIPCK(hipEventRecord(c->ev_gathered, c->stream));
         c->nuis_caught_up = true;
         if (nuis_spec_can_rescore(c, c->spec_move)) {
             if (nuis_spec_rescore(c)) return -1;
         } else if (nuis_spec_score(c, c->spec_move)) {
             return -1;
         }
+        if (s_serial) HIPCK(hipEventRecord(c->ev_gathered, c->stream));
     }
     return 0;
 }

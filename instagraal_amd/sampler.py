@@ -460,6 +460,7 @@ class sampler:  # noqa: N801 - the reference's class name
         import time as _t
 
         prof = self.nuis_profile = dict(propose=0.0, step=0.0, book=0.0)
+        trace = getattr(self, "nuis_step_trace", None)  # a list: (seconds, accepted) per step (tools/nuisance_rate.py)
         curr = np.copy(self.param_simu)
         out = proposal(0, curr)
         names = res.dtype.names
@@ -508,6 +509,8 @@ class sampler:  # noqa: N801 - the reference's class name
             prof["propose"] += t1 - ta
             prof["step"] += t2 - t1
             prof["book"] += t3 - t2
+            if trace is not None:
+                trace.append((t3 - ta, int(success)))
         last = res[-1]
         self.o = float(last["o"])
         self.n_contigs = np.int32(last["n_contigs"])

@@ -366,3 +366,75 @@ def write_text_dataset(folder, n_contigs=10, mean_frags=110, seed=7, contacts_pe
             for i in range(0, len(seq), 70):
                 f.write(seq[i:i + 70] + "\n")
     return n, len(pairs)
+
+
+def write_text_dataset_large(folder, n_frags0=85_000, n_contigs=140, seed=11, contacts_per_frag=30, median_bp=300.0):
+    """The same three text files + FASTA as ``write_text_dataset`` at the scale of BASELINE.json's config 1 (a
+    yeast-like folder, ~85 k restriction fragments on ~140 contigs; level 4 of its pyramid has ~1 000 bins), generated with
+    array operations (the small generator's per-contact Python loop would take hours here).  Cis partners: the fragment of
+    the same contig nearest to a log-uniform genomic offset (~ 1/s decay); trans partners uniform; a few fragments below the
+    builder's 50 bp filter and a few without any contact.  Returns (n_frags, n_contact_lines)."""
+    import os
+
+    rng = np.random.default_rng(seed)
+    os.makedirs(folder, exist_ok=True)
+    w = rng.dirichlet(np.full(n_contigs, 3.0))
+    sizes = np.maximum(20, np.round(w * n_frags0)).astype(np.int64)
+    n = int(sizes.sum())
+    names = ["ctg%03d" % (i + 1) for i in range(n_contigs)]
+    contig_of = np.repeat(np.arange(n_contigs), sizes)
+    first = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    lens = np.clip(np.round(rng.lognormal(np.log(median_bp), 0.6, size=n)), 20, 4000).astype(np.int64)
+    short = rng.random(n) < 0.02
+    lens[short] = rng.integers(20, 50, size=int(short.sum()))
+    ends_glob = np.cumsum(lens)
+    base = np.concatenate([[0], ends_glob])[first][contig_of]  # bp before the fragment's contig
+    ends = ends_glob - base
+    begins = ends - lens
+    mids_kb = (begins + ends) / 2000.0
+    idx_in = np.arange(n) - first[contig_of] + 1
+    gc = rng.uniform(0.3, 0.6, size=n)
+    with open(os.path.join(folder, "fragments_list.txt"), "w") as f:
+        f.write("id\tchrom\tstart_pos\tend_pos\tsize\tgc_content\n")
+        f.write("".join("%d\t%s\t%d\t%d\t%d\t%.4f\n" % (idx_in[k], names[contig_of[k]], begins[k], ends[k], lens[k], gc[k]) for k in range(n)))
+    clen = ends[first + sizes - 1]
+    with open(os.path.join(folder, "info_contigs.txt"), "w") as f:
+        f.write("contig\tlength\tn_frags\tcumul_length\n")
+        for ci in range(n_contigs):
+            f.write("%s\t%d\t%d\t%d\n" % (names[ci], clen[ci], sizes[ci], first[ci]))
+    # contacts
+    dead = rng.random(n) < 0.015
+    n_draw = n * contacts_per_frag
+    a = rng.integers(0, n, size=n_draw)
+    cis = rng.random(n_draw) < 0.85
+    off = np.exp(rng.uniform(np.log(0.3), np.log(300.0), size=n_draw)) * rng.choice([-1.0, 1.0], size=n_draw)
+    # nearest fragment of the same contig to mids[a] + off: search in a key that orders contigs apart
+    span = float(mids_kb.max()) + 1e4
+    key = contig_of * (4.0 * span) + mids_kb
+    want = contig_of[a] * (4.0 * span) + np.clip(mids_kb[a] + off, 0.0, span)
+    pos = np.searchsorted(key, want)
+    lo, hi = first[contig_of[a]], first[contig_of[a]] + sizes[contig_of[a]] - 1
+    p0 = np.clip(pos - 1, lo, hi)
+    p1 = np.clip(pos, lo, hi)
+    b_cis = np.where(np.abs(key[p0] - want) <= np.abs(key[p1] - want), p0, p1)
+    b = np.where(cis, b_cis, rng.integers(0, n, size=n_draw))
+    ok = (a != b) & ~dead[a] & ~dead[b]
+    fa, fb = np.minimum(a[ok], b[ok]), np.maximum(a[ok], b[ok])
+    pair, cnt = np.unique(fa.astype(np.int64) * n + fb, return_counts=True)
+    with open(os.path.join(folder, "abs_fragments_contacts_weighted.txt"), "w") as f:
+        f.write("id_frag_a\tid_frag_b\tn_contact\n")
+        f.write("".join("%d\t%d\t%d\n" % (q // n, q % n, k) for q, k in zip(pair.tolist(), cnt.tolist())))
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    with open(os.path.join(folder, "genome.fa"), "wb") as f:
+        for ci in range(n_contigs):
+            seq = letters[rng.integers(0, 4, size=int(clen[ci]))]
+            f.write((">%s\n" % names[ci]).encode())
+            full = (len(seq) // 70) * 70
+            if full:
+                body = np.empty((full // 70, 71), np.uint8)
+                body[:, :70] = seq[:full].reshape(-1, 70)
+                body[:, 70] = 10
+                f.write(body.tobytes())
+            if len(seq) > full:
+                f.write(seq[full:].tobytes() + b"\n")
+    return n, int(pair.size)

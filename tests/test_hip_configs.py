@@ -72,6 +72,19 @@ def test_cfg2_live_oracle_then_properties():
         assert np.array_equal(s.all_scores, o.all_scores)
         assert (a[0], a[1], a[2], a[3], float(a[4]), int(a[5])) == (b[0], b[1], b[2], b[3], float(b[4]), int(b[5]))
     assert np.array_equal(s.gpu_vect_frags.copy_from_gpu().soa17(), o.gpu_vect_frags.soa17())
+    # the next 40 moves through the BATCH path (speculative batches, two-tier scoring, the draw inside the call) against the
+    # oracle drawing with numpy and stepping one move at a time from the same generator state
+    more = frags[40:80].astype(np.int32)
+    st = np.random.get_state()
+    res = s.step_sampler_batch(more, 5)
+    after = np.random.get_state()
+    np.random.set_state(st)
+    for f, r in zip(more, res):
+        b = o.step_sampler(int(f), 5, o.dt)
+        assert (float(r["o"]), float(r["dist"]), int(r["op_sampled"]), int(r["id_f_sampled"]), float(np.float32(r["mean_len"])), int(r["n_contigs"])) == (
+            b[0], b[1], b[2], b[3], float(b[4]), int(b[5]))
+    assert np.array_equal(np.random.get_state()[1], after[1]) and np.random.get_state()[2] == after[2]
+    assert np.array_equal(s.gpu_vect_frags.copy_from_gpu().soa17(), o.gpu_vect_frags.soa17())
     s.free_gpu()
     del o
     # 2 000 moves: maintained sums, batch-width independence, structural validity

@@ -141,3 +141,43 @@ def test_replay_golden(case):
     # the maintained exact sums equal a from-scratch recomputation
     nz2, z2, limbs = ctx.full_likelihood()
     res, _ = ctx.step(int(g["frag"][0]), [int(c) for c in g["cands"][0] if c >= 0])
+
+
+@pytest.mark.parametrize("cut", [False, True])
+@pytest.mark.parametrize("case", CASES)
+def test_replay_golden_through_the_batch_path(case, cut):
+    """The same golden trajectories through ``ig_step_batch`` -- the speculative batches of 24 moves, two-tier scoring (float
+    screening + exact contenders), in-order commit on the device: what ``bench.py`` and ``full_em`` run -- instead of one
+    ``ig_step`` per move: return tuples, stale flags after the run, genome states.  Checkpoint states are compared by cutting
+    the run into calls at the checkpoints (results do not depend on where a run is cut)."""
+    from instagraal_amd import hip_lib, synth
+
+    g = np.load(os.path.join(GOLDEN, case + ".npz"))
+    prob = synth.make_problem(*synth.CONFIGS[str(g["config"])])
+    ctx = make_ctx(prob)
+    if bool(g["bomb"]):
+        ctx.bomb(np.arange(prob.n_frags, dtype=np.int32))
+    frags = np.asarray(g["frag"], np.int32)
+    cands = np.asarray(g["cands"], np.int32)
+    # cut: one call per checkpoint interval (every stored genome state is compared); else ONE call (full-width batches), the
+    # last stored state being the final one
+    cuts = sorted(set(int(t) + 1 for t in g["state_every"]) | {len(frags)}) if cut else [len(frags)]
+    assert int(g["state_every"][-1]) == len(frags) - 1
+    b0 = ctx.batch_stats()["batches"]
+    start = 0
+    for end in cuts:
+        res = ctx.step_batch(frags[start:end], cands[start:end])
+        for t in range(start, end):
+            r, q = g["ret"][t], res[t - start]
+            got = (float(q["o"]), float(q["dist"]), int(q["op_sampled"]), int(q["id_f_sampled"]), float(q["mean_len"]), int(q["n_contigs"]))
+            assert got == (r[0], r[1], int(r[2]), int(r[3]), r[4], int(r[5])), (t, got, list(r))
+        assert np.array_equal(ctx.valid_insert(), g["valid"][end - 1]), end
+        if end - 1 in g["state_every"]:
+            k = list(g["state_every"]).index(end - 1)
+            assert np.array_equal(ctx.download_state(), g["states"][k]), end
+        start = end
+    assert ctx.batch_stats()["batches"] - b0 < len(frags)  # the moves went through batches (a few contigs: many conflicts, short batches)
+    sums, _ = ctx.debug_globals()
+    _, _, limbs = ctx.full_likelihood()
+    assert [int(x) for x in sums[:5]] == [int(x) for x in limbs[:5]]
+    ctx.close()

@@ -35,6 +35,7 @@ print("   screened pass:", s.ctx.debug_nuis_screen_stats())
 if hasattr(s, "nuis_profile"):
     tot = sum(s.nuis_profile.values())
     print("   host time per move: " + ", ".join("%s %.0f us" % (k, 1e6 * v / n) for k, v in s.nuis_profile.items()) + " (sum %.0f us)" % (1e6 * tot / n))
+s.nuis_step_trace = []
 if os.environ.get("NUIS_LONG"):  # the rate as the chain settles: chunks of 600 moves
     for k in range(int(os.environ["NUIS_LONG"])):
         fr = np.random.permutation(prob.n_frags)[:600]
@@ -42,6 +43,12 @@ if os.environ.get("NUIS_LONG"):  # the rate as the chain settles: chunks of 600 
         t0 = time.perf_counter()
         res, tup = s.step_sampler_nuisance_batch(fr, 5, s.dt, 0, 600)
         dt = time.perf_counter() - t0
+        tr = np.array(s.nuis_step_trace)
+        s.nuis_step_trace.clear()
+        rej, acc = tr[tr[:, 1] == 0, 0] * 1e6, tr[tr[:, 1] == 1, 0] * 1e6
+        print("            per step: rejected n=%d median %.0f us, p25 %.0f, p75 %.0f, p95 %.0f, mean %.0f; accepted n=%d median %.0f us mean %.0f" % (
+            len(rej), np.median(rej), np.percentile(rej, 25), np.percentile(rej, 75), np.percentile(rej, 95), rej.mean(), len(acc),
+            np.median(acc) if len(acc) else 0, acc.mean() if len(acc) else 0))
         print("   chunk %d: %.0f moves/s, accept %.2f, device wait %.0f us/move, host %s, %s" % (
             k, 600 / dt, np.mean([q[6] for q in tup]), 1e6 * (s.ctx.debug_nuis_wait() - w0) / 600,
             ", ".join("%s %.0f" % (a, 1e6 * v / 600) for a, v in s.nuis_profile.items()), s.ctx.debug_nuis_screen_stats()), flush=True)
