@@ -169,6 +169,11 @@ int ig_nuis_step_next(ig_ctx* ctx, double temperature, double u, const float p_n
  * step runs the exact pass as well.  0 = the exact pass on every step (env IG_NUIS_SCREEN); env IG_NUIS_SCREEN_VERIFY=1: both
  * on every step, the bound checked. */
 int ig_set_nuis_screen(int on);
+/* *accepted = 3 from ig_nuis_step_next: the step was ACCEPTED from the screened interval alone (every L_test in it gives a ratio
+ * above u); its exact pass -- the promotion of the maintained sum needs it, the decision does not -- runs behind the decision, next
+ * to the re-scoring of the moves ahead; *nz_test was the interval's midpoint.  The exact value (what eval_likelihood_4_nuisance
+ * returns, CL:1296-1344, and likelihood_t becomes, CL:3036): here, any time before the next step is accepted that way. */
+int ig_nuis_exact_result(ig_ctx* ctx, double* nz_test);
 
 /* ---- bookkeeping -------------------------------------------------------- */
 int ig_renumber_contigs(ig_ctx* ctx, int32_t* n_contigs, float* mean_len, int32_t* max_id); /* CL:2715-2881 */

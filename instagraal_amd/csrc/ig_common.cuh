@@ -196,6 +196,12 @@ struct MoveBuf {
      * the moves of this batch committed meanwhile}.  The Q5 tail walk is the one scoring step that reads the live tables: it
      * skips a slot whose contigs are on the list (the decide step stops in front of such a slot anyway) */
     const int* stale;
+    /* the Q5 tail of a candidate's slice list -- its last S_c mod 64 contacts as (local row, local column, count) -- found once per
+     * structural scoring (a radix descent over the window's rows and a walk of their ends: the longest chain of the scoring
+     * launches) and kept for the re-evaluations under other parameters: tail_n[cw] = -1 not walked yet (k_gather), else the number
+     * of entries in tail_ent[cw][3][64] */
+    int* tail_n;
+    int* tail_ent;
     int N, M, capC, capW;
     /* strides of the per-window arrays above (Lloc .. loc: sN fragments, subs / rowcnt / coords: sM sub-fragments): the
      * largest window the genome can produce right now -- two contigs of the current maximum length, with headroom -- not
@@ -228,6 +234,10 @@ struct NuisHost {
     long long diff[8];
     long long nzb[2];
     volatile int diff_seq;
+    /* an accepted step whose exact pass ran BEHIND the decision (the screened interval was decisive): the pass's exact limbs, left by
+     * the promotion of the sums (k_nuis_promote, mode 2) */
+    long long exact[2];
+    volatile int exact_seq;
 };
 
 struct ig_ctx {
@@ -253,6 +263,14 @@ struct ig_ctx {
     bool nuis_diff;               /* the step in flight ran the screened pass (the exact one only if it does not decide) */
     bool nuis_exact_queued;       /* ... and the exact pass behind it already (verify mode) */
     bool nuis_screen_rejected;    /* the last ig_nuis_end: rejected from the screened interval, no exact pass */
+    /* a decisively accepted step: the exact pass (needed for the promotion of the maintained sum and for the returned likelihood,
+     * not for the decision) runs on the side stream while the library stream promotes the parameters and re-scores the moves
+     * ahead; the sums are promoted in front of the next kernel that reads them (flush_pending_sums) */
+    long long* scratch_exact;
+    hipEvent_t ev_exact;
+    bool nuis_sums_pending, nuis_accept_certain;
+    int exact_seq;
+    bool nuis_nzb_copied;         /* the step's move was finished outside the batch commit: its NuisHost.nzb was copied from the control block */
     double nscr[12];               /* statistics: steps screened, rejected from the interval, exact passes, void, largest bound, largest used fraction, sum of bounds */
     bool nuis_in_flight;
     bool side_busy;      /* launch_full_nz on a side stream: the library stream is busy with a batch (one workgroup per CU for the pass) */

@@ -44,6 +44,7 @@
 #include "ig_kernels_nuis.cuh"
 
 /* ================================================================== host side */
+static void flush_pending_sums(ig_ctx* c); /* behind a decisively accepted nuisance step: see k_nuis_promote */
 
 template <class T>
 static int dalloc(T** p, size_t n)
@@ -195,6 +196,10 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->tile_partial0 = nullptr;
     c->diff_seq = 0;
     c->nuis_diff = c->nuis_exact_queued = c->nuis_screen_rejected = false;
+    c->scratch_exact = nullptr;
+    c->nuis_sums_pending = c->nuis_accept_certain = false;
+    c->exact_seq = 0;
+    HIPCK(hipEventCreateWithFlags(&c->ev_exact, hipEventDisableTiming));
     for (double& v : c->nscr) v = 0.0;
     HIPCK(hipEventCreateWithFlags(&c->ev_slice, hipEventDisableTiming));
     HIPCK(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
@@ -278,6 +283,8 @@ static void free_move_buffers(ig_ctx* c)
     hipFree(m.ident);
     hipFree(m.work);
     hipFree(m.slot_items);
+    hipFree(m.tail_n);
+    hipFree(m.tail_ent);
     hipFree(c->own_tag);
     hipFree(c->own_idx);
     c->own_tag = c->own_idx = nullptr;
@@ -299,6 +306,8 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipStreamDestroy(c->stream3);
     hipEventDestroy(c->ev_gathered);
     hipEventDestroy(c->ev_main);
+    hipEventDestroy(c->ev_exact);
+    hipFree(c->scratch_exact);
     if (c->host_nuis) hipHostFree(c->host_nuis);
     if (c->h_stage) hipHostFree(c->h_stage);
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
@@ -354,6 +363,7 @@ extern "C" void ig_destroy(ig_ctx* c)
 extern "C" int ig_sync(ig_ctx* c)
 {
     HIPCK(hipSetDevice(c->device));
+    flush_pending_sums(c);
     HIPCK(hipStreamSynchronize(c->stream));
     drain_timers(c);
     return 0;
@@ -540,6 +550,9 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
     m.work_cap = (int)std::min<size_t>((size_t)1 << 20, 4 * C * NSLOT * SLICE_SEG + 4096);
     DALLOC(m.work, (size_t)m.work_cap + 32);
     DALLOC(m.slot_items, (size_t)capW * 8);
+    DALLOC(m.tail_n, C);
+    DALLOC(m.tail_ent, C * 3 * 64);
+    HIPCK(hipMemset(m.tail_n, 0xff, C * sizeof(int)));
     HIPCK(hipMemset(m.cont, 0xff, C * sizeof(unsigned)));
     DALLOC(c->own_tag, N);
     DALLOC(c->own_idx, N);
@@ -1096,6 +1109,7 @@ static int check_ready(ig_ctx* c)
 {
     if (!c->have_contacts || !c->have_sub || !c->have_state || !c->have_params)
         return fail("contacts, sub-fragment table, state and parameters must be uploaded before a move");
+    flush_pending_sums(c);
     c->nuis_caught_up = false;
     c->main_drained = false;
     c->nuis_spec = c->spec_valid = false; /* every entry point that runs moves passes here: a run of ig_nuis_step_begin ends with it */
@@ -1296,6 +1310,7 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                 if (c->exact_grid <= 0) c->exact_grid = 32768;
                 c->exact_grid = std::max(std::min(c->exact_grid, c->mb.work_cap), exact_grid_floor(c, max_c));
                 if (!c->tail_fused) hipStreamWaitEvent(c->stream, c->ev_tail, 0); /* the contender test reads the exact tail sums (quirk Q5) */
+                flush_pending_sums(c); /* ... and the maintained sum (its intervals are placed with it) */
                 hipLaunchKernelGGL(k_contend, dim3(nWp), dim3(256), 0, c->stream, c->glob, c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, c->mb.cont, pb,
                                    getenv("IG_CONTEND_ALL") ? atoi(getenv("IG_CONTEND_ALL")) : 0, c->exact_grid,
                                    getenv("IG_EXACT_CHUNK") ? std::max(256, atoi(getenv("IG_EXACT_CHUNK"))) : EXACT_CHUNK);
@@ -1403,6 +1418,7 @@ static int validate_move(ig_ctx* c, int frag_a, const int32_t* cands, int C)
 /* the decide + apply launches of the slots [next, w_now) of the batch at move `done` */
 static void launch_commit(ig_ctx* c, int done, int w_now, int next, int resumed_plain, bool publish = false)
 {
+    flush_pending_sums(c);
     TimedLaunch t(c, T_COMMIT);
     hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(64), 0, c->stream, c->glob, c->mb, c->d_results, done, w_now, next, c->dirty_buf,
                        c->batch_out, (volatile int*)c->host_bo_dev, ++c->bo_seq, resumed_plain);
@@ -1972,16 +1988,18 @@ extern "C" int ig_set_nuis_screen(int on)
 }
 
 /* the exact tiles kernel over the list the step's k_tile_trans left (tables, signatures, constants of the test set are in place) */
-static void launch_nuis_exact_tiles(ig_ctx* c, hipStream_t s3)
+static void launch_nuis_exact_tiles(ig_ctx* c, hipStream_t s3, long long* out = nullptr, bool publish = true)
 {
+    if (!out) out = c->scratch_nuis;
     static const int s_grid = getenv("IG_FULL_GRID") ? atoi(getenv("IG_FULL_GRID")) : 512;
     const int per = TILE_TRANS_THREADS / 64;
     const int n_trans = (c->n_tile_info + per - 1) / per;
     const int grid = std::min(c->n_tile_work, s_grid);
     hipLaunchKernelGGL(k_full_nz_tiled, dim3(grid), dim3(FULL_TILED_THREADS), sizeof(FullTiledLds), s3, c->tile_work, c->tiled_cc, c->tabrec,
-                       c->tab_prev.len, c->full_const, c->lgf_tab, c->M, c->pz_n1, c->scratch_nuis, c->n_tile_static, (TileDyn*)c->tile_dyn,
-                       c->tile_dyn_list, (long long*)nullptr, c->host_nuis_dev, ++c->sums_seq, c->tile_partial, n_trans);
-    c->nuis_pub_sums = true;
+                       c->tab_prev.len, c->full_const, c->lgf_tab, c->M, c->pz_n1, out, c->n_tile_static, (TileDyn*)c->tile_dyn,
+                       c->tile_dyn_list, (long long*)nullptr, publish ? c->host_nuis_dev : (NuisHost*)nullptr, publish ? ++c->sums_seq : 0, c->tile_partial,
+                       n_trans);
+    if (publish) c->nuis_pub_sums = true;
 }
 
 static int launch_nuis_diff(ig_ctx* c, const ig_params& hp, float mean_kb, hipStream_t s3, bool fuse_catch = false)
@@ -2313,9 +2331,14 @@ static int nuis_spec_finish(ig_ctx* c)
         redone = true;
     }
     c->spec_slot = c->spec_next;
+    c->nuis_nzb_copied = false;
     if (redone) {
         c->nuis_pub_res = false;
         HIPCK(hipMemcpyAsync(&c->host_nuis->res, c->d_results + c->spec_move, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
+        /* ... and the maintained sum of the state the move was decided against (the decide step left it in the slot's control
+         * block): the step's screened pass starts from it */
+        HIPCK(hipMemcpyAsync((void*)c->host_nuis->nzb, &c->mb.ctl[c->spec_slot].nzb_hi, 2 * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+        c->nuis_nzb_copied = true;
         if (queue_max_readback(c)) return -1;
     }
     c->spec_next++;
@@ -2346,6 +2369,7 @@ static int nuis_end_impl(ig_ctx* c, ig_move_result* out, double* nz_test, double
     if (!c->nuis_in_flight) return fail("ig_nuis_end: no step in flight");
     c->nuis_in_flight = false;
     c->nuis_screen_rejected = false;
+    c->nuis_accept_certain = false;
     const auto w0 = std::chrono::steady_clock::now();
     if (c->nuis_spec && nuis_spec_finish(c)) return -1;
     bool have_nzb = false;
@@ -2360,6 +2384,7 @@ static int nuis_end_impl(ig_ctx* c, ig_move_result* out, double* nz_test, double
         }
         HIPCK(hipStreamSynchronize(c->stream));
         take_max_readback(c);
+        have_nzb = c->nuis_spec && c->nuis_nzb_copied;
     }
     /* the screened pass: decide from its interval where that is possible */
     bool scr_valid = false;
@@ -2390,12 +2415,40 @@ static int nuis_end_impl(ig_ctx* c, ig_move_result* out, double* nz_test, double
             scr_valid = true;
             c->nscr[4] = std::max(c->nscr[4], scr_B);
             c->nscr[6] += scr_B;
+            bool accept = false;
             if (Tu && Tu[0] > 0.0 && Tu[1] > 0.0 && !g_nuis_screen_verify) {
                 const double z = nuis_z_from_sums((const long long*)hn->sums);
-                const double x_hi = (((scr_mid + scr_B) + z) - hn->res.o) / Tu[0];
+                const double x_hi = (((scr_mid + scr_B) + z) - hn->res.o) / Tu[0], x_lo = (((scr_mid - scr_B) + z) - hn->res.o) / Tu[0];
                 reject = exp(x_hi) <= Tu[1] * (1.0 - 1e-9); /* exp is monotone: every L_test in the interval gives a ratio below u */
+                static const int s_defer = getenv("IG_NUIS_DEFER") ? atoi(getenv("IG_NUIS_DEFER")) : 1;
+                accept = s_defer && !reject && exp(x_lo) >= Tu[1] * (1.0 + 1e-9) && c->host_nuis_dev; /* ... above it: accepted whatever the exact sum */
             }
-            if (!reject) c->nscr[7] += 1.0;
+            if (!reject && !accept) c->nscr[7] += 1.0;
+            if (accept) {
+                /* the exact pass is needed -- for the maintained sum under the new parameters and for the likelihood the step
+                 * returns -- but not for the decision: it runs on the side stream while the library stream promotes the parameters
+                 * and re-scores the moves ahead; its sums are promoted in front of the next kernel that reads the maintained sum
+                 * (flush_pending_sums), the caller fetches the exact value later (ig_nuis_exact_result) */
+                if (!c->scratch_exact) {
+                    DALLOC(c->scratch_exact, 8);
+                    HIPCK(hipMemset(c->scratch_exact, 0, 8 * sizeof(long long)));
+                }
+                c->nscr[2] += 1.0;
+                launch_nuis_exact_tiles(c, c->stream3, c->scratch_exact, false);
+                HIPCK(hipEventRecord(c->ev_exact, c->stream3));
+                c->nuis_sums_pending = true;
+                c->nuis_accept_certain = true;
+                c->nuis_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+                drain_timers(c);
+                c->main_drained = c->nuis_spec;
+                *out = hn->res;
+                if (out->error) return fail("device-side consistency failure %d", out->error);
+                if (nz_test) *nz_test = scr_mid;
+                if (z_test) *z_test = nuis_z_from_sums((const long long*)hn->sums);
+                if (limbs5)
+                    for (int i = 0; i < 5; i++) limbs5[i] = 0;
+                return 0;
+            }
         }
         if (reject) {
             c->nscr[1] += 1.0;
@@ -2467,6 +2520,23 @@ extern "C" int ig_debug_nuis_screen_stats(ig_ctx* c, double out12[12])
     return 0;
 }
 
+/* the exact likelihood of the non-zero pixels under the test parameters of the last step that ig_nuis_step_next reported with
+ * *accepted = 3 (decided from the screened interval, the exact pass behind the decision) */
+extern "C" int ig_nuis_exact_result(ig_ctx* c, double* nz_test)
+{
+    HIPCK(hipSetDevice(c->device));
+    if (c->exact_seq == 0 && !c->nuis_sums_pending) return fail("ig_nuis_exact_result: no step was accepted ahead of its exact pass");
+    flush_pending_sums(c);
+    NuisHost* hn = c->host_nuis;
+    if (!hn) return fail("ig_nuis_exact_result: no run");
+    if (!wait_host_flag(&hn->exact_seq, c->exact_seq, c->stream)) {
+        HIPCK(hipStreamSynchronize(c->stream));
+        if (hn->exact_seq != c->exact_seq) return fail("ig_nuis_exact_result: the promotion of the sums did not report");
+    }
+    *nz_test = ig_acc_to_double(hn->exact[0], hn->exact[1]);
+    return 0;
+}
+
 /* the accepted step's parameters become the model's (CL:3032-3036) without another pass over all contacts: the maintained
  * exact sum under the new parameters on the CURRENT state = their full pass on the state before the last move (what the
  * step just evaluated, quirk Q12) + that move's exact delta under them (k_delta over the touched contigs); the zero-pixel sum
@@ -2475,25 +2545,55 @@ extern "C" int ig_debug_nuis_screen_stats(ig_ctx* c, double out12[12])
  * accepted steps: the promotion clears what it has read.  One launch: thread 0 of block 0 promotes (parameters, maintained
  * sums), every block builds its share of the model's score / screening constants from the SAME parameters (set 1: what set 0
  * is being overwritten with), i.e. k_build_score_const and k_build_screen_const for the promoted set. */
-__global__ void __launch_bounds__(256) k_nuis_promote(Glob* g, const long long* __restrict__ full_sums, long long* acc8, PzTab pz,
-                                                      const double* __restrict__ lgf_tab, ScoreConst* score_const, ScreenConst* screen_const)
+/* mode 0: everything; 1: parameters, constants and the zero-pixel sum only (the exact pass over all contacts is still running:
+ * ig_nuis_accept behind a decisively accepted step); 2: the maintained sum, once that pass is through (flush_pending_sums: one
+ * block), its exact limbs to the host */
+__global__ void __launch_bounds__(256) k_nuis_promote(Glob* g, long long* full_sums, long long* acc8, PzTab pz, const double* __restrict__ lgf_tab,
+                                                      ScoreConst* score_const, ScreenConst* screen_const, int mode, NuisHost* hn, int hn_seq)
 {
-    build_score_const_block(g, pz, lgf_tab, score_const, 1);
-    build_screen_const_block(g, pz, screen_const, 1);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        g->par[0] = g->par[1];
-        long long h = full_sums[0] + acc8[6], l = full_sums[1] + acc8[7];
-        ig_acc_normalize((int64_t*)&h, (int64_t*)&l);
-        g->nz_hi = h;
-        g->nz_lo = l;
-        h = acc8[0];
-        l = acc8[1];
-        ig_acc_normalize((int64_t*)&h, (int64_t*)&l);
-        g->z_hi = h;
-        g->z_lo = l;
-        if (acc8[2] != g->n_intra) g->error = 8; /* the pair count does not depend on the parameters */
-        for (int q = 0; q < 8; q++) acc8[q] = 0;
+    if (mode != 2) {
+        build_score_const_block(g, pz, lgf_tab, score_const, 1);
+        build_screen_const_block(g, pz, screen_const, 1);
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (mode != 2) {
+            g->par[0] = g->par[1];
+            long long h = acc8[0], l = acc8[1];
+            ig_acc_normalize((int64_t*)&h, (int64_t*)&l);
+            g->z_hi = h;
+            g->z_lo = l;
+            if (acc8[2] != g->n_intra) g->error = 8; /* the pair count does not depend on the parameters */
+            for (int q = 0; q < 6; q++) acc8[q] = 0;
+        }
+        if (mode != 1) {
+            long long h = full_sums[0] + acc8[6], l = full_sums[1] + acc8[7];
+            ig_acc_normalize((int64_t*)&h, (int64_t*)&l);
+            g->nz_hi = h;
+            g->nz_lo = l;
+            acc8[6] = acc8[7] = 0;
+            if (mode == 2) {
+                long long eh = full_sums[0], el = full_sums[1];
+                ig_acc_normalize((int64_t*)&eh, (int64_t*)&el);
+                for (int q = 0; q < 8; q++) full_sums[q] = 0; /* the side buffer of the deferred pass: zero between two uses */
+                if (hn) {
+                    hn->exact[0] = eh;
+                    hn->exact[1] = el;
+                    __threadfence_system();
+                    hn->exact_seq = hn_seq;
+                }
+            }
+        }
+    }
+}
+
+/* the maintained sum of a decisively accepted step, as soon as something is about to read it: behind the exact pass (event) */
+static void flush_pending_sums(ig_ctx* c)
+{
+    if (!c->nuis_sums_pending) return;
+    c->nuis_sums_pending = false;
+    hipStreamWaitEvent(c->stream, c->ev_exact, 0);
+    hipLaunchKernelGGL(k_nuis_promote, dim3(1), dim3(64), 0, c->stream, c->glob, c->scratch_exact, c->scratch_accept, PzTab{c->pz_tab, c->pz_n}, c->lgf_tab,
+                       c->score_const, c->screen_const, 2, c->host_nuis_dev, ++c->exact_seq);
 }
 
 extern "C" int ig_nuis_accept(ig_ctx* c)
@@ -2533,7 +2633,7 @@ extern "C" int ig_nuis_accept(ig_ctx* c)
     std::swap(c->pz_n, c->pz_n1);
     const PzTab pz0{c->pz_tab, c->pz_n};
     hipLaunchKernelGGL(k_nuis_promote, dim3((LDS_PZ + 2 + 255) / 256), dim3(256), 0, c->stream, c->glob, c->scratch_nuis, acc8, pz0, c->lgf_tab,
-                       c->score_const, c->screen_const);
+                       c->score_const, c->screen_const, c->nuis_sums_pending ? 1 : 0, (NuisHost*)nullptr, 0);
     HIPCK(hipGetLastError());
     return 0;
 }
@@ -2557,11 +2657,12 @@ extern "C" int ig_nuis_step_next(ig_ctx* c, double temperature, double u, const 
     const double ratio = exp(((nz + z) - out->o) / temperature);
     int acc;
     if (c->nuis_screen_rejected) acc = 0; /* every L_test of the screened interval gives a ratio below u */
+    else if (c->nuis_accept_certain) acc = 1; /* ... above u */
     else if (ratio != ratio) acc = 0; /* NaN >= u is false */
     else if (ratio >= u * (1.0 + 1e-9)) acc = 1;
     else if (ratio <= u * (1.0 - 1e-9)) acc = 0;
     else acc = 2;
-    *accepted = acc;
+    *accepted = (acc == 1 && c->nuis_accept_certain) ? 3 : acc; /* 3: accepted, *nz_test is the screened midpoint, the exact value through ig_nuis_exact_result */
     if (acc == 2) return 0;
     if (acc == 1 && ig_nuis_accept(c)) return -1;
     const float* p_next = acc ? p_next_accepted : p_next_rejected;
@@ -2871,6 +2972,7 @@ extern "C" int ig_debug_set_tail_quirk(int on)
 extern "C" int ig_debug_globals(ig_ctx* c, int64_t* sums5, int32_t* ints6)
 {
     HIPCK(hipSetDevice(c->device));
+    flush_pending_sums(c);
     HIPCK(hipStreamSynchronize(c->stream));
     Glob hg;
     HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));

@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(256)
         mb.scr_ub[CW(w, t)] = 0;
         mb.cont[CW(w, t)] = 0xffffffffu;
         mb.ident[CW(w, t)] = 0;
+        mb.tail_n[CW(w, t)] = -1; /* new windows: the Q5 tail has to be found again */
     }
     if (t < C) {
         CandMeta m;
@@ -1815,6 +1816,17 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
     const long long Sc = slice_total(part);
     const int r = (int)(Sc % 64);
     if (!(tail_quirk && r > 0)) return;
+    int n_tail;
+    const int cached = mb.tail_n[cw];
+    if (cached >= 0) { /* found when this slot was scored before (under other parameters): only the terms are new */
+        n_tail = min(cached, 64);
+        if (tid < n_tail) {
+            t_li[tid] = mb.tail_ent[(size_t)cw * 192 + tid];
+            t_lj[tid] = mb.tail_ent[(size_t)cw * 192 + 64 + tid];
+            t_ob[tid] = mb.tail_ent[(size_t)cw * 192 + 128 + tid];
+        }
+        __syncthreads();
+    } else {
     /* T = the largest sub-fragment id with (kept contacts in rows of id >= T) >= r.  Radix descent, 8 bits of the id per pass over
      * the window's rows (histogram of the kept contacts by id, suffix sums from the top): 3 passes at M = 150 k where a
      * bisection on the id took 18 -- on windows of thousands of rows this walk is the longest chain of the launch. */
@@ -1916,8 +1928,15 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
         }
     }
     __syncthreads();
-    const int n_tail = min(sh_n_tail, 64);
+    n_tail = min(sh_n_tail, 64);
     if (tid == 0 && n_tail != r) g->error = 5; /* the walk must find exactly r contacts */
+    if (tid < n_tail) {
+        mb.tail_ent[(size_t)cw * 192 + tid] = t_li[tid];
+        mb.tail_ent[(size_t)cw * 192 + 64 + tid] = t_lj[tid];
+        mb.tail_ent[(size_t)cw * 192 + 128 + tid] = t_ob[tid];
+    }
+    if (tid == 0) mb.tail_n[cw] = n_tail;
+    }
     for (int k = 1 + wv; k < ncol; k += 4) {
         const uint2* col = mb.coords + (size_t)(cw * NSLOT + k) * M;
         const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;

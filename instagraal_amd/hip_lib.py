@@ -318,7 +318,8 @@ class Context:
 
     def nuis_step_next(self, temperature, u, p_next_rejected, p_next_accepted, mean_subfrag_kb, has_next):
         """end of the step in flight + acceptance test + promotion + begin of the next step (ig_nuis_step_next)
-        -> (move result, nz_test, z_test, accepted: 0 / 1 / 2 = undecided)"""
+        -> (move result, nz_test, z_test, accepted: 0 / 1 / 2 = undecided / 3 = accepted ahead of its exact pass: nz_test is the
+        screened midpoint, the exact value comes from ``nuis_exact_result``)"""
         res = MoveResult()
         nz, z, acc = C.c_double(), C.c_double(), C.c_int32()
         pr = None if p_next_rejected is None else np.ascontiguousarray(p_next_rejected, np.float32)
@@ -327,6 +328,12 @@ class Context:
                                     C.c_float(float(mean_subfrag_kb)), C.c_int32(int(has_next)), C.byref(res), C.byref(nz), C.byref(z),
                                     C.byref(acc)))
         return res, nz.value, z.value, acc.value
+
+    def nuis_exact_result(self):
+        """exact nz_test of the last step ``nuis_step_next`` reported as accepted = 3 (decided from the screened interval)"""
+        nz = C.c_double()
+        _ck(lib().ig_nuis_exact_result(self._h, C.byref(nz)))
+        return nz.value
 
     def nuis_end(self):
         res = MoveResult()

@@ -467,8 +467,18 @@ class sampler:  # noqa: N801 - the reference's class name
         p8 = lambda q: [q[k][0] for k in PARAM_NAMES]
         self.ctx.nuis_run_begin(frags, cands)
         self.ctx.nuis_step_begin(0, p8(out), mean_kb)
+        patch = None  # (step, z): a step accepted ahead of its exact pass, its likelihood still to be filled in
+        def fill_in():
+            j, zj = patch
+            lik = np.array([self.ctx.nuis_exact_result()]) + zj
+            tuples[j] = tuples[j][:5] + (lik,) + tuples[j][6:]
+            if j == len(tuples) - 1:
+                self.likelihood_t = self.likelihood_nuis = lik
         for i in range(n):
             ta = _t.perf_counter()
+            if patch is not None:  # the exact pass of the step before last ran behind its decision: done by now
+                fill_in()
+                patch = None
             # while the GPU works on step i: the next step's proposal for the case that this one is rejected (the root finding
             # for d_max is the expensive part of a step on the host); the one for the other case only if it comes to that --
             # the kernels of the promotion run while it is computed
@@ -479,6 +489,9 @@ class sampler:  # noqa: N801 - the reference's class name
             # end of step i, the acceptance test, the promotion and (rejected) the first launches of step i + 1 in one call
             r, nz, z, success = self.ctx.nuis_step_next(self.temperature(t0 + i, n_step), unif[i], p8(nxt_rej), None, mean_kb, has_next)
             t2 = _t.perf_counter()
+            deferred = success == 3  # accepted from the screened interval: nz is its midpoint until the exact pass is through
+            if deferred:
+                success = 1
             if success == 1 and has_next:
                 nxt_acc = proposal(i + 1, out)
                 self.ctx.nuis_step_begin(i + 1, p8(nxt_acc), mean_kb)
@@ -503,6 +516,8 @@ class sampler:  # noqa: N801 - the reference's class name
                 curr = np.copy(out)
             kuhn, lm, c1, slope, d, d_max, fact, d_nuc = self.param_simu[0]
             tuples.append((fact, d, d_max, d_nuc, slope, self.likelihood_t, success, None))
+            if deferred:
+                patch = (i, z)
             if has_next:
                 out = nxt_acc if success else nxt_rej
             t3 = _t.perf_counter()
@@ -511,6 +526,8 @@ class sampler:  # noqa: N801 - the reference's class name
             prof["book"] += t3 - t2
             if trace is not None:
                 trace.append((t3 - ta, int(success)))
+        if patch is not None:
+            fill_in()
         last = res[-1]
         self.o = float(last["o"])
         self.n_contigs = np.int32(last["n_contigs"])

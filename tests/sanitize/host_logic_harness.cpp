@@ -213,6 +213,18 @@ static void model_full_nz_tiled(void** a, dim3, dim3)
     }
 }
 
+static void model_promote(void** a, dim3, dim3)
+{
+    const int mode = *(int*)a[7], seq = *(int*)a[9];
+    NuisHost* hn = *(NuisHost**)a[8];
+    if (mode == 2 && hn) {
+        long long* full = *(long long**)a[1];
+        hn->exact[0] = full[0];
+        hn->exact[1] = full[1];
+        hn->exact_seq = seq;
+    }
+}
+
 int main()
 {
     setenv("IG_NUIS_SCREEN_NOCHECK", "1", 1); /* the models' screened and exact sums are unrelated numbers */
@@ -221,6 +233,7 @@ int main()
     fake_hip::set_model("k_commit_batch", model_commit_batch);
     fake_hip::set_model("k_full_diff_tiled", model_diff);
     fake_hip::set_model("k_full_nz_tiled", model_full_nz_tiled);
+    fake_hip::set_model("k_nuis_promote", model_promote);
 
     // ---- argument checks before anything is uploaded
     ig_ctx* c = nullptr;
@@ -412,7 +425,14 @@ int main()
                     double nzt, zt;
                     const double u = (rnd() % 1000 + 1) / 1001.0;
                     CHECK(ig_nuis_step_next(c, 1.0, u, pr_, give_acc ? pa_ : nullptr, 1.8f, has_next, &one, &nzt, &zt, &acc) == 0);
-                    CHECK(acc == 0 || acc == 1 || acc == 2);
+                    CHECK(acc == 0 || acc == 1 || acc == 2 || acc == 3);
+                    if (acc == 3) { /* accepted from the screened interval, the exact pass behind the decision: its value later */
+                        acc = 1;
+                        if (rnd() & 1) {
+                            double ex = 0;
+                            CHECK(ig_nuis_exact_result(c, &ex) == 0);
+                        }
+                    }
                     if (acc == 2) { /* a close call handed back: the caller decides, accepts, begins the next step */
                         if (rnd() & 1) {
                             CHECK(ig_nuis_accept(c) == 0);

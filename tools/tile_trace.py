@@ -50,3 +50,21 @@ print("screened pass: workgroups %d, items %d, contacts %d; span %.1f us; output
 print("  per workgroup us min/med/max %.1f %.1f %.1f; until staged (sum over its items) med %.1f max %.1f; contact loops med %.1f max %.1f; start offset max %.1f" % (
     dur.min(), np.median(dur), dur.max(), np.median(t[:, 4]) / 100.0, t[:, 4].max() / 100.0, np.median(t[:, 5]) / 100.0, t[:, 5].max() / 100.0, (t[:, 0].max() - t0) / 100.0))
 print("  per item: staged after %.2f us, loops %.2f us (medians)" % (np.median(t[:, 4] / np.maximum(items, 1)) / 100.0, np.median(t[:, 5] / np.maximum(items, 1)) / 100.0))
+# what makes a workgroup slow?  duration against its number of runs (stagings), its XCD, its place in the grid
+runs = items
+for k in sorted(set(runs.tolist())):
+    m = runs == k
+    print("  %d run(s): %3d workgroups, duration med %.1f max %.1f us, staged med %.1f, loops med %.1f" % (k, m.sum(), np.median(dur[m]), dur[m].max(), np.median(t[m, 4]) / 100.0, np.median(t[m, 5]) / 100.0))
+xcc = (t[:, 2] >> 32) & 0xf
+hw = t[:, 2] & 0xffffffff
+cu = (hw >> 8) & 0xf
+se = (hw >> 13) & 0x7
+for x in range(8):
+    m = xcc == x
+    if m.any():
+        print("  XCD %d: %3d workgroups, duration med %.1f max %.1f" % (x, m.sum(), np.median(dur[m]), dur[m].max()))
+order = np.argsort(-dur)[:12]
+print("  slowest:", [(int(i), round(float(dur[i]), 1), int(runs[i]), int(xcc[i]), int(contacts[i])) for i in order])
+q = np.arange(len(dur))
+for lo in range(0, len(dur), 64):
+    print("  workgroups %3d..%3d: duration med %.1f" % (lo, min(lo + 63, len(dur) - 1), np.median(dur[lo:lo + 64])))
