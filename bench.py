@@ -141,7 +141,9 @@ def main():
     ap.add_argument("--config", default="cfg3", help="synthetic shape: cfg2 | cfg3 | cfg5 | small | tiny")
     ap.add_argument("--neighbours", type=int, default=5)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--runner", default="batch", choices=("batch", "sharded"), help="N > 1: what is split over the ranks")
+    ap.add_argument("--runner", default="batch", choices=("batch", "sharded", "replicas"),
+                    help="N > 1: what is split over the ranks (batch / sharded: ONE chain, bit-identical to one GPU, 'strong'); replicas: "
+                         "N independent chains, one per GPU, no data-path collective ('weak': the aggregate BASELINE's >= 6x asks for)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--nuisance-moves", type=int, default=150, help="moves of the nuisance-on loop timed after the run (0: skip)")
@@ -197,7 +199,8 @@ def main():
     log("[rank %d] uploaded + initial likelihood %.6f in %.1fs" % (rank, float(s.curr_likelihood_on_nz[0]), time.time() - t0))
 
     # trajectory: a shuffled cycle prefix; the candidate lists are drawn INSIDE the timed region, as step_sampler does
-    np.random.seed(a.seed)
+    replicas = world > 1 and a.runner == "replicas"
+    np.random.seed(a.seed + (rank if replicas else 0))  # replicas: every rank its own chain
     mps = max(1, a.moves_per_step)
     n_warm, n_moves = a.warmup * mps, a.steps * mps
     n_total = n_warm + n_moves
@@ -206,7 +209,7 @@ def main():
     frags = np.resize(order, n_total).astype(np.int32)
 
     runner = None
-    if world > 1:
+    if world > 1 and not replicas:
         from instagraal_amd.multi_gpu import BatchRunner, ShardedRunner
 
         runner = (BatchRunner if a.runner == "batch" else ShardedRunner)(s.ctx, rank, world, dist=dist)
@@ -225,7 +228,7 @@ def main():
     # record between two kernels of a stream costs ~6 us of idle queue, four of them per batch were 4 % of the timed region
     s.ctx.set_timer_sampling(4)
     s.ctx.reset_timers(1 | (((1 << 2) | (1 << 10)) << 1))
-    batches_before = s.ctx.batch_stats()["batches"] if world == 1 else 0
+    batches_before = s.ctx.batch_stats()["batches"] if (world == 1 or replicas) else 0
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -244,14 +247,14 @@ def main():
     s.ctx.reset_timers(0)
     s.ctx.set_timer_sampling(1)
     n_timed = int(n_screen if (n_screen and screen_ms >= score_ms) else n_launch)
-    screened = s.ctx.debug_screen_stats() if world == 1 else None
+    screened = s.ctx.debug_screen_stats() if (world == 1 or replicas) else None
     # the dominant kernel: the screening pass when the batches are scored in two tiers, else the exact kernel
     dom_name, dom_ms, dom_key = ("k_screen", screen_ms, "k_screen") if (n_screen and screen_ms >= score_ms) else ("k_score_list", score_ms, "k_score_list")
     if n_screen and screen_ms >= score_ms:
         n_launch = n_screen
-    bstats = s.ctx.batch_stats() if world == 1 else None
+    bstats = s.ctx.batch_stats() if (world == 1 or replicas) else None
     # launches of the dominant kernel in the timed region: one per scored batch (the timed ones are a sample of them)
-    n_launch = (bstats["batches"] - batches_before) if (world == 1 and bstats["batches"] > batches_before) else 4 * int(n_launch)
+    n_launch = (bstats["batches"] - batches_before) if (bstats is not None and bstats["batches"] > batches_before) else 4 * int(n_launch)
 
     # the draw alone, for the record (it ran on a host thread next to the launches above)
     st = np.random.get_state()
@@ -262,7 +265,7 @@ def main():
 
     # self-check: the incrementally maintained exact likelihood equals a from-scratch recomputation
     exact_ok = None
-    if world == 1 or a.runner == "batch":
+    if world == 1 or a.runner in ("batch", "replicas"):
         sums, _ = s.ctx.debug_globals()
         _, _, limbs = s.ctx.full_likelihood(0)
         exact_ok = bool(int(sums[0]) == int(limbs[0]) and int(sums[1]) == int(limbs[1]))
@@ -288,7 +291,7 @@ def main():
         # algorithmic bytes of one launch of the dominant kernel = sum of the per-move B_min of the moves it scored
         # (committed moves only: a slot that had to be re-scored is work, not algorithmic traffic)
         n_launch = max(int(n_launch), 1)
-        split = world if (world > 1) else 1  # N > 1: a rank scores 1/N of the slots (or of the contact rows) of a launch
+        split = world if (world > 1 and not replicas) else 1  # N > 1, one chain: a rank scores 1/N of the slots (or of the contact rows) of a launch
         bytes_min = float(res["bytes_min"].sum()) / n_launch / split
         n_evals = float(res["n_evals"].sum()) / n_launch / split
         achieved = bytes_min / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -325,14 +328,14 @@ def main():
         valu_peak = 256 * 128 * 2.4e9
         out = {
             "metric": "MCMC moves/s (accepted+rejected) at fixed n_frags x nnz",
-            "value": n_moves / elapsed,
+            "value": (world if replicas else 1) * n_moves / elapsed,  # replicas: every rank ran its own n_moves
             "unit": "moves/s",
             "n_gpus": dist.get_world_size() if dist is not None else 1,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if replicas else "strong",
             "vs_baseline": None,
             "dtype": "f32 screening tier with a rigorous bound (every column) + f64 terms (f32 inputs) for the contenders / exact i64 fixed-point sums",
             "data": "synthetic",
@@ -340,7 +343,7 @@ def main():
                 prob_name(prob), prob.n_sub_frags, a.neighbours), "name": a.config, "seed": a.seed,
                 "step": "one batch of %d moves (step_sampler calls)" % mps, "moves_per_step": mps, "moves_timed": n_moves,
                 "moves_warmup": n_warm,
-                "parallelism": "1 GPU" if world == 1 else (
+                "parallelism": "1 GPU" if world == 1 else ("replicas only: %d independent chains, one per GPU, no data-path collective" % world) if replicas else (
                     "batch slots split over %d ranks, all-gather of score records" % world if a.runner == "batch" else
                     "contact rows split over %d ranks, all-reduce of exact partial sums per move" % world),
                 "timed_region": "candidate draw (host thread) + H2D + kernels + D2H of the result records",

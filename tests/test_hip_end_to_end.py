@@ -112,7 +112,7 @@ def test_two_processes_batch_runner():
     raise AssertionError(last)
 
 
-@pytest.mark.parametrize("runner", ["batch", "sharded"])
+@pytest.mark.parametrize("runner", ["batch", "sharded", "replicas"])
 def test_bench_starts_its_own_ranks(runner):
     """`python bench.py --gpus 2` without a launcher: the script starts its two ranks itself (child processes; this rig has
     one GPU, so IG_BENCH_ONE_DEVICE=1 puts both on cuda:0 with gloo collectives) and relays rank 0's JSON line; both ways
@@ -133,8 +133,9 @@ def test_bench_starts_its_own_ranks(runner):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 60 and out["value"] > 0
     assert out["roofline"]["launches"] > 0
-    if runner == "batch":
+    if runner in ("batch", "replicas"):
         assert out["config"]["maintained_likelihood_exact"] is True
+    assert out["scaling"] == ("weak" if runner == "replicas" else "strong")
 
 
 def test_bench_line_contract_one_gpu():
