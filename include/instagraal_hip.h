@@ -169,6 +169,12 @@ int ig_nuis_step_next(ig_ctx* ctx, double temperature, double u, const float p_n
  * step runs the exact pass as well.  0 = the exact pass on every step (env IG_NUIS_SCREEN); env IG_NUIS_SCREEN_VERIFY=1: both
  * on every step, the bound checked. */
 int ig_set_nuis_screen(int on);
+/* The screened pass has two tiers.  The first reads no contact at all: the same change of the likelihood from a histogram of the
+ * cis contacts over log2 of their distance (in which the term's exponent is piecewise linear), kept up to date by the moves that
+ * change the genome, with its own rigorous bound; the pass over the contacts runs only where that interval does not decide
+ * (csrc/ig_kernels_nuis.cuh, "tier 0").  0 = start with the pass over the contacts (env IG_NUIS_HIST); IG_NUIS_SCREEN_VERIFY=1
+ * checks both tiers against the exact pass on every step. */
+int ig_set_nuis_hist(int on);
 /* *accepted = 3 from ig_nuis_step_next: the step was ACCEPTED from the screened interval alone (every L_test in it gives a ratio
  * above u); its exact pass -- the promotion of the maintained sum needs it, the decision does not -- runs behind the decision, next
  * to the re-scoring of the moves ahead; *nz_test was the interval's midpoint.  The exact value (what eval_likelihood_4_nuisance
@@ -225,6 +231,11 @@ int ig_debug_diff_trace(ig_ctx* ctx, const float p_test[8], float mean_subfrag_k
  * largest bound, largest |screened - exact| / bound seen, sum of the bounds, steps whose interval did not decide, void because of
  * {the parameter pair, a contact, a workgroup's sums, a move record that did not come from the batch commit}} */
 int ig_debug_nuis_screen_stats(ig_ctx* ctx, double out12[12]);
+/* its histogram tier: {evaluations, steps rejected there, accepted there, void, sum of its bounds, largest |screened - exact| / bound
+ * seen, moves walked into the histogram, builds from scratch, void because of {as above}} */
+int ig_debug_nuis_hist_stats(ig_ctx* ctx, double out12[12]);
+/* the maintained histogram against one built from scratch (the last move of the run is walked in first): words that differ, -1: none kept */
+int ig_debug_nuis_hist_check(ig_ctx* ctx, int64_t* mismatches);
 int ig_debug_set_full_hist(int on); /* from-scratch pass: all-trans tiles from their count histograms (1, default) or contact by contact (0) */
 
 #ifdef __cplusplus

@@ -238,6 +238,24 @@ struct NuisHost {
      * the promotion of the sums (k_nuis_promote, mode 2) */
     long long exact[2];
     volatile int exact_seq;
+    int changed; /* the record's move changed the genome (k_commit_batch, with the record) */
+};
+
+/* The cis contacts of the state BEFORE the last move as a histogram over log2 of their distance (ig_kernels_nuis.cuh, tier 0 of
+ * the screened nuisance pass): bin = floor(x 2^NH_OCT_BITS), x = log2 s in units of 2^-NH_FRAC_BITS; per bin
+ * {contacts, sum of the offsets inside the bin, sum of the counts, sum of count x offset} -- integers, maintained with atomics by
+ * the moves that change the genome, so independent of any order. */
+#define NH_OCT_BITS 10
+#define NH_FRAC_BITS 20
+#define NH_LMAX 24
+#define NH_NB ((2 * NH_LMAX) << NH_OCT_BITS)
+#define NH_SUB (1 << (NH_FRAC_BITS - NH_OCT_BITS)) /* offsets inside a bin: 0 .. NH_SUB - 1 */
+#define NH_MISC 16
+struct NuisHist {
+    long long* bins; /* [NH_NB][4] */
+    long long* dh;   /* [LDS_PZ + 1]: cis contacts by rank distance (the last entry: that far or further) */
+    long long* misc; /* {cis at distance 0: contacts, counts; cis on a ring; cis outside the binned range; all contacts, their counts;
+                      * contacts with a count beyond the screening term's domain} */
 };
 
 struct ig_ctx {
@@ -271,6 +289,17 @@ struct ig_ctx {
     bool nuis_sums_pending, nuis_accept_certain;
     int exact_seq;
     bool nuis_nzb_copied;         /* the step's move was finished outside the batch commit: its NuisHost.nzb was copied from the control block */
+    /* tier 0 of the screened pass: the histogram of the cis contacts' distances (NuisHist), valid for the state before the last
+     * move of a run once nh_pending_slot's move has been walked (nh_flush_pending) */
+    NuisHist nh;
+    long long* scratch_hist; /* k_hist_eval's 8 output words (zero between two launches) */
+    bool nh_valid;
+    int nh_pending_slot;     /* the slot of the last move of the run, not yet in the histogram (-1: none) */
+    int nuis_tier;           /* the step in flight: 0 the histogram decided / is deciding, 1 the pass over the contacts */
+    bool nuis_tiles_listed;  /* ... k_tile_trans has run (the passes over the tiles need its list) */
+    hipEvent_t ev_walk;
+    double nhs[12];          /* statistics: evaluations, rejected / accepted there, void, sum of bounds, largest used fraction, walks, builds, void because of {parameters, a contact, sums, no record} */
+    bool nh_tracking;        /* a step of a run is being enqueued / ended: the moves applied now are followed by the histogram */
     double nscr[12];               /* statistics: steps screened, rejected from the interval, exact passes, void, largest bound, largest used fraction, sum of bounds */
     bool nuis_in_flight;
     bool side_busy;      /* launch_full_nz on a side stream: the library stream is busy with a batch (one workgroup per CU for the pass) */

@@ -200,6 +200,15 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->nuis_sums_pending = c->nuis_accept_certain = false;
     c->exact_seq = 0;
     HIPCK(hipEventCreateWithFlags(&c->ev_exact, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&c->ev_walk, hipEventDisableTiming));
+    c->nh = NuisHist{nullptr, nullptr, nullptr};
+    c->scratch_hist = nullptr;
+    c->nh_valid = false;
+    c->nh_pending_slot = -1;
+    c->nh_tracking = false;
+    c->nuis_tier = 1;
+    c->nuis_tiles_listed = false;
+    for (double& v : c->nhs) v = 0.0;
     for (double& v : c->nscr) v = 0.0;
     HIPCK(hipEventCreateWithFlags(&c->ev_slice, hipEventDisableTiming));
     HIPCK(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
@@ -307,6 +316,11 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipEventDestroy(c->ev_gathered);
     hipEventDestroy(c->ev_main);
     hipEventDestroy(c->ev_exact);
+    hipEventDestroy(c->ev_walk);
+    hipFree(c->nh.bins);
+    hipFree(c->nh.dh);
+    hipFree(c->nh.misc);
+    hipFree(c->scratch_hist);
     hipFree(c->scratch_exact);
     if (c->host_nuis) hipHostFree(c->host_nuis);
     if (c->h_stage) hipHostFree(c->h_stage);
@@ -587,6 +601,8 @@ extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* 
     if (Z < 0 || M <= 0) return fail("ig_upload_contacts: bad sizes");
     if (world < 1 || rank < 0 || rank >= world) return fail("ig_upload_contacts: bad shard %d/%d", rank, world);
     if (c->M && c->M != M) return fail("ig_upload_contacts: M=%d does not match the sub-fragment table (%d)", M, c->M);
+    c->nh_valid = false;
+    c->nh_pending_slot = -1;
     std::vector<long long> rp((size_t)M + 1, 0);
     std::vector<int2> cc((size_t)Z);
     int max_count = 0;
@@ -851,6 +867,8 @@ extern "C" int ig_upload_state(ig_ctx* c, const int32_t* soa, int32_t N)
  * likelihood sums of the current state */
 static int launch_recompute(ig_ctx* c)
 {
+    c->nh_valid = false; /* (the histogram of the screened nuisance pass: rebuilt by the next run) */
+    c->nh_pending_slot = -1;
     if (!c->have_state || !c->have_sub) return 0;
     const int N = c->N, M = c->M;
     hipLaunchKernelGGL(k_fill_tables, dim3((M + 255) / 256), dim3(256), 0, c->stream, c->st, c->sub_tab, c->tab, M);
@@ -1372,8 +1390,19 @@ static void enqueue_choose(ig_ctx* c, int w, int force_slot)
 }
 
 /* one-move tail: exact delta, apply, genome distance, result record */
+/* a move is about to be applied outside a run of (move, nuisance step) pairs: the histogram of the screened pass's first tier
+ * (NuisHist) does not follow it */
+static inline void nh_untracked_move(ig_ctx* c)
+{
+    if (!c->nh_tracking) {
+        c->nh_valid = false;
+        c->nh_pending_slot = -1;
+    }
+}
+
 static void enqueue_apply(ig_ctx* c, int move, int w, int forced, bool log_dirty = false)
 {
+    nh_untracked_move(c);
     const int N = c->N;
     const PzTab pz{c->pz_tab, c->pz_n};
     {
@@ -1418,6 +1447,7 @@ static int validate_move(ig_ctx* c, int frag_a, const int32_t* cands, int C)
 /* the decide + apply launches of the slots [next, w_now) of the batch at move `done` */
 static void launch_commit(ig_ctx* c, int done, int w_now, int next, int resumed_plain, bool publish = false)
 {
+    nh_untracked_move(c);
     flush_pending_sums(c);
     TimedLaunch t(c, T_COMMIT);
     hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(64), 0, c->stream, c->glob, c->mb, c->d_results, done, w_now, next, c->dirty_buf,
@@ -2002,7 +2032,47 @@ static void launch_nuis_exact_tiles(ig_ctx* c, hipStream_t s3, long long* out = 
     if (publish) c->nuis_pub_sums = true;
 }
 
-static int launch_nuis_diff(ig_ctx* c, const ig_params& hp, float mean_kb, hipStream_t s3, bool fuse_catch = false)
+/* tier 0 of the screened pass (ig_kernels_nuis.cuh): the histogram of the cis contacts' distances.  IG_NUIS_HIST=0: off */
+static int g_nuis_hist = -1;
+static bool nuis_hist_usable(ig_ctx* c)
+{
+    if (g_nuis_hist < 0) g_nuis_hist = getenv("IG_NUIS_HIST") ? atoi(getenv("IG_NUIS_HIST")) : 1;
+    return g_nuis_hist && nuis_screen_usable(c);
+}
+extern "C" int ig_set_nuis_hist(int on)
+{
+    g_nuis_hist = on ? 1 : 0;
+    return 0;
+}
+static int ensure_nuis_hist(ig_ctx* c)
+{
+    if (c->nh.bins) return 0;
+    DALLOC(c->nh.bins, (size_t)NH_NB * 4);
+    DALLOC(c->nh.dh, (size_t)LDS_PZ + 1);
+    DALLOC(c->nh.misc, NH_MISC);
+    DALLOC(c->scratch_hist, 16);
+    HIPCK(hipMemset(c->scratch_hist, 0, 16 * sizeof(long long)));
+    c->nh_valid = false;
+    return 0;
+}
+/* the last move of the run is not in the histogram yet (a step is evaluated on the state BEFORE its move): walk it in now -- before
+ * anything replaces what the walk reads: the move's slot in the batch buffers, and tab_prev as of before the move */
+static int nh_flush_pending(ig_ctx* c)
+{
+    const int w = c->nh_pending_slot;
+    c->nh_pending_slot = -1;
+    if (w < 0 || !c->nh_valid || !c->nh.bins) return 0;
+    static const int s_blocks = getenv("IG_HIST_WALK_BLOCKS") ? std::max(1, atoi(getenv("IG_HIST_WALK_BLOCKS"))) : 128;
+    hipLaunchKernelGGL(k_hist_walk, dim3(s_blocks), dim3(256), 0, c->stream3, c->rowptr, c->cc, c->tab_prev, c->glob, c->mb, w, c->nh);
+    HIPCK(hipEventRecord(c->ev_walk, c->stream3));
+    HIPCK(hipStreamWaitEvent(c->stream, c->ev_walk, 0));
+    c->nhs[6] += 1.0;
+    return 0;
+}
+
+/* what every tier of a step's screened pass needs first: the test set's tables and constants, tab_prev caught up (fuse_catch) and
+ * packed, the scratch words cleared (k_nuis_prepare) */
+static int launch_nuis_prepare(ig_ctx* c, const ig_params& hp, float mean_kb, hipStream_t s3, bool fuse_catch)
 {
     if (!c->diff_const) {
         DALLOC(c->diff_const, 1);
@@ -2017,12 +2087,33 @@ static int launch_nuis_diff(ig_ctx* c, const ig_params& hp, float mean_kb, hipSt
                        c->scratch_nuis, t, c->M, c->tabrec, c->tile_sig, FULL_TB, c->tile_dyn, n_pack, c->score_const, c->pz_n, c->diff_const,
                        c->scratch_diff, c->screen_const, fuse_catch ? c->tab : Tables{nullptr, nullptr, nullptr, nullptr}, c->prev_touched);
     /* the library stream's next kernels replace what the catch-up reads: they wait for it (not for the pass behind it) */
-    if (fuse_catch) HIPCK(hipEventRecord(c->ev_main, s3));
+    if (fuse_catch) {
+        HIPCK(hipEventRecord(c->ev_main, s3));
+        HIPCK(hipStreamWaitEvent(c->stream, c->ev_main, 0));
+    }
+    c->nuis_tiles_listed = false;
+    return 0;
+}
+
+/* the list of the tiles whose contacts a pass has to read, the all-trans tiles' histogram sums under both sets (k_tile_trans);
+ * with_zero: the zero-pixel sum of the test set in the same launch (else: someone else's job -- the histogram tier's launch) */
+static void launch_nuis_tile_list(ig_ctx* c, hipStream_t s3, bool with_zero)
+{
     const int per = TILE_TRANS_THREADS / 64;
-    const int n_trans = (c->n_tile_info + per - 1) / per, n_zero = std::min(256, std::max(32, c->M / 4096));
-    hipLaunchKernelGGL(k_tile_trans, dim3(n_trans + n_zero), dim3(TILE_TRANS_THREADS), 0, s3, c->tile_info, c->n_tile_info, c->tile_sig, c->tile_hist,
-                       c->full_const, (TileDyn*)c->tile_dyn, c->tile_dyn_list, 1, c->tile_partial, n_trans, t, c->glob, 1, c->M, c->scratch_nuis + 2,
-                       c->score_const, c->tile_partial0);
+    const int n_trans = (c->n_tile_info + per - 1) / per, n_zero = with_zero ? std::min(256, std::max(32, c->M / 4096)) : 0;
+    if (n_trans + n_zero > 0) /* (a matrix of a single tile has no off-diagonal ones to list) */
+        hipLaunchKernelGGL(k_tile_trans, dim3(n_trans + n_zero), dim3(TILE_TRANS_THREADS), 0, s3, c->tile_info, c->n_tile_info, c->tile_sig, c->tile_hist,
+                           c->full_const, (TileDyn*)c->tile_dyn, c->tile_dyn_list, 1, c->tile_partial, n_trans, c->tab_prev, c->glob, 1, c->M,
+                           c->scratch_nuis + 2, c->score_const, c->tile_partial0);
+    c->nuis_tiles_listed = true;
+}
+
+/* tier 1: the float pass over the contacts (k_full_diff_tiled) behind the tile list */
+static int launch_nuis_diff(ig_ctx* c, const ig_params& hp, hipStream_t s3, bool with_zero)
+{
+    launch_nuis_tile_list(c, s3, with_zero);
+    const int per = TILE_TRANS_THREADS / 64;
+    const int n_trans = (c->n_tile_info + per - 1) / per;
     /* two workgroups per CU less two: the one-wave kernels of the move next to the pass (decide, commit) find a SIMD with registers
      * to spare at once (the stream workgroups take all 512 VGPRs of a SIMD between them).  (Measured and dropped: k_tile_trans's
      * blocks as the head of this kernel's grid, the stream workgroups waiting for them in front of the list: 95 - 112 us instead of
@@ -2045,10 +2136,7 @@ static int launch_nuis_diff(ig_ctx* c, const ig_params& hp, float mean_kb, hipSt
                                c->diff_const, c->M, c->scratch_diff, c->n_tile_static, (TileDyn*)c->tile_dyn, c->tile_dyn_list, c->host_nuis_dev,
                                c->diff_seq, c->tile_partial, c->tile_partial0, n_trans, c->scratch_nuis, c->diff_trace);
     }
-    if (fuse_catch) HIPCK(hipStreamWaitEvent(c->stream, c->ev_main, 0));
-    c->nuis_diff = true;
-    c->nuis_exact_queued = false;
-    c->nuis_pub_sums = false;
+    c->nuis_tier = 1;
     if (g_nuis_screen_verify) { /* the exact pass behind it, unconditionally */
         launch_nuis_exact_tiles(c, s3);
         c->nuis_exact_queued = true;
@@ -2056,11 +2144,44 @@ static int launch_nuis_diff(ig_ctx* c, const ig_params& hp, float mean_kb, hipSt
     return 0;
 }
 
+/* tier 0: the histogram (built here if it is not valid: the first step of a run, or after moves outside one), its evaluation and
+ * the zero-pixel sum of the test set in one launch */
+static int launch_nuis_hist(ig_ctx* c, hipStream_t s3)
+{
+    if (ensure_nuis_hist(c)) return -1;
+    if (!c->nh_valid) {
+        HIPCK(hipMemsetAsync(c->nh.bins, 0, (size_t)NH_NB * 4 * sizeof(long long), s3));
+        HIPCK(hipMemsetAsync(c->nh.dh, 0, ((size_t)LDS_PZ + 1) * sizeof(long long), s3));
+        HIPCK(hipMemsetAsync(c->nh.misc, 0, NH_MISC * sizeof(long long), s3));
+        hipLaunchKernelGGL(k_hist_build, dim3(2048), dim3(256), 0, s3, c->rowptr, c->cc, c->tab_prev, c->M, c->nh);
+        c->nh_valid = true;
+        c->nhs[7] += 1.0;
+    }
+    const int n_zero = std::min(256, std::max(32, c->M / 1024));
+    ++c->diff_seq;
+    hipLaunchKernelGGL(k_hist_eval, dim3(n_zero + NH_NB / 256 + 1), dim3(256), 0, s3, c->nh, c->glob, c->full_const, c->score_const, c->diff_const,
+                       c->scratch_hist, c->host_nuis_dev, c->diff_seq, c->tab_prev, c->M, c->scratch_nuis + 2, n_zero, c->scratch_nuis);
+    c->nuis_tier = 0;
+    return 0;
+}
+
+/* a step's screened pass: the tier it starts with */
+static int launch_nuis_screened(ig_ctx* c, const ig_params& hp, float mean_kb, hipStream_t s3, bool fuse_catch)
+{
+    if (launch_nuis_prepare(c, hp, mean_kb, s3, fuse_catch)) return -1;
+    c->nuis_diff = true;
+    c->nuis_exact_queued = false;
+    c->nuis_pub_sums = false;
+    if (nuis_hist_usable(c)) return launch_nuis_hist(c, s3);
+    return launch_nuis_diff(c, hp, s3, true);
+}
+
 /* tab_prev := the state before the move about to be decided, then (second stream) the full pass under p_test on it */
 static int enqueue_nuis_pass(ig_ctx* c, const float p_test[8], float mean_subfrag_kb)
 {
     if (ensure_host_nuis(c)) return -1;
     if (!c->pz_tab1) DALLOC(c->pz_tab1, PZ_MAX);
+    if (nh_flush_pending(c)) return -1; /* (before tab_prev catches up with the last move) */
     /* the nuisance pass first (second stream), the move behind it (library stream): the pass is the longer of the two and
      * would otherwise start only when the host is through with the move's dozen launches */
     hipStream_t s3 = c->stream3;
@@ -2094,7 +2215,7 @@ static int enqueue_nuis_pass(ig_ctx* c, const float p_test[8], float mean_subfra
     c->nuis_pub_sums = false;
     c->nuis_diff = false;
     c->nuis_screen_rejected = false;
-    if (use_diff) return launch_nuis_diff(c, hp, mean_subfrag_kb, s3, fuse_catch);
+    if (use_diff) return launch_nuis_screened(c, hp, mean_subfrag_kb, s3, fuse_catch);
     c->pub_sums = (c->nuis_spec && c->host_nuis_dev) ? c->host_nuis_dev : nullptr; /* launch_full_nz: the tiled kernel's last workgroup publishes */
     const bool zero_done = launch_full_nz(c, c->tab_prev, 1, c->scratch_nuis, PzTab{c->pz_tab1, c->pz_n1}, s3, c->scratch_nuis + 2, &hp, mean_subfrag_kb);
     c->pub_sums = nullptr;
@@ -2167,6 +2288,7 @@ extern "C" int ig_nuis_run_begin(ig_ctx* c, int32_t n_moves, const int32_t* frag
     if (n_moves <= 0) return fail("ig_nuis_run_begin: no moves");
     if (max_c < 1 || max_c > IG_MAX_CANDIDATES) return fail("ig_nuis_run_begin: max_c out of range");
     if (!c->init_links_inverse) return fail("ig_nuis_run_begin: the initial prev / next arrays are not mutually inverse (ig_links_inverse): ig_nuis_begin, one pair at a time");
+    if (nh_flush_pending(c)) return -1; /* the last move of the run before: into the histogram while its slot is still there */
     static const int s_cap = getenv("IG_NUIS_WMAX") ? atoi(getenv("IG_NUIS_WMAX")) : 24;
     if (g_nuis_w < 0) g_nuis_w = getenv("IG_NUIS_W") ? std::max(0, atoi(getenv("IG_NUIS_W"))) : 0;
     const int Wmax = std::max(1, std::min(std::max(s_cap, g_nuis_w), max_batch_width(c, max_c)));
@@ -2221,6 +2343,7 @@ static void nuis_spec_invalidate(ig_ctx* c)
 /* score a batch of moves starting at `move`: the structural half of all its slots, the parameter half of the first ones */
 static int nuis_spec_score(ig_ctx* c, int move)
 {
+    if (nh_flush_pending(c)) return -1; /* (the buffers of the last move's slot are about to be overwritten) */
     nuis_spec_invalidate(c);
     const int W = std::min(nuis_struct_width(c), c->up_moves - move);
     const int r = std::min(nuis_spec_width(c), W);
@@ -2265,6 +2388,7 @@ extern "C" int ig_nuis_step_begin(ig_ctx* c, int32_t move, const float p_test[8]
     if (c->nuis_in_flight) return fail("ig_nuis_step_begin: the previous step was not ended (ig_nuis_end)");
     if (move != c->spec_move || move >= c->up_moves) return fail("ig_nuis_step_begin: move %d, expected %d of %d", move, c->spec_move, c->up_moves);
     c->nuis_in_flight = true;
+    c->nh_tracking = true; /* until the step is ended: the one move it applies is walked into the histogram at the head of the next step */
     /* a batch is scored in this step (or still being scored: right after an accepted step): the pass leaves half of every CU
      * to it; else it takes the machine (all that runs next to it is one decision and one apply) */
     const bool restruct = !nuis_spec_can_rescore(c, move);
@@ -2363,7 +2487,18 @@ static double nuis_z_from_sums(const long long h_in[8])
 
 /* Tu = {temperature, u} of the Metropolis test when the caller is ig_nuis_step_next: a step whose screened interval lies
  * below T ln u is rejected without the exact pass (nuis_screen_rejected; *nz_test is then the interval's midpoint) */
+static int nuis_end_body(ig_ctx* c, ig_move_result* out, double* nz_test, double* z_test, int64_t* limbs5, const double* Tu);
 static int nuis_end_impl(ig_ctx* c, ig_move_result* out, double* nz_test, double* z_test, int64_t* limbs5, const double* Tu)
+{
+    const int rc = nuis_end_body(c, out, nz_test, z_test, limbs5, Tu);
+    c->nh_tracking = false;
+    if (rc) { /* (whatever went wrong: the histogram is rebuilt by the next step that wants it) */
+        c->nh_valid = false;
+        c->nh_pending_slot = -1;
+    }
+    return rc;
+}
+static int nuis_end_body(ig_ctx* c, ig_move_result* out, double* nz_test, double* z_test, int64_t* limbs5, const double* Tu)
 {
     HIPCK(hipSetDevice(c->device));
     if (!c->nuis_in_flight) return fail("ig_nuis_end: no step in flight");
@@ -2373,10 +2508,12 @@ static int nuis_end_impl(ig_ctx* c, ig_move_result* out, double* nz_test, double
     const auto w0 = std::chrono::steady_clock::now();
     if (c->nuis_spec && nuis_spec_finish(c)) return -1;
     bool have_nzb = false;
+    int moved = 1; /* the move changed the genome (0 only when k_commit_batch said so) */
     if (c->nuis_spec && c->nuis_pub_res && wait_host_flag(&c->host_nuis->res_seq, c->res_seq, c->stream)) {
         c->max_L = std::max(c->max_L, c->host_nuis->max_L);
         c->max_SL = std::max(c->max_SL, c->host_nuis->max_SL);
         have_nzb = true; /* the record came from k_commit_batch, with the maintained sum of the state before the move */
+        moved = c->host_nuis->changed;
     } else {
         if (c->nuis_spec && c->nuis_pub_res) { /* no flag although the stream has drained: fetch the record the plain way */
             HIPCK(hipMemcpyAsync(&c->host_nuis->res, c->d_results + c->spec_move - 1, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
@@ -2386,79 +2523,114 @@ static int nuis_end_impl(ig_ctx* c, ig_move_result* out, double* nz_test, double
         take_max_readback(c);
         have_nzb = c->nuis_spec && c->nuis_nzb_copied;
     }
-    /* the screened pass: decide from its interval where that is possible */
-    bool scr_valid = false;
-    double scr_mid = 0.0, scr_B = 0.0;
+    /* the screened pass: decide from its interval where that is possible -- the histogram's first (tier 0), then the float pass
+     * over the contacts (tier 1), then the exact pass */
+    bool scr_valid = false, scr0_valid = false;
+    double scr_mid = 0.0, scr_B = 0.0, scr0_mid = 0.0, scr0_B = 0.0;
     if (c->nuis_diff) {
         NuisHost* hn = c->host_nuis;
-        if (!wait_host_flag(&hn->diff_seq, c->diff_seq, c->stream3)) {
-            HIPCK(hipStreamSynchronize(c->stream3));
-            HIPCK(hipMemcpy((void*)hn->diff, c->scratch_diff, 8 * sizeof(long long), hipMemcpyDeviceToHost));
-            HIPCK(hipMemcpy((void*)hn->sums, c->scratch_nuis, 8 * sizeof(long long), hipMemcpyDeviceToHost));
-        }
-        long long d[8];
-        memcpy(d, (const void*)hn->diff, sizeof d);
+        bool reject = false, accept = false;
         c->nscr[0] += 1.0;
-        bool reject = false;
-        if (d[4] != 0 || d[3] <= 0 || !have_nzb) {
-            c->nscr[3] += 1.0; /* void: outside the screening term's domain, or the move did not come out of the batch commit */
-            if (d[4] & 1) c->nscr[8] += 1.0;  /* ... the parameter pair (one-log domain, size of the proposal) */
-            if (d[4] & 2) c->nscr[9] += 1.0;  /* ... a contact (ring, count, rank distance beyond the tables) */
-            if (d[4] & 4) c->nscr[10] += 1.0; /* ... a workgroup's sums (|log2 s|, |y|, not a number) */
-            if (!have_nzb) c->nscr[11] += 1.0;
-        } else {
-            long long hi = hn->nzb[0] + d[0], lo = hn->nzb[1] + d[1];
-            ig_acc_normalize((int64_t*)&hi, (int64_t*)&lo);
-            const double base = ig_acc_to_double(hi, lo);
-            scr_mid = base + (double)d[2] * (1.0 / DIFF_FIX);
-            scr_B = (double)d[3] * (1.0 / DIFF_FIX) + 1e-6 + 1e-14 * (__builtin_fabs(base) + __builtin_fabs(hn->res.o)); /* + the double roundings here */
-            scr_valid = true;
-            c->nscr[4] = std::max(c->nscr[4], scr_B);
-            c->nscr[6] += scr_B;
-            bool accept = false;
-            if (Tu && Tu[0] > 0.0 && Tu[1] > 0.0 && !g_nuis_screen_verify) {
-                const double z = nuis_z_from_sums((const long long*)hn->sums);
-                const double x_hi = (((scr_mid + scr_B) + z) - hn->res.o) / Tu[0], x_lo = (((scr_mid - scr_B) + z) - hn->res.o) / Tu[0];
-                reject = exp(x_hi) <= Tu[1] * (1.0 - 1e-9); /* exp is monotone: every L_test in the interval gives a ratio below u */
-                static const int s_defer = getenv("IG_NUIS_DEFER") ? atoi(getenv("IG_NUIS_DEFER")) : 1;
-                accept = s_defer && !reject && exp(x_lo) >= Tu[1] * (1.0 + 1e-9) && c->host_nuis_dev; /* ... above it: accepted whatever the exact sum */
-            }
-            if (!reject && !accept) c->nscr[7] += 1.0;
-            if (accept) {
-                /* the exact pass is needed -- for the maintained sum under the new parameters and for the likelihood the step
-                 * returns -- but not for the decision: it runs on the side stream while the library stream promotes the parameters
-                 * and re-scores the moves ahead; its sums are promoted in front of the next kernel that reads the maintained sum
-                 * (flush_pending_sums), the caller fetches the exact value later (ig_nuis_exact_result) */
-                if (!c->scratch_exact) {
-                    DALLOC(c->scratch_exact, 8);
-                    HIPCK(hipMemset(c->scratch_exact, 0, 8 * sizeof(long long)));
+        for (;;) {
+            const int tier = c->nuis_tier;
+            if (!wait_host_flag(&hn->diff_seq, c->diff_seq, c->stream3)) {
+                HIPCK(hipStreamSynchronize(c->stream3));
+                if (tier == 0) { /* (its words are cleared by the launch itself: the copies it leaves) */
+                    long long t3[3];
+                    HIPCK(hipMemcpy(t3, c->scratch_hist + 9, sizeof t3, hipMemcpyDeviceToHost));
+                    for (int q = 0; q < 8; q++) hn->diff[q] = 0;
+                    hn->diff[2] = t3[0];
+                    hn->diff[3] = t3[1];
+                    hn->diff[4] = t3[2];
+                } else {
+                    HIPCK(hipMemcpy((void*)hn->diff, c->scratch_diff, 8 * sizeof(long long), hipMemcpyDeviceToHost));
                 }
-                c->nscr[2] += 1.0;
-                launch_nuis_exact_tiles(c, c->stream3, c->scratch_exact, false);
-                HIPCK(hipEventRecord(c->ev_exact, c->stream3));
-                c->nuis_sums_pending = true;
-                c->nuis_accept_certain = true;
-                c->nuis_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
-                drain_timers(c);
-                c->main_drained = c->nuis_spec;
-                *out = hn->res;
-                if (out->error) return fail("device-side consistency failure %d", out->error);
-                if (nz_test) *nz_test = scr_mid;
-                if (z_test) *z_test = nuis_z_from_sums((const long long*)hn->sums);
-                if (limbs5)
-                    for (int i = 0; i < 5; i++) limbs5[i] = 0;
-                return 0;
+                HIPCK(hipMemcpy((void*)hn->sums, c->scratch_nuis, 8 * sizeof(long long), hipMemcpyDeviceToHost));
             }
+            long long d[8];
+            memcpy(d, (const void*)hn->diff, sizeof d);
+            scr_valid = false;
+            if (tier == 0) c->nhs[0] += 1.0;
+            if (d[4] != 0 || d[3] <= 0 || !have_nzb) {
+                if (tier == 0) {
+                    c->nhs[3] += 1.0;
+                    if (getenv("IG_NUIS_HIST_TRACE"))
+                        fprintf(stderr, "[nuis] move %d: histogram tier void: flags %lld sum %lld bound %lld contacts %lld record %d\n", c->spec_move - 1,
+                                d[4], d[2], d[3], d[5], (int)have_nzb);
+                    if (d[4] & 1) c->nhs[8] += 1.0;
+                    if (d[4] & 2) c->nhs[9] += 1.0;
+                    if (d[4] & 4) c->nhs[10] += 1.0;
+                    if (!have_nzb) c->nhs[11] += 1.0;
+                } else {
+                    c->nscr[3] += 1.0; /* void: outside the screening term's domain, or the move did not come out of the batch commit */
+                    if (d[4] & 1) c->nscr[8] += 1.0;  /* ... the parameter pair (one-log domain, size of the proposal) */
+                    if (d[4] & 2) c->nscr[9] += 1.0;  /* ... a contact (ring, count, rank distance beyond the tables) */
+                    if (d[4] & 4) c->nscr[10] += 1.0; /* ... a workgroup's sums (|log2 s|, |y|, not a number) */
+                    if (!have_nzb) c->nscr[11] += 1.0;
+                }
+            } else {
+                long long hi = hn->nzb[0] + d[0], lo = hn->nzb[1] + d[1];
+                ig_acc_normalize((int64_t*)&hi, (int64_t*)&lo);
+                const double base = ig_acc_to_double(hi, lo);
+                scr_mid = base + (double)d[2] * (1.0 / DIFF_FIX);
+                scr_B = (double)d[3] * (1.0 / DIFF_FIX) + 1e-6 + 1e-14 * (__builtin_fabs(base) + __builtin_fabs(hn->res.o)); /* + the double roundings here */
+                scr_valid = true;
+                if (tier == 0) {
+                    c->nhs[4] += scr_B;
+                } else {
+                    c->nscr[4] = std::max(c->nscr[4], scr_B);
+                    c->nscr[6] += scr_B;
+                }
+                if (Tu && Tu[0] > 0.0 && Tu[1] > 0.0 && !g_nuis_screen_verify) {
+                    const double z = nuis_z_from_sums((const long long*)hn->sums);
+                    const double x_hi = (((scr_mid + scr_B) + z) - hn->res.o) / Tu[0], x_lo = (((scr_mid - scr_B) + z) - hn->res.o) / Tu[0];
+                    reject = exp(x_hi) <= Tu[1] * (1.0 - 1e-9); /* exp is monotone: every L_test in the interval gives a ratio below u */
+                    static const int s_defer = getenv("IG_NUIS_DEFER") ? atoi(getenv("IG_NUIS_DEFER")) : 1;
+                    accept = s_defer && !reject && exp(x_lo) >= Tu[1] * (1.0 + 1e-9) && c->host_nuis_dev; /* ... above it: accepted whatever the exact sum */
+                }
+            }
+            if (tier == 0) {
+                if (reject) c->nhs[1] += 1.0;
+                if (accept) c->nhs[2] += 1.0;
+                if (!reject && !accept) { /* the histogram does not decide (or the check wants every tier): the pass over the contacts */
+                    scr0_valid = scr_valid;
+                    scr0_mid = scr_mid;
+                    scr0_B = scr_B;
+                    if (launch_nuis_diff(c, c->nuis_test, c->stream3, false)) return -1;
+                    continue;
+                }
+            }
+            break;
+        }
+        if (scr_valid && !reject && !accept) c->nscr[7] += 1.0;
+        if (accept) {
+            /* the exact pass is needed -- for the maintained sum under the new parameters and for the likelihood the step
+             * returns -- but not for the decision: it runs on the side stream while the library stream promotes the parameters
+             * and re-scores the moves ahead; its sums are promoted in front of the next kernel that reads the maintained sum
+             * (flush_pending_sums), the caller fetches the exact value later (ig_nuis_exact_result) */
+            if (!c->scratch_exact) {
+                DALLOC(c->scratch_exact, 8);
+                HIPCK(hipMemset(c->scratch_exact, 0, 8 * sizeof(long long)));
+            }
+            c->nscr[2] += 1.0;
+            if (!c->nuis_tiles_listed) launch_nuis_tile_list(c, c->stream3, false);
+            launch_nuis_exact_tiles(c, c->stream3, c->scratch_exact, false);
+            HIPCK(hipEventRecord(c->ev_exact, c->stream3));
+            c->nuis_sums_pending = true;
+            c->nuis_accept_certain = true;
         }
         if (reject) {
             c->nscr[1] += 1.0;
             c->nuis_screen_rejected = true;
+        }
+        if (reject || accept) {
             c->nuis_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
             HIPCK(hipGetLastError());
             drain_timers(c);
             c->main_drained = c->nuis_spec;
             *out = hn->res;
             if (out->error) return fail("device-side consistency failure %d", out->error);
+            if (c->nuis_spec) c->nh_pending_slot = (c->nh_valid && moved) ? c->spec_slot : -1;
             if (nz_test) *nz_test = scr_mid;
             if (z_test) *z_test = nuis_z_from_sums((const long long*)hn->sums);
             if (limbs5)
@@ -2466,7 +2638,10 @@ static int nuis_end_impl(ig_ctx* c, ig_move_result* out, double* nz_test, double
             return 0;
         }
         c->nscr[2] += 1.0;
-        if (!c->nuis_exact_queued) launch_nuis_exact_tiles(c, c->stream3); /* the exact pass over the same list of tiles */
+        if (!c->nuis_exact_queued) { /* the exact pass over the same list of tiles */
+            if (!c->nuis_tiles_listed) launch_nuis_tile_list(c, c->stream3, false);
+            launch_nuis_exact_tiles(c, c->stream3);
+        }
     }
     if (!(c->nuis_spec && c->nuis_pub_sums && wait_host_flag(&c->host_nuis->sums_seq, c->sums_seq, c->stream3))) {
         if (c->nuis_spec && c->nuis_pub_sums)
@@ -2479,14 +2654,28 @@ static int nuis_end_impl(ig_ctx* c, ig_move_result* out, double* nz_test, double
     c->main_drained = c->nuis_spec; /* a run's step: its last kernel on the library stream has delivered (or the stream was synchronised) */
     *out = c->host_nuis->res;
     if (out->error) return fail("device-side consistency failure %d", out->error);
-    if (scr_valid) { /* the exact pass ran as well: how much of the bound did the screened sum use?  (verify mode: the check) */
+    if (c->nuis_spec) c->nh_pending_slot = (c->nh_valid && moved) ? c->spec_slot : -1; /* (the histogram follows the move at the head of the next step) */
+    if (scr_valid || scr0_valid) { /* the exact pass ran as well: how much of the bounds did the screened sums use?  (verify mode: the check) */
         long long e[2] = {c->host_nuis->sums[0], c->host_nuis->sums[1]};
         ig_acc_normalize((int64_t*)&e[0], (int64_t*)&e[1]);
-        const double err = __builtin_fabs(scr_mid - ig_acc_to_double(e[0], e[1]));
-        if (scr_B > 0.0) c->nscr[5] = std::max(c->nscr[5], err / scr_B);
+        const double exact = ig_acc_to_double(e[0], e[1]);
         static const int s_nocheck = getenv("IG_NUIS_SCREEN_NOCHECK") ? atoi(getenv("IG_NUIS_SCREEN_NOCHECK")) : 0; /* tuning builds that compute garbage */
-        if (!(err <= scr_B) && !s_nocheck)
-            return fail("screened nuisance pass: |screened - exact| = %.6g exceeds its bound %.6g (move %d)", err, scr_B, c->spec_move - 1);
+        if (scr_valid) {
+            const double err = __builtin_fabs(scr_mid - exact);
+            if (scr_B > 0.0) c->nscr[5] = std::max(c->nscr[5], err / scr_B);
+            if (!(err <= scr_B) && !s_nocheck)
+                return fail("screened nuisance pass: |screened - exact| = %.6g exceeds its bound %.6g (move %d)", err, scr_B, c->spec_move - 1);
+        }
+        static const int s_trace = getenv("IG_NUIS_HIST_TRACE") ? atoi(getenv("IG_NUIS_HIST_TRACE")) : 0;
+        if (s_trace)
+            fprintf(stderr, "[nuis] move %d exact %.9f  hist %s mid-exact %.3e B %.3e  pass %s mid-exact %.3e B %.3e\n", c->spec_move - 1, exact,
+                    scr0_valid ? "ok" : "--", scr0_mid - exact, scr0_B, scr_valid ? "ok" : "--", scr_mid - exact, scr_B);
+        if (scr0_valid) {
+            const double err = __builtin_fabs(scr0_mid - exact);
+            if (scr0_B > 0.0) c->nhs[5] = std::max(c->nhs[5], err / scr0_B);
+            if (!(err <= scr0_B) && !s_nocheck)
+                return fail("screened nuisance pass, histogram tier: |screened - exact| = %.6g exceeds its bound %.6g (move %d)", err, scr0_B, c->spec_move - 1);
+        }
     }
     long long h[8];
     memcpy(h, (const void*)c->host_nuis->sums, sizeof h);
@@ -2517,6 +2706,53 @@ extern "C" int ig_nuis_end(ig_ctx* c, ig_move_result* out, double* nz_test, doub
 extern "C" int ig_debug_nuis_screen_stats(ig_ctx* c, double out12[12])
 {
     for (int i = 0; i < 12; i++) out12[i] = c->nscr[i];
+    return 0;
+}
+
+/* the histogram tier: {evaluations, steps rejected there, accepted there, void, sum of its bounds, largest used fraction of a bound
+ * (where the exact pass ran), moves walked into the histogram, builds from scratch} since the handle was made */
+extern "C" int ig_debug_nuis_hist_stats(ig_ctx* c, double out12[12])
+{
+    for (int i = 0; i < 12; i++) out12[i] = c->nhs[i];
+    return 0;
+}
+
+/* the maintained histogram against one built from scratch from the tables of the state it stands for (the state before the last
+ * move of the run; the current state once that move has been walked in, which this call does): *mismatches = words that differ
+ * (-1: no histogram) */
+extern "C" int ig_debug_nuis_hist_check(ig_ctx* c, int64_t* mismatches)
+{
+    HIPCK(hipSetDevice(c->device));
+    *mismatches = -1;
+    if (c->nuis_in_flight) return fail("ig_debug_nuis_hist_check: a step is in flight");
+    HIPCK(hipStreamSynchronize(c->stream));
+    HIPCK(hipStreamSynchronize(c->stream3));
+    if (!c->nh.bins || !c->nh_valid) return 0;
+    if (nh_flush_pending(c)) return -1;
+    HIPCK(hipStreamSynchronize(c->stream3));
+    const size_t nb = (size_t)NH_NB * 4, nd = (size_t)LDS_PZ + 1;
+    NuisHist t{nullptr, nullptr, nullptr};
+    DALLOC(t.bins, nb);
+    DALLOC(t.dh, nd);
+    DALLOC(t.misc, NH_MISC);
+    HIPCK(hipMemset(t.bins, 0, nb * sizeof(long long)));
+    HIPCK(hipMemset(t.dh, 0, nd * sizeof(long long)));
+    HIPCK(hipMemset(t.misc, 0, NH_MISC * sizeof(long long)));
+    hipLaunchKernelGGL(k_hist_build, dim3(2048), dim3(256), 0, c->stream3, c->rowptr, c->cc, c->tab, c->M, t);
+    HIPCK(hipStreamSynchronize(c->stream3));
+    std::vector<long long> a(nb + nd + NH_MISC), b(nb + nd + NH_MISC);
+    HIPCK(hipMemcpy(a.data(), c->nh.bins, nb * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(a.data() + nb, c->nh.dh, nd * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(a.data() + nb + nd, c->nh.misc, NH_MISC * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(b.data(), t.bins, nb * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(b.data() + nb, t.dh, nd * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(b.data() + nb + nd, t.misc, NH_MISC * sizeof(long long), hipMemcpyDeviceToHost));
+    hipFree(t.bins);
+    hipFree(t.dh);
+    hipFree(t.misc);
+    int64_t bad = 0;
+    for (size_t i = 0; i < a.size(); i++) bad += a[i] != b[i];
+    *mismatches = bad;
     return 0;
 }
 
@@ -2671,6 +2907,7 @@ extern "C" int ig_nuis_step_next(ig_ctx* c, double temperature, double u, const 
      * under the parameters just promoted: that needs nothing from the caller, and runs while it computes */
     if (has_next && acc == 1 && c->spec_move < c->up_moves) {
         /* (first what the pass of the next step waits for, or it would queue behind the scoring launches) */
+        if (nh_flush_pending(c)) return -1; /* (the histogram's walk of the last move reads tab_prev as of before it) */
         hipLaunchKernelGGL(k_catch_up, dim3(16), dim3(256), 0, c->stream, c->tab, c->tab_prev, c->prev_touched, c->glob);
         static const int s_serial = getenv("IG_NUIS_SERIAL") ? atoi(getenv("IG_NUIS_SERIAL")) : 0; /* the next pass behind the scoring launches, not next to them */
         if (!s_serial) HIPCK(hipEventRecord(c->ev_gathered, c->stream));
@@ -2937,7 +3174,10 @@ extern "C" int ig_debug_diff_trace(ig_ctx* c, const float p_test[8], float mean_
     c->diff_trace = d;
     const bool sb = c->side_busy;
     c->side_busy = false;
-    const int rc = launch_nuis_diff(c, hp, mean_subfrag_kb, c->stream3);
+    const bool ver = g_nuis_screen_verify;
+    g_nuis_screen_verify = 0;
+    const int rc = launch_nuis_prepare(c, hp, mean_subfrag_kb, c->stream3, false) || launch_nuis_diff(c, hp, c->stream3, true);
+    g_nuis_screen_verify = ver;
     c->side_busy = sb;
     c->diff_trace = nullptr;
     c->nuis_diff = false;

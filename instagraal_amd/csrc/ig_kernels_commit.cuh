@@ -880,6 +880,7 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
             hn->nzb[1] = mb.ctl[committed - 1].nzb_lo;
             hn->max_L = g->max_L;
             hn->max_SL = g->max_SL;
+            hn->changed = mb.ctl[committed - 1].n_dirty;
             __threadfence_system();
             hn->res_seq = hn_seq;
         }

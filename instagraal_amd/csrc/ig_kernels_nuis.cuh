@@ -69,6 +69,7 @@ struct alignas(16) DiffConst {
     float pzc_abs_max;    /* largest |pzc| of either set */
     unsigned cut;         /* rank distances from here on are not in the tables' LDS copies (a longer table: the pass is void if one occurs) */
     int ok;               /* both sets in the one-log domain, DY and |dlv| within DIFF_X0 */
+    int ok0;              /* ... what the histogram tier needs of that: the one-log domain, negative slopes, tables */
 };
 
 /* built by the blocks of k_nuis_prepare that build the test set's tables: thread i of that range */
@@ -122,10 +123,9 @@ __device__ __forceinline__ void build_diff_const(int i, const Glob* g, const ig_
         out->s17 = (float)(s_of(17.0) * (1.0 + 1e-6));
         out->zdy = (dslope == 0.0 && dla == 0.0) ? 1 : 0;
         out->cut = (pz_n_c > LDS_PZ || pz_n_t > LDS_PZ) ? (unsigned)LDS_PZ : 0xffffffffu;
-        out->ok = (hc.fast && ht.fast && pc.slope < 0.0f && pt.slope < 0.0f && dy_max <= (double)DIFF_X0 && a_dv <= 64.0 && cy < 200.0 &&
-                   pz_n_c > 0 && pz_n_t > 0 && scr0->pzc_max < 1e5f)
-                      ? 1
-                      : 0;
+        const bool ok0 = hc.fast && ht.fast && pc.slope < 0.0f && pt.slope < 0.0f && cy < 200.0 && pz_n_c > 0 && pz_n_t > 0 && scr0->pzc_max < 1e5f;
+        out->ok0 = ok0 ? 1 : 0;
+        out->ok = (ok0 && dy_max <= (double)DIFF_X0 && a_dv <= 64.0) ? 1 : 0;
     }
     if (i == 1) { /* the largest |pzc| of either set (only a 4e-15 slack on the contract's own double roundings hangs on it):
                    * the model's from its screening constants, the test set's from its largest entry -- P_z decreases with the
@@ -460,6 +460,367 @@ __global__ void __launch_bounds__(DIFF_THREADS) __attribute__((amdgpu_waves_per_
             tr[3] = ((long long)n_items << 32) | (n_read & 0xffffffffLL);
             tr[4] = t_stage;
             tr[5] = t_loop;
+        }
+    }
+}
+
+/* ================================================================================================================================
+ * Tier 0: the same difference from a HISTOGRAM of the cis contacts' distances, without reading a contact.
+ *
+ * In x = log2 s the exponent of the term is piecewise LINEAR: yy(x) = x < log2 d_max ? max(slope x + la, lv) : lv, with at most
+ * two kinks per parameter set (where the power law meets the trans level; d_max).  Between the kinks of both sets
+ *     dt = ob log10(2) (dA x + dB) - [2^(A_t x + B_t) - 2^(A_c x + B_c)] + dpzc[d]
+ * with (A, B) = (slope, la) or (0, lv) per set: the first part needs sum(ob) and sum(ob x) of the contacts of a bin EXACTLY (it
+ * is linear), the second a Taylor expansion around the bin's centre with sum(1), sum(x) and a remainder of second order in the bin
+ * width (2^-NH_OCT_BITS octaves: ~1e-6 of the bin's sum of P), the third a histogram over the rank distance.  The histogram
+ * (NuisHist: integers, maintained with atomics) is built once from the tables (k_hist_build), follows every move that changes
+ * the genome (k_hist_walk: the contacts inside the move's contigs whose bin changes, before and after from the winner's columns)
+ * and is evaluated per step by k_hist_eval: ~50 k bins instead of the 160 MB of contacts of the pass above.  A bin that holds a
+ * kink of either set is bounded piece by piece (interval arithmetic on its sums).  Trans contacts are not in the histogram: their
+ * number and the sum of their counts are the totals minus the cis ones, and their term depends on the count alone.
+ * x is the hardware's log2 (v_log_f32) of the float distance, rounded to 2^-NH_FRAC_BITS: within e = 2^-22 (|x| + 2) + 2^-20 of
+ * the true log2 s; every bound below is taken over the bin widened by e.
+ * The interval it yields is used exactly like the pass's (nuis_end_impl); where it does not decide, the pass over the contacts
+ * runs as before. */
+struct NhKey {
+    int kind; /* 0 trans (not in the histogram), 1 binned, 2 cis at distance 0, 3 cis on a ring, 4 cis outside the binned range */
+    int bin, off, d;
+};
+__device__ __forceinline__ NhKey nh_key(bool cis, bool ring, float sv, unsigned d)
+{
+    NhKey k;
+    k.kind = 0;
+    k.bin = 0;
+    k.off = 0;
+    k.d = (int)min(d, (unsigned)LDS_PZ);
+    if (!cis) return k;
+    if (ring) {
+        k.kind = 3;
+        return k;
+    }
+    if (!(sv > 0.0f)) {
+        k.kind = 2;
+        return k;
+    }
+    const float xf = __builtin_rintf(__builtin_amdgcn_logf(sv) * (float)(1 << NH_FRAC_BITS)); /* (a power of two: the product is exact) */
+    const float lim = (float)(NH_LMAX << NH_FRAC_BITS);
+    if (!(xf >= -lim) || !(xf < lim)) {
+        k.kind = 4;
+        return k;
+    }
+    const int q = (int)xf + (NH_LMAX << NH_FRAC_BITS);
+    k.kind = 1;
+    k.bin = q >> (NH_FRAC_BITS - NH_OCT_BITS);
+    k.off = q & (NH_SUB - 1);
+    return k;
+}
+__device__ __forceinline__ bool nh_same(const NhKey& a, const NhKey& b)
+{
+    return a.kind == b.kind && (a.kind == 0 || (a.bin == b.bin && a.off == b.off && a.d == b.d));
+}
+__device__ __forceinline__ void nh_apply(const NuisHist& h, const NhKey& k, int ob, long long sign)
+{
+    if (k.kind == 0) return;
+    if (k.kind == 1) {
+        long long* b = h.bins + 4 * (size_t)k.bin;
+        atomic_add_ll(&b[0], sign);
+        atomic_add_ll(&b[1], sign * k.off);
+        atomic_add_ll(&b[2], sign * ob);
+        atomic_add_ll(&b[3], sign * (long long)ob * k.off);
+        atomic_add_ll(&h.dh[k.d], sign);
+    } else if (k.kind == 2) {
+        atomic_add_ll(&h.misc[0], sign);
+        atomic_add_ll(&h.misc[1], sign * ob);
+        atomic_add_ll(&h.dh[k.d], sign);
+    } else {
+        atomic_add_ll(&h.misc[k.kind == 3 ? 2 : 3], sign);
+    }
+}
+
+/* the histogram of the state in `t`, from scratch (h zeroed by the caller): a wave per row of the contact matrix */
+__global__ void __launch_bounds__(256) k_hist_build(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables t, int M, NuisHist h)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    long long n_all = 0, ob_all = 0, n_big = 0;
+    for (int i = blockIdx.x * (blockDim.x >> 6) + wv; i < M; i += gridDim.x * (blockDim.x >> 6)) {
+        const long long b = rowptr[i], e = rowptr[i + 1];
+        if (b == e) continue;
+        const int2 cp1 = t.cp[i];
+        const float d1 = t.dist[i];
+        const bool ring1 = t.stot[i] != 0.0f;
+        for (long long q = b + lane; q < e; q += 64) {
+            const int2 v = cc[q];
+            const int2 cp2 = t.cp[v.x];
+            n_all++;
+            ob_all += v.y;
+            if ((unsigned)v.y - 1u >= 16383u) n_big++; /* (the pass is void for good: such a contact is in no bin) */
+            if (cp2.x != cp1.x || v.y <= 0) continue;
+            const bool ring = ring1 || t.stot[v.x] != 0.0f;
+            const NhKey k = nh_key(true, ring, fabsf(d1 - t.dist[v.x]), abs_diff_u32((unsigned)cp1.y, (unsigned)cp2.y));
+            nh_apply(h, k, v.y, 1);
+        }
+    }
+    n_all = wave_sum_ll(n_all);
+    ob_all = wave_sum_ll(ob_all);
+    n_big = wave_sum_ll(n_big);
+    if (lane == 0) {
+        if (n_all) atomic_add_ll(&h.misc[4], n_all);
+        if (ob_all) atomic_add_ll(&h.misc[5], ob_all);
+        if (n_big) atomic_add_ll(&h.misc[6], n_big);
+    }
+}
+
+/* the histogram follows the move of slot w (already applied; `tab`: the tables of the state BEFORE it, as k_delta's third mode):
+ * every contact inside the move's contigs whose key differs between the current genome's column and the winner's */
+__global__ void __launch_bounds__(256) k_hist_walk(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, const Glob* g,
+                                                   MoveBuf mb, int w, NuisHist h)
+{
+    const MoveCtl& mc = mb.ctl[w];
+    if (g->error || !mc.n_dirty) return;
+    const int cw = CW(w, mc.ch_c), k = mc.ch_k;
+    const CandMeta& m = mb.meta[cw];
+    const int M = mb.sM, m_loc = m.m_loc;
+    const uint2* col0 = mb.coords + (size_t)(cw * NSLOT) * M;
+    const uint2* colk = mb.coords + (size_t)(cw * NSLOT + k) * M;
+    const ColMeta* cm0 = mb.cmeta + (size_t)(cw * NSLOT) * NCODE;
+    const ColMeta* cmk = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
+    const int* subs = mb.subs + (size_t)cw * M;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    auto key_of = [](uint2 a, uint2 b, const ColMeta* cm) {
+        const int ci = (int)(a.y >> 28), cj = (int)(b.y >> 28);
+        const bool cis = ci == cj;
+        return nh_key(cis, cis && cm[ci].stot != 0.0f, fabsf(__uint_as_float(a.x) - __uint_as_float(b.x)),
+                      abs_diff_u32(a.y & 0x0fffffffu, b.y & 0x0fffffffu));
+    };
+    for (int r = blockIdx.x * (blockDim.x >> 6) + wv; r < m_loc; r += gridDim.x * (blockDim.x >> 6)) {
+        const int i = subs[r];
+        const long long b = rowptr[i], e = rowptr[i + 1];
+        if (b == e) continue;
+        const int2 cp1 = tab.cp[i];
+        const uint2 a0 = col0[r], a1 = colk[r];
+        for (long long q = b + lane; q < e; q += 64) {
+            const int2 v = cc[q];
+            const int2 cp2 = tab.cp[v.x];
+            if (!slice_keep(m, cp1.x, cp2.x, cp1.y, cp2.y, v.y, true)) continue;
+            const int lj = ((m.same || cp2.x == m.ctgA) ? 0 : m.SLA) + cp2.y;
+            const NhKey k0 = key_of(a0, col0[lj], cm0), k1 = key_of(a1, colk[lj], cmk);
+            if (nh_same(k0, k1)) continue;
+            nh_apply(h, k0, v.y, -1);
+            nh_apply(h, k1, v.y, 1);
+        }
+    }
+}
+
+/* out16: [2] sum, [3] bound (2^-20 units), [4] void flags (as the pass: 1 parameters, 2 contacts, 4 sums), [5] binned cis contacts,
+ * [6] their counts, [7] an upper bound of their sum of P under both sets, [8] workgroups through; zero between two launches (the last
+ * workgroup publishes and clears).  Grid: n_zero blocks of the zero-pixel sum under the test set (-> zero_out), NH_NB / 256 blocks
+ * of bins, one block for the rank-distance histogram. */
+__global__ void __launch_bounds__(256) k_hist_eval(NuisHist h, const Glob* g, const ScoreConst* __restrict__ sc_t, const ScoreConst* __restrict__ sc_c,
+                                                   const DiffConst* __restrict__ dc, long long* out16, NuisHost* hn, int hn_seq, Tables zt, int M,
+                                                   long long* zero_out, int n_zero_blocks, const long long* __restrict__ zero_sums)
+{
+    __shared__ double red[5][4];
+    __shared__ unsigned red_bad[4];
+    __shared__ long long red_n[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if ((int)blockIdx.x < n_zero_blocks) {
+        full_zero_block(zt, g, 1, M, zero_out, (int)blockIdx.x, n_zero_blocks);
+    } else {
+        const int bb = (int)blockIdx.x - n_zero_blocks;
+        const ig_hot hc = sc_c->hot, ht = sc_t->hot;
+        const double c10 = IG_LOG2_10_INV, ln2 = 0.69314718055994530942;
+        const double a_c = hc.slope, b_c = hc.log2_amp, lv_c = hc.log2_v_inter, a_t = ht.slope, b_t = ht.log2_amp, lv_t = ht.log2_v_inter;
+        const bool ok = dc->ok0 != 0;
+        double S = 0.0, E = 0.0, SP = 0.0, mag = 0.0, yhi = -1e300, ylo = 1e300; /* (yy decreases with x: its extremes sit at the bin's ends) */
+        unsigned bad = ok ? 0u : 1u;
+        long long n_cis = 0, ob_cis = 0;
+        if (ok && bb < NH_NB / 256) {
+            const int bin = bb * 256 + tid;
+            const long long n = h.bins[4 * (size_t)bin], sd = h.bins[4 * (size_t)bin + 1], sob = h.bins[4 * (size_t)bin + 2],
+                            sobd = h.bins[4 * (size_t)bin + 3];
+            if (n < 0 || sd < 0 || sob < n || sobd < 0) bad |= 4u | 16u;
+            if (n > 0 && !(bad & 4u)) {
+                n_cis = n;
+                ob_cis = sob;
+                const double wbin = 1.0 / (double)(1 << NH_OCT_BITS), unit = 1.0 / (double)(1 << NH_FRAC_BITS);
+                const double x0 = (double)bin * wbin - (double)NH_LMAX;
+                const double e = 0x1p-22 * (__builtin_fmax(__builtin_fabs(x0), __builtin_fabs(x0 + wbin)) + 2.0) + 0x1p-20;
+                const double lo = x0 - e, hi = x0 + wbin + e;
+                const double nd = (double)n, sobf = (double)sob;
+                /* the kinks of the two sets (slopes < 0, see ok0): where the power law meets the trans level, and d_max */
+                const double xd_c = ig_log2_pos((double)hc.d_max, ig_tab()), xd_t = ig_log2_pos((double)ht.d_max, ig_tab());
+                double kk[4] = {(lv_c - b_c) / a_c, (lv_t - b_t) / a_t, xd_c, xd_t};
+                int nk = 0;
+                double cut[6];
+                cut[0] = lo;
+                for (int q = 0; q < 4; q++)
+                    if (kk[q] > lo - 1e-9 && kk[q] < hi + 1e-9) {
+                        const double v = __builtin_fmin(__builtin_fmax(kk[q], lo), hi);
+                        int at = ++nk;
+                        while (at > 1 && cut[at - 1] > v) {
+                            cut[at] = cut[at - 1];
+                            at--;
+                        }
+                        cut[at] = v;
+                    }
+                cut[nk + 1] = hi;
+                /* (A, B) of a set at a point that is not a kink */
+                auto piece = [&](double x, double a, double b, double lv, double xd, double& A, double& B) {
+                    const bool pw = (x < xd) && (a * x + b > lv);
+                    A = pw ? a : 0.0;
+                    B = pw ? b : lv;
+                };
+                if (nk == 0) { /* smooth bin: exact first part, Taylor for the second */
+                    const double xm = x0 + 0.5 * wbin;
+                    double Ac, Bc, At, Bt;
+                    piece(xm, a_c, b_c, lv_c, xd_c, Ac, Bc);
+                    piece(xm, a_t, b_t, lv_t, xd_t, At, Bt);
+                    const double dA = At - Ac, dB = Bt - Bc;
+                    const double sobx = x0 * sobf + (double)sobd * unit; /* sum ob x_i */
+                    const double t1 = c10 * (dA * sobx + dB * sobf);
+                    const double e1 = c10 * __builtin_fabs(dA) * e * sobf;
+                    const double Pt = exp2(At * xm + Bt), Pc = exp2(Ac * xm + Bc);
+                    const double dP = Pt - Pc, dP1 = ln2 * (At * Pt - Ac * Pc);
+                    const double sx = (x0 - xm) * nd + (double)sd * unit; /* sum (x_i - xm) */
+                    const double t2 = dP * nd + dP1 * sx;
+                    const double Pt_lo = exp2(At * lo + Bt) * (1.0 + 1e-12), Pc_lo = exp2(Ac * lo + Bc) * (1.0 + 1e-12);
+                    const double dyy = __builtin_fmax(__builtin_fabs(dA * lo + dB), __builtin_fabs(dA * hi + dB));
+                    const double dPmax = Pc_lo * (exp2(dyy) - 1.0) * (1.0 + 1e-9) + 1e-300;
+                    const double M1 = ln2 * (__builtin_fabs(dA) * Pt_lo + __builtin_fabs(Ac) * dPmax);
+                    const double M2 = ln2 * ln2 * (__builtin_fabs(At * At - Ac * Ac) * Pt_lo + Ac * Ac * dPmax);
+                    const double hw = 0.5 * wbin + e;
+                    const double e2 = M1 * e * nd + 0.5 * M2 * nd * hw * hw;
+                    S = t1 - t2;
+                    E = e1 + e2;
+                    SP = nd * (Pt_lo + Pc_lo);
+                    mag = __builtin_fabs(t1) + __builtin_fabs(t2) + c10 * (__builtin_fabs(dA) * ((double)NH_LMAX + 1.0) + __builtin_fabs(dB)) * sobf + (Pt_lo + Pc_lo) * nd;
+                    yhi = __builtin_fmax(Ac * lo + Bc, At * lo + Bt);
+                    ylo = __builtin_fmin(Ac * hi + Bc, At * hi + Bt);
+                } else { /* a kink inside: the hull over the pieces of g(x) = log10(2) dyy(x) and of dP(x) */
+                    double g_lo = 1e300, g_hi = -1e300, p_lo = 1e300, p_hi = -1e300;
+                    for (int q = 0; q <= nk; q++) {
+                        const double u = cut[q], v = cut[q + 1];
+                        if (!(v > u)) continue;
+                        const double xm = 0.5 * (u + v);
+                        double Ac, Bc, At, Bt;
+                        piece(xm, a_c, b_c, lv_c, xd_c, Ac, Bc);
+                        piece(xm, a_t, b_t, lv_t, xd_t, At, Bt);
+                        const double dA = At - Ac, dB = Bt - Bc;
+                        const double gu = c10 * (dA * u + dB), gv = c10 * (dA * v + dB);
+                        g_lo = __builtin_fmin(g_lo, __builtin_fmin(gu, gv));
+                        g_hi = __builtin_fmax(g_hi, __builtin_fmax(gu, gv));
+                        const double Ptu = exp2(At * u + Bt), Pcu = exp2(Ac * u + Bc), Ptv = exp2(At * v + Bt), Pcv = exp2(Ac * v + Bc);
+                        const double dyy = __builtin_fmax(__builtin_fabs(dA * u + dB), __builtin_fabs(dA * v + dB));
+                        const double dPmax = Pcu * (exp2(dyy) - 1.0) * (1.0 + 1e-9);
+                        const double M2 = ln2 * ln2 * (__builtin_fabs(At * At - Ac * Ac) * Ptu + Ac * Ac * dPmax) * (1.0 + 1e-9);
+                        const double cv = M2 * (v - u) * (v - u) * 0.125 + 1e-12 * (Ptu + Pcu);
+                        p_lo = __builtin_fmin(p_lo, __builtin_fmin(Ptu - Pcu, Ptv - Pcv) - cv);
+                        p_hi = __builtin_fmax(p_hi, __builtin_fmax(Ptu - Pcu, Ptv - Pcv) + cv);
+                        SP = __builtin_fmax(SP, nd * (Ptu + Pcu) * (1.0 + 1e-12));
+                        yhi = __builtin_fmax(yhi, __builtin_fmax(Ac * u + Bc, At * u + Bt));
+                        ylo = __builtin_fmin(ylo, __builtin_fmin(Ac * v + Bc, At * v + Bt));
+                    }
+                    const double d_lo = g_lo * sobf - p_hi * nd, d_hi = g_hi * sobf - p_lo * nd;
+                    S = 0.5 * (d_lo + d_hi);
+                    E = 0.5 * (d_hi - d_lo);
+                    mag = __builtin_fabs(d_lo) + __builtin_fabs(d_hi) + __builtin_fabs(g_lo * sobf) + __builtin_fabs(p_hi * nd);
+                    if (!(g_hi >= g_lo) || !(p_hi >= p_lo)) bad |= 4u | 128u;
+                }
+                /* the contract clamps a term to |t| < 2^20, the expansion does not: P < 2^17.5 and, with counts below 2^14,
+                 * |ob log10 P| + log10(ob!) + P_z < 16383 (100 log10 2 + 3.8) + 1e5 < 2^20 - 2^17.5 */
+                if (!(yhi <= 17.5) || !(ylo >= -100.0)) bad |= 4u | 32u;
+                if (!(__builtin_fabs(S) < 1e15) || !(E < 1e12)) bad |= 4u | 64u; /* not a number */
+                E += 1e-13 * mag;
+            }
+        } else if (ok) { /* the last block: P_z by rank distance */
+            for (int d = tid; d <= LDS_PZ; d += 256) {
+                const long long n = h.dh[d];
+                if (n < 0) bad |= 4u;
+                if (n > 0) {
+                    if (d == LDS_PZ && dc->cut != 0xffffffffu) bad |= 2u; /* a rank distance beyond the tables' staged part */
+                    const double pt = sc_t->tab.pzc[d], pc = sc_c->tab.pzc[d];
+                    S += (pt - pc) * (double)n;
+                    E += 1e-13 * (__builtin_fabs(pt) + __builtin_fabs(pc)) * (double)n;
+                }
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            S += __shfl_down(S, o, 64);
+            E += __shfl_down(E, o, 64);
+            SP += __shfl_down(SP, o, 64);
+            bad |= __shfl_down(bad, o, 64);
+            n_cis += __shfl_down(n_cis, o, 64);
+            ob_cis += __shfl_down(ob_cis, o, 64);
+        }
+        if (lane == 0) {
+            red[0][wv] = S;
+            red[1][wv] = E;
+            red[2][wv] = SP;
+            red_bad[wv] = bad;
+            red_n[0][wv] = n_cis;
+            red_n[1][wv] = ob_cis;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            S = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+            E = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+            SP = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+            bad = red_bad[0] | red_bad[1] | red_bad[2] | red_bad[3];
+            n_cis = red_n[0][0] + red_n[0][1] + red_n[0][2] + red_n[0][3];
+            ob_cis = red_n[1][0] + red_n[1][1] + red_n[1][2] + red_n[1][3];
+            if (S != 0.0) atomic_add_ll(&out16[2], (long long)__builtin_rint(S * DIFF_FIX));
+            if (E != 0.0) atomic_add_ll(&out16[3], (long long)__builtin_ceil(1.01 * E * DIFF_FIX) + 1);
+            if (n_cis) atomic_add_ll(&out16[5], n_cis);
+            if (ob_cis) atomic_add_ll(&out16[6], ob_cis);
+            if (SP != 0.0) atomic_add_ll(&out16[7], (long long)__builtin_ceil(SP) + 1);
+            if (bad) atomicOr((unsigned long long*)&out16[4], (unsigned long long)bad);
+        }
+    }
+    /* the last workgroup through: what does not belong to a bin (trans contacts, cis ones at distance 0, the contract's own
+     * roundings), then the sums to the (mapped) host memory and the flag; the words are cleared for the next launch */
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd((unsigned long long*)&out16[8], 1ull) == (unsigned long long)gridDim.x - 1ull) {
+            __threadfence();
+            long long o[8];
+            for (int q = 0; q < 8; q++) o[q] = __hip_atomic_load(&out16[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const ig_hot hc = sc_c->hot, ht = sc_t->hot;
+            const long long n_zero = h.misc[0], ob_zero = h.misc[1], n_ring = h.misc[2], n_out = h.misc[3], n_all = h.misc[4], ob_all = h.misc[5],
+                            n_big = h.misc[6];
+            unsigned bad = (unsigned)o[4];
+            if (!dc->ok0) bad |= 1u;
+            if (n_ring != 0 || n_out != 0 || n_big != 0) bad |= 2u;
+            const long long n_tr = n_all - (o[5] + n_zero + n_ring + n_out), ob_tr = ob_all - (o[6] + ob_zero);
+            if (n_tr < 0 || ob_tr < n_tr || n_zero < 0 || ob_zero < n_zero || n_all <= 0) bad |= 4u | 256u;
+            if (!(__builtin_fmax(hc.log2_v_inter, ht.log2_v_inter) <= 17.5) || !(__builtin_fmin(hc.log2_v_inter, ht.log2_v_inter) >= -100.0)) bad |= 4u | 32u;
+            const double c10 = IG_LOG2_10_INV;
+            const double dlv = ht.log2_v_inter - hc.log2_v_inter, dexb = (double)ht.v_inter - (double)hc.v_inter;
+            const double dpz_tr = sc_t->tab.pzc[LDS_PZ] - sc_c->tab.pzc[LDS_PZ];
+            const double Dg = c10 * dlv * (double)(ob_tr + ob_zero) - dexb * (double)(n_tr + n_zero) + dpz_tr * (double)n_tr;
+            const double vv = (double)ht.v_inter + (double)hc.v_inter;
+            const double sp = (double)o[7] + vv * (double)(n_tr + n_zero);
+            const double nn = (double)n_all;
+            /* the contract itself (two quantisations per contact, its double roundings), as the pass above (T4) */
+            const double T4 = nn * 0x1p-31 + 4e-15 * ((double)ob_all * 105.0 + 2.6 * sp + nn * (double)dc->pzc_abs_max);
+            const double Eg = T4 + 2.0 / DIFF_FIX +
+                              1e-13 * (c10 * __builtin_fabs(dlv) * (double)ob_all + __builtin_fabs(dexb) * nn + __builtin_fabs(dpz_tr) * nn);
+            if (!(__builtin_fabs(Dg) < 1e15) || !(Eg < 1e12)) bad |= 4u | 512u;
+            o[2] += (long long)__builtin_rint(Dg * DIFF_FIX);
+            o[3] += (long long)__builtin_ceil(Eg * DIFF_FIX) + 1;
+            o[4] = (long long)bad;
+            o[0] = o[1] = 0;
+            o[5] = n_all;
+            for (int q = 0; q < 9; q++) out16[q] = 0;
+            if (hn) {
+                for (int q = 0; q < 8; q++) hn->diff[q] = o[q];
+                for (int q = 0; q < 8; q++) hn->sums[q] = __hip_atomic_load(&zero_sums[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence_system();
+                hn->diff_seq = hn_seq;
+            }
+            out16[9] = o[2]; /* (device copies for a host that could not map its memory, and for the tests) */
+            out16[10] = o[3];
+            out16[11] = o[4];
         }
     }
 }

@@ -176,6 +176,11 @@ def set_nuis_screen(on):
     _ck(lib().ig_set_nuis_screen(C.c_int(int(on))))
 
 
+def set_nuis_hist(on):
+    """the screened pass starts from the histogram of the cis contacts' distances (default) or from the pass over the contacts"""
+    _ck(lib().ig_set_nuis_hist(C.c_int(int(on))))
+
+
 def debug_set_full_hist(on):
     """from-scratch pass over all contacts: tiles of trans pairs only from their count histograms (default) or contact by
     contact -- same exact sums (tests)"""
@@ -406,6 +411,22 @@ class Context:
         return dict(screened=int(o[0]), rejected_screened=int(o[1]), exact_passes=int(o[2]), void=int(o[3]), largest_bound=float(o[4]),
                     largest_used_fraction=float(o[5]), mean_bound=float(o[6] / n), undecided=int(o[7]),
                     void_why=dict(parameters=int(o[8]), contact=int(o[9]), sums=int(o[10]), no_record=int(o[11])))
+
+    def debug_nuis_hist_stats(self):
+        """the histogram tier of the screened nuisance pass: evaluations, steps rejected / accepted there, void, mean bound, largest
+        |screened - exact| / bound, moves walked into the histogram, builds from scratch"""
+        o = np.zeros(12, np.float64)
+        _ck(lib().ig_debug_nuis_hist_stats(self._h, _p(o)))
+        n = max(o[0] - o[3], 1.0)
+        return dict(evaluated=int(o[0]), rejected=int(o[1]), accepted=int(o[2]), void=int(o[3]), mean_bound=float(o[4] / n),
+                    largest_used_fraction=float(o[5]), walks=int(o[6]), builds=int(o[7]),
+                    void_why=dict(parameters=int(o[8]), contact=int(o[9]), sums=int(o[10]), no_record=int(o[11])))
+
+    def debug_nuis_hist_check(self):
+        """words of the maintained histogram that differ from one built from scratch (-1: no histogram kept)"""
+        n = C.c_int64()
+        _ck(lib().ig_debug_nuis_hist_check(self._h, C.byref(n)))
+        return int(n.value)
 
     def batch_stats(self):
         o = np.zeros(4, np.int64)

@@ -13,8 +13,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run(prob, n, seed, mode, monkeypatch, coo=False, params=None, warm=0):
-    """mode: 'exact' (screening off), 'screened' (default), 'verify'"""
+def _run(prob, n, seed, mode, monkeypatch, coo=False, params=None, warm=0, hist=True):
+    """mode: 'exact' (screening off), 'screened' (default), 'verify'; hist=False: the screened pass without its histogram tier"""
     from instagraal_amd import hip_lib
     from instagraal_amd.sampler import sampler as hip_sampler
 
@@ -22,6 +22,7 @@ def _run(prob, n, seed, mode, monkeypatch, coo=False, params=None, warm=0):
     if mode == "verify":
         monkeypatch.setenv("IG_NUIS_SCREEN_VERIFY", "1")
     hip_lib.set_nuis_screen(mode != "exact")
+    hip_lib.set_nuis_hist(hist)
     try:
         np.random.seed(seed)
         s = hip_sampler(**prob.sampler_kwargs(), device_id=0, coo=(prob.coo_row, prob.coo_col, prob.coo_cnt) if coo else None)
@@ -40,10 +41,14 @@ def _run(prob, n, seed, mode, monkeypatch, coo=False, params=None, warm=0):
         out = (rows, nu, s.gpu_vect_frags.copy_from_gpu().soa17().tobytes(), np.random.get_state()[1][:8].tobytes(),
                [float(s.param_simu[k][0]) for k in ("fact", "slope", "d_max", "v_inter")])
         stats = s.ctx.debug_nuis_screen_stats()
+        stats["hist"] = s.ctx.debug_nuis_hist_stats()
+        # the maintained histogram (every move of the run walked in) against one built from scratch from the final tables
+        stats["hist_mismatch"] = s.ctx.debug_nuis_hist_check()
         s.free_gpu()
         return out, stats
     finally:
         hip_lib.set_nuis_screen(1)
+        hip_lib.set_nuis_hist(1)
 
 
 @pytest.mark.parametrize("cfg,n", [("tiny", 250), ("small", 400), ("cfg2", 500)])
@@ -54,12 +59,20 @@ def test_screened_pass_bound_holds_and_changes_nothing(cfg, n, monkeypatch):
     exact, st0 = _run(prob, n, 5, "exact", monkeypatch)
     verified, st1 = _run(prob, n, 5, "verify", monkeypatch)  # raises when a bound is violated
     screened, st2 = _run(prob, n, 5, "screened", monkeypatch)
+    tier1, st3 = _run(prob, n, 5, "screened", monkeypatch, hist=False)
     assert st0["screened"] == 0
     assert verified == exact
     assert screened == exact
-    print(cfg, "verify:", st1, "\n    screened:", st2)
+    assert tier1 == exact
+    print(cfg, "verify:", st1, "\n    screened:", st2, "\n    without the histogram tier:", st3)
     assert st1["screened"] > 0.9 * n and st1["largest_used_fraction"] < 0.5  # rigorous, hence loose
     assert st2["rejected_screened"] > 0  # steps were decided without the exact pass
+    # the histogram tier: evaluated on every screened step, its bound checked in verify mode, the histogram itself exact
+    assert st1["hist"]["evaluated"] == st1["screened"] and st1["hist"]["largest_used_fraction"] <= 1.0
+    assert st1["hist_mismatch"] == 0 and st2["hist_mismatch"] == 0 and st3["hist_mismatch"] == -1
+    assert st2["hist"]["walks"] > 0 and st2["hist"]["builds"] == 1
+    assert st2["hist"]["rejected"] + st2["hist"]["accepted"] > 0  # steps were decided without reading a contact
+    assert st3["hist"]["evaluated"] == 0
     assert 0 < sum(q[6] for q in exact[1]) < n  # accepted and rejected steps
 
 
@@ -86,7 +99,7 @@ def test_screened_pass_other_parameters_and_large_counts(monkeypatch):
         screened, _ = _run(prob, 200, 9, "screened", monkeypatch, params=params)
         assert verified == exact and screened == exact
         print(params["slope"], st)
-        assert st["largest_used_fraction"] < 0.5
+        assert st["largest_used_fraction"] < 0.5 and st["hist"]["largest_used_fraction"] <= 1.0 and st["hist_mismatch"] == 0
 
 
 def test_screened_pass_at_the_headline_shape(monkeypatch):
@@ -100,11 +113,14 @@ def test_screened_pass_at_the_headline_shape(monkeypatch):
     screened, st2 = _run(prob, 300, 3, "screened", monkeypatch, coo=True)
     assert verified == exact and screened == exact
     print("cfg3 verify:", st, "\n     screened:", st2)
-    assert st["largest_used_fraction"] < 0.5
+    assert st["largest_used_fraction"] < 0.5 and st["hist"]["largest_used_fraction"] <= 1.0
+    assert st["hist_mismatch"] == 0 and st2["hist_mismatch"] == 0
     assert st2["rejected_screened"] > 0.3 * st2["screened"]
     # settled: 2 400 steps of warm-up, then 300 verified ones
     verified, st = _run(prob, 300, 4, "verify", monkeypatch, coo=True, warm=2400)
     screened, st2 = _run(prob, 300, 4, "screened", monkeypatch, coo=True, warm=2400)
     assert verified == screened
     print("cfg3 settled verify:", st, "\n     screened:", st2)
-    assert st["largest_used_fraction"] < 0.5
+    assert st["largest_used_fraction"] < 0.5 and st["hist"]["largest_used_fraction"] <= 1.0
+    assert st["hist_mismatch"] == 0 and st2["hist_mismatch"] == 0
+    assert st2["hist"]["rejected"] + st2["hist"]["accepted"] > 0.5 * st2["screened"]

@@ -109,6 +109,19 @@ static float time_ms(F f, int reps = 5)
     return best;
 }
 
+// (3) no-return 64-bit atomic adds into a table of `bins` words: every lane its own pseudo-random bin (a histogram update),
+// `per` adds per thread.  spread: the bins a wave touches lie within `spread` consecutive words (0: anywhere)
+__global__ void k_atomics(unsigned long long* tab, unsigned bins, int per, unsigned spread)
+{
+    unsigned x = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u;
+    const unsigned base = spread ? ((blockIdx.x * 97u + (threadIdx.x >> 6)) * 7919u) % (bins - spread) : 0u;
+    for (int i = 0; i < per; i++) {
+        x = x * 1664525u + 1013904223u;
+        const unsigned b = spread ? base + (x >> 8) % spread : (x >> 8) % bins;
+        __hip_atomic_fetch_add(&tab[b], (unsigned long long)(x & 1023u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 int main(int argc, char** argv)
 {
     const size_t mb = argc > 1 ? atoi(argv[1]) : 400;
@@ -164,5 +177,23 @@ int main(int argc, char** argv)
     valu("v_log_f32 + v_add_f32 (64 + 64 per iteration)", time_ms([&] { hipLaunchKernelGGL(k_valu<2>, dim3(grid), dim3(threads), 0, 0, fo, iters); }), 64);
     valu("v_exp_f32 + v_mul_f32 (64 + 64 per iteration)", time_ms([&] { hipLaunchKernelGGL(k_valu<3>, dim3(grid), dim3(threads), 0, 0, fo, iters); }), 64);
     valu("v_fma_f64 (64 per iteration, + 8 x 8 conversions)", time_ms([&] { hipLaunchKernelGGL(k_valu<4>, dim3(grid), dim3(threads), 0, 0, fo, iters); }), 64);
+    // ---- (3) atomics
+    {
+        unsigned long long* tab;
+        const unsigned bins = 3 * 49152;
+        CK(hipMalloc(&tab, bins * 8));
+        CK(hipMemset(tab, 0, bins * 8));
+        auto atom = [&](const char* name, int g, int t, int per, unsigned spread) {
+            const float ms = time_ms([&] { hipLaunchKernelGGL(k_atomics, dim3(g), dim3(t), 0, 0, tab, bins, per, spread); });
+            const double n = (double)g * t * per;
+            printf("%-64s %8.1f us  %7.2f G atomics/s\n", name, ms * 1e3, n / (ms * 1e-3) / 1e9);
+        };
+        atom("64-bit atomic add, 147 k bins, 1 M adds (256 x 256 x 16)", 256, 256, 16, 0);
+        atom("64-bit atomic add, 147 k bins, 16 M adds (2048 x 256 x 32)", 2048, 256, 32, 0);
+        atom("64-bit atomic add, 147 k bins, 64 M adds (4096 x 256 x 64)", 4096, 256, 64, 0);
+        atom("... a wave's bins within 256 words, 16 M adds", 2048, 256, 32, 256);
+        atom("... a wave's bins within 16 words, 16 M adds", 2048, 256, 32, 16);
+        atom("64-bit atomic add, 147 k bins, 64 k adds (64 x 256 x 4)", 64, 256, 4, 0);
+    }
     return 0;
 }

@@ -32,6 +32,7 @@ b1 = s.ctx.batch_stats()
 print("   of the library call: %.0f us per move waiting for the device" % (1e6 * (s.ctx.debug_nuis_wait() - w0) / n))
 print("   batches scored: %d for %d moves; one-move tails %d" % (b1["batches"] - b0["batches"], n, b1["one_move_tails"] - b0["one_move_tails"]))
 print("   screened pass:", s.ctx.debug_nuis_screen_stats())
+print("   its histogram tier:", s.ctx.debug_nuis_hist_stats())
 if hasattr(s, "nuis_profile"):
     tot = sum(s.nuis_profile.values())
     print("   host time per move: " + ", ".join("%s %.0f us" % (k, 1e6 * v / n) for k, v in s.nuis_profile.items()) + " (sum %.0f us)" % (1e6 * tot / n))
@@ -52,6 +53,7 @@ if os.environ.get("NUIS_LONG"):  # the rate as the chain settles: chunks of 600 
         print("   chunk %d: %.0f moves/s, accept %.2f, device wait %.0f us/move, host %s, %s" % (
             k, 600 / dt, np.mean([q[6] for q in tup]), 1e6 * (s.ctx.debug_nuis_wait() - w0) / 600,
             ", ".join("%s %.0f" % (a, 1e6 * v / 600) for a, v in s.nuis_profile.items()), s.ctx.debug_nuis_screen_stats()), flush=True)
+        print("            histogram tier:", s.ctx.debug_nuis_hist_stats(), flush=True)
 if os.environ.get("NUIS_ONLY"):
     sys.exit(0)
 t_s = t_n = 0.0
