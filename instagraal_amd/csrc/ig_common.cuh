@@ -291,6 +291,7 @@ struct ig_ctx {
     bool nuis_nzb_copied;         /* the step's move was finished outside the batch commit: its NuisHost.nzb was copied from the control block */
     /* tier 0 of the screened pass: the histogram of the cis contacts' distances (NuisHist), valid for the state before the last
      * move of a run once nh_pending_slot's move has been walked (nh_flush_pending) */
+    struct NuisWorker* worker; /* the helper thread that enqueues a run's next step (ig_hip.hip) */
     NuisHist nh;
     long long* scratch_hist; /* k_hist_eval's 8 output words (zero between two launches) */
     bool nh_valid;

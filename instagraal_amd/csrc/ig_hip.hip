@@ -33,6 +33,8 @@
  * path).
  */
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 #include "ig_common.cuh"
@@ -45,6 +47,103 @@
 
 /* ================================================================== host side */
 static void flush_pending_sums(ig_ctx* c); /* behind a decisively accepted nuisance step: see k_nuis_promote */
+
+/* ---- the launches of a run's NEXT step on a helper thread ------------------------------------------------------------------
+ * Once a step's Metropolis test reads 600 KB instead of 160 MB (ig_kernels_nuis.cuh, tier 0) a (move, nuisance step) pair is
+ * bound by the host: the caller's proposal arithmetic and the half-dozen launches of the next step, one after the other on one
+ * thread.  ig_nuis_step_next hands the launches to this thread and returns; the caller computes its next proposal meanwhile.
+ * EVERY entry point that takes a handle waits for the thread first (IG_JOIN): outside the task nothing is shared.  An error of
+ * the deferred launches is reported by the entry point that waits for them.  IG_NUIS_ASYNC=0: no helper thread. */
+struct NuisWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<int> state{0}; /* 0 idle, 1 a task is waiting / running, 2 quit */
+    int rc = 0;
+    std::string err;
+    int move = 0;
+    float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float mean_kb = 0;
+    std::thread::id tid;
+};
+static int nuis_step_begin_impl(ig_ctx* c, int32_t move, const float p_test[8], float mean_subfrag_kb);
+static int nuis_join(ig_ctx* c)
+{
+    NuisWorker* w = c->worker;
+    if (!w || std::this_thread::get_id() == w->tid) return 0;
+    if (w->state.load(std::memory_order_acquire) == 1) {
+        for (unsigned spin = 0; w->state.load(std::memory_order_acquire) == 1; spin++)
+            if ((spin & 0x3ff) == 0x3ff) std::this_thread::yield();
+    }
+    if (w->rc) {
+        const int rc = w->rc;
+        w->rc = 0;
+        (void)rc;
+        return fail("%s", w->err.c_str());
+    }
+    return 0;
+}
+static void nuis_worker_main(ig_ctx* c)
+{
+    NuisWorker* w = c->worker;
+    hipSetDevice(c->device);
+    for (;;) {
+        int st = w->state.load(std::memory_order_acquire);
+        if (st == 0) { /* spin for a while (a step of a run is tens of microseconds away), then sleep */
+            bool got = false;
+            for (unsigned spin = 0; spin < 200000 && !got; spin++) got = w->state.load(std::memory_order_acquire) != 0;
+            if (!got) {
+                std::unique_lock<std::mutex> lk(w->mu);
+                w->cv.wait(lk, [&] { return w->state.load(std::memory_order_acquire) != 0; });
+            }
+            continue;
+        }
+        if (st == 2) return;
+        const int rc = nuis_step_begin_impl(c, w->move, w->p, w->mean_kb);
+        if (rc) w->err = g_err;
+        w->rc = rc;
+        w->state.store(0, std::memory_order_release);
+    }
+}
+static int nuis_defer_step_begin(ig_ctx* c, int32_t move, const float p_test[8], float mean_subfrag_kb)
+{
+    static const int s_async = getenv("IG_NUIS_ASYNC") ? atoi(getenv("IG_NUIS_ASYNC")) : 1;
+    if (!s_async) return nuis_step_begin_impl(c, move, p_test, mean_subfrag_kb);
+    if (!c->worker) {
+        c->worker = new NuisWorker();
+        c->worker->th = std::thread(nuis_worker_main, c);
+        c->worker->tid = c->worker->th.get_id();
+    }
+    NuisWorker* w = c->worker;
+    if (nuis_join(c)) return -1;
+    w->move = move;
+    memcpy(w->p, p_test, sizeof w->p);
+    w->mean_kb = mean_subfrag_kb;
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->state.store(1, std::memory_order_release);
+    }
+    w->cv.notify_one();
+    return 0;
+}
+static void nuis_worker_stop(ig_ctx* c)
+{
+    NuisWorker* w = c->worker;
+    if (!w) return;
+    (void)nuis_join(c);
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->state.store(2, std::memory_order_release);
+    }
+    w->cv.notify_one();
+    w->th.join();
+    delete w;
+    c->worker = nullptr;
+}
+#define IG_JOIN(c)                    \
+    do {                              \
+        if (nuis_join(c)) return -1;  \
+    } while (0)
 
 template <class T>
 static int dalloc(T** p, size_t n)
@@ -201,6 +300,7 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->exact_seq = 0;
     HIPCK(hipEventCreateWithFlags(&c->ev_exact, hipEventDisableTiming));
     HIPCK(hipEventCreateWithFlags(&c->ev_walk, hipEventDisableTiming));
+    c->worker = nullptr;
     c->nh = NuisHist{nullptr, nullptr, nullptr};
     c->scratch_hist = nullptr;
     c->nh_valid = false;
@@ -307,6 +407,7 @@ static void free_move_buffers(ig_ctx* c)
 extern "C" void ig_destroy(ig_ctx* c)
 {
     if (!c) return;
+    nuis_worker_stop(c);
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     hipStreamSynchronize(c->stream2);
@@ -376,6 +477,7 @@ extern "C" void ig_destroy(ig_ctx* c)
 
 extern "C" int ig_sync(ig_ctx* c)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     flush_pending_sums(c);
     HIPCK(hipStreamSynchronize(c->stream));
@@ -385,6 +487,7 @@ extern "C" int ig_sync(ig_ctx* c)
 
 extern "C" int ig_set_stream(ig_ctx* c, void* s)
 {
+    IG_JOIN(c);
     HIPCK(hipStreamSynchronize(c->stream));
     if (c->own_stream) hipStreamDestroy(c->stream);
     if (s) {
@@ -597,6 +700,7 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
 extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* col, const int32_t* cnt, int64_t Z, int32_t M,
                                   int32_t rank, int32_t world)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (Z < 0 || M <= 0) return fail("ig_upload_contacts: bad sizes");
     if (world < 1 || rank < 0 || rank >= world) return fail("ig_upload_contacts: bad shard %d/%d", rank, world);
@@ -734,6 +838,7 @@ extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* 
 
 extern "C" int ig_upload_subfrag_table(ig_ctx* c, const float* xyzw, int32_t M)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (M <= 0) return fail("ig_upload_subfrag_table: M <= 0");
     if (c->M && c->M != M) return fail("ig_upload_subfrag_table: M=%d does not match the contacts (%d)", M, c->M);
@@ -788,6 +893,7 @@ static bool links_inverse(const int32_t* ip, const int32_t* in, size_t n)
 
 extern "C" int ig_upload_state(ig_ctx* c, const int32_t* soa, int32_t N)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (N <= 0) return fail("ig_upload_state: N <= 0");
     if (!c->have_sub) return fail("ig_upload_state: upload the sub-fragment table first");
@@ -909,6 +1015,7 @@ static int launch_recompute(ig_ctx* c)
 
 extern "C" int ig_set_params(ig_ctx* c, const float p[8], float mean_subfrag_kb, int which)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (which != 0 && which != 1) return fail("ig_set_params: which must be 0 or 1");
     if (which == 0) c->nuis_spec = c->spec_valid = false; /* moves scored ahead (ig_nuis_step_begin) were scored under the old set */
@@ -942,6 +1049,7 @@ extern "C" int ig_set_params(ig_ctx* c, const float p[8], float mean_subfrag_kb,
 
 extern "C" int ig_set_insert_config(ig_ctx* c, const int32_t list_bounds[IG_N_INSERT_BLOCKS], int32_t max_bounds_insert)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     HIPCK(hipStreamSynchronize(c->stream));
     HIPCK(hipMemcpy(c->glob->list_bounds, list_bounds, 6 * sizeof(int), hipMemcpyHostToDevice));
@@ -952,6 +1060,7 @@ extern "C" int ig_set_insert_config(ig_ctx* c, const int32_t list_bounds[IG_N_IN
 extern "C" int ig_set_initial_genome(ig_ctx* c, const int32_t* ip, const int32_t* in, const int32_t* orientable,
                                      const int32_t* blacklisted, int32_t nb)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (!c->have_state) return fail("ig_set_initial_genome: upload the state first");
     const size_t n = c->N;
@@ -995,6 +1104,7 @@ static void canonical_ids(const int* pos, const int* cid, const int* L, size_t n
 
 extern "C" int ig_download_state(ig_ctx* c, int32_t* soa)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (!c->have_state) return fail("ig_download_state: no state");
     const size_t n = c->N;
@@ -1018,6 +1128,7 @@ extern "C" int ig_download_state(ig_ctx* c, int32_t* soa)
 
 extern "C" int ig_renumber_contigs(ig_ctx* c, int32_t* n_contigs, float* mean_len, int32_t* max_id)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     HIPCK(hipStreamSynchronize(c->stream));
     int nc;
@@ -1030,6 +1141,7 @@ extern "C" int ig_renumber_contigs(ig_ctx* c, int32_t* n_contigs, float* mean_le
 
 extern "C" int ig_bomb(ig_ctx* c, const int32_t* shuffle)
 {
+    IG_JOIN(c);
     (void)shuffle; /* explode_genome writes id_c = shuffle[i] (KA:419); the renumbering that follows (CL:1948) erases it */
     HIPCK(hipSetDevice(c->device));
     if (!c->have_state) return fail("ig_bomb: no state");
@@ -1042,6 +1154,7 @@ extern "C" int ig_bomb(ig_ctx* c, const int32_t* shuffle)
 
 extern "C" int ig_genome_distance(ig_ctx* c, double* d)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     HIPCK(hipStreamSynchronize(c->stream));
     Glob hg;
@@ -1053,6 +1166,7 @@ extern "C" int ig_genome_distance(ig_ctx* c, double* d)
 
 extern "C" int ig_get_valid_insert(ig_ctx* c, int32_t out12[12])
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     HIPCK(hipStreamSynchronize(c->stream));
     HIPCK(hipMemcpy(out12, c->glob->valid_insert, 12 * sizeof(int), hipMemcpyDeviceToHost));
@@ -1061,6 +1175,7 @@ extern "C" int ig_get_valid_insert(ig_ctx* c, int32_t out12[12])
 
 extern "C" int ig_full_likelihood(ig_ctx* c, int which, int use_prev, double* nz, double* z, int64_t* limbs5)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (!c->have_contacts || !c->have_state || !c->have_params) return fail("ig_full_likelihood: contacts, state and parameters are required");
     if (which != 0 && which != 1) return fail("ig_full_likelihood: which must be 0 or 1");
@@ -1550,7 +1665,7 @@ static int batch_width(ig_ctx* c, int max_c)
     return std::min(g_batch_w, max_batch_width(c, max_c));
 }
 
-extern "C" int ig_batch_max_width(ig_ctx* c, int32_t max_c) { return max_batch_width(c, max_c); }
+extern "C" int ig_batch_max_width(ig_ctx* c, int32_t max_c) { IG_JOIN(c); return max_batch_width(c, max_c); }
 
 /* validate and upload the pre-drawn (fragment, candidates) lists of a run of moves */
 static int upload_moves(ig_ctx* c, int n_moves, const int32_t* frags, const int32_t* cands, int max_c)
@@ -1648,6 +1763,7 @@ static int run_moves(ig_ctx* c, int n_moves, int max_c, int Wmax, Ready ready)
 extern "C" int ig_step_batch(ig_ctx* c, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c,
                              ig_move_result* results)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (check_ready(c)) return -1;
     if (n_moves <= 0) return 0;
@@ -1669,6 +1785,7 @@ extern "C" int ig_step_batch(ig_ctx* c, int32_t n_moves, const int32_t* frags, c
 extern "C" int ig_step_batch_draw(ig_ctx* c, ig_neighbours* nb, uint32_t* mt_key624, int32_t* mt_pos, int32_t n_moves,
                                   const int32_t* frags, int32_t n_neighbours, int32_t* cands_out, ig_move_result* results)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (check_ready(c)) return -1;
     if (n_moves <= 0) return 0;
@@ -1745,6 +1862,7 @@ extern "C" int ig_step_batch_draw(ig_ctx* c, ig_neighbours* nb, uint32_t* mt_key
 
 extern "C" int ig_batch_upload(ig_ctx* c, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c, int32_t max_w)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (check_ready(c)) return -1;
     if (n_moves <= 0) return fail("ig_batch_upload: no moves");
@@ -1761,6 +1879,7 @@ extern "C" int ig_batch_upload(ig_ctx* c, int32_t n_moves, const int32_t* frags,
 
 extern "C" int ig_batch_score(ig_ctx* c, int32_t move0, int32_t W, int32_t slot_begin, int32_t slot_end)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (W < 1 || W > c->mb.capW || move0 < 0 || move0 + W > c->up_moves) return fail("ig_batch_score: batch out of range");
     if (slot_begin < 0 || slot_end > W || slot_begin > slot_end) return fail("ig_batch_score: slot range out of range");
@@ -1772,6 +1891,7 @@ extern "C" int ig_batch_score(ig_ctx* c, int32_t move0, int32_t W, int32_t slot_
 
 extern "C" int ig_batch_records(ig_ctx* c, void** records, int64_t* bytes_per_slot)
 {
+    IG_JOIN(c);
     if (!c->mb.rec) return fail("ig_batch_records: no batch buffers yet (ig_batch_upload first)");
     *records = c->mb.rec;
     *bytes_per_slot = (int64_t)c->mb.rec_stride;
@@ -1780,6 +1900,7 @@ extern "C" int ig_batch_records(ig_ctx* c, void** records, int64_t* bytes_per_sl
 
 extern "C" int ig_batch_commit(ig_ctx* c, int32_t move0, int32_t W, int32_t* n_committed)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (W < 1 || W > c->mb.capW || move0 < 0 || move0 + W > c->up_moves) return fail("ig_batch_commit: batch out of range");
     int next = 0;
@@ -1802,6 +1923,7 @@ extern "C" int ig_batch_commit(ig_ctx* c, int32_t move0, int32_t W, int32_t* n_c
 
 extern "C" int ig_batch_results(ig_ctx* c, int32_t n_moves, ig_move_result* results)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (n_moves < 0 || n_moves > c->up_moves) return fail("ig_batch_results: out of range");
     return download_results(c, n_moves, results);
@@ -1816,6 +1938,7 @@ extern "C" int ig_set_batch_width(int w)
 /* bytes of the move buffers: {per-window arrays (strides sN, sM), slice pool, everything else sized by slots and candidates} */
 extern "C" int ig_scratch_bytes(ig_ctx* c, int64_t out3[3])
 {
+    IG_JOIN(c);
     const MoveBuf& m = c->mb;
     const int64_t C = (int64_t)m.capC * m.capW;
     out3[0] = C * ((int64_t)m.sN * 4 * 3 + (int64_t)m.sM * 4 * 2 + (int64_t)m.sM * NSLOT * 8 + (int64_t)NSLOT * NDYN * m.sN * 4);
@@ -1828,6 +1951,7 @@ extern "C" int ig_scratch_bytes(ig_ctx* c, int64_t out3[3])
 
 extern "C" int ig_batch_stats(ig_ctx* c, int64_t out3[4])
 {
+    IG_JOIN(c);
     out3[0] = c->n_batches;
     out3[1] = c->n_batch_committed;
     out3[2] = c->n_batch_pending;
@@ -1837,6 +1961,7 @@ extern "C" int ig_batch_stats(ig_ctx* c, int64_t out3[4])
 
 extern "C" int ig_step(ig_ctx* c, int32_t frag_a, const int32_t* cands, int32_t C, ig_move_result* out, double* scores)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (check_ready(c)) return -1;
     if (c->world > 1) return fail("ig_step: this handle scores a contact shard (ig_set_shard %d/%d): partial sums only -- use ig_step_begin / all-reduce / ig_step_finish", c->rank, c->world);
@@ -1860,6 +1985,7 @@ extern "C" int ig_step(ig_ctx* c, int32_t frag_a, const int32_t* cands, int32_t 
 
 extern "C" int ig_score_move(ig_ctx* c, int32_t frag_a, const int32_t* cands, int32_t C, double* scores)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (check_ready(c)) return -1;
     if (c->world > 1) return fail("ig_score_move: this handle scores a contact shard (ig_set_shard %d/%d): partial sums only -- use ig_step_begin / all-reduce / ig_step_finish", c->rank, c->world);
@@ -1878,6 +2004,7 @@ extern "C" int ig_score_move(ig_ctx* c, int32_t frag_a, const int32_t* cands, in
 
 extern "C" int ig_apply(ig_ctx* c, int32_t frag_a, int32_t frag_b, int32_t op)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (check_ready(c)) return -1;
     if (c->world > 1) return fail("ig_apply: this handle scores a contact shard (ig_set_shard %d/%d): partial sums only -- use ig_step_begin / all-reduce / ig_step_finish", c->rank, c->world);
@@ -1902,6 +2029,7 @@ extern "C" int ig_apply(ig_ctx* c, int32_t frag_a, int32_t frag_b, int32_t op)
 
 extern "C" int ig_set_shard(ig_ctx* c, int32_t rank, int32_t world)
 {
+    IG_JOIN(c);
     if (world < 1 || rank < 0 || rank >= world) return fail("ig_set_shard: bad shard %d/%d", rank, world);
     HIPCK(hipStreamSynchronize(c->stream));
     c->rank = rank;
@@ -1909,11 +2037,12 @@ extern "C" int ig_set_shard(ig_ctx* c, int32_t rank, int32_t world)
     return 0;
 }
 
-extern "C" int64_t ig_partials_count(ig_ctx* c) { return (int64_t)c->mb.capC * P_STRIDE; }
-extern "C" void* ig_partials_device_ptr(ig_ctx* c) { return c->mb.part; }
+extern "C" int64_t ig_partials_count(ig_ctx* c) { (void)nuis_join(c); return (int64_t)c->mb.capC * P_STRIDE; }
+extern "C" void* ig_partials_device_ptr(ig_ctx* c) { (void)nuis_join(c); return c->mb.part; }
 
 extern "C" int ig_step_begin(ig_ctx* c, int32_t frag_a, const int32_t* cands, int32_t C)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (check_ready(c)) return -1;
     if (validate_move(c, frag_a, cands, C)) return -1;
@@ -1928,6 +2057,7 @@ extern "C" int ig_step_begin(ig_ctx* c, int32_t frag_a, const int32_t* cands, in
 
 extern "C" int ig_step_finish(ig_ctx* c, ig_move_result* out, double* scores)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     int C = 0;
     enqueue_move(c, 0, IG_MAX_CANDIDATES, -1, 1);
@@ -2226,6 +2356,7 @@ static int enqueue_nuis_pass(ig_ctx* c, const float p_test[8], float mean_subfra
 
 extern "C" int ig_nuis_begin(ig_ctx* c, int32_t frag_a, const int32_t* cands, int32_t C, const float p_test[8], float mean_subfrag_kb)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (check_ready(c)) return -1;
     if (c->world > 1) return fail("ig_nuis_begin: this handle scores a contact shard");
@@ -2271,7 +2402,7 @@ static int nuis_spec_width(ig_ctx* c)
 
 /* 1: the initial prev / next arrays (ig_upload_state / ig_set_initial_genome) are mutually inverse -- what the batch commit's
  * genome-distance bookkeeping relies on; 0: moves are applied one at a time */
-extern "C" int ig_links_inverse(ig_ctx* c) { return c->init_links_inverse ? 1 : 0; }
+extern "C" int ig_links_inverse(ig_ctx* c) { IG_JOIN(c); return c->init_links_inverse ? 1 : 0; }
 
 extern "C" int ig_set_nuis_width(int w)
 {
@@ -2281,6 +2412,7 @@ extern "C" int ig_set_nuis_width(int w)
 
 extern "C" int ig_nuis_run_begin(ig_ctx* c, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (check_ready(c)) return -1;
     if (c->world > 1) return fail("ig_nuis_run_begin: this handle scores a contact shard");
@@ -2382,6 +2514,11 @@ static int nuis_spec_rescore(ig_ctx* c)
 }
 
 extern "C" int ig_nuis_step_begin(ig_ctx* c, int32_t move, const float p_test[8], float mean_subfrag_kb)
+{
+    IG_JOIN(c);
+    return nuis_step_begin_impl(c, move, p_test, mean_subfrag_kb);
+}
+static int nuis_step_begin_impl(ig_ctx* c, int32_t move, const float p_test[8], float mean_subfrag_kb)
 {
     HIPCK(hipSetDevice(c->device));
     if (!c->nuis_spec) return fail("ig_nuis_step_begin: no run (ig_nuis_run_begin)");
@@ -2698,6 +2835,7 @@ static int nuis_end_body(ig_ctx* c, ig_move_result* out, double* nz_test, double
 
 extern "C" int ig_nuis_end(ig_ctx* c, ig_move_result* out, double* nz_test, double* z_test, int64_t* limbs5)
 {
+    IG_JOIN(c);
     return nuis_end_impl(c, out, nz_test, z_test, limbs5, nullptr);
 }
 
@@ -2705,6 +2843,7 @@ extern "C" int ig_nuis_end(ig_ctx* c, ig_move_result* out, double* nz_test, doub
  * fraction of a bound (where the exact pass ran), sum of the bounds, steps whose interval did not decide} since the handle was made */
 extern "C" int ig_debug_nuis_screen_stats(ig_ctx* c, double out12[12])
 {
+    IG_JOIN(c);
     for (int i = 0; i < 12; i++) out12[i] = c->nscr[i];
     return 0;
 }
@@ -2713,6 +2852,7 @@ extern "C" int ig_debug_nuis_screen_stats(ig_ctx* c, double out12[12])
  * (where the exact pass ran), moves walked into the histogram, builds from scratch} since the handle was made */
 extern "C" int ig_debug_nuis_hist_stats(ig_ctx* c, double out12[12])
 {
+    IG_JOIN(c);
     for (int i = 0; i < 12; i++) out12[i] = c->nhs[i];
     return 0;
 }
@@ -2722,6 +2862,7 @@ extern "C" int ig_debug_nuis_hist_stats(ig_ctx* c, double out12[12])
  * (-1: no histogram) */
 extern "C" int ig_debug_nuis_hist_check(ig_ctx* c, int64_t* mismatches)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     *mismatches = -1;
     if (c->nuis_in_flight) return fail("ig_debug_nuis_hist_check: a step is in flight");
@@ -2760,6 +2901,7 @@ extern "C" int ig_debug_nuis_hist_check(ig_ctx* c, int64_t* mismatches)
  * *accepted = 3 (decided from the screened interval, the exact pass behind the decision) */
 extern "C" int ig_nuis_exact_result(ig_ctx* c, double* nz_test)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (c->exact_seq == 0 && !c->nuis_sums_pending) return fail("ig_nuis_exact_result: no step was accepted ahead of its exact pass");
     flush_pending_sums(c);
@@ -2834,6 +2976,7 @@ static void flush_pending_sums(ig_ctx* c)
 
 extern "C" int ig_nuis_accept(ig_ctx* c)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (c->nuis_in_flight) return fail("ig_nuis_accept: end the step first (ig_nuis_end)");
     static const int s_slow = getenv("IG_NUIS_SLOW_ACCEPT") ? atoi(getenv("IG_NUIS_SLOW_ACCEPT")) : 0;
@@ -2884,6 +3027,7 @@ extern "C" int ig_nuis_accept(ig_ctx* c)
 extern "C" int ig_nuis_step_next(ig_ctx* c, double temperature, double u, const float p_next_rejected[8], const float p_next_accepted[8],
                                  float mean_subfrag_kb, int32_t has_next, ig_move_result* out, double* nz_test, double* z_test, int32_t* accepted)
 {
+    IG_JOIN(c);
     if (!c->nuis_spec) return fail("ig_nuis_step_next: no run (ig_nuis_run_begin)");
     double nz = 0.0, z = 0.0;
     const double Tu[2] = {temperature, u};
@@ -2902,7 +3046,7 @@ extern "C" int ig_nuis_step_next(ig_ctx* c, double temperature, double u, const 
     if (acc == 2) return 0;
     if (acc == 1 && ig_nuis_accept(c)) return -1;
     const float* p_next = acc ? p_next_accepted : p_next_rejected;
-    if (has_next && p_next) return ig_nuis_step_begin(c, c->spec_move, p_next, mean_subfrag_kb);
+    if (has_next && p_next) return nuis_defer_step_begin(c, c->spec_move, p_next, mean_subfrag_kb); /* (on the helper thread: see NuisWorker) */
     /* the caller has yet to work out the next test parameters; what is certain is that the moves ahead have to be scored
      * under the parameters just promoted: that needs nothing from the caller, and runs while it computes */
     if (has_next && acc == 1 && c->spec_move < c->up_moves) {
@@ -2924,6 +3068,7 @@ extern "C" int ig_nuis_step_next(ig_ctx* c, double temperature, double u, const 
 
 extern "C" int ig_kernel_time_ms(ig_ctx* c, const char* name, double* avg_ms, int64_t* n)
 {
+    IG_JOIN(c);
     drain_timers(c);
     for (int i = 0; i < T_COUNT; i++)
         if (!strcmp(name, c->timers[i].name)) {
@@ -2936,6 +3081,7 @@ extern "C" int ig_kernel_time_ms(ig_ctx* c, const char* name, double* avg_ms, in
 
 extern "C" int ig_reset_timers(ig_ctx* c, int enable)
 {
+    IG_JOIN(c);
     HIPCK(hipStreamSynchronize(c->stream));
     drain_timers(c);
     for (int i = 0; i < T_COUNT; i++) {
@@ -2956,6 +3102,7 @@ extern "C" int ig_reset_timers(ig_ctx* c, int enable)
 /* time every n-th launch of the selected kernels only (default 1: every launch) */
 extern "C" int ig_set_timer_sampling(ig_ctx* c, int every)
 {
+    IG_JOIN(c);
     c->timing_every = std::max(1, every);
     return 0;
 }
@@ -2965,6 +3112,7 @@ extern "C" int ig_set_timer_sampling(ig_ctx* c, int every)
 extern "C" int ig_debug_eval_terms(ig_ctx* c, const float* s, const float* s_tot, const int32_t* ob, int64_t n, float* ex, float* exc,
                                    double* term, int64_t* q)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (!c->have_params) return fail("ig_debug_eval_terms: set parameters first");
     float *ds, *dst, *dex, *dexc;
@@ -3000,6 +3148,7 @@ extern "C" int ig_debug_eval_terms(ig_ctx* c, const float* s, const float* s_tot
 
 extern "C" int ig_debug_candidate_state(ig_ctx* c, int32_t cand, int32_t slot, int32_t* soa)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     HIPCK(hipStreamSynchronize(c->stream));
     if (cand < 0 || cand >= c->mb.capC || slot < 0 || slot > IG_N_TMP_STRUCT) return fail("ig_debug_candidate_state: bad index");
@@ -3030,6 +3179,7 @@ extern "C" int ig_debug_candidate_state(ig_ctx* c, int32_t cand, int32_t slot, i
 extern "C" int ig_debug_last_sums(ig_ctx* c, int64_t* nz_hi, int64_t* nz_lo, int64_t* z_hi, int64_t* z_lo, int64_t* n_intra,
                                   int64_t* ext_hi, int64_t* ext_lo, int64_t* n_slice, int32_t* n_uniq, int32_t* uniq)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     HIPCK(hipStreamSynchronize(c->stream));
     Glob hg;
@@ -3082,6 +3232,7 @@ extern "C" int ig_debug_last_sums(ig_ctx* c, int64_t* nz_hi, int64_t* nz_lo, int
 
 extern "C" int ig_debug_tables(ig_ctx* c, float* dist, int32_t* id_c, float* s_tot, int32_t* pos, int32_t* len)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     HIPCK(hipStreamSynchronize(c->stream));
     const size_t m = c->M;
@@ -3101,6 +3252,7 @@ extern "C" int ig_debug_tables(ig_ctx* c, float* dist, int32_t* id_c, float* s_t
  * both below SCR_KL = SCR_KE = 4 in these units): out[0], out[1] as k_transcendental_error defines them */
 extern "C" int ig_debug_transcendental_error(ig_ctx* c, double out2[2])
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     double* d;
     DALLOC(d, 2);
@@ -3116,6 +3268,7 @@ extern "C" int ig_debug_transcendental_error(ig_ctx* c, double out2[2])
  * scored exactly} since the state was uploaded */
 extern "C" int ig_debug_screen_stats(ig_ctx* c, double out4[6])
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     HIPCK(hipStreamSynchronize(c->stream));
     out4[0] = out4[1] = 0.0;
@@ -3134,6 +3287,7 @@ extern "C" int ig_debug_screen_stats(ig_ctx* c, double out4[6])
  * out [4 x n]; n_items receives the number of workgroups */
 extern "C" int ig_debug_tile_trace(ig_ctx* c, int64_t* out, int64_t cap, int64_t* n_items)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     *n_items = c->n_tile_work;
     if (!out || cap < c->n_tile_work) return 0;
@@ -3156,6 +3310,7 @@ extern "C" int ig_debug_tile_trace(ig_ctx* c, int64_t* out, int64_t cap, int64_t
  * words */
 extern "C" int ig_debug_diff_trace(ig_ctx* c, const float p_test[8], float mean_subfrag_kb, int64_t* out, int64_t cap, int64_t* n, int64_t* sums8)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (!c->tiled_cc || c->n_tile_work <= 0 || !c->score_const || !c->screen_const || !c->pz_tab) return fail("ig_debug_diff_trace: no tiled contacts / parameters");
     const int grid = std::min(c->n_tile_work, 512);
@@ -3191,6 +3346,7 @@ extern "C" int ig_debug_diff_trace(ig_ctx* c, const float p_test[8], float mean_
 /* seconds ig_nuis_end (also inside ig_nuis_step_next) has spent waiting for the device since the handle was created */
 extern "C" int ig_debug_nuis_wait(ig_ctx* c, double* seconds)
 {
+    IG_JOIN(c);
     *seconds = c->nuis_wait_s;
     return 0;
 }
@@ -3211,6 +3367,7 @@ extern "C" int ig_debug_set_tail_quirk(int on)
 /* maintained exact sums {nz_hi, nz_lo, z_hi, z_lo, n_intra} and {n_contigs, next_cid, ch_c, ch_k, ch_slot, ch_windowed} */
 extern "C" int ig_debug_globals(ig_ctx* c, int64_t* sums5, int32_t* ints6)
 {
+    IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     flush_pending_sums(c);
     HIPCK(hipStreamSynchronize(c->stream));

@@ -88,11 +88,43 @@ def _solve(p, val_inter, s0):
         return np.abs(val_inter - A * (c0 * np.power(u, slope) * np.exp(c1 / (np.power(u, 2) + dd))))
 
     x0 = np.asarray(s0).flatten()
+    # fsolve's shape check evaluates the residual once on the caller's (possibly float32) s0 and takes the forward-difference step
+    # from the dtype of what comes back: a function of the dtypes of the arguments alone -- looked up, evaluated the first time
+    key = tuple(type(v) for v in p) + (type(val_inter), x0.dtype)
+    if _quiet:  # (the caller holds np.errstate(all="ignore") around a run of calls: nothing here can warn)
+        eps = _eps_for.get(key)
+        if eps is None:
+            res = np.atleast_1d(residual(x0[:1]))
+            eps = _eps_for[key] = np.finfo(res.dtype if np.issubdtype(res.dtype, np.inexact) else np.dtype(float)).eps
+        return _hybrd(residual, x0, (), 1, 1.49012e-08, 200 * (x0.size + 1), -10, -10, eps, 100, None)[0][0]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)
-        res = np.atleast_1d(residual(x0[:1]))  # fsolve's shape check: one evaluation on the caller's (possibly float32) s0
+        res = np.atleast_1d(residual(x0[:1]))
         dt = res.dtype if np.issubdtype(res.dtype, np.inexact) else np.dtype(float)
         return _hybrd(residual, x0, (), 1, 1.49012e-08, 200 * (x0.size + 1), -10, -10, np.finfo(dt).eps, 100, None)[0][0]
+
+
+_quiet = False
+_eps_for = {}
+
+
+class quiet_runs:
+    """``with quiet_runs():`` around a run of ``estimate_max_dist_intra_nuis`` calls (the nuisance loop: one root per step on the
+    host's critical path): floating-point warnings off once for the whole run instead of a ``warnings.catch_warnings`` per call,
+    and the dtype probe of the residual looked up instead of evaluated.  Same MINPACK call, same arguments, same bits."""
+
+    def __enter__(self):
+        global _quiet
+        self._err = np.errstate(all="ignore")
+        self._err.__enter__()
+        self._was = _quiet
+        _quiet = True
+        return self
+
+    def __exit__(self, *a):
+        global _quiet
+        _quiet = self._was
+        return self._err.__exit__(*a)
 
 
 def estimate_max_dist_intra(p, val_inter):

@@ -448,14 +448,24 @@ class sampler:  # noqa: N801 - the reference's class name
                     res[k][i] = getattr(self.last_result, k)
                 tuples.append(self.step_nuisance_parameters(dt, t0 + i, n_step))
             return res, tuples
+        with opti.quiet_runs():
+            return self._nuisance_run(frags, n_neighbours, t0, n_step, res)
+
+    def _nuisance_run(self, frags, n_neighbours, t0, n_step, res):
+        n = frags.size
         cands, id_modif, gauss, unif = self.neighbours.draw_nuisance(frags, max(1, n_neighbours))
         tuples = []
         mean_kb = self.mean_kb()
 
+        gauss_l, id_modif_l, unif_l = gauss.tolist(), id_modif.tolist(), unif.tolist()
+        sig_for = [None]
+
         def proposal(i, params):
-            self._sigmas(params)
-            g = float(gauss[i])
-            return self._propose(params, int(id_modif[i]), lambda sigma: 0.0 + float(sigma) * g)
+            if sig_for[0] is not params:  # (the sigmas depend on the current parameters only: once per accepted step)
+                self._sigmas(params)
+                sig_for[0] = params
+            g = gauss_l[i]
+            return self._propose(params, id_modif_l[i], lambda sigma: 0.0 + float(sigma) * g)
 
         import time as _t
 
@@ -468,6 +478,8 @@ class sampler:  # noqa: N801 - the reference's class name
         self.ctx.nuis_run_begin(frags, cands)
         self.ctx.nuis_step_begin(0, p8(out), mean_kb)
         patch = None  # (step, z): a step accepted ahead of its exact pass, its likelihood still to be filled in
+        res_rows = []
+
         def fill_in():
             j, zj = patch
             lik = np.array([self.ctx.nuis_exact_result()]) + zj
@@ -487,7 +499,7 @@ class sampler:  # noqa: N801 - the reference's class name
             nxt_acc = None
             t1 = _t.perf_counter()
             # end of step i, the acceptance test, the promotion and (rejected) the first launches of step i + 1 in one call
-            r, nz, z, success = self.ctx.nuis_step_next(self.temperature(t0 + i, n_step), unif[i], p8(nxt_rej), None, mean_kb, has_next)
+            r, nz, z, success = self.ctx.nuis_step_next(self.temperature(t0 + i, n_step), unif_l[i], p8(nxt_rej), None, mean_kb, has_next)
             t2 = _t.perf_counter()
             deferred = success == 3  # accepted from the screened interval: nz is its midpoint until the exact pass is through
             if deferred:
@@ -501,15 +513,14 @@ class sampler:  # noqa: N801 - the reference's class name
             if success == 2:  # exp() within 1e-9 of u: the reference's own arithmetic decides
                 with np.errstate(over="ignore"):
                     ratio = np.exp((self.likelihood_nuis - self.likelihood_t) / self.temperature(t0 + i, n_step))
-                success = 1 if ratio >= unif[i] else 0
+                success = 1 if ratio >= unif_l[i] else 0
                 if success:
                     self.ctx.nuis_accept()
                 if has_next:
                     if success:
                         nxt_acc = proposal(i + 1, out)
                     self.ctx.nuis_step_begin(i + 1, p8(nxt_acc if success else nxt_rej), mean_kb)
-            for k in names:
-                res[k][i] = getattr(r, k)
+            res_rows.append(r)
             if success:
                 self.param_simu = out
                 self.likelihood_t = self.likelihood_nuis
@@ -528,6 +539,8 @@ class sampler:  # noqa: N801 - the reference's class name
                 trace.append((t3 - ta, int(success)))
         if patch is not None:
             fill_in()
+        for k in names:  # (the records: one column at a time, outside the loop)
+            res[k] = [getattr(r, k) for r in res_rows]
         last = res[-1]
         self.o = float(last["o"])
         self.n_contigs = np.int32(last["n_contigs"])
