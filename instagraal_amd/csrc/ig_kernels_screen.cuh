@@ -44,6 +44,10 @@ struct alignas(16) ScreenConst {
     float zc_ub;   /* upper bound of P_z log10(e) for a pair on a circular contig (< 0: none, the bound of such a column is void) */
     int fast;      /* parameters in the one-log domain */
     int pz_n;      /* length of the P_z table the exact path uses */
+    const float* pz_full; /* that table (rank distances from LDS_PZ on are read from it: windows beyond the staged size only) */
+    ig_params par;        /* ... and what the exact path evaluates behind its end (pz_lookup) */
+    float mean_kb;
+    int pz_far_ok; /* P_z decreases with the rank distance (slope < 0): pzc_max bounds the entries behind the LDS copy as well */
 };
 
 __device__ __forceinline__ void build_screen_const_block(const Glob* g, PzTab pz, ScreenConst* out, int which)
@@ -61,6 +65,10 @@ __device__ __forceinline__ void build_screen_const_block(const Glob* g, PzTab pz
         out->cy = (float)((__builtin_fabs(h.log2_amp) + __builtin_fabs(h.slope) + __builtin_fabs(h.log2_v_inter)) * 1.0001 + 1e-6);
         out->fast = h.fast;
         out->pz_n = pz.n;
+        out->pz_full = pz.v;
+        out->par = p;
+        out->mean_kb = g->mean_kb;
+        out->pz_far_ok = (h.fast && p.slope < 0.0f) ? 1 : 0;
         /* Pairs on a CIRCULAR contig (a ring made by a candidate: KA:3588-3649) are evaluated with rippe_contacts_circ, which
          * clamps BELOW with d_max (quirk Q6): P >= d_max, hundreds of contacts expected per pair -- such a column loses by
          * orders of magnitude and only needs an UPPER bound to be ruled out:
@@ -109,7 +117,7 @@ struct alignas(16) ScreenLds {
 template <bool STAGED, bool HAS_CUT, bool MASKED, bool CIRC = false, bool QUAD = false>
 __device__ __forceinline__ void screen_term(unsigned long long pk, bool live, const uint2* gcol, const ScreenLds& L, float slope, float la,
                                             float lv, float d_max, float c10, unsigned cut, double& acc, float& exs, float& obs, float& ymax,
-                                            unsigned& bad, unsigned circ_mask = 0, float zc_ub = 0.0f)
+                                            unsigned& bad, unsigned circ_mask = 0, float zc_ub = 0.0f, const ScreenConst* __restrict__ far_sc = nullptr)
 {
     const unsigned lo = (unsigned)pk, hi = (unsigned)(pk >> 32);
     bad |= MASKED ? (live ? hi : 0u) : hi; /* bits 8.. = the count: the largest count's leading bit survives the OR (checked at the end) */
@@ -123,7 +131,13 @@ __device__ __forceinline__ void screen_term(unsigned long long pk, bool live, co
     const unsigned d = QUAD ? dq >> 2 : dq; /* QUAD: the staged column holds 4 x rank (screen_pair); across contigs d stays >= LDS_PZ */
     const float sv = fabsf(__uint_as_float(ai.x) - __uint_as_float(bj.x));
     const bool in = cis && (sv > 0.0f) && (sv < d_max);
-    const float pzc = L.pzc[min(d, (unsigned)LDS_PZ)];
+    float pzc = L.pzc[min(d, (unsigned)LDS_PZ)];
+    if (HAS_CUT) { /* a P_z table longer than its LDS copy and a window longer than that copy: the far pairs' entries from the table
+                    * itself (same conversion as the copy's; pz_full == nullptr: no bound for them, the column is scored exactly) */
+        const bool far = cis && d >= cut && (!MASKED || live);
+        if (far && far_sc) pzc = (float)((double)pz_lookup(PzTab{far_sc->pz_full, far_sc->pz_n}, far_sc->par, far_sc->mean_kb, (int)d) * IG_LOG_E_F);
+        bad |= (far && !far_sc) ? 0x80000000u : 0u; /* counts are below 2^24: bit 31 is free */
+    }
     const float lg2 = __builtin_amdgcn_logf(sv);
     const float y = __builtin_fmaf(slope, lg2, la);
     float ymx;
@@ -154,7 +168,6 @@ __device__ __forceinline__ void screen_term(unsigned long long pk, bool live, co
     exs += exa;
     obs += oba;
     __asm__("v_max_f32 %0, %0, |%1|" : "+v"(ymax) : "v"(yya));
-    if (HAS_CUT) bad |= (cis && d >= cut && (!MASKED || live)) ? 0x80000000u : 0u; /* counts are below 2^24: bit 31 is free */
 }
 
 /* two screened terms at once, for the common case (column staged in LDS, no ring on the window, P_z table inside its LDS
@@ -204,7 +217,8 @@ __device__ __forceinline__ void screen_pair(unsigned long long pk0, unsigned lon
 template <bool STAGED, bool HAS_CUT, bool CIRC = false, bool PAIRS = false, bool QUAD = PAIRS>
 __device__ __forceinline__ void screen_loop(const unsigned long long* __restrict__ slp, unsigned n, const uint2* gcol, const ScreenLds& L,
                                             float slope, float la_s, float lv_s, float d_max, unsigned cut, double& acc, float& exs, float& obs,
-                                            float& ymax, unsigned& bad, unsigned circ_mask = 0, float zc_ub = 0.0f)
+                                            float& ymax, unsigned& bad, unsigned circ_mask = 0, float zc_ub = 0.0f,
+                                            const ScreenConst* __restrict__ far_sc = nullptr)
 {
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned step = 64 * SCREEN_BATCH, stride = step * (SCORE_THREADS / 64);
@@ -232,7 +246,7 @@ __device__ __forceinline__ void screen_loop(const unsigned long long* __restrict
 #pragma unroll
             for (int u = 0; u < SCREEN_BATCH; u++)
                 screen_term<STAGED, HAS_CUT, false, CIRC, QUAD>(pk[u], true, gcol, L, slope, la, lv, d_max, c10, cut, acc, exs, obs, ymax, bad, circ_mask,
-                                                                  zc_ub);
+                                                                  zc_ub, far_sc);
         }
     }
     if (PAIRS) {
@@ -245,7 +259,7 @@ __device__ __forceinline__ void screen_loop(const unsigned long long* __restrict
         for (int u = 0; u < SCREEN_BATCH; u++) {
             const bool live = s0 + u * 64 + lane < n;
             screen_term<STAGED, HAS_CUT, true, CIRC, QUAD>(live ? nx[u] : safe, live, gcol, L, slope, la, lv, d_max, c10, cut, acc, exs, obs, ymax, bad,
-                                                            circ_mask, zc_ub);
+                                                            circ_mask, zc_ub, far_sc);
         }
     }
 }
@@ -277,7 +291,10 @@ __device__ __forceinline__ void screen_column(ScreenLds& L, const ScreenConst* _
     /* the common case -- staged column, P_z table inside its LDS copy -- takes the two-terms-at-a-time loop (screen_pair),
      * which wants the ranks of the staged column pre-multiplied by 4 (ranks are below 2^20 in packed lists: no overlap with
      * the contig code in bits 28..30) */
-    const bool pairs = staged && pz_n <= LDS_PZ;
+    /* (a staged window holds at most LDS_COL_SMALL = LDS_PZ sub-fragments: every rank distance inside it is in the LDS copy,
+     * however long the table) */
+    static_assert(LDS_COL_SMALL <= LDS_PZ, "a staged window's rank distances must lie inside the staged P_z table");
+    const bool pairs = staged;
     if (staged)
         for (int i = threadIdx.x; i < m_loc; i += SCORE_THREADS) {
             uint2 v = gcol[i];
@@ -301,19 +318,17 @@ __device__ __forceinline__ void screen_column(ScreenLds& L, const ScreenConst* _
     float exs = 0.0f, ymax = 0.0f, obs = 0.0f;
     unsigned bad = 0;
     const unsigned cut = pz_n > LDS_PZ ? (unsigned)LDS_PZ : 0xffffffffu;
+    const ScreenConst* far_sc = sc->pz_far_ok ? sc : nullptr;
     const unsigned long long* slp = mb.sl_pk + off;
     if (circ_mask) {
-        if (pairs) screen_loop<true, true, true, false, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad, circ_mask, zc_ub);
-        else if (staged) screen_loop<true, true, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad, circ_mask, zc_ub);
-        else screen_loop<false, true, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad, circ_mask, zc_ub);
+        if (pairs) screen_loop<true, false, true, false, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad, circ_mask, zc_ub);
+        else screen_loop<false, true, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad, circ_mask, zc_ub, far_sc);
     } else if (pairs) {
         screen_loop<true, false, false, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
-    } else if (pz_n > LDS_PZ) { /* a P_z table longer than its LDS copy: pairs beyond the copy void the column's bound */
-        if (staged) screen_loop<true, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
-        else screen_loop<false, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
+    } else if (pz_n > LDS_PZ) { /* a P_z table longer than its LDS copy, a window longer than that copy: far pairs from the table itself */
+        screen_loop<false, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad, 0, 0.0f, far_sc);
     } else {
-        if (staged) screen_loop<true, false>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
-        else screen_loop<false, false>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
+        screen_loop<false, false>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
     }
     for (int o = 32; o > 0; o >>= 1) {
         acc += __shfl_down(acc, o, 64);
@@ -433,8 +448,7 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
     /* which of the two columns there is anything to do for (a column whose genome is the current one has column 0's sums) */
     const bool doA = kA == 0 || mb.sinfo[cw * NSLOT + mb.meta[cw].uniq[kA - 1]].x != 0;
     const bool doB = kB <= n_uniq && mb.sinfo[cw * NSLOT + mb.meta[cw].uniq[kB - 1]].x != 0;
-    const int pz_n = sc->pz_n;
-    bool plain = doA && doB && sc->fast && m_loc <= LDS_COL_SMALL && pz_n <= LDS_PZ;
+    bool plain = doA && doB && sc->fast && m_loc <= LDS_COL_SMALL; /* (staged: every rank distance is inside the LDS copy of the table) */
     if (plain) { /* no ring on either window */
         const ColMeta* cmA = mb.cmeta + (size_t)(cw * NSLOT + kA) * NCODE;
         const ColMeta* cmB = mb.cmeta + (size_t)(cw * NSLOT + kB) * NCODE;

@@ -93,6 +93,27 @@ def test_screening_with_large_counts_and_other_parameters(monkeypatch):
         assert stats[0] < 0.5
 
 
+@pytest.mark.parametrize("cfg,n_moves", [("small", 400), ("bigctg", 160)])
+def test_screening_with_a_table_longer_than_its_staged_copy(cfg, n_moves, monkeypatch):
+    """a far d_max (what a nuisance chain drifts to): the P_z table is longer than the 1 024 entries the screening kernel stages.
+    Staged windows hold no rank distance beyond the copy (the two-columns-per-pass loop serves them as before); unstaged ones
+    (bigctg: windows of thousands of sub-fragments) read their far pairs' entries from the table itself -- neither voids a
+    column's bound any more: the exact kernel keeps to the contenders"""
+    from instagraal_amd import synth
+
+    prob = synth.make_problem(*synth.CONFIGS[cfg])
+    prob.params = dict(prob.params, slope=-0.6, d_max=2.5e6)
+    np.random.seed(12)
+    frags = np.resize(np.random.permutation(prob.n_frags), n_moves).astype(np.int32)
+    exact, _, _ = _run(prob, frags, 4, {"IG_SCREEN": "0"}, monkeypatch)
+    verified, stats, _ = _run(prob, frags, 4, {"IG_SCREEN_VERIFY": "1"}, monkeypatch)
+    screened, stats2, _ = _run(prob, frags, 4, {}, monkeypatch)
+    assert verified == exact and screened == exact
+    print(cfg, "long table: used fraction %.3g, largest bound %.3g, columns screened %d, scored exactly %d, terms %d / %d" % stats2)
+    assert 0 < stats[0] < 0.5
+    assert stats2[3] < 0.3 * stats2[2]  # (void bounds would send every column through the exact kernel)
+
+
 def test_screening_at_the_headline_shape(monkeypatch):
     from instagraal_amd import synth
 

@@ -50,10 +50,18 @@ if os.environ.get("NUIS_LONG"):  # the rate as the chain settles: chunks of 600 
         print("            per step: rejected n=%d median %.0f us, p25 %.0f, p75 %.0f, p95 %.0f, mean %.0f; accepted n=%d median %.0f us mean %.0f" % (
             len(rej), np.median(rej), np.percentile(rej, 25), np.percentile(rej, 75), np.percentile(rej, 95), rej.mean(), len(acc),
             np.median(acc) if len(acc) else 0, acc.mean() if len(acc) else 0))
+        edges = [0, 80, 120, 200, 300, 450, 700, 1e9]
+        hh = np.histogram(tr[:, 0] * 1e6, edges)[0]
+        tot = [float((tr[(tr[:, 0] * 1e6 >= a) & (tr[:, 0] * 1e6 < b), 0] * 1e6).sum()) / 600 for a, b in zip(edges[:-1], edges[1:])]
+        print("            steps by duration (us) " + ", ".join("<%g: %d (%.0f us/step)" % (b, n_, t_) for b, n_, t_ in zip(edges[1:], hh, tot)))
         print("   chunk %d: %.0f moves/s, accept %.2f, device wait %.0f us/move, host %s, %s" % (
             k, 600 / dt, np.mean([q[6] for q in tup]), 1e6 * (s.ctx.debug_nuis_wait() - w0) / 600,
             ", ".join("%s %.0f" % (a, 1e6 * v / 600) for a, v in s.nuis_profile.items()), s.ctx.debug_nuis_screen_stats()), flush=True)
         print("            histogram tier:", s.ctx.debug_nuis_hist_stats(), flush=True)
+        print("            parameters now:", {k: float(s.param_simu[k][0]) for k in s.param_simu.dtype.names}, flush=True)
+        ss = s.ctx.debug_screen_stats()
+        print("            two-tier scoring so far: columns screened %d, scored exactly %d (%.1f %%); terms %.3g / %.3g (%.1f %%)" % (
+            ss[2], ss[3], 100.0 * ss[3] / max(ss[2], 1), ss[4], ss[5], 100.0 * ss[5] / max(ss[4], 1)), flush=True)
 if os.environ.get("NUIS_ONLY"):
     sys.exit(0)
 t_s = t_n = 0.0

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Timeline figures of a rocprofv3 kernel trace (rocpd sqlite): span, time with at least one kernel running, idle gaps, and
-a text dump of the launches of a few steps around the middle.   python tools/rocprof_timeline.py run.db [n_dump]"""
+a text dump of the launches of a few steps around the middle (or behind the given fraction of the trace, from the first launch
+of a named kernel there).   python tools/rocprof_timeline.py run.db [n_dump [fraction [kernel]]]"""
 import sqlite3
 import sys
 
 
-def main(db_path, n_dump=60):
+def main(db_path, n_dump=60, frac=0.5, anchor=None):
     db = sqlite3.connect(db_path)
     cur = db.cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
@@ -30,7 +31,12 @@ def main(db_path, n_dump=60):
     if gaps:
         print("idle gaps: n=%d total %.1f ms, median %.1f us, p90 %.1f us, max %.1f us" % (
             len(gaps), sum(gaps) / 1e6, gaps[len(gaps) // 2] / 1e3, gaps[int(len(gaps) * 0.9)] / 1e3, gaps[-1] / 1e3))
-    mid = len(rows) // 2
+    mid = int(len(rows) * frac)
+    if anchor:  # the dump starts a few launches in front of the first launch of that kernel behind the given place
+        for i in range(mid, len(rows)):
+            if anchor in rows[i][2]:
+                mid = max(i - 8, 0)
+                break
     base = rows[mid][0]
     for s, e, n, q in rows[mid:mid + n_dump]:
         short = n.split("(")[0]
@@ -39,4 +45,5 @@ def main(db_path, n_dump=60):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 60)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 60, float(sys.argv[3]) if len(sys.argv) > 3 else 0.5,
+         sys.argv[4] if len(sys.argv) > 4 else None)
