@@ -284,6 +284,9 @@ def main():
             st = getattr(s.ctx, "debug_nuis_screen_stats", None)
             if st is not None:
                 nuis["screened_pass"] = st()
+            st = getattr(s.ctx, "debug_nuis_hist_stats", None)
+            if st is not None:  # its first tier: the Metropolis test from a histogram of the cis contacts' distances
+                nuis["screened_pass"]["histogram_tier"] = st()
         except Exception as e:  # a diagnostic next to the headline, never instead of it
             nuis = {"moves_per_s": None, "error": repr(e)}
 
