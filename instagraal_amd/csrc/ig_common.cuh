@@ -292,6 +292,29 @@ struct ig_ctx {
     /* tier 0 of the screened pass: the histogram of the cis contacts' distances (NuisHist), valid for the state before the last
      * move of a run once nh_pending_slot's move has been walked (nh_flush_pending) */
     struct NuisWorker* worker; /* the helper thread that enqueues a run's next step (ig_hip.hip) */
+    /* the NEXT batch of a run of (move, nuisance step) pairs, scored in the background (nuis_bg_launch) while the steps of the
+     * current one go on: a second set of batch buffers, a snapshot of the state it is scored against (5 MB at the headline
+     * shape), its own low-priority stream.  bg_valid: moves [bg_base, bg_base + bg_W) are in mb2, the parameter half of the
+     * first bg_r of them under the parameters as of accepted step number bg_accepts. */
+    MoveBuf mb2;
+    hipStream_t stream_bg;
+    hipEvent_t ev_snap, ev_bg_done;
+    int* st2_block;
+    State st2;
+    Tables tab2;
+    Glob* glob2;
+    unsigned* touched_bits2;
+    int touched_flip2;
+    int* bg_mark; /* device: entries of dirty_buf at the snapshot (the contigs modified after it are behind them) */
+    int bg_N, bg_M;
+    bool spec_changed; /* a move decided from the batch in the buffers has changed the genome */
+    bool bg_stale;     /* ... since the snapshot of the background batch */
+    bool bg_valid, spec_adopted; /* spec_adopted: the batch in the buffers came from the background (its slots may be stale from slot 0 on) */
+    int bg_base, bg_W, bg_r;
+    long long n_accepts, bg_accepts;
+    int bg_own_begin, bg_own_end, bg_own_screened;
+    bool bg_tail_fused;
+    long long n_bg_launched, n_bg_adopted;
     NuisHist nh;
     long long* scratch_hist; /* k_hist_eval's 8 output words (zero between two launches) */
     bool nh_valid;

@@ -301,6 +301,19 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     HIPCK(hipEventCreateWithFlags(&c->ev_exact, hipEventDisableTiming));
     HIPCK(hipEventCreateWithFlags(&c->ev_walk, hipEventDisableTiming));
     c->worker = nullptr;
+    memset((void*)&c->mb2, 0, sizeof c->mb2);
+    c->stream_bg = nullptr;
+    c->st2_block = nullptr;
+    memset((void*)&c->st2, 0, sizeof c->st2);
+    c->tab2 = Tables{nullptr, nullptr, nullptr, nullptr};
+    c->glob2 = nullptr;
+    c->touched_bits2 = nullptr;
+    c->touched_flip2 = 0;
+    c->bg_mark = nullptr;
+    c->bg_N = c->bg_M = 0;
+    c->bg_valid = c->spec_adopted = false;
+    c->n_accepts = c->bg_accepts = 0;
+    c->n_bg_launched = c->n_bg_adopted = 0;
     c->nh = NuisHist{nullptr, nullptr, nullptr};
     c->scratch_hist = nullptr;
     c->nh_valid = false;
@@ -342,9 +355,8 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
 }
 
 /* the per-window arrays of the move buffers (strides sN / sM) */
-static void free_window_buffers(ig_ctx* c)
+static void free_window_buffers(MoveBuf& m)
 {
-    MoveBuf& m = c->mb;
     hipFree(m.Lloc);
     hipFree(m.lbloc);
     hipFree(m.slloc);
@@ -359,9 +371,8 @@ static void free_window_buffers(ig_ctx* c)
     m.loc = nullptr;
     m.sN = m.sM = 0;
 }
-static void free_slice_pool(ig_ctx* c)
+static void free_slice_pool(MoveBuf& m)
 {
-    MoveBuf& m = c->mb;
     hipFree(m.sl_li);
     hipFree(m.sl_lj);
     hipFree(m.sl_ob);
@@ -370,11 +381,12 @@ static void free_slice_pool(ig_ctx* c)
     m.sl_pk = nullptr;
     m.pool_cap = 0;
 }
-static void free_move_buffers(ig_ctx* c)
+/* one set of batch buffers (the handle has two: the second one holds the batch a run of (move, nuisance step) pairs scores in the
+ * background, nuis_bg_launch) */
+static void free_movebuf(MoveBuf& m)
 {
-    MoveBuf& m = c->mb;
-    free_window_buffers(c);
-    free_slice_pool(c);
+    free_window_buffers(m);
+    free_slice_pool(m);
     hipFree(m.meta);
     hipFree(m.cmeta);
     hipFree(m.part);
@@ -394,13 +406,19 @@ static void free_move_buffers(ig_ctx* c)
     hipFree(m.slot_items);
     hipFree(m.tail_n);
     hipFree(m.tail_ent);
+    memset((void*)&m, 0, sizeof m);
+}
+static void free_move_buffers(ig_ctx* c)
+{
+    free_movebuf(c->mb);
+    free_movebuf(c->mb2);
+    c->bg_valid = false;
     hipFree(c->own_tag);
     hipFree(c->own_idx);
     c->own_tag = c->own_idx = nullptr;
     hipFree(c->batch_out);
     hipFree(c->dirty_buf);
     c->dirty_buf = nullptr;
-    memset((void*)&m, 0, sizeof m);
     c->batch_out = nullptr;
 }
 
@@ -418,6 +436,17 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipEventDestroy(c->ev_main);
     hipEventDestroy(c->ev_exact);
     hipEventDestroy(c->ev_walk);
+    if (c->stream_bg) {
+        hipStreamSynchronize(c->stream_bg);
+        hipStreamDestroy(c->stream_bg);
+        hipEventDestroy(c->ev_snap);
+        hipEventDestroy(c->ev_bg_done);
+    }
+    hipFree(c->st2_block);
+    hipFree(c->tab2.dist);
+    hipFree(c->glob2);
+    hipFree(c->touched_bits2);
+    hipFree(c->bg_mark);
     hipFree(c->nh.bins);
     hipFree(c->nh.dh);
     hipFree(c->nh.misc);
@@ -572,9 +601,8 @@ static bool launch_full_nz(ig_ctx* c, const Tables& t, int which, long long* out
  * bin plus the contig of a candidate, so twice the longest contig (Glob.max_L / max_SL: exact after a recount, raised by
  * every committed move that changed the genome by its window's total -- a batch can at most double it) with headroom,
  * not the whole genome: 12 MB instead of 0.84 GB per slot at the headline shape.  Grown when the bound grows. */
-static int ensure_window_buffers(ig_ctx* c)
+static int ensure_window_buffers(ig_ctx* c, MoveBuf& m)
 {
-    MoveBuf& m = c->mb;
     if (!m.capC || !m.capW) return 0;
     const int need_n = std::min(c->N, std::max(2 * c->max_L, 1)), need_m = std::min(c->M, std::max(2 * c->max_SL, 1));
     static const int s_env_full = getenv("IG_FULL_WINDOWS") ? atoi(getenv("IG_FULL_WINDOWS")) : 0; /* strides = the whole genome */
@@ -583,7 +611,8 @@ static int ensure_window_buffers(ig_ctx* c)
     const int sN = s_full ? c->N : std::min(c->N, std::max(256, need_n + need_n / 2));
     const int sM = s_full ? c->M : std::min(c->M, std::max(768, need_m + need_m / 2));
     HIPCK(hipStreamSynchronize(c->stream));
-    free_window_buffers(c);
+    if (c->stream_bg) HIPCK(hipStreamSynchronize(c->stream_bg));
+    free_window_buffers(m);
     const size_t C = (size_t)m.capC * m.capW;
     DALLOC(m.Lloc, C * sN);
     DALLOC(m.lbloc, C * sN);
@@ -597,14 +626,14 @@ static int ensure_window_buffers(ig_ctx* c)
     m.sM = sM;
     return 0;
 }
+static int ensure_window_buffers(ig_ctx* c) { return ensure_window_buffers(c, c->mb); }
 
 /* the slice pool: room for the lists of a batch.  A slot whose lists do not fit behind the earlier ones is re-run; when
  * the FIRST slot of a batch does not fit, the host grows the pool (grow_slice_pool) and repeats the batch.  The worst case
  * of one slot is capC x Z entries (windows = the whole genome); it starts at 2 Z. */
-static int alloc_slice_pool(ig_ctx* c, size_t entries)
+static int alloc_slice_pool(MoveBuf& m, size_t entries)
 {
-    MoveBuf& m = c->mb;
-    free_slice_pool(c);
+    free_slice_pool(m);
     if (m.packed) {
         DALLOC(m.sl_pk, entries + 8192); /* slack: k_screen's look-ahead loads run past the end of the last list */
     } else {
@@ -615,6 +644,7 @@ static int alloc_slice_pool(ig_ctx* c, size_t entries)
     m.pool_cap = (long long)entries;
     return 0;
 }
+static int alloc_slice_pool(ig_ctx* c, size_t entries) { return alloc_slice_pool(c->mb, entries); }
 static size_t slice_pool_max(const ig_ctx* c) { return (size_t)std::max<long long>(c->Z, 1) * (size_t)std::max(c->mb.capC, 1); }
 static int grow_slice_pool(ig_ctx* c)
 {
@@ -624,6 +654,7 @@ static int grow_slice_pool(ig_ctx* c)
     return alloc_slice_pool(c, std::min(mx, (size_t)c->mb.pool_cap * 4));
 }
 
+static int alloc_movebuf(ig_ctx* c, MoveBuf& m, int capC, int capW, int want_packed, size_t pool_entries);
 static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
 {
     const int want_packed = (!(getenv("IG_WIDE_LISTS") && atoi(getenv("IG_WIDE_LISTS"))) && c->M < (1 << 20) && c->max_count < (1 << 24)) ? 1 : 0;
@@ -633,20 +664,47 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
     capC = std::max(capC, c->mb.capC);
     capW = std::max(capW, c->mb.capW);
     HIPCK(hipStreamSynchronize(c->stream));
+    if (c->stream_bg) HIPCK(hipStreamSynchronize(c->stream_bg));
     free_move_buffers(c);
-    MoveBuf& m = c->mb;
-    const size_t N = c->N, C = (size_t)capC * capW;
+    const size_t N = c->N;
+    c->mb.capC = capC; /* (slice_pool_max reads it) */
+    size_t Zc = std::min(slice_pool_max(c), std::max<size_t>((size_t)1 << 22, 2 * (size_t)std::max<long long>(c->Z, 1))); /* 32 MB, or 2 Z */
+    if (const char* e = getenv("IG_POOL_ENTRIES")) /* tests: a small pool forces the overflow / re-run / growth paths */
+        Zc = std::max<size_t>((size_t)atoll(e), 1024);
+    if (alloc_movebuf(c, c->mb, capC, capW, want_packed, Zc)) return -1;
+    DALLOC(c->own_tag, N);
+    DALLOC(c->own_idx, N);
+    HIPCK(hipMemset(c->own_tag, 0xff, N * sizeof(int)));
+    DALLOC(c->batch_out, 12);
+    if (!c->host_bo && !(getenv("IG_NO_HOST_FLAG") && atoi(getenv("IG_NO_HOST_FLAG")))) {
+        /* the batch outcome is also written to mapped host memory (commit_loop polls it); without it: copy + synchronise */
+        int* hp = nullptr;
+        if (hipHostMalloc((void**)&hp, 12 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+                memset(hp, 0, 12 * sizeof(int));
+                c->host_bo = hp;
+                c->host_bo_dev = (int*)dp;
+            } else {
+                hipHostFree(hp);
+            }
+        }
+        (void)hipGetLastError();
+    }
+    DALLOC(c->dirty_buf, 2 * IG_MAX_BATCH + 4);
+    return ensure_window_buffers(c);
+}
+
+/* the arrays of one set of batch buffers but the per-window ones (ensure_window_buffers) */
+static int alloc_movebuf(ig_ctx* c, MoveBuf& m, int capC, int capW, int want_packed, size_t pool_entries)
+{
+    const size_t C = (size_t)capC * capW;
     m.N = c->N;
     m.M = c->M;
     m.capC = capC;
     m.capW = capW;
     m.packed = want_packed; /* IG_WIDE_LISTS=1 (tests) forces the 12-byte form */
-    {
-        size_t Zc = std::min(slice_pool_max(c), std::max<size_t>((size_t)1 << 22, 2 * (size_t)std::max<long long>(c->Z, 1))); /* 32 MB, or 2 Z */
-        if (const char* e = getenv("IG_POOL_ENTRIES")) /* tests: a small pool forces the overflow / re-run / growth paths */
-            Zc = std::max<size_t>((size_t)atoll(e), 1024);
-        if (alloc_slice_pool(c, Zc)) return -1;
-    }
+    if (alloc_slice_pool(m, pool_entries)) return -1;
     DALLOC(m.slbound, C * SLICE_SEG);
     DALLOC(m.sloff, C * SLICE_SEG);
     DALLOC(m.meta, C);
@@ -671,30 +729,10 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
     DALLOC(m.tail_ent, C * 3 * 64);
     HIPCK(hipMemset(m.tail_n, 0xff, C * sizeof(int)));
     HIPCK(hipMemset(m.cont, 0xff, C * sizeof(unsigned)));
-    DALLOC(c->own_tag, N);
-    DALLOC(c->own_idx, N);
-    HIPCK(hipMemset(c->own_tag, 0xff, N * sizeof(int)));
-    DALLOC(c->batch_out, 12);
-    if (!c->host_bo && !(getenv("IG_NO_HOST_FLAG") && atoi(getenv("IG_NO_HOST_FLAG")))) {
-        /* the batch outcome is also written to mapped host memory (commit_loop polls it); without it: copy + synchronise */
-        int* hp = nullptr;
-        if (hipHostMalloc((void**)&hp, 12 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
-            void* dp = nullptr;
-            if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
-                memset(hp, 0, 12 * sizeof(int));
-                c->host_bo = hp;
-                c->host_bo_dev = (int*)dp;
-            } else {
-                hipHostFree(hp);
-            }
-        }
-        (void)hipGetLastError();
-    }
-    DALLOC(c->dirty_buf, 2 * IG_MAX_BATCH + 4);
     HIPCK(hipMemset(m.cmeta, 0, C * NSLOT * NCODE * sizeof(ColMeta)));
     HIPCK(hipMemset(m.slbound, 0, C * SLICE_SEG * sizeof(long long)));
     HIPCK(hipMemset(m.ctl, 0, (size_t)capW * sizeof(MoveCtl)));
-    return ensure_window_buffers(c);
+    return 0;
 }
 
 extern "C" int ig_upload_contacts(ig_ctx* c, const int32_t* row, const int32_t* col, const int32_t* cnt, int64_t Z, int32_t M,
@@ -1360,7 +1398,7 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
         ig_ctx* c;
         StaleGuard(ig_ctx* ctx, bool on) : c(ctx) { c->mb.stale = on ? c->dirty_buf : nullptr; }
         ~StaleGuard() { c->mb.stale = nullptr; }
-    } stale_guard(c, par_only && pb > 0);
+    } stale_guard(c, par_only && (pb > 0 || c->spec_adopted)); /* (a batch adopted from the background: stale from its first slot on) */
     const int N = c->N;
     const int gN = std::max((N + 255) / 256, W);
     const PzTab pz{c->pz_tab, c->pz_n};
@@ -2421,6 +2459,8 @@ extern "C" int ig_nuis_run_begin(ig_ctx* c, int32_t n_moves, const int32_t* frag
     if (max_c < 1 || max_c > IG_MAX_CANDIDATES) return fail("ig_nuis_run_begin: max_c out of range");
     if (!c->init_links_inverse) return fail("ig_nuis_run_begin: the initial prev / next arrays are not mutually inverse (ig_links_inverse): ig_nuis_begin, one pair at a time");
     if (nh_flush_pending(c)) return -1; /* the last move of the run before: into the histogram while its slot is still there */
+    c->bg_valid = false;
+    c->spec_adopted = false;
     static const int s_cap = getenv("IG_NUIS_WMAX") ? atoi(getenv("IG_NUIS_WMAX")) : 24;
     if (g_nuis_w < 0) g_nuis_w = getenv("IG_NUIS_W") ? std::max(0, atoi(getenv("IG_NUIS_W"))) : 0;
     const int Wmax = std::max(1, std::min(std::max(s_cap, g_nuis_w), max_batch_width(c, max_c)));
@@ -2476,6 +2516,9 @@ static void nuis_spec_invalidate(ig_ctx* c)
 static int nuis_spec_score(ig_ctx* c, int move)
 {
     if (nh_flush_pending(c)) return -1; /* (the buffers of the last move's slot are about to be overwritten) */
+    c->bg_valid = false; /* (a batch scored in the background belongs to the batch it was launched from) */
+    c->spec_adopted = false;
+    c->spec_changed = false;
     nuis_spec_invalidate(c);
     const int W = std::min(nuis_struct_width(c), c->up_moves - move);
     const int r = std::min(nuis_spec_width(c), W);
@@ -2513,6 +2556,226 @@ static int nuis_spec_rescore(ig_ctx* c)
     return 0;
 }
 
+/* ---- the next batch of a run, scored in the background ---------------------------------------------------------------------
+ * The step that scores a new batch costs 450 - 650 us (gather, mutate, slice, screen, exact: a dozen latency-bound launches) while a
+ * normal step leaves the machine idle more than half of the time, waiting for the host's proposal.  A batch does not get used
+ * up: it ends when a move touches a contig an earlier move of the batch modified (20 of 24 slots on average at the headline
+ * shape).  So whenever a move of the batch in the buffers has CHANGED the genome -- from then on the batch is going stale -- or the
+ * batch has IG_NUIS_BG_LEAD slots left, a batch that starts at the very NEXT move is scored on a low-priority stream into a second
+ * set of buffers against a SNAPSHOT of the state (state arrays, tables, scalars: copied on the library stream behind the step's
+ * commit; the moves committed meanwhile cannot race with it).  When the batch in the buffers ends -- conflict or used up -- the
+ * buffers are swapped (nuis_bg_adopt) and the decisions go on at the slot of the move in question: the slots before it belong to
+ * moves decided meanwhile; the contigs modified since the snapshot are the tail of the decide step's list (bg_mark), loaded by the
+ * first decision from the adopted batch like the list of an earlier launch; slot 0 was scored with every block-insert slot of
+ * its candidate 0 like the other slots (its stale flags were not known); a slot's fresh contig ids are those a batch scored at
+ * the snapshot would hand out (one set per move since); an accepted step since the launch voids the parameter half only.
+ * IG_NUIS_BG=1 / ig_set_nuis_background(1): on (off by default, see nuis_bg_enabled).  Results do not depend on it
+ * (tests/test_hip_nuis_screen.py). */
+__global__ void k_bg_fix(const int* __restrict__ dirty_buf, int* bg_mark) { bg_mark[0] = dirty_buf[0]; }
+__global__ void __launch_bounds__(64) k_bg_adopt(Glob* g, const Glob* g2, int* dirty_buf, const int* __restrict__ bg_mark)
+{
+    const int lane = threadIdx.x;
+    const int n = dirty_buf[0], m = min(max(bg_mark[0], 0), n);
+    constexpr int NQ = (2 * IG_MAX_BATCH + 2 + 63) / 64;
+    int v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) v[q] = (lane + 64 * q < n - m) ? dirty_buf[1 + m + lane + 64 * q] : -2;
+    __builtin_amdgcn_s_barrier(); /* (one wave: everything is read before anything is written) */
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+        if (lane + 64 * q < n - m) dirty_buf[1 + lane + 64 * q] = v[q];
+    if (lane == 0) {
+        dirty_buf[0] = n - m;
+        if (g2->error && !g->error) g->error = g2->error; /* (the background kernels reported into the snapshot) */
+        g->next_cid = max(g->next_cid, g2->next_cid);
+    }
+}
+
+static int g_nuis_bg = -1;
+static bool nuis_bg_enabled()
+{
+    /* OFF unless asked for: measured at the headline shape (settled chain, tools/nuisance_rate.py) 8.0 k (move + step)/s with a lead of
+     * 6 slots, 7.4 / 6.9 k with 10 / 14, 6.8 k when every move that changes the genome starts one -- against 9.6 k without.  The
+     * batch scored in the background is a dozen machine-filling launches: next to it a step's own small kernels take 100 instead of
+     * 56 us (device wait 45 -> 60 - 85 us per step), and most batches end in a conflict whose move is stale in the background batch
+     * as well (its cause came after the snapshot), so the step that scores a batch is not even avoided (p95 of a step: 430 us either
+     * way).  Kept switchable and tested (same results): a cheaper structural half would change the balance. */
+    if (g_nuis_bg < 0) g_nuis_bg = getenv("IG_NUIS_BG") ? atoi(getenv("IG_NUIS_BG")) : 0;
+    return g_nuis_bg != 0;
+}
+extern "C" int ig_set_nuis_background(int on)
+{
+    g_nuis_bg = on ? 1 : 0;
+    return 0;
+}
+static int ensure_bg_buffers(ig_ctx* c)
+{
+    if (!c->stream_bg) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&c->stream_bg, hipStreamDefault, least) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCK(hipStreamCreate(&c->stream_bg));
+        }
+        HIPCK(hipEventCreateWithFlags(&c->ev_snap, hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&c->ev_bg_done, hipEventDisableTiming));
+        DALLOC(c->glob2, 1);
+        DALLOC(c->bg_mark, 4);
+    }
+    if (c->bg_N != c->N || c->bg_M != c->M || !c->st2_block) {
+        HIPCK(hipStreamSynchronize(c->stream_bg));
+        hipFree(c->st2_block);
+        hipFree(c->tab2.dist);
+        hipFree(c->touched_bits2);
+        c->st2_block = nullptr;
+        c->tab2.dist = nullptr;
+        c->touched_bits2 = nullptr;
+        const size_t n = (size_t)c->N, M = (size_t)c->M;
+        DALLOC(c->st2_block, 17 * n);
+        int** sp = (int**)&c->st2;
+        for (int k = 0; k < 17; k++) sp[k] = c->st2_block + k * n;
+        int* blk;
+        DALLOC(blk, 6 * M + 2);
+        c->tab2.dist = (float*)blk;
+        c->tab2.stot = (float*)(blk + M);
+        c->tab2.len = blk + 2 * M;
+        c->tab2.cp = (int2*)(blk + 4 * M + ((4 * M) & 1));
+        const size_t n_tw = (M + 31) / 32 + 1;
+        DALLOC(c->touched_bits2, 2 * n_tw);
+        HIPCK(hipMemset(c->touched_bits2, 0, 2 * n_tw * sizeof(unsigned)));
+        c->touched_flip2 = 0;
+        c->bg_N = c->N;
+        c->bg_M = c->M;
+    }
+    const MoveBuf& a = c->mb;
+    MoveBuf& m = c->mb2;
+    if (m.capC != a.capC || m.capW != a.capW || m.N != a.N || m.M != a.M || m.packed != a.packed || m.pool_cap < a.pool_cap) {
+        HIPCK(hipStreamSynchronize(c->stream_bg));
+        free_movebuf(m);
+        if (alloc_movebuf(c, m, a.capC, a.capW, a.packed, (size_t)a.pool_cap)) return -1;
+    }
+    return ensure_window_buffers(c, m);
+}
+
+/* the kernels of enqueue_score take what they read from the handle: for the launches of the background batch the handle shows
+ * the second set of buffers, the snapshot and the background stream */
+struct BgSwap {
+    ig_ctx* c;
+    hipStream_t stream;
+    State st;
+    Tables tab, tab_prev;
+    Glob* glob;
+    int own_begin, own_end, own_screened;
+    bool tail_fused, no_predict;
+    explicit BgSwap(ig_ctx* ctx) : c(ctx)
+    {
+        stream = c->stream;
+        st = c->st;
+        tab = c->tab;
+        tab_prev = c->tab_prev;
+        glob = c->glob;
+        own_begin = c->own_begin;
+        own_end = c->own_end;
+        own_screened = c->own_screened;
+        tail_fused = c->tail_fused;
+        no_predict = c->no_predict;
+        std::swap(c->mb, c->mb2);
+        std::swap(c->touched_bits, c->touched_bits2);
+        std::swap(c->touched_flip, c->touched_flip2);
+        c->stream = c->stream_bg;
+        c->st = c->st2;
+        c->tab = c->tab2;
+        c->tab_prev = c->tab2; /* (k_gather's catch-up of the pre-move tables: onto itself) */
+        c->glob = c->glob2;
+    }
+    ~BgSwap()
+    {
+        c->bg_own_begin = c->own_begin;
+        c->bg_own_end = c->own_end;
+        c->bg_own_screened = c->own_screened;
+        c->bg_tail_fused = c->tail_fused;
+        std::swap(c->mb, c->mb2);
+        std::swap(c->touched_bits, c->touched_bits2);
+        std::swap(c->touched_flip, c->touched_flip2);
+        c->stream = stream;
+        c->st = st;
+        c->tab = tab;
+        c->tab_prev = tab_prev;
+        c->glob = glob;
+        c->own_begin = own_begin;
+        c->own_end = own_end;
+        c->own_screened = own_screened;
+        c->tail_fused = tail_fused;
+        c->no_predict = no_predict;
+    }
+};
+
+/* called behind the launches of a step whose move sits in slot spec_next of the batch in the buffers: a batch from the move behind it */
+static int nuis_bg_launch(ig_ctx* c)
+{
+    const int base2 = c->spec_base + c->spec_next + 1;
+    const int W2 = std::min(nuis_struct_width(c), c->up_moves - base2);
+    if (W2 < 1) return 0;
+    const int r2 = std::min(nuis_spec_width(c), W2);
+    if (ensure_bg_buffers(c)) return -1;
+    flush_pending_sums(c); /* (the snapshot of the scalars: with the maintained sum in place) */
+    HIPCK(hipStreamWaitEvent(c->stream, c->ev_bg_done, 0)); /* (a dropped background batch may still be reading the snapshot) */
+    HIPCK(hipMemcpyAsync(c->st2_block, c->st_block, 17 * (size_t)c->N * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(hipMemcpyAsync(c->tab2.dist, c->tab.dist, (6 * (size_t)c->M + 2) * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(hipMemcpyAsync(c->glob2, c->glob, sizeof(Glob), hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_bg_fix, dim3(1), dim3(1), 0, c->stream, c->dirty_buf, c->bg_mark);
+    HIPCK(hipEventRecord(c->ev_snap, c->stream));
+    HIPCK(hipStreamWaitEvent(c->stream_bg, c->ev_snap, 0));
+    {
+        BgSwap sw(c);
+        c->no_predict = true;
+        enqueue_score(c, base2, W2, c->up_max_c, -2, 2, 0, W2, 0, r2, false);
+        HIPCK(hipEventRecord(c->ev_bg_done, c->stream));
+    }
+    c->bg_valid = true;
+    c->bg_stale = false;
+    c->bg_base = base2;
+    c->bg_W = W2;
+    c->bg_r = r2;
+    c->bg_accepts = c->n_accepts;
+    c->n_bg_launched++;
+    return 0;
+}
+
+/* the batch in the buffers has ended at `move` (conflict, or used up) and the background one holds that move: swap */
+static bool nuis_bg_holds(const ig_ctx* c, int move) { return nuis_bg_enabled() && c->bg_valid && move >= c->bg_base && move < c->bg_base + c->bg_W; }
+static int nuis_bg_adopt(ig_ctx* c, int move)
+{
+    if (nh_flush_pending(c)) return -1; /* (the histogram's walk of the last move reads its slot in the buffers about to be swapped out) */
+    nuis_spec_invalidate(c); /* (the run lengths of the batch that ends here) */
+    HIPCK(hipStreamWaitEvent(c->stream, c->ev_bg_done, 0));
+    std::swap(c->mb, c->mb2);
+    std::swap(c->touched_bits, c->touched_bits2);
+    std::swap(c->touched_flip, c->touched_flip2);
+    c->own_begin = c->bg_own_begin;
+    c->own_end = c->bg_own_end;
+    c->own_screened = c->bg_own_screened;
+    c->tail_fused = c->bg_tail_fused;
+    hipLaunchKernelGGL(k_bg_adopt, dim3(1), dim3(64), 0, c->stream, c->glob, c->glob2, c->dirty_buf, c->bg_mark);
+    c->spec_base = c->bg_base;
+    c->spec_W = c->bg_W;
+    c->spec_next = move - c->bg_base;
+    c->spec_valid = true;
+    c->spec_prev_pending = false;
+    c->spec_adopted = true;
+    c->spec_changed = c->bg_stale; /* (a move since the snapshot has changed the genome: this batch is going stale already) */
+    c->spec_par_begin = 0;
+    c->spec_par_end = (c->bg_accepts == c->n_accepts) ? c->bg_r : 0;
+    c->bg_valid = false;
+    c->n_bg_adopted++;
+    /* an accepted step since the launch, or the parameter half of the first slots only and the move behind them: again from here */
+    if (c->spec_next >= c->spec_par_end) {
+        c->spec_par_begin = c->spec_par_end = c->spec_next; /* (no piece of this batch was used: nothing for the run lengths) */
+        return nuis_spec_rescore(c);
+    }
+    return 0;
+}
+
 extern "C" int ig_nuis_step_begin(ig_ctx* c, int32_t move, const float p_test[8], float mean_subfrag_kb)
 {
     IG_JOIN(c);
@@ -2534,17 +2797,28 @@ static int nuis_step_begin_impl(ig_ctx* c, int32_t move, const float p_test[8], 
     if (enqueue_nuis_pass(c, p_test, mean_subfrag_kb)) return -1;
     c->side_busy = true;
     if (restruct) {
-        if (nuis_spec_score(c, move)) return -1;
+        if (nuis_bg_holds(c, move)) {
+            if (nuis_bg_adopt(c, move)) return -1;
+        } else if (nuis_spec_score(c, move)) {
+            return -1;
+        }
     } else if (repar) {
         if (nuis_spec_rescore(c)) return -1;
     }
     /* the result record reaches the host as soon as the move is applied: written by k_commit_batch itself where the host
      * memory is mapped, else copied (and copied in the rare cases ig_nuis_end has to redo the move) */
     c->nuis_pub_res = c->host_nuis_dev != nullptr;
-    launch_commit(c, c->spec_base, c->spec_next + 1, c->spec_next, c->spec_prev_pending ? 0 : 1, c->nuis_pub_res);
+    launch_commit(c, c->spec_base, c->spec_next + 1, c->spec_next, (c->spec_prev_pending ? 0 : 1) | (c->spec_adopted ? 2 : 0), c->nuis_pub_res);
     if (!c->nuis_pub_res) {
         HIPCK(hipMemcpyAsync(&c->host_nuis->res, c->d_results + move, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
         if (queue_max_readback(c)) return -1;
+    }
+    /* the next batch in the background, once this one is nearly used up */
+    static const int s_lead = getenv("IG_NUIS_BG_LEAD") ? std::max(0, atoi(getenv("IG_NUIS_BG_LEAD"))) : 6;
+    static const int s_on_change = getenv("IG_NUIS_BG_CHANGED") ? atoi(getenv("IG_NUIS_BG_CHANGED")) : 1;
+    if (nuis_bg_enabled() && c->spec_valid && !c->bg_valid && ((c->spec_changed && s_on_change) || c->spec_W - c->spec_next - 1 <= s_lead) &&
+        c->spec_base + c->spec_next + 1 < c->up_moves && c->host_nuis_dev) {
+        if (nuis_bg_launch(c)) return -1;
     }
     HIPCK(hipGetLastError());
     return 0;
@@ -2573,7 +2847,10 @@ static int nuis_spec_finish(ig_ctx* c)
         }
         /* not decided: a contig of the move was modified by an earlier move of the batch (w > 0), or the first slot did not
          * fit the slice pool / the exact kernel's grid: score a batch from this move */
-        if (w == 0) {
+        if (w == 0 && c->spec_adopted && bo[2] == 0) {
+            /* the first slot of a batch scored in the background: a contig of the move was modified after the snapshot */
+            c->spec_valid = false; /* says nothing about run lengths */
+        } else if (w == 0) {
             if (bo[2] == 1) {
                 if (grow_slice_pool(c)) return -1;
             } else if (bo[2] == 2) {
@@ -2587,8 +2864,13 @@ static int nuis_spec_finish(ig_ctx* c)
             c->spec_valid = false; /* says nothing about run lengths */
         }
         if (attempt > 8) return fail("move %d of a run could not be decided", c->spec_move);
-        if (nuis_spec_score(c, c->spec_move)) return -1;
-        launch_commit(c, c->spec_base, 1, 0, 0);
+        if (nuis_bg_holds(c, c->spec_move)) { /* the batch scored in the background meanwhile holds the move */
+            if (nuis_bg_adopt(c, c->spec_move)) return -1;
+            launch_commit(c, c->spec_base, c->spec_next + 1, c->spec_next, 1 | 2);
+        } else {
+            if (nuis_spec_score(c, c->spec_move)) return -1;
+            launch_commit(c, c->spec_base, 1, 0, 0);
+        }
         redone = true;
     }
     c->spec_slot = c->spec_next;
@@ -2768,6 +3050,7 @@ static int nuis_end_body(ig_ctx* c, ig_move_result* out, double* nz_test, double
             *out = hn->res;
             if (out->error) return fail("device-side consistency failure %d", out->error);
             if (c->nuis_spec) c->nh_pending_slot = (c->nh_valid && moved) ? c->spec_slot : -1;
+            if (c->nuis_spec && moved) c->spec_changed = c->bg_stale = true;
             if (nz_test) *nz_test = scr_mid;
             if (z_test) *z_test = nuis_z_from_sums((const long long*)hn->sums);
             if (limbs5)
@@ -2792,6 +3075,7 @@ static int nuis_end_body(ig_ctx* c, ig_move_result* out, double* nz_test, double
     *out = c->host_nuis->res;
     if (out->error) return fail("device-side consistency failure %d", out->error);
     if (c->nuis_spec) c->nh_pending_slot = (c->nh_valid && moved) ? c->spec_slot : -1; /* (the histogram follows the move at the head of the next step) */
+    if (c->nuis_spec && moved) c->spec_changed = c->bg_stale = true; /* (the batch in the buffers goes stale from here: time to score the next one) */
     if (scr_valid || scr0_valid) { /* the exact pass ran as well: how much of the bounds did the screened sums use?  (verify mode: the check) */
         long long e[2] = {c->host_nuis->sums[0], c->host_nuis->sums[1]};
         ig_acc_normalize((int64_t*)&e[0], (int64_t*)&e[1]);
@@ -2854,6 +3138,15 @@ extern "C" int ig_debug_nuis_hist_stats(ig_ctx* c, double out12[12])
 {
     IG_JOIN(c);
     for (int i = 0; i < 12; i++) out12[i] = c->nhs[i];
+    return 0;
+}
+
+/* batches of runs scored in the background: {launched, adopted} since the handle was made */
+extern "C" int ig_debug_nuis_bg_stats(ig_ctx* c, int64_t out2[2])
+{
+    IG_JOIN(c);
+    out2[0] = c->n_bg_launched;
+    out2[1] = c->n_bg_adopted;
     return 0;
 }
 
@@ -2994,6 +3287,7 @@ extern "C" int ig_nuis_accept(ig_ctx* c)
         HIPCK(hipMemset(c->scratch_accept, 0, 8 * sizeof(long long)));
     }
     long long* acc8 = c->scratch_accept;
+    c->n_accepts++;
     c->main_drained = false;
     const int w = c->spec_slot; /* the slot of the move just applied (0 unless it came out of a batch: ig_nuis_step_begin) */
     /* whatever was scored ahead was scored under the old parameters -- but only its parameter-dependent half: windows, candidate

@@ -371,12 +371,14 @@ __global__ void __launch_bounds__(64)
         int n_dirty = 0, committed = w_start, pending = -1, n_cand = 0, n_predicted = 0, stop_overflow = 0;
         int max_L = g->max_L, max_SL = g->max_SL;
         const float n_frags_f = (float)g->N; /* not inside the loop: a load there waits for the prefetches issued before it */
-        if (w_start > 0) {
+        /* resumed_plain bit 1: the list is loaded even at w_start == 0 -- a batch scored in the background against a snapshot of
+         * the state: the contigs modified since then are on it (nuis_bg_adopt) */
+        if (w_start > 0 || (resumed_plain & 2)) {
             n_dirty = dirty_buf[0];
 #pragma unroll
             for (int j = 0; j < ND; j++)
                 if (lane + 64 * j < n_dirty) dirty[j] = dirty_buf[1 + lane + 64 * j];
-            if (!resumed_plain) {
+            if (w_start > 0 && !(resumed_plain & 1)) {
                 const MoveCtl pm = mb.ctl[w_start - 1];
                 const CandMeta& m = mb.meta[CW(w_start - 1, pm.ch_c)];
 #pragma unroll

@@ -181,6 +181,11 @@ def set_nuis_hist(on):
     _ck(lib().ig_set_nuis_hist(C.c_int(int(on))))
 
 
+def set_nuis_background(on):
+    """the batches of a nuisance run scored ahead in the background, or when they are needed (default)"""
+    _ck(lib().ig_set_nuis_background(C.c_int(int(on))))
+
+
 def debug_set_full_hist(on):
     """from-scratch pass over all contacts: tiles of trans pairs only from their count histograms (default) or contact by
     contact -- same exact sums (tests)"""
@@ -421,6 +426,12 @@ class Context:
         return dict(evaluated=int(o[0]), rejected=int(o[1]), accepted=int(o[2]), void=int(o[3]), mean_bound=float(o[4] / n),
                     largest_used_fraction=float(o[5]), walks=int(o[6]), builds=int(o[7]),
                     void_why=dict(parameters=int(o[8]), contact=int(o[9]), sums=int(o[10]), no_record=int(o[11])))
+
+    def debug_nuis_bg_stats(self):
+        """batches of nuisance runs scored in the background: (launched, adopted)"""
+        o = np.zeros(2, np.int64)
+        _ck(lib().ig_debug_nuis_bg_stats(self._h, _p(o)))
+        return int(o[0]), int(o[1])
 
     def debug_nuis_hist_check(self):
         """words of the maintained histogram that differ from one built from scratch (-1: no histogram kept)"""

@@ -159,6 +159,13 @@ hipError_t hipStreamCreate(hipStream_t* s)
     *s = (hipStream_t)malloc(8); // a handle that must be destroyed exactly once (LeakSanitizer / double free)
     return hipSuccess;
 }
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { return hipStreamCreate(s); }
+hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest)
+{
+    *least = 0;
+    *greatest = -1;
+    return hipSuccess;
+}
 hipError_t hipStreamDestroy(hipStream_t s)
 {
     free((void*)s);
