@@ -307,6 +307,7 @@ struct ig_ctx {
     int touched_flip2;
     int* bg_mark; /* device: entries of dirty_buf at the snapshot (the contigs modified after it are behind them) */
     int bg_N, bg_M;
+    bool last_moved;   /* the move of the step just ended changed the genome (or nobody said it did not) */
     bool spec_changed; /* a move decided from the batch in the buffers has changed the genome */
     bool bg_stale;     /* ... since the snapshot of the background batch */
     bool bg_valid, spec_adopted; /* spec_adopted: the batch in the buffers came from the background (its slots may be stale from slot 0 on) */
