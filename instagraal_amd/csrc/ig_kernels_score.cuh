@@ -852,7 +852,9 @@ __device__ __forceinline__ void score_loop(const ScoreArgs& a, const ig_hot& h, 
  * Windows above LDS_COL_SMALL sub-fragments are not staged: 8-byte gathers of the coordinates from L2 (a second instance of
  * the loop behind a uniform branch).  A 32 KB-column instance for them was measured slower (3 waves / SIMD) even on windows
  * of thousands of sub-fragments and is gone. */
+#ifndef LDS_COL_SMALL
 #define LDS_COL_SMALL 1024
+#endif
 /* what every workgroup of k_score_list stages: built once per parameter set (k_build_score_const), copied to LDS as is */
 struct ScoreTables {
     double mt[IG_TAB_SIZE];  /* the log2 / exp2 tables of the arithmetic contract; at LDS offset 0: the table pair is read without address arithmetic */

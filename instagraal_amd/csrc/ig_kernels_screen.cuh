@@ -102,7 +102,7 @@ struct ScreenSum {
 };
 
 #ifndef SCREEN_BATCH
-#define SCREEN_BATCH 4
+#define SCREEN_BATCH 2 /* entries a lane has in flight per step (one pair): 2 / 4 / 6 / 8 -> 208 / 212 / 218 / 232 us per launch at the headline shape */
 #endif
 struct alignas(16) ScreenLds {
     float pzc[LDS_PZ + 2]; /* first member: copied with 16-byte vectors */
