@@ -172,8 +172,10 @@ int ig_set_nuis_screen(int on);
 /* The screened pass has two tiers.  The first reads no contact at all: the same change of the likelihood from a histogram of the
  * cis contacts over log2 of their distance (in which the term's exponent is piecewise linear), kept up to date by the moves that
  * change the genome, with its own rigorous bound; the pass over the contacts runs only where that interval does not decide
- * (csrc/ig_kernels_nuis.cuh, "tier 0").  0 = start with the pass over the contacts (env IG_NUIS_HIST); IG_NUIS_SCREEN_VERIFY=1
- * checks both tiers against the exact pass on every step. */
+ * (csrc/ig_kernels_nuis.cuh, "tier 0").  1 (default): where it pays -- a cost model on the host (contacts, contigs, share of the
+ * moves that change the genome) switches it off where few long contigs make the walks dearer than the pass; 2: always; 0 = start
+ * with the pass over the contacts (env IG_NUIS_HIST); IG_NUIS_SCREEN_VERIFY=1 checks both tiers against the exact pass on every
+ * step. */
 int ig_set_nuis_hist(int on);
 /* The batches of a run are scored ahead in the BACKGROUND: once a move of the batch in the buffers has changed the genome (or the
  * batch is nearly used up) a batch from the next move on is scored on a low-priority stream against a snapshot of the state, into a

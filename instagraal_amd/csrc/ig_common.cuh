@@ -325,6 +325,8 @@ struct ig_ctx {
     hipEvent_t ev_walk;
     double nhs[12];          /* statistics: evaluations, rejected / accepted there, void, sum of bounds, largest used fraction, walks, builds, void because of {parameters, a contact, sums, no record} */
     bool nh_tracking;        /* a step of a run is being enqueued / ended: the moves applied now are followed by the histogram */
+    bool nh_policy_on;       /* the histogram tier is worth its walks at the moment (nuis_hist_usable's cost model) */
+    double nh_p_changed;     /* moving average: share of a run's moves that change the genome */
     double nscr[12];               /* statistics: steps screened, rejected from the interval, exact passes, void, largest bound, largest used fraction, sum of bounds */
     bool nuis_in_flight;
     bool side_busy;      /* launch_full_nz on a side stream: the library stream is busy with a batch (one workgroup per CU for the pass) */

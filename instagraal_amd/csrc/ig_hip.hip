@@ -322,6 +322,8 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->nh_valid = false;
     c->nh_pending_slot = -1;
     c->nh_tracking = false;
+    c->nh_policy_on = true;
+    c->nh_p_changed = 0.1;
     c->nuis_tier = 1;
     c->nuis_tiles_listed = false;
     for (double& v : c->nhs) v = 0.0;
@@ -2208,11 +2210,30 @@ static int g_nuis_hist = -1;
 static bool nuis_hist_usable(ig_ctx* c)
 {
     if (g_nuis_hist < 0) g_nuis_hist = getenv("IG_NUIS_HIST") ? atoi(getenv("IG_NUIS_HIST")) : 1;
-    return g_nuis_hist && nuis_screen_usable(c);
+    if (!g_nuis_hist || !nuis_screen_usable(c)) return false;
+    if (g_nuis_hist >= 2) return true; /* (2: whatever the cost model says -- tests) */
+    /* The histogram pays where the pass over the contacts is long and the moves are local.  Per step it costs its evaluation
+     * (~16 us) plus, for the share p of the moves that change the genome, the walk over the contacts inside the move's two contigs
+     * -- about 2 Z / n_contigs of them, 10 atomics each at ~24 G/s (profiles/r03_microbench.txt); the pass over the contacts costs
+     * ~20 us of launches + the cis tiles' 8 bytes per contact at ~5 TB/s.  Few long contigs (the late stage of an assembly: 4
+     * contigs of 1 000 bins, 58 % of the moves change the genome) turn the balance: 3.0 k (move + step)/s with the histogram
+     * there, 3.9 k without.  With hysteresis; a histogram that is switched off is dropped (the walks stop) and rebuilt when it
+     * comes back. */
+    const double Z = (double)c->Z, nc = (double)std::max(c->n_contigs_seen, 1), p = c->nh_p_changed;
+    const double t0 = 16.0 + p * (2.0 * Z / nc) * 10.0 / 24e3, t1 = 20.0 + Z * 8.0 * 0.4 / 5e6;
+    if (c->n_contigs_seen <= 0) return c->nh_policy_on; /* (no batch decided yet) */
+    if (c->nh_policy_on ? t0 > 1.25 * t1 : t0 < 0.8 * t1) {
+        c->nh_policy_on = !c->nh_policy_on;
+        if (!c->nh_policy_on) {
+            c->nh_valid = false;
+            c->nh_pending_slot = -1;
+        }
+    }
+    return c->nh_policy_on;
 }
 extern "C" int ig_set_nuis_hist(int on)
 {
-    g_nuis_hist = on ? 1 : 0;
+    g_nuis_hist = on < 0 ? 0 : std::min(on, 2);
     return 0;
 }
 static int ensure_nuis_hist(ig_ctx* c)
@@ -3056,6 +3077,7 @@ static int nuis_end_body(ig_ctx* c, ig_move_result* out, double* nz_test, double
             if (out->error) return fail("device-side consistency failure %d", out->error);
             if (c->nuis_spec) c->nh_pending_slot = (c->nh_valid && moved) ? c->spec_slot : -1;
             if (c->nuis_spec && moved) c->spec_changed = c->bg_stale = true;
+            if (c->nuis_spec) c->nh_p_changed = 0.98 * c->nh_p_changed + 0.02 * (moved ? 1.0 : 0.0);
             if (nz_test) *nz_test = scr_mid;
             if (z_test) *z_test = nuis_z_from_sums((const long long*)hn->sums);
             if (limbs5)
@@ -3081,6 +3103,7 @@ static int nuis_end_body(ig_ctx* c, ig_move_result* out, double* nz_test, double
     if (out->error) return fail("device-side consistency failure %d", out->error);
     if (c->nuis_spec) c->nh_pending_slot = (c->nh_valid && moved) ? c->spec_slot : -1; /* (the histogram follows the move at the head of the next step) */
     if (c->nuis_spec && moved) c->spec_changed = c->bg_stale = true; /* (the batch in the buffers goes stale from here: time to score the next one) */
+    if (c->nuis_spec) c->nh_p_changed = 0.98 * c->nh_p_changed + 0.02 * (moved ? 1.0 : 0.0); /* (the histogram tier's cost model, nuis_hist_usable) */
     if (scr_valid || scr0_valid) { /* the exact pass ran as well: how much of the bounds did the screened sums use?  (verify mode: the check) */
         long long e[2] = {c->host_nuis->sums[0], c->host_nuis->sums[1]};
         ig_acc_normalize((int64_t*)&e[0], (int64_t*)&e[1]);

@@ -177,7 +177,8 @@ def set_nuis_screen(on):
 
 
 def set_nuis_hist(on):
-    """the screened pass starts from the histogram of the cis contacts' distances (default) or from the pass over the contacts"""
+    """the screened pass starts from the histogram of the cis contacts' distances where that pays (1, default: a cost model decides),
+    always (2), or never (0)"""
     _ck(lib().ig_set_nuis_hist(C.c_int(int(on))))
 
 

@@ -87,6 +87,22 @@ def _solve(p, val_inter, s0):
         u = lm * np.abs(x) / kuhn
         return np.abs(val_inter - A * (c0 * np.power(u, slope) * np.exp(c1 / (np.power(u, 2) + dd))))
 
+    iterate = residual
+    if _quiet and c1 == 0:
+        # d == 2 (the only value the reference ever uses, l.8): the exponential factor is exp(0 / ...) = 1 exactly, and what is left
+        # is IEEE double arithmetic on values that are exact in double (float32 parameters) around ONE library call, numpy's own
+        # pow -- the same loop for a Python float as for the one-element array.  Same bits as the expression above
+        # (tests/test_cpu_abi_and_host.py compares the two residuals and the roots), an eighth of its time: MINPACK evaluates it
+        # seven times per root, and the root is what a nuisance step costs on the host.
+        fl, fk, fs, fA, fv, fc0, npow = float(lm), float(kuhn), float(slope), float(A), float(val_inter), float(c0), np.power
+
+        def iterate(x):
+            x0 = x[0]
+            if x0 != x0:
+                x[np.isnan(x)] = 0
+                x0 = x[0]
+            return abs(fv - fA * (fc0 * float(npow(fl * abs(x0) / fk, fs))))
+
     x0 = np.asarray(s0).flatten()
     # fsolve's shape check evaluates the residual once on the caller's (possibly float32) s0 and takes the forward-difference step
     # from the dtype of what comes back: a function of the dtypes of the arguments alone -- looked up, evaluated the first time
@@ -96,7 +112,7 @@ def _solve(p, val_inter, s0):
         if eps is None:
             res = np.atleast_1d(residual(x0[:1]))
             eps = _eps_for[key] = np.finfo(res.dtype if np.issubdtype(res.dtype, np.inexact) else np.dtype(float)).eps
-        return _hybrd(residual, x0, (), 1, 1.49012e-08, 200 * (x0.size + 1), -10, -10, eps, 100, None)[0][0]
+        return _hybrd(iterate, x0, (), 1, 1.49012e-08, 200 * (x0.size + 1), -10, -10, eps, 100, None)[0][0]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)
         res = np.atleast_1d(residual(x0[:1]))

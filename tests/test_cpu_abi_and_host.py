@@ -106,6 +106,15 @@ def test_root_finding_fast_path_is_fsolve():
         b = opti._solve([kuhn, lm, slope, d, fact], d_nuc, s0)
         assert type(a) is type(b)
         assert a == b or (a != a and b != b), (it, a, b)
+        # ... and inside a nuisance run (quiet_runs: floating-point warnings off once per run, the residual's dtype looked up, and for
+        # d == 2 a residual in Python floats around numpy's own pow): the same bits again
+        with opti.quiet_runs():
+            q = opti._solve([kuhn, lm, slope, d, fact], d_nuc, s0)
+        assert type(q) is type(b) and (np.float64(q).tobytes() == np.float64(b).tobytes() or (q != q and b != b)), (it, b, q)
+    # another value of d: the general residual inside a run as well
+    with opti.quiet_runs():
+        q = opti._solve([50.0, 9.6, -1.4, 3.0, p["fact"]], p["v_inter"], 500.0)
+    assert q == opti._solve_fsolve([50.0, 9.6, -1.4, 3.0, p["fact"]], p["v_inter"], 500.0)
 
 
 def test_initial_rippe_estimation_matches_reference():
