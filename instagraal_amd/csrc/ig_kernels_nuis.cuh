@@ -778,9 +778,13 @@ __global__ void __launch_bounds__(256) k_hist_eval(NuisHist h, const Glob* g, co
     }
     /* the last workgroup through: what does not belong to a bin (trans contacts, cis ones at distance 0, the contract's own
      * roundings), then the sums to the (mapped) host memory and the flag; the words are cleared for the next launch */
+    /* (everything a workgroup contributes is an atomic, acknowledged by the time the barrier lets thread 0 through: no release
+     * fence in front of the ticket -- on this part an agent-scope release is a write-back of the XCD's L2, once per workgroup) */
     __syncthreads();
     if (tid == 0) {
+#ifdef HIST_TICKET_FENCE
         __threadfence();
+#endif
         if (atomicAdd((unsigned long long*)&out16[8], 1ull) == (unsigned long long)gridDim.x - 1ull) {
             __threadfence();
             long long o[8];

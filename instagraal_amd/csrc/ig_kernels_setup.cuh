@@ -105,9 +105,9 @@ __device__ __forceinline__ void full_zero_block(const Tables& t, const Glob* g, 
         if (v) atomic_add_ll(&out[threadIdx.x], v);
     }
     /* what the host needs next to the sums to form the zero-pixel likelihood: one copy back instead of two */
-    if (block == 0 && threadIdx.x == 0) {
-        out[3] = __double_as_longlong(g->n_tot_pxl);
-        out[5] = (long long)__float_as_int(g->par[which].v_inter);
+    if (block == 0 && threadIdx.x == 0) { /* (atomic stores: a launch whose last workgroup reads them needs no fence for these two) */
+        __hip_atomic_store(&out[3], __double_as_longlong(g->n_tot_pxl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&out[5], (long long)__float_as_int(g->par[which].v_inter), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 __global__ void k_full_zero(Tables t, const Glob* g, int which, int M, long long* out) { full_zero_block(t, g, which, M, out, blockIdx.x, gridDim.x); }
