@@ -177,7 +177,27 @@ static void model_commit_batch(void** a, dim3, dim3)
     hn->nzb[1] = 12345;
     hn->max_L = 0;
     hn->max_SL = 0;
+    hn->changed = (int)(rnd() % 4 == 0); /* a move in four changes the genome: the histogram's walk is launched behind it */
     hn->res_seq = seq;
+}
+/* the histogram tier of the screened pass (k_hist_eval): decisive either way, undecided (the pass over the contacts follows), void */
+static long g_hists = 0;
+static void model_hist_eval(void** a, dim3, dim3)
+{
+    NuisHost* hn = *(NuisHost**)a[6];
+    const int seq = *(int*)a[7];
+    g_hists++;
+    if (!hn) return;
+    const int mode = (int)(rnd() % 4);
+    for (int q = 0; q < 8; q++) hn->diff[q] = 0;
+    for (int q = 0; q < 8; q++) hn->sums[q] = 0;
+    hn->diff[3] = 1 << 18; /* a bound of 0.25 */
+    hn->diff[5] = 1000;
+    if (mode == 0) hn->diff[2] = -(1LL << 40);       /* rejected from the interval */
+    else if (mode == 1) hn->diff[2] = (1LL << 40);   /* accepted from the interval: the exact pass behind the decision */
+    else if (mode == 2) hn->diff[3] = 1LL << 45;     /* an interval that decides nothing: tier 1 */
+    else hn->diff[4] = 1 + (int)(rnd() % 7);         /* void: tier 1 */
+    hn->diff_seq = seq;
 }
 static int g_diff_mode = 0; // 0 random, 1 always decisive reject, 2 always undecided, 3 always void
 static long g_diffs = 0, g_exacts = 0;
@@ -232,6 +252,7 @@ int main()
     fake_hip::set_model("k_decide_batch", model_decide);
     fake_hip::set_model("k_commit_batch", model_commit_batch);
     fake_hip::set_model("k_full_diff_tiled", model_diff);
+    fake_hip::set_model("k_hist_eval", model_hist_eval);
     fake_hip::set_model("k_full_nz_tiled", model_full_nz_tiled);
     fake_hip::set_model("k_nuis_promote", model_promote);
 
@@ -404,6 +425,8 @@ int main()
             // ---- runs of (move, nuisance step) pairs
             for (int mode = 0; mode < 4; mode++) {
                 g_diff_mode = mode;
+                CHECK(ig_set_nuis_hist(mode == 3 ? 0 : 2) == 0);       /* the histogram tier whatever its cost model says / not at all */
+                CHECK(ig_set_nuis_background(mode == 1 ? 1 : 0) == 0); /* one run with its batches scored ahead in the background */
                 const int n = 160;
                 CHECK(ig_nuis_run_begin(c, n, frags.data(), cands.data(), max_c) == 0);
                 CHECK(ig_nuis_step_begin(c, 1, p8, 1.8f) != 0); // moves in order only
@@ -469,6 +492,13 @@ int main()
                          "screened steps %.0f, rejected from the interval %.0f, void %.0f\n",
                  fake_hip::launches(), fake_hip::allocations(), g_decides, g_pendings, g_conflicts, g_overflows, g_diffs, g_exacts, st[0], st[1], st[3]);
     CHECK(g_pendings > 0 && g_conflicts > 0 && g_overflows > 0 && g_diffs > 0 && g_exacts > 0 && st[1] > 0 && st[3] > 0);
+    double hs[12];
+    int64_t bg[2];
+    CHECK(ig_debug_nuis_hist_stats(c, hs) == 0 && ig_debug_nuis_bg_stats(c, bg) == 0);
+    std::fprintf(stderr, "[harness] histogram tier: evaluations %.0f (model calls %ld), rejected there %.0f, accepted there %.0f, void %.0f, walks %.0f, builds %.0f; "
+                         "background batches launched %lld, adopted %lld\n",
+                 hs[0], g_hists, hs[1], hs[2], hs[3], hs[6], hs[7], (long long)bg[0], (long long)bg[1]);
+    CHECK(g_hists > 0 && hs[1] > 0 && hs[2] > 0 && hs[3] > 0 && hs[6] > 0);
     ig_destroy(c);
     ig_destroy(nullptr);
     std::puts("host logic harness ok");
