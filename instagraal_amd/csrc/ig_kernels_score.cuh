@@ -1788,12 +1788,16 @@ __global__ void __launch_bounds__(256) k_predict(Glob* g, MoveBuf mb, int w_begi
  * order, so "last" = highest rows, found by bisection on the row id).  Quirk Q5 (KA:4362, block 64 CL:200):
  * a column at list position >= r never receives those contacts; which columns that applies to is decided
  * when the uniq list is known (k_scores / k_commit_batch). */
+/* the tail walk's LDS (a kernel that hosts the walk next to other workgroups overlays it with theirs: k_screen_tail) */
+struct TailLds {
+    int t_li[64], t_lj[64], t_ob[64], t_rows[64];
+    int sh_n_rows, sh_n_tail, sh_cnt;
+    long long sh_red[4];
+    int hist[256];
+};
 __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, Glob* g, MoveBuf mb,
-                              const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int w_begin, int c, int w_rel)
+                              const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int w_begin, int c, int w_rel, TailLds& TL)
 {
-    __shared__ int t_li[64], t_lj[64], t_ob[64], t_rows[64];
-    __shared__ int sh_n_rows, sh_n_tail, sh_cnt;
-    __shared__ long long sh_red[4];
     const int w = w_begin + w_rel;
     if (c >= mb.ctl[w].C) return;
     const int cw = CW(w, c);
@@ -1827,26 +1831,25 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
     if (cached >= 0) { /* found when this slot was scored before (under other parameters): only the terms are new */
         n_tail = min(cached, 64);
         if (tid < n_tail) {
-            t_li[tid] = mb.tail_ent[(size_t)cw * 192 + tid];
-            t_lj[tid] = mb.tail_ent[(size_t)cw * 192 + 64 + tid];
-            t_ob[tid] = mb.tail_ent[(size_t)cw * 192 + 128 + tid];
+            TL.t_li[tid] = mb.tail_ent[(size_t)cw * 192 + tid];
+            TL.t_lj[tid] = mb.tail_ent[(size_t)cw * 192 + 64 + tid];
+            TL.t_ob[tid] = mb.tail_ent[(size_t)cw * 192 + 128 + tid];
         }
         __syncthreads();
     } else {
     /* T = the largest sub-fragment id with (kept contacts in rows of id >= T) >= r.  Radix descent, 8 bits of the id per pass over
      * the window's rows (histogram of the kept contacts by id, suffix sums from the top): 3 passes at M = 150 k where a
      * bisection on the id took 18 -- on windows of thousands of rows this walk is the longest chain of the launch. */
-    __shared__ int hist[256];
     int lo_t = 0, bits = 0; /* invariant: count(id >= lo_t) >= r > count(id >= lo_t + 2^bits) =: n_above */
     while ((1 << bits) < mb.M) bits++;
     int n_above = 0;
     while (bits > 0) {
         const int sh = max(bits - 8, 0), nb = 1 << (bits - sh);
-        for (int b = tid; b < nb; b += blockDim.x) hist[b] = 0;
+        for (int b = tid; b < nb; b += blockDim.x) TL.hist[b] = 0;
         __syncthreads();
         for (int ls = tid; ls < m.m_loc; ls += blockDim.x) {
             const int d = subs[ls] - lo_t, n = rowcnt[ls];
-            if (n > 0 && d >= 0 && (d >> bits) == 0) atomicAdd(&hist[d >> sh], n);
+            if (n > 0 && d >= 0 && (d >> bits) == 0) atomicAdd(&TL.hist[d >> sh], n);
         }
         __syncthreads();
         /* the highest bin b with n_above + (bins b .. nb-1) >= r: wave 0, four bins per lane, suffix sums across the lanes */
@@ -1854,7 +1857,7 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
             int h[4], mine = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                h[q] = (4 * lane + q < nb) ? hist[4 * lane + q] : 0;
+                h[q] = (4 * lane + q < nb) ? TL.hist[4 * lane + q] : 0;
                 mine += h[q];
             }
             int suf = mine; /* inclusive suffix sum over lanes >= lane */
@@ -1870,40 +1873,40 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
                     if (acc + h[b] >= r) break;
                     acc += h[b];
                 }
-                hist[0] = 4 * lane + b; /* the bin, and the contacts above it */
-                hist[1] = acc;
+                TL.hist[0] = 4 * lane + b; /* the bin, and the contacts above it */
+                TL.hist[1] = acc;
             }
         }
         __syncthreads();
-        const int b = hist[0];
-        n_above = hist[1];
+        const int b = TL.hist[0];
+        n_above = TL.hist[1];
         __syncthreads();
         lo_t += b << sh;
         bits = sh;
     }
     const int T = lo_t;
     if (tid == 0) {
-        sh_n_rows = 0;
-        sh_n_tail = 0;
-        sh_cnt = 0;
+        TL.sh_n_rows = 0;
+        TL.sh_n_tail = 0;
+        TL.sh_cnt = 0;
     }
     __syncthreads();
     int above = 0; /* kept contacts in rows > T */
     for (int ls = tid; ls < m.m_loc; ls += blockDim.x) {
         const int s = subs[ls];
         if (s >= T && rowcnt[ls] > 0) {
-            const int slot = atomicAdd(&sh_n_rows, 1);
-            if (slot < 64) t_rows[slot] = ls;
+            const int slot = atomicAdd(&TL.sh_n_rows, 1);
+            if (slot < 64) TL.t_rows[slot] = ls;
             if (s > T) above += rowcnt[ls];
         }
     }
     above = wave_sum_i(above);
-    if (lane == 0 && above) atomicAdd(&sh_cnt, above);
+    if (lane == 0 && above) atomicAdd(&TL.sh_cnt, above);
     __syncthreads();
-    const int n_rows = min(sh_n_rows, 64);
-    const int need_T = r - sh_cnt; /* contacts to take from the END of row T */
+    const int n_rows = min(TL.sh_n_rows, 64);
+    const int need_T = r - TL.sh_cnt; /* contacts to take from the END of row T */
     for (int ri = wv; ri < n_rows; ri += 4) {
-        const int ls = t_rows[ri];
+        const int ls = TL.t_rows[ri];
         const int i = subs[ls];
         const int2 cp1 = tab.cp[i];
         const long long b = rowptr[i], e = rowptr[i + 1];
@@ -1923,23 +1926,23 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
             const int rank = __popcll(mask & ((1ull << lane) - 1ull));
             const int took = min((int)__popcll(mask), remaining);
             int basei = 0;
-            if (lane == 0 && took) basei = atomicAdd(&sh_n_tail, took);
+            if (lane == 0 && took) basei = atomicAdd(&TL.sh_n_tail, took);
             basei = __shfl(basei, 0, 64);
             if (keep && rank < remaining && basei + rank < 64) {
-                t_li[basei + rank] = ls;
-                t_lj[basei + rank] = lj;
-                t_ob[basei + rank] = v.y;
+                TL.t_li[basei + rank] = ls;
+                TL.t_lj[basei + rank] = lj;
+                TL.t_ob[basei + rank] = v.y;
             }
             remaining -= took;
         }
     }
     __syncthreads();
-    n_tail = min(sh_n_tail, 64);
+    n_tail = min(TL.sh_n_tail, 64);
     if (tid == 0 && n_tail != r) g->error = 5; /* the walk must find exactly r contacts */
     if (tid < n_tail) {
-        mb.tail_ent[(size_t)cw * 192 + tid] = t_li[tid];
-        mb.tail_ent[(size_t)cw * 192 + 64 + tid] = t_lj[tid];
-        mb.tail_ent[(size_t)cw * 192 + 128 + tid] = t_ob[tid];
+        mb.tail_ent[(size_t)cw * 192 + tid] = TL.t_li[tid];
+        mb.tail_ent[(size_t)cw * 192 + 64 + tid] = TL.t_lj[tid];
+        mb.tail_ent[(size_t)cw * 192 + 128 + tid] = TL.t_ob[tid];
     }
     if (tid == 0) mb.tail_n[cw] = n_tail;
     }
@@ -1948,7 +1951,7 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
         const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
         long long hi = 0, lo = 0;
         if (lane < n_tail) {
-            const long long q = eval_q(p, hot, mean, col[t_li[lane]], col[t_lj[lane]], cm, t_ob[lane], lgfact_dev(t_ob[lane], lgf_tab), pz,
+            const long long q = eval_q(p, hot, mean, col[TL.t_li[lane]], col[TL.t_lj[lane]], cm, TL.t_ob[lane], lgfact_dev(TL.t_ob[lane], lgf_tab), pz,
                                        ig_tab());
             hi = q >> 32;
             lo = (long long)(unsigned int)q;
@@ -1967,7 +1970,8 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
 __global__ void __launch_bounds__(256) k_tail(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, Glob* g,
                                               MoveBuf mb, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int w_begin)
 {
-    prefinal_tail(rowptr, cc, tab, g, mb, lgf_tab, tail_quirk, pz, w_begin, blockIdx.x, blockIdx.y);
+    __shared__ TailLds T;
+    prefinal_tail(rowptr, cc, tab, g, mb, lgf_tab, tail_quirk, pz, w_begin, blockIdx.x, blockIdx.y, T);
 }
 
 /* k_records: after k_score_list and k_tail: the slot-major records of the commit step */

@@ -433,9 +433,8 @@ __device__ __forceinline__ void screen_publish(const ScreenConst* __restrict__ s
 /* one workgroup of the screening pass: segment `seg` of the slice list of candidate zc (= slot * max_c + c), columns 2 ypair, 2 ypair + 1 */
 __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc, const MoveBuf& mb, ScreenSum* __restrict__ scr,
                                              unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub, int max_c, int w_begin, int seg, int ypair,
-                                             int zc)
+                                             int zc, ScreenLds2& L2)
 {
-    __shared__ ScreenLds2 L2;
     ScreenLds& L = L2.one;
     const int w = w_begin + zc / max_c, c = zc % max_c;
     const int kA = 2 * ypair, kB = kA + 1;
@@ -593,7 +592,8 @@ __global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
     k_screen(const ScreenConst* __restrict__ sc, MoveBuf mb, ScreenSum* __restrict__ scr, unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub,
              int max_c, int w_begin)
 {
-    screen_block(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, blockIdx.x, blockIdx.y, blockIdx.z);
+    __shared__ ScreenLds2 L2;
+    screen_block(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, blockIdx.x, blockIdx.y, blockIdx.z, L2);
 }
 
 /* k_screen and k_tail in ONE launch.  The Q5 tail walk (prefinal_tail: one workgroup per candidate, a chain of dependent
@@ -607,13 +607,16 @@ __global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
                   unsigned* __restrict__ scr_ub, int max_c, int w_begin, int n_tail, const long long* __restrict__ rowptr,
                   const int2* __restrict__ cc, Tables tab, Glob* g, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz)
 {
+    /* one block of LDS for either kind of workgroup (the tail walk's 2.3 KB on top of the screening block's 20.2 KB cost the eighth
+     * workgroup per CU) */
+    __shared__ __align__(16) unsigned char lds_raw[sizeof(ScreenLds2) > sizeof(TailLds) ? sizeof(ScreenLds2) : sizeof(TailLds)];
     const int b = (int)blockIdx.x;
     if (b < n_tail) {
-        prefinal_tail(rowptr, cc, tab, g, mb, lgf_tab, tail_quirk, pz, w_begin, b % max_c, b / max_c);
+        prefinal_tail(rowptr, cc, tab, g, mb, lgf_tab, tail_quirk, pz, w_begin, b % max_c, b / max_c, *(TailLds*)lds_raw);
         return;
     }
     const int s = b - n_tail, ny = (NSLOT + 1) / 2;
-    screen_block(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, s % SLICE_SEG, (s / SLICE_SEG) % ny, s / (SLICE_SEG * ny));
+    screen_block(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, s % SLICE_SEG, (s / SLICE_SEG) % ny, s / (SLICE_SEG * ny), *(ScreenLds2*)lds_raw);
 }
 
 /* k_contend: one workgroup per move slot.  From the screened sums, the exact zero-pixel sums and the exact tail sums: an
