@@ -291,6 +291,8 @@ struct ig_ctx {
     bool nuis_nzb_copied;         /* the step's move was finished outside the batch commit: its NuisHost.nzb was copied from the control block */
     /* tier 0 of the screened pass: the histogram of the cis contacts' distances (NuisHist), valid for the state before the last
      * move of a run once nh_pending_slot's move has been walked (nh_flush_pending) */
+    struct ScreenSum* probe_scr; /* IG_SCREEN_PROBE: scratch outputs of the probe launches of k_screen */
+    unsigned* probe_void;
     struct NuisWorker* worker; /* the helper thread that enqueues a run's next step (ig_hip.hip) */
     /* the NEXT batch of a run of (move, nuisance step) pairs, scored in the background (nuis_bg_launch) while the steps of the
      * current one go on: a second set of batch buffers, a snapshot of the state it is scored against (5 MB at the headline
@@ -415,7 +417,7 @@ struct ig_ctx {
         double total_ms;
         long long n;
         long long seen; /* launches since the timers were reset (timing_every) */
-    } timers[12];
+    } timers[13];
     std::vector<hipEvent_t> ev_pool; /* recycled timer events */
     long long n_batches, n_batch_committed, n_batch_pending, n_batch_predicted;
     int up_moves, up_max_c; /* the uploaded move lists */

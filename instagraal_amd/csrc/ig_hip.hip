@@ -161,8 +161,8 @@ static int dalloc(T** p, size_t n)
         if (dalloc(&(p), (n))) return -1; \
     } while (0)
 
-enum { T_GATHER = 0, T_MUTATE, T_SCORE, T_FINALIZE, T_DELTA, T_APPLY, T_POST, T_COMMIT, T_SLICE, T_ARGMAX, T_SCREEN, T_DIFF, T_COUNT };
-static const char* kTimerNames[T_COUNT] = {"gather", "mutate", "score", "finalize", "delta", "apply", "post", "commit", "slice", "argmax", "screen", "diff"};
+enum { T_GATHER = 0, T_MUTATE, T_SCORE, T_FINALIZE, T_DELTA, T_APPLY, T_POST, T_COMMIT, T_SLICE, T_ARGMAX, T_SCREEN, T_DIFF, T_PROBE, T_COUNT };
+static const char* kTimerNames[T_COUNT] = {"gather", "mutate", "score", "finalize", "delta", "apply", "post", "commit", "slice", "argmax", "screen", "diff", "probe"};
 
 struct TimedLaunch {
     ig_ctx* c;
@@ -303,6 +303,8 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     HIPCK(hipEventCreateWithFlags(&c->ev_exact, hipEventDisableTiming));
     HIPCK(hipEventCreateWithFlags(&c->ev_walk, hipEventDisableTiming));
     c->worker = nullptr;
+    c->probe_scr = nullptr;
+    c->probe_void = nullptr;
     c->last_moved = true;
     memset((void*)&c->mb2, 0, sizeof c->mb2);
     c->stream_bg = nullptr;
@@ -452,6 +454,8 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipFree(c->glob2);
     hipFree(c->touched_bits2);
     hipFree(c->bg_mark);
+    hipFree(c->probe_scr);
+    hipFree(c->probe_void);
     hipFree(c->nh.bins);
     hipFree(c->nh.dh);
     hipFree(c->nh.misc);
@@ -1473,15 +1477,44 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
             }
             int contenders_only = 0;
             if (screen) {
+                const int ny = (NSLOT + 1) / 2;
                 {
                     TimedLaunch t(c, T_SCREEN);
                     if (c->tail_fused)
-                        hipLaunchKernelGGL(k_screen_tail, dim3(max_c * nWp + SLICE_SEG * ((NSLOT + 1) / 2) * max_c * nWp), dim3(SCORE_THREADS), 0, c->stream,
+                        hipLaunchKernelGGL(k_screen_tail, dim3(max_c * nWp + SLICE_SEG * ny * max_c * nWp), dim3(SCORE_THREADS), 0, c->stream,
                                            c->screen_const, c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, max_c, pb, max_c * nWp, c->rowptr, c->cc,
                                            c->tab, c->glob, c->lgf_tab, g_tail_quirk, pz);
                     else
-                        hipLaunchKernelGGL(k_screen, dim3(SLICE_SEG, (NSLOT + 1) / 2, max_c * nWp), dim3(SCORE_THREADS), 0, c->stream, c->screen_const,
+                        hipLaunchKernelGGL(k_screen<0>, dim3(SLICE_SEG, ny, max_c * nWp), dim3(SCORE_THREADS), 0, c->stream, c->screen_const,
                                            c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, max_c, pb);
+                }
+                /* IG_SCREEN_PROBE=mask (tools/screen_probe.py): the screening kernel WITHOUT the parts in the mask, launched behind the real
+                 * one on the same lists and columns, sums into scratch words: timed as "probe" (ig_kernel_time_ms), results untouched */
+                static const int s_probe = getenv("IG_SCREEN_PROBE") ? atoi(getenv("IG_SCREEN_PROBE")) : -1;
+                if (s_probe >= 0) {
+                    const size_t C = (size_t)c->mb.capC * c->mb.capW;
+                    if (!c->probe_scr) {
+                        if (dalloc(&c->probe_scr, C * NSLOT) || dalloc(&c->probe_void, 2 * C)) return;
+                    }
+                    hipMemsetAsync(c->probe_scr, 0, C * NSLOT * sizeof(ScreenSum), c->stream);
+                    hipMemsetAsync(c->probe_void, 0, 2 * C * sizeof(unsigned), c->stream);
+                    TimedLaunch tp(c, T_PROBE);
+                    const dim3 grid(SLICE_SEG, ny, max_c * nWp);
+#define IG_PROBE(A)                                                                                                                                   \
+    hipLaunchKernelGGL(k_screen<A>, grid, dim3(SCORE_THREADS), 0, c->stream, c->screen_const, c->mb, c->probe_scr, c->probe_void, c->probe_void + C, \
+                       max_c, pb)
+                    switch (s_probe) {
+                    case 1: IG_PROBE(1); break;
+                    case 2: IG_PROBE(2); break;
+                    case 3: IG_PROBE(3); break;
+                    case 4: IG_PROBE(4); break;
+                    case 5: IG_PROBE(5); break;
+                    case 6: IG_PROBE(6); break;
+                    case 7: IG_PROBE(7); break;
+                    case 8: IG_PROBE(8); break;
+                    default: IG_PROBE(0); break;
+                    }
+#undef IG_PROBE
                 }
                 if (c->exact_grid <= 0) c->exact_grid = 32768;
                 c->exact_grid = std::max(std::min(c->exact_grid, c->mb.work_cap), exact_grid_floor(c, max_c));

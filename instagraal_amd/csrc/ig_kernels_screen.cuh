@@ -387,25 +387,42 @@ struct alignas(16) ScreenLds2 {
     float red_e2[SCORE_THREADS / 64], red_y2[SCORE_THREADS / 64];
 };
 /* the arithmetic of screen_pair on precomputed LDS byte offsets (o = 8 x local index) for one column */
+/* ABL != 0: probe instances (IG_SCREEN_PROBE, wrong sums into scratch words): what the loop costs without its parts, timed on the
+ * real trajectory next to the real launch -- bit 0: no P_z gather, bit 1: the partner's record made up from the row's (one LDS gather
+ * per entry and column instead of two), bit 2: no transcendental functions, bit 3: no entries (set-up, staging, reduction and
+ * publication only) */
+template <int ABL = 0>
 __device__ __forceinline__ void screen_pair_col(unsigned oi0, unsigned oj0, unsigned oi1, unsigned oj1, f32x2 obf, const char* colb, const char* pzb,
                                                 float slope, float la, float lv, float d_max, float c10, double& acc, f32x2& exs2, float& ymax)
 {
-    const uint2 a0 = *(const uint2*)(colb + oi0), b0 = *(const uint2*)(colb + oj0);
-    const uint2 a1 = *(const uint2*)(colb + oi1), b1 = *(const uint2*)(colb + oj1);
+    const uint2 a0 = *(const uint2*)(colb + oi0), a1 = *(const uint2*)(colb + oi1);
+    uint2 b0, b1;
+    if (ABL & 2) {
+        b0 = make_uint2(a0.x ^ oj0, a0.y + (oj0 & 0xff8u));
+        b1 = make_uint2(a1.x ^ oj1, a1.y + (oj1 & 0xff8u));
+    } else {
+        b0 = *(const uint2*)(colb + oj0);
+        b1 = *(const uint2*)(colb + oj1);
+    }
     const unsigned d0 = abs_diff_u32(a0.y, b0.y), d1 = abs_diff_u32(a1.y, b1.y);
     f32x2 sv; /* scalar subtractions, see screen_pair */
     __asm__("v_sub_f32 %0, %1, %2" : "=v"(sv.x) : "v"(__uint_as_float(a0.x)), "v"(__uint_as_float(b0.x)));
     __asm__("v_sub_f32 %0, %1, %2" : "=v"(sv.y) : "v"(__uint_as_float(a1.x)), "v"(__uint_as_float(b1.x)));
     const bool in0 = (d0 < (1u << 27)) && (sv.x != 0.0f) && (fabsf(sv.x) < d_max);
     const bool in1 = (d1 < (1u << 27)) && (sv.y != 0.0f) && (fabsf(sv.y) < d_max);
-    const f32x2 pzc = {*(const float*)(pzb + min(d0, 4u * LDS_PZ)), *(const float*)(pzb + min(d1, 4u * LDS_PZ))};
-    const f32x2 lg2 = {__builtin_amdgcn_logf(fabsf(sv.x)), __builtin_amdgcn_logf(fabsf(sv.y))};
+    f32x2 pzc, lg2;
+    if (ABL & 1) pzc = f32x2{__uint_as_float(d0 | 0x3f800000u), __uint_as_float(d1 | 0x3f800000u)};
+    else pzc = f32x2{*(const float*)(pzb + min(d0, 4u * LDS_PZ)), *(const float*)(pzb + min(d1, 4u * LDS_PZ))};
+    if (ABL & 4) lg2 = f32x2{fabsf(sv.x) * 0.001f, fabsf(sv.y) * 0.001f};
+    else lg2 = f32x2{__builtin_amdgcn_logf(fabsf(sv.x)), __builtin_amdgcn_logf(fabsf(sv.y))};
     const f32x2 y = __builtin_elementwise_fma(f32x2{slope, slope}, lg2, f32x2{la, la});
     float m0, m1;
     __asm__("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(y.x), "v"(lv));
     __asm__("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(y.y), "v"(lv));
     const f32x2 yy = {in0 ? m0 : lv, in1 ? m1 : lv};
-    const f32x2 ex = {__builtin_amdgcn_exp2f(yy.x), __builtin_amdgcn_exp2f(yy.y)};
+    f32x2 ex;
+    if (ABL & 4) ex = f32x2{yy.x * 1.5f, yy.y * 1.5f};
+    else ex = f32x2{__builtin_amdgcn_exp2f(yy.x), __builtin_amdgcn_exp2f(yy.y)};
     const f32x2 m = obf * yy;
     const f32x2 t = __builtin_elementwise_fma(m, f32x2{c10, c10}, -ex) + pzc;
     float tsum; /* (kept scalar: the vectoriser pairs it with the other column's sum through three v_mov) */
@@ -431,6 +448,7 @@ __device__ __forceinline__ void screen_publish(const ScreenConst* __restrict__ s
     }
 }
 /* one workgroup of the screening pass: segment `seg` of the slice list of candidate zc (= slot * max_c + c), columns 2 ypair, 2 ypair + 1 */
+template <int ABL = 0>
 __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc, const MoveBuf& mb, ScreenSum* __restrict__ scr,
                                              unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub, int max_c, int w_begin, int seg, int ypair,
                                              int zc, ScreenLds2& L2)
@@ -497,7 +515,7 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
 #pragma unroll
     for (int u = 0; u < SCREEN_BATCH; u++) nx[u] = ptr[u * 64];
     unsigned s0 = wave * step;
-    const unsigned nn = (unsigned)n;
+    const unsigned nn = (ABL & 8) ? 0u : (unsigned)n; /* (probe bit 3: no entries at all -- what a workgroup costs before and after its loop) */
     for (; s0 + step <= nn; s0 += stride) { /* full steps: both columns from one pass over the entries */
         ptr += stride;
 #pragma unroll
@@ -511,8 +529,8 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
             nx[u] = ptr[u * 64];
             nx[u + 1] = ptr[(u + 1) * 64];
             obs2 += obf;
-            screen_pair_col(oi0, oj0, oi1, oj1, obf, colA, pzb, slope, la, lv, d_max, c10, accA, exsA, ymaxA);
-            screen_pair_col(oi0, oj0, oi1, oj1, obf, colBb, pzb, slope, la, lv, d_max, c10, accB, exsB, ymaxB);
+            screen_pair_col<ABL>(oi0, oj0, oi1, oj1, obf, colA, pzb, slope, la, lv, d_max, c10, accA, exsA, ymaxA);
+            screen_pair_col<ABL>(oi0, oj0, oi1, oj1, obf, colBb, pzb, slope, la, lv, d_max, c10, accB, exsB, ymaxB);
         }
     }
     float exA = exsA.x + exsA.y, exB = exsB.x + exsB.y, obs = obs2.x + obs2.y;
@@ -588,12 +606,13 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
 #ifndef SCREEN_MIN_WAVES
 #define SCREEN_MIN_WAVES 7 /* seven workgroups per CU (what the LDS admits) need <= 96 SGPRs (106 admit six) */
 #endif
+template <int ABL = 0>
 __global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
     k_screen(const ScreenConst* __restrict__ sc, MoveBuf mb, ScreenSum* __restrict__ scr, unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub,
              int max_c, int w_begin)
 {
     __shared__ ScreenLds2 L2;
-    screen_block(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, blockIdx.x, blockIdx.y, blockIdx.z, L2);
+    screen_block<ABL>(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, blockIdx.x, blockIdx.y, blockIdx.z, L2);
 }
 
 /* k_screen and k_tail in ONE launch.  The Q5 tail walk (prefinal_tail: one workgroup per candidate, a chain of dependent
