@@ -1512,6 +1512,17 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                     case 6: IG_PROBE(6); break;
                     case 7: IG_PROBE(7); break;
                     case 8: IG_PROBE(8); break;
+                    case 16: IG_PROBE(16); break;
+                    case 32: IG_PROBE(32); break;
+                    case 512: IG_PROBE(512); break;
+                    case 1024: IG_PROBE(1024); break;
+                    case 2048: IG_PROBE(2048); break;
+                    case 4096: IG_PROBE(4096); break;
+                    case 1056: IG_PROBE(1056); break; /* 1024 + 32 */
+                    case 96: IG_PROBE(96); break;   /* 32 + 64 */
+                    case 160: IG_PROBE(160); break; /* 32 + 128 */
+                    case 288: IG_PROBE(288); break; /* 32 + 256 */
+                    case 480: IG_PROBE(480); break; /* 32 + 64 + 128 + 256 */
                     default: IG_PROBE(0); break;
                     }
 #undef IG_PROBE

@@ -106,12 +106,16 @@ struct ScreenSum {
 #endif
 struct alignas(16) ScreenLds {
     float pzc[LDS_PZ + 2]; /* first member: copied with 16-byte vectors */
-    uint2 col[LDS_COL_SMALL];
     ColMeta cm[NCODE];
     double red_s[SCORE_THREADS / 64];
     float red_e[SCORE_THREADS / 64], red_y[SCORE_THREADS / 64], red_o[SCORE_THREADS / 64];
     unsigned red_bad[SCORE_THREADS / 64];
+    unsigned pad_[2];
+    /* LAST, and flush with the end of the block: inside a ScreenLds2 the second column's array follows it without a gap, and the
+     * one-column routine stages windows of up to 2 x LDS_COL_SMALL sub-fragments across the two (screen_column) */
+    uint2 col[LDS_COL_SMALL];
 };
+static_assert(sizeof(ScreenLds) == offsetof(ScreenLds, col) + sizeof(uint2) * LDS_COL_SMALL, "col must end the block");
 
 /* one screened term; MASKED: the lane's entry may lie past the end of the list (last, partly filled step) */
 template <bool STAGED, bool HAS_CUT, bool MASKED, bool CIRC = false, bool QUAD = false>
@@ -280,7 +284,11 @@ __device__ __forceinline__ void screen_column(ScreenLds& L, const ScreenConst* _
     if (c >= C || k > n_uniq || n == 0 || off < 0) return;
     if (k > 0 && mb.sinfo[cw * NSLOT + mb.meta[cw].uniq[k - 1]].x == 0) return;
     const uint2* gcol = mb.coords + (size_t)(cw * NSLOT + k) * mb.sM;
-    const bool staged = m_loc <= LDS_COL_SMALL;
+    /* staged: in LDS -- up to LDS_COL_SMALL sub-fragments with the ranks pre-multiplied for the two-terms-at-a-time loop; up to twice
+     * that across the second column's array (the block is always a ScreenLds2's first member) for the one-term loop: windows of
+     * 1 025 .. 2 048 sub-fragments (two grown contigs) were gathered from global memory, a fifth of the launch's time for a few
+     * workgroups at the headline shape (tools/screen_probe.py) */
+    const bool staged = m_loc <= 2 * LDS_COL_SMALL;
     {
         const float4* src = (const float4*)sc->pzc;
         float4* dst = (float4*)L.pzc;
@@ -294,7 +302,7 @@ __device__ __forceinline__ void screen_column(ScreenLds& L, const ScreenConst* _
     /* (a staged window holds at most LDS_COL_SMALL = LDS_PZ sub-fragments: every rank distance inside it is in the LDS copy,
      * however long the table) */
     static_assert(LDS_COL_SMALL <= LDS_PZ, "a staged window's rank distances must lie inside the staged P_z table");
-    const bool pairs = staged;
+    const bool pairs = m_loc <= LDS_COL_SMALL;
     if (staged)
         for (int i = threadIdx.x; i < m_loc; i += SCORE_THREADS) {
             uint2 v = gcol[i];
@@ -322,13 +330,16 @@ __device__ __forceinline__ void screen_column(ScreenLds& L, const ScreenConst* _
     const unsigned long long* slp = mb.sl_pk + off;
     if (circ_mask) {
         if (pairs) screen_loop<true, false, true, false, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad, circ_mask, zc_ub);
+        else if (staged) screen_loop<true, true, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad, circ_mask, zc_ub, far_sc);
         else screen_loop<false, true, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad, circ_mask, zc_ub, far_sc);
     } else if (pairs) {
         screen_loop<true, false, false, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
     } else if (pz_n > LDS_PZ) { /* a P_z table longer than its LDS copy, a window longer than that copy: far pairs from the table itself */
-        screen_loop<false, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad, 0, 0.0f, far_sc);
+        if (staged) screen_loop<true, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad, 0, 0.0f, far_sc);
+        else screen_loop<false, true>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad, 0, 0.0f, far_sc);
     } else {
-        screen_loop<false, false>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
+        if (staged) screen_loop<true, false>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
+        else screen_loop<false, false>(slp, (unsigned)n, gcol, L, slope, la, lv, d_max, cut, acc, exs, obs, ymax, bad);
     }
     for (int o = 32; o > 0; o >>= 1) {
         acc += __shfl_down(acc, o, 64);
@@ -382,7 +393,7 @@ __device__ __forceinline__ void screen_column(ScreenLds& L, const ScreenConst* _
  * two columns' terms); anything else takes the one-column routine, column by column. */
 struct alignas(16) ScreenLds2 {
     ScreenLds one;            /* the one-column routine's block; its pzc table and col[] serve the pair loop as column A */
-    uint2 colB[LDS_COL_SMALL]; /* column B of the pair loop */
+    uint2 colB[LDS_COL_SMALL]; /* column B of the pair loop (directly behind one.col) */
     double red_s2[SCORE_THREADS / 64];
     float red_e2[SCORE_THREADS / 64], red_y2[SCORE_THREADS / 64];
 };
@@ -390,7 +401,7 @@ struct alignas(16) ScreenLds2 {
 /* ABL != 0: probe instances (IG_SCREEN_PROBE, wrong sums into scratch words): what the loop costs without its parts, timed on the
  * real trajectory next to the real launch -- bit 0: no P_z gather, bit 1: the partner's record made up from the row's (one LDS gather
  * per entry and column instead of two), bit 2: no transcendental functions, bit 3: no entries (set-up, staging, reduction and
- * publication only) */
+ * publication only), bit 4: leave behind the first round of loads, bit 5: leave behind the staging's barrier */
 template <int ABL = 0>
 __device__ __forceinline__ void screen_pair_col(unsigned oi0, unsigned oj0, unsigned oi1, unsigned oj1, f32x2 obf, const char* colb, const char* pzb,
                                                 float slope, float la, float lv, float d_max, float c10, double& acc, f32x2& exs2, float& ymax)
@@ -455,38 +466,58 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
 {
     ScreenLds& L = L2.one;
     const int w = w_begin + zc / max_c, c = zc % max_c;
-    const int kA = 2 * ypair, kB = kA + 1;
     const int cw = CW(w, c);
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned step = 64 * SCREEN_BATCH, stride = step * (SCORE_THREADS / 64);
+    /* What a workgroup needs is requested in rounds: everything whose address follows from the block index first (descriptors,
+     * the uniq list, the constants, the P_z table), unconditionally; then the changed flags behind the uniq list; then the two
+     * columns, their ring flags and the first entries.
+     * The pairs are pairs of LIVE columns: a column whose genome is the current genome on the window (k_mutate's changed flag:
+     * a third of them at the headline shape) has column 0's sums and is not screened; paired by index (2 y, 2 y + 1) two pairs in
+     * five had one such column and took the one-column routine -- 80 of the launch's 209 us (tools/screen_probe.py).  Pair y is the
+     * (2 y)-th and (2 y + 1)-th live column instead: only a candidate's last, odd column is left alone. */
+    const CandMeta* mp = &mb.meta[cw];
     const int C = mb.ctl[w].C;
-    const int n_uniq = mb.meta[cw].n_uniq, m_loc = mb.meta[cw].m_loc;
+    const int n_uniq = mp->n_uniq, m_loc = mp->m_loc;
+    const int uq = (lane >= 1 && lane <= IG_N_TMP_STRUCT) ? mp->uniq[lane - 1] : 0; /* lane q: column q's mutation slot */
     const long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + seg];
     const long long off = mb.sloff[(size_t)cw * SLICE_SEG + seg];
-    if (c >= C || kA > n_uniq || n == 0 || off < 0) return;
-    /* which of the two columns there is anything to do for (a column whose genome is the current one has column 0's sums) */
-    const bool doA = kA == 0 || mb.sinfo[cw * NSLOT + mb.meta[cw].uniq[kA - 1]].x != 0;
-    const bool doB = kB <= n_uniq && mb.sinfo[cw * NSLOT + mb.meta[cw].uniq[kB - 1]].x != 0;
-    bool plain = doA && doB && sc->fast && m_loc <= LDS_COL_SMALL; /* (staged: every rank distance is inside the LDS copy of the table) */
-    if (plain) { /* no ring on either window */
-        const ColMeta* cmA = mb.cmeta + (size_t)(cw * NSLOT + kA) * NCODE;
-        const ColMeta* cmB = mb.cmeta + (size_t)(cw * NSLOT + kB) * NCODE;
-        for (int q = 0; q < NCODE; q++) plain &= (cmA[q].stot == 0) && (cmB[q].stot == 0);
-    }
-    if (!plain) {
-        if (doA) screen_column(L, sc, mb, scr, scr_void, scr_ub, w, c, kA, seg);
-        if (doA && doB) __syncthreads(); /* the second column restages the LDS */
-        if (doB) screen_column(L, sc, mb, scr, scr_void, scr_ub, w, c, kB, seg);
-        return;
-    }
     const float slope = sc->slope, la_s = sc->la, lv_s = sc->lv, d_max = sc->d_max;
-    {
-        const float4* src = (const float4*)sc->pzc;
-        float4* dst = (float4*)L.pzc;
-        for (int i = threadIdx.x; i < (LDS_PZ + 2) / 4; i += SCORE_THREADS) dst[i] = src[i];
-        if (threadIdx.x < (LDS_PZ + 2) % 4) L.pzc[(LDS_PZ + 2) / 4 * 4 + threadIdx.x] = sc->pzc[(LDS_PZ + 2) / 4 * 4 + threadIdx.x];
+    const int fast = sc->fast;
+    float4 pz_v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float pz_t = 0.0f;
+    if (!(ABL & 64)) { /* (probe bit 6: no P_z table) */
+        pz_v = ((const float4*)sc->pzc)[threadIdx.x]; /* (LDS_PZ + 2) / 4 = 256 vectors and two more words */
+        pz_t = sc->pzc[(LDS_PZ + 2) / 4 * 4 + (threadIdx.x & 1)];
     }
-    {
+    if (c >= C || 2 * ypair > n_uniq || n == 0 || off < 0) return;
+    if (ABL & 16) return; /* (probe: dispatch and the first round of loads only) */
+    /* second round: which columns are live (uniq entries past n_uniq are stale: index clamped, value unused) */
+    const int chg = (lane >= 1 && (int)lane <= n_uniq) ? mb.sinfo[cw * NSLOT + min(max(uq, 0), NSLOT - 1)].x : 0;
+    const unsigned live = (unsigned)__ballot(lane == 0 || ((int)lane <= n_uniq && chg != 0)); /* (every wave asks the same) */
+    const int n_live = __popc(live);
+    if (2 * ypair >= n_live) return;
+    unsigned rest = live;
+    for (int q = 0; q < 2 * ypair; q++) rest &= rest - 1; /* drop the 2 y lowest set bits */
+    const int kA = __ffs(rest) - 1;
+    rest &= rest - 1;
+    const int kB_real = rest ? __ffs(rest) - 1 : -1;
+    /* a candidate's last, odd column goes through the pair loop next to itself (its second copy is not published): the one-column
+     * routine -- staging again behind a barrier, half the work per fixed cost -- took twice a pair's time for it */
+    const bool doA = true, doB = kB_real >= 0;
+    const int kB = doB ? kB_real : kA;
+    /* third round */
+    const float ring_a = lane < NCODE ? mb.cmeta[(size_t)(cw * NSLOT + kA) * NCODE + lane].stot : 0.0f;
+    const float ring_b = lane < NCODE ? mb.cmeta[(size_t)(cw * NSLOT + max(kB, 0)) * NCODE + lane].stot : 0.0f;
+    const unsigned long long* slp = mb.sl_pk + off;
+    const unsigned long long* ptr = slp + wave * step + lane;
+    unsigned long long nx[SCREEN_BATCH];
+#pragma unroll
+    for (int u = 0; u < SCREEN_BATCH; u++) nx[u] = (ABL & 256) ? 0ull : ptr[u * 64]; /* (the pool has slack behind its last entry; probe bit 8: no entries requested) */
+    const bool small = m_loc <= LDS_COL_SMALL;
+    if (small && !(ABL & 128)) { /* (probe bit 7: no columns) */
         const uint2* gA = mb.coords + (size_t)(cw * NSLOT + kA) * mb.sM;
-        const uint2* gB = mb.coords + (size_t)(cw * NSLOT + kB) * mb.sM;
+        const uint2* gB = mb.coords + (size_t)(cw * NSLOT + max(kB, 0)) * mb.sM;
         for (int i = threadIdx.x; i < m_loc; i += SCORE_THREADS) { /* ranks x 4, see screen_pair */
             uint2 va = gA[i], vb = gB[i];
             va.y = (va.y & 0xf0000000u) | ((va.y & 0x0fffffffu) << 2);
@@ -495,25 +526,38 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
             L2.colB[i] = vb;
         }
     }
+    if (!(ABL & 64)) {
+        ((float4*)L.pzc)[threadIdx.x] = pz_v;
+        if (threadIdx.x < (LDS_PZ + 2) % 4) L.pzc[(LDS_PZ + 2) / 4 * 4 + threadIdx.x] = pz_t;
+    }
+    const bool ring = __any(ring_a != 0.0f || (doB && ring_b != 0.0f)); /* (every wave asks the same eight codes) */
+    const bool plain = fast && small && !ring; /* staged, no ring on either window: the pair loop */
+    if (ABL & 512) return; /* (probe: everything requested and staged, no barrier, no pass of either kind) */
+    if (!plain) {
+        if (ABL & 1024) return; /* (probe: the pairs that take the one-column routine leave) */
+        if ((ABL & 2048) && ring) return; /* (probe: ... those with a ring) */
+        if ((ABL & 4096) && !ring) return; /* (probe: ... those without) */
+        __syncthreads(); /* (everybody is through with the staging above: the one-column routine stages again) */
+        screen_column(L, sc, mb, scr, scr_void, scr_ub, w, c, kA, seg);
+        if (doB) {
+            __syncthreads(); /* the second column restages the LDS */
+            screen_column(L, sc, mb, scr, scr_void, scr_ub, w, c, kB, seg);
+        }
+        return;
+    }
     __syncthreads();
-    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned step = 64 * SCREEN_BATCH, stride = step * (SCORE_THREADS / 64);
+    if (ABL & 32) return; /* (probe: ... and the second round, the staging, the barrier) */
     const float c10 = (float)IG_LOG2_10_INV;
     float la, lv;
     __asm__ volatile("v_mov_b32 %0, %1" : "=v"(la) : "s"(la_s));
     __asm__ volatile("v_mov_b32 %0, %1" : "=v"(lv) : "s"(lv_s));
-    const unsigned long long* slp = mb.sl_pk + off;
-    const unsigned long long* ptr = slp + wave * step + lane;
     const char* colA = (const char*)L.col;
     const char* colBb = (const char*)L2.colB;
     const char* pzb = (const char*)L.pzc;
     double accA = 0.0, accB = 0.0;
-    f32x2 exsA = {0.0f, 0.0f}, exsB = {0.0f, 0.0f}, obs2 = {0.0f, 0.0f};
-    float ymaxA = 0.0f, ymaxB = 0.0f;
+    float ymaxA = 0.0f, ymaxB = 0.0f, exA = 0.0f, exB = 0.0f, obs = 0.0f;
     unsigned bad = 0;
-    unsigned long long nx[SCREEN_BATCH];
-#pragma unroll
-    for (int u = 0; u < SCREEN_BATCH; u++) nx[u] = ptr[u * 64];
+    f32x2 exsA = {0.0f, 0.0f}, exsB = {0.0f, 0.0f}, obs2 = {0.0f, 0.0f};
     unsigned s0 = wave * step;
     const unsigned nn = (ABL & 8) ? 0u : (unsigned)n; /* (probe bit 3: no entries at all -- what a workgroup costs before and after its loop) */
     for (; s0 + step <= nn; s0 += stride) { /* full steps: both columns from one pass over the entries */
@@ -533,7 +577,9 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
             screen_pair_col<ABL>(oi0, oj0, oi1, oj1, obf, colBb, pzb, slope, la, lv, d_max, c10, accB, exsB, ymaxB);
         }
     }
-    float exA = exsA.x + exsA.y, exB = exsB.x + exsB.y, obs = obs2.x + obs2.y;
+    exA += exsA.x + exsA.y;
+    exB += exsB.x + exsB.y;
+    obs += obs2.x + obs2.y;
     if (s0 < nn) { /* the partly filled step: one term at a time, masked */
         const unsigned long long safe = slp[0];
         float obs_dummy = 0.0f;
@@ -589,7 +635,7 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
         L2.red_y2[wave] = ymaxB;
     }
     __syncthreads();
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < (doB ? 2 : 1)) {
         const bool isB = threadIdx.x == 1;
         double S = 0.0, E = 0.0, O = 0.0, Y = 0.0;
         unsigned B = 0;

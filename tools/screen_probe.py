@@ -36,8 +36,14 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 n = sys.argv[2] if len(sys.argv) > 2 else "1200"
 names = {0: "everything (the kernel as it is, without the tail walks)", 1: "no P_z gather", 2: "one record gather per entry and column instead of two",
          3: "no P_z gather, one record gather", 4: "no v_log / v_exp", 5: "no P_z gather, no v_log / v_exp", 6: "one record gather, no v_log / v_exp",
-         7: "none of the three", 8: "no entries at all: set-up, staging, reduction, publication"}
-for mask in range(9):
+         7: "none of the three", 8: "no entries at all: set-up, staging, reduction, publication",
+         16: "dispatch and the first round of loads only", 32: "... and the second round, the staging, its barrier",
+         512: "everything requested and staged; no barrier, no pass", 1024: "the kernel without the pairs that take the one-column routine",
+         1056: "up to the staging's barrier, without those pairs", 2048: "the kernel without the pairs with a ring on a window",
+         4096: "the kernel without a candidate's last, odd column (and other one-column cases without a ring)",
+         96: "... without the P_z table", 160: "... without the columns", 288: "... without the first entries", 480: "... without any of the three"}
+masks = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else list(range(9)) + [16, 32]
+for mask in masks:
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", cfg, n], env=dict(os.environ, IG_SCREEN_PROBE=str(mask)), capture_output=True, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if not line:
