@@ -192,6 +192,8 @@ struct MoveBuf {
     unsigned long long* work;
     int work_cap;
     int* slot_items; /* [capW][8] work items a slot puts on each of the eight sub-lists (k_contend -> k_worklist) */
+    int* order;      /* [capW * capC] the (slot, candidate) pairs of the batch by falling size of their slice lists (w << 8 | c; k_offsets):
+                      * the screening launch hands out the long ones first */
     /* set while the parameter-dependent half of slots scored EARLIER is redone (enqueue_score, par_only): {n, contig ids modified by
      * the moves of this batch committed meanwhile}.  The Q5 tail walk is the one scoring step that reads the live tables: it
      * skips a slot whose contigs are on the list (the decide step stops in front of such a slot anyway) */

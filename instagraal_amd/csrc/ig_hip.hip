@@ -411,6 +411,7 @@ static void free_movebuf(MoveBuf& m)
     hipFree(m.ident);
     hipFree(m.work);
     hipFree(m.slot_items);
+    hipFree(m.order);
     hipFree(m.tail_n);
     hipFree(m.tail_ent);
     memset((void*)&m, 0, sizeof m);
@@ -734,6 +735,8 @@ static int alloc_movebuf(ig_ctx* c, MoveBuf& m, int capC, int capW, int want_pac
     m.work_cap = (int)std::min<size_t>((size_t)1 << 20, 4 * C * NSLOT * SLICE_SEG + 4096);
     DALLOC(m.work, (size_t)m.work_cap + 32);
     DALLOC(m.slot_items, (size_t)capW * 8);
+    DALLOC(m.order, C + (size_t)capW);
+    HIPCK(hipMemset(m.order, 0, (C + (size_t)capW) * sizeof(int)));
     DALLOC(m.tail_n, C);
     DALLOC(m.tail_ent, C * 3 * 64);
     HIPCK(hipMemset(m.tail_n, 0xff, C * sizeof(int)));
@@ -1440,7 +1443,7 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
         if (force_slot < 0 && nW > 0) {
             if (!par_only) {
                 TimedLaunch t(c, T_SLICE);
-                hipLaunchKernelGGL(k_offsets, dim3(1), dim3(OFFSETS_THREADS), 0, c->stream, c->mb, W, w_begin, w_end);
+                hipLaunchKernelGGL(k_offsets, dim3(1), dim3(OFFSETS_THREADS), 0, c->stream, c->mb, W, w_begin, w_end, max_c);
                 /* a wave walks a row (a workgroup 4 rows at a time).  Measured at cfg3 (us per launch of 24 slots): 32 workgroups per
                  * candidate 193, 64: 156, 96: 148, 128: 136, 256 with the chunks of a row dealt to several waves: 146 */
                 static const int s_rb = getenv("IG_SLICE_RB") ? atoi(getenv("IG_SLICE_RB")) : 0;
@@ -1478,15 +1481,18 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
             int contenders_only = 0;
             if (screen) {
                 const int ny = (NSLOT + 1) / 2;
+                /* the long lists first (MoveBuf.order, k_offsets): when this launch screens the slots that one placed */
+                static const int s_order = getenv("IG_SCREEN_ORDER") ? atoi(getenv("IG_SCREEN_ORDER")) : 1;
+                const int use_order = (s_order && !par_only && pb == w_begin && pe == w_end && nWp * max_c <= (int)OFFSETS_THREADS) ? 1 : 0;
                 {
                     TimedLaunch t(c, T_SCREEN);
                     if (c->tail_fused)
                         hipLaunchKernelGGL(k_screen_tail, dim3(max_c * nWp + SLICE_SEG * ny * max_c * nWp), dim3(SCORE_THREADS), 0, c->stream,
                                            c->screen_const, c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, max_c, pb, max_c * nWp, c->rowptr, c->cc,
-                                           c->tab, c->glob, c->lgf_tab, g_tail_quirk, pz);
+                                           c->tab, c->glob, c->lgf_tab, g_tail_quirk, pz, use_order);
                     else
                         hipLaunchKernelGGL(k_screen<0>, dim3(SLICE_SEG, ny, max_c * nWp), dim3(SCORE_THREADS), 0, c->stream, c->screen_const,
-                                           c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, max_c, pb);
+                                           c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, max_c, pb, use_order);
                 }
                 /* IG_SCREEN_PROBE=mask (tools/screen_probe.py): the screening kernel WITHOUT the parts in the mask, launched behind the real
                  * one on the same lists and columns, sums into scratch words: timed as "probe" (ig_kernel_time_ms), results untouched */
@@ -1502,7 +1508,7 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                     const dim3 grid(SLICE_SEG, ny, max_c * nWp);
 #define IG_PROBE(A)                                                                                                                                   \
     hipLaunchKernelGGL(k_screen<A>, grid, dim3(SCORE_THREADS), 0, c->stream, c->screen_const, c->mb, c->probe_scr, c->probe_void, c->probe_void + C, \
-                       max_c, pb)
+                       max_c, pb, use_order)
                     switch (s_probe) {
                     case 1: IG_PROBE(1); break;
                     case 2: IG_PROBE(2); break;

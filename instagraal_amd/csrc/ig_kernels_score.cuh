@@ -410,12 +410,25 @@ __global__ void __launch_bounds__(256) k_mutate_winners(State st, Tables tab, co
 /* k_offsets: where each candidate's slice list starts in the pool = exclusive prefix sum of the upper bounds
  * (one small workgroup; a slot whose lists do not fit is flagged and re-run at the head of the next batch) */
 #define OFFSETS_THREADS 1024
-__global__ void __launch_bounds__(OFFSETS_THREADS) k_offsets(MoveBuf mb, int W, int w_begin, int w_end)
+__global__ void __launch_bounds__(OFFSETS_THREADS) k_offsets(MoveBuf mb, int W, int w_begin, int w_end, int max_c)
 {
     /* entries = (slot, candidate, segment) in this order; thread t owns `per` consecutive entries; exclusive scan of the
      * per-thread sums across the workgroup (wave scans + one LDS step) */
     __shared__ long long wave_tot[OFFSETS_THREADS / 64];
+    __shared__ long long s_tot[IG_MAX_BATCH * IG_MAX_CANDIDATES];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    /* (for the order of the screening launch, below) */
+    const int n_idx = (w_end - w_begin) * max_c;
+    const bool can_order = n_idx <= IG_MAX_BATCH * IG_MAX_CANDIDATES && n_idx <= (int)OFFSETS_THREADS;
+    long long my_tot = 0;
+    if (can_order && tid < n_idx) {
+        const int w = w_begin + tid / max_c, c = tid % max_c;
+        const bool used = c < mb.ctl[w].C;
+        for (int sg = 0; sg < SLICE_SEG; sg++) {
+            const long long b = mb.slbound[(size_t)(w * mb.capC + c) * SLICE_SEG + sg]; /* (requested whether used or not: no wait in front of the scan) */
+            my_tot += (used && b > 0) ? b : 0;
+        }
+    }
     const int n = W * mb.capC * SLICE_SEG;
     const int per = (n + OFFSETS_THREADS - 1) / OFFSETS_THREADS;
     auto bound_of = [&](int i) -> long long {
@@ -461,6 +474,33 @@ __global__ void __launch_bounds__(OFFSETS_THREADS) k_offsets(MoveBuf mb, int W, 
         const int i = tid * per + q;
         if (i < n && bound_of(i) >= 0 && mb.ctl[i / SLICE_SEG / mb.capC].overflow) mb.sloff[i] = -1;
     }
+    /* the (slot, candidate) pairs of this launch by falling list size: the screening kernel's workgroups are as long as their
+     * candidate's lists (two grown contigs: ten times the median), and the long ones handed out last were the launch's tail
+     * (the totals were requested at the top: their round trips ran next to the scan's) */
+    if (can_order) {
+        if (tid < n_idx) s_tot[tid] = my_tot;
+        __syncthreads();
+        if (tid < n_idx) {
+            int rank = 0;
+            for (int u = 0; u < n_idx; u++) rank += (s_tot[u] > my_tot) || (s_tot[u] == my_tot && u < tid);
+            mb.order[rank] = ((w_begin + tid / max_c) << 8) | (tid % max_c);
+        }
+        /* ... and the slots by falling size of all their lists (k_slice's grid: a slot per z) */
+        const int n_slots = w_end - w_begin;
+        long long st = 0;
+        if (tid < n_slots)
+            for (int cc2 = 0; cc2 < max_c; cc2++) st += s_tot[tid * max_c + cc2];
+        __syncthreads();
+        if (tid < n_slots) s_tot[tid] = st;
+        __syncthreads();
+        if (tid < n_slots) {
+            int rank = 0;
+            for (int u = 0; u < n_slots; u++) rank += (s_tot[u] > st) || (s_tot[u] == st && u < tid);
+            mb.order[mb.capC * mb.capW + rank] = w_begin + tid;
+        }
+    } else if (tid < w_end - w_begin) {
+        mb.order[mb.capC * mb.capW + tid] = w_begin + tid;
+    }
 }
 
 #define LDS_COL_CAP 4096  /* local sub-fragments whose column fits the 32 KB LDS stage */
@@ -492,7 +532,7 @@ template <bool PACKED>
 __global__ void __launch_bounds__(256, SLICE_MIN_WAVES) k_slice(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab,
                                                                  Glob* g, MoveBuf mb, int rank, int world, int w_begin, int share_rows, int max_j)
 {
-    const int w = w_begin + blockIdx.z;
+    const int w = mb.order[mb.capC * mb.capW + blockIdx.z]; /* (the slots with the longest rows first: k_offsets; w_begin + z without it) */
     const bool shared_plane = (blockIdx.y == 0); /* first: its waves write every kept contact once per candidate */
     const int cand_plane = (int)blockIdx.y - 1;
     __shared__ long long seg_off[IG_MAX_CANDIDATES][SLICE_SEG];

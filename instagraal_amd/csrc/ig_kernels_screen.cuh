@@ -462,10 +462,12 @@ __device__ __forceinline__ void screen_publish(const ScreenConst* __restrict__ s
 template <int ABL = 0>
 __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc, const MoveBuf& mb, ScreenSum* __restrict__ scr,
                                              unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub, int max_c, int w_begin, int seg, int ypair,
-                                             int zc, ScreenLds2& L2)
+                                             int zc, ScreenLds2& L2, int use_order)
 {
     ScreenLds& L = L2.one;
-    const int w = w_begin + zc / max_c, c = zc % max_c;
+    /* (use_order: the launch covers the slots k_offsets ordered -- the long lists first) */
+    const int oc = use_order ? mb.order[zc] : (((w_begin + zc / max_c) << 8) | (zc % max_c));
+    const int w = oc >> 8, c = oc & 255;
     const int cw = CW(w, c);
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned step = 64 * SCREEN_BATCH, stride = step * (SCORE_THREADS / 64);
@@ -655,10 +657,10 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
 template <int ABL = 0>
 __global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
     k_screen(const ScreenConst* __restrict__ sc, MoveBuf mb, ScreenSum* __restrict__ scr, unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub,
-             int max_c, int w_begin)
+             int max_c, int w_begin, int use_order)
 {
     __shared__ ScreenLds2 L2;
-    screen_block<ABL>(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, blockIdx.x, blockIdx.y, blockIdx.z, L2);
+    screen_block<ABL>(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, blockIdx.x, blockIdx.y, blockIdx.z, L2, use_order);
 }
 
 /* k_screen and k_tail in ONE launch.  The Q5 tail walk (prefinal_tail: one workgroup per candidate, a chain of dependent
@@ -670,7 +672,7 @@ __global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
 __global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
     k_screen_tail(const ScreenConst* __restrict__ sc, MoveBuf mb, ScreenSum* __restrict__ scr, unsigned* __restrict__ scr_void,
                   unsigned* __restrict__ scr_ub, int max_c, int w_begin, int n_tail, const long long* __restrict__ rowptr,
-                  const int2* __restrict__ cc, Tables tab, Glob* g, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz)
+                  const int2* __restrict__ cc, Tables tab, Glob* g, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int use_order)
 {
     /* one block of LDS for either kind of workgroup (the tail walk's 2.3 KB on top of the screening block's 20.2 KB cost the eighth
      * workgroup per CU) */
@@ -681,7 +683,7 @@ __global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
         return;
     }
     const int s = b - n_tail, ny = (NSLOT + 1) / 2;
-    screen_block(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, s % SLICE_SEG, (s / SLICE_SEG) % ny, s / (SLICE_SEG * ny), *(ScreenLds2*)lds_raw);
+    screen_block(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, s % SLICE_SEG, (s / SLICE_SEG) % ny, s / (SLICE_SEG * ny), *(ScreenLds2*)lds_raw, use_order);
 }
 
 /* k_contend: one workgroup per move slot.  From the screened sums, the exact zero-pixel sums and the exact tail sums: an
