@@ -1523,6 +1523,10 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                     case 512: IG_PROBE(512); break;
                     case 1024: IG_PROBE(1024); break;
                     case 2048: IG_PROBE(2048); break;
+                    case 1032: IG_PROBE(1032); break; /* 1024 + 8 */
+                    case 1544: IG_PROBE(1544); break; /* 1024 + 512 + 8 */
+                    case 8192: IG_PROBE(8192); break;
+                    case 8199: IG_PROBE(8199); break; /* 8192 + 7 */
                     case 4096: IG_PROBE(4096); break;
                     case 1056: IG_PROBE(1056); break; /* 1024 + 32 */
                     case 96: IG_PROBE(96); break;   /* 32 + 64 */

@@ -572,8 +572,10 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
             const unsigned oi1 = (lo1 << 3) & 0x7ffff8u, oj1 = __builtin_amdgcn_alignbit(hi1, lo1, 17) & 0x7ffff8u;
             const f32x2 obf = {(float)(hi0 >> 8), (float)(hi1 >> 8)};
             /* unpacked: the next step's entries straight into the same registers (no copy of the look-ahead) */
-            nx[u] = ptr[u * 64];
-            nx[u + 1] = ptr[(u + 1) * 64];
+            if (!(ABL & 8192)) { /* (probe bit 13: the first step's entries again and again -- no loads inside the loop) */
+                nx[u] = ptr[u * 64];
+                nx[u + 1] = ptr[(u + 1) * 64];
+            }
             obs2 += obf;
             screen_pair_col<ABL>(oi0, oj0, oi1, oj1, obf, colA, pzb, slope, la, lv, d_max, c10, accA, exsA, ymaxA);
             screen_pair_col<ABL>(oi0, oj0, oi1, oj1, obf, colBb, pzb, slope, la, lv, d_max, c10, accB, exsB, ymaxB);

@@ -41,6 +41,8 @@ names = {0: "everything (the kernel as it is, without the tail walks)", 1: "no P
          512: "everything requested and staged; no barrier, no pass", 1024: "the kernel without the pairs that take the one-column routine",
          1056: "up to the staging's barrier, without those pairs", 2048: "the kernel without the pairs with a ring on a window",
          4096: "the kernel without a candidate's last, odd column (and other one-column cases without a ring)",
+         1032: "no entries, and without the pairs that take the one-column routine", 1544: "... up to the staging only (no barrier, no reduction, no publication)",
+         8192: "the kernel without the loads of its entries inside the loop", 8199: "... and without P_z gather, record gather, v_log / v_exp",
          96: "... without the P_z table", 160: "... without the columns", 288: "... without the first entries", 480: "... without any of the three"}
 masks = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else list(range(9)) + [16, 32]
 for mask in masks:
