@@ -213,7 +213,9 @@ struct MoveBuf {
 /* layout of MoveBuf.part per candidate (int64 units) */
 #define P_NZ 0                 /* [NSLOT][2] slice sums per column k (k=0: current = "extract") */
 #ifndef SLICE_SEG
-#define SLICE_SEG 16
+#define SLICE_SEG 8 /* 16 until round 3: the screening kernel's workgroups (one per segment, pair of columns and candidate) live as long
+                     * around their pass as in it (tools/screen_probe.py); 32 / 16 / 8 / 4 / 2 segments: k_screen 264 / 197 / 168 / 164 / 242 us,
+                     * 36.9 / 41.3 / 43.3 / 42.6 / 36.0 k moves/s (fewer append cursors cost k_slice) */
 #endif
 #define P_CNT (NSLOT * 2)      /* [SLICE_SEG] kept entries per segment; S_c = their sum (slice_total) */
 #define P_STRIDE (NSLOT * 2 + SLICE_SEG)

@@ -1484,15 +1484,19 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                 /* the long lists first (MoveBuf.order, k_offsets): when this launch screens the slots that one placed */
                 static const int s_order = getenv("IG_SCREEN_ORDER") ? atoi(getenv("IG_SCREEN_ORDER")) : 1;
                 const int use_order = (s_order && !par_only && pb == w_begin && pe == w_end && nWp * max_c <= (int)OFFSETS_THREADS) ? 1 : 0;
+                /* narrow batches (late in an assembly: few long contigs, a conflict at nearly every move): few (segment, pair,
+                 * candidate) triples, each with a long list -- Q workgroups split a segment so that the launch has ~7 000 of them */
+                static const int s_q = getenv("IG_SCREEN_PARTS") ? atoi(getenv("IG_SCREEN_PARTS")) : 0;
+                const int Q = s_q > 0 ? std::min(s_q, 16) : std::max(1, std::min(8, (7000 + SLICE_SEG * ny * max_c * nWp - 1) / (SLICE_SEG * ny * max_c * nWp)));
                 {
                     TimedLaunch t(c, T_SCREEN);
                     if (c->tail_fused)
-                        hipLaunchKernelGGL(k_screen_tail, dim3(max_c * nWp + SLICE_SEG * ny * max_c * nWp), dim3(SCORE_THREADS), 0, c->stream,
+                        hipLaunchKernelGGL(k_screen_tail, dim3(max_c * nWp + SLICE_SEG * Q * ny * max_c * nWp), dim3(SCORE_THREADS), 0, c->stream,
                                            c->screen_const, c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, max_c, pb, max_c * nWp, c->rowptr, c->cc,
-                                           c->tab, c->glob, c->lgf_tab, g_tail_quirk, pz, use_order);
+                                           c->tab, c->glob, c->lgf_tab, g_tail_quirk, pz, use_order, Q);
                     else
-                        hipLaunchKernelGGL(k_screen<0>, dim3(SLICE_SEG, ny, max_c * nWp), dim3(SCORE_THREADS), 0, c->stream, c->screen_const,
-                                           c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, max_c, pb, use_order);
+                        hipLaunchKernelGGL(k_screen<0>, dim3(SLICE_SEG * Q, ny, max_c * nWp), dim3(SCORE_THREADS), 0, c->stream, c->screen_const,
+                                           c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, max_c, pb, use_order, Q);
                 }
                 /* IG_SCREEN_PROBE=mask (tools/screen_probe.py): the screening kernel WITHOUT the parts in the mask, launched behind the real
                  * one on the same lists and columns, sums into scratch words: timed as "probe" (ig_kernel_time_ms), results untouched */
@@ -1505,10 +1509,10 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                     hipMemsetAsync(c->probe_scr, 0, C * NSLOT * sizeof(ScreenSum), c->stream);
                     hipMemsetAsync(c->probe_void, 0, 2 * C * sizeof(unsigned), c->stream);
                     TimedLaunch tp(c, T_PROBE);
-                    const dim3 grid(SLICE_SEG, ny, max_c * nWp);
+                    const dim3 grid(SLICE_SEG * Q, ny, max_c * nWp);
 #define IG_PROBE(A)                                                                                                                                   \
     hipLaunchKernelGGL(k_screen<A>, grid, dim3(SCORE_THREADS), 0, c->stream, c->screen_const, c->mb, c->probe_scr, c->probe_void, c->probe_void + C, \
-                       max_c, pb, use_order)
+                       max_c, pb, use_order, Q)
                     switch (s_probe) {
                     case 1: IG_PROBE(1); break;
                     case 2: IG_PROBE(2); break;

@@ -268,16 +268,30 @@ __device__ __forceinline__ void screen_loop(const unsigned long long* __restrict
     }
 }
 
+/* a workgroup's share of a segment of n entries when Q workgroups split it (narrow batches with long lists: few (segment, pair,
+ * candidate) triples, each long): part q of Q equal parts, cut at multiples of a workgroup's step; the partial sums of the parts
+ * meet in the same atomics as the segments' */
+__device__ __forceinline__ void screen_chunk(long long& n, long long& off, int q, int Q)
+{
+    if (Q <= 1) return;
+    const long long unit = 64 * SCREEN_BATCH * (SCORE_THREADS / 64);
+    const long long per = ((n + Q - 1) / Q + unit - 1) / unit * unit;
+    const long long b = (long long)q * per, e = b + per < n ? b + per : n;
+    off += b < n ? b : n;
+    n = e > b ? e - b : 0;
+}
 /* one column k of candidate (w, c) over segment `seg` of its slice list: stage, stream, publish sum and bound.  Called by
  * every thread of the workgroup (barriers inside). */
 __device__ __forceinline__ void screen_column(ScreenLds& L, const ScreenConst* __restrict__ sc, const MoveBuf& mb, ScreenSum* __restrict__ scr,
-                                              unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub, int w, int c, int k, int seg)
+                                              unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub, int w, int c, int k, int seg, int q = 0,
+                                              int Q = 1)
 {
     const int cw = CW(w, c);
     const int C = mb.ctl[w].C;
     const int n_uniq = mb.meta[cw].n_uniq, m_loc = mb.meta[cw].m_loc;
-    const long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + seg];
-    const long long off = mb.sloff[(size_t)cw * SLICE_SEG + seg];
+    long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + seg];
+    long long off = mb.sloff[(size_t)cw * SLICE_SEG + seg];
+    if (off >= 0) screen_chunk(n, off, q, Q);
     const float slope = sc->slope, la = sc->la, lv = sc->lv, d_max = sc->d_max, cy = sc->cy, pzc_max = sc->pzc_max;
     const int fast = sc->fast, pz_n = sc->pz_n;
     /* a column whose genome is the current genome on the window (k_mutate: nothing changed) has column 0's sums exactly */
@@ -462,7 +476,7 @@ __device__ __forceinline__ void screen_publish(const ScreenConst* __restrict__ s
 template <int ABL = 0>
 __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc, const MoveBuf& mb, ScreenSum* __restrict__ scr,
                                              unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub, int max_c, int w_begin, int seg, int ypair,
-                                             int zc, ScreenLds2& L2, int use_order)
+                                             int zc, ScreenLds2& L2, int use_order, int q = 0, int Q = 1)
 {
     ScreenLds& L = L2.one;
     /* (use_order: the launch covers the slots k_offsets ordered -- the long lists first) */
@@ -482,8 +496,9 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
     const int C = mb.ctl[w].C;
     const int n_uniq = mp->n_uniq, m_loc = mp->m_loc;
     const int uq = (lane >= 1 && lane <= IG_N_TMP_STRUCT) ? mp->uniq[lane - 1] : 0; /* lane q: column q's mutation slot */
-    const long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + seg];
-    const long long off = mb.sloff[(size_t)cw * SLICE_SEG + seg];
+    long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + seg];
+    long long off = mb.sloff[(size_t)cw * SLICE_SEG + seg];
+    if (off >= 0) screen_chunk(n, off, q, Q);
     const float slope = sc->slope, la_s = sc->la, lv_s = sc->lv, d_max = sc->d_max;
     const int fast = sc->fast;
     float4 pz_v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -540,10 +555,10 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
         if ((ABL & 2048) && ring) return; /* (probe: ... those with a ring) */
         if ((ABL & 4096) && !ring) return; /* (probe: ... those without) */
         __syncthreads(); /* (everybody is through with the staging above: the one-column routine stages again) */
-        screen_column(L, sc, mb, scr, scr_void, scr_ub, w, c, kA, seg);
+        screen_column(L, sc, mb, scr, scr_void, scr_ub, w, c, kA, seg, q, Q);
         if (doB) {
             __syncthreads(); /* the second column restages the LDS */
-            screen_column(L, sc, mb, scr, scr_void, scr_ub, w, c, kB, seg);
+            screen_column(L, sc, mb, scr, scr_void, scr_ub, w, c, kB, seg, q, Q);
         }
         return;
     }
@@ -659,10 +674,10 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
 template <int ABL = 0>
 __global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
     k_screen(const ScreenConst* __restrict__ sc, MoveBuf mb, ScreenSum* __restrict__ scr, unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub,
-             int max_c, int w_begin, int use_order)
+             int max_c, int w_begin, int use_order, int Q)
 {
     __shared__ ScreenLds2 L2;
-    screen_block<ABL>(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, blockIdx.x, blockIdx.y, blockIdx.z, L2, use_order);
+    screen_block<ABL>(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, blockIdx.x % SLICE_SEG, blockIdx.y, blockIdx.z, L2, use_order, blockIdx.x / SLICE_SEG, Q);
 }
 
 /* k_screen and k_tail in ONE launch.  The Q5 tail walk (prefinal_tail: one workgroup per candidate, a chain of dependent
@@ -674,7 +689,7 @@ __global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
 __global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
     k_screen_tail(const ScreenConst* __restrict__ sc, MoveBuf mb, ScreenSum* __restrict__ scr, unsigned* __restrict__ scr_void,
                   unsigned* __restrict__ scr_ub, int max_c, int w_begin, int n_tail, const long long* __restrict__ rowptr,
-                  const int2* __restrict__ cc, Tables tab, Glob* g, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int use_order)
+                  const int2* __restrict__ cc, Tables tab, Glob* g, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int use_order, int Q)
 {
     /* one block of LDS for either kind of workgroup (the tail walk's 2.3 KB on top of the screening block's 20.2 KB cost the eighth
      * workgroup per CU) */
@@ -684,8 +699,9 @@ __global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
         prefinal_tail(rowptr, cc, tab, g, mb, lgf_tab, tail_quirk, pz, w_begin, b % max_c, b / max_c, *(TailLds*)lds_raw);
         return;
     }
-    const int s = b - n_tail, ny = (NSLOT + 1) / 2;
-    screen_block(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, s % SLICE_SEG, (s / SLICE_SEG) % ny, s / (SLICE_SEG * ny), *(ScreenLds2*)lds_raw, use_order);
+    const int s = b - n_tail, ny = (NSLOT + 1) / 2, nxq = SLICE_SEG * Q; /* x: segment fastest (block -> XCD), then the part of it */
+    screen_block(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, s % SLICE_SEG, (s / nxq) % ny, s / (nxq * ny), *(ScreenLds2*)lds_raw, use_order,
+                 (s % nxq) / SLICE_SEG, Q);
 }
 
 /* k_contend: one workgroup per move slot.  From the screened sums, the exact zero-pixel sums and the exact tail sums: an
