@@ -257,10 +257,15 @@ struct NuisHost {
 #define NH_MISC 16
 struct NuisHist {
     long long* bins; /* [NH_NB][4] */
-    long long* dh;   /* [LDS_PZ + 1]: cis contacts by rank distance (the last entry: that far or further) */
+    long long* dh;   /* [dh_n + 1]: cis contacts by rank distance (the last entry: that far or further -- with dh_n = the number of
+                      * sub-fragments no contact gets there).  Up to LDS_PZ the evaluation reads P_z from the staged tables, beyond
+                      * (contigs of more than LDS_PZ sub-fragments under a table longer than that) from the tables / the formula */
     long long* misc; /* {cis at distance 0: contacts, counts; cis on a ring; cis outside the binned range; all contacts, their counts;
-                      * contacts with a count beyond the screening term's domain} */
+                      * contacts with a count beyond the screening term's domain; the largest rank distance ever entered (the
+                      * evaluation's loop bound: it never comes down)} */
+    int dh_n;
 };
+#define NH_DH_BLOCKS 8 /* workgroups of k_hist_eval that share the rank distances */
 
 struct ig_ctx {
     int device;

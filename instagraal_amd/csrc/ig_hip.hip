@@ -319,7 +319,7 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->bg_valid = c->spec_adopted = false;
     c->n_accepts = c->bg_accepts = 0;
     c->n_bg_launched = c->n_bg_adopted = 0;
-    c->nh = NuisHist{nullptr, nullptr, nullptr};
+    c->nh = NuisHist{nullptr, nullptr, nullptr, 0};
     c->scratch_hist = nullptr;
     c->nh_valid = false;
     c->nh_pending_slot = -1;
@@ -2296,10 +2296,20 @@ extern "C" int ig_set_nuis_hist(int on)
 }
 static int ensure_nuis_hist(ig_ctx* c)
 {
-    if (c->nh.bins) return 0;
+    const int dh_n = std::max(c->M, LDS_PZ); /* a rank distance is below the number of sub-fragments */
+    if (c->nh.bins && c->nh.dh_n == dh_n) return 0;
+    if (c->nh.bins) {
+        hipFree(c->nh.bins);
+        hipFree(c->nh.dh);
+        hipFree(c->nh.misc);
+        hipFree(c->scratch_hist);
+        c->nh = NuisHist{nullptr, nullptr, nullptr, 0};
+        c->scratch_hist = nullptr;
+    }
     DALLOC(c->nh.bins, (size_t)NH_NB * 4);
-    DALLOC(c->nh.dh, (size_t)LDS_PZ + 1);
+    DALLOC(c->nh.dh, (size_t)dh_n + 1);
     DALLOC(c->nh.misc, NH_MISC);
+    c->nh.dh_n = dh_n;
     DALLOC(c->scratch_hist, 16);
     HIPCK(hipMemset(c->scratch_hist, 0, 16 * sizeof(long long)));
     c->nh_valid = false;
@@ -2401,7 +2411,7 @@ static int launch_nuis_hist(ig_ctx* c, hipStream_t s3)
     if (ensure_nuis_hist(c)) return -1;
     if (!c->nh_valid) {
         HIPCK(hipMemsetAsync(c->nh.bins, 0, (size_t)NH_NB * 4 * sizeof(long long), s3));
-        HIPCK(hipMemsetAsync(c->nh.dh, 0, ((size_t)LDS_PZ + 1) * sizeof(long long), s3));
+        HIPCK(hipMemsetAsync(c->nh.dh, 0, ((size_t)c->nh.dh_n + 1) * sizeof(long long), s3));
         HIPCK(hipMemsetAsync(c->nh.misc, 0, NH_MISC * sizeof(long long), s3));
         hipLaunchKernelGGL(k_hist_build, dim3(2048), dim3(256), 0, s3, c->rowptr, c->cc, c->tab_prev, c->M, c->nh);
         c->nh_valid = true;
@@ -2409,8 +2419,9 @@ static int launch_nuis_hist(ig_ctx* c, hipStream_t s3)
     }
     const int n_zero = std::min(256, std::max(32, c->M / 1024));
     ++c->diff_seq;
-    hipLaunchKernelGGL(k_hist_eval, dim3(n_zero + NH_NB / 256 + 1), dim3(256), 0, s3, c->nh, c->glob, c->full_const, c->score_const, c->diff_const,
-                       c->scratch_hist, c->host_nuis_dev, c->diff_seq, c->tab_prev, c->M, c->scratch_nuis + 2, n_zero, c->scratch_nuis);
+    hipLaunchKernelGGL(k_hist_eval, dim3(n_zero + NH_NB / 256 + NH_DH_BLOCKS), dim3(256), 0, s3, c->nh, c->glob, c->full_const, c->score_const,
+                       c->diff_const, c->scratch_hist, c->host_nuis_dev, c->diff_seq, c->tab_prev, c->M, c->scratch_nuis + 2, n_zero, c->scratch_nuis,
+                       PzTab{c->pz_tab1, c->pz_n1}, PzTab{c->pz_tab, c->pz_n});
     c->nuis_tier = 0;
     return 0;
 }
@@ -3250,8 +3261,8 @@ extern "C" int ig_debug_nuis_hist_check(ig_ctx* c, int64_t* mismatches)
     if (!c->nh.bins || !c->nh_valid) return 0;
     if (nh_flush_pending(c)) return -1;
     HIPCK(hipStreamSynchronize(c->stream3));
-    const size_t nb = (size_t)NH_NB * 4, nd = (size_t)LDS_PZ + 1;
-    NuisHist t{nullptr, nullptr, nullptr};
+    const size_t nb = (size_t)NH_NB * 4, nd = (size_t)c->nh.dh_n + 1;
+    NuisHist t{nullptr, nullptr, nullptr, c->nh.dh_n};
     DALLOC(t.bins, nb);
     DALLOC(t.dh, nd);
     DALLOC(t.misc, NH_MISC);
@@ -3271,7 +3282,9 @@ extern "C" int ig_debug_nuis_hist_check(ig_ctx* c, int64_t* mismatches)
     hipFree(t.dh);
     hipFree(t.misc);
     int64_t bad = 0;
-    for (size_t i = 0; i < a.size(); i++) bad += a[i] != b[i];
+    for (size_t i = 0; i < a.size(); i++)
+        if (i != nb + nd + 7) bad += a[i] != b[i];
+    bad += a[nb + nd + 7] < b[nb + nd + 7]; /* (the largest rank distance ever entered: a loop bound that never comes down) */
     *mismatches = bad;
     return 0;
 }

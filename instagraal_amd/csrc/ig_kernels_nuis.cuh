@@ -486,13 +486,13 @@ struct NhKey {
     int kind; /* 0 trans (not in the histogram), 1 binned, 2 cis at distance 0, 3 cis on a ring, 4 cis outside the binned range */
     int bin, off, d;
 };
-__device__ __forceinline__ NhKey nh_key(bool cis, bool ring, float sv, unsigned d)
+__device__ __forceinline__ NhKey nh_key(bool cis, bool ring, float sv, unsigned d, int dh_n)
 {
     NhKey k;
     k.kind = 0;
     k.bin = 0;
     k.off = 0;
-    k.d = (int)min(d, (unsigned)LDS_PZ);
+    k.d = (int)min(d, (unsigned)dh_n);
     if (!cis) return k;
     if (ring) {
         k.kind = 3;
@@ -528,10 +528,14 @@ __device__ __forceinline__ void nh_apply(const NuisHist& h, const NhKey& k, int 
         atomic_add_ll(&b[2], sign * ob);
         atomic_add_ll(&b[3], sign * (long long)ob * k.off);
         atomic_add_ll(&h.dh[k.d], sign);
+        if (sign > 0 && k.d > LDS_PZ && (long long)k.d > __hip_atomic_load(&h.misc[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax((unsigned long long*)&h.misc[7], (unsigned long long)k.d);
     } else if (k.kind == 2) {
         atomic_add_ll(&h.misc[0], sign);
         atomic_add_ll(&h.misc[1], sign * ob);
         atomic_add_ll(&h.dh[k.d], sign);
+        if (sign > 0 && k.d > LDS_PZ && (long long)k.d > __hip_atomic_load(&h.misc[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax((unsigned long long*)&h.misc[7], (unsigned long long)k.d);
     } else {
         atomic_add_ll(&h.misc[k.kind == 3 ? 2 : 3], sign);
     }
@@ -556,7 +560,7 @@ __global__ void __launch_bounds__(256) k_hist_build(const long long* __restrict_
             if ((unsigned)v.y - 1u >= 16383u) n_big++; /* (the pass is void for good: such a contact is in no bin) */
             if (cp2.x != cp1.x || v.y <= 0) continue;
             const bool ring = ring1 || t.stot[v.x] != 0.0f;
-            const NhKey k = nh_key(true, ring, fabsf(d1 - t.dist[v.x]), abs_diff_u32((unsigned)cp1.y, (unsigned)cp2.y));
+            const NhKey k = nh_key(true, ring, fabsf(d1 - t.dist[v.x]), abs_diff_u32((unsigned)cp1.y, (unsigned)cp2.y), h.dh_n);
             nh_apply(h, k, v.y, 1);
         }
     }
@@ -586,11 +590,12 @@ __global__ void __launch_bounds__(256) k_hist_walk(const long long* __restrict__
     const ColMeta* cmk = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
     const int* subs = mb.subs + (size_t)cw * M;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    auto key_of = [](uint2 a, uint2 b, const ColMeta* cm) {
+    const int dh_n = h.dh_n;
+    auto key_of = [dh_n](uint2 a, uint2 b, const ColMeta* cm) {
         const int ci = (int)(a.y >> 28), cj = (int)(b.y >> 28);
         const bool cis = ci == cj;
         return nh_key(cis, cis && cm[ci].stot != 0.0f, fabsf(__uint_as_float(a.x) - __uint_as_float(b.x)),
-                      abs_diff_u32(a.y & 0x0fffffffu, b.y & 0x0fffffffu));
+                      abs_diff_u32(a.y & 0x0fffffffu, b.y & 0x0fffffffu), dh_n);
     };
     for (int r = blockIdx.x * (blockDim.x >> 6) + wv; r < m_loc; r += gridDim.x * (blockDim.x >> 6)) {
         const int i = subs[r];
@@ -617,7 +622,8 @@ __global__ void __launch_bounds__(256) k_hist_walk(const long long* __restrict__
  * of bins, one block for the rank-distance histogram. */
 __global__ void __launch_bounds__(256) k_hist_eval(NuisHist h, const Glob* g, const ScoreConst* __restrict__ sc_t, const ScoreConst* __restrict__ sc_c,
                                                    const DiffConst* __restrict__ dc, long long* out16, NuisHost* hn, int hn_seq, Tables zt, int M,
-                                                   long long* zero_out, int n_zero_blocks, const long long* __restrict__ zero_sums)
+                                                   long long* zero_out, int n_zero_blocks, const long long* __restrict__ zero_sums, PzTab pz_t,
+                                                   PzTab pz_c)
 {
     __shared__ double red[5][4];
     __shared__ unsigned red_bad[4];
@@ -732,13 +738,23 @@ __global__ void __launch_bounds__(256) k_hist_eval(NuisHist h, const Glob* g, co
                 if (!(__builtin_fabs(S) < 1e15) || !(E < 1e12)) bad |= 4u | 64u; /* not a number */
                 E += 1e-13 * mag;
             }
-        } else if (ok) { /* the last block: P_z by rank distance */
-            for (int d = tid; d <= LDS_PZ; d += 256) {
+        } else if (ok) { /* the last blocks: P_z by rank distance -- the staged entries where the tables end inside the staged part (the
+                          * trans level from there on), table / formula as the contract's own rare path reads them (pz_lookup) beyond */
+            const int j = bb - NH_NB / 256, nj = (int)gridDim.x - n_zero_blocks - NH_NB / 256;
+            const int d_end = min(h.dh_n, max(LDS_PZ, (int)h.misc[7]));
+            const bool staged_all = dc->cut == 0xffffffffu;
+            for (int d = j * 256 + tid; d <= d_end; d += nj * 256) {
                 const long long n = h.dh[d];
                 if (n < 0) bad |= 4u;
                 if (n > 0) {
-                    if (d == LDS_PZ && dc->cut != 0xffffffffu) bad |= 2u; /* a rank distance beyond the tables' staged part */
-                    const double pt = sc_t->tab.pzc[d], pc = sc_c->tab.pzc[d];
+                    double pt, pc;
+                    if (d < LDS_PZ || staged_all) {
+                        pt = sc_t->tab.pzc[min(d, LDS_PZ)];
+                        pc = sc_c->tab.pzc[min(d, LDS_PZ)];
+                    } else {
+                        pt = (double)pz_lookup(pz_t, sc_t->par, sc_t->mean_kb, d) * IG_LOG_E_F;
+                        pc = (double)pz_lookup(pz_c, sc_c->par, sc_c->mean_kb, d) * IG_LOG_E_F;
+                    }
                     S += (pt - pc) * (double)n;
                     E += 1e-13 * (__builtin_fabs(pt) + __builtin_fabs(pc)) * (double)n;
                 }
@@ -794,7 +810,9 @@ __global__ void __launch_bounds__(256) k_hist_eval(NuisHist h, const Glob* g, co
                             n_big = h.misc[6];
             unsigned bad = (unsigned)o[4];
             if (!dc->ok0) bad |= 1u;
-            if (n_ring != 0 || n_out != 0 || n_big != 0) bad |= 2u;
+            if (n_ring != 0) bad |= 2u | 1024u; /* (bits from 16 up: which test it was, for the trace) */
+            if (n_out != 0) bad |= 2u | 2048u;
+            if (n_big != 0) bad |= 2u | 4096u;
             const long long n_tr = n_all - (o[5] + n_zero + n_ring + n_out), ob_tr = ob_all - (o[6] + ob_zero);
             if (n_tr < 0 || ob_tr < n_tr || n_zero < 0 || ob_zero < n_zero || n_all <= 0) bad |= 4u | 256u;
             if (!(__builtin_fmax(hc.log2_v_inter, ht.log2_v_inter) <= 17.5) || !(__builtin_fmin(hc.log2_v_inter, ht.log2_v_inter) >= -100.0)) bad |= 4u | 32u;

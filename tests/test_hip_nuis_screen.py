@@ -133,3 +133,25 @@ def test_screened_pass_at_the_headline_shape(monkeypatch):
     assert st["largest_used_fraction"] < 0.5 and st["hist"]["largest_used_fraction"] <= 1.0
     assert st["hist_mismatch"] == 0 and st2["hist_mismatch"] == 0
     assert st2["hist"]["rejected"] + st2["hist"]["accepted"] > 0.5 * st2["screened"]
+
+
+def test_histogram_tier_with_rank_distances_beyond_the_staged_table(monkeypatch):
+    """contigs of ~6 000 sub-fragments with contacts up to 11 000 ranks apart, under parameters whose P_z table is longer than the
+    1 024 entries the kernels stage (d_max / mean sub-fragment size beyond PZ_MAX: table up to 4 096 ranks, the formula behind it) --
+    what a chain settles into (soak at cfg3: d_max 2.9e6 kb) once a contig has grown past 1 024 sub-fragments.  The histogram keeps
+    every rank distance apart and its evaluation reads P_z the way the contract's rare path does: no step is void, the bound holds
+    (verify mode), results unchanged"""
+    from instagraal_amd import synth
+
+    prob = synth.make_problem(4000, 300_000, seed=11, mean_contig_len=2000, max_cis_kb=20000.0)
+    amp = prob.params["c1"] * prob.params["fact"]
+    params = dict(prob.params, slope=-0.53, d_max=3.0e6, v_inter=float(amp * 3.0e6 ** -0.53))  # (P(d_max) = the trans level, as the chain keeps it)
+    exact, _ = _run(prob, 150, 13, "exact", monkeypatch, params=params)
+    verified, st = _run(prob, 150, 13, "verify", monkeypatch, params=params)
+    screened, st2 = _run(prob, 150, 13, "screened", monkeypatch, params=params)
+    assert verified == exact and screened == exact
+    print("long contigs, long table: verify", st, "\n   screened", st2)
+    assert st["hist"]["evaluated"] == 150 and st["hist"]["void_why"]["contact"] == 0 and st2["hist"]["void_why"]["contact"] == 0
+    assert st["hist"]["void"] <= 5 and st2["hist"]["void"] <= 5  # (a proposal outside the one-log domain now and then)
+    assert st["hist"]["largest_used_fraction"] <= 1.0 and st["hist_mismatch"] == 0 and st2["hist_mismatch"] == 0
+    assert st2["hist"]["rejected"] + st2["hist"]["accepted"] > 0.5 * st2["screened"]

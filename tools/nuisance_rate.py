@@ -38,11 +38,12 @@ if hasattr(s, "nuis_profile"):
     print("   host time per move: " + ", ".join("%s %.0f us" % (k, 1e6 * v / n) for k, v in s.nuis_profile.items()) + " (sum %.0f us)" % (1e6 * tot / n))
 s.nuis_step_trace = []
 if os.environ.get("NUIS_LONG"):  # the rate as the chain settles: chunks of 600 moves
+    CH = int(os.environ.get("NUIS_CHUNK", "600"))  # moves per call
     for k in range(int(os.environ["NUIS_LONG"])):
-        fr = np.random.permutation(prob.n_frags)[:600]
+        fr = np.random.permutation(prob.n_frags)[:CH]
         w0 = s.ctx.debug_nuis_wait()
         t0 = time.perf_counter()
-        res, tup = s.step_sampler_nuisance_batch(fr, 5, s.dt, 0, 600)
+        res, tup = s.step_sampler_nuisance_batch(fr, 5, s.dt, 0, CH)
         dt = time.perf_counter() - t0
         tr = np.array(s.nuis_step_trace)
         s.nuis_step_trace.clear()
@@ -52,11 +53,11 @@ if os.environ.get("NUIS_LONG"):  # the rate as the chain settles: chunks of 600 
             np.median(acc) if len(acc) else 0, acc.mean() if len(acc) else 0))
         edges = [0, 80, 120, 200, 300, 450, 700, 1e9]
         hh = np.histogram(tr[:, 0] * 1e6, edges)[0]
-        tot = [float((tr[(tr[:, 0] * 1e6 >= a) & (tr[:, 0] * 1e6 < b), 0] * 1e6).sum()) / 600 for a, b in zip(edges[:-1], edges[1:])]
+        tot = [float((tr[(tr[:, 0] * 1e6 >= a) & (tr[:, 0] * 1e6 < b), 0] * 1e6).sum()) / CH for a, b in zip(edges[:-1], edges[1:])]
         print("            steps by duration (us) " + ", ".join("<%g: %d (%.0f us/step)" % (b, n_, t_) for b, n_, t_ in zip(edges[1:], hh, tot)))
         print("   chunk %d: %.0f moves/s, accept %.2f, device wait %.0f us/move, host %s, %s" % (
-            k, 600 / dt, np.mean([q[6] for q in tup]), 1e6 * (s.ctx.debug_nuis_wait() - w0) / 600,
-            ", ".join("%s %.0f" % (a, 1e6 * v / 600) for a, v in s.nuis_profile.items()), s.ctx.debug_nuis_screen_stats()), flush=True)
+            k, CH / dt, np.mean([q[6] for q in tup]), 1e6 * (s.ctx.debug_nuis_wait() - w0) / CH,
+            ", ".join("%s %.0f" % (a, 1e6 * v / CH) for a, v in s.nuis_profile.items()), s.ctx.debug_nuis_screen_stats()), flush=True)
         print("            histogram tier:", s.ctx.debug_nuis_hist_stats(), flush=True)
         print("            parameters now:", {k: float(s.param_simu[k][0]) for k in s.param_simu.dtype.names}, flush=True)
         ss = s.ctx.debug_screen_stats()

@@ -49,5 +49,8 @@ for c in range(ncycles):
     check("nuisance %d" % c, time.perf_counter() - t0, n)
     print("             host per move: " + ", ".join("%s %.0f us" % (k, 1e6 * v / n) for k, v in s.nuis_profile.items()) +
           "; of the library call %.0f us waiting for the device" % (1e6 * (s.ctx.debug_nuis_wait() - w0) / n))
+    print("             screened pass %s" % (s.ctx.debug_nuis_screen_stats(),))
+    print("             histogram tier %s" % (s.ctx.debug_nuis_hist_stats(),))
+    print("             batches %s" % (s.ctx.batch_stats(),))
     print("             accepted %.2f of the nuisance steps; parameters %s" % (np.mean([q[6] for q in tup]), [float(s.param_simu[k][0]) for k in ("fact", "slope", "d_max", "v_inter")]))
 print("soak ok")
