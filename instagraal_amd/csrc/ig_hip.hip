@@ -2278,7 +2278,10 @@ static bool nuis_hist_usable(ig_ctx* c)
      * there, 3.9 k without.  With hysteresis; a histogram that is switched off is dropped (the walks stop) and rebuilt when it
      * comes back. */
     const double Z = (double)c->Z, nc = (double)std::max(c->n_contigs_seen, 1), p = c->nh_p_changed;
-    const double t0 = 16.0 + p * (2.0 * Z / nc) * 10.0 / 24e3, t1 = 20.0 + Z * 8.0 * 0.4 / 5e6;
+    /* (the pass over the contacts is void where a table is longer than its staged part and a contig longer than that -- it reads P_z
+     * by rank distance from LDS only -- and the exact pass, ~2.5 x the float one, runs instead; the histogram keeps every rank distance) */
+    const bool t1_void = std::max(c->pz_n, c->pz_n1) > LDS_PZ && c->max_SL > LDS_PZ;
+    const double t0 = 16.0 + p * (2.0 * Z / nc) * 10.0 / 24e3, t1 = 20.0 + Z * 8.0 * 0.4 / 5e6 * (t1_void ? 2.5 : 1.0);
     if (c->n_contigs_seen <= 0) return c->nh_policy_on; /* (no batch decided yet) */
     if (c->nh_policy_on ? t0 > 1.25 * t1 : t0 < 0.8 * t1) {
         c->nh_policy_on = !c->nh_policy_on;
