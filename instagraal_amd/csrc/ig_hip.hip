@@ -1666,6 +1666,15 @@ static void launch_commit(ig_ctx* c, int done, int w_now, int next, int resumed_
     nh_untracked_move(c);
     flush_pending_sums(c);
     TimedLaunch t(c, T_COMMIT);
+    static const int s_fused = getenv("IG_FUSED_COMMIT") ? atoi(getenv("IG_FUSED_COMMIT")) : 1;
+    if (s_fused && !(c->own_begin > 0 || c->own_end < w_now)) { /* one launch: a wave decides, a wave applies behind it (k_decide_commit) */
+        const int seq = ++c->bo_seq;
+        hipLaunchKernelGGL(k_decide_commit, dim3(1), dim3(64 + FUSED_CW * 64), 0, c->stream, c->glob, c->mb, c->d_results, done, w_now, next, c->dirty_buf,
+                           c->batch_out, (volatile int*)c->host_bo_dev, seq, resumed_plain, c->st, c->tab, c->tab_prev, c->init_prev, c->init_next,
+                           c->orientable, c->black, c->own_tag, c->own_idx, c->prev_touched, publish ? c->host_nuis_dev : nullptr,
+                           publish ? ++c->res_seq : 0);
+        return;
+    }
     hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(64), 0, c->stream, c->glob, c->mb, c->d_results, done, w_now, next, c->dirty_buf,
                        c->batch_out, (volatile int*)c->host_bo_dev, ++c->bo_seq, resumed_plain);
     if (c->own_begin > 0 || c->own_end < w_now)

@@ -337,9 +337,28 @@ __device__ __forceinline__ void wave_argmax_step(double& v, int& i)
 #endif
 /* step 1 of the batch commit: ONE wave (it may use the whole register file: the data of the next move is held in
  * registers while the current one is decided) */
-__global__ void __launch_bounds__(64)
-    k_decide_batch(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out,
-                   volatile int* host_out, int seq, int resumed_plain)
+/* FUSED (k_decide_commit): the wave hands every decision to the commit wave of its workgroup through LDS -- the record, the few
+ * words of the control block the apply step reads, then prog[0] = slots decided so far; prog[1] = 1 + the final count once it is
+ * through.  LDS operations of a wave complete in order: no fence (a release would wait for the prefetches of the next three
+ * moves, i.e. one memory round trip per decision: measured 38 k instead of 43 k moves/s).  The record goes to memory from the
+ * commit wave alone (two waves storing to the same words without a fence between them land in either order). */
+struct FusedLds {
+    volatile int prog[2];
+    volatile int bar[3 * IG_MAX_BATCH + 2]; /* arrivals at the commit waves' barriers (three per move, one behind their prologue) */
+    long long delta[IG_MAX_BATCH];          /* a move's change of the genome-distance credits, summed over the commit waves */
+    int fin_max_L, fin_max_SL;
+    ig_move_result rec[IG_MAX_BATCH];
+    int ch_c[IG_MAX_BATCH], ch_slot[IG_MAX_BATCH], ch_k[IG_MAX_BATCH], n_dirty[IG_MAX_BATCH], vmask[IG_MAX_BATCH];
+    long long nzb_hi[IG_MAX_BATCH], nzb_lo[IG_MAX_BATCH];
+    /* the statistics columns, summed over the candidates ahead of the decisions (they depend on the stale-flag mask of the decision
+     * through candidate 0's list length alone: its terms apart) */
+    long long st_sc[IG_MAX_BATCH], st_ev[IG_MAX_BATCH], st_by[IG_MAX_BATCH];
+    long long s0_slice[IG_MAX_BATCH];
+    int s0_mloc[IG_MAX_BATCH], s0_base[IG_MAX_BATCH];
+};
+template <bool FUSED>
+__device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out,
+                                            volatile int* host_out, int seq, int resumed_plain, FusedLds* sh)
 {
     /* w_start > 0: slot w_start - 1 was the pending move, meanwhile applied by the one-move kernels; the rest of the batch
      * is still valid wherever it does not touch a contig modified so far (dirty_buf carries the list across the calls).
@@ -559,6 +578,8 @@ __global__ void __launch_bounds__(64)
                 ev = rl64(wave_sum_ll(ev), 0);
                 by = rl64(wave_sum_ll(by), 0);
             }
+            long long nzb_hi_w = 0, nzb_lo_w = 0;
+            const unsigned vmask_w = vmask; /* the stale flags this move was scored under (vmask moves on below) */
             if (lane == 0) {
                 MoveCtl& o = mb.ctl[w];
                 o.ch_c = bc;
@@ -573,6 +594,8 @@ __global__ void __launch_bounds__(64)
                 o.d_lo = 0;
                 o.nzb_hi = nz_hi; /* the state this move was scored against (the nuisance step's screened pass starts from it) */
                 o.nzb_lo = nz_lo;
+                nzb_hi_w = nz_hi;
+                nzb_lo_w = nz_lo;
                 o.n_dirty = br_changed;
                 o.pad = (int)vmask; /* the stale flags this move was scored under */
                 if (br.k <= 0) g->error = 3; /* an unscored slot won: cannot happen */
@@ -619,7 +642,18 @@ __global__ void __launch_bounds__(64)
                 r.bytes_min = 68LL * b_nloc;
                 r.error = err0;
                 r.pad = 0;
-                res[move0 + w] = r;
+                if (FUSED) {
+                    sh->rec[w] = r;
+                    sh->ch_c[w] = bc;
+                    sh->ch_slot[w] = bslot;
+                    sh->ch_k[w] = br.k;
+                    sh->n_dirty[w] = br_changed;
+                    sh->vmask[w] = (int)vmask_w;
+                    sh->nzb_hi[w] = nzb_hi_w;
+                    sh->nzb_lo[w] = nzb_lo_w;
+                } else {
+                    res[move0 + w] = r;
+                }
             }
             if (br_changed) {
 #pragma unroll
@@ -630,6 +664,10 @@ __global__ void __launch_bounds__(64)
                 n_dirty += 2;
             }
             committed = w + 1;
+            if (FUSED) { /* the record of slot w is in LDS: the commit wave may apply it */
+                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) sh->prog[0] = w + 1;
+            }
             return true;
         };
         /* three moves in flight, each in its OWN registers (a rotation `cur = nxt` made the compiler wait for every
@@ -689,7 +727,21 @@ __global__ void __launch_bounds__(64)
             }
         }
         if (lane < 12) g->valid_insert[lane] = ((vmask >> lane) & 1u) ? 1 : -1;
+        if (FUSED) {
+            if (lane == 0) {
+                sh->fin_max_L = max_L;
+                sh->fin_max_SL = max_SL;
+            }
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) sh->prog[1] = committed + 1;
+        }
     }
+}
+__global__ void __launch_bounds__(64)
+    k_decide_batch(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out,
+                   volatile int* host_out, int seq, int resumed_plain)
+{
+    decide_body<false>(g, mb, res, move0, W, w_start, dirty_buf, batch_out, host_out, seq, resumed_plain, nullptr);
 }
 
 /* step 2 of the batch commit: one workgroup applies the moves [w_start, batch_out[0]) k_decide_batch committed */
@@ -887,6 +939,268 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
             hn->res_seq = hn_seq;
         }
     }
+}
+
+/* k_decide_commit: both steps in ONE launch.  The decide wave is a chain of 24 decisions (2 us each) during which nothing else ran,
+ * the apply step (one workgroup) a chain of dependent loads of its own that could not start before the last decision.  Here eight
+ * more waves work behind the decide wave: as a decision arrives (through LDS) they write its record and, for a move that changes
+ * the genome, its ownership marks and the credits of the genome distance it can change -- k_commit_batch's steps 2a / 2b / 2d,
+ * which read the state as of the batch's start through the marks -- so that what is left behind the last decision is the catch-up
+ * of tab_prev and the winners' copy into the live state (2c).  Same words in memory as the two kernels leave (every batch-path
+ * golden and the W = 1 comparisons run through it). */
+#define FUSED_CW 7 /* commit waves of k_decide_commit (a move is applied by all of them: its loops are k_commit_batch's, 512 threads wide) */
+/* a barrier of the commit waves alone (the decide wave never waits): arrivals counted in LDS, one word per use */
+__device__ __forceinline__ void cw_barrier(FusedLds* sh, int id)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) atomicAdd((int*)&sh->bar[id], 1);
+    while (sh->bar[id] < FUSED_CW) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_prev, Glob* g, MoveBuf mb, const int* __restrict__ ip,
+                                             const int* __restrict__ in, const int* __restrict__ orientable, const unsigned char* __restrict__ black,
+                                             int* own_tag, int* own_idx, int* prev_touched, ig_move_result* res, int move0, int W, int w_start,
+                                             NuisHost* hn, int hn_seq, FusedLds* sh)
+{
+    const int lane = threadIdx.x & 63, ctid = (int)threadIdx.x - 64, cwv = ctid >> 6;
+    constexpr int NCT = FUSED_CW * 64;
+    /* the statistics columns of every slot, ahead of the decisions (k_commit_batch 2d): 16 lanes per slot */
+    for (int w = w_start + (ctid >> 4); w < W; w += NCT / 16) {
+        const int c = lane & 15;
+        const int C = mb.ctl[w].C;
+        long long Sc = 0, ev = 0, by = 0;
+        if (c < C) {
+            const CandMeta& m = mb.meta[CW(w, c)];
+            const CandPre& cp = cpre_at(mb, CW(w, c));
+            const bool apart = (c == 0) && mb.ctl[w].superset0;
+            Sc = cp.n_slice;
+            if (!apart) {
+                ev = cp.n_slice * (m.n_uniq + 1);
+                by = 12 * cp.n_slice + 20LL * m.m_loc * m.n_uniq + 8LL * m.n_uniq;
+            }
+            if (c == 0) {
+                sh->s0_slice[w] = cp.n_slice;
+                sh->s0_mloc[w] = m.m_loc;
+                sh->s0_base[w] = cp.base_cnt;
+            }
+        }
+        for (int o = 8; o > 0; o >>= 1) { /* over the 16 lanes of the slot */
+            Sc += __shfl_xor(Sc, o, 64);
+            ev += __shfl_xor(ev, o, 64);
+            by += __shfl_xor(by, o, 64);
+        }
+        if (c == 0) {
+            sh->st_sc[w] = Sc;
+            sh->st_ev[w] = ev;
+            sh->st_by[w] = by;
+        }
+    }
+    const int tag_base = g->stamp_ctr;
+    long long c2 = g->credit2; /* (used by the first commit wave's lane 0) */
+    const double norm = 3.0 * (double)(g->N - g->n_black);
+    const int N = mb.sN, M = mb.sM;
+    int processed = w_start;
+    long long hn_last_sc = 0, hn_last_ev = 0, hn_last_by = 0; /* (lane 0 of the first commit wave: the last applied move's statistics) */
+    cw_barrier(sh, 3 * IG_MAX_BATCH); /* (the statistics are in LDS) */
+#ifdef FUSED_PROBE
+    return;
+#endif
+    auto winner_loc = [&](int w) -> const int* { return mb.loc + ((size_t)(CW(w, sh->ch_c[w]) * NSLOT + sh->ch_slot[w]) * NDYN) * N; };
+    /* While the decisions come in: a move that changes the genome gets its ownership marks and its credits -- evaluated through the
+     * marks on the state as of the batch's start, as k_commit_batch does (nothing is applied yet: a later move's marks, written
+     * while an earlier one's credits are still being read, say "later" to them either way) -- and every move its record. */
+    for (;;) {
+        int upto, fin;
+        for (;;) {
+            fin = sh->prog[1]; /* (first: a final count read before the last progress word misses nothing, the other way round could) */
+            upto = sh->prog[0];
+            if (upto > processed || fin) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __asm__ volatile("" ::: "memory");
+        if (fin) upto = fin - 1;
+        for (int w = processed; w < upto; w++) {
+#ifdef FUSED_PROBE2
+            if (false) {
+#else
+            if (sh->n_dirty[w]) {
+#endif
+                const int cw = CW(w, sh->ch_c[w]);
+                const int n_loc = mb.meta[cw].n_loc;
+                const int* gid = mb.Lloc + (size_t)cw * N;
+                const int* wl = winner_loc(w);
+                for (int x = ctid; x < n_loc; x += NCT) {
+                    const int f = gid[x];
+                    own_tag[f] = tag_base + w;
+                    own_idx[f] = x;
+                }
+                cw_barrier(sh, 3 * w);
+                auto changed_member = [&](int y) -> bool {
+                    if (y < 0 || own_tag[y] != tag_base + w) return false;
+                    const int xi = own_idx[y];
+                    return wl[(size_t)5 * N + xi] != st.prev[y] || wl[(size_t)6 * N + xi] != st.next[y] || wl[(size_t)10 * N + xi] != st.ori[y];
+                };
+                long long d = 0;
+                for (int item = ctid; item < 3 * n_loc; item += NCT) {
+                    const int x0 = item / 3;
+                    const int f0 = gid[x0];
+                    if (wl[(size_t)5 * N + x0] == st.prev[f0] && wl[(size_t)6 * N + x0] == st.next[f0] && wl[(size_t)10 * N + x0] == st.ori[f0])
+                        continue;
+                    const int q = item % 3;
+                    const int f = (q == 0) ? f0 : ((q == 1) ? ip[f0] : in[f0]);
+                    if (f < 0 || black[f]) continue;
+                    if (q > 0) {
+                        if (changed_member(f)) continue;
+                        if (q == 2 && (ip[f0] == f || changed_member(in[f]))) continue;
+                    }
+                    auto view_at = [&](int t) {
+                        return [=](int x) -> int3 {
+                            const int tg = own_tag[x] - tag_base;
+                            if (tg >= 0 && tg <= t) {
+                                const int* b = winner_loc(tg);
+                                const int xi = own_idx[x];
+                                return make_int3(b[(size_t)5 * N + xi], b[(size_t)6 * N + xi], b[(size_t)10 * N + xi]);
+                            }
+                            return make_int3(st.prev[x], st.next[x], st.ori[x]);
+                        };
+                    };
+                    d += credit2_view(view_at(w), ip, in, orientable, f) - credit2_view(view_at(w - 1), ip, in, orientable, f);
+                }
+                d = wave_sum_ll(d);
+                if (lane == 0 && d) atomicAdd((unsigned long long*)&sh->delta[w], (unsigned long long)d);
+                cw_barrier(sh, 3 * w + 1); /* (the move's sum is complete) */
+            }
+            if (ctid == 0) {
+                const unsigned vmask = (unsigned)sh->vmask[w];
+                long long Sc = sh->st_sc[w], ev = sh->st_ev[w], by = sh->st_by[w];
+                if (mb.ctl[w].superset0) { /* candidate 0 as the reference would have scored it: its list under the stale flags of the decision */
+                    const long long nu = sh->s0_base[w] + __popc(vmask);
+                    ev += sh->s0_slice[w] * (nu + 1);
+                    by += 12 * sh->s0_slice[w] + 20LL * sh->s0_mloc[w] * nu + 8LL * nu;
+                }
+                c2 += sh->delta[w];
+                ig_move_result r = sh->rec[w];
+                r.n_slice = Sc;
+                r.n_evals = ev;
+                r.bytes_min += by;
+                r.dist = (norm - 0.5 * (double)c2) / norm;
+                res[move0 + w] = r;
+                hn_last_sc = Sc;
+                hn_last_ev = ev;
+                hn_last_by = r.bytes_min;
+            }
+        }
+        processed = max(processed, upto);
+        if (fin) break;
+    }
+    const int committed = processed;
+    if (committed == w_start) return; /* nothing was committed: as k_commit_batch, nothing is touched */
+    /* The decisions are in, every credit is read (the barrier behind the last move's): the winners become the live genome together --
+     * disjoint contigs --, tab_prev first catching up with the move applied last before this call, then receiving every move but the
+     * last one (k_commit_batch 2c) */
+#ifdef FUSED_PROBE3
+    if (true) return;
+#endif
+    const int n_prev0 = g->n_prev_touched;
+    for (int i = ctid; i < n_prev0; i += NCT) {
+        const int s2 = prev_touched[i];
+        tab_prev.dist[s2] = tab.dist[s2];
+        tab_prev.stot[s2] = tab.stot[s2];
+        tab_prev.cp[s2] = tab.cp[s2];
+        tab_prev.len[s2] = tab.len[s2];
+    }
+    cw_barrier(sh, 3 * IG_MAX_BATCH + 1);
+    {
+        constexpr int GT = NCT / 2; /* two groups of four waves, a move each */
+        const int grp = ctid / GT, gtid = ctid % GT;
+        int nth = 0; /* the moves that change the genome, dealt out in turn */
+        for (int w = w_start; w < committed; w++) {
+            if (!sh->n_dirty[w]) continue;
+            if ((nth++ & 1) != grp) continue;
+            const int cw = CW(w, sh->ch_c[w]);
+            const CandMeta& m = mb.meta[cw];
+            const bool last = (w == committed - 1);
+            const int* base = winner_loc(w);
+            const int* gid = mb.Lloc + (size_t)cw * N;
+            for (int x = gtid; x < m.n_loc; x += GT) {
+                const int f = gid[x];
+                st.pos[f] = base[x];
+                st.spos[f] = base[(size_t)N + x];
+                st.cid[f] = base[(size_t)2 * N + x];
+                st.sbp[f] = base[(size_t)3 * N + x];
+                st.circ[f] = base[(size_t)4 * N + x];
+                st.prev[f] = base[(size_t)5 * N + x];
+                st.next[f] = base[(size_t)6 * N + x];
+                st.L[f] = base[(size_t)7 * N + x];
+                st.SL[f] = base[(size_t)8 * N + x];
+                st.LB[f] = base[(size_t)9 * N + x];
+                st.ori[f] = base[(size_t)10 * N + x];
+            }
+            const int k = sh->ch_k[w];
+            const uint2* col = mb.coords + (size_t)(cw * NSLOT + k) * M;
+            const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
+            const int* subs = mb.subs + (size_t)cw * M;
+            const int fresh = mb.ctl[w].fresh;
+            for (int ls = gtid; ls < m.m_loc; ls += GT) {
+                const int s = subs[ls];
+                const uint2 v = col[ls];
+                const int code = (int)(v.y >> 28);
+                const float dist = __uint_as_float(v.x);
+                const int2 cp = make_int2(code == 0 ? m.ctgA : (code == 1 ? m.ctgB : fresh + (code - 2)), (int)(v.y & 0x0fffffffu));
+                const float stot = cm[code].stot;
+                const int len = cm[code].len;
+                tab.dist[s] = dist;
+                tab.cp[s] = cp;
+                tab.stot[s] = stot;
+                tab.len[s] = len;
+                if (last) {
+                    prev_touched[ls] = s;
+                } else {
+                    tab_prev.dist[s] = dist;
+                    tab_prev.cp[s] = cp;
+                    tab_prev.stot[s] = stot;
+                    tab_prev.len[s] = len;
+                }
+            }
+        }
+    }
+    if (ctid == 0) {
+        g->credit2 = c2;
+        g->stamp_ctr = tag_base + W + 2;
+        g->n_prev_touched = sh->n_dirty[committed - 1] ? mb.meta[CW(committed - 1, sh->ch_c[committed - 1])].m_loc : 0;
+        if (hn) { /* the last committed move's record straight to the (mapped) host memory, then the flag the host spins on */
+            ig_move_result r = sh->rec[committed - 1];
+            r.n_slice = hn_last_sc;
+            r.n_evals = hn_last_ev;
+            r.bytes_min = hn_last_by;
+            r.dist = (norm - 0.5 * (double)c2) / norm;
+            hn->res = r;
+            hn->nzb[0] = sh->nzb_hi[committed - 1];
+            hn->nzb[1] = sh->nzb_lo[committed - 1];
+            hn->max_L = sh->fin_max_L;
+            hn->max_SL = sh->fin_max_SL;
+            hn->changed = sh->n_dirty[committed - 1];
+            __threadfence_system();
+            hn->res_seq = hn_seq;
+        }
+    }
+}
+__global__ void __launch_bounds__(64 + FUSED_CW * 64)
+    k_decide_commit(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out, volatile int* host_out,
+                    int seq, int resumed_plain, State st, Tables tab, Tables tab_prev, const int* __restrict__ ip, const int* __restrict__ in,
+                    const int* __restrict__ orientable, const unsigned char* __restrict__ black, int* own_tag, int* own_idx, int* prev_touched,
+                    NuisHost* hn, int hn_seq)
+{
+    __shared__ FusedLds sh;
+    for (int i = threadIdx.x; i < 3 * IG_MAX_BATCH + 2; i += blockDim.x) sh.bar[i] = 0;
+    for (int i = threadIdx.x; i < IG_MAX_BATCH; i += blockDim.x) sh.delta[i] = 0;
+    if (threadIdx.x == 0) {
+        sh.prog[0] = w_start;
+        sh.prog[1] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) decide_body<true>(g, mb, res, move0, W, w_start, dirty_buf, batch_out, host_out, seq, resumed_plain, &sh);
+    else commit_waves(st, tab, tab_prev, g, mb, ip, in, orientable, black, own_tag, own_idx, prev_touched, res, move0, W, w_start, hn, hn_seq, &sh);
 }
 
 __global__ void k_debug_terms(const float* s, const float* stot, const int* ob, long long n, const Glob* g,

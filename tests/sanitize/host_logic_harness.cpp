@@ -199,6 +199,15 @@ static void model_hist_eval(void** a, dim3, dim3)
     else hn->diff[4] = 1 + (int)(rnd() % 7);         /* void: tier 1 */
     hn->diff_seq = seq;
 }
+/* k_decide_commit: both in one launch (the decide step's arguments first, the apply step's behind them) */
+static void model_decide_commit(void** a, dim3 g, dim3 b)
+{
+    model_decide(a, g, b);
+    void* shifted[19] = {nullptr};
+    shifted[17] = a[21];
+    shifted[18] = a[22];
+    model_commit_batch(shifted, g, b);
+}
 static int g_diff_mode = 0; // 0 random, 1 always decisive reject, 2 always undecided, 3 always void
 static long g_diffs = 0, g_exacts = 0;
 static void model_diff(void** a, dim3, dim3)
@@ -251,6 +260,7 @@ int main()
     setenv("IG_POOL_ENTRIES", "4096", 1);      /* a small slice pool: the growth paths are taken */
     fake_hip::set_model("k_decide_batch", model_decide);
     fake_hip::set_model("k_commit_batch", model_commit_batch);
+    fake_hip::set_model("k_decide_commit", model_decide_commit);
     fake_hip::set_model("k_full_diff_tiled", model_diff);
     fake_hip::set_model("k_hist_eval", model_hist_eval);
     fake_hip::set_model("k_full_nz_tiled", model_full_nz_tiled);
