@@ -1667,7 +1667,12 @@ static void launch_commit(ig_ctx* c, int done, int w_now, int next, int resumed_
     flush_pending_sums(c);
     TimedLaunch t(c, T_COMMIT);
     static const int s_fused = getenv("IG_FUSED_COMMIT") ? atoi(getenv("IG_FUSED_COMMIT")) : 1;
-    if (s_fused && !(c->own_begin > 0 || c->own_end < w_now)) { /* one launch: a wave decides, a wave applies behind it (k_decide_commit) */
+    /* one launch where that pays (k_decide_commit: seven waves work behind the decide wave): plain batches of moves on windows that
+     * 448 threads apply as fast as k_commit_batch's 1 024 -- not a run's one-move launches (their host waits for the record, which the
+     * fused kernel writes behind a longer prologue: 10.2 k instead of 10.7 k), not the late shapes (bigctg: 5.7 k instead of 5.9 k),
+     * not a rank's share of a batch (the winners of the other ranks are mutated in between).  IG_FUSED_COMMIT=0 / 2: never / always. */
+    const bool fuse = s_fused >= 2 || (s_fused == 1 && !publish && c->max_SL <= 4096);
+    if (fuse && !(c->own_begin > 0 || c->own_end < w_now)) {
         const int seq = ++c->bo_seq;
         hipLaunchKernelGGL(k_decide_commit, dim3(1), dim3(64 + FUSED_CW * 64), 0, c->stream, c->glob, c->mb, c->d_results, done, w_now, next, c->dirty_buf,
                            c->batch_out, (volatile int*)c->host_bo_dev, seq, resumed_plain, c->st, c->tab, c->tab_prev, c->init_prev, c->init_next,
