@@ -1019,6 +1019,19 @@ __device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_pr
         }
         __asm__ volatile("" ::: "memory");
         if (fin) upto = fin - 1;
+        if (processed == w_start && upto > w_start) { /* a move will be committed: tab_prev catches up with the move applied last before
+                                                       * this call (k_commit_batch 2c) -- now, while there is little to do, not behind the
+                                                       * last decision; the tables and the list are not touched before the end */
+            const int n_prev0 = g->n_prev_touched;
+            for (int i = ctid; i < n_prev0; i += NCT) {
+                const int s2 = prev_touched[i];
+                tab_prev.dist[s2] = tab.dist[s2];
+                tab_prev.stot[s2] = tab.stot[s2];
+                tab_prev.cp[s2] = tab.cp[s2];
+                tab_prev.len[s2] = tab.len[s2];
+            }
+            cw_barrier(sh, 3 * IG_MAX_BATCH + 1);
+        }
         for (int w = processed; w < upto; w++) {
 #ifdef FUSED_PROBE2
             if (false) {
@@ -1068,7 +1081,23 @@ __device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_pr
                 }
                 d = wave_sum_ll(d);
                 if (lane == 0 && d) atomicAdd((unsigned long long*)&sh->delta[w], (unsigned long long)d);
-                cw_barrier(sh, 3 * w + 1); /* (the move's sum is complete) */
+                cw_barrier(sh, 3 * w + 1); /* (the move's sum is complete, its credits are read) */
+                /* the winner becomes the live genome: nothing reads these fragments' state any more -- a later move's credits take
+                 * them from the winner's buffers, through the marks */
+                for (int x = ctid; x < n_loc; x += NCT) {
+                    const int f = gid[x];
+                    st.pos[f] = wl[x];
+                    st.spos[f] = wl[(size_t)N + x];
+                    st.cid[f] = wl[(size_t)2 * N + x];
+                    st.sbp[f] = wl[(size_t)3 * N + x];
+                    st.circ[f] = wl[(size_t)4 * N + x];
+                    st.prev[f] = wl[(size_t)5 * N + x];
+                    st.next[f] = wl[(size_t)6 * N + x];
+                    st.L[f] = wl[(size_t)7 * N + x];
+                    st.SL[f] = wl[(size_t)8 * N + x];
+                    st.LB[f] = wl[(size_t)9 * N + x];
+                    st.ori[f] = wl[(size_t)10 * N + x];
+                }
             }
             if (ctid == 0) {
                 const unsigned vmask = (unsigned)sh->vmask[w];
@@ -1095,21 +1124,8 @@ __device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_pr
     }
     const int committed = processed;
     if (committed == w_start) return; /* nothing was committed: as k_commit_batch, nothing is touched */
-    /* The decisions are in, every credit is read (the barrier behind the last move's): the winners become the live genome together --
-     * disjoint contigs --, tab_prev first catching up with the move applied last before this call, then receiving every move but the
-     * last one (k_commit_batch 2c) */
-#ifdef FUSED_PROBE3
-    if (true) return;
-#endif
-    const int n_prev0 = g->n_prev_touched;
-    for (int i = ctid; i < n_prev0; i += NCT) {
-        const int s2 = prev_touched[i];
-        tab_prev.dist[s2] = tab.dist[s2];
-        tab_prev.stot[s2] = tab.stot[s2];
-        tab_prev.cp[s2] = tab.cp[s2];
-        tab_prev.len[s2] = tab.len[s2];
-    }
-    cw_barrier(sh, 3 * IG_MAX_BATCH + 1);
+    /* The decisions are in: the coordinate tables of the moves that changed the genome -- disjoint contigs, two at a time --; tab_prev
+     * receives every move but the last one (k_commit_batch 2c; its catch-up ran when the first decision came) */
     {
         constexpr int GT = NCT / 2; /* two groups of four waves, a move each */
         const int grp = ctid / GT, gtid = ctid % GT;
@@ -1120,22 +1136,6 @@ __device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_pr
             const int cw = CW(w, sh->ch_c[w]);
             const CandMeta& m = mb.meta[cw];
             const bool last = (w == committed - 1);
-            const int* base = winner_loc(w);
-            const int* gid = mb.Lloc + (size_t)cw * N;
-            for (int x = gtid; x < m.n_loc; x += GT) {
-                const int f = gid[x];
-                st.pos[f] = base[x];
-                st.spos[f] = base[(size_t)N + x];
-                st.cid[f] = base[(size_t)2 * N + x];
-                st.sbp[f] = base[(size_t)3 * N + x];
-                st.circ[f] = base[(size_t)4 * N + x];
-                st.prev[f] = base[(size_t)5 * N + x];
-                st.next[f] = base[(size_t)6 * N + x];
-                st.L[f] = base[(size_t)7 * N + x];
-                st.SL[f] = base[(size_t)8 * N + x];
-                st.LB[f] = base[(size_t)9 * N + x];
-                st.ori[f] = base[(size_t)10 * N + x];
-            }
             const int k = sh->ch_k[w];
             const uint2* col = mb.coords + (size_t)(cw * NSLOT + k) * M;
             const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
