@@ -13,7 +13,7 @@ tag = sys.argv[1]
 cfg = os.environ.get("CONFIG", "cfg3")  # the shape tools/profile_round.sh was run with
 outdir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
 KERNELS = {"k_screen": ("_Z13k_screen_tail", "_Z8k_screen"), "k_score_list": "_Z12k_score_list", "k_slice": "_Z7k_slice", "k_tail": "_Z6k_tail",
-           "k_full_nz_tiled": "_Z15k_full_nz_tiled", "k_decide_batch": "_Z14k_decide_batch", "k_mutate": "_Z8k_mutate"}
+           "k_full_nz_tiled": "_Z15k_full_nz_tiled", "k_decide_batch": ("_Z14k_decide_batch", "_Z15k_decide_commit"), "k_mutate": "_Z8k_mutate"}
 merged = {}
 for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "%s_pmc_pass*.json" % tag))):
     d = json.load(open(f))
