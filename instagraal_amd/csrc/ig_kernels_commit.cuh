@@ -1002,9 +1002,6 @@ __device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_pr
     int processed = w_start;
     long long hn_last_sc = 0, hn_last_ev = 0, hn_last_by = 0; /* (lane 0 of the first commit wave: the last applied move's statistics) */
     cw_barrier(sh, 3 * IG_MAX_BATCH); /* (the statistics are in LDS) */
-#ifdef FUSED_PROBE
-    return;
-#endif
     auto winner_loc = [&](int w) -> const int* { return mb.loc + ((size_t)(CW(w, sh->ch_c[w]) * NSLOT + sh->ch_slot[w]) * NDYN) * N; };
     /* While the decisions come in: a move that changes the genome gets its ownership marks and its credits -- evaluated through the
      * marks on the state as of the batch's start, as k_commit_batch does (nothing is applied yet: a later move's marks, written
@@ -1033,11 +1030,7 @@ __device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_pr
             cw_barrier(sh, 3 * IG_MAX_BATCH + 1);
         }
         for (int w = processed; w < upto; w++) {
-#ifdef FUSED_PROBE2
-            if (false) {
-#else
             if (sh->n_dirty[w]) {
-#endif
                 const int cw = CW(w, sh->ch_c[w]);
                 const int n_loc = mb.meta[cw].n_loc;
                 const int* gid = mb.Lloc + (size_t)cw * N;
