@@ -1447,7 +1447,13 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                 /* a wave walks a row (a workgroup 4 rows at a time).  Measured at cfg3 (us per launch of 24 slots): 32 workgroups per
                  * candidate 193, 64: 156, 96: 148, 128: 136, 256 with the chunks of a row dealt to several waves: 146 */
                 static const int s_rb = getenv("IG_SLICE_RB") ? atoi(getenv("IG_SLICE_RB")) : 0;
-                const int rb = s_rb > 0 ? s_rb : SLICE_RB;
+                /* ... and with the lists in 8 segments (round 3), workgroups per plane -> moves/s: cfg3 24: 43.1 k, 32: 44.2, 40: 45.5, 48: 45.2 - 45.7,
+                 * 64: 45.4, 80: 45.3, 96: 44.6, 128: 43.9; cfg2 32: 57.3 k, 48: 55.9, 96: 55.5; cfg5 32: 28.4 k, 48: 29.9, 96: 30.1; bigctg 32: 5.3 k,
+                 * 48: 5.75, 96: 5.93 -- the count follows the contacts a plane holds (two contigs' rows: 2 Z / contigs of the last batch) */
+                const int rb_auto = c->n_contigs_seen > 0
+                                        ? std::min(SLICE_RB, std::max(32, (int)(2.0 * (double)c->Z / (double)c->n_contigs_seen / 2100.0)))
+                                        : SLICE_RB;
+                const int rb = s_rb > 0 ? s_rb : rb_auto;
                 static const int s_share = getenv("IG_SLICE_SHARE") ? atoi(getenv("IG_SLICE_SHARE")) : 1; /* A's rows once per move */
                 static const int s_maxj = getenv("IG_SLICE_J") ? std::max(1, atoi(getenv("IG_SLICE_J"))) : 1 << 20;
                 if (c->mb.packed)
