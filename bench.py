@@ -47,10 +47,12 @@ def prob_name(prob):
     return "%dk bins / %.0fM contacts" % (prob.n_frags // 1000, prob.n_contacts / 1e6)
 
 
-def cpu_baseline(prob, frags, cands, budget_s=30.0, max_moves=24):
+def cpu_baseline(prob, frags, cands, budget_s=30.0, max_moves=24, hip_res=None, params=None):
     """The oracle (a CPU port of the reference ALGORITHM: full-N genome rewrites, full-Z slice scans) timed on a bounded
     sample of the same workload -- the first moves of the same trajectory -- on one thread and on all host cores (OpenMP
-    over the contact-length loops: slice scans, full likelihood)."""
+    over the contact-length loops: slice scans, full likelihood).  hip_res: the HIP path's records of the SAME moves from the same
+    initial state (the first moves of the run): what the oracle computes while it is timed is compared with them, move by move.
+    The oracle is the checker and the baseline here, never the thing measured as the product."""
     from oracle import oracle_lib as ol
     from oracle.sampler_oracle import OracleSampler
 
@@ -58,11 +60,12 @@ def cpu_baseline(prob, frags, cands, budget_s=30.0, max_moves=24):
     t0 = time.time()
     ol.set_threads(1)
     s = OracleSampler(**prob.sampler_kwargs(), mode=ol.MODE_DET)
-    s.set_param_simu(prob.params)
+    s.set_param_simu(prob.params if params is None else params)
     s.eval_likelihood_init()
     log("[cpu_baseline] oracle set-up %.1fs" % (time.time() - t0))
     ncores = os.cpu_count() or 1
     rates, n_done, spent = {}, 0, {}
+    n_checked = n_same = 0
     plan = sorted({1, min(16, ncores), ncores})  # the contact-length loops stop scaling long before 256 threads
     # 10 moves each on one thread and on 16 (the figures worth quoting: ~1.3 s and ~0.7 s per move at cfg3), a few on all cores
     # (slower than 16 threads: the rest of a move is serial in the reference's algorithm) -- `sample` says how many each got
@@ -75,7 +78,15 @@ def cpu_baseline(prob, frags, cands, budget_s=30.0, max_moves=24):
         t0 = time.time()
         while n < min(quota[threads], max_moves) and n_done < len(frags):
             c = [int(x) for x in cands[n_done] if x >= 0]
-            s.step_sampler(int(frags[n_done]), len(c), s.dt, candidates=c)
+            b = s.step_sampler(int(frags[n_done]), len(c), s.dt, candidates=c)
+            if hip_res is not None and n_done < len(hip_res):
+                r = hip_res[n_done]
+                same = (float(r["o"]), float(r["dist"]), int(r["op_sampled"]), int(r["id_f_sampled"]), int(r["n_contigs"])) == (
+                    float(b[0]), float(b[1]), int(b[2]), int(b[3]), int(b[5]))
+                n_checked += 1
+                n_same += int(same)
+                if not same:
+                    log("[cpu_baseline] move %d DIFFERS: HIP %r, oracle %r" % (n_done, r, b))
             n += 1
             n_done += 1
             if time.time() - t0 > share[threads] and n >= 2:
@@ -86,6 +97,8 @@ def cpu_baseline(prob, frags, cands, budget_s=30.0, max_moves=24):
     ol.set_threads(1)
     best = max(rates, key=lambda k: rates[k])
     return dict(value=rates[best], unit="moves/s", cores=best, kind="port", value_1_thread=rates[1],
+                checked_against_hip={"moves": n_checked, "identical": n_same,
+                                     "what": "o, dist, op_sampled, id_f_sampled, n_contigs of the HIP batch path's records of the same moves"},
                 value_all_cores=rates.get(ncores), value_by_threads={str(k): v for k, v in rates.items()}, host_cores=ncores,
                 sample="the first %d moves of the same seeded trajectory on %s, oracle DET mode: " % (n_done, prob_name(prob)) +
                        ", ".join("%d moves in %.1f s on %d thread%s" % (done_by[k], spent[k], k, "s" if k > 1 else "") for k in plan))
@@ -144,6 +157,10 @@ def main():
     ap.add_argument("--runner", default="batch", choices=("batch", "sharded", "replicas"),
                     help="N > 1: what is split over the ranks (batch / sharded: ONE chain, bit-identical to one GPU, 'strong'); replicas: "
                          "N independent chains, one per GPU, no data-path collective ('weak': the aggregate BASELINE's >= 6x asks for)")
+    ap.add_argument("--params", default="synthetic", choices=("synthetic", "settled"),
+                    help="P(s) parameters of the timed moves: the synthetic set of BASELINE.md section 3 (slope -1.5: the headline), or the set a "
+                         "nuisance chain settles into on this data (slope -0.53, d_max 2.9e6 kb: synth.settled_params)")
+    ap.add_argument("--settled-batches", type=int, default=40, help="batches of the default line's config.settled_parameters sample (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--nuisance-moves", type=int, default=150, help="moves of the nuisance-on loop timed after the run (0: skip)")
@@ -194,7 +211,7 @@ def main():
     t0 = time.time()
     kw = prob.sampler_kwargs()
     s = hip_sampler(**kw, device_id=local_rank, coo=(prob.coo_row, prob.coo_col, prob.coo_cnt))
-    s.set_param_simu(prob.params)
+    s.set_param_simu(prob.params if a.params == "synthetic" else synth.settled_params(prob.params))
     s.eval_likelihood_init()
     log("[rank %d] uploaded + initial likelihood %.6f in %.1fs" % (rank, float(s.curr_likelihood_on_nz[0]), time.time() - t0))
 
@@ -222,8 +239,10 @@ def main():
         cands = s.draw_candidates(fr, a.neighbours)  # every rank draws the same lists from the same generator state
         return runner.run(fr, cands), cands
 
+    first_res = first_cands = None  # the run's first moves (from the initial state): the cpu_baseline leg replays them on the oracle
     if n_warm:
-        run(frags[:n_warm])
+        first_res, first_cands = run(frags[:n_warm])
+        first_res, first_cands = first_res[:48].copy(), np.array(first_cands[:48])
     # hipEvent pairs around the two scoring kernels (k_screen, k_score_list) on the library's stream, every 4th launch: an event
     # record between two kernels of a stream costs ~6 us of idle queue, four of them per batch were 4 % of the timed region
     s.ctx.set_timer_sampling(4)
@@ -290,6 +309,44 @@ def main():
         except Exception as e:  # a diagnostic next to the headline, never instead of it
             nuis = {"moves_per_s": None, "error": repr(e)}
 
+    # the plain batch under the parameters a nuisance chain settles into (95 of the default 100 cycles run there): the same call,
+    # the model's parameters replaced (maintained sums recomputed), on the genome as the measurements above left it
+    settled = None
+    if rank == 0 and world == 1 and a.settled_batches > 0 and a.params == "synthetic":
+        try:
+            sp = synth.settled_params(prob.params)
+            s.set_param_simu(sp)
+            nb = a.settled_batches
+            fr = np.resize(np.random.permutation(prob.n_frags), (nb + 8) * mps).astype(np.int32)
+            s.step_sampler_batch(fr[:8 * mps], a.neighbours)
+            sc0 = s.ctx.debug_screen_stats()
+            b0 = s.ctx.batch_stats()
+            s.ctx.set_timer_sampling(4)
+            s.ctx.reset_timers(1 | (((1 << 2) | (1 << 10)) << 1))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rs = s.step_sampler_batch(fr[8 * mps:], a.neighbours)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            ex_ms, _ = s.ctx.kernel_time_ms("score")
+            sc_ms, _ = s.ctx.kernel_time_ms("screen")
+            s.ctx.reset_timers(0)
+            s.ctx.set_timer_sampling(1)
+            sc1 = s.ctx.debug_screen_stats()
+            b1 = s.ctx.batch_stats()
+            sums, _ = s.ctx.debug_globals()
+            _, _, limbs = s.ctx.full_likelihood(0)
+            nbat = max(b1["batches"] - b0["batches"], 1)
+            settled = {"moves_per_s": nb * mps / dt, "k_screen_ms": sc_ms, "exact_ms": ex_ms,
+                       "exact_columns_pct": 100.0 * (sc1[3] - sc0[3]) / max(sc1[2] - sc0[2], 1),
+                       "exact_terms_pct": 100.0 * (sc1[5] - sc0[5]) / max(sc1[4] - sc0[4], 1),
+                       "moves": nb * mps, "batches": nbat, "moves_per_batch": nb * mps / nbat, "ms_per_batch": 1e3 * dt / nbat,
+                       "maintained_likelihood_exact": bool(int(sums[0]) == int(limbs[0]) and int(sums[1]) == int(limbs[1])),
+                       "parameters": {k: float(sp[k]) for k in ("slope", "fact", "d_max", "v_inter")}}
+            del rs
+        except Exception as e:  # a diagnostic next to the headline, never instead of it
+            settled = {"moves_per_s": None, "error": repr(e)}
+
     if rank == 0:
         # algorithmic bytes of one launch of the dominant kernel = sum of the per-move B_min of the moves it scored
         # (committed moves only: a slot that had to be re-scored is work, not algorithmic traffic)
@@ -342,8 +399,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32 screening tier with a rigorous bound (every column) + f64 terms (f32 inputs) for the contenders / exact i64 fixed-point sums",
             "data": "synthetic",
-            "config": {"workload": "synthetic Hi-C %s (%d sub-frags), level 4, %d neighbours, nuisance sampling off" % (
-                prob_name(prob), prob.n_sub_frags, a.neighbours), "name": a.config, "seed": a.seed,
+            "config": {"workload": "synthetic Hi-C %s (%d sub-frags), level 4, %d neighbours, nuisance sampling off%s" % (
+                prob_name(prob), prob.n_sub_frags, a.neighbours, "" if a.params == "synthetic" else ", P(s) parameters of a settled chain"), "name": a.config, "seed": a.seed,
                 "step": "one batch of %d moves (step_sampler calls)" % mps, "moves_per_step": mps, "moves_timed": n_moves,
                 "moves_warmup": n_warm,
                 "parallelism": "1 GPU" if world == 1 else ("replicas only: %d independent chains, one per GPU, no data-path collective" % world) if replicas else (
@@ -356,6 +413,8 @@ def main():
                 "term_evals_per_move": float(res["n_evals"].mean()), "moves_per_launch": n_moves / n_launch,
                 "batches": bstats, "maintained_likelihood_exact": exact_ok,
                 "nuisance_on": nuis,
+                "settled_parameters": settled,
+                "parameters": a.params,
                 "nuisance_on_moves_per_s": None if nuis is None else nuis.get("moves_per_s"),
                 "reference_equivalent_GBps": b_ref * (n_moves / elapsed) / 1e9,
                 "B_ref_bytes_per_move": b_ref},
@@ -382,7 +441,13 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(prob, frags[n_warm:], cands, a.cpu_budget)
+                if first_res is None:
+                    first_res, first_cands = res[:48], np.array(cands[:48])
+                out["cpu_baseline"] = cpu_baseline(prob, frags, first_cands, a.cpu_budget, hip_res=first_res,
+                                                   params=None if a.params == "synthetic" else synth.settled_params(prob.params))
+                cb = out["cpu_baseline"].get("checked_against_hip")
+                if cb and cb["identical"] != cb["moves"]:
+                    raise SystemExit("bench.py: the oracle disagrees with the HIP path on %d of %d moves" % (cb["moves"] - cb["identical"], cb["moves"]))
             except Exception as e:  # the baseline is a report, never the product path
                 out["cpu_baseline"] = {"value": None, "unit": "moves/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)

@@ -177,14 +177,6 @@ int ig_set_nuis_screen(int on);
  * with the pass over the contacts (env IG_NUIS_HIST); IG_NUIS_SCREEN_VERIFY=1 checks both tiers against the exact pass on every
  * step. */
 int ig_set_nuis_hist(int on);
-/* The batches of a run are scored ahead in the BACKGROUND: once a move of the batch in the buffers has changed the genome (or the
- * batch is nearly used up) a batch from the next move on is scored on a low-priority stream against a snapshot of the state, into a
- * second set of buffers, and adopted when the batch in the buffers ends (the contigs modified since the snapshot count as
- * conflicts).  0 = every batch is scored when it is needed: the default -- at the headline shape the background launches slow the
- * steps next to them by more than they save; env IG_NUIS_BG, IG_NUIS_BG_LEAD (slots left at which the
- * background scoring starts in any case, default 6), IG_NUIS_BG_CHANGED=0 (not at every move that changes the genome).  Results
- * do not depend on it. */
-int ig_set_nuis_background(int on);
 /* *accepted = 3 from ig_nuis_step_next: the step was ACCEPTED from the screened interval alone (every L_test in it gives a ratio
  * above u); its exact pass -- the promotion of the maintained sum needs it, the decision does not -- runs behind the decision, next
  * to the re-scoring of the moves ahead; *nz_test was the interval's midpoint.  The exact value (what eval_likelihood_4_nuisance
@@ -246,7 +238,11 @@ int ig_debug_nuis_screen_stats(ig_ctx* ctx, double out12[12]);
 int ig_debug_nuis_hist_stats(ig_ctx* ctx, double out12[12]);
 /* the maintained histogram against one built from scratch (the last move of the run is walked in first): words that differ, -1: none kept */
 int ig_debug_nuis_hist_check(ig_ctx* ctx, int64_t* mismatches);
-int ig_debug_nuis_bg_stats(ig_ctx* ctx, int64_t out2[2]); /* batches scored in the background: {launched, adopted} */
+/* two-tier scoring, the decide step's zero-score rule (a score of exactly 0.0 counts as "not scored", CL:1435-1440: a move whose
+ * contenders hold one under the live scalars is scored again with every column exact): fault injection for the tests -- every n-th
+ * move of a two-tier batch takes that path (0 = off) -- and how often a handle has taken it */
+int ig_debug_set_zero_inject(int every);
+int ig_debug_zero_fallbacks(ig_ctx* ctx, int64_t* fallbacks);
 int ig_debug_set_full_hist(int on); /* from-scratch pass: all-trans tiles from their count histograms (1, default) or contact by contact (0) */
 
 #ifdef __cplusplus

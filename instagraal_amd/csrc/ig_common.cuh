@@ -267,6 +267,27 @@ struct NuisHist {
 };
 #define NH_DH_BLOCKS 8 /* workgroups of k_hist_eval that share the rank distances */
 
+/* ---- chains of (move, nuisance step) pairs decided on the device (ig_nuis_chain_begin) ------------------------
+ * Once a chain has settled, 97 % of its nuisance steps are rejected and most moves leave the genome alone: nothing a pair does
+ * depends on the host.  A SEGMENT evaluates the Metropolis intervals of the next CHAIN_SEG steps' test parameter sets from the
+ * histogram of the cis contacts' distances in one launch (k_hist_eval_chain: the histogram is that of the current state, valid
+ * for every step up to and including the first move that changes the genome), then ONE decide wave takes the moves from the
+ * batch's score records in order, tests each step against its interval with the live likelihood in registers, and stops in
+ * front of the first pair that needs the host -- a test that is not a certain rejection, a conflict, a pending windowed winner,
+ * an overflow -- or behind the first move that changes the genome (the histogram has to follow it before the next segment). */
+#define CHAIN_SEG 8    /* test parameter sets evaluated per segment */
+#define CHAIN_MAX 64   /* ... uploaded per call */
+#define DIFF_FIX 1048576.0 /* 2^20: the screened nuisance passes publish sums and bounds as integers (deterministic totals) */
+struct ChainIn {       /* host -> device, per step: the test parameters (KA:91-100 order) and ln of the acceptance uniform */
+    float p[8];
+    double ln_u;
+};
+struct ChainTest {     /* k_hist_eval_chain -> the decide wave, per set: the histogram tier's interval of D (2^-20 units), its void flags,
+                        * the zero-pixel likelihood of the test set */
+    long long s_fix, b_fix, flags;
+    double z;
+};
+
 struct ig_ctx {
     int device;
     hipStream_t stream;
@@ -303,30 +324,9 @@ struct ig_ctx {
     struct ScreenSum* probe_scr; /* IG_SCREEN_PROBE: scratch outputs of the probe launches of k_screen */
     unsigned* probe_void;
     struct NuisWorker* worker; /* the helper thread that enqueues a run's next step (ig_hip.hip) */
-    /* the NEXT batch of a run of (move, nuisance step) pairs, scored in the background (nuis_bg_launch) while the steps of the
-     * current one go on: a second set of batch buffers, a snapshot of the state it is scored against (5 MB at the headline
-     * shape), its own low-priority stream.  bg_valid: moves [bg_base, bg_base + bg_W) are in mb2, the parameter half of the
-     * first bg_r of them under the parameters as of accepted step number bg_accepts. */
-    MoveBuf mb2;
-    hipStream_t stream_bg;
-    hipEvent_t ev_snap, ev_bg_done;
-    int* st2_block;
-    State st2;
-    Tables tab2;
-    Glob* glob2;
-    unsigned* touched_bits2;
-    int touched_flip2;
-    int* bg_mark; /* device: entries of dirty_buf at the snapshot (the contigs modified after it are behind them) */
-    int bg_N, bg_M;
     bool last_moved;   /* the move of the step just ended changed the genome (or nobody said it did not) */
     bool spec_changed; /* a move decided from the batch in the buffers has changed the genome */
-    bool bg_stale;     /* ... since the snapshot of the background batch */
-    bool bg_valid, spec_adopted; /* spec_adopted: the batch in the buffers came from the background (its slots may be stale from slot 0 on) */
-    int bg_base, bg_W, bg_r;
-    long long n_accepts, bg_accepts;
-    int bg_own_begin, bg_own_end, bg_own_screened;
-    bool bg_tail_fused;
-    long long n_bg_launched, n_bg_adopted;
+    long long n_accepts;
     NuisHist nh;
     long long* scratch_hist; /* k_hist_eval's 8 output words (zero between two launches) */
     bool nh_valid;
@@ -393,7 +393,18 @@ struct ig_ctx {
     int* batch_out; /* committed moves, pending slot, (unused), candidates, predicted deltas used, contigs */
     int *host_bo, *host_bo_dev; /* the same in mapped host memory (+ [7] = sequence number of the decide launch), and its device address */
     int bo_seq;
-    int last_stop; /* what the last decided batch stopped at: 0 a conflict / its end, 1 the slice pool, 2 the exact kernel's grid */
+    int last_stop; /* what the last decided batch stopped at: 0 a conflict / its end, 1 the slice pool, 2 the exact kernel's grid, 3 a score of exactly 0.0 */
+    bool exact_next; /* ... 3: the next scoring leaves the screening tier out (enqueue_score) */
+    /* chains (see ChainIn): per-set constants of a segment, the uploaded sets, the intervals, scratch words; statistics */
+    struct ChainSet* chain_sets; /* [CHAIN_SEG] */
+    ChainIn* chain_in;           /* [CHAIN_MAX] device */
+    ChainIn* chain_in_host;      /* pinned staging */
+    ChainTest* chain_tests;      /* [CHAIN_SEG] */
+    long long *chain_out16, *chain_zs; /* [CHAIN_SEG][16], [CHAIN_SEG][8] */
+    long long n_chain_calls, n_chain_segments, n_chain_pairs, n_chain_stops[8];
+    int chain_done, chain_reason; /* of the last chain: pairs completed, why it ended */
+    bool chain_busy;
+    long long n_zero_fallbacks;
     int n_contigs_seen; /* contigs after the last batch (0: none yet): picks k_mutate's launch shape */
     double w_ema; /* moving average of the moves a batch gets through: sets the width of the next one */
     int* dirty_buf; /* [1 + 2 * IG_MAX_BATCH + 2] contigs modified by the committed moves of the batch in flight */

@@ -63,12 +63,15 @@ struct NuisWorker {
     std::atomic<int> state{0}; /* 0 idle, 1 a task is waiting / running, 2 quit */
     int rc = 0;
     std::string err;
+    int kind = 0; /* the task: 0 ig_nuis_step_begin, 1 a chain of pairs (ig_nuis_chain_begin) */
     int move = 0;
     float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float mean_kb = 0;
+    int n_sets = 0;
     std::thread::id tid;
 };
 static int nuis_step_begin_impl(ig_ctx* c, int32_t move, const float p_test[8], float mean_subfrag_kb);
+static int nuis_chain_impl(ig_ctx* c, int32_t move, int32_t n_sets, float mean_subfrag_kb);
 static int nuis_join(ig_ctx* c)
 {
     NuisWorker* w = c->worker;
@@ -101,16 +104,17 @@ static void nuis_worker_main(ig_ctx* c)
             continue;
         }
         if (st == 2) return;
-        const int rc = nuis_step_begin_impl(c, w->move, w->p, w->mean_kb);
+        const int rc = w->kind == 1 ? nuis_chain_impl(c, w->move, w->n_sets, w->mean_kb) : nuis_step_begin_impl(c, w->move, w->p, w->mean_kb);
         if (rc) w->err = g_err;
         w->rc = rc;
         w->state.store(0, std::memory_order_release);
     }
 }
-static int nuis_defer_step_begin(ig_ctx* c, int32_t move, const float p_test[8], float mean_subfrag_kb)
+/* kind 0: p_test = the step's test parameters; kind 1: a chain over the n_sets sets staged in chain_in_host */
+static int nuis_defer(ig_ctx* c, int kind, int32_t move, const float* p_test, float mean_subfrag_kb, int n_sets)
 {
     static const int s_async = getenv("IG_NUIS_ASYNC") ? atoi(getenv("IG_NUIS_ASYNC")) : 1;
-    if (!s_async) return nuis_step_begin_impl(c, move, p_test, mean_subfrag_kb);
+    if (!s_async) return kind == 1 ? nuis_chain_impl(c, move, n_sets, mean_subfrag_kb) : nuis_step_begin_impl(c, move, p_test, mean_subfrag_kb);
     if (!c->worker) {
         c->worker = new NuisWorker();
         c->worker->th = std::thread(nuis_worker_main, c);
@@ -118,15 +122,21 @@ static int nuis_defer_step_begin(ig_ctx* c, int32_t move, const float p_test[8],
     }
     NuisWorker* w = c->worker;
     if (nuis_join(c)) return -1;
+    w->kind = kind;
     w->move = move;
-    memcpy(w->p, p_test, sizeof w->p);
+    if (p_test) memcpy(w->p, p_test, sizeof w->p);
     w->mean_kb = mean_subfrag_kb;
+    w->n_sets = n_sets;
     {
         std::lock_guard<std::mutex> lk(w->mu);
         w->state.store(1, std::memory_order_release);
     }
     w->cv.notify_one();
     return 0;
+}
+static int nuis_defer_step_begin(ig_ctx* c, int32_t move, const float p_test[8], float mean_subfrag_kb)
+{
+    return nuis_defer(c, 0, move, p_test, mean_subfrag_kb, 0);
 }
 static void nuis_worker_stop(ig_ctx* c)
 {
@@ -306,19 +316,7 @@ extern "C" int ig_create(int device_id, ig_ctx** out)
     c->probe_scr = nullptr;
     c->probe_void = nullptr;
     c->last_moved = true;
-    memset((void*)&c->mb2, 0, sizeof c->mb2);
-    c->stream_bg = nullptr;
-    c->st2_block = nullptr;
-    memset((void*)&c->st2, 0, sizeof c->st2);
-    c->tab2 = Tables{nullptr, nullptr, nullptr, nullptr};
-    c->glob2 = nullptr;
-    c->touched_bits2 = nullptr;
-    c->touched_flip2 = 0;
-    c->bg_mark = nullptr;
-    c->bg_N = c->bg_M = 0;
-    c->bg_valid = c->spec_adopted = false;
-    c->n_accepts = c->bg_accepts = 0;
-    c->n_bg_launched = c->n_bg_adopted = 0;
+    c->n_accepts = 0;
     c->nh = NuisHist{nullptr, nullptr, nullptr, 0};
     c->scratch_hist = nullptr;
     c->nh_valid = false;
@@ -388,8 +386,7 @@ static void free_slice_pool(MoveBuf& m)
     m.sl_pk = nullptr;
     m.pool_cap = 0;
 }
-/* one set of batch buffers (the handle has two: the second one holds the batch a run of (move, nuisance step) pairs scores in the
- * background, nuis_bg_launch) */
+/* one set of batch buffers */
 static void free_movebuf(MoveBuf& m)
 {
     free_window_buffers(m);
@@ -419,8 +416,6 @@ static void free_movebuf(MoveBuf& m)
 static void free_move_buffers(ig_ctx* c)
 {
     free_movebuf(c->mb);
-    free_movebuf(c->mb2);
-    c->bg_valid = false;
     hipFree(c->own_tag);
     hipFree(c->own_idx);
     c->own_tag = c->own_idx = nullptr;
@@ -444,17 +439,6 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipEventDestroy(c->ev_main);
     hipEventDestroy(c->ev_exact);
     hipEventDestroy(c->ev_walk);
-    if (c->stream_bg) {
-        hipStreamSynchronize(c->stream_bg);
-        hipStreamDestroy(c->stream_bg);
-        hipEventDestroy(c->ev_snap);
-        hipEventDestroy(c->ev_bg_done);
-    }
-    hipFree(c->st2_block);
-    hipFree(c->tab2.dist);
-    hipFree(c->glob2);
-    hipFree(c->touched_bits2);
-    hipFree(c->bg_mark);
     hipFree(c->probe_scr);
     hipFree(c->probe_void);
     hipFree(c->nh.bins);
@@ -553,10 +537,10 @@ static int g_full_hist = -1;
 static bool launch_full_nz(ig_ctx* c, const Tables& t, int which, long long* out, PzTab pz, hipStream_t stream = nullptr,
                            long long* zero_out = nullptr, const ig_params* p_host = nullptr, float mean_kb = 0.0f)
 {
-    static int s_wgs = getenv("IG_FULL_WGS") ? atoi(getenv("IG_FULL_WGS")) : 8 * 256;
+    const int s_wgs = 8 * 256;
     if (!stream) stream = c->stream;
     static const int s_tiled = getenv("IG_FULL_TILED") ? atoi(getenv("IG_FULL_TILED")) : 1;
-    if (g_full_hist < 0) g_full_hist = getenv("IG_FULL_HIST") ? atoi(getenv("IG_FULL_HIST")) : 1; /* 0: read every tile's contacts */
+    if (g_full_hist < 0) g_full_hist = 1; /* ig_debug_set_full_hist(0): read every tile's contacts */
     const int s_hist = g_full_hist;
     const bool tiled = s_tiled && c->tiled_cc && c->n_tile_work > 0;
     const int n_pack = (c->M + FULL_TB - 1) / FULL_TB;
@@ -592,7 +576,7 @@ static bool launch_full_nz(ig_ctx* c, const Tables& t, int which, long long* out
          * every wave slot would keep the move's kernels waiting until the pass is over (k_decide_batch: 70 instead of 12 us),
          * and the pass is bound by its arithmetic, not by its occupancy */
         static const int s_grid = getenv("IG_FULL_GRID") ? atoi(getenv("IG_FULL_GRID")) : 512;
-        static const int s_grid_side = getenv("IG_FULL_GRID_SIDE") ? atoi(getenv("IG_FULL_GRID_SIDE")) : 256;
+        const int s_grid_side = 256;
         const int grid = std::min(c->n_tile_work, (stream != c->stream && c->side_busy) ? s_grid_side : s_grid);
         if (grid > 0)
             hipLaunchKernelGGL(k_full_nz_tiled, dim3(grid), dim3(FULL_TILED_THREADS), sizeof(FullTiledLds), stream, c->tile_work, c->tiled_cc,
@@ -615,13 +599,11 @@ static int ensure_window_buffers(ig_ctx* c, MoveBuf& m)
 {
     if (!m.capC || !m.capW) return 0;
     const int need_n = std::min(c->N, std::max(2 * c->max_L, 1)), need_m = std::min(c->M, std::max(2 * c->max_SL, 1));
-    static const int s_env_full = getenv("IG_FULL_WINDOWS") ? atoi(getenv("IG_FULL_WINDOWS")) : 0; /* strides = the whole genome */
-    const bool s_full = s_env_full || c->full_windows;
+    const bool s_full = c->full_windows; /* strides = the whole genome */
     if (m.Lloc && (s_full ? (m.sN == c->N && m.sM == c->M) : (m.sN >= need_n && m.sM >= need_m))) return 0;
     const int sN = s_full ? c->N : std::min(c->N, std::max(256, need_n + need_n / 2));
     const int sM = s_full ? c->M : std::min(c->M, std::max(768, need_m + need_m / 2));
     HIPCK(hipStreamSynchronize(c->stream));
-    if (c->stream_bg) HIPCK(hipStreamSynchronize(c->stream_bg));
     free_window_buffers(m);
     const size_t C = (size_t)m.capC * m.capW;
     DALLOC(m.Lloc, C * sN);
@@ -674,7 +656,6 @@ static int ensure_move_buffers(ig_ctx* c, int capC, int capW = 1)
     capC = std::max(capC, c->mb.capC);
     capW = std::max(capW, c->mb.capW);
     HIPCK(hipStreamSynchronize(c->stream));
-    if (c->stream_bg) HIPCK(hipStreamSynchronize(c->stream_bg));
     free_move_buffers(c);
     const size_t N = c->N;
     c->mb.capC = capC; /* (slice_pool_max reads it) */
@@ -1410,7 +1391,7 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
         ig_ctx* c;
         StaleGuard(ig_ctx* ctx, bool on) : c(ctx) { c->mb.stale = on ? c->dirty_buf : nullptr; }
         ~StaleGuard() { c->mb.stale = nullptr; }
-    } stale_guard(c, par_only && (pb > 0 || c->spec_adopted)); /* (a batch adopted from the background: stale from its first slot on) */
+    } stale_guard(c, par_only && pb > 0);
     const int N = c->N;
     const int gN = std::max((N + 255) / 256, W);
     const PzTab pz{c->pz_tab, c->pz_n};
@@ -1433,9 +1414,8 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
             c->own_end = w_end;
             if (nW > 0) {
                 /* long contigs (late in an assembly: windows of thousands of sub-fragments): more threads per candidate genome */
-                static const int s_mt = getenv("IG_MUTATE_THREADS") ? atoi(getenv("IG_MUTATE_THREADS")) : 0;
                 const int mean_len = c->n_contigs_seen > 0 ? c->N / c->n_contigs_seen : 0;
-                const int mutate_threads = s_mt > 0 ? s_mt : (mean_len >= 600 ? 1024 : (mean_len >= 150 ? 512 : 256));
+                const int mutate_threads = mean_len >= 600 ? 1024 : (mean_len >= 150 ? 512 : 256);
                 hipLaunchKernelGGL(k_mutate, dim3(NSLOT, max_c, nW), dim3(mutate_threads), 0, c->stream, c->st, c->tab, c->sub_tab, c->rowptr,
                                    c->glob, c->mb, pz, w_begin);
             }
@@ -1446,16 +1426,14 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                 hipLaunchKernelGGL(k_offsets, dim3(1), dim3(OFFSETS_THREADS), 0, c->stream, c->mb, W, w_begin, w_end, max_c);
                 /* a wave walks a row (a workgroup 4 rows at a time).  Measured at cfg3 (us per launch of 24 slots): 32 workgroups per
                  * candidate 193, 64: 156, 96: 148, 128: 136, 256 with the chunks of a row dealt to several waves: 146 */
-                static const int s_rb = getenv("IG_SLICE_RB") ? atoi(getenv("IG_SLICE_RB")) : 0;
                 /* ... and with the lists in 8 segments (round 3), workgroups per plane -> moves/s: cfg3 24: 43.1 k, 32: 44.2, 40: 45.5, 48: 45.2 - 45.7,
                  * 64: 45.4, 80: 45.3, 96: 44.6, 128: 43.9; cfg2 32: 57.3 k, 48: 55.9, 96: 55.5; cfg5 32: 28.4 k, 48: 29.9, 96: 30.1; bigctg 32: 5.3 k,
                  * 48: 5.75, 96: 5.93 -- the count follows the contacts a plane holds (two contigs' rows: 2 Z / contigs of the last batch) */
                 const int rb_auto = c->n_contigs_seen > 0
                                         ? std::min(SLICE_RB, std::max(32, (int)(2.0 * (double)c->Z / (double)c->n_contigs_seen / 2100.0)))
                                         : SLICE_RB;
-                const int rb = s_rb > 0 ? s_rb : rb_auto;
-                static const int s_share = getenv("IG_SLICE_SHARE") ? atoi(getenv("IG_SLICE_SHARE")) : 1; /* A's rows once per move */
-                static const int s_maxj = getenv("IG_SLICE_J") ? std::max(1, atoi(getenv("IG_SLICE_J"))) : 1 << 20;
+                const int rb = rb_auto;
+                const int s_share = 1, s_maxj = 1 << 20; /* A's rows once per move */
                 if (c->mb.packed)
                     hipLaunchKernelGGL(k_slice<true>, dim3(rb, max_c + 1, nW), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->rank,
                                        c->world, w_begin, s_share, s_maxj);
@@ -1471,12 +1449,13 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
              * IG_SCREEN_VERIFY=1: everything exact AND screened, the bound checked column by column. */
             const int s_screen = getenv("IG_SCREEN") ? atoi(getenv("IG_SCREEN")) : 1; /* read per launch, like the next one */
             const int verify = getenv("IG_SCREEN_VERIFY") ? atoi(getenv("IG_SCREEN_VERIFY")) : 0; /* read per launch: a test toggles it */
-            static const int s_screen_min_w = getenv("IG_SCREEN_MIN_W") ? atoi(getenv("IG_SCREEN_MIN_W")) : 2;
-            const bool screen = (s_screen || verify) && phase == 2 && W >= s_screen_min_w && W > 1 && c->world == 1 && c->mb.packed;
+            /* exact_next: the decide step met a score of exactly 0.0 among the contenders (stop code 3) -- this scoring is exact in every column */
+            const bool exact_once = c->exact_next && !par_only;
+            if (exact_once) c->exact_next = false;
+            const bool screen = (s_screen || verify) && phase == 2 && W > 1 && c->world == 1 && c->mb.packed && !exact_once;
             /* the Q5 tail walk only needs the slice: in the screening kernel's launch (k_screen_tail), else on a second stream
              * next to k_score_list */
-            static const int s_fuse = getenv("IG_FUSE_TAIL") ? atoi(getenv("IG_FUSE_TAIL")) : 1;
-            c->tail_fused = screen && s_fuse;
+            c->tail_fused = screen;
             if (phase == 2 && !c->tail_fused) {
                 hipEventRecord(c->ev_slice, c->stream);
                 hipStreamWaitEvent(c->stream2, c->ev_slice, 0);
@@ -1488,12 +1467,10 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
             if (screen) {
                 const int ny = (NSLOT + 1) / 2;
                 /* the long lists first (MoveBuf.order, k_offsets): when this launch screens the slots that one placed */
-                static const int s_order = getenv("IG_SCREEN_ORDER") ? atoi(getenv("IG_SCREEN_ORDER")) : 1;
-                const int use_order = (s_order && !par_only && pb == w_begin && pe == w_end && nWp * max_c <= (int)OFFSETS_THREADS) ? 1 : 0;
+                const int use_order = (!par_only && pb == w_begin && pe == w_end && nWp * max_c <= (int)OFFSETS_THREADS) ? 1 : 0;
                 /* narrow batches (late in an assembly: few long contigs, a conflict at nearly every move): few (segment, pair,
                  * candidate) triples, each with a long list -- Q workgroups split a segment so that the launch has ~7 000 of them */
-                static const int s_q = getenv("IG_SCREEN_PARTS") ? atoi(getenv("IG_SCREEN_PARTS")) : 0;
-                const int Q = s_q > 0 ? std::min(s_q, 16) : std::max(1, std::min(8, (7000 + SLICE_SEG * ny * max_c * nWp - 1) / (SLICE_SEG * ny * max_c * nWp)));
+                const int Q = std::max(1, std::min(8, (7000 + SLICE_SEG * ny * max_c * nWp - 1) / (SLICE_SEG * ny * max_c * nWp)));
                 {
                     TimedLaunch t(c, T_SCREEN);
                     if (c->tail_fused)
@@ -1552,8 +1529,7 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
                 if (!c->tail_fused) hipStreamWaitEvent(c->stream, c->ev_tail, 0); /* the contender test reads the exact tail sums (quirk Q5) */
                 flush_pending_sums(c); /* ... and the maintained sum (its intervals are placed with it) */
                 hipLaunchKernelGGL(k_contend, dim3(nWp), dim3(256), 0, c->stream, c->glob, c->mb, c->mb.scr, c->mb.scr_void, c->mb.scr_ub, c->mb.cont, pb,
-                                   getenv("IG_CONTEND_ALL") ? atoi(getenv("IG_CONTEND_ALL")) : 0, c->exact_grid,
-                                   getenv("IG_EXACT_CHUNK") ? std::max(256, atoi(getenv("IG_EXACT_CHUNK"))) : EXACT_CHUNK);
+                                   0, c->exact_grid, EXACT_CHUNK);
                 hipLaunchKernelGGL(k_worklist, dim3(nWp), dim3(256), 0, c->stream, c->mb, c->mb.cont, pb, c->exact_grid);
                 contenders_only = verify ? 0 : 1;
             }
@@ -1581,6 +1557,7 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
         }
     }
     if (phase == 1 || phase == 2) {
+        flush_pending_sums(c); /* (k_predict reads the maintained sum: with or without the screening tier in front of it) */
         if (force_slot < 0 && nWp > 0) {
             if (phase == 1) /* after the all-reduce of the list lengths (contact shards): no overlap */
                 hipLaunchKernelGGL(k_tail, dim3(max_c, nWp), dim3(256), 0, c->stream, c->rowptr, c->cc, c->tab, c->glob, c->mb, c->lgf_tab,
@@ -1592,11 +1569,9 @@ static void enqueue_score(ig_ctx* c, int move0, int W, int max_c, int force_slot
             /* batches: predicted windowed winners get their exact delta now (not those decided one move per call, ig_nuis_step_begin:
              * a pause costs them nothing they would not wait for anyway) */
             if (phase == 2 && W > 1 && c->world == 1 && !c->no_predict) {
-                static const int s_pred2 = getenv("IG_PREDICT_PASSES") ? atoi(getenv("IG_PREDICT_PASSES")) : 2;
-                if (s_pred2 >= 2) hipLaunchKernelGGL(k_predict, dim3(nWp), dim3(256), 0, c->stream, c->glob, c->mb, pb, 0);
+                hipLaunchKernelGGL(k_predict, dim3(nWp), dim3(256), 0, c->stream, c->glob, c->mb, pb, 0);
                 hipLaunchKernelGGL(k_predict, dim3(nWp), dim3(256), 0, c->stream, c->glob, c->mb, pb, 1);
-                static const int s_drb = getenv("IG_DELTA_RB") ? atoi(getenv("IG_DELTA_RB")) : DELTA_RB;
-                hipLaunchKernelGGL(k_delta, dim3(s_drb, 2, nWp), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->tab_prev,
+                hipLaunchKernelGGL(k_delta, dim3(DELTA_RB, 2, nWp), dim3(SCORE_THREADS), 0, c->stream, c->rowptr, c->cc, c->tab, c->tab_prev,
                                    c->prev_touched, c->glob, c->mb, c->lgf_tab, pz, pb, 1, 0);
             }
         }
@@ -1665,6 +1640,8 @@ static int validate_move(ig_ctx* c, int frag_a, const int32_t* cands, int C)
     return 0;
 }
 
+static int g_zero_inject = 0; /* ig_debug_set_zero_inject: the decide step treats every n-th move of a two-tier batch as one with a score of exactly 0.0 */
+
 /* commit the scored batch [move0, move0 + w_now): k_commit_batch, the one-move tail for a windowed winner, resume */
 /* the decide + apply launches of the slots [next, w_now) of the batch at move `done` */
 static void launch_commit(ig_ctx* c, int done, int w_now, int next, int resumed_plain, bool publish = false)
@@ -1678,16 +1655,18 @@ static void launch_commit(ig_ctx* c, int done, int w_now, int next, int resumed_
      * fused kernel writes behind a longer prologue: 10.2 k instead of 10.7 k), not the late shapes (bigctg: 5.7 k instead of 5.9 k),
      * not a rank's share of a batch (the winners of the other ranks are mutated in between).  IG_FUSED_COMMIT=0 / 2: never / always. */
     const bool fuse = s_fused >= 2 || (s_fused == 1 && !publish && c->max_SL <= 4096);
+    /* contender-only records (two-tier scoring): the decide step checks for scores of exactly 0.0 (decide_body, stop code 3) */
+    const int zcheck = (c->own_screened == 1 ? 1 : 0) | (std::max(g_zero_inject, 0) << 8);
     if (fuse && !(c->own_begin > 0 || c->own_end < w_now)) {
         const int seq = ++c->bo_seq;
         hipLaunchKernelGGL(k_decide_commit, dim3(1), dim3(64 + FUSED_CW * 64), 0, c->stream, c->glob, c->mb, c->d_results, done, w_now, next, c->dirty_buf,
                            c->batch_out, (volatile int*)c->host_bo_dev, seq, resumed_plain, c->st, c->tab, c->tab_prev, c->init_prev, c->init_next,
                            c->orientable, c->black, c->own_tag, c->own_idx, c->prev_touched, publish ? c->host_nuis_dev : nullptr,
-                           publish ? ++c->res_seq : 0);
+                           publish ? ++c->res_seq : 0, zcheck);
         return;
     }
     hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(64), 0, c->stream, c->glob, c->mb, c->d_results, done, w_now, next, c->dirty_buf,
-                       c->batch_out, (volatile int*)c->host_bo_dev, ++c->bo_seq, resumed_plain);
+                       c->batch_out, (volatile int*)c->host_bo_dev, ++c->bo_seq, resumed_plain, zcheck);
     if (c->own_begin > 0 || c->own_end < w_now)
         hipLaunchKernelGGL(k_mutate_winners, dim3(2, w_now), dim3(256), 0, c->stream, c->st, c->tab, c->sub_tab, c->rowptr, c->glob,
                            c->mb, PzTab{c->pz_tab, c->pz_n}, next, c->own_begin, c->own_end, c->batch_out);
@@ -1730,6 +1709,10 @@ static int wait_commit(ig_ctx* c, int bo[12], bool first_of_batch, int next)
     c->max_L = std::max(c->max_L, bo[8]);
     c->max_SL = std::max(c->max_SL, bo[9]);
     c->last_stop = bo[10];
+    if (bo[10] == 3) { /* a scored column came out as exactly 0.0 under the live scalars: the next scoring is exact in every column */
+        c->exact_next = true;
+        c->n_zero_fallbacks++;
+    }
     return 0;
 }
 
@@ -1741,7 +1724,8 @@ static int commit_loop(ig_ctx* c, int done, int w_now, int* next_out)
         int bo[12];
         if (wait_commit(c, bo, next == 0, next)) return -1;
         if (bo[2] && next == 0 && bo[0] == 0 && bo[1] < 0) { /* the batch's first slot did not fit the slice pool (1) or the exact
-                                                               * kernel's grid (2): the caller enlarges it and repeats the batch */
+                                                               * kernel's grid (2): the caller enlarges it and repeats the batch; (3) a
+                                                               * score of exactly 0.0: the caller repeats it, every column exact */
             *next_out = -bo[2];
             return 0;
         }
@@ -1848,11 +1832,10 @@ static int run_moves(ig_ctx* c, int n_moves, int max_c, int Wmax, Ready ready)
      * contig an earlier move of the batch modified, and slots scored behind the first conflict are wasted work.  Moving
      * average of the moves a batch got through (a batch that got through all of them counts double: the run was at
      * least that long); the next batch is 1.5 x that, at most Wmax.  Results do not depend on the widths. */
-    static const int s_adaptive = getenv("IG_ADAPTIVE_W") ? atoi(getenv("IG_ADAPTIVE_W")) : 1;
     if (c->w_ema <= 0.0 || c->w_ema > Wmax) c->w_ema = Wmax;
     int done = 0;
     while (done < n_moves) {
-        const int w_want = s_adaptive ? std::max(2, std::min(Wmax, (int)(1.5 * c->w_ema + 1.5))) : Wmax;
+        const int w_want = std::max(2, std::min(Wmax, (int)(1.5 * c->w_ema + 1.5)));
         const int w_now = std::min(w_want, n_moves - done);
         if (ready(done, w_now)) return -1;
         if (ensure_window_buffers(c)) return -1; /* the longest contig may have grown */
@@ -1862,6 +1845,7 @@ static int run_moves(ig_ctx* c, int n_moves, int max_c, int Wmax, Ready ready)
         if (next < 0) { /* the first slot did not fit: more room, the same batch again (nothing was committed) */
             if (next == -1) {
                 if (grow_slice_pool(c)) return -1;
+            } else if (next == -3) { /* (wait_commit has set exact_next: the same batch again without the screening tier) */
             } else {
                 if (c->exact_grid >= c->mb.work_cap) return fail("the exact kernel's work list cannot hold the first move of a batch");
                 c->exact_grid = std::min(c->mb.work_cap, c->exact_grid * 4);
@@ -2029,6 +2013,7 @@ extern "C" int ig_batch_commit(ig_ctx* c, int32_t move0, int32_t W, int32_t* n_c
     if (next < 0) { /* the first slot did not fit the slice pool / the exact kernel's grid: more room, the caller scores the batch again */
         if (next == -1) {
             if (grow_slice_pool(c)) return -1;
+        } else if (next == -3) { /* (the next ig_batch_score is exact in every column: exact_next) */
         } else {
             if (c->exact_grid >= c->mb.work_cap) return fail("the exact kernel's work list cannot hold the first move of a batch");
             c->exact_grid = std::min(c->mb.work_cap, c->exact_grid * 4);
@@ -2253,11 +2238,23 @@ static bool wait_host_flag(volatile int* flag, int seq, hipStream_t stream)
 
 /* ---- the Metropolis test from a screened pass (ig_kernels_nuis.cuh) ------------------------------------------------------
  * IG_NUIS_SCREEN=0: every step through the exact pass, as before; IG_NUIS_SCREEN_VERIFY=1: both, the bound checked on the host */
-static int g_nuis_screen = -1, g_nuis_screen_verify = -1;
+static int g_nuis_screen = -1, g_nuis_screen_verify = 0, g_nuis_hist_trace = 0;
+static int g_nuis_hist = -1; /* tier 0 of the screened pass: ig_set_nuis_hist / IG_NUIS_HIST (0: off, 1: where its cost model says, 2: always) */
+static int g_nuis_chain = -1; /* chains of pairs decided on the device: ig_set_nuis_chain / IG_NUIS_CHAIN (default 1) */
+static int g_nuis_w = -1;    /* moves scored ahead per launch in a run of ig_nuis_step_begin: env IG_NUIS_W, ig_set_nuis_width; 0: follow the run lengths */
+static void nuis_latch_env()
+{
+    if (g_nuis_hist < 0) g_nuis_hist = getenv("IG_NUIS_HIST") ? atoi(getenv("IG_NUIS_HIST")) : 1;
+    if (g_nuis_w < 0) g_nuis_w = getenv("IG_NUIS_W") ? std::max(0, atoi(getenv("IG_NUIS_W"))) : 0;
+    if (g_nuis_chain < 0) g_nuis_chain = getenv("IG_NUIS_CHAIN") ? atoi(getenv("IG_NUIS_CHAIN")) : 1;
+    if (g_nuis_screen < 0) g_nuis_screen = getenv("IG_NUIS_SCREEN") ? atoi(getenv("IG_NUIS_SCREEN")) : 1;
+    g_nuis_screen_verify = getenv("IG_NUIS_SCREEN_VERIFY") ? atoi(getenv("IG_NUIS_SCREEN_VERIFY")) : 0; /* per run: a test toggles it */
+    g_nuis_hist_trace = getenv("IG_NUIS_HIST_TRACE") ? atoi(getenv("IG_NUIS_HIST_TRACE")) : 0;
+}
 static bool nuis_screen_usable(ig_ctx* c)
 {
-    if (g_nuis_screen < 0) g_nuis_screen = getenv("IG_NUIS_SCREEN") ? atoi(getenv("IG_NUIS_SCREEN")) : 1;
-    g_nuis_screen_verify = getenv("IG_NUIS_SCREEN_VERIFY") ? atoi(getenv("IG_NUIS_SCREEN_VERIFY")) : 0; /* read per step: a test toggles it */
+    /* (the environment is read on the caller's thread, where a run begins -- nuis_latch_env: this function also runs on the helper
+     * thread, and getenv next to a setenv of the interpreter's thread is undefined) */
     static const int s_tiled = getenv("IG_FULL_TILED") ? atoi(getenv("IG_FULL_TILED")) : 1;
     return (g_nuis_screen || g_nuis_screen_verify) && c->nuis_spec && c->host_nuis_dev && s_tiled && c->tiled_cc && c->n_tile_work > 0 &&
            c->score_const && c->screen_const && c->pz_tab && g_full_hist != 0;
@@ -2284,10 +2281,9 @@ static void launch_nuis_exact_tiles(ig_ctx* c, hipStream_t s3, long long* out = 
 }
 
 /* tier 0 of the screened pass (ig_kernels_nuis.cuh): the histogram of the cis contacts' distances.  IG_NUIS_HIST=0: off */
-static int g_nuis_hist = -1;
 static bool nuis_hist_usable(ig_ctx* c)
 {
-    if (g_nuis_hist < 0) g_nuis_hist = getenv("IG_NUIS_HIST") ? atoi(getenv("IG_NUIS_HIST")) : 1;
+    if (g_nuis_hist < 0) g_nuis_hist = 1; /* (IG_NUIS_HIST: nuis_latch_env) */
     if (!g_nuis_hist || !nuis_screen_usable(c)) return false;
     if (g_nuis_hist >= 2) return true; /* (2: whatever the cost model says -- tests) */
     /* The histogram pays where the pass over the contacts is long and the moves are local.  Per step it costs its evaluation
@@ -2345,7 +2341,7 @@ static int nh_flush_pending(ig_ctx* c)
     const int w = c->nh_pending_slot;
     c->nh_pending_slot = -1;
     if (w < 0 || !c->nh_valid || !c->nh.bins) return 0;
-    static const int s_blocks = getenv("IG_HIST_WALK_BLOCKS") ? std::max(1, atoi(getenv("IG_HIST_WALK_BLOCKS"))) : 128;
+    const int s_blocks = 128;
     hipLaunchKernelGGL(k_hist_walk, dim3(s_blocks), dim3(256), 0, c->stream3, c->rowptr, c->cc, c->tab_prev, c->glob, c->mb, w, c->nh);
     HIPCK(hipEventRecord(c->ev_walk, c->stream3));
     HIPCK(hipStreamWaitEvent(c->stream, c->ev_walk, 0));
@@ -2402,7 +2398,7 @@ static int launch_nuis_diff(ig_ctx* c, const ig_params& hp, hipStream_t s3, bool
      * blocks as the head of this kernel's grid, the stream workgroups waiting for them in front of the list: 95 - 112 us instead of
      * 11 + 68 - 84 -- 400 head blocks with this kernel's footprint hold the machine before the first contact is read.) */
     static const int s_grid = getenv("IG_FULL_GRID") ? atoi(getenv("IG_FULL_GRID")) : 510;
-    static const int s_grid_side = getenv("IG_FULL_GRID_SIDE") ? atoi(getenv("IG_FULL_GRID_SIDE")) : 256;
+    const int s_grid_side = 256;
     const int grid = std::min(c->n_tile_work, c->side_busy ? s_grid_side : s_grid);
     {
         TimedLaunch tl(c, T_DIFF, s3);
@@ -2515,6 +2511,7 @@ extern "C" int ig_nuis_begin(ig_ctx* c, int32_t frag_a, const int32_t* cands, in
     if (check_ready(c)) return -1;
     if (c->world > 1) return fail("ig_nuis_begin: this handle scores a contact shard");
     if (c->nuis_in_flight) return fail("ig_nuis_begin: the previous step was not ended (ig_nuis_end)");
+    nuis_latch_env();
     if (validate_move(c, frag_a, cands, C)) return -1;
     if (ensure_move_buffers(c, std::max(8, (int)C))) return -1;
     if (ensure_io(c, 1, C)) return -1;
@@ -2543,10 +2540,9 @@ extern "C" int ig_nuis_begin(ig_ctx* c, int32_t frag_a, const int32_t* cands, in
  * moves starting at i if move i has no valid scores yet (first step, after an accepted step, after a conflict, batch used
  * up), and decides + applies move i ALONE from its records (k_decide_batch over one slot); ig_nuis_end / ig_nuis_accept as
  * above.  An accepted step invalidates the slots scored ahead.  Same results as one move and one step at a time. */
-static int g_nuis_w = -1; /* moves scored ahead per launch in a run of ig_nuis_step_begin: env IG_NUIS_W, ig_set_nuis_width; 0: follow the run lengths */
 static int nuis_spec_width(ig_ctx* c)
 {
-    if (g_nuis_w < 0) g_nuis_w = getenv("IG_NUIS_W") ? std::max(0, atoi(getenv("IG_NUIS_W"))) : 0;
+    if (g_nuis_w < 0) g_nuis_w = 0; /* (IG_NUIS_W: nuis_latch_env) */
     const int s_w = g_nuis_w;
     const int cap = std::min(c->mb.capW, IG_MAX_BATCH);
     if (s_w > 0) return std::min(s_w, cap);
@@ -2571,14 +2567,13 @@ extern "C" int ig_nuis_run_begin(ig_ctx* c, int32_t n_moves, const int32_t* frag
     if (check_ready(c)) return -1;
     if (c->world > 1) return fail("ig_nuis_run_begin: this handle scores a contact shard");
     if (c->nuis_in_flight) return fail("ig_nuis_run_begin: a step is in flight (ig_nuis_end)");
+    nuis_latch_env();
     if (n_moves <= 0) return fail("ig_nuis_run_begin: no moves");
     if (max_c < 1 || max_c > IG_MAX_CANDIDATES) return fail("ig_nuis_run_begin: max_c out of range");
     if (!c->init_links_inverse) return fail("ig_nuis_run_begin: the initial prev / next arrays are not mutually inverse (ig_links_inverse): ig_nuis_begin, one pair at a time");
     if (nh_flush_pending(c)) return -1; /* the last move of the run before: into the histogram while its slot is still there */
-    c->bg_valid = false;
-    c->spec_adopted = false;
-    static const int s_cap = getenv("IG_NUIS_WMAX") ? atoi(getenv("IG_NUIS_WMAX")) : 24;
-    if (g_nuis_w < 0) g_nuis_w = getenv("IG_NUIS_W") ? std::max(0, atoi(getenv("IG_NUIS_W"))) : 0;
+    const int s_cap = 24; /* (wider structural batches: 40 / 64 slots 8.7 / 8.0 k instead of 9.1 k -- slots behind the first conflict are wasted) */
+    if (g_nuis_w < 0) g_nuis_w = 0; /* (IG_NUIS_W: nuis_latch_env) */
     const int Wmax = std::max(1, std::min(std::max(s_cap, g_nuis_w), max_batch_width(c, max_c)));
     if (ensure_move_buffers(c, std::max(8, (int)max_c), Wmax)) return -1;
     if (upload_moves(c, n_moves, frags, cands, max_c)) return -1;
@@ -2598,8 +2593,6 @@ static int nuis_struct_width(ig_ctx* c)
 {
     const int cap = std::min(c->mb.capW, IG_MAX_BATCH);
     if (g_nuis_w > 0) return std::min(g_nuis_w, cap);
-    static const int s_keep = getenv("IG_NUIS_KEEP") ? atoi(getenv("IG_NUIS_KEEP")) : 1; /* 0: the structural half is redone with every scoring (as before) */
-    if (!s_keep) return nuis_spec_width(c);
     if (c->spec_struct_ema <= 0.0) c->spec_struct_ema = cap;
     return std::max(nuis_spec_width(c), std::min(cap, (int)(1.5 * c->spec_struct_ema + 1.5)));
 }
@@ -2629,18 +2622,25 @@ static void nuis_spec_invalidate(ig_ctx* c)
 }
 
 /* score a batch of moves starting at `move`: the structural half of all its slots, the parameter half of the first ones */
+/* chains of pairs decided on the device (ig_nuis_chain_begin): 1 (default; env IG_NUIS_CHAIN, ig_set_nuis_chain): the runs score the
+ * parameter half of EVERY slot of a batch (a chain takes the slots as far as the batch stands, an accepted step is rare where chains
+ * pay) and predict the windowed winners' deltas (a pending move would end a chain) */
+static bool nuis_chain_on() { return g_nuis_chain != 0; }
+extern "C" int ig_set_nuis_chain(int on)
+{
+    g_nuis_chain = on ? 1 : 0;
+    return 0;
+}
+
 static int nuis_spec_score(ig_ctx* c, int move)
 {
     if (nh_flush_pending(c)) return -1; /* (the buffers of the last move's slot are about to be overwritten) */
-    c->bg_valid = false; /* (a batch scored in the background belongs to the batch it was launched from) */
-    c->spec_adopted = false;
     c->spec_changed = false;
     nuis_spec_invalidate(c);
     const int W = std::min(nuis_struct_width(c), c->up_moves - move);
-    const int r = std::min(nuis_spec_width(c), W);
+    const int r = nuis_chain_on() ? W : std::min(nuis_spec_width(c), W);
     if (ensure_window_buffers(c)) return -1; /* the longest contig may have grown */
-    static const int s_nopred = getenv("IG_NUIS_PREDICT") ? !atoi(getenv("IG_NUIS_PREDICT")) : 1;
-    c->no_predict = s_nopred != 0;
+    c->no_predict = !nuis_chain_on(); /* (decided one move per step: a pause for a windowed winner costs nothing the step would not wait for anyway) */
     enqueue_score(c, move, W, c->up_max_c, -1, 2, 0, W, 0, r, false);
     c->no_predict = false;
     c->spec_base = move;
@@ -2662,233 +2662,12 @@ static bool nuis_spec_can_rescore(const ig_ctx* c, int move)
 static int nuis_spec_rescore(ig_ctx* c)
 {
     nuis_par_invalidate(c);
-    const int pb = c->spec_next, pe = std::min(c->spec_W, pb + nuis_spec_width(c));
-    static const int s_nopred = getenv("IG_NUIS_PREDICT") ? !atoi(getenv("IG_NUIS_PREDICT")) : 1;
-    c->no_predict = s_nopred != 0;
+    const int pb = c->spec_next, pe = nuis_chain_on() ? c->spec_W : std::min(c->spec_W, pb + nuis_spec_width(c));
+    c->no_predict = !nuis_chain_on();
     enqueue_score(c, c->spec_base, c->spec_W, c->up_max_c, -1, 2, 0, c->spec_W, pb, pe, true);
     c->no_predict = false;
     c->spec_par_begin = pb;
     c->spec_par_end = pe;
-    return 0;
-}
-
-/* ---- the next batch of a run, scored in the background ---------------------------------------------------------------------
- * The step that scores a new batch costs 450 - 650 us (gather, mutate, slice, screen, exact: a dozen latency-bound launches) while a
- * normal step leaves the machine idle more than half of the time, waiting for the host's proposal.  A batch does not get used
- * up: it ends when a move touches a contig an earlier move of the batch modified (20 of 24 slots on average at the headline
- * shape).  So whenever a move of the batch in the buffers has CHANGED the genome -- from then on the batch is going stale -- or the
- * batch has IG_NUIS_BG_LEAD slots left, a batch that starts at the very NEXT move is scored on a low-priority stream into a second
- * set of buffers against a SNAPSHOT of the state (state arrays, tables, scalars: copied on the library stream behind the step's
- * commit; the moves committed meanwhile cannot race with it).  When the batch in the buffers ends -- conflict or used up -- the
- * buffers are swapped (nuis_bg_adopt) and the decisions go on at the slot of the move in question: the slots before it belong to
- * moves decided meanwhile; the contigs modified since the snapshot are the tail of the decide step's list (bg_mark), loaded by the
- * first decision from the adopted batch like the list of an earlier launch; slot 0 was scored with every block-insert slot of
- * its candidate 0 like the other slots (its stale flags were not known); a slot's fresh contig ids are those a batch scored at
- * the snapshot would hand out (one set per move since); an accepted step since the launch voids the parameter half only.
- * IG_NUIS_BG=1 / ig_set_nuis_background(1): on (off by default, see nuis_bg_enabled).  Results do not depend on it
- * (tests/test_hip_nuis_screen.py). */
-__global__ void k_bg_fix(const int* __restrict__ dirty_buf, int* bg_mark) { bg_mark[0] = dirty_buf[0]; }
-__global__ void __launch_bounds__(64) k_bg_adopt(Glob* g, const Glob* g2, int* dirty_buf, const int* __restrict__ bg_mark)
-{
-    const int lane = threadIdx.x;
-    const int n = dirty_buf[0], m = min(max(bg_mark[0], 0), n);
-    constexpr int NQ = (2 * IG_MAX_BATCH + 2 + 63) / 64;
-    int v[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) v[q] = (lane + 64 * q < n - m) ? dirty_buf[1 + m + lane + 64 * q] : -2;
-    __builtin_amdgcn_s_barrier(); /* (one wave: everything is read before anything is written) */
-#pragma unroll
-    for (int q = 0; q < NQ; q++)
-        if (lane + 64 * q < n - m) dirty_buf[1 + lane + 64 * q] = v[q];
-    if (lane == 0) {
-        dirty_buf[0] = n - m;
-        if (g2->error && !g->error) g->error = g2->error; /* (the background kernels reported into the snapshot) */
-        g->next_cid = max(g->next_cid, g2->next_cid);
-    }
-}
-
-static int g_nuis_bg = -1;
-static bool nuis_bg_enabled()
-{
-    /* OFF unless asked for: measured at the headline shape (settled chain, tools/nuisance_rate.py) 8.0 k (move + step)/s with a lead of
-     * 6 slots, 7.4 / 6.9 k with 10 / 14, 6.8 k when every move that changes the genome starts one -- against 9.6 k without.  The
-     * batch scored in the background is a dozen machine-filling launches: next to it a step's own small kernels take 100 instead of
-     * 56 us (device wait 45 -> 60 - 85 us per step), and most batches end in a conflict whose move is stale in the background batch
-     * as well (its cause came after the snapshot), so the step that scores a batch is not even avoided (p95 of a step: 430 us either
-     * way).  Kept switchable and tested (same results): a cheaper structural half would change the balance. */
-    if (g_nuis_bg < 0) g_nuis_bg = getenv("IG_NUIS_BG") ? atoi(getenv("IG_NUIS_BG")) : 0;
-    return g_nuis_bg != 0;
-}
-extern "C" int ig_set_nuis_background(int on)
-{
-    g_nuis_bg = on ? 1 : 0;
-    return 0;
-}
-static int ensure_bg_buffers(ig_ctx* c)
-{
-    if (!c->stream_bg) {
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&c->stream_bg, hipStreamDefault, least) != hipSuccess) {
-            (void)hipGetLastError();
-            HIPCK(hipStreamCreate(&c->stream_bg));
-        }
-        HIPCK(hipEventCreateWithFlags(&c->ev_snap, hipEventDisableTiming));
-        HIPCK(hipEventCreateWithFlags(&c->ev_bg_done, hipEventDisableTiming));
-        DALLOC(c->glob2, 1);
-        DALLOC(c->bg_mark, 4);
-    }
-    if (c->bg_N != c->N || c->bg_M != c->M || !c->st2_block) {
-        HIPCK(hipStreamSynchronize(c->stream_bg));
-        hipFree(c->st2_block);
-        hipFree(c->tab2.dist);
-        hipFree(c->touched_bits2);
-        c->st2_block = nullptr;
-        c->tab2.dist = nullptr;
-        c->touched_bits2 = nullptr;
-        const size_t n = (size_t)c->N, M = (size_t)c->M;
-        DALLOC(c->st2_block, 17 * n);
-        int** sp = (int**)&c->st2;
-        for (int k = 0; k < 17; k++) sp[k] = c->st2_block + k * n;
-        int* blk;
-        DALLOC(blk, 6 * M + 2);
-        c->tab2.dist = (float*)blk;
-        c->tab2.stot = (float*)(blk + M);
-        c->tab2.len = blk + 2 * M;
-        c->tab2.cp = (int2*)(blk + 4 * M + ((4 * M) & 1));
-        const size_t n_tw = (M + 31) / 32 + 1;
-        DALLOC(c->touched_bits2, 2 * n_tw);
-        HIPCK(hipMemset(c->touched_bits2, 0, 2 * n_tw * sizeof(unsigned)));
-        c->touched_flip2 = 0;
-        c->bg_N = c->N;
-        c->bg_M = c->M;
-    }
-    const MoveBuf& a = c->mb;
-    MoveBuf& m = c->mb2;
-    if (m.capC != a.capC || m.capW != a.capW || m.N != a.N || m.M != a.M || m.packed != a.packed || m.pool_cap < a.pool_cap) {
-        HIPCK(hipStreamSynchronize(c->stream_bg));
-        free_movebuf(m);
-        if (alloc_movebuf(c, m, a.capC, a.capW, a.packed, (size_t)a.pool_cap)) return -1;
-    }
-    return ensure_window_buffers(c, m);
-}
-
-/* the kernels of enqueue_score take what they read from the handle: for the launches of the background batch the handle shows
- * the second set of buffers, the snapshot and the background stream */
-struct BgSwap {
-    ig_ctx* c;
-    hipStream_t stream;
-    State st;
-    Tables tab, tab_prev;
-    Glob* glob;
-    int own_begin, own_end, own_screened;
-    bool tail_fused, no_predict;
-    explicit BgSwap(ig_ctx* ctx) : c(ctx)
-    {
-        stream = c->stream;
-        st = c->st;
-        tab = c->tab;
-        tab_prev = c->tab_prev;
-        glob = c->glob;
-        own_begin = c->own_begin;
-        own_end = c->own_end;
-        own_screened = c->own_screened;
-        tail_fused = c->tail_fused;
-        no_predict = c->no_predict;
-        std::swap(c->mb, c->mb2);
-        std::swap(c->touched_bits, c->touched_bits2);
-        std::swap(c->touched_flip, c->touched_flip2);
-        c->stream = c->stream_bg;
-        c->st = c->st2;
-        c->tab = c->tab2;
-        c->tab_prev = c->tab2; /* (k_gather's catch-up of the pre-move tables: onto itself) */
-        c->glob = c->glob2;
-    }
-    ~BgSwap()
-    {
-        c->bg_own_begin = c->own_begin;
-        c->bg_own_end = c->own_end;
-        c->bg_own_screened = c->own_screened;
-        c->bg_tail_fused = c->tail_fused;
-        std::swap(c->mb, c->mb2);
-        std::swap(c->touched_bits, c->touched_bits2);
-        std::swap(c->touched_flip, c->touched_flip2);
-        c->stream = stream;
-        c->st = st;
-        c->tab = tab;
-        c->tab_prev = tab_prev;
-        c->glob = glob;
-        c->own_begin = own_begin;
-        c->own_end = own_end;
-        c->own_screened = own_screened;
-        c->tail_fused = tail_fused;
-        c->no_predict = no_predict;
-    }
-};
-
-/* called behind the launches of a step whose move sits in slot spec_next of the batch in the buffers: a batch from the move behind it */
-static int nuis_bg_launch(ig_ctx* c)
-{
-    const int base2 = c->spec_base + c->spec_next + 1;
-    const int W2 = std::min(nuis_struct_width(c), c->up_moves - base2);
-    if (W2 < 1) return 0;
-    const int r2 = std::min(nuis_spec_width(c), W2);
-    if (ensure_bg_buffers(c)) return -1;
-    flush_pending_sums(c); /* (the snapshot of the scalars: with the maintained sum in place) */
-    HIPCK(hipStreamWaitEvent(c->stream, c->ev_bg_done, 0)); /* (a dropped background batch may still be reading the snapshot) */
-    HIPCK(hipMemcpyAsync(c->st2_block, c->st_block, 17 * (size_t)c->N * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
-    HIPCK(hipMemcpyAsync(c->tab2.dist, c->tab.dist, (6 * (size_t)c->M + 2) * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
-    HIPCK(hipMemcpyAsync(c->glob2, c->glob, sizeof(Glob), hipMemcpyDeviceToDevice, c->stream));
-    hipLaunchKernelGGL(k_bg_fix, dim3(1), dim3(1), 0, c->stream, c->dirty_buf, c->bg_mark);
-    HIPCK(hipEventRecord(c->ev_snap, c->stream));
-    HIPCK(hipStreamWaitEvent(c->stream_bg, c->ev_snap, 0));
-    {
-        BgSwap sw(c);
-        c->no_predict = true;
-        enqueue_score(c, base2, W2, c->up_max_c, -2, 2, 0, W2, 0, r2, false);
-        HIPCK(hipEventRecord(c->ev_bg_done, c->stream));
-    }
-    c->bg_valid = true;
-    c->bg_stale = false;
-    c->bg_base = base2;
-    c->bg_W = W2;
-    c->bg_r = r2;
-    c->bg_accepts = c->n_accepts;
-    c->n_bg_launched++;
-    return 0;
-}
-
-/* the batch in the buffers has ended at `move` (conflict, or used up) and the background one holds that move: swap */
-static bool nuis_bg_holds(const ig_ctx* c, int move) { return nuis_bg_enabled() && c->bg_valid && move >= c->bg_base && move < c->bg_base + c->bg_W; }
-static int nuis_bg_adopt(ig_ctx* c, int move)
-{
-    if (nh_flush_pending(c)) return -1; /* (the histogram's walk of the last move reads its slot in the buffers about to be swapped out) */
-    nuis_spec_invalidate(c); /* (the run lengths of the batch that ends here) */
-    HIPCK(hipStreamWaitEvent(c->stream, c->ev_bg_done, 0));
-    std::swap(c->mb, c->mb2);
-    std::swap(c->touched_bits, c->touched_bits2);
-    std::swap(c->touched_flip, c->touched_flip2);
-    c->own_begin = c->bg_own_begin;
-    c->own_end = c->bg_own_end;
-    c->own_screened = c->bg_own_screened;
-    c->tail_fused = c->bg_tail_fused;
-    hipLaunchKernelGGL(k_bg_adopt, dim3(1), dim3(64), 0, c->stream, c->glob, c->glob2, c->dirty_buf, c->bg_mark);
-    c->spec_base = c->bg_base;
-    c->spec_W = c->bg_W;
-    c->spec_next = move - c->bg_base;
-    c->spec_valid = true;
-    c->spec_prev_pending = false;
-    c->spec_adopted = true;
-    c->spec_changed = c->bg_stale; /* (a move since the snapshot has changed the genome: this batch is going stale already) */
-    c->spec_par_begin = 0;
-    c->spec_par_end = (c->bg_accepts == c->n_accepts) ? c->bg_r : 0;
-    c->bg_valid = false;
-    c->n_bg_adopted++;
-    /* an accepted step since the launch, or the parameter half of the first slots only and the move behind them: again from here */
-    if (c->spec_next >= c->spec_par_end) {
-        c->spec_par_begin = c->spec_par_end = c->spec_next; /* (no piece of this batch was used: nothing for the run lengths) */
-        return nuis_spec_rescore(c);
-    }
     return 0;
 }
 
@@ -2913,28 +2692,17 @@ static int nuis_step_begin_impl(ig_ctx* c, int32_t move, const float p_test[8], 
     if (enqueue_nuis_pass(c, p_test, mean_subfrag_kb)) return -1;
     c->side_busy = true;
     if (restruct) {
-        if (nuis_bg_holds(c, move)) {
-            if (nuis_bg_adopt(c, move)) return -1;
-        } else if (nuis_spec_score(c, move)) {
-            return -1;
-        }
+        if (nuis_spec_score(c, move)) return -1;
     } else if (repar) {
         if (nuis_spec_rescore(c)) return -1;
     }
     /* the result record reaches the host as soon as the move is applied: written by k_commit_batch itself where the host
      * memory is mapped, else copied (and copied in the rare cases ig_nuis_end has to redo the move) */
     c->nuis_pub_res = c->host_nuis_dev != nullptr;
-    launch_commit(c, c->spec_base, c->spec_next + 1, c->spec_next, (c->spec_prev_pending ? 0 : 1) | (c->spec_adopted ? 2 : 0), c->nuis_pub_res);
+    launch_commit(c, c->spec_base, c->spec_next + 1, c->spec_next, c->spec_prev_pending ? 0 : 1, c->nuis_pub_res);
     if (!c->nuis_pub_res) {
         HIPCK(hipMemcpyAsync(&c->host_nuis->res, c->d_results + move, sizeof(ig_move_result), hipMemcpyDeviceToHost, c->stream));
         if (queue_max_readback(c)) return -1;
-    }
-    /* the next batch in the background, once this one is nearly used up */
-    static const int s_lead = getenv("IG_NUIS_BG_LEAD") ? std::max(0, atoi(getenv("IG_NUIS_BG_LEAD"))) : 6;
-    static const int s_on_change = getenv("IG_NUIS_BG_CHANGED") ? atoi(getenv("IG_NUIS_BG_CHANGED")) : 1;
-    if (nuis_bg_enabled() && c->spec_valid && !c->bg_valid && ((c->spec_changed && s_on_change) || c->spec_W - c->spec_next - 1 <= s_lead) &&
-        c->spec_base + c->spec_next + 1 < c->up_moves && c->host_nuis_dev) {
-        if (nuis_bg_launch(c)) return -1;
     }
     HIPCK(hipGetLastError());
     return 0;
@@ -2963,15 +2731,13 @@ static int nuis_spec_finish(ig_ctx* c)
         }
         /* not decided: a contig of the move was modified by an earlier move of the batch (w > 0), or the first slot did not
          * fit the slice pool / the exact kernel's grid: score a batch from this move */
-        if (w == 0 && c->spec_adopted && bo[2] == 0) {
-            /* the first slot of a batch scored in the background: a contig of the move was modified after the snapshot */
-            c->spec_valid = false; /* says nothing about run lengths */
-        } else if (w == 0) {
+        if (w == 0) {
             if (bo[2] == 1) {
                 if (grow_slice_pool(c)) return -1;
             } else if (bo[2] == 2) {
                 if (c->exact_grid >= c->mb.work_cap) return fail("the exact kernel's work list cannot hold the first move of a batch");
                 c->exact_grid = std::min(c->mb.work_cap, c->exact_grid * 4);
+            } else if (bo[2] == 3) { /* (a score of exactly 0.0: exact_next is set, the scoring below leaves the screening tier out) */
             } else {
                 Glob hg;
                 HIPCK(hipMemcpy(&hg, c->glob, sizeof hg, hipMemcpyDeviceToHost));
@@ -2980,13 +2746,8 @@ static int nuis_spec_finish(ig_ctx* c)
             c->spec_valid = false; /* says nothing about run lengths */
         }
         if (attempt > 8) return fail("move %d of a run could not be decided", c->spec_move);
-        if (nuis_bg_holds(c, c->spec_move)) { /* the batch scored in the background meanwhile holds the move */
-            if (nuis_bg_adopt(c, c->spec_move)) return -1;
-            launch_commit(c, c->spec_base, c->spec_next + 1, c->spec_next, 1 | 2);
-        } else {
-            if (nuis_spec_score(c, c->spec_move)) return -1;
-            launch_commit(c, c->spec_base, 1, 0, 0);
-        }
+        if (nuis_spec_score(c, c->spec_move)) return -1;
+        launch_commit(c, c->spec_base, 1, 0, 0);
         redone = true;
     }
     c->spec_slot = c->spec_next;
@@ -3091,7 +2852,7 @@ static int nuis_end_body(ig_ctx* c, ig_move_result* out, double* nz_test, double
             if (d[4] != 0 || d[3] <= 0 || !have_nzb) {
                 if (tier == 0) {
                     c->nhs[3] += 1.0;
-                    if (getenv("IG_NUIS_HIST_TRACE"))
+                    if (g_nuis_hist_trace)
                         fprintf(stderr, "[nuis] move %d: histogram tier void: flags %lld sum %lld bound %lld contacts %lld record %d\n", c->spec_move - 1,
                                 d[4], d[2], d[3], d[5], (int)have_nzb);
                     if (d[4] & 1) c->nhs[8] += 1.0;
@@ -3122,8 +2883,7 @@ static int nuis_end_body(ig_ctx* c, ig_move_result* out, double* nz_test, double
                     const double z = nuis_z_from_sums((const long long*)hn->sums);
                     const double x_hi = (((scr_mid + scr_B) + z) - hn->res.o) / Tu[0], x_lo = (((scr_mid - scr_B) + z) - hn->res.o) / Tu[0];
                     reject = exp(x_hi) <= Tu[1] * (1.0 - 1e-9); /* exp is monotone: every L_test in the interval gives a ratio below u */
-                    static const int s_defer = getenv("IG_NUIS_DEFER") ? atoi(getenv("IG_NUIS_DEFER")) : 1;
-                    accept = s_defer && !reject && exp(x_lo) >= Tu[1] * (1.0 + 1e-9) && c->host_nuis_dev; /* ... above it: accepted whatever the exact sum */
+                    accept = !reject && exp(x_lo) >= Tu[1] * (1.0 + 1e-9) && c->host_nuis_dev; /* ... above it: accepted whatever the exact sum */
                 }
             }
             if (tier == 0) {
@@ -3168,7 +2928,7 @@ static int nuis_end_body(ig_ctx* c, ig_move_result* out, double* nz_test, double
             *out = hn->res;
             if (out->error) return fail("device-side consistency failure %d", out->error);
             if (c->nuis_spec) c->nh_pending_slot = (c->nh_valid && moved) ? c->spec_slot : -1;
-            if (c->nuis_spec && moved) c->spec_changed = c->bg_stale = true;
+            if (c->nuis_spec && moved) c->spec_changed = true;
             if (c->nuis_spec) c->nh_p_changed = 0.98 * c->nh_p_changed + 0.02 * (moved ? 1.0 : 0.0);
             if (nz_test) *nz_test = scr_mid;
             if (z_test) *z_test = nuis_z_from_sums((const long long*)hn->sums);
@@ -3194,7 +2954,7 @@ static int nuis_end_body(ig_ctx* c, ig_move_result* out, double* nz_test, double
     *out = c->host_nuis->res;
     if (out->error) return fail("device-side consistency failure %d", out->error);
     if (c->nuis_spec) c->nh_pending_slot = (c->nh_valid && moved) ? c->spec_slot : -1; /* (the histogram follows the move at the head of the next step) */
-    if (c->nuis_spec && moved) c->spec_changed = c->bg_stale = true; /* (the batch in the buffers goes stale from here: time to score the next one) */
+    if (c->nuis_spec && moved) c->spec_changed = true; /* (the batch in the buffers goes stale from here: time to score the next one) */
     if (c->nuis_spec) c->nh_p_changed = 0.98 * c->nh_p_changed + 0.02 * (moved ? 1.0 : 0.0); /* (the histogram tier's cost model, nuis_hist_usable) */
     if (scr_valid || scr0_valid) { /* the exact pass ran as well: how much of the bounds did the screened sums use?  (verify mode: the check) */
         long long e[2] = {c->host_nuis->sums[0], c->host_nuis->sums[1]};
@@ -3207,8 +2967,7 @@ static int nuis_end_body(ig_ctx* c, ig_move_result* out, double* nz_test, double
             if (!(err <= scr_B) && !s_nocheck)
                 return fail("screened nuisance pass: |screened - exact| = %.6g exceeds its bound %.6g (move %d)", err, scr_B, c->spec_move - 1);
         }
-        static const int s_trace = getenv("IG_NUIS_HIST_TRACE") ? atoi(getenv("IG_NUIS_HIST_TRACE")) : 0;
-        if (s_trace)
+        if (g_nuis_hist_trace)
             fprintf(stderr, "[nuis] move %d exact %.9f  hist %s mid-exact %.3e B %.3e  pass %s mid-exact %.3e B %.3e\n", c->spec_move - 1, exact,
                     scr0_valid ? "ok" : "--", scr0_mid - exact, scr0_B, scr_valid ? "ok" : "--", scr_mid - exact, scr_B);
         if (scr0_valid) {
@@ -3258,15 +3017,6 @@ extern "C" int ig_debug_nuis_hist_stats(ig_ctx* c, double out12[12])
 {
     IG_JOIN(c);
     for (int i = 0; i < 12; i++) out12[i] = c->nhs[i];
-    return 0;
-}
-
-/* batches of runs scored in the background: {launched, adopted} since the handle was made */
-extern "C" int ig_debug_nuis_bg_stats(ig_ctx* c, int64_t out2[2])
-{
-    IG_JOIN(c);
-    out2[0] = c->n_bg_launched;
-    out2[1] = c->n_bg_adopted;
     return 0;
 }
 
@@ -3394,16 +3144,6 @@ extern "C" int ig_nuis_accept(ig_ctx* c)
     IG_JOIN(c);
     HIPCK(hipSetDevice(c->device));
     if (c->nuis_in_flight) return fail("ig_nuis_accept: end the step first (ig_nuis_end)");
-    static const int s_slow = getenv("IG_NUIS_SLOW_ACCEPT") ? atoi(getenv("IG_NUIS_SLOW_ACCEPT")) : 0;
-    if (s_slow) { /* the plain way: set the parameters, recompute everything */
-        const float p[8] = {c->nuis_test.kuhn, c->nuis_test.lm, c->nuis_test.c1, c->nuis_test.slope, c->nuis_test.d, c->nuis_test.d_max,
-                            c->nuis_test.fact, c->nuis_test.v_inter};
-        const bool run = c->nuis_spec;
-        nuis_spec_invalidate(c);
-        const int rc = ig_set_params(c, p, c->nuis_mean_kb, 0);
-        c->nuis_spec = run;
-        return rc;
-    }
     if (!c->scratch_accept) {
         DALLOC(c->scratch_accept, 8);
         HIPCK(hipMemset(c->scratch_accept, 0, 8 * sizeof(long long)));
@@ -3414,8 +3154,7 @@ extern "C" int ig_nuis_accept(ig_ctx* c)
     const int w = c->spec_slot; /* the slot of the move just applied (0 unless it came out of a batch: ig_nuis_step_begin) */
     /* whatever was scored ahead was scored under the old parameters -- but only its parameter-dependent half: windows, candidate
      * genomes, columns and slice lists of the batch's remaining slots stand (IG_NUIS_KEEP=0: redone as well) */
-    static const int s_keep = getenv("IG_NUIS_KEEP") ? atoi(getenv("IG_NUIS_KEEP")) : 1;
-    if (s_keep && c->nuis_spec) nuis_par_invalidate(c);
+    if (c->nuis_spec) nuis_par_invalidate(c);
     else nuis_spec_invalidate(c);
     const PzTab pz1{c->pz_tab1, c->pz_n1};
     /* the move's delta under the new parameters; contig membership of the partners as of BEFORE the move: tab_prev.  A move that
@@ -3470,17 +3209,189 @@ extern "C" int ig_nuis_step_next(ig_ctx* c, double temperature, double u, const 
     if (has_next && acc == 1 && c->spec_move < c->up_moves) {
         /* (first what the pass of the next step waits for, or it would queue behind the scoring launches) */
         if (nh_flush_pending(c)) return -1; /* (the histogram's walk of the last move reads tab_prev as of before it) */
+        /* INVARIANT: behind a decisively accepted step the exact pass may still be running on the side stream (nuis_sums_pending) while
+         * this catch-up rewrites tab_prev.len of the last move's contigs.  The pass reads tab_prev.len on its ring path only, and a ring
+         * among the contacts voids both screened tiers (no decisive accept then: the exact pass ran in front of the decision).  Whoever
+         * lets a ring through the screened tiers must order this launch behind ev_exact. */
         hipLaunchKernelGGL(k_catch_up, dim3(16), dim3(256), 0, c->stream, c->tab, c->tab_prev, c->prev_touched, c->glob);
-        static const int s_serial = getenv("IG_NUIS_SERIAL") ? atoi(getenv("IG_NUIS_SERIAL")) : 0; /* the next pass behind the scoring launches, not next to them */
-        if (!s_serial) HIPCK(hipEventRecord(c->ev_gathered, c->stream));
+        HIPCK(hipEventRecord(c->ev_gathered, c->stream)); /* (the next pass next to the scoring launches, not behind them: 4.8 k against 4.5 k) */
         c->nuis_caught_up = true;
         if (nuis_spec_can_rescore(c, c->spec_move)) {
             if (nuis_spec_rescore(c)) return -1;
         } else if (nuis_spec_score(c, c->spec_move)) {
             return -1;
         }
-        if (s_serial) HIPCK(hipEventRecord(c->ev_gathered, c->stream));
     }
+    return 0;
+}
+
+
+/* ---- chains of (move, nuisance step) pairs decided on the device (ig_common.cuh: ChainIn) ------------------------
+ * ig_nuis_chain_begin(move, n_sets, ...): the pairs move .. move + n_sets - 1 of the run, as far as the device can take them alone:
+ * segment after segment (k_catch_up, k_chain_prepare, k_hist_eval_chain, k_decide_chain, k_commit_batch on the library stream; the
+ * histogram's walk of a move that changed the genome between two segments) until a pair needs the host.  Asynchronous (the
+ * helper thread drives the segments; ig_nuis_chain_done polls, ig_nuis_chain_end waits): the caller prepares the proposals of the
+ * steps behind meanwhile.  Every pair a chain completes is a move decided exactly as k_decide_batch decides it and a step
+ * REJECTED from the histogram tier's interval with the margins of nuis_end_body; the pair a chain stops in front of is untouched. */
+enum { CHAIN_R_SETS = 0, /* every set was used: the steps went through */
+       CHAIN_R_TEST = 1,     /* the next pair's step is not a certain rejection (accepted, undecided, or its interval void) */
+       CHAIN_R_CONFLICT = 2, /* the next move touches a contig an earlier move of its batch modified */
+       CHAIN_R_PENDING = 3,  /* ... is a windowed winner without a predicted delta */
+       CHAIN_R_OVERFLOW = 4, /* ... did not fit a pool / the exact kernel's grid / holds a score of exactly 0.0 */
+       CHAIN_R_NO_SLOTS = 5, /* no slot scored under the model's parameters is left (batch used up, parameters promoted, first step) */
+       CHAIN_R_UNSUPPORTED = 6 /* the histogram tier is not in use (its cost model, verify mode, no mapped host memory) */ };
+static int ensure_chain(ig_ctx* c)
+{
+    if (c->chain_sets) return 0;
+    DALLOC(c->chain_sets, CHAIN_SEG);
+    DALLOC(c->chain_in, CHAIN_MAX);
+    DALLOC(c->chain_tests, CHAIN_SEG);
+    DALLOC(c->chain_out16, (size_t)CHAIN_SEG * 16);
+    DALLOC(c->chain_zs, (size_t)CHAIN_SEG * 8);
+    HIPCK(hipMemset(c->chain_out16, 0, (size_t)CHAIN_SEG * 16 * sizeof(long long)));
+    return 0;
+}
+static int nuis_chain_impl(ig_ctx* c, int32_t move, int32_t n_sets, float mean_kb)
+{
+    c->chain_done = 0;
+    c->chain_reason = CHAIN_R_UNSUPPORTED;
+    HIPCK(hipSetDevice(c->device));
+    if (!c->nuis_spec) return fail("ig_nuis_chain_begin: no run (ig_nuis_run_begin)");
+    if (c->nuis_in_flight) return fail("ig_nuis_chain_begin: a step is in flight (ig_nuis_end)");
+    if (move != c->spec_move || move >= c->up_moves) return fail("ig_nuis_chain_begin: move %d, expected %d of %d", move, c->spec_move, c->up_moves);
+    c->n_chain_calls++;
+    auto leave = [&](int reason) {
+        c->chain_reason = reason;
+        c->n_chain_stops[reason]++;
+        return 0;
+    };
+    if (ensure_host_nuis(c)) return -1;
+    if (!c->host_bo || g_nuis_screen_verify || !nuis_hist_usable(c)) return leave(CHAIN_R_UNSUPPORTED);
+    if (!c->spec_valid || c->spec_next >= c->spec_par_end || c->spec_base + c->spec_next != move) return leave(CHAIN_R_NO_SLOTS);
+    if (ensure_chain(c) || ensure_nuis_hist(c)) return -1;
+    hipStream_t st = c->stream;
+    HIPCK(hipMemcpyAsync(c->chain_in, c->chain_in_host, (size_t)n_sets * sizeof(ChainIn), hipMemcpyHostToDevice, st));
+    c->nh_tracking = true; /* the moves applied below are followed by the histogram (walked in behind their segment) */
+    struct Untrack {
+        ig_ctx* c;
+        ~Untrack() { c->nh_tracking = false; }
+    } untrack{c};
+    if (nh_flush_pending(c)) return -1; /* the last move of the step before (walk on the side stream, the library stream waits for it) */
+    c->main_drained = false;
+    int done = 0, reason = CHAIN_R_SETS;
+    const PzTab pz0{c->pz_tab, c->pz_n};
+    for (;;) {
+        const int w0 = c->spec_next;
+        const int avail = std::min(std::min(CHAIN_SEG, n_sets - done), std::min(c->spec_par_end - w0, c->up_moves - c->spec_move));
+        if (avail <= 0) {
+            reason = (n_sets - done <= 0) ? CHAIN_R_SETS : CHAIN_R_NO_SLOTS;
+            break;
+        }
+        /* tab_prev := the current state (the zero-pixel sums of the test sets are taken on it; every step of the segment up to
+         * its first changing move sees this state as "before its move", quirk Q12) */
+        if (!c->nuis_caught_up) hipLaunchKernelGGL(k_catch_up, dim3(16), dim3(256), 0, st, c->tab, c->tab_prev, c->prev_touched, c->glob);
+        c->nuis_caught_up = false;
+        const int n_const = (std::max(std::max(PZ_MAX, LDS_PZ + 2), std::max((int)IG_TAB_SIZE, LDS_LGF)) + 255) / 256;
+        hipLaunchKernelGGL(k_chain_prepare, dim3(n_const, avail), dim3(256), 0, st, c->glob, c->chain_in, done, mean_kb, c->chain_sets, c->lgf_tab,
+                           c->score_const, c->pz_n, c->screen_const, c->chain_out16, c->chain_zs);
+        if (!c->nh_valid) { /* (the first step of a run, or after moves outside one: from the tables just caught up) */
+            HIPCK(hipMemsetAsync(c->nh.bins, 0, (size_t)NH_NB * 4 * sizeof(long long), st));
+            HIPCK(hipMemsetAsync(c->nh.dh, 0, ((size_t)c->nh.dh_n + 1) * sizeof(long long), st));
+            HIPCK(hipMemsetAsync(c->nh.misc, 0, NH_MISC * sizeof(long long), st));
+            hipLaunchKernelGGL(k_hist_build, dim3(2048), dim3(256), 0, st, c->rowptr, c->cc, c->tab_prev, c->M, c->nh);
+            c->nh_valid = true;
+            c->nhs[7] += 1.0;
+        }
+        const int n_zero = std::min(256, std::max(32, c->M / 1024));
+        hipLaunchKernelGGL(k_hist_eval_chain, dim3(n_zero + NH_NB / 256 + NH_DH_BLOCKS, avail), dim3(256), 0, st, c->nh, c->glob, c->chain_sets,
+                           c->score_const, c->chain_out16, c->tab_prev, c->M, c->chain_zs, n_zero, pz0, c->chain_tests);
+        flush_pending_sums(c);
+        const int zcheck = (c->own_screened == 1 ? 1 : 0) | (std::max(g_zero_inject, 0) << 8);
+        const ChainArgs ca{c->chain_tests, c->chain_in, done, 1.0};
+        hipLaunchKernelGGL(k_decide_chain, dim3(1), dim3(64), 0, st, c->glob, c->mb, c->d_results, c->spec_base, w0 + avail, w0, c->dirty_buf, c->batch_out,
+                           (volatile int*)c->host_bo_dev, ++c->bo_seq, c->spec_prev_pending ? 0 : 1, zcheck, ca);
+        hipLaunchKernelGGL(k_commit_batch, dim3(1), dim3(COMMIT_THREADS), 0, st, c->st, c->tab, c->tab_prev, c->glob, c->mb, c->init_prev, c->init_next,
+                           c->orientable, c->black, c->own_tag, c->own_idx, c->prev_touched, c->d_results, c->spec_base, w0 + avail, w0, c->batch_out,
+                           (NuisHost*)nullptr, 0);
+        int bo[12];
+        if (wait_commit(c, bo, w0 == c->spec_par_begin, w0)) return -1;
+        if (c->own_screened == 1 && w0 == c->spec_par_begin && !(bo[2] && bo[0] == w0 && bo[1] < 0))
+            c->exact_grid = std::min(c->mb.work_cap, std::max(exact_grid_floor(c, c->up_max_c), (int)(1.25 * bo[6]) + 2048));
+        const int j = bo[0] - w0;
+        if (j < 0 || j > avail) return fail("ig_nuis_chain: the decide step reported %d of %d pairs", j, avail);
+        c->n_chain_segments++;
+        c->n_chain_pairs += j;
+        c->spec_next += j;
+        c->spec_move += j;
+        done += j;
+        if (j > 0) {
+            c->spec_prev_pending = false;
+            c->spec_slot = c->spec_next - 1;
+            c->nhs[0] += j; /* evaluations of the histogram tier that decided a step, all of them rejections */
+            c->nhs[1] += j;
+            c->nscr[0] += j;
+            c->nscr[1] += j;
+            const bool moved = bo[11] != 0;
+            c->last_moved = moved;
+            for (int q = 0; q < j; q++) c->nh_p_changed = 0.98 * c->nh_p_changed + 0.02 * ((moved && q == j - 1) ? 1.0 : 0.0);
+            if (moved) { /* the histogram follows the move before tab_prev does (here, on the library stream: the commit is still running) */
+                hipLaunchKernelGGL(k_hist_walk, dim3(128), dim3(256), 0, st, c->rowptr, c->cc, c->tab_prev, c->glob, c->mb, c->spec_slot, c->nh);
+                c->nhs[6] += 1.0;
+            }
+        }
+        if (bo[10] == 5 || (bo[10] == 0 && bo[1] < 0 && j == avail)) continue; /* behind a changing move / the segment went through */
+        if (bo[1] >= 0) reason = CHAIN_R_PENDING;
+        else if (bo[10] == 4) reason = CHAIN_R_TEST;
+        else if (bo[10] == 0) reason = CHAIN_R_CONFLICT;
+        else reason = CHAIN_R_OVERFLOW;
+        break;
+    }
+    HIPCK(hipGetLastError());
+    c->nh_pending_slot = -1;
+    c->chain_done = done;
+    return leave(reason);
+}
+
+extern "C" int ig_nuis_chain_begin(ig_ctx* c, int32_t move, int32_t n_sets, const float* p_tests, const double* u, const double* temperature,
+                                   float mean_subfrag_kb)
+{
+    IG_JOIN(c);
+    if (n_sets < 1 || n_sets > CHAIN_MAX) return fail("ig_nuis_chain_begin: 1..%d sets (got %d)", CHAIN_MAX, n_sets);
+    if (!c->chain_in_host) HIPCK(hipHostMalloc((void**)&c->chain_in_host, CHAIN_MAX * sizeof(ChainIn), hipHostMallocDefault));
+    for (int k = 0; k < n_sets; k++) {
+        ChainIn& ci = c->chain_in_host[k];
+        memcpy(ci.p, p_tests + 8 * (size_t)k, sizeof ci.p);
+        /* the step is rejected iff exp((L_test - L_move) / T) < u; on the device: (upper end of L_test) - L_move <= T (ln u - 2e-9), the
+         * host's 1e-9 relative margin on u doubled and taken in the exponent (nuis_end_body); anything else is not decided there */
+        const double T = temperature[k], uu = u[k];
+        ci.ln_u = (T > 0.0 && uu > 0.0) ? T * (log(uu) - 2e-9) - 1e-12 * __builtin_fabs(T * log(uu)) : -IG_INF;
+    }
+    c->chain_busy = true;
+    return nuis_defer(c, 1, move, nullptr, mean_subfrag_kb, n_sets);
+}
+/* 1: the chain has ended (ig_nuis_chain_end returns at once), 0: its segments are still being driven */
+extern "C" int ig_nuis_chain_done(ig_ctx* c)
+{
+    NuisWorker* w = c->worker;
+    return (!w || w->state.load(std::memory_order_acquire) != 1) ? 1 : 0;
+}
+extern "C" int ig_nuis_chain_end(ig_ctx* c, int32_t* n_done, int32_t* reason)
+{
+    IG_JOIN(c);
+    if (!c->chain_busy) return fail("ig_nuis_chain_end: no chain was begun");
+    c->chain_busy = false;
+    *n_done = c->chain_done;
+    *reason = c->chain_reason;
+    return 0;
+}
+/* {calls, segments, pairs completed, ends by reason (CHAIN_R_*: 7 values)} since the handle was made */
+extern "C" int ig_debug_nuis_chain_stats(ig_ctx* c, int64_t out10[10])
+{
+    IG_JOIN(c);
+    out10[0] = c->n_chain_calls;
+    out10[1] = c->n_chain_segments;
+    out10[2] = c->n_chain_pairs;
+    for (int q = 0; q < 7; q++) out10[3 + q] = c->n_chain_stops[q];
     return 0;
 }
 
@@ -3697,7 +3608,6 @@ extern "C" int ig_debug_screen_stats(ig_ctx* c, double out4[6])
     out4[3] = (double)hg.scr_cont;
     out4[4] = (double)hg.scr_terms;
     out4[5] = (double)hg.scr_terms_exact;
-    if (getenv("IG_SCREEN_STATS")) fprintf(stderr, "[screen] void columns %lld of %lld\n", hg.scr_void_cols, hg.scr_cols);
     return 0;
 }
 
@@ -3773,6 +3683,21 @@ extern "C" int ig_debug_nuis_wait(ig_ctx* c, double* seconds)
 extern "C" int ig_debug_set_full_hist(int on)
 {
     g_full_hist = on ? 1 : 0;
+    return 0;
+}
+
+/* fault injection for the decide step's zero-score rule: every n-th move of a two-tier batch is treated as one whose contenders hold
+ * a score of exactly 0.0 (stop code 3: the move is scored again with every column exact); 0 = off.  *fallbacks (may be NULL): how
+ * often a handle has taken that path. */
+extern "C" int ig_debug_set_zero_inject(int every)
+{
+    g_zero_inject = every > 0 ? every : 0;
+    return 0;
+}
+extern "C" int ig_debug_zero_fallbacks(ig_ctx* c, int64_t* fallbacks)
+{
+    IG_JOIN(c);
+    *fallbacks = c->n_zero_fallbacks;
     return 0;
 }
 

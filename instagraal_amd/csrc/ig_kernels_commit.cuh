@@ -356,10 +356,29 @@ struct FusedLds {
     long long s0_slice[IG_MAX_BATCH];
     int s0_mloc[IG_MAX_BATCH], s0_base[IG_MAX_BATCH];
 };
-template <bool FUSED>
+/* CHAIN (k_decide_chain): a segment of a chain of (move, nuisance step) pairs -- ig_common.cuh, ChainIn.  Behind every decision
+ * the step's Metropolis test (CL:3026-3036: exp((L_test - L_move) / T) >= u) against the interval k_hist_eval_chain left for its
+ * test set: L_test = the maintained exact sum as of before the move + D +- B, + the zero-pixel likelihood of the set; a step
+ * whose whole interval lies below T ln u (with the margins nuis_end_body keeps on the host) is rejected and the wave goes on;
+ * anything else stops the segment IN FRONT of the pair (stop code 4: nothing of it is committed, the host takes it through
+ * ig_nuis_step_begin / ig_nuis_step_next).  A move that changes the genome is committed, its step tested -- the interval is that of
+ * the state before the move --, and the segment ends behind it (stop code 5): the histogram follows the move first. */
+struct ChainArgs {
+    const ChainTest* tests;
+    const ChainIn* in;
+    int set0;
+    double temperature;
+};
+template <bool FUSED, bool CHAIN = false>
 __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out,
-                                            volatile int* host_out, int seq, int resumed_plain, FusedLds* sh)
+                                            volatile int* host_out, int seq, int resumed_plain, FusedLds* sh, int zcheck,
+                                            const ChainArgs ca = ChainArgs{nullptr, nullptr, 0, 1.0})
 {
+    /* zcheck bit 0: the records hold the CONTENDER columns only (two-tier scoring).  k_contend ruled the others out against lower
+     * bounds of columns it took for scored -- under the batch-start scalars; a column whose score comes out as exactly 0.0 under the
+     * LIVE ones counts as "not scored" in the reference's argmax (CL:1435-1440) and bounds nothing: the batch stops in front of such
+     * a move (stop code 3) and the host scores it again with every column exact.  zcheck >> 8: fault injection for the tests
+     * (ig_debug_set_zero_inject): every that-many-th move is treated as such a move. */
     /* w_start > 0: slot w_start - 1 was the pending move, meanwhile applied by the one-move kernels; the rest of the batch
      * is still valid wherever it does not touch a contig modified so far (dirty_buf carries the list across the calls).
      * resumed_plain: slot w_start - 1 was committed by an earlier launch of this kernel (a batch decided one move per call,
@@ -390,9 +409,7 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
         int n_dirty = 0, committed = w_start, pending = -1, n_cand = 0, n_predicted = 0, stop_overflow = 0;
         int max_L = g->max_L, max_SL = g->max_SL;
         const float n_frags_f = (float)g->N; /* not inside the loop: a load there waits for the prefetches issued before it */
-        /* resumed_plain bit 1: the list is loaded even at w_start == 0 -- a batch scored in the background against a snapshot of
-         * the state: the contigs modified since then are on it (nuis_bg_adopt) */
-        if (w_start > 0 || (resumed_plain & 2)) {
+        if (w_start > 0) {
             n_dirty = dirty_buf[0];
 #pragma unroll
             for (int j = 0; j < ND; j++)
@@ -421,6 +438,19 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
         /* the candidate counts of all slots up front (lane w: slot w): a prefetch must not wait for its own first load */
         const int all_C = (lane < W) ? mb.ctl[lane].C : 0;
         const int all_sup = (lane < W) ? mb.ctl[lane].superset0 : 0;
+        /* CHAIN: the interval of step w_start + lane in lane `lane` */
+        long long ct_s = 0, ct_b = 0, ct_f = 1;
+        double ct_z = 0.0, ct_lnu = -IG_INF;
+        bool halt_after = false;
+        int chain_changed = 0;
+        if (CHAIN && lane < W - w_start && lane < CHAIN_SEG) {
+            const ChainTest t = ca.tests[lane];
+            ct_s = t.s_fix;
+            ct_b = t.b_fix;
+            ct_f = t.flags;
+            ct_z = t.z;
+            ct_lnu = ca.in[ca.set0 + lane].ln_u;
+        }
         auto load_move = [&](int w) {
             MoveData d;
             d.C = __builtin_amdgcn_readlane(all_C, w);
@@ -471,6 +501,7 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
              * index of the maximal score (all scores zero: index 0) -- one reduction of (score, index). */
             double bestv = -IG_INF;
             int best = 0x7fffffff;
+            bool zhit = false; /* a scored column whose live score is exactly 0.0 */
             auto score_of = [&](int i, const SlotPre& r, double ext, int cr, int cbase) -> double {
                 const int c = i / IG_N_TMP_STRUCT, slot = i % IG_N_TMP_STRUCT;
                 const bool sup = (c == 0) && d.superset0 && (slot >= 12);
@@ -481,7 +512,9 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
                 const double val_inter = -1.0 * log_e * (n_tot_pxl - (double)(n_intra + r.dni)) * p.v_inter;
                 const double val_intra = ig_acc_to_double(z_hi + r.dz_hi, z_lo + r.dz_lo) * log_e;
                 const double z = val_intra + val_inter;
-                return nzd + z + cur_nz - ext;
+                const double v = nzd + z + cur_nz - ext;
+                zhit |= (v == 0.0);
+                return v;
             };
 #pragma unroll
             for (int j = 0; j < NJ; j++) sc[j] = 0.0;
@@ -511,6 +544,14 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
                         bestv = ok;
                         best = i;
                     }
+                }
+            }
+            if (zcheck & 1) {
+                const int inj = zcheck >> 8;
+                if (__any(zhit) || (inj > 0 && (move0 + w) % inj == inj - 1)) {
+                    n_cand -= C;
+                    stop_overflow = 3;
+                    return false;
                 }
             }
             /* (score, index) reduced into lane 63 with DPP moves: row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then lane 15 of
@@ -577,6 +618,20 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
                 Sc = rl64(wave_sum_ll(Sc), 0);
                 ev = rl64(wave_sum_ll(ev), 0);
                 by = rl64(wave_sum_ll(by), 0);
+            }
+            if (CHAIN && !is_pending) { /* the step's test: a certain rejection, or the segment stops in front of this pair */
+                const int kt = w - w_start;
+                const long long t_b = rl64(ct_b, kt), t_f = rl64(ct_f, kt);
+                const double mid = cur_nz + (double)rl64(ct_s, kt) * (1.0 / DIFF_FIX);
+                const double B = (double)t_b * (1.0 / DIFF_FIX) + 1e-6 + 1e-14 * (__builtin_fabs(cur_nz) + __builtin_fabs(bests));
+                const double x_hi = (((mid + B) + rld(ct_z, kt)) - bests) / ca.temperature;
+                /* exp(x_hi) <= u (1 - 1e-9) on the host; here in the exponent, with twice the margin (ln u is the host's double) */
+                const bool rej = (kt < CHAIN_SEG) && (t_f == 0) && (t_b > 0) && (x_hi <= rld(ct_lnu, kt) - 2e-9);
+                if (!rej) {
+                    n_cand -= C;
+                    stop_overflow = 4;
+                    return false;
+                }
             }
             long long nzb_hi_w = 0, nzb_lo_w = 0;
             const unsigned vmask_w = vmask; /* the stale flags this move was scored under (vmask moves on below) */
@@ -664,6 +719,13 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
                 n_dirty += 2;
             }
             committed = w + 1;
+            if (CHAIN) {
+                chain_changed = br_changed;
+                if (br_changed) {
+                    halt_after = true;
+                    stop_overflow = 5;
+                }
+            }
             if (FUSED) { /* the record of slot w is in LDS: the commit wave may apply it */
                 __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) sh->prog[0] = w + 1;
@@ -675,11 +737,11 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
         auto clampw = [&](int w) { return w < W ? w : W - 1; };
         MoveData d0 = load_move(clampw(w_start)), d1 = load_move(clampw(w_start + 1)), d2 = load_move(clampw(w_start + 2));
         for (int w = w_start; w < W; w += 3) {
-            if (!decide_one(w, d0)) break;
+            if (!decide_one(w, d0) || (CHAIN && halt_after)) break;
             d0 = load_move(clampw(w + 3));
-            if (w + 1 >= W || !decide_one(w + 1, d1)) break;
+            if (w + 1 >= W || !decide_one(w + 1, d1) || (CHAIN && halt_after)) break;
             d1 = load_move(clampw(w + 4));
-            if (w + 2 >= W || !decide_one(w + 2, d2)) break;
+            if (w + 2 >= W || !decide_one(w + 2, d2) || (CHAIN && halt_after)) break;
             d2 = load_move(clampw(w + 5));
         }
 #pragma unroll
@@ -709,6 +771,7 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
             if (mb.work)
                 for (int x = 0; x < 8; x++) need = max(need, 8 * (int)mb.work[8 + x]);
             batch_out[6] = need;
+            batch_out[11] = chain_changed; /* (a chain's segment: its last committed move changed the genome) */
             /* the host polls this copy (mapped, coherent host memory): it learns the outcome while k_commit_batch is still
              * running and has the next launches queued behind it when it ends */
             if (host_out) {
@@ -722,6 +785,7 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
                 host_out[4] = n_predicted;
                 host_out[5] = n_contigs;
                 host_out[6] = need;
+                host_out[11] = chain_changed;
                 __threadfence_system();
                 host_out[7] = seq;
             }
@@ -739,9 +803,16 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
 }
 __global__ void __launch_bounds__(64)
     k_decide_batch(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out,
-                   volatile int* host_out, int seq, int resumed_plain)
+                   volatile int* host_out, int seq, int resumed_plain, int zcheck)
 {
-    decide_body<false>(g, mb, res, move0, W, w_start, dirty_buf, batch_out, host_out, seq, resumed_plain, nullptr);
+    decide_body<false>(g, mb, res, move0, W, w_start, dirty_buf, batch_out, host_out, seq, resumed_plain, nullptr, zcheck);
+}
+
+__global__ void __launch_bounds__(64)
+    k_decide_chain(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out, volatile int* host_out, int seq,
+                   int resumed_plain, int zcheck, ChainArgs ca)
+{
+    decide_body<false, true>(g, mb, res, move0, W, w_start, dirty_buf, batch_out, host_out, seq, resumed_plain, nullptr, zcheck, ca);
 }
 
 /* step 2 of the batch commit: one workgroup applies the moves [w_start, batch_out[0]) k_decide_batch committed */
@@ -1184,7 +1255,7 @@ __global__ void __launch_bounds__(64 + FUSED_CW * 64)
     k_decide_commit(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out, volatile int* host_out,
                     int seq, int resumed_plain, State st, Tables tab, Tables tab_prev, const int* __restrict__ ip, const int* __restrict__ in,
                     const int* __restrict__ orientable, const unsigned char* __restrict__ black, int* own_tag, int* own_idx, int* prev_touched,
-                    NuisHost* hn, int hn_seq)
+                    NuisHost* hn, int hn_seq, int zcheck)
 {
     __shared__ FusedLds sh;
     for (int i = threadIdx.x; i < 3 * IG_MAX_BATCH + 2; i += blockDim.x) sh.bar[i] = 0;
@@ -1194,7 +1265,7 @@ __global__ void __launch_bounds__(64 + FUSED_CW * 64)
         sh.prog[1] = 0;
     }
     __syncthreads();
-    if (threadIdx.x < 64) decide_body<true>(g, mb, res, move0, W, w_start, dirty_buf, batch_out, host_out, seq, resumed_plain, &sh);
+    if (threadIdx.x < 64) decide_body<true>(g, mb, res, move0, W, w_start, dirty_buf, batch_out, host_out, seq, resumed_plain, &sh, zcheck);
     else commit_waves(st, tab, tab_prev, g, mb, ip, in, orientable, black, own_tag, own_idx, prev_touched, res, move0, W, w_start, hn, hn_seq, &sh);
 }
 

@@ -53,7 +53,7 @@
 #endif
 #define DIFF_X0 0.25f
 #define DIFF_LB 24.0f
-#define DIFF_FIX 1048576.0 /* 2^20: sums and bounds are published as integers (deterministic totals) */
+/* (DIFF_FIX = 2^20: ig_common.cuh -- sums and bounds are published as integers: deterministic totals) */
 
 struct alignas(16) DiffConst {
     float dpzc[LDS_PZ + 2]; /* (pzc_t - pzc_c)[d], the last entries: the trans level's */
@@ -620,19 +620,23 @@ __global__ void __launch_bounds__(256) k_hist_walk(const long long* __restrict__
  * [6] their counts, [7] an upper bound of their sum of P under both sets, [8] workgroups through; zero between two launches (the last
  * workgroup publishes and clears).  Grid: n_zero blocks of the zero-pixel sum under the test set (-> zero_out), NH_NB / 256 blocks
  * of bins, one block for the rank-distance histogram. */
-__global__ void __launch_bounds__(256) k_hist_eval(NuisHist h, const Glob* g, const ScoreConst* __restrict__ sc_t, const ScoreConst* __restrict__ sc_c,
-                                                   const DiffConst* __restrict__ dc, long long* out16, NuisHost* hn, int hn_seq, Tables zt, int M,
-                                                   long long* zero_out, int n_zero_blocks, const long long* __restrict__ zero_sums, PzTab pz_t,
-                                                   PzTab pz_c)
+/* CHAIN (k_hist_eval_chain): one of the CHAIN_SEG sets of a segment -- the test set's parameters come with its constants (never
+ * Glob.par[1]), the interval goes to the decide wave (ChainTest) instead of the host */
+template <bool CHAIN>
+__device__ __forceinline__ void hist_eval_body(NuisHist h, const Glob* g, const ScoreConst* __restrict__ sc_t, const ScoreConst* __restrict__ sc_c,
+                                               const DiffConst* __restrict__ dc, long long* out16, NuisHost* hn, int hn_seq, Tables zt, int M,
+                                               long long* zero_out, int n_zero_blocks, const long long* __restrict__ zero_sums, PzTab pz_t,
+                                               PzTab pz_c, const int block, const int n_blocks, ChainTest* ct)
 {
     __shared__ double red[5][4];
     __shared__ unsigned red_bad[4];
     __shared__ long long red_n[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if ((int)blockIdx.x < n_zero_blocks) {
-        full_zero_block(zt, g, 1, M, zero_out, (int)blockIdx.x, n_zero_blocks);
+    if (block < n_zero_blocks) {
+        if (CHAIN) full_zero_block_p(zt, sc_t->par, sc_t->mean_kb, g->n_tot_pxl, M, zero_out, block, n_zero_blocks);
+        else full_zero_block(zt, g, 1, M, zero_out, block, n_zero_blocks);
     } else {
-        const int bb = (int)blockIdx.x - n_zero_blocks;
+        const int bb = block - n_zero_blocks;
         const ig_hot hc = sc_c->hot, ht = sc_t->hot;
         const double c10 = IG_LOG2_10_INV, ln2 = 0.69314718055994530942;
         const double a_c = hc.slope, b_c = hc.log2_amp, lv_c = hc.log2_v_inter, a_t = ht.slope, b_t = ht.log2_amp, lv_t = ht.log2_v_inter;
@@ -740,7 +744,7 @@ __global__ void __launch_bounds__(256) k_hist_eval(NuisHist h, const Glob* g, co
             }
         } else if (ok) { /* the last blocks: P_z by rank distance -- the staged entries where the tables end inside the staged part (the
                           * trans level from there on), table / formula as the contract's own rare path reads them (pz_lookup) beyond */
-            const int j = bb - NH_NB / 256, nj = (int)gridDim.x - n_zero_blocks - NH_NB / 256;
+            const int j = bb - NH_NB / 256, nj = n_blocks - n_zero_blocks - NH_NB / 256;
             const int d_end = min(h.dh_n, max(LDS_PZ, (int)h.misc[7]));
             const bool staged_all = dc->cut == 0xffffffffu;
             for (int d = j * 256 + tid; d <= d_end; d += nj * 256) {
@@ -801,7 +805,7 @@ __global__ void __launch_bounds__(256) k_hist_eval(NuisHist h, const Glob* g, co
 #ifdef HIST_TICKET_FENCE
         __threadfence();
 #endif
-        if (atomicAdd((unsigned long long*)&out16[8], 1ull) == (unsigned long long)gridDim.x - 1ull) {
+        if (atomicAdd((unsigned long long*)&out16[8], 1ull) == (unsigned long long)n_blocks - 1ull) {
             __threadfence();
             long long o[8];
             for (int q = 0; q < 8; q++) o[q] = __hip_atomic_load(&out16[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -834,7 +838,17 @@ __global__ void __launch_bounds__(256) k_hist_eval(NuisHist h, const Glob* g, co
             o[0] = o[1] = 0;
             o[5] = n_all;
             for (int q = 0; q < 9; q++) out16[q] = 0;
-            if (hn) {
+            if (CHAIN) { /* the interval and the zero-pixel likelihood of the set (as nuis_z_from_sums forms it on the host) */
+                long long zh = __hip_atomic_load(&zero_sums[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                          zl = __hip_atomic_load(&zero_sums[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const long long ni = __hip_atomic_load(&zero_sums[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ig_acc_normalize((int64_t*)&zh, (int64_t*)&zl);
+                const double log_e = 0.43429448190325182;
+                ct->s_fix = o[2];
+                ct->b_fix = o[3];
+                ct->flags = o[4];
+                ct->z = ig_acc_to_double(zh, zl) * log_e + log_e * (g->n_tot_pxl - (double)ni) * -1.0 * (double)sc_t->par.v_inter;
+            } else if (hn) {
                 for (int q = 0; q < 8; q++) hn->diff[q] = o[q];
                 for (int q = 0; q < 8; q++) hn->sums[q] = __hip_atomic_load(&zero_sums[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __threadfence_system();
@@ -845,4 +859,62 @@ __global__ void __launch_bounds__(256) k_hist_eval(NuisHist h, const Glob* g, co
             out16[11] = o[4];
         }
     }
+}
+__global__ void __launch_bounds__(256) k_hist_eval(NuisHist h, const Glob* g, const ScoreConst* __restrict__ sc_t, const ScoreConst* __restrict__ sc_c,
+                                                   const DiffConst* __restrict__ dc, long long* out16, NuisHost* hn, int hn_seq, Tables zt, int M,
+                                                   long long* zero_out, int n_zero_blocks, const long long* __restrict__ zero_sums, PzTab pz_t,
+                                                   PzTab pz_c)
+{
+    hist_eval_body<false>(h, g, sc_t, sc_c, dc, out16, hn, hn_seq, zt, M, zero_out, n_zero_blocks, zero_sums, pz_t, pz_c, (int)blockIdx.x, (int)gridDim.x,
+                          nullptr);
+}
+
+/* ---- chains: CHAIN_SEG test sets per launch (ig_common.cuh, ChainIn) ------------------------------------------------------------ */
+struct ChainSet { /* what k_hist_eval needs of one test set: built by k_chain_prepare exactly as k_nuis_prepare builds the single step's */
+    ScoreConst sc;
+    DiffConst dc;
+    float pz[PZ_MAX];
+    int pz_n;
+};
+/* the P_z table's length for a parameter set, as ig_set_params / enqueue_nuis_pass size it on the host */
+__device__ __forceinline__ int chain_pz_n(float d_max, float mean_kb)
+{
+    const double need = (mean_kb > 0) ? (double)d_max / (double)mean_kb + 2.0 : 0.0;
+    return (need > 0 && need < (double)PZ_MAX) ? (int)need : ((need >= (double)PZ_MAX) ? PZ_MAX : 0);
+}
+/* grid (blocks of 256 over the longest table, sets): set y = the uploaded set in[set0 + y] */
+__global__ void __launch_bounds__(256) k_chain_prepare(const Glob* g, const ChainIn* __restrict__ in, int set0, float mean_kb, ChainSet* sets,
+                                                       const double* __restrict__ lgf_tab, const ScoreConst* __restrict__ sc0, int pz_n0,
+                                                       const ScreenConst* __restrict__ scr0, long long* out16, long long* zs)
+{
+    const int k = (int)blockIdx.y;
+    ChainSet& S = sets[k];
+    const ChainIn& ci = in[set0 + k];
+    const ig_params p = {ci.p[0], ci.p[1], ci.p[2], ci.p[3], ci.p[4], ci.p[5], ci.p[6], ci.p[7]};
+    const int pz_n = chain_pz_n(p.d_max, mean_kb);
+    const int i = (int)blockIdx.x * blockDim.x + threadIdx.x;
+    const float s_z = (float)i * mean_kb;
+    const float pzv = (i < pz_n && s_z < p.d_max) ? ig_rippe(s_z, p, ig_tab()) : p.v_inter;
+    if (i < pz_n) S.pz[i] = pzv;
+    if (i < IG_TAB_SIZE) S.sc.tab.mt[i] = ig_tab()[i];
+    if (i < LDS_PZ + 2) S.sc.tab.pzc[i] = (double)(i < min(pz_n, LDS_PZ) ? pzv : p.v_inter) * IG_LOG_E_F;
+    if (i < LDS_LGF) S.sc.tab.lgf[i] = lgf_tab[i];
+    if (i == 0) {
+        S.sc.hot = ig_hot_make(p, ig_tab());
+        S.sc.par = p;
+        S.sc.mean_kb = mean_kb;
+        S.pz_n = pz_n;
+        for (int q = 0; q < 16; q++) out16[16 * k + q] = 0;
+        for (int q = 0; q < 8; q++) zs[8 * k + q] = 0;
+    }
+    build_diff_const(i, g, p, mean_kb, pzv, pz_n, sc0, pz_n0, &S.dc, scr0);
+}
+/* grid (blocks of one evaluation, sets) */
+__global__ void __launch_bounds__(256) k_hist_eval_chain(NuisHist h, const Glob* g, const ChainSet* __restrict__ sets, const ScoreConst* __restrict__ sc_c,
+                                                         long long* out16, Tables zt, int M, long long* zs, int n_zero_blocks, PzTab pz_c, ChainTest* tests)
+{
+    const int k = (int)blockIdx.y;
+    const ChainSet& S = sets[k];
+    hist_eval_body<true>(h, g, &S.sc, sc_c, &S.dc, out16 + 16 * k, nullptr, 0, zt, M, zs + 8 * k + 2, n_zero_blocks, zs + 8 * k, PzTab{S.pz, S.pz_n}, pz_c,
+                         (int)blockIdx.x, (int)gridDim.x, tests + k);
 }

@@ -41,10 +41,6 @@ __global__ void __launch_bounds__(256)
              int max_c, Tables tab, Tables tab_prev, const int* __restrict__ prev_touched, int force_slot, unsigned* touched_next,
              int n_touched_words)
 {
-    /* force_slot == -2: no forced slot, and slot 0 is scored like the others -- with every block-insert slot of candidate 0 (a batch
-     * scored in the background: the insert flags its first move will see are not known yet, nuis_bg_launch) */
-    const bool all_superset = force_slot == -2;
-    if (all_superset) force_slot = -1;
     /* the sub-fragments of this batch's windows, one bit each (mb.touched: set below by the fragments that drop themselves into
      * a window, read by k_slice in front of its gather of the partner's (contig, rank)); two bitmaps take turns: the one the
      * NEXT batch sets is cleared here */
@@ -124,7 +120,7 @@ __global__ void __launch_bounds__(256)
         mc.ch_score = 0.0;
         mc.n_slice_tot = mc.n_eval_tot = mc.bytes_min = 0;
         mc.d_hi = mc.d_lo = 0;
-        mc.superset0 = ((w > 0 || all_superset) && force_slot < 0) ? 1 : 0;
+        mc.superset0 = (w > 0 && force_slot < 0) ? 1 : 0;
         mc.n_dirty = 0;
         mc.pred = -1;
         mc.pred_c = mc.pred_k = 0;
@@ -188,7 +184,7 @@ __global__ void __launch_bounds__(256)
         if (force_slot >= 0) {
             u[n++] = force_slot;
         } else if (t == 0) {
-            n = build_uniq(u, true, m->LA, m->LB, (w == 0 && !all_superset) ? g->valid_insert : nullptr);
+            n = build_uniq(u, true, m->LA, m->LB, (w == 0) ? g->valid_insert : nullptr);
         } else {
             n = build_uniq(u, false, m->LA, m->LB, sh_flags[t - 1]);
         }

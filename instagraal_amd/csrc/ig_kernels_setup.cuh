@@ -73,10 +73,10 @@ __global__ void __launch_bounds__(256) k_pack_tab_sig(Tables t, int M, int4* __r
 }
 
 /* eval_likelihood_on_zero (KA:3850-3917) over all sub-fragments -> out[0..2] = hi, lo, n_intra */
-__device__ __forceinline__ void full_zero_block(const Tables& t, const Glob* g, int which, int M, long long* out, int block, int n_blocks)
+/* (the parameter set and the scalars as arguments: the chain's segments evaluate sets that never become Glob.par[1]) */
+__device__ __forceinline__ void full_zero_block_p(const Tables& t, const ig_params p, const float mean, const double n_tot_pxl, int M, long long* out,
+                                                  int block, int n_blocks)
 {
-    const ig_params p = g->par[which];
-    const float mean = g->mean_kb;
     long long hi = 0, lo = 0, ni = 0;
     for (int s = block * blockDim.x + threadIdx.x; s < M; s += n_blocks * blockDim.x) {
         const int pos = t.cp[s].y, len = t.len[s];
@@ -106,9 +106,13 @@ __device__ __forceinline__ void full_zero_block(const Tables& t, const Glob* g, 
     }
     /* what the host needs next to the sums to form the zero-pixel likelihood: one copy back instead of two */
     if (block == 0 && threadIdx.x == 0) { /* (atomic stores: a launch whose last workgroup reads them needs no fence for these two) */
-        __hip_atomic_store(&out[3], __double_as_longlong(g->n_tot_pxl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&out[5], (long long)__float_as_int(g->par[which].v_inter), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&out[3], __double_as_longlong(n_tot_pxl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&out[5], (long long)__float_as_int(p.v_inter), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+__device__ __forceinline__ void full_zero_block(const Tables& t, const Glob* g, int which, int M, long long* out, int block, int n_blocks)
+{
+    full_zero_block_p(t, g->par[which], g->mean_kb, g->n_tot_pxl, M, out, block, n_blocks);
 }
 __global__ void k_full_zero(Tables t, const Glob* g, int which, int M, long long* out) { full_zero_block(t, g, which, M, out, blockIdx.x, gridDim.x); }
 

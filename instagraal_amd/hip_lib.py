@@ -182,9 +182,10 @@ def set_nuis_hist(on):
     _ck(lib().ig_set_nuis_hist(C.c_int(int(on))))
 
 
-def set_nuis_background(on):
-    """the batches of a nuisance run scored ahead in the background, or when they are needed (default)"""
-    _ck(lib().ig_set_nuis_background(C.c_int(int(on))))
+def debug_set_zero_inject(every):
+    """tests: the decide step treats every n-th move of a two-tier batch as one whose contenders hold a score of exactly 0.0
+    (the move is scored again with every column exact); 0 = off"""
+    _ck(lib().ig_debug_set_zero_inject(C.c_int(int(every))))
 
 
 def debug_set_full_hist(on):
@@ -428,11 +429,11 @@ class Context:
                     largest_used_fraction=float(o[5]), walks=int(o[6]), builds=int(o[7]),
                     void_why=dict(parameters=int(o[8]), contact=int(o[9]), sums=int(o[10]), no_record=int(o[11])))
 
-    def debug_nuis_bg_stats(self):
-        """batches of nuisance runs scored in the background: (launched, adopted)"""
-        o = np.zeros(2, np.int64)
-        _ck(lib().ig_debug_nuis_bg_stats(self._h, _p(o)))
-        return int(o[0]), int(o[1])
+    def debug_zero_fallbacks(self):
+        """moves that were scored again with every column exact because a contender's score came out as exactly 0.0"""
+        n = C.c_int64()
+        _ck(lib().ig_debug_zero_fallbacks(self._h, C.byref(n)))
+        return int(n.value)
 
     def debug_nuis_hist_check(self):
         """words of the maintained histogram that differ from one built from scratch (-1: no histogram kept)"""

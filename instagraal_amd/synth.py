@@ -131,6 +131,15 @@ def rippe_params(mean_subfrag_kb, v_inter=5e-3, p_at_mean=20.0):
     return dict(kuhn=kuhn, lm=lm, c1=float(c1), slope=slope, d=d, d_max=float(d_max), fact=float(fact), v_inter=v_inter)
 
 
+def settled_params(params):
+    """P(s) parameters as a nuisance chain has them once it has settled on the synthetic data (tools/soak.py at cfg3 after two whole
+    nuisance cycles, profiles/r03y_soak_cfg3.txt: slope -0.53, fact 7.8e5, d_max 2.9e6 kb, trans level 2.9e-3) -- where a default run
+    spends 95 of its 100 cycles.  The P_z table is longer than its staged copy there and 4 x as many columns reach the exact tier."""
+    kuhn, lm, slope = float(params["kuhn"]), float(params["lm"]), -0.5303
+    c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+    return dict(params, slope=slope, c1=float(c1), fact=7.76e5, d_max=2.93e6, v_inter=2.936e-3)
+
+
 def make_problem(n_frags, n_contacts, seed=DEFAULT_SEED, mean_contig_len=50, cis_frac=0.8, cis_fill=0.85,
                  max_cis_kb=2000.0, with_level_csr=True) -> SynthProblem:
     rng = np.random.default_rng(seed)

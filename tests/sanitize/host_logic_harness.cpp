@@ -436,7 +436,6 @@ int main()
             for (int mode = 0; mode < 4; mode++) {
                 g_diff_mode = mode;
                 CHECK(ig_set_nuis_hist(mode == 3 ? 0 : 2) == 0);       /* the histogram tier whatever its cost model says / not at all */
-                CHECK(ig_set_nuis_background(mode == 1 ? 1 : 0) == 0); /* one run with its batches scored ahead in the background */
                 const int n = 160;
                 CHECK(ig_nuis_run_begin(c, n, frags.data(), cands.data(), max_c) == 0);
                 CHECK(ig_nuis_step_begin(c, 1, p8, 1.8f) != 0); // moves in order only
@@ -503,11 +502,9 @@ int main()
                  fake_hip::launches(), fake_hip::allocations(), g_decides, g_pendings, g_conflicts, g_overflows, g_diffs, g_exacts, st[0], st[1], st[3]);
     CHECK(g_pendings > 0 && g_conflicts > 0 && g_overflows > 0 && g_diffs > 0 && g_exacts > 0 && st[1] > 0 && st[3] > 0);
     double hs[12];
-    int64_t bg[2];
-    CHECK(ig_debug_nuis_hist_stats(c, hs) == 0 && ig_debug_nuis_bg_stats(c, bg) == 0);
-    std::fprintf(stderr, "[harness] histogram tier: evaluations %.0f (model calls %ld), rejected there %.0f, accepted there %.0f, void %.0f, walks %.0f, builds %.0f; "
-                         "background batches launched %lld, adopted %lld\n",
-                 hs[0], g_hists, hs[1], hs[2], hs[3], hs[6], hs[7], (long long)bg[0], (long long)bg[1]);
+    CHECK(ig_debug_nuis_hist_stats(c, hs) == 0);
+    std::fprintf(stderr, "[harness] histogram tier: evaluations %.0f (model calls %ld), rejected there %.0f, accepted there %.0f, void %.0f, walks %.0f, builds %.0f\n",
+                 hs[0], g_hists, hs[1], hs[2], hs[3], hs[6], hs[7]);
     CHECK(g_hists > 0 && hs[1] > 0 && hs[2] > 0 && hs[3] > 0 && hs[6] > 0);
     ig_destroy(c);
     ig_destroy(nullptr);

@@ -13,9 +13,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run(prob, n, seed, mode, monkeypatch, coo=False, params=None, warm=0, hist=True, background=False):
-    """mode: 'exact' (screening off), 'screened' (default), 'verify'; hist=False: the screened pass without its histogram tier;
-    background=True: the batches of the run scored ahead in the background against a snapshot of the state (off by default)"""
+def _run(prob, n, seed, mode, monkeypatch, coo=False, params=None, warm=0, hist=True):
+    """mode: 'exact' (screening off), 'screened' (default), 'verify'; hist=False: the screened pass without its histogram tier"""
     from instagraal_amd import hip_lib
     from instagraal_amd.sampler import sampler as hip_sampler
 
@@ -24,7 +23,6 @@ def _run(prob, n, seed, mode, monkeypatch, coo=False, params=None, warm=0, hist=
         monkeypatch.setenv("IG_NUIS_SCREEN_VERIFY", "1")
     hip_lib.set_nuis_screen(mode != "exact")
     hip_lib.set_nuis_hist(2 if hist else 0)  # (2: whatever the host's cost model would choose for a problem this small)
-    hip_lib.set_nuis_background(background)
     try:
         np.random.seed(seed)
         s = hip_sampler(**prob.sampler_kwargs(), device_id=0, coo=(prob.coo_row, prob.coo_col, prob.coo_cnt) if coo else None)
@@ -46,13 +44,11 @@ def _run(prob, n, seed, mode, monkeypatch, coo=False, params=None, warm=0, hist=
         stats["hist"] = s.ctx.debug_nuis_hist_stats()
         # the maintained histogram (every move of the run walked in) against one built from scratch from the final tables
         stats["hist_mismatch"] = s.ctx.debug_nuis_hist_check()
-        stats["background"] = s.ctx.debug_nuis_bg_stats()  # batches scored in the background: (launched, adopted)
         s.free_gpu()
         return out, stats
     finally:
         hip_lib.set_nuis_screen(1)
         hip_lib.set_nuis_hist(1)
-        hip_lib.set_nuis_background(0)
 
 
 @pytest.mark.parametrize("cfg,n", [("tiny", 250), ("small", 400), ("cfg2", 500)])
@@ -64,11 +60,6 @@ def test_screened_pass_bound_holds_and_changes_nothing(cfg, n, monkeypatch):
     verified, st1 = _run(prob, n, 5, "verify", monkeypatch)  # raises when a bound is violated
     screened, st2 = _run(prob, n, 5, "screened", monkeypatch)
     tier1, st3 = _run(prob, n, 5, "screened", monkeypatch, hist=False)
-    ahead, st4 = _run(prob, n, 5, "screened", monkeypatch, background=True)
-    ahead_exact, st5 = _run(prob, n, 5, "exact", monkeypatch, background=True)
-    assert ahead == exact and ahead_exact == exact  # batches scored ahead in the background change nothing
-    print(cfg, "batches scored in the background (launched, adopted):", st4["background"])
-    assert st2["background"] == (0, 0) and st4["background"][1] > 0 and st5["background"][1] > 0, (st2["background"], st4["background"])
     assert st0["screened"] == 0
     assert verified == exact
     assert screened == exact
