@@ -177,6 +177,23 @@ int ig_set_nuis_screen(int on);
  * with the pass over the contacts (env IG_NUIS_HIST); IG_NUIS_SCREEN_VERIFY=1 checks both tiers against the exact pass on every
  * step. */
 int ig_set_nuis_hist(int on);
+/* Chains: the pairs move .. move + n_sets - 1 of a run, as far as the device can take them WITHOUT the host (csrc/ig_common.cuh,
+ * ChainIn): per segment the Metropolis intervals of the next 8 steps' test sets from the histogram tier in one launch, then one decide
+ * wave that takes the moves from the batch's score records in order and tests each step (CL:3026-3036) against its interval with
+ * the live likelihood; it stops in front of the first pair that needs the host (a step that is not a certain rejection, a conflict,
+ * a pending windowed winner, an overflow) -- that pair is untouched and goes through ig_nuis_step_begin / ig_nuis_step_next -- and
+ * goes on behind a move that changed the genome once the histogram has followed it.  p_tests [n_sets][8] in KA:91-100 order, u /
+ * temperature [n_sets]: the acceptance uniforms and temperatures of those steps (n_sets <= 64).  Asynchronous: a helper thread
+ * drives the segments; ig_nuis_chain_done polls (1: ended), ig_nuis_chain_end waits: *n_done pairs completed (each a move decided
+ * exactly as ig_step_batch decides it and a step rejected with the margins of ig_nuis_step_next; their records: ig_batch_results),
+ * *reason: 0 sets used up, 1 test, 2 conflict, 3 pending, 4 overflow, 5 no slot scored under the model's parameters, 6 the
+ * histogram tier is not in use.  ig_set_nuis_chain(0) / env IG_NUIS_CHAIN=0: the runs keep to one pair per call (parameter halves
+ * scored in pieces that follow the run lengths, no winner prediction).  Results do not depend on any of it. */
+int ig_set_nuis_chain(int on);
+int ig_nuis_chain_begin(ig_ctx* ctx, int32_t move, int32_t n_sets, const float* p_tests, const double* u, const double* temperature,
+                        float mean_subfrag_kb);
+int ig_nuis_chain_done(ig_ctx* ctx);
+int ig_nuis_chain_end(ig_ctx* ctx, int32_t* n_done, int32_t* reason);
 /* *accepted = 3 from ig_nuis_step_next: the step was ACCEPTED from the screened interval alone (every L_test in it gives a ratio
  * above u); its exact pass -- the promotion of the maintained sum needs it, the decision does not -- runs behind the decision, next
  * to the re-scoring of the moves ahead; *nz_test was the interval's midpoint.  The exact value (what eval_likelihood_4_nuisance
@@ -243,6 +260,7 @@ int ig_debug_nuis_hist_check(ig_ctx* ctx, int64_t* mismatches);
  * move of a two-tier batch takes that path (0 = off) -- and how often a handle has taken it */
 int ig_debug_set_zero_inject(int every);
 int ig_debug_zero_fallbacks(ig_ctx* ctx, int64_t* fallbacks);
+int ig_debug_nuis_chain_stats(ig_ctx* ctx, int64_t out10[10]); /* chains: {calls, segments, pairs completed, ends by reason [7]} */
 int ig_debug_set_full_hist(int on); /* from-scratch pass: all-trans tiles from their count histograms (1, default) or contact by contact (0) */
 
 #ifdef __cplusplus

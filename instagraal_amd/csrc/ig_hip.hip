@@ -446,6 +446,12 @@ extern "C" void ig_destroy(ig_ctx* c)
     hipFree(c->nh.misc);
     hipFree(c->scratch_hist);
     hipFree(c->scratch_exact);
+    hipFree(c->chain_sets);
+    hipFree(c->chain_in);
+    hipFree(c->chain_tests);
+    hipFree(c->chain_out16);
+    hipFree(c->chain_zs);
+    if (c->chain_in_host) hipHostFree(c->chain_in_host);
     if (c->host_nuis) hipHostFree(c->host_nuis);
     if (c->h_stage) hipHostFree(c->h_stage);
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);

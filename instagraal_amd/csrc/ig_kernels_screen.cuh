@@ -77,7 +77,7 @@ __device__ __forceinline__ void build_screen_const_block(const Glob* g, PzTab pz
          * the second for slope < 0 (P decreasing in n = K s (S - s) / S, which is smallest, K mean (len - 1) / len >= n0, at
          * rank distance 1); other slopes: no bound, the column is scored exactly. */
         float zc = -1.0f;
-        if (h.fast && p.slope < 0.0f && p.kuhn > 0.0f && p.lm > 0.0f && g->mean_kb > 0.0f && p.d_max > 0.0f && p.d_max < 1e5f) { /* d_max < 1e5: the bound stays above the contract's clamp at -2^20 */
+        if (h.fast && p.slope < 0.0f && p.kuhn > 0.0f && p.lm > 0.0f && g->mean_kb > 0.0f && p.d_max > 0.0f && p.d_max < 1e30f) { /* (any d_max: screen_term takes the contract's clamp at -2^20 into the bound) */
             const double n0 = ((double)p.lm / (double)p.kuhn) * (double)g->mean_kb * 0.5;
             const double pmax = ig_exp2(h.slope * ig_log2_pos(n0, ig_tab()), ig_tab()) * (double)p.fact / ((double)p.kuhn * p.kuhn * p.kuhn);
             const double top = __builtin_fmax(__builtin_fmax(pmax, (double)p.d_max), (double)p.v_inter);
@@ -156,7 +156,13 @@ __device__ __forceinline__ void screen_term(unsigned long long pk, bool live, co
         const bool ring = cis && ((circ_mask >> (ai.y >> 28)) & 1u);
         const float em = fmaxf(d_max, 0.43429448f * obf);
         const float lem = __builtin_amdgcn_logf(em) * c10;
-        const float ub = __builtin_fmaf(obf, lem, -em) + zc_ub + 1e-5f * (obf * fabsf(lem) + em);
+        /* ... of the term as the contract evaluates it: CLAMPED at -2^20 (ig_quantize) -- with a far d_max (a settled nuisance chain:
+         * 3e6 kb, i.e. 3e6 contacts expected per ring pair) every such term sits at the clamp, above the unclamped bound.  The
+         * screened sums leave log10(ob!) out (it is the same in every column): clamp(t - lgf) + lgf <= max(ub, -2^20 + lgf), and
+         * log10(ob!) <= ob log10(ob) */
+        const float ub0 = __builtin_fmaf(obf, lem, -em) + zc_ub + 1e-5f * (obf * fabsf(lem) + em);
+        const float lgf_ub = obf * __builtin_amdgcn_logf(fmaxf(obf, 1.0f)) * c10 * 1.00001f + 1e-3f;
+        const float ub = fmaxf(ub0, -1048576.0f + lgf_ub);
         t = ring ? ub : t;
         exa = ring ? 0.0f : exa;
         oba = ring ? 0.0f : oba;

@@ -182,6 +182,27 @@ def set_nuis_hist(on):
     _ck(lib().ig_set_nuis_hist(C.c_int(int(on))))
 
 
+def set_nuis_chain(on):
+    """runs of (move, nuisance step) pairs decided on the device, as far as they need no host (default), or one pair per library call"""
+    global _nuis_chain
+    _nuis_chain = bool(on)
+    _ck(lib().ig_set_nuis_chain(C.c_int(int(on))))
+
+
+_nuis_chain = None
+
+
+def nuis_chain_wanted():
+    """what ``set_nuis_chain`` / IG_NUIS_CHAIN say (default: on)"""
+    if _nuis_chain is not None:
+        return bool(_nuis_chain)
+    return os.environ.get("IG_NUIS_CHAIN", "1") != "0"
+
+
+CHAIN_MAX = 64  # test parameter sets per ig_nuis_chain_begin (csrc/ig_common.cuh)
+CHAIN_REASONS = ("sets used up", "test", "conflict", "pending", "overflow", "no scored slots", "unsupported")
+
+
 def debug_set_zero_inject(every):
     """tests: the decide step treats every n-th move of a two-tier batch as one whose contenders hold a score of exactly 0.0
     (the move is scored again with every column exact); 0 = off"""
@@ -340,6 +361,29 @@ class Context:
                                     C.c_float(float(mean_subfrag_kb)), C.c_int32(int(has_next)), C.byref(res), C.byref(nz), C.byref(z),
                                     C.byref(acc)))
         return res, nz.value, z.value, acc.value
+
+    def nuis_chain_begin(self, move, p_tests, u, temperature, mean_subfrag_kb):
+        """the pairs move .. move + K - 1 of the run as far as the device can take them alone (ig_nuis_chain_begin; asynchronous):
+        p_tests (K, 8) float32, u / temperature (K,) float64"""
+        p = np.ascontiguousarray(p_tests, np.float32)
+        uu = np.ascontiguousarray(u, np.float64)
+        tt = np.ascontiguousarray(temperature, np.float64)
+        assert p.ndim == 2 and p.shape[1] == 8 and uu.size == p.shape[0] == tt.size
+        _ck(lib().ig_nuis_chain_begin(self._h, C.c_int32(int(move)), C.c_int32(p.shape[0]), _p(p), _p(uu), _p(tt), C.c_float(float(mean_subfrag_kb))))
+
+    def nuis_chain_done(self):
+        return bool(lib().ig_nuis_chain_done(self._h))
+
+    def nuis_chain_end(self):
+        """-> (pairs completed: each a move decided and a step rejected, index into CHAIN_REASONS of why the chain ended)"""
+        n, r = C.c_int32(), C.c_int32()
+        _ck(lib().ig_nuis_chain_end(self._h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def debug_nuis_chain_stats(self):
+        o = np.zeros(10, np.int64)
+        _ck(lib().ig_debug_nuis_chain_stats(self._h, _p(o)))
+        return dict(calls=int(o[0]), segments=int(o[1]), pairs=int(o[2]), ends={k: int(v) for k, v in zip(CHAIN_REASONS, o[3:10])})
 
     def nuis_exact_result(self):
         """exact nz_test of the last step ``nuis_step_next`` reported as accepted = 3 (decided from the screened interval)"""

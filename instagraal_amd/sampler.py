@@ -452,95 +452,135 @@ class sampler:  # noqa: N801 - the reference's class name
             return self._nuisance_run(frags, n_neighbours, t0, n_step, res)
 
     def _nuisance_run(self, frags, n_neighbours, t0, n_step, res):
-        n = frags.size
-        cands, id_modif, gauss, unif = self.neighbours.draw_nuisance(frags, max(1, n_neighbours))
-        tuples = []
-        mean_kb = self.mean_kb()
-
-        gauss_l, id_modif_l, unif_l = gauss.tolist(), id_modif.tolist(), unif.tolist()
-        sig_for = [None]
-
-        def proposal(i, params):
-            if sig_for[0] is not params:  # (the sigmas depend on the current parameters only: once per accepted step)
-                self._sigmas(params)
-                sig_for[0] = params
-            g = gauss_l[i]
-            return self._propose(params, id_modif_l[i], lambda sigma: 0.0 + float(sigma) * g)
-
+        """the run of (move, nuisance step) pairs.  Two kinds of library calls: a CHAIN (``ig_nuis_chain_begin``: the pairs ahead as far
+        as the device decides them alone -- moves from the batch's score records, steps rejected from the histogram tier's interval --
+        while this loop prepares the proposals of the steps behind), and ONE pair the plain way for whatever a chain stops in front of
+        (an accepted or undecided step, a conflict, a batch used up: ``ig_nuis_step_begin`` + ``ig_nuis_step_next``).  A rejected step
+        changes no parameter, so the proposals of the steps ahead are a pure function of the current parameters and the pre-drawn
+        stream: they are computed once per accepted step's epoch, ahead of their use."""
         import time as _t
 
-        prof = self.nuis_profile = dict(propose=0.0, step=0.0, book=0.0)
-        trace = getattr(self, "nuis_step_trace", None)  # a list: (seconds, accepted) per step (tools/nuisance_rate.py)
+        n = frags.size
+        cands, id_modif, gauss, unif = self.neighbours.draw_nuisance(frags, max(1, n_neighbours))
+        mean_kb = self.mean_kb()
+        gauss_l, id_modif_l, unif_l = gauss.tolist(), id_modif.tolist(), unif.tolist()
+        temps = np.array([float(self.temperature(t0 + i, n_step)) for i in range(n)]) if type(self).temperature is not sampler.temperature else np.ones(n)
+        prof = self.nuis_profile = dict(propose=0.0, step=0.0, book=0.0, chain=0.0)
+        trace = getattr(self, "nuis_step_trace", None)  # a list: (seconds, accepted) per plain step (tools/nuisance_rate.py)
+        use_chain = hip_lib.nuis_chain_wanted()
+        names = PARAM_NAMES
         curr = np.copy(self.param_simu)
-        out = proposal(0, curr)
-        names = res.dtype.names
-        p8 = lambda q: [q[k][0] for k in PARAM_NAMES]
-        self.ctx.nuis_run_begin(frags, cands)
-        self.ctx.nuis_step_begin(0, p8(out), mean_kb)
-        patch = None  # (step, z): a step accepted ahead of its exact pass, its likelihood still to be filled in
-        res_rows = []
+        self._sigmas(curr)
+        props = {}  # step -> (test parameters as the structured array, as 8 floats): valid while `curr` stands
+
+        def prop(i):
+            q = props.get(i)
+            if q is None:
+                g = gauss_l[i]
+                out = self._propose(curr, id_modif_l[i], lambda sigma: 0.0 + float(sigma) * g)
+                q = props[i] = (out, [out[k][0] for k in names])
+            return q
+
+        # per step: the parameters it ends with (index into `epochs`), success; likelihood_t of an accepted step; the exact likelihood
+        # of a step accepted ahead of its exact pass is filled in when the next plain step (or the end of the run) fetches it
+        epochs = [self.param_simu]
+        ep_of = np.zeros(n, np.int64)
+        success_of = np.zeros(n, np.int8)
+        lik_acc = {}
+        patch = None  # (step, z)
 
         def fill_in():
             j, zj = patch
-            lik = np.array([self.ctx.nuis_exact_result()]) + zj
-            tuples[j] = tuples[j][:5] + (lik,) + tuples[j][6:]
-            if j == len(tuples) - 1:
-                self.likelihood_t = self.likelihood_nuis = lik
-        for i in range(n):
-            ta = _t.perf_counter()
-            if patch is not None:  # the exact pass of the step before last ran behind its decision: done by now
-                fill_in()
-                patch = None
-            # while the GPU works on step i: the next step's proposal for the case that this one is rejected (the root finding
-            # for d_max is the expensive part of a step on the host); the one for the other case only if it comes to that --
-            # the kernels of the promotion run while it is computed
-            has_next = i + 1 < n
-            nxt_rej = proposal(i + 1, curr) if has_next else out
-            nxt_acc = None
-            t1 = _t.perf_counter()
-            # end of step i, the acceptance test, the promotion and (rejected) the first launches of step i + 1 in one call
-            r, nz, z, success = self.ctx.nuis_step_next(self.temperature(t0 + i, n_step), unif_l[i], p8(nxt_rej), None, mean_kb, has_next)
-            t2 = _t.perf_counter()
-            deferred = success == 3  # accepted from the screened interval: nz is its midpoint until the exact pass is through
-            if deferred:
-                success = 1
-            if success == 1 and has_next:
-                nxt_acc = proposal(i + 1, out)
-                self.ctx.nuis_step_begin(i + 1, p8(nxt_acc), mean_kb)
-            self.param_simu_test = out
-            self.likelihood_t = r.o
-            self.likelihood_nuis = np.array([nz]) + z
-            if success == 2:  # exp() within 1e-9 of u: the reference's own arithmetic decides
-                with np.errstate(over="ignore"):
-                    ratio = np.exp((self.likelihood_nuis - self.likelihood_t) / self.temperature(t0 + i, n_step))
-                success = 1 if ratio >= unif_l[i] else 0
-                if success:
-                    self.ctx.nuis_accept()
-                if has_next:
+            lik_acc[j] = np.array([self.ctx.nuis_exact_result()]) + zj
+
+        self.ctx.nuis_run_begin(frags, cands)
+        i = 0
+        try_chain = False  # (the first pair scores the first batch: the plain way)
+        LOOK = 2 * hip_lib.CHAIN_MAX
+        try:
+            while i < n:
+                if use_chain and try_chain:
+                    ta = _t.perf_counter()
+                    ready = 0  # proposals in hand from step i on
+                    while ready < 16 and (i + ready) in props:
+                        ready += 1
+                    K = min(n - i, max(8, ready))
+                    p_tests = np.array([prop(t)[1] for t in range(i, i + K)], np.float32)
+                    self.ctx.nuis_chain_begin(i, p_tests, unif[i:i + K], temps[i:i + K], mean_kb)
+                    t = i + K
+                    lim = min(n, i + K + LOOK)
+                    while t < lim and not self.ctx.nuis_chain_done():  # the proposals of the steps behind, while the device works
+                        if t not in props:
+                            prop(t)
+                        t += 1
+                    j, reason = self.ctx.nuis_chain_end()
+                    ep_of[i:i + j] = len(epochs) - 1
+                    i += j
+                    prof["chain"] += _t.perf_counter() - ta
+                    if reason == 0 and i < n:
+                        continue  # every set was used: the next chain
+                    if reason == 6:
+                        use_chain = False  # the histogram tier is not in use: one pair per call from here on
+                    if i >= n:
+                        break
+                # ---- one pair the plain way
+                ta = _t.perf_counter()
+                out, p8 = prop(i)
+                if patch is not None:  # (before the next step can be accepted ahead of its exact pass)
+                    fill_in()
+                    patch = None
+                t1 = _t.perf_counter()
+                T = float(temps[i])
+                self.ctx.nuis_step_begin(i, p8, mean_kb)
+                # (has_next without parameters: behind an accepted step the library re-scores the slots ahead under the promoted
+                # parameters at once -- that needs nothing from here and runs while the proposals of the new epoch are worked out)
+                r, nz, z, success = self.ctx.nuis_step_next(T, unif_l[i], None, None, mean_kb, i + 1 < n)
+                t2 = _t.perf_counter()
+                deferred = success == 3  # accepted from the screened interval: nz is its midpoint until the exact pass is through
+                if deferred:
+                    success = 1
+                self.param_simu_test = out
+                lik_nuis = np.array([nz]) + z
+                rescored = success == 1
+                if success == 2:  # exp() within 1e-9 of u: the reference's own arithmetic decides
+                    with np.errstate(over="ignore"):
+                        ratio = np.exp((lik_nuis - r.o) / T)
+                    success = 1 if ratio >= unif_l[i] else 0
                     if success:
-                        nxt_acc = proposal(i + 1, out)
-                    self.ctx.nuis_step_begin(i + 1, p8(nxt_acc if success else nxt_rej), mean_kb)
-            res_rows.append(r)
-            if success:
-                self.param_simu = out
-                self.likelihood_t = self.likelihood_nuis
-                curr = np.copy(out)
-            kuhn, lm, c1, slope, d, d_max, fact, d_nuc = self.param_simu[0]
-            tuples.append((fact, d, d_max, d_nuc, slope, self.likelihood_t, success, None))
-            if deferred:
-                patch = (i, z)
-            if has_next:
-                out = nxt_acc if success else nxt_rej
-            t3 = _t.perf_counter()
-            prof["propose"] += t1 - ta
-            prof["step"] += t2 - t1
-            prof["book"] += t3 - t2
-            if trace is not None:
-                trace.append((t3 - ta, int(success)))
-        if patch is not None:
-            fill_in()
-        for k in names:  # (the records: one column at a time, outside the loop)
-            res[k] = [getattr(r, k) for r in res_rows]
+                        self.ctx.nuis_accept()
+                if success:
+                    curr = np.copy(out)
+                    self.param_simu = out
+                    epochs.append(out)
+                    props = {}
+                    self._sigmas(curr)
+                    lik_acc[i] = lik_nuis
+                    if deferred:
+                        patch = (i, z)
+                ep_of[i] = len(epochs) - 1
+                success_of[i] = success
+                self.likelihood_nuis = lik_nuis
+                try_chain = rescored or not success  # (accepted by the arithmetic here: the slots ahead are void, a plain pair scores them)
+                i += 1
+                t3 = _t.perf_counter()
+                prof["propose"] += t1 - ta
+                prof["step"] += t2 - t1
+                prof["book"] += t3 - t2
+                if trace is not None:
+                    trace.append((t3 - ta, int(success)))
+        finally:
+            if patch is not None:
+                fill_in()
+        # the records of all moves at once; the 8-tuples from them
+        res[:] = self.ctx.batch_results(n)
+        o_col = res["o"]
+        tuples = []
+        for k in range(n):
+            kuhn, lm, c1, slope, d, d_max, fact, d_nuc = epochs[ep_of[k]][0]
+            lik = lik_acc[k] if success_of[k] else o_col[k]
+            tuples.append((fact, d, d_max, d_nuc, slope, lik, int(success_of[k]), None))
+        self.param_simu = epochs[-1]
+        self.likelihood_t = tuples[-1][5]
         last = res[-1]
         self.o = float(last["o"])
         self.n_contigs = np.int32(last["n_contigs"])

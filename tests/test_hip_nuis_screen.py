@@ -13,8 +13,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run(prob, n, seed, mode, monkeypatch, coo=False, params=None, warm=0, hist=True):
-    """mode: 'exact' (screening off), 'screened' (default), 'verify'; hist=False: the screened pass without its histogram tier"""
+def _run(prob, n, seed, mode, monkeypatch, coo=False, params=None, warm=0, hist=True, chain=True):
+    """mode: 'exact' (screening off), 'screened' (default), 'verify'; hist=False: the screened pass without its histogram tier;
+    chain=False: one (move, step) pair per library call (default: the pairs ahead are decided on the device as far as they need no
+    host, ig_nuis_chain_begin)"""
     from instagraal_amd import hip_lib
     from instagraal_amd.sampler import sampler as hip_sampler
 
@@ -23,6 +25,7 @@ def _run(prob, n, seed, mode, monkeypatch, coo=False, params=None, warm=0, hist=
         monkeypatch.setenv("IG_NUIS_SCREEN_VERIFY", "1")
     hip_lib.set_nuis_screen(mode != "exact")
     hip_lib.set_nuis_hist(2 if hist else 0)  # (2: whatever the host's cost model would choose for a problem this small)
+    hip_lib.set_nuis_chain(chain)
     try:
         np.random.seed(seed)
         s = hip_sampler(**prob.sampler_kwargs(), device_id=0, coo=(prob.coo_row, prob.coo_col, prob.coo_cnt) if coo else None)
@@ -44,11 +47,13 @@ def _run(prob, n, seed, mode, monkeypatch, coo=False, params=None, warm=0, hist=
         stats["hist"] = s.ctx.debug_nuis_hist_stats()
         # the maintained histogram (every move of the run walked in) against one built from scratch from the final tables
         stats["hist_mismatch"] = s.ctx.debug_nuis_hist_check()
+        stats["chain"] = s.ctx.debug_nuis_chain_stats()
         s.free_gpu()
         return out, stats
     finally:
         hip_lib.set_nuis_screen(1)
         hip_lib.set_nuis_hist(1)
+        hip_lib.set_nuis_chain(1)
 
 
 @pytest.mark.parametrize("cfg,n", [("tiny", 250), ("small", 400), ("cfg2", 500)])
@@ -60,6 +65,10 @@ def test_screened_pass_bound_holds_and_changes_nothing(cfg, n, monkeypatch):
     verified, st1 = _run(prob, n, 5, "verify", monkeypatch)  # raises when a bound is violated
     screened, st2 = _run(prob, n, 5, "screened", monkeypatch)
     tier1, st3 = _run(prob, n, 5, "screened", monkeypatch, hist=False)
+    one_by_one, st4 = _run(prob, n, 5, "screened", monkeypatch, chain=False)
+    assert one_by_one == exact  # the pairs decided on the device in chains change nothing
+    print(cfg, "chains:", st2["chain"])
+    assert st2["chain"]["pairs"] > 0 and st4["chain"]["calls"] == 0 and st0["chain"]["pairs"] == 0 and st1["chain"]["pairs"] == 0
     assert st0["screened"] == 0
     assert verified == exact
     assert screened == exact

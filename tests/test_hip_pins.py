@@ -143,8 +143,10 @@ def test_libm_live_oracle_cfg2_and_large_counts():
     big = copy.deepcopy(synth.make_problem(*synth.CONFIGS["small"]))
     cnt = big.coo_cnt.copy()
     cnt[::5] *= 70
-    cnt[::53] *= 500
-    assert (cnt >= 1024).sum() > 100
+    cnt[::53] *= 20
+    # (the arithmetic contract clamps a term at +-2^20, include/ig_detmath.h ig_quantize -- reached by a count in the hundreds of
+    # thousands against an expectation of a few: outside what the two arithmetics can be compared on)
+    assert (cnt >= 1024).sum() > 100 and cnt.max() < 100_000
     big.coo_cnt = cnt
     M = big.n_sub_frags
     big.sub_csr = sp.csr_matrix((cnt, (big.coo_row, big.coo_col)), shape=(M, M), dtype=np.int32)

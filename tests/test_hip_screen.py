@@ -129,6 +129,26 @@ def test_screening_at_the_headline_shape(monkeypatch):
     assert 0 < stats[0] < 0.5
 
 
+def test_screening_at_the_settled_parameters(monkeypatch):
+    """the headline shape under the parameters a nuisance chain settles into (synth.settled_params: slope -0.53, d_max 2.9e6 kb --
+    where a default run spends 95 of its 100 cycles): the P_z table longer than its staged copy, and a ring pair's term at the
+    contract's clamp (-2^20: 3e6 contacts expected per pair) -- the ring columns are ruled out by their clamped upper bound instead
+    of going through the exact kernel's general loop (they were half of the exact tier's columns and nine tenths of its time)"""
+    from instagraal_amd import synth
+
+    prob = synth.make_problem(*synth.CONFIGS["cfg3"])
+    prob.params = synth.settled_params(prob.params)
+    np.random.seed(2)
+    frags = np.resize(np.random.permutation(prob.n_frags), 400).astype(np.int32)
+    exact, _, _ = _run(prob, frags, 3, {"IG_SCREEN": "0"}, monkeypatch, coo=True)
+    verified, stats, _ = _run(prob, frags, 3, {"IG_SCREEN_VERIFY": "1"}, monkeypatch, coo=True)
+    screened, stats2, _ = _run(prob, frags, 3, {}, monkeypatch, coo=True)
+    assert verified == exact and screened == exact
+    print("cfg3, settled parameters: largest used fraction of a bound %.3g, largest bound %.3g, columns screened %d, scored exactly %d, terms %d / %d" % stats2)
+    assert stats2[3] < 0.08 * stats2[2]  # the ties and the current genome's columns; 10 % with the rings
+    assert 0 < stats[0] < 0.5
+
+
 @pytest.mark.parametrize("n_neighbours", [1, 6, 9, 16])
 @pytest.mark.parametrize("cfg,n_moves", [("tiny", 160), ("small", 330)])
 def test_other_candidate_counts(cfg, n_moves, n_neighbours, monkeypatch):

@@ -47,8 +47,13 @@ if os.environ.get("NUIS_LONG"):  # the rate as the chain settles: chunks of 600 
         dt = time.perf_counter() - t0
         tr = np.array(s.nuis_step_trace)
         s.nuis_step_trace.clear()
+        if tr.size == 0:
+            tr = np.zeros((1, 2))
         rej, acc = tr[tr[:, 1] == 0, 0] * 1e6, tr[tr[:, 1] == 1, 0] * 1e6
-        print("            per step: rejected n=%d median %.0f us, p25 %.0f, p75 %.0f, p95 %.0f, mean %.0f; accepted n=%d median %.0f us mean %.0f" % (
+        if len(rej) == 0:
+            rej = np.zeros(1)
+        print("            chains so far:", s.ctx.debug_nuis_chain_stats(), "; plain pairs this chunk: %d" % len(tr))
+        print("            per PLAIN step: rejected n=%d median %.0f us, p25 %.0f, p75 %.0f, p95 %.0f, mean %.0f; accepted n=%d median %.0f us mean %.0f" % (
             len(rej), np.median(rej), np.percentile(rej, 25), np.percentile(rej, 75), np.percentile(rej, 95), rej.mean(), len(acc),
             np.median(acc) if len(acc) else 0, acc.mean() if len(acc) else 0))
         edges = [0, 80, 120, 200, 300, 450, 700, 1e9]
