@@ -114,10 +114,16 @@ def nuisance_rate(s, prob, n_moves, n_neighbours, settle=0):
     run = getattr(s, "step_sampler_nuisance_batch", None)
     if run is not None:
         run(frags[:10 + settle], n_neighbours, s.dt, 0, n_moves)
+        b0, c0 = s.ctx.batch_stats(), s.ctx.debug_nuis_chain_stats()
         t0 = time.perf_counter()
         out = run(frags[10 + settle:], n_neighbours, s.dt, 0, n_moves)
         dt = time.perf_counter() - t0
-        return n_moves / dt, float(np.mean([q[6] for q in out[1]])), "step_sampler_nuisance_batch"
+        b1, c1 = s.ctx.batch_stats(), s.ctx.debug_nuis_chain_stats()
+        extra = {"batches_per_1000_moves": 1000.0 * (b1["batches"] - b0["batches"]) / n_moves,
+                 "pairs_decided_in_chains_pct": 100.0 * (c1["pairs"] - c0["pairs"]) / n_moves,
+                 "chain_calls": c1["calls"] - c0["calls"], "chain_segments": c1["segments"] - c0["segments"],
+                 "chain_ends": {k: c1["ends"][k] - c0["ends"][k] for k in c1["ends"]}}
+        return n_moves / dt, float(np.mean([q[6] for q in out[1]])), "step_sampler_nuisance_batch", extra
     for t, f in enumerate(frags[:10]):
         s.step_sampler(int(f), n_neighbours, s.dt)
         s.step_nuisance_parameters(s.dt, t, n_moves)
@@ -127,7 +133,7 @@ def nuisance_rate(s, prob, n_moves, n_neighbours, settle=0):
         s.step_sampler(int(f), n_neighbours, s.dt)
         acc += s.step_nuisance_parameters(s.dt, t, n_moves)[6]
     dt = time.perf_counter() - t0
-    return n_moves / dt, acc / float(n_moves), "step_sampler + step_nuisance_parameters per move"
+    return n_moves / dt, acc / float(n_moves), "step_sampler + step_nuisance_parameters per move", {}
 
 
 def spawn_workers(a):
@@ -292,13 +298,13 @@ def main():
     nuis = None
     if rank == 0 and world == 1 and a.nuisance_moves > 0:
         try:
-            rate, acc, how = nuisance_rate(s, prob, a.nuisance_moves, a.neighbours)
-            nuis = {"moves_per_s": rate, "accept_rate": acc, "moves": a.nuisance_moves, "loop": how,
+            rate, acc, how, extra = nuisance_rate(s, prob, a.nuisance_moves, a.neighbours)
+            nuis = {"moves_per_s": rate, "accept_rate": acc, "moves": a.nuisance_moves, "loop": how, **extra,
                     "regime": "the first %d (move, step) pairs behind the timed moves: large proposals, decisive tests" % a.nuisance_moves}
             if a.nuisance_settle > 0:
                 n_set = 4 * a.nuisance_moves
-                rate2, acc2, _ = nuisance_rate(s, prob, n_set, a.neighbours, settle=a.nuisance_settle)
-                nuis["settled"] = {"moves_per_s": rate2, "accept_rate": acc2, "moves": n_set, "after_steps": a.nuisance_moves + 10 + a.nuisance_settle,
+                rate2, acc2, _, extra2 = nuisance_rate(s, prob, n_set, a.neighbours, settle=a.nuisance_settle)
+                nuis["settled"] = {"moves_per_s": rate2, "accept_rate": acc2, "moves": n_set, "after_steps": a.nuisance_moves + 10 + a.nuisance_settle, **extra2,
                                    "regime": "behind %d more (move, step) pairs: where a run spends its 95 cycles" % a.nuisance_settle}
             st = getattr(s.ctx, "debug_nuis_screen_stats", None)
             if st is not None:

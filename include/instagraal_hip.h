@@ -187,8 +187,8 @@ int ig_set_nuis_hist(int on);
  * drives the segments; ig_nuis_chain_done polls (1: ended), ig_nuis_chain_end waits: *n_done pairs completed (each a move decided
  * exactly as ig_step_batch decides it and a step rejected with the margins of ig_nuis_step_next; their records: ig_batch_results),
  * *reason: 0 sets used up, 1 test, 2 conflict, 3 pending, 4 overflow, 5 no slot scored under the model's parameters, 6 the
- * histogram tier is not in use.  ig_set_nuis_chain(0) / env IG_NUIS_CHAIN=0: the runs keep to one pair per call (parameter halves
- * scored in pieces that follow the run lengths, no winner prediction).  Results do not depend on any of it. */
+ * histogram tier is not in use.  ig_set_nuis_chain(0) / env IG_NUIS_CHAIN=0: the runs keep to one pair per call (and score their
+ * batches without winner prediction).  Results do not depend on any of it. */
 int ig_set_nuis_chain(int on);
 int ig_nuis_chain_begin(ig_ctx* ctx, int32_t move, int32_t n_sets, const float* p_tests, const double* u, const double* temperature,
                         float mean_subfrag_kb);

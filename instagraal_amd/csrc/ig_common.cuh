@@ -270,7 +270,7 @@ struct NuisHist {
 /* ---- chains of (move, nuisance step) pairs decided on the device (ig_nuis_chain_begin) ------------------------
  * Once a chain has settled, 97 % of its nuisance steps are rejected and most moves leave the genome alone: nothing a pair does
  * depends on the host.  A SEGMENT evaluates the Metropolis intervals of the next CHAIN_SEG steps' test parameter sets from the
- * histogram of the cis contacts' distances in one launch (k_hist_eval_chain: the histogram is that of the current state, valid
+ * histogram of the cis contacts' distances in one launch (k_chain_hist_eval: the histogram is that of the current state, valid
  * for every step up to and including the first move that changes the genome), then ONE decide wave takes the moves from the
  * batch's score records in order, tests each step against its interval with the live likelihood in registers, and stops in
  * front of the first pair that needs the host -- a test that is not a certain rejection, a conflict, a pending windowed winner,
@@ -282,7 +282,7 @@ struct ChainIn {       /* host -> device, per step: the test parameters (KA:91-1
     float p[8];
     double ln_u;
 };
-struct ChainTest {     /* k_hist_eval_chain -> the decide wave, per set: the histogram tier's interval of D (2^-20 units), its void flags,
+struct ChainTest {     /* k_chain_hist_eval -> the decide wave, per set: the histogram tier's interval of D (2^-20 units), its void flags,
                         * the zero-pixel likelihood of the test set */
     long long s_fix, b_fix, flags;
     double z;
@@ -355,7 +355,8 @@ struct ig_ctx {
      * valid; the structural half (windows, candidate genomes, slice lists) of all spec_W slots: an accepted step only voids
      * the former (ig_kernels: k_rescore_prepare) */
     int spec_par_begin, spec_par_end;
-    double spec_ema, spec_struct_ema; /* moves decided per parameter scoring / per structural batch: set the widths */
+    double spec_ema, spec_struct_ema; /* moves decided between two accepted steps / per structural batch: set the widths */
+    int since_accept;                 /* moves decided since the last accepted step */
     ig_params nuis_test;           /* the test parameters of the step in flight */
     ig_params par_model;           /* host copy of the model's parameters (set 0): ig_set_params, ig_nuis_accept */
     float nuis_mean_kb;

@@ -357,7 +357,7 @@ struct FusedLds {
     int s0_mloc[IG_MAX_BATCH], s0_base[IG_MAX_BATCH];
 };
 /* CHAIN (k_decide_chain): a segment of a chain of (move, nuisance step) pairs -- ig_common.cuh, ChainIn.  Behind every decision
- * the step's Metropolis test (CL:3026-3036: exp((L_test - L_move) / T) >= u) against the interval k_hist_eval_chain left for its
+ * the step's Metropolis test (CL:3026-3036: exp((L_test - L_move) / T) >= u) against the interval k_chain_hist_eval left for its
  * test set: L_test = the maintained exact sum as of before the move + D +- B, + the zero-pixel likelihood of the set; a step
  * whose whole interval lies below T ln u (with the margins nuis_end_body keeps on the host) is rejected and the wave goes on;
  * anything else stops the segment IN FRONT of the pair (stop code 4: nothing of it is committed, the host takes it through
@@ -1282,4 +1282,23 @@ __global__ void k_debug_terms(const float* s, const float* stot, const int* ob, 
     if (hot.fast && ob[i] > 0) term[i] = ig_term_hot(s[i], 0, ob[i], lgfact_dev(ob[i], lgf_tab), exc[i], &hot, ig_tab());
     else term[i] = ig_pixel_term(ex[i], exc[i], ob[i], lgfact_dev(ob[i], lgf_tab), ig_tab());
     q[i] = ig_quantize(term[i]);
+}
+
+/* the same for a segment of a chain of (move, nuisance step) pairs (k_decide_chain's decisions, the apply step behind them) */
+__global__ void __launch_bounds__(64 + FUSED_CW * 64)
+    k_chain_decide_commit(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out, volatile int* host_out,
+                          int seq, int resumed_plain, State st, Tables tab, Tables tab_prev, const int* __restrict__ ip, const int* __restrict__ in,
+                          const int* __restrict__ orientable, const unsigned char* __restrict__ black, int* own_tag, int* own_idx, int* prev_touched,
+                          int zcheck, ChainArgs ca)
+{
+    __shared__ FusedLds sh;
+    for (int i = threadIdx.x; i < 3 * IG_MAX_BATCH + 2; i += blockDim.x) sh.bar[i] = 0;
+    for (int i = threadIdx.x; i < IG_MAX_BATCH; i += blockDim.x) sh.delta[i] = 0;
+    if (threadIdx.x == 0) {
+        sh.prog[0] = w_start;
+        sh.prog[1] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) decide_body<true, true>(g, mb, res, move0, W, w_start, dirty_buf, batch_out, host_out, seq, resumed_plain, &sh, zcheck, ca);
+    else commit_waves(st, tab, tab_prev, g, mb, ip, in, orientable, black, own_tag, own_idx, prev_touched, res, move0, W, w_start, nullptr, 0, &sh);
 }

@@ -620,7 +620,7 @@ __global__ void __launch_bounds__(256) k_hist_walk(const long long* __restrict__
  * [6] their counts, [7] an upper bound of their sum of P under both sets, [8] workgroups through; zero between two launches (the last
  * workgroup publishes and clears).  Grid: n_zero blocks of the zero-pixel sum under the test set (-> zero_out), NH_NB / 256 blocks
  * of bins, one block for the rank-distance histogram. */
-/* CHAIN (k_hist_eval_chain): one of the CHAIN_SEG sets of a segment -- the test set's parameters come with its constants (never
+/* CHAIN (k_chain_hist_eval): one of the CHAIN_SEG sets of a segment -- the test set's parameters come with its constants (never
  * Glob.par[1]), the interval goes to the decide wave (ChainTest) instead of the host */
 template <bool CHAIN>
 __device__ __forceinline__ void hist_eval_body(NuisHist h, const Glob* g, const ScoreConst* __restrict__ sc_t, const ScoreConst* __restrict__ sc_c,
@@ -633,8 +633,8 @@ __device__ __forceinline__ void hist_eval_body(NuisHist h, const Glob* g, const 
     __shared__ long long red_n[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (block < n_zero_blocks) {
-        if (CHAIN) full_zero_block_p(zt, sc_t->par, sc_t->mean_kb, g->n_tot_pxl, M, zero_out, block, n_zero_blocks);
-        else full_zero_block(zt, g, 1, M, zero_out, block, n_zero_blocks);
+        if (CHAIN) full_zero_block_p(zt, sc_t->par, sc_t->mean_kb, g->n_tot_pxl, M, zero_out, block, n_zero_blocks, pz_t.v, pz_t.n);
+        else full_zero_block(zt, g, 1, M, zero_out, block, n_zero_blocks, pz_t.v, pz_t.n);
     } else {
         const int bb = block - n_zero_blocks;
         const ig_hot hc = sc_c->hot, ht = sc_t->hot;
@@ -883,10 +883,26 @@ __device__ __forceinline__ int chain_pz_n(float d_max, float mean_kb)
     return (need > 0 && need < (double)PZ_MAX) ? (int)need : ((need >= (double)PZ_MAX) ? PZ_MAX : 0);
 }
 /* grid (blocks of 256 over the longest table, sets): set y = the uploaded set in[set0 + y] */
+/* live.dist != nullptr: the blocks behind the tables' (of set 0's row) bring tab_prev up to the current state first (k_catch_up's job:
+ * one launch less at the head of every segment) */
 __global__ void __launch_bounds__(256) k_chain_prepare(const Glob* g, const ChainIn* __restrict__ in, int set0, float mean_kb, ChainSet* sets,
                                                        const double* __restrict__ lgf_tab, const ScoreConst* __restrict__ sc0, int pz_n0,
-                                                       const ScreenConst* __restrict__ scr0, long long* out16, long long* zs)
+                                                       const ScreenConst* __restrict__ scr0, long long* out16, long long* zs, int n_const, Tables live,
+                                                       Tables prev, const int* __restrict__ prev_touched)
 {
+    if ((int)blockIdx.x >= n_const) {
+        if (blockIdx.y == 0 && live.dist) {
+            const int nb = (int)gridDim.x - n_const, b = (int)blockIdx.x - n_const;
+            for (int i = b * blockDim.x + threadIdx.x; i < g->n_prev_touched; i += nb * blockDim.x) {
+                const int s = prev_touched[i];
+                prev.dist[s] = live.dist[s];
+                prev.stot[s] = live.stot[s];
+                prev.cp[s] = live.cp[s];
+                prev.len[s] = live.len[s];
+            }
+        }
+        return;
+    }
     const int k = (int)blockIdx.y;
     ChainSet& S = sets[k];
     const ChainIn& ci = in[set0 + k];
@@ -910,7 +926,7 @@ __global__ void __launch_bounds__(256) k_chain_prepare(const Glob* g, const Chai
     build_diff_const(i, g, p, mean_kb, pzv, pz_n, sc0, pz_n0, &S.dc, scr0);
 }
 /* grid (blocks of one evaluation, sets) */
-__global__ void __launch_bounds__(256) k_hist_eval_chain(NuisHist h, const Glob* g, const ChainSet* __restrict__ sets, const ScoreConst* __restrict__ sc_c,
+__global__ void __launch_bounds__(256) k_chain_hist_eval(NuisHist h, const Glob* g, const ChainSet* __restrict__ sets, const ScoreConst* __restrict__ sc_c,
                                                          long long* out16, Tables zt, int M, long long* zs, int n_zero_blocks, PzTab pz_c, ChainTest* tests)
 {
     const int k = (int)blockIdx.y;

@@ -74,15 +74,17 @@ __global__ void __launch_bounds__(256) k_pack_tab_sig(Tables t, int M, int4* __r
 
 /* eval_likelihood_on_zero (KA:3850-3917) over all sub-fragments -> out[0..2] = hi, lo, n_intra */
 /* (the parameter set and the scalars as arguments: the chain's segments evaluate sets that never become Glob.par[1]) */
+/* pz / pz_n: the set's P_z table where the caller has it (pz[pos] is the direct evaluation's value: k_build_pz / k_nuis_prepare build it
+ * with the same functions -- a lookup instead of a power function per sub-fragment); nullptr: evaluated */
 __device__ __forceinline__ void full_zero_block_p(const Tables& t, const ig_params p, const float mean, const double n_tot_pxl, int M, long long* out,
-                                                  int block, int n_blocks)
+                                                  int block, int n_blocks, const float* __restrict__ pz = nullptr, int pz_n = 0)
 {
     long long hi = 0, lo = 0, ni = 0;
     for (int s = block * blockDim.x + threadIdx.x; s < M; s += n_blocks * blockDim.x) {
         const int pos = t.cp[s].y, len = t.len[s];
         if (pos == 0) ni += ((long long)len * (long long)(len - 1)) / 2;
         if (pos > 0) {
-            const long long q = zero_q(p, pos, len, t.stot[s], mean, nullptr, 0);
+            const long long q = zero_q(p, pos, len, t.stot[s], mean, pz, pz_n);
             hi += q >> 32;
             lo += (long long)(unsigned int)q;
         }
@@ -110,11 +112,15 @@ __device__ __forceinline__ void full_zero_block_p(const Tables& t, const ig_para
         __hip_atomic_store(&out[5], (long long)__float_as_int(p.v_inter), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-__device__ __forceinline__ void full_zero_block(const Tables& t, const Glob* g, int which, int M, long long* out, int block, int n_blocks)
+__device__ __forceinline__ void full_zero_block(const Tables& t, const Glob* g, int which, int M, long long* out, int block, int n_blocks,
+                                                const float* __restrict__ pz = nullptr, int pz_n = 0)
 {
-    full_zero_block_p(t, g->par[which], g->mean_kb, g->n_tot_pxl, M, out, block, n_blocks);
+    full_zero_block_p(t, g->par[which], g->mean_kb, g->n_tot_pxl, M, out, block, n_blocks, pz, pz_n);
 }
-__global__ void k_full_zero(Tables t, const Glob* g, int which, int M, long long* out) { full_zero_block(t, g, which, M, out, blockIdx.x, gridDim.x); }
+__global__ void k_full_zero(Tables t, const Glob* g, int which, int M, long long* out, const float* __restrict__ pz = nullptr, int pz_n = 0)
+{
+    full_zero_block(t, g, which, M, out, blockIdx.x, gridDim.x, pz, pz_n);
+}
 
 __global__ void k_count_heads(State st, int N, int* out, Glob* g)
 {

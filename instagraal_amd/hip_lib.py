@@ -18,7 +18,8 @@ SRC = os.path.join(HERE, "csrc", "ig_hip.hip")
 SRC_HOST = os.path.join(HERE, "csrc", "ig_draw.cpp")  # host-only part: the candidate draw
 DEPS = [SRC, SRC_HOST] + [os.path.join(HERE, "csrc", f) for f in ("ig_ops.cuh", "ig_common.cuh", "ig_model.cuh", "ig_kernels_setup.cuh",
                                                           "ig_kernels_score.cuh", "ig_kernels_screen.cuh", "ig_kernels_commit.cuh",
-                                                          "ig_kernels_nuis.cuh")] + \
+                                                          "ig_kernels_nuis.cuh", "ig_host_core.inc", "ig_host_upload.inc",
+                                                          "ig_host_batch.inc", "ig_host_nuis.inc", "ig_host_debug.inc")] + \
        [os.path.join(ROOT, "include", f) for f in ("ig_detmath.h", "ig_detmath_tables.h", "instagraal_hip.h")]
 
 N_TMP_STRUCT = 24

@@ -162,6 +162,56 @@ static void model_decide(void** a, dim3, dim3)
         ho[7] = seq;
     }
 }
+/* k_decide_chain: a segment of a chain of (move, nuisance step) pairs: as many pairs as it likes, then one of its ways to end --
+ * through (stop 0), behind a move that changed the genome (5, bo[11] = 1), in front of a pair whose step is not a certain rejection
+ * (4), a conflict (0, short), a pending move, an overflow (1 .. 3) */
+static long g_chain_decides = 0, g_chain_pairs = 0;
+static void model_decide_chain(void** a, dim3, dim3)
+{
+    const int W = *(int*)a[4], w_start = *(int*)a[5], seq = *(int*)a[9];
+    int* bo = *(int**)a[7];
+    volatile int* ho = *(volatile int**)a[8];
+    g_chain_decides++;
+    int committed = W, pending = -1, stop = 0, changed = 0;
+    const uint32_t r = rnd() % 12;
+    const int span = W - w_start;
+    if (r <= 2 && span >= 1) { /* behind a changing move somewhere in the segment */
+        committed = w_start + 1 + (int)(rnd() % (uint32_t)span);
+        stop = 5;
+        changed = 1;
+    } else if (r <= 4) { /* in front of a pair that needs the host */
+        committed = w_start + (int)(rnd() % (uint32_t)(span + 1));
+        if (committed == W) committed = W - 1;
+        stop = 4;
+    } else if (r == 5) { /* a conflict */
+        committed = w_start + (int)(rnd() % (uint32_t)span);
+        stop = 0;
+    } else if (r == 6) {
+        pending = w_start + (int)(rnd() % (uint32_t)span);
+        committed = pending;
+        g_pendings++;
+    } else if (r == 7) {
+        committed = w_start + (int)(rnd() % (uint32_t)span);
+        stop = 1 + (int)(rnd() % 3);
+    }
+    g_chain_pairs += committed - w_start;
+    int vals[12] = {0};
+    vals[0] = committed;
+    vals[1] = pending;
+    vals[2] = (committed == w_start && pending < 0 && stop >= 1 && stop <= 3) ? stop : 0;
+    vals[3] = 5 * (committed - w_start);
+    vals[5] = 1 + (int)(rnd() % 1000);
+    vals[6] = (int)(rnd() % 60000);
+    vals[10] = stop;
+    vals[11] = changed;
+    for (int i = 0; i < 12; i++)
+        if (i != 7) bo[i] = vals[i];
+    if (ho) {
+        for (int i = 0; i < 12; i++)
+            if (i != 7) ho[i] = vals[i];
+        ho[7] = seq;
+    }
+}
 static double g_move_score = -1000.0;
 static void model_commit_batch(void** a, dim3, dim3)
 {
@@ -261,6 +311,8 @@ int main()
     fake_hip::set_model("k_decide_batch", model_decide);
     fake_hip::set_model("k_commit_batch", model_commit_batch);
     fake_hip::set_model("k_decide_commit", model_decide_commit);
+    fake_hip::set_model("k_decide_chain", model_decide_chain);
+    fake_hip::set_model("k_chain_decide_commit", model_decide_chain);
     fake_hip::set_model("k_full_diff_tiled", model_diff);
     fake_hip::set_model("k_hist_eval", model_hist_eval);
     fake_hip::set_model("k_full_nz_tiled", model_full_nz_tiled);
@@ -479,6 +531,52 @@ int main()
                     n_acc += acc == 1;
                 }
                 std::fprintf(stderr, "[harness]   nuisance run (max_c %d, pass mode %d): %d of %d steps accepted\n", max_c, mode, n_acc, n);
+                // ---- the same run the way the sampler drives it: chains of pairs decided on the device (the model of the decide wave
+                // scripts their ends), one pair the plain way for what a chain stops in front of
+                CHECK(ig_nuis_run_begin(c, n, frags.data(), cands.data(), max_c) == 0);
+                {
+                    int i = 0;
+                    bool try_chain = false;
+                    long plain = 0, chained = 0;
+                    while (i < n) {
+                        if (try_chain) {
+                            const int K = std::min(n - i, 1 + (int)(rnd() % 24));
+                            std::vector<float> pt_(8 * (size_t)K);
+                            std::vector<double> uu(K), tt(K, 1.0);
+                            for (int k = 0; k < K; k++) {
+                                memcpy(&pt_[8 * (size_t)k], p8, sizeof p8);
+                                pt_[8 * (size_t)k + 3] = -1.5f + 0.001f * (float)((int)(rnd() % 11) - 5);
+                                uu[k] = (rnd() % 1000) / 1001.0; /* (0 among them: no threshold, never a certain rejection) */
+                            }
+                            CHECK(ig_nuis_chain_begin(c, i + 1, K, pt_.data(), uu.data(), tt.data(), 1.8f) != 0 || true); /* (wrong move: reported by _end) */
+                            int32_t nd = -1, why = -1;
+                            if (ig_nuis_chain_end(c, &nd, &why) == 0) CHECK(false); /* the chain for a move that is not the next one fails */
+                            CHECK(ig_nuis_chain_begin(c, i, K, pt_.data(), uu.data(), tt.data(), 1.8f) == 0);
+                            while (!ig_nuis_chain_done(c)) {
+                            }
+                            CHECK(ig_nuis_chain_end(c, &nd, &why) == 0);
+                            CHECK(nd >= 0 && nd <= K && why >= 0 && why <= 6);
+                            CHECK(ig_nuis_chain_end(c, &nd, &why) != 0); /* no chain was begun */
+                            i += nd;
+                            chained += nd;
+                            if (why == 0 && i < n) continue;
+                            if (i >= n) break;
+                        }
+                        CHECK(ig_nuis_step_begin(c, i, pt, 1.8f) == 0);
+                        int32_t acc = -1;
+                        double nzt, zt;
+                        const double u = (rnd() % 1000 + 1) / 1001.0;
+                        CHECK(ig_nuis_step_next(c, 1.0, u, nullptr, nullptr, 1.8f, i + 1 < n, &one, &nzt, &zt, &acc) == 0);
+                        bool rescored = acc == 1 || acc == 3;
+                        if (acc == 2 && (rnd() & 1)) CHECK(ig_nuis_accept(c) == 0);
+                        try_chain = rescored || acc == 0;
+                        plain++;
+                        i++;
+                    }
+                    std::fprintf(stderr, "[harness]   the same in chains: %ld pairs in chains, %ld the plain way\n", chained, plain);
+                    CHECK(mode == 3 || chained > 0);
+                }
+                CHECK(ig_batch_results(c, n, std::vector<ig_move_result>((size_t)n).data()) == 0);
                 // one pair at a time (no run)
                 CHECK(ig_nuis_begin(c, frags[1], cands.data() + (size_t)max_c, 1, pt, 1.8f) == 0);
                 CHECK(ig_nuis_begin(c, frags[1], cands.data() + (size_t)max_c, 1, pt, 1.8f) != 0);
