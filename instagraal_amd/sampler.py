@@ -399,6 +399,36 @@ class sampler:  # noqa: N801 - the reference's class name
             out = [(kuhn, lm, c1, slope, d, new_d_max, fact, new_d_nuc)]
         return np.array(out, dtype=PARAM_DTYPE)
 
+    def _epoch8(self, curr_param):
+        """what the proposals of the steps between two accepted ones share: the current parameters as eight float32 scalars, c1
+        recomputed from them the way every branch of ``_propose`` recomputes it (CL:2985-3013)"""
+        kuhn, lm, c1, slope, d, d_max, fact, d_nuc = curr_param[0]
+        c1 = np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))
+        return (kuhn, lm, c1, slope, d, d_max, fact, d_nuc)
+
+    def _propose8(self, e8, id_modif, g):
+        """``_propose`` on ``_epoch8``'s tuple with the standard normal ``g`` of the step, -> the eight float32 values of the
+        structured array ``_propose`` builds (same expressions, same dtypes, same bits: tests/test_cpu_abi_and_host.py): the run loop
+        computes one proposal per step on the host's critical path and needs the array only for the steps that are accepted"""
+        kuhn, lm, c1, slope, d, d_max, fact, d_nuc = e8
+        f32 = np.float32
+        if id_modif == 0:
+            new_fact = fact + (0.0 + float(self.sigma_fact) * g)
+            new_d_max = opti.estimate_max_dist_intra_nuis([kuhn, lm, slope, d, new_fact], d_nuc, d_max)
+            return (kuhn, lm, c1, slope, d, f32(new_d_max), f32(new_fact), d_nuc)
+        if id_modif == 1:
+            new_slope = slope + (0.0 + float(self.sigma_slope) * g)
+            new_d_max = opti.estimate_max_dist_intra_nuis([kuhn, lm, new_slope, d, fact], d_nuc, d_max)
+            c1 = f32((0.53 * np.power(lm / kuhn, new_slope)) * np.power(kuhn, -3))
+            return (kuhn, lm, c1, f32(new_slope), d, f32(new_d_max), fact, d_nuc)
+        if id_modif == 2:
+            new_d_max = d_max + (0.0 + float(self.sigma_d_max) * g)
+            new_d_nuc = opti.peval(new_d_max, [kuhn, lm, slope, d, fact])  # 5 values where 4 are read (quirk Q12)
+            return (kuhn, lm, c1, slope, d, f32(new_d_max), fact, f32(new_d_nuc))
+        new_d_nuc = d_nuc if self.sigma_d_nuc <= 0 else d_nuc + (0.0 + float(self.sigma_d_nuc) * g)
+        new_d_max = opti.estimate_max_dist_intra_nuis([kuhn, lm, slope, d, fact], new_d_nuc, d_max)
+        return (kuhn, lm, c1, slope, d, f32(new_d_max), fact, f32(new_d_nuc))
+
     def step_nuisance_parameters(self, dt, t, n_step):  # CL:2961-3051
         curr_param = np.copy(self.param_simu)
         self._sigmas(curr_param)
@@ -471,15 +501,19 @@ class sampler:  # noqa: N801 - the reference's class name
         names = PARAM_NAMES
         curr = np.copy(self.param_simu)
         self._sigmas(curr)
-        props = {}  # step -> (test parameters as the structured array, as 8 floats): valid while `curr` stands
+        e8 = self._epoch8(curr)
+        props = {}  # step -> the eight float32 test parameters of its proposal: valid while `curr` stands
 
         def prop(i):
             q = props.get(i)
             if q is None:
-                g = gauss_l[i]
-                out = self._propose(curr, id_modif_l[i], lambda sigma: 0.0 + float(sigma) * g)
-                q = props[i] = (out, [out[k][0] for k in names])
+                q = props[i] = self._propose8(e8, id_modif_l[i], gauss_l[i])
             return q
+
+        def as_array(p8):
+            return np.array([p8], dtype=PARAM_DTYPE)
+
+        last_test = [None]  # the test parameters of the last step that went the plain way
 
         # per step: the parameters it ends with (index into `epochs`), success; likelihood_t of an accepted step; the exact likelihood
         # of a step accepted ahead of its exact pass is filled in when the next plain step (or the end of the run) fetches it
@@ -493,11 +527,74 @@ class sampler:  # noqa: N801 - the reference's class name
             j, zj = patch
             lik_acc[j] = np.array([self.ctx.nuis_exact_result()]) + zj
 
+        def accepted(i, p8, lik_nuis, deferred, z):
+            nonlocal curr, props, patch, e8
+            out = as_array(p8)
+            curr = np.copy(out)
+            self.param_simu = out
+            epochs.append(out)
+            props = {}
+            self._sigmas(curr)
+            e8 = self._epoch8(curr)
+            lik_acc[i] = lik_nuis
+            if deferred:
+                patch = (i, z)
+
+        def pairs_pipelined(i0):
+            """steps i0 .. n - 1, one pair per library call with the next step begun inside the call that ends this one (the loop of
+            rounds 2 - 3: where chains are off or the histogram tier is not in use): while the GPU works on step i the proposal of
+            step i + 1 for the case that this one is rejected is worked out; the one for the other case only if it comes to that"""
+            nonlocal patch
+            p8 = prop(i0)
+            self.ctx.nuis_step_begin(i0, p8, mean_kb)
+            for i in range(i0, n):
+                ta = _t.perf_counter()
+                has_next = i + 1 < n
+                nxt = prop(i + 1) if has_next else None
+                if patch is not None:  # (the exact pass of the step accepted last ran behind its decision: done by now)
+                    fill_in()
+                    patch = None
+                t1 = _t.perf_counter()
+                T = float(temps[i])
+                r, nz, z, success = self.ctx.nuis_step_next(T, unif_l[i], nxt if has_next else None, None, mean_kb, has_next)
+                t2 = _t.perf_counter()
+                deferred = success == 3
+                if deferred:
+                    success = 1
+                lik_nuis = np.array([nz]) + z
+                began = success == 0  # (rejected: the library has begun step i + 1 with the parameters handed over)
+                if success == 2:  # exp() within 1e-9 of u: the reference's own arithmetic decides
+                    with np.errstate(over="ignore"):
+                        ratio = np.exp((lik_nuis - r.o) / T)
+                    success = 1 if ratio >= unif_l[i] else 0
+                    if success:
+                        self.ctx.nuis_accept()
+                if success:
+                    accepted(i, p8, lik_nuis, deferred, z)
+                    nxt = prop(i + 1) if has_next else None  # (under the promoted parameters)
+                ep_of[i] = len(epochs) - 1
+                success_of[i] = success
+                self.likelihood_nuis = lik_nuis
+                last_test[0] = p8
+                if has_next:
+                    if not began:
+                        self.ctx.nuis_step_begin(i + 1, nxt, mean_kb)
+                    p8 = nxt
+                t3 = _t.perf_counter()
+                prof["propose"] += t1 - ta
+                prof["step"] += t2 - t1
+                prof["book"] += t3 - t2
+                if trace is not None:
+                    trace.append((t3 - ta, int(success)))
+
         self.ctx.nuis_run_begin(frags, cands)
         i = 0
         try_chain = False  # (the first pair scores the first batch: the plain way)
         LOOK = 2 * hip_lib.CHAIN_MAX
         try:
+            if not use_chain:
+                pairs_pipelined(0)
+                i = n
             while i < n:
                 if use_chain and try_chain:
                     ta = _t.perf_counter()
@@ -505,7 +602,7 @@ class sampler:  # noqa: N801 - the reference's class name
                     while ready < 16 and (i + ready) in props:
                         ready += 1
                     K = min(n - i, max(8, ready))
-                    p_tests = np.array([prop(t)[1] for t in range(i, i + K)], np.float32)
+                    p_tests = np.array([prop(t) for t in range(i, i + K)], np.float32)
                     self.ctx.nuis_chain_begin(i, p_tests, unif[i:i + K], temps[i:i + K], mean_kb)
                     t = i + K
                     lim = min(n, i + K + LOOK)
@@ -519,13 +616,15 @@ class sampler:  # noqa: N801 - the reference's class name
                     prof["chain"] += _t.perf_counter() - ta
                     if reason == 0 and i < n:
                         continue  # every set was used: the next chain
-                    if reason == 6:
-                        use_chain = False  # the histogram tier is not in use: one pair per call from here on
                     if i >= n:
+                        break
+                    if reason == 6:  # the histogram tier is not in use: one pair per call from here on
+                        pairs_pipelined(i)
+                        i = n
                         break
                 # ---- one pair the plain way
                 ta = _t.perf_counter()
-                out, p8 = prop(i)
+                p8 = prop(i)
                 if patch is not None:  # (before the next step can be accepted ahead of its exact pass)
                     fill_in()
                     patch = None
@@ -539,7 +638,6 @@ class sampler:  # noqa: N801 - the reference's class name
                 deferred = success == 3  # accepted from the screened interval: nz is its midpoint until the exact pass is through
                 if deferred:
                     success = 1
-                self.param_simu_test = out
                 lik_nuis = np.array([nz]) + z
                 rescored = success == 1
                 if success == 2:  # exp() within 1e-9 of u: the reference's own arithmetic decides
@@ -549,17 +647,11 @@ class sampler:  # noqa: N801 - the reference's class name
                     if success:
                         self.ctx.nuis_accept()
                 if success:
-                    curr = np.copy(out)
-                    self.param_simu = out
-                    epochs.append(out)
-                    props = {}
-                    self._sigmas(curr)
-                    lik_acc[i] = lik_nuis
-                    if deferred:
-                        patch = (i, z)
+                    accepted(i, p8, lik_nuis, deferred, z)
                 ep_of[i] = len(epochs) - 1
                 success_of[i] = success
                 self.likelihood_nuis = lik_nuis
+                last_test[0] = p8
                 try_chain = rescored or not success  # (accepted by the arithmetic here: the slots ahead are void, a plain pair scores them)
                 i += 1
                 t3 = _t.perf_counter()
@@ -580,6 +672,8 @@ class sampler:  # noqa: N801 - the reference's class name
             lik = lik_acc[k] if success_of[k] else o_col[k]
             tuples.append((fact, d, d_max, d_nuc, slope, lik, int(success_of[k]), None))
         self.param_simu = epochs[-1]
+        if last_test[0] is not None:
+            self.param_simu_test = as_array(last_test[0])
         self.likelihood_t = tuples[-1][5]
         last = res[-1]
         self.o = float(last["o"])

@@ -312,3 +312,36 @@ def test_host_logic_under_address_and_ub_sanitizers(tmp_path):
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
     assert r.returncode == 0 and "host logic harness ok" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+def test_fast_proposals_equal_the_reference_shaped_ones():
+    """sampler._propose8 (the run loop's proposal: eight float32 values from a tuple) against sampler._propose (the branch-for-branch
+    restatement of CL:2979-3017 on structured arrays, which the goldens pin): same bits for every modifier, under the synthetic
+    parameters and under a settled chain's"""
+    from instagraal_amd import synth
+    from instagraal_amd import optim_rippe_curve_update as opti
+    from instagraal_amd.sampler import PARAM_DTYPE, PARAM_NAMES, sampler
+
+    class bare(sampler):
+        def __init__(self):
+            pass
+
+    s = bare()
+    base = synth.rippe_params(1.8)
+    rng = np.random.RandomState(5)
+    n = 0
+    with opti.quiet_runs():
+        for params in (base, synth.settled_params(base), dict(base, slope=-0.9, d_max=5.0e4, v_inter=1e-3)):
+            curr = np.zeros(1, PARAM_DTYPE)
+            for k in PARAM_NAMES:
+                curr[k] = np.float32(params[k])
+            s._sigmas(curr)
+            e8 = s._epoch8(curr)
+            for _ in range(300):
+                m, g = int(rng.randint(0, 4)), float(rng.standard_normal())
+                want = s._propose(curr, m, lambda sigma: 0.0 + float(sigma) * g)
+                got = s._propose8(e8, m, g)
+                assert all(type(v) is np.float32 for v in got), [type(v) for v in got]
+                assert np.array([got], dtype=PARAM_DTYPE).tobytes() == want.tobytes(), (m, g, got, want)
+                n += 1
+    assert n == 900

@@ -155,3 +155,40 @@ def test_histogram_tier_with_rank_distances_beyond_the_staged_table(monkeypatch)
     assert st["hist"]["void"] <= 5 and st2["hist"]["void"] <= 5  # (a proposal outside the one-log domain now and then)
     assert st["hist"]["largest_used_fraction"] <= 1.0 and st["hist_mismatch"] == 0 and st2["hist_mismatch"] == 0
     assert st2["hist"]["rejected"] + st2["hist"]["accepted"] > 0.5 * st2["screened"]
+
+
+def test_chains_under_a_temperature_and_without_the_helper_thread(monkeypatch):
+    """the chains' thresholds T (ln u - margin) with a temperature other than the reference's 1.0 (sampler.temperature is a method
+    a caller may override: CL:3163-3165), varying from step to step; and the segments driven on the caller's thread (IG_NUIS_ASYNC=0)"""
+    from instagraal_amd import hip_lib, synth
+    from instagraal_amd.sampler import sampler as hip_sampler
+
+    class cooled(hip_sampler):
+        def temperature(self, t, n_step):
+            return 0.5 + 0.25 * (t % 3)
+
+    prob = synth.make_problem(*synth.CONFIGS["small"])
+    outs = {}
+    try:
+        for chain, async_ in ((0, "1"), (1, "1"), (1, "0")):
+            monkeypatch.setenv("IG_NUIS_ASYNC", async_)
+            hip_lib.set_nuis_chain(chain)
+            hip_lib.set_nuis_hist(2)
+            np.random.seed(41)
+            s = cooled(**prob.sampler_kwargs(), device_id=0)
+            s.set_param_simu(prob.params)
+            s.bins = np.arange(1.0, 60.0, 1.0)
+            s.eval_likelihood_init()
+            frags = np.resize(np.random.permutation(prob.n_frags), 500)
+            res, tuples = s.step_sampler_nuisance_batch(frags, 5, s.dt, 0, 500)
+            st = s.ctx.debug_nuis_chain_stats()
+            outs[(chain, async_)] = (res[["o", "dist", "op_sampled", "id_f_sampled", "n_contigs"]].tobytes(),
+                                     [tuple(float(np.ravel(x)[0]) for x in q[:7]) for q in tuples],
+                                     s.gpu_vect_frags.copy_from_gpu().soa17().tobytes(), np.random.get_state()[1][:8].tobytes())
+            assert (st["pairs"] > 0) == bool(chain), st
+            s.free_gpu()
+    finally:
+        hip_lib.set_nuis_chain(1)
+        hip_lib.set_nuis_hist(1)
+    assert outs[(1, "1")] == outs[(0, "1")] and outs[(1, "0")] == outs[(0, "1")]
+    assert 0 < sum(q[6] for q in outs[(0, "1")][1]) < 500

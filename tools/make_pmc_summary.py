@@ -11,11 +11,13 @@ import sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 tag = sys.argv[1]
 cfg = os.environ.get("CONFIG", "cfg3")  # the shape tools/profile_round.sh was run with
+if os.environ.get("PARAMS", "synthetic") == "settled":
+    cfg += "settled"
 outdir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
 KERNELS = {"k_screen": ("_Z13k_screen_tail", "_Z8k_screen"), "k_score_list": "_Z12k_score_list", "k_slice": "_Z7k_slice", "k_tail": "_Z6k_tail",
            "k_full_nz_tiled": "_Z15k_full_nz_tiled", "k_decide_batch": ("_Z14k_decide_batch", "_Z15k_decide_commit"), "k_mutate": "_Z8k_mutate"}
 merged = {}
-for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "%s_pmc_pass*.json" % tag))):
+for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "%s_%s_pmc_pass*.json" % (tag, cfg)))):
     d = json.load(open(f))
     for name, ctrs in d.items():
         for short, prefix in KERNELS.items():
@@ -25,7 +27,8 @@ for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "%s_pmc_pass*.json" %
                     e[c] = v["avg"]
                     e.setdefault("launches", v["launches"])
 out = {"command": "tools/profile_round.sh %s: rocprofv3 --pmc <one group per pass> -- python3 bench.py --no-cpu-baseline --nuisance-moves 0 "
-                  "--config %s --steps 12 --warmup 2 (12 batches of 24 moves; one MI355X, W = 24 moves per launch)" % (tag, cfg),
+                  "--config %s%s --settled-batches 0 --steps 12 --warmup 2 (12 batches of 24 moves; one MI355X, W = 24 moves per launch)" % (
+                      tag, cfg.replace("settled", ""), " --params settled" if cfg.endswith("settled") else ""),
        "note": "FETCH_SIZE / WRITE_SIZE are KB per dispatch (separate passes). traffic_bytes_per_launch = 2 x FETCH_SIZE (gfx950 "
                "correction of MI355X_MICROARCH.md, calibrated in round 1 on k_full_nz) + WRITE_SIZE.  Instruction counts are per "
                "dispatch and per counter instance as rocprofv3 reports them."}
