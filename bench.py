@@ -381,8 +381,9 @@ def main():
                 traffic_src = "profiles/" + os.path.basename(pmc[-1])
                 # the whole batch: every kernel of it that was counted (the slice lists' round trip -- written by k_slice, read
                 # by the scoring kernels -- is in neither B_min nor the dominant kernel's figure)
-                per_k = {k: float(v["traffic_bytes_per_launch"]) for k, v in allk.items() if isinstance(v, dict) and "traffic_bytes_per_launch" in v
-                         and k in ("k_screen", "k_slice", "k_mutate", "k_score_list", "k_decide_batch")}
+                # every kernel of a batch that was counted (k_predict runs twice per batch; k_full_nz_tiled and k_tail are not part of one)
+                per_k = {k: float(v["traffic_bytes_per_launch"]) * (2.0 if k == "k_predict" else 1.0) for k, v in allk.items()
+                         if isinstance(v, dict) and "traffic_bytes_per_launch" in v and k not in ("k_full_nz_tiled", "k_tail", "k_commit_batch")}
                 batch_traffic = {"bytes_per_batch": sum(per_k.values()), "by_kernel": per_k}
         except Exception:
             traffic = valu_busy = traffic_src = batch_traffic = None

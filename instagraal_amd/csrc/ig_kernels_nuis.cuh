@@ -848,6 +848,7 @@ __device__ __forceinline__ void hist_eval_body(NuisHist h, const Glob* g, const 
                 ct->b_fix = o[3];
                 ct->flags = o[4];
                 ct->z = ig_acc_to_double(zh, zl) * log_e + log_e * (g->n_tot_pxl - (double)ni) * -1.0 * (double)sc_t->par.v_inter;
+                for (int q = 0; q < 8; q++) ((long long*)zero_sums)[q] = 0; /* (the next segment adds to them again) */
             } else if (hn) {
                 for (int q = 0; q < 8; q++) hn->diff[q] = o[q];
                 for (int q = 0; q < 8; q++) hn->sums[q] = __hip_atomic_load(&zero_sums[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -882,27 +883,12 @@ __device__ __forceinline__ int chain_pz_n(float d_max, float mean_kb)
     const double need = (mean_kb > 0) ? (double)d_max / (double)mean_kb + 2.0 : 0.0;
     return (need > 0 && need < (double)PZ_MAX) ? (int)need : ((need >= (double)PZ_MAX) ? PZ_MAX : 0);
 }
-/* grid (blocks of 256 over the longest table, sets): set y = the uploaded set in[set0 + y] */
-/* live.dist != nullptr: the blocks behind the tables' (of set 0's row) bring tab_prev up to the current state first (k_catch_up's job:
- * one launch less at the head of every segment) */
-__global__ void __launch_bounds__(256) k_chain_prepare(const Glob* g, const ChainIn* __restrict__ in, int set0, float mean_kb, ChainSet* sets,
+/* grid (blocks of 256 over the longest table, sets of the call): set y = the uploaded set in[y] */
+__global__ void __launch_bounds__(256) k_chain_prepare(const Glob* g, const ChainIn* __restrict__ in, float mean_kb, ChainSet* sets,
                                                        const double* __restrict__ lgf_tab, const ScoreConst* __restrict__ sc0, int pz_n0,
-                                                       const ScreenConst* __restrict__ scr0, long long* out16, long long* zs, int n_const, Tables live,
-                                                       Tables prev, const int* __restrict__ prev_touched)
+                                                       const ScreenConst* __restrict__ scr0, long long* zs, int n_sets)
 {
-    if ((int)blockIdx.x >= n_const) {
-        if (blockIdx.y == 0 && live.dist) {
-            const int nb = (int)gridDim.x - n_const, b = (int)blockIdx.x - n_const;
-            for (int i = b * blockDim.x + threadIdx.x; i < g->n_prev_touched; i += nb * blockDim.x) {
-                const int s = prev_touched[i];
-                prev.dist[s] = live.dist[s];
-                prev.stot[s] = live.stot[s];
-                prev.cp[s] = live.cp[s];
-                prev.len[s] = live.len[s];
-            }
-        }
-        return;
-    }
+    const int set0 = 0;
     const int k = (int)blockIdx.y;
     ChainSet& S = sets[k];
     const ChainIn& ci = in[set0 + k];
@@ -920,8 +906,8 @@ __global__ void __launch_bounds__(256) k_chain_prepare(const Glob* g, const Chai
         S.sc.par = p;
         S.sc.mean_kb = mean_kb;
         S.pz_n = pz_n;
-        for (int q = 0; q < 16; q++) out16[16 * k + q] = 0;
-        for (int q = 0; q < 8; q++) zs[8 * k + q] = 0;
+        if (k < CHAIN_SEG) /* (the segments' scratch words: zero between two launches -- k_chain_hist_eval's last workgroups clear them) */
+            for (int q = 0; q < 8; q++) zs[8 * k + q] = 0;
     }
     build_diff_const(i, g, p, mean_kb, pzv, pz_n, sc0, pz_n0, &S.dc, scr0);
 }

@@ -15,7 +15,9 @@ if os.environ.get("PARAMS", "synthetic") == "settled":
     cfg += "settled"
 outdir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
 KERNELS = {"k_screen": ("_Z13k_screen_tail", "_Z8k_screen"), "k_score_list": "_Z12k_score_list", "k_slice": "_Z7k_slice", "k_tail": "_Z6k_tail",
-           "k_full_nz_tiled": "_Z15k_full_nz_tiled", "k_decide_batch": ("_Z14k_decide_batch", "_Z15k_decide_commit"), "k_mutate": "_Z8k_mutate"}
+           "k_full_nz_tiled": "_Z15k_full_nz_tiled", "k_decide_batch": ("_Z14k_decide_batch", "_Z15k_decide_commit"), "k_mutate": "_Z8k_mutate",
+           "k_gather": "_Z8k_gather", "k_delta": "_Z7k_delta", "k_offsets": "_Z9k_offsets", "k_contend": "_Z9k_contend", "k_worklist": "_Z10k_worklist",
+           "k_records": "_Z9k_records", "k_predict": "_Z9k_predict", "k_commit_batch": "_Z14k_commit_batch"}
 merged = {}
 for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "%s_%s_pmc_pass*.json" % (tag, cfg)))):
     d = json.load(open(f))
