@@ -416,15 +416,28 @@ struct alignas(16) ScreenLds2 {
     uint2 colB[LDS_COL_SMALL]; /* column B of the pair loop (directly behind one.col) */
     double red_s2[SCORE_THREADS / 64];
     float red_e2[SCORE_THREADS / 64], red_y2[SCORE_THREADS / 64];
+    unsigned red_void[SCORE_THREADS / 64]; /* bit 0 / 1: column A / B holds a ring pair whose count is beyond the linear bound */
 };
 /* the arithmetic of screen_pair on precomputed LDS byte offsets (o = 8 x local index) for one column */
 /* ABL != 0: probe instances (IG_SCREEN_PROBE, wrong sums into scratch words): what the loop costs without its parts, timed on the
  * real trajectory next to the real launch -- bit 0: no P_z gather, bit 1: the partner's record made up from the row's (one LDS gather
  * per entry and column instead of two), bit 2: no transcendental functions, bit 3: no entries (set-up, staging, reduction and
  * publication only), bit 4: leave behind the first round of loads, bit 5: leave behind the staging's barrier */
-template <int ABL = 0>
+/* CIRC (round 4): a column with a ring on its window (a candidate that closes a contig) through the same pass -- a pair on the ring
+ * contributes the UPPER bound of its term instead of the term (screen_term has the derivation): with ob <= d_max ln 10 the bound is
+ * linear in the count, ub = ob log10(d_max) - d_max + zc_ub (+ margins), clamped below like the contract's term at -2^20 (+ log10(ob!)
+ * <= ob log10(2^14), which the screened sums leave out); a larger count voids the column (bit 31 of `bad`).  The error sums take the
+ * ring pairs' linear-contig values along: too large, which a bound may be.  Until round 4 such columns went through the one-column
+ * routine, staged again behind a barrier: 23 us of the launch's 172 at the headline shape (tools/screen_probe.py). */
+struct RingUb {
+    unsigned mask; /* contig codes that are rings in this column */
+    float k1, k0;  /* ub = ob k1 + k0 */
+    float ob_max;  /* counts above it: the linear form does not hold */
+};
+template <int ABL = 0, bool CIRC = false>
 __device__ __forceinline__ void screen_pair_col(unsigned oi0, unsigned oj0, unsigned oi1, unsigned oj1, f32x2 obf, const char* colb, const char* pzb,
-                                                float slope, float la, float lv, float d_max, float c10, double& acc, f32x2& exs2, float& ymax)
+                                                float slope, float la, float lv, float d_max, float c10, double& acc, f32x2& exs2, float& ymax,
+                                                const RingUb ru = RingUb{0u, 0.0f, 0.0f, 0.0f}, unsigned* bad = nullptr)
 {
     const uint2 a0 = *(const uint2*)(colb + oi0), a1 = *(const uint2*)(colb + oi1);
     uint2 b0, b1;
@@ -455,7 +468,15 @@ __device__ __forceinline__ void screen_pair_col(unsigned oi0, unsigned oj0, unsi
     if (ABL & 4) ex = f32x2{yy.x * 1.5f, yy.y * 1.5f};
     else ex = f32x2{__builtin_amdgcn_exp2f(yy.x), __builtin_amdgcn_exp2f(yy.y)};
     const f32x2 m = obf * yy;
-    const f32x2 t = __builtin_elementwise_fma(m, f32x2{c10, c10}, -ex) + pzc;
+    f32x2 t = __builtin_elementwise_fma(m, f32x2{c10, c10}, -ex) + pzc;
+    if (CIRC) {
+        const bool r0 = (d0 < (1u << 27)) && ((ru.mask >> (a0.y >> 28)) & 1u), r1 = (d1 < (1u << 27)) && ((ru.mask >> (a1.y >> 28)) & 1u);
+        const float u0 = fmaxf(__builtin_fmaf(obf.x, ru.k1, ru.k0), __builtin_fmaf(obf.x, 4.2145f, -1048575.9f));
+        const float u1 = fmaxf(__builtin_fmaf(obf.y, ru.k1, ru.k0), __builtin_fmaf(obf.y, 4.2145f, -1048575.9f));
+        t.x = r0 ? u0 : t.x;
+        t.y = r1 ? u1 : t.y;
+        *bad |= ((r0 && obf.x > ru.ob_max) || (r1 && obf.y > ru.ob_max)) ? 0x80000000u : 0u;
+    }
     float tsum; /* (kept scalar: the vectoriser pairs it with the other column's sum through three v_mov) */
     __asm__("v_add_f32 %0, %1, %2" : "=v"(tsum) : "v"(t.x), "v"(t.y));
     acc += (double)tsum;
@@ -553,8 +574,13 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
         ((float4*)L.pzc)[threadIdx.x] = pz_v;
         if (threadIdx.x < (LDS_PZ + 2) % 4) L.pzc[(LDS_PZ + 2) / 4 * 4 + threadIdx.x] = pz_t;
     }
-    const bool ring = __any(ring_a != 0.0f || (doB && ring_b != 0.0f)); /* (every wave asks the same eight codes) */
-    const bool plain = fast && small && !ring; /* staged, no ring on either window: the pair loop */
+    const unsigned circA = (unsigned)__ballot(lane < NCODE && ring_a != 0.0f), circB = doB ? (unsigned)__ballot(lane < NCODE && ring_b != 0.0f) : 0u;
+    const bool ring = (circA | circB) != 0u; /* (every wave asks the same eight codes) */
+    /* a ring goes through the pair loop's second instance where it has an upper bound (zc_ub) and is not on the current genome's own
+     * column (k = 0 needs both bounds: void, the one-column routine says so); badA / badB: the columns are voided apart */
+    const float zc_ub_s = sc->zc_ub;
+    const bool ring_ok = zc_ub_s >= 0.0f && !(kA == 0 && circA) && !(ABL & (1024 | 2048 | 4096));
+    const bool plain = fast && small && (!ring || ring_ok); /* staged: the pair loop */
     if (ABL & 512) return; /* (probe: everything requested and staged, no barrier, no pass of either kind) */
     if (!plain) {
         if (ABL & 1024) return; /* (probe: the pairs that take the one-column routine leave) */
@@ -579,10 +605,36 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
     const char* pzb = (const char*)L.pzc;
     double accA = 0.0, accB = 0.0;
     float ymaxA = 0.0f, ymaxB = 0.0f, exA = 0.0f, exB = 0.0f, obs = 0.0f;
-    unsigned bad = 0;
+    unsigned bad = 0, badA = 0, badB = 0;
     f32x2 exsA = {0.0f, 0.0f}, exsB = {0.0f, 0.0f}, obs2 = {0.0f, 0.0f};
     unsigned s0 = wave * step;
     const unsigned nn = (ABL & 8) ? 0u : (unsigned)n; /* (probe bit 3: no entries at all -- what a workgroup costs before and after its loop) */
+    /* the ring pairs' bound, linear in the count while 0.434 ob <= d_max (screen_term: em = max(d_max, 0.434 ob)) */
+    const float lem_s = __builtin_amdgcn_logf(fmaxf(d_max, 1e-30f)) * c10;
+    const RingUb ruA{circA, lem_s + 1e-5f * fabsf(lem_s), zc_ub_s - d_max + 1e-5f * d_max, d_max * 2.3f},
+                 ruB{circB, lem_s + 1e-5f * fabsf(lem_s), zc_ub_s - d_max + 1e-5f * d_max, d_max * 2.3f};
+    if (ring && threadIdx.x == 0) { /* (every segment's workgroup: an empty one left before) */
+        if (circA) atomicOr(&scr_ub[cw], 1u << kA);
+        if (circB) atomicOr(&scr_ub[cw], 1u << kB);
+    }
+    if (ring) { /* the same pass, the ring pairs' upper bounds selected in (a second instance of the loop: the common one stays as it is) */
+        for (; s0 + step <= nn; s0 += stride) {
+            ptr += stride;
+#pragma unroll
+            for (int u = 0; u < SCREEN_BATCH; u += 2) {
+                const unsigned lo0 = (unsigned)nx[u], hi0 = (unsigned)(nx[u] >> 32), lo1 = (unsigned)nx[u + 1], hi1 = (unsigned)(nx[u + 1] >> 32);
+                bad |= hi0 | hi1;
+                const unsigned oi0 = (lo0 << 3) & 0x7ffff8u, oj0 = __builtin_amdgcn_alignbit(hi0, lo0, 17) & 0x7ffff8u;
+                const unsigned oi1 = (lo1 << 3) & 0x7ffff8u, oj1 = __builtin_amdgcn_alignbit(hi1, lo1, 17) & 0x7ffff8u;
+                const f32x2 obf = {(float)(hi0 >> 8), (float)(hi1 >> 8)};
+                nx[u] = ptr[u * 64];
+                nx[u + 1] = ptr[(u + 1) * 64];
+                obs2 += obf;
+                screen_pair_col<0, true>(oi0, oj0, oi1, oj1, obf, colA, pzb, slope, la, lv, d_max, c10, accA, exsA, ymaxA, ruA, &badA);
+                screen_pair_col<0, true>(oi0, oj0, oi1, oj1, obf, colBb, pzb, slope, la, lv, d_max, c10, accB, exsB, ymaxB, ruB, &badB);
+            }
+        }
+    }
     for (; s0 + step <= nn; s0 += stride) { /* full steps: both columns from one pass over the entries */
         ptr += stride;
 #pragma unroll
@@ -613,7 +665,8 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
         for (int u = 0; u < SCREEN_BATCH; u++) {
             const bool live = s0 + u * 64 + lane < nn;
             const unsigned long long e = live ? nx[u] : safe;
-            screen_term<true, false, true, false, true>(e, live, nullptr, L, slope, la, lv, d_max, c10, 0xffffffffu, accA, exA, obs, ymaxA, bad);
+            if (ring) screen_term<true, false, true, true, true>(e, live, nullptr, L, slope, la, lv, d_max, c10, 0xffffffffu, accA, exA, obs, ymaxA, bad, circA, zc_ub_s);
+            else screen_term<true, false, true, false, true>(e, live, nullptr, L, slope, la, lv, d_max, c10, 0xffffffffu, accA, exA, obs, ymaxA, bad);
             /* column B: the same routine on a view of the block whose col[] is column B */
             {
                 const unsigned lo = (unsigned)e, hi = (unsigned)(e >> 32);
@@ -629,7 +682,15 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
                 __asm__("v_max_f32 %0, %1, %2" : "=v"(ymx) : "v"(y), "v"(lv));
                 const float yy = in ? ymx : lv;
                 const float ex = __builtin_amdgcn_exp2f(yy);
-                const float t = __builtin_fmaf((float)(hi >> 8) * yy, c10, -ex) + pzc;
+                float t = __builtin_fmaf((float)(hi >> 8) * yy, c10, -ex) + pzc;
+                if (ring && cis && ((circB >> (ai.y >> 28)) & 1u)) { /* (screen_term's bound, as column A's masked step takes it) */
+                    const float obf1 = (float)(hi >> 8);
+                    const float em = fmaxf(d_max, 0.43429448f * obf1);
+                    const float lem = __builtin_amdgcn_logf(em) * c10;
+                    const float ub0 = __builtin_fmaf(obf1, lem, -em) + zc_ub_s + 1e-5f * (obf1 * fabsf(lem) + em);
+                    const float lgf_ub = obf1 * __builtin_amdgcn_logf(fmaxf(obf1, 1.0f)) * c10 * 1.00001f + 1e-3f;
+                    t = fmaxf(ub0, -1048576.0f + lgf_ub);
+                }
                 accB += (double)(live ? t : 0.0f);
                 exB += live ? ex : 0.0f;
                 const float yya = live ? yy : 0.0f;
@@ -648,6 +709,8 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
         ymaxA = fmaxf(ymaxA, __shfl_down(ymaxA, o, 64));
         ymaxB = fmaxf(ymaxB, __shfl_down(ymaxB, o, 64));
         bad |= __shfl_down(bad, o, 64);
+        badA |= __shfl_down(badA, o, 64);
+        badB |= __shfl_down(badB, o, 64);
     }
     if (lane == 0) {
         L.red_s[wave] = accA;
@@ -655,6 +718,7 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
         L.red_o[wave] = obs;
         L.red_y[wave] = ymaxA;
         L.red_bad[wave] = bad;
+        L2.red_void[wave] = (badA >> 31) | ((badB >> 31) << 1);
         L2.red_s2[wave] = accB;
         L2.red_e2[wave] = exB;
         L2.red_y2[wave] = ymaxB;
@@ -671,6 +735,7 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
             Y = __builtin_fmax(Y, (double)(isB ? L2.red_y2[v] : L.red_y[v]));
             B |= L.red_bad[v];
         }
+        for (int v = 0; v < SCORE_THREADS / 64; v++) B |= ((L2.red_void[v] >> (isB ? 1 : 0)) & 1u) ? 0x80000000u : 0u;
         screen_publish(sc, scr, scr_void, cw, isB ? kB : kA, n, S, E, O, Y, B);
     }
 }
