@@ -182,6 +182,8 @@ struct MoveBuf {
     unsigned* scr_void;    /* [..] bit k */
     unsigned* scr_ub;      /* [..] bit k: the screened sum is an upper bound only (a ring on the window) */
     unsigned* cont;        /* [..] bit k: column k can still win (k_contend) */
+    unsigned* livecol;     /* [..] bit k: column k's genome differs from the current genome on the window (k_mutate: the screening kernel pairs
+                            * the live columns; from the mutation slots' changed flags it took a dependent round of loads per workgroup) */
     unsigned* ident;       /* [..] bit k: column k's genome IS the current genome on the window (its sums are column 0's: neither
                             * screened nor scored) */
     /* two-tier scoring: the exact kernel's work list of a batch: eight interleaved sub-lists (k_contend), work[0..8) = their

@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(256)
         mb.scr_ub[CW(w, t)] = 0;
         mb.cont[CW(w, t)] = 0xffffffffu;
         mb.ident[CW(w, t)] = 0;
+        mb.livecol[CW(w, t)] = 0;
         mb.tail_n[CW(w, t)] = -1; /* new windows: the Q5 tail has to be found again */
     }
     if (t < C) {
@@ -303,7 +304,10 @@ __device__ __forceinline__ void mutate_one(const State& st, const Tables& tab, c
         if ((threadIdx.x & 63) == 0 && hd) atomicAdd(&sh_hd, hd);
         if (ch) atomicOr(&sh_ch, 1);
         __syncthreads();
-        if (threadIdx.x == 0) mb.sinfo[cw * NSLOT + slot] = make_int2(sh_ch, sh_hd);
+        if (threadIdx.x == 0) {
+            mb.sinfo[cw * NSLOT + slot] = make_int2(sh_ch, sh_hd);
+            if (sh_ch && k > 0) atomicOr(&mb.livecol[cw], 1u << k); /* (by column: what the screening kernel pairs) */
+        }
     }
     /* ---- coordinate column k (fill_vect_dist, KA:3699-3760) + zero-pixel sums on the window */
     const ig_params p = g->par[0];

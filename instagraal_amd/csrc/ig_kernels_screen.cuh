@@ -522,7 +522,7 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
     const CandMeta* mp = &mb.meta[cw];
     const int C = mb.ctl[w].C;
     const int n_uniq = mp->n_uniq, m_loc = mp->m_loc;
-    const int uq = (lane >= 1 && lane <= IG_N_TMP_STRUCT) ? mp->uniq[lane - 1] : 0; /* lane q: column q's mutation slot */
+    const unsigned livecol = mb.livecol[cw]; /* bit k: column k's genome differs from the current one (k_mutate) */
     long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + seg];
     long long off = mb.sloff[(size_t)cw * SLICE_SEG + seg];
     if (off >= 0) screen_chunk(n, off, q, Q);
@@ -536,9 +536,9 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
     }
     if (c >= C || 2 * ypair > n_uniq || n == 0 || off < 0) return;
     if (ABL & 16) return; /* (probe: dispatch and the first round of loads only) */
-    /* second round: which columns are live (uniq entries past n_uniq are stale: index clamped, value unused) */
-    const int chg = (lane >= 1 && (int)lane <= n_uniq) ? mb.sinfo[cw * NSLOT + min(max(uq, 0), NSLOT - 1)].x : 0;
-    const unsigned live = (unsigned)__ballot(lane == 0 || ((int)lane <= n_uniq && chg != 0)); /* (every wave asks the same) */
+    /* which columns are live: column 0 and the changed ones (one word from k_mutate; until round 4 the changed flags of the
+     * mutation slots behind the uniq list: a dependent round of loads in front of the columns) */
+    const unsigned live = 1u | (livecol & (n_uniq >= 31 ? 0xfffffffeu : ((2u << n_uniq) - 2u)));
     const int n_live = __popc(live);
     if (2 * ypair >= n_live) return;
     unsigned rest = live;
