@@ -302,7 +302,7 @@ def main():
             nuis = {"moves_per_s": rate, "accept_rate": acc, "moves": a.nuisance_moves, "loop": how, **extra,
                     "regime": "the first %d (move, step) pairs behind the timed moves: large proposals, decisive tests" % a.nuisance_moves}
             if a.nuisance_settle > 0:
-                n_set = 4 * a.nuisance_moves
+                n_set = 16 * a.nuisance_moves  # (2 400 pairs: a 600-pair sample read 15.5 - 17.3 k from run to run)
                 rate2, acc2, _, extra2 = nuisance_rate(s, prob, n_set, a.neighbours, settle=a.nuisance_settle)
                 nuis["settled"] = {"moves_per_s": rate2, "accept_rate": acc2, "moves": n_set, "after_steps": a.nuisance_moves + 10 + a.nuisance_settle, **extra2,
                                    "regime": "behind %d more (move, step) pairs: where a run spends its 95 cycles" % a.nuisance_settle}

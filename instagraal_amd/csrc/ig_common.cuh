@@ -327,7 +327,6 @@ struct ig_ctx {
     unsigned* probe_void;
     struct NuisWorker* worker; /* the helper thread that enqueues a run's next step (ig_hip.hip) */
     bool last_moved;   /* the move of the step just ended changed the genome (or nobody said it did not) */
-    bool spec_changed; /* a move decided from the batch in the buffers has changed the genome */
     long long n_accepts;
     NuisHist nh;
     long long* scratch_hist; /* k_hist_eval's 8 output words (zero between two launches) */
