@@ -498,6 +498,8 @@ class sampler:  # noqa: N801 - the reference's class name
         prof = self.nuis_profile = dict(propose=0.0, step=0.0, book=0.0, chain=0.0)
         trace = getattr(self, "nuis_step_trace", None)  # a list: (seconds, accepted) per plain step (tools/nuisance_rate.py)
         use_chain = hip_lib.nuis_chain_wanted()
+        if not hasattr(self, "_nuis_acc_ema"):
+            self._nuis_acc_ema = 0.0  # share of the recent steps that were accepted (kept from run to run)
         names = PARAM_NAMES
         curr = np.copy(self.param_simu)
         self._sigmas(curr)
@@ -540,16 +542,17 @@ class sampler:  # noqa: N801 - the reference's class name
             if deferred:
                 patch = (i, z)
 
-        def pairs_pipelined(i0):
-            """steps i0 .. n - 1, one pair per library call with the next step begun inside the call that ends this one (the loop of
-            rounds 2 - 3: where chains are off or the histogram tier is not in use): while the GPU works on step i the proposal of
-            step i + 1 for the case that this one is rejected is worked out; the one for the other case only if it comes to that"""
+        def pairs_pipelined(i0, i1):
+            """steps i0 .. i1 - 1, one pair per library call with the next step begun inside the call that ends this one (the loop of
+            rounds 2 - 3: where chains are off, the histogram tier is not in use, or every third step is accepted -- a chain only ever
+            rejects): while the GPU works on step i the proposal of step i + 1 for the case that this one is rejected is worked out;
+            the one for the other case only if it comes to that"""
             nonlocal patch
             p8 = prop(i0)
             self.ctx.nuis_step_begin(i0, p8, mean_kb)
-            for i in range(i0, n):
+            for i in range(i0, i1):
                 ta = _t.perf_counter()
-                has_next = i + 1 < n
+                has_next = i + 1 < i1
                 nxt = prop(i + 1) if has_next else None
                 if patch is not None:  # (the exact pass of the step accepted last ran behind its decision: done by now)
                     fill_in()
@@ -576,6 +579,7 @@ class sampler:  # noqa: N801 - the reference's class name
                 success_of[i] = success
                 self.likelihood_nuis = lik_nuis
                 last_test[0] = p8
+                self._nuis_acc_ema = 0.9 * self._nuis_acc_ema + 0.1 * float(success)
                 if has_next:
                     if not began:
                         self.ctx.nuis_step_begin(i + 1, nxt, mean_kb)
@@ -593,9 +597,15 @@ class sampler:  # noqa: N801 - the reference's class name
         LOOK = 2 * hip_lib.CHAIN_MAX
         try:
             if not use_chain:
-                pairs_pipelined(0)
+                pairs_pipelined(0, n)
                 i = n
             while i < n:
+                if self._nuis_acc_ema > 0.3:  # (the first steps of a run's first nuisance cycle: a third of the proposals accepted)
+                    i1 = min(n, i + 16)
+                    pairs_pipelined(i, i1)
+                    i = i1
+                    try_chain = False
+                    continue
                 if use_chain and try_chain:
                     ta = _t.perf_counter()
                     ready = 0  # proposals in hand from step i on
@@ -611,6 +621,7 @@ class sampler:  # noqa: N801 - the reference's class name
                             prop(t)
                         t += 1
                     j, reason = self.ctx.nuis_chain_end()
+                    self._nuis_acc_ema *= 0.9 ** j
                     ep_of[i:i + j] = len(epochs) - 1
                     i += j
                     prof["chain"] += _t.perf_counter() - ta
@@ -619,7 +630,7 @@ class sampler:  # noqa: N801 - the reference's class name
                     if i >= n:
                         break
                     if reason == 6:  # the histogram tier is not in use: one pair per call from here on
-                        pairs_pipelined(i)
+                        pairs_pipelined(i, n)
                         i = n
                         break
                 # ---- one pair the plain way
@@ -652,6 +663,7 @@ class sampler:  # noqa: N801 - the reference's class name
                 success_of[i] = success
                 self.likelihood_nuis = lik_nuis
                 last_test[0] = p8
+                self._nuis_acc_ema = 0.9 * self._nuis_acc_ema + 0.1 * float(success)
                 try_chain = rescored or not success  # (accepted by the arithmetic here: the slots ahead are void, a plain pair scores them)
                 i += 1
                 t3 = _t.perf_counter()
