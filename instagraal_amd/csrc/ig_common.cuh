@@ -207,6 +207,9 @@ struct MoveBuf {
     int* tail_n;
     int* tail_ent;
     int N, M, capC, capW;
+    int nseg; /* list segments of the batch in the buffers: 8, or 16 = SLICE_SEG where a batch is a few slots with long lists (few long
+               * contigs, late in an assembly: the screening launch needs its workgroups -- bigctg 5.9 -> 6.3 k moves/s); set by the
+               * host with the structural half of a scoring (enqueue_score), a power of two */
     /* strides of the per-window arrays above (Lloc .. loc: sN fragments, subs / rowcnt / coords: sM sub-fragments): the
      * largest window the genome can produce right now -- two contigs of the current maximum length, with headroom -- not
      * the whole genome; the host grows them when the maximum grows (ensure_window_buffers) */
@@ -215,9 +218,9 @@ struct MoveBuf {
 /* layout of MoveBuf.part per candidate (int64 units) */
 #define P_NZ 0                 /* [NSLOT][2] slice sums per column k (k=0: current = "extract") */
 #ifndef SLICE_SEG
-#define SLICE_SEG 8 /* 16 until round 3: the screening kernel's workgroups (one per segment, pair of columns and candidate) live as long
+#define SLICE_SEG 16 /* the MOST segments (array strides); a batch uses MoveBuf.nseg of them: 8 (16 until round 3: the screening kernel's workgroups (one per segment, pair of columns and candidate) live as long
                      * around their pass as in it (tools/screen_probe.py); 32 / 16 / 8 / 4 / 2 segments: k_screen 264 / 197 / 168 / 164 / 242 us,
-                     * 36.9 / 41.3 / 43.3 / 42.6 / 36.0 k moves/s (fewer append cursors cost k_slice) */
+                     * 36.9 / 41.3 / 43.3 / 42.6 / 36.0 k moves/s (fewer append cursors cost k_slice)) */
 #endif
 #define P_CNT (NSLOT * 2)      /* [SLICE_SEG] kept entries per segment; S_c = their sum (slice_total) */
 #define P_STRIDE (NSLOT * 2 + SLICE_SEG)

@@ -347,7 +347,7 @@ __device__ __forceinline__ void mutate_one(const State& st, const Tables& tab, c
                 mb.rowcnt[(size_t)cw * M + ls] = 0; /* k_slice adds the kept contacts of the row (several waves per row) */
                 /* upper bound of the slice segment this row appends to; the row's range for k_slice */
                 const long long rb = rowptr[s], re = rowptr[s + 1];
-                atomicAdd((unsigned long long*)&seg_bound[ls % SLICE_SEG], (unsigned long long)(re - rb));
+                atomicAdd((unsigned long long*)&seg_bound[ls & (mb.nseg - 1)], (unsigned long long)(re - rb));
                 mb.rowbe[(size_t)cw * M + ls] = make_int4((int)(unsigned)rb, (int)(rb >> 32), (int)(re - rb), s);
             }
             if (npos == 0) ni += ((long long)SLc * (long long)(SLc - 1)) / 2;
@@ -595,7 +595,7 @@ __global__ void __launch_bounds__(256, SLICE_MIN_WAVES) k_slice(const long long*
     const int J = min(max_j, max(1, nrw / max(n_rows, 1)));
     for (int item = blockIdx.x * 4 + wv; item < n_rows * J; item += nrw) {
         const int r = row_lo + item % n_rows, j = item / n_rows;
-        const int seg = r % SLICE_SEG;
+        const int seg = r & (mb.nseg - 1);
         /* the row's range, written by k_mutate next to the window's sub-fragment list: ONE round trip in front of the contacts;
          * its (contig, rank) follows from its place in the window (A's sub-fragments first, by rank, then B's) */
         const int4 be = rowbe[r];

@@ -748,7 +748,7 @@ __global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
              int max_c, int w_begin, int use_order, int Q)
 {
     __shared__ ScreenLds2 L2;
-    screen_block<ABL>(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, blockIdx.x % SLICE_SEG, blockIdx.y, blockIdx.z, L2, use_order, blockIdx.x / SLICE_SEG, Q);
+    screen_block<ABL>(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, blockIdx.x % mb.nseg, blockIdx.y, blockIdx.z, L2, use_order, blockIdx.x / mb.nseg, Q);
 }
 
 /* k_screen and k_tail in ONE launch.  The Q5 tail walk (prefinal_tail: one workgroup per candidate, a chain of dependent
@@ -770,9 +770,9 @@ __global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
         prefinal_tail(rowptr, cc, tab, g, mb, lgf_tab, tail_quirk, pz, w_begin, b % max_c, b / max_c, *(TailLds*)lds_raw);
         return;
     }
-    const int s = b - n_tail, ny = (NSLOT + 1) / 2, nxq = SLICE_SEG * Q; /* x: segment fastest (block -> XCD), then the part of it */
-    screen_block(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, s % SLICE_SEG, (s / nxq) % ny, s / (nxq * ny), *(ScreenLds2*)lds_raw, use_order,
-                 (s % nxq) / SLICE_SEG, Q);
+    const int s = b - n_tail, ny = (NSLOT + 1) / 2, nseg = mb.nseg, nxq = nseg * Q; /* x: segment fastest (block -> XCD), then the part of it */
+    screen_block(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, s % nseg, (s / nxq) % ny, s / (nxq * ny), *(ScreenLds2*)lds_raw, use_order,
+                 (s % nxq) / nseg, Q);
 }
 
 /* k_contend: one workgroup per move slot.  From the screened sums, the exact zero-pixel sums and the exact tail sums: an
@@ -882,7 +882,7 @@ __global__ void __launch_bounds__(256) k_contend(Glob* g, MoveBuf mb, const Scre
          * host keeps grid_cap above twice that for the widest move (exact_grid_floor); should it ever not be, the loop ends at
          * whole segments, k_worklist flags the slot (overflow 2) and the host enlarges the grid) */
         long long ch = chunk0 > 0 ? chunk0 : EXACT_CHUNK;
-        while (ch < (1LL << 40) && tot / ch + (long long)C * NSLOT * SLICE_SEG > grid_cap / 2) ch *= 2;
+        while (ch < (1LL << 40) && tot / ch + (long long)C * NSLOT * mb.nseg > grid_cap / 2) ch *= 2;
         mb.ctl[w].exact_chunk = (int)ch;
         s_kind[0] = (int)ch; /* (the intervals are done with) */
     }
