@@ -594,17 +594,21 @@ class sampler:  # noqa: N801 - the reference's class name
         self.ctx.nuis_run_begin(frags, cands)
         i = 0
         try_chain = False  # (the first pair scores the first batch: the plain way)
+        empty = 0  # chains in a row that decided no pair (intervals that decide nothing: a void histogram tier, tests at the margin)
         LOOK = 2 * hip_lib.CHAIN_MAX
         try:
             if not use_chain:
                 pairs_pipelined(0, n)
                 i = n
             while i < n:
-                if self._nuis_acc_ema > 0.3:  # (the first steps of a run's first nuisance cycle: a third of the proposals accepted)
-                    i1 = min(n, i + 16)
+                if self._nuis_acc_ema > 0.3 or empty >= 4:
+                    # (the first steps of a run's first nuisance cycle: a third of the proposals accepted; or chains that get nowhere:
+                    # a chain only ever rejects, and only from a certain interval -- one pair per call for a while, then another try)
+                    i1 = min(n, i + (16 if empty < 4 else 32))
                     pairs_pipelined(i, i1)
                     i = i1
                     try_chain = False
+                    empty = min(empty, 3)
                     continue
                 if use_chain and try_chain:
                     ta = _t.perf_counter()
@@ -621,6 +625,7 @@ class sampler:  # noqa: N801 - the reference's class name
                             prop(t)
                         t += 1
                     j, reason = self.ctx.nuis_chain_end()
+                    empty = 0 if j else empty + 1
                     self._nuis_acc_ema *= 0.9 ** j
                     ep_of[i:i + j] = len(epochs) - 1
                     i += j

@@ -42,9 +42,13 @@ if os.environ.get("NUIS_LONG"):  # the rate as the chain settles: chunks of 600 
     for k in range(int(os.environ["NUIS_LONG"])):
         fr = np.random.permutation(prob.n_frags)[:CH]
         w0 = s.ctx.debug_nuis_wait()
+        clk = [(n_, getattr(time, n_)) for n_ in ("CLOCK_MONOTONIC", "CLOCK_BOOTTIME", "CLOCK_REALTIME", "CLOCK_MONOTONIC_RAW") if hasattr(time, n_)]
+        ns0 = [time.clock_gettime_ns(c_) for _, c_ in clk]
         t0 = time.perf_counter()
         res, tup = s.step_sampler_nuisance_batch(fr, 5, s.dt, 0, CH)
         dt = time.perf_counter() - t0
+        # (for tools/rocprof_stats.py: the chunk's window on whichever clock the tracer stamps its launches with)
+        print("CHUNK_WINDOW_NS %d " % k + " ".join("%d,%d" % (a_, time.clock_gettime_ns(c_)) for a_, (_, c_) in zip(ns0, clk)))
         tr = np.array(s.nuis_step_trace)
         s.nuis_step_trace.clear()
         if tr.size == 0:
