@@ -93,9 +93,12 @@ class BatchRunner:
     ``tensor_factory(kind, nbytes)`` (tests) returns the uint8 tensor standing for a record buffer; by default the
     device buffers of the context are wrapped without a copy."""
 
-    def __init__(self, ctx, rank, world, dist=None, width=None, tensor_factory=None):
+    def __init__(self, ctx, rank, world, dist=None, width=None, tensor_factory=None, exchange_alone=False):
+        """``exchange_alone`` (tests on a one-GPU rig): a world of ONE rank still runs its collective -- the one way to put the
+        record buffers through RCCL there (two ranks may not share a device)"""
         self.ctx, self.rank, self.world = ctx, rank, world
-        if dist is None and world > 1:
+        self._collective = world > 1 or bool(exchange_alone)
+        if dist is None and self._collective:
             import torch.distributed as dist
         self.dist = dist
         self.width = int(width) if width else max(24, 8 * world)
@@ -154,7 +157,7 @@ class BatchRunner:
             self.width = max(world, min(self.width, (fit // world) * world))
         per_max = -(-self.width // world)
         cap_slots = per_max * world  # the all-gather works on equal chunks
-        if self._tensor_factory is None and world > 1:
+        if self._tensor_factory is None and self._collective:
             # kernels and collectives must be ordered on ONE stream: a dedicated torch stream (its handle is not the
             # null stream, which ig_set_stream reads as "make your own") becomes the library's stream and, inside the
             # `with`, torch's current stream, which is what ProcessGroupNCCL orders its collectives against
@@ -170,7 +173,7 @@ class BatchRunner:
     def _run(self, frags, cands, n, cap_slots):
         world, rank = self.world, self.rank
         self.ctx.batch_upload(frags, cands, cap_slots)
-        if world > 1:
+        if self._collective:
             self._buffers(cap_slots)
         done = 0
         while done < n:
@@ -180,7 +183,7 @@ class BatchRunner:
             per = -(-w_now // world)
             b, e = min(rank * per, w_now), min((rank + 1) * per, w_now)
             self.ctx.batch_score(done, w_now, b, e)
-            if world > 1:
+            if self._collective:
                 self._exchange(per)
             got = self.ctx.batch_commit(done, w_now)
             if w_now == w_want:
