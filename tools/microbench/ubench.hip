@@ -122,6 +122,15 @@ __global__ void k_atomics(unsigned long long* tab, unsigned bins, int per, unsig
     }
 }
 
+// (4) a chain of dependent launches: a kernel of `wgs` workgroups that each spin for ~`ns` (s_memrealtime: 100 MHz), launched
+// back to back on one stream, and the same chain as the kernel nodes of a hipGraph (instantiated once, launched again and again)
+__global__ void k_spin(unsigned long long* out, int ticks)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(2);
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t0;
+}
+
 int main(int argc, char** argv)
 {
     const size_t mb = argc > 1 ? atoi(argv[1]) : 400;
@@ -194,6 +203,49 @@ int main(int argc, char** argv)
         atom("... a wave's bins within 256 words, 16 M adds", 2048, 256, 32, 256);
         atom("... a wave's bins within 16 words, 16 M adds", 2048, 256, 32, 16);
         atom("64-bit atomic add, 147 k bins, 64 k adds (64 x 256 x 4)", 64, 256, 4, 0);
+    }
+    // ---- (4) launch chains: stream against hipGraph
+    {
+        hipStream_t st;
+        CK(hipStreamCreate(&st));
+        unsigned long long* o2;
+        CK(hipMalloc(&o2, 64));
+        for (int wgs : {1, 2048}) {
+            for (int us : {5, 30}) {
+                const int n = 13, ticks = us * 100;
+                auto chain = [&] { for (int i = 0; i < n; i++) hipLaunchKernelGGL(k_spin, dim3(wgs), dim3(256), 0, st, o2, ticks); };
+                auto run_ms = [&](auto f) {
+                    hipEvent_t a, b;
+                    CK(hipEventCreate(&a));
+                    CK(hipEventCreate(&b));
+                    f();
+                    CK(hipStreamSynchronize(st));
+                    float best = 1e30f;
+                    for (int r = 0; r < 20; r++) {
+                        CK(hipEventRecord(a, st));
+                        f();
+                        CK(hipEventRecord(b, st));
+                        CK(hipEventSynchronize(b));
+                        float ms;
+                        CK(hipEventElapsedTime(&ms, a, b));
+                        best = ms < best ? ms : best;
+                    }
+                    return best;
+                };
+                const float ms_stream = run_ms(chain);
+                hipGraph_t gr;
+                hipGraphExec_t ge;
+                CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+                chain();
+                CK(hipStreamEndCapture(st, &gr));
+                CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+                const float ms_graph = run_ms([&] { CK(hipGraphLaunch(ge, st)); });
+                printf("13 dependent launches of %4d workgroups x %2d us: stream %7.1f us (%.1f us per launch beyond its work), hipGraph %7.1f us (%.1f)\n", wgs,
+                       us, ms_stream * 1e3, (ms_stream * 1e3 - n * us) / n, ms_graph * 1e3, (ms_graph * 1e3 - n * us) / n);
+                CK(hipGraphExecDestroy(ge));
+                CK(hipGraphDestroy(gr));
+            }
+        }
     }
     return 0;
 }
