@@ -505,11 +505,13 @@ class sampler:  # noqa: N801 - the reference's class name
         self._sigmas(curr)
         e8 = self._epoch8(curr)
         props = {}  # step -> the eight float32 test parameters of its proposal: valid while `curr` stands
+        P = np.empty((n, 8), np.float32)  # ... and row i of it: a chain call hands over rows i .. i + K - 1 as they lie
 
         def prop(i):
             q = props.get(i)
             if q is None:
                 q = props[i] = self._propose8(e8, id_modif_l[i], gauss_l[i])
+                P[i] = q
             return q
 
         def as_array(p8):
@@ -617,8 +619,9 @@ class sampler:  # noqa: N801 - the reference's class name
                     while ready < _KCAP and (i + ready) in props:
                         ready += 1
                     K = min(n - i, max(8, ready))
-                    p_tests = np.array([prop(t) for t in range(i, i + K)], np.float32)
-                    self.ctx.nuis_chain_begin(i, p_tests, unif[i:i + K], temps[i:i + K], mean_kb)
+                    for t in range(i + ready, i + K):
+                        prop(t)
+                    self.ctx.nuis_chain_begin(i, P[i:i + K], unif[i:i + K], temps[i:i + K], mean_kb)
                     t = i + K
                     lim = min(n, i + K + LOOK)
                     while t < lim and not self.ctx.nuis_chain_done():  # the proposals of the steps behind, while the device works
