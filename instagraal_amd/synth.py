@@ -255,6 +255,10 @@ def make_problem(n_frags, n_contacts, seed=DEFAULT_SEED, mean_contig_len=50, cis
 
     # ---- trans: uniform distinct pairs in different contigs
     n_trans = Z - n_cis
+    n_trans_avail = (M * (M - 1) - int((n_sub_of_contig.astype(np.int64) * (n_sub_of_contig - 1)).sum())) // 2  # pairs across contigs
+    if n_trans > 0.6 * n_trans_avail:  # (the rejection loop below would crawl, or never end)
+        raise ValueError("make_problem: %d contacts asked for, %d cis pairs and %d trans pairs exist (at most 60 %% of the trans pairs are drawn)"
+                         % (Z, n_avail, n_trans_avail))
     tkeys = np.zeros(0, dtype=np.int64)
     while tkeys.size < n_trans:
         need = int((n_trans - tkeys.size) * 1.1) + 1024

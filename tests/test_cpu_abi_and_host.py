@@ -345,3 +345,13 @@ def test_fast_proposals_equal_the_reference_shaped_ones():
                 assert np.array([got], dtype=PARAM_DTYPE).tobytes() == want.tobytes(), (m, g, got, want)
                 n += 1
     assert n == 900
+
+
+def test_synth_refuses_contact_counts_that_do_not_exist():
+    """make_problem draws distinct pairs: more contacts than the sub-fragments have pairs used to loop for ever in the trans draw
+    (found by tools/fuzz_batches.py: 60 bins / 24 000 contacts); it says so now"""
+    from instagraal_amd import synth
+
+    with pytest.raises(ValueError, match="trans pairs exist"):
+        synth.make_problem(60, 24000, 1, 20, cis_frac=0.3)
+    assert synth.make_problem(60, 600, 1, 20, cis_frac=0.3).n_contacts == 600

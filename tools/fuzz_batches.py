@@ -1,0 +1,141 @@
+"""Randomised comparison of the structural moves' code paths on one MI355X (no oracle: HIP against HIP, byte for byte).
+
+For a stream of seeded random problems (bins, contacts per bin, contig lengths, cis share, count scale, neighbours per move) and P(s)
+parameters (the synthetic defaults, a settled chain's, random slopes / d_max) the same run of moves goes
+
+    A  through speculative batches of 24 slots, two-tier scoring, the fused decide + apply launch      (the default)
+    B  one move per call through the exact kernel on every column                                      (step_sampler)
+    C  batches with every column through the exact kernel                                              (IG_SCREEN=0)
+    D  batches of another width (2 .. 40 slots), 12-byte list entries now and then                     (ig_set_batch_width, IG_WIDE_LISTS)
+    E  batches with the zero-score fault injection                                                     (ig_debug_set_zero_inject)
+
+and must return the same move records and genome; the maintained exact sums must equal a from-scratch pass in every run.
+
+    python tools/fuzz_batches.py [cases] [first seed]
+"""
+import os
+import sys
+import time
+import warnings
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+import numpy as np
+
+warnings.filterwarnings("ignore", category=RuntimeWarning)
+from instagraal_amd import hip_lib, synth
+from instagraal_amd.sampler import sampler as hip_sampler
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+COLS = ["o", "dist", "op_sampled", "id_f_sampled", "mean_len", "n_contigs"]
+
+
+def make_case(seed):
+    r = np.random.RandomState(seed)
+    n_frags = int(r.choice([60, 150, 300, 700, 1500, 4000, 9000]))
+    per = int(r.choice([8, 30, 100, 400]))
+    per = max(8, min(per, 1200000 // n_frags, n_frags))  # (3 n sub-fragments: at most a fifth of their pairs hold a contact)
+    mean_len = int(r.choice([2, 4, 15, 50, 200, 1000]))
+    mean_len = min(mean_len, max(2, n_frags // 3))
+    prob = synth.make_problem(n_frags, n_frags * per, 5000 + seed, mean_len, cis_frac=float(r.choice([0.3, 0.6, 0.8, 0.95])))
+    scale = int(r.choice([1, 1, 1, 9, 60]))
+    if scale > 1:
+        import copy
+
+        import scipy.sparse as sp
+        prob = copy.deepcopy(prob)
+        cnt = prob.coo_cnt.copy()
+        cnt[::3] *= scale
+        prob.coo_cnt = cnt
+        M = prob.n_sub_frags
+        prob.sub_csr = sp.csr_matrix((cnt, (prob.coo_row, prob.coo_col)), shape=(M, M), dtype=np.int32)
+        prob.sub_csr.sort_indices()
+    kind = int(r.choice([0, 0, 1, 2, 2]))
+    params = dict(prob.params)
+    if kind == 1:
+        params = synth.settled_params(prob.params)
+    elif kind == 2:
+        slope = -float(r.uniform(0.3, 2.2))
+        kuhn, lm = float(prob.params["kuhn"]), float(prob.params["lm"])
+        params = dict(prob.params, slope=slope, c1=float(np.float32((0.53 * np.power(lm / kuhn, slope)) * np.power(kuhn, -3))),
+                      d_max=float(prob.params["d_max"]) * float(r.choice([0.3, 1.0, 30.0, 3000.0])),
+                      v_inter=float(prob.params["v_inter"]) * float(r.choice([0.1, 1.0, 10.0])))
+    n = int(r.choice([100, 250, 500]))
+    width = int(r.choice([2, 3, 7, 16, 31, 40]))
+    wide = int(r.randint(4) == 0)
+    inject = int(r.choice([3, 11]))
+    n_nb = int(r.choice([1, 3, 5, 5, 9]))
+    return prob, params, n, width, wide, inject, n_nb, dict(n_frags=n_frags, per=per, mean_len=mean_len, scale=scale, params=kind, n=n, width=width,
+                                                           wide=wide, inject=inject, neighbours=n_nb)
+
+
+def run(prob, params, n, n_nb, seed, mode, width=0, wide=0, inject=0):
+    os.environ.pop("IG_SCREEN", None)
+    os.environ.pop("IG_WIDE_LISTS", None)
+    if mode == "C":
+        os.environ["IG_SCREEN"] = "0"
+    if wide:
+        os.environ["IG_WIDE_LISTS"] = "1"
+    hip_lib.set_batch_width(width if width else 24)
+    hip_lib.debug_set_zero_inject(inject)
+    try:
+        np.random.seed(seed)
+        s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
+        s.set_param_simu(params)
+        s.eval_likelihood_init()
+        frags = np.resize(np.random.permutation(prob.n_frags), n).astype(np.int32)
+        if mode == "B":
+            rows = []
+            for f in frags:
+                o, dist, op, idf, ml, nc = s.step_sampler(int(f), n_nb)
+                rows.append((float(o), float(dist), int(op), int(idf), float(ml), int(nc)))
+            rec = repr(rows)
+        else:
+            res = s.step_sampler_batch(frags, n_nb)
+            rec = repr([(float(q["o"]), float(q["dist"]), int(q["op_sampled"]), int(q["id_f_sampled"]), float(np.float32(q["mean_len"])), int(q["n_contigs"]))
+                        for q in res])
+        sums, _ = s.ctx.debug_globals()
+        _, _, limbs = s.ctx.full_likelihood(0)
+        assert [int(x) for x in sums[:5]] == [int(x) for x in limbs[:5]], "maintained sums != from-scratch pass (%s)" % mode
+        out = (rec, s.gpu_vect_frags.copy_from_gpu().soa17().tobytes(), np.random.get_state()[1][:8].tobytes())
+        st = dict(s.ctx.batch_stats(), zero_fallbacks=s.ctx.debug_zero_fallbacks())
+        sc = s.ctx.debug_screen_stats() if mode == "A" else None
+        s.free_gpu()
+        return out, st, sc
+    finally:
+        os.environ.pop("IG_SCREEN", None)
+        os.environ.pop("IG_WIDE_LISTS", None)
+        hip_lib.set_batch_width(24)
+        hip_lib.debug_set_zero_inject(0)
+
+
+bad = 0
+t00 = time.time()
+for k in range(n_cases):
+    seed = seed0 + k
+    prob, params, n, width, wide, inject, n_nb, desc = make_case(seed)
+    t0 = time.time()
+    try:
+        a, sa, sc = run(prob, params, n, n_nb, seed, "A")
+        b, _, _ = run(prob, params, n, n_nb, seed, "B")
+        d, sd, _ = run(prob, params, n, n_nb, seed, "D", width=width, wide=wide)
+        ok = a == b and d == b
+        extra = ""
+        if k % 2 == 0:
+            c, _, _ = run(prob, params, n, n_nb, seed, "C")
+            ok = ok and c == b
+            extra += " +exact"
+        if k % 2 == 1:
+            e, se, _ = run(prob, params, n, n_nb, seed, "E", inject=inject)
+            ok = ok and e == b and se["zero_fallbacks"] > 0
+            extra += " +inject(%d fallbacks)" % se["zero_fallbacks"]
+        which = "" if ok else " [A==B %s, D==B %s]" % (a == b, d == b)
+        print("case %4d %s %s: batches %d (width %d: %d), one-move tails %d, columns screened / exact %s  (%.1f s%s)%s" % (
+            seed, "ok  " if ok else "DIFF", desc, sa["batches"], width, sd["batches"], sa["one_move_tails"],
+            (sc[2], sc[3]) if sc else None, time.time() - t0, extra, which), flush=True)
+        bad += not ok
+    except Exception as ex:  # a failed library call is a finding as well
+        bad += 1
+        print("case %4d FAIL %s: %r" % (seed, desc, ex), flush=True)
+print("%d cases, %d bad, %.0f s" % (n_cases, bad, time.time() - t00))
+sys.exit(1 if bad else 0)

@@ -37,7 +37,7 @@ def make_case(seed):
     per = int(r.choice([15, 60, 150, 400]))
     mean_len = int(r.choice([4, 15, 50, 200, 1000]))
     mean_len = min(mean_len, max(4, n_frags // 3))
-    per = max(15, min(per, 1500000 // n_frags))  # (the host builds every problem: a few seconds at most)
+    per = max(15, min(per, 1500000 // n_frags, n_frags))  # (the host builds every problem: a few seconds at most; a fifth of the pairs at most)
     prob = synth.make_problem(n_frags, n_frags * per, 1000 + seed, mean_len)
     scale = int(r.choice([1, 1, 1, 7, 40]))
     if scale > 1:
