@@ -260,6 +260,10 @@ int ig_debug_nuis_hist_check(ig_ctx* ctx, int64_t* mismatches);
  * move of a two-tier batch takes that path (0 = off) -- and how often a handle has taken it */
 int ig_debug_set_zero_inject(int every);
 int ig_debug_zero_fallbacks(ig_ctx* ctx, int64_t* fallbacks);
+/* tests: moves of the one-move path (ig_step, ig_score_move, ig_apply, ig_step_begin, ig_step_batch at width 1, ig_nuis_begin) whose
+ * lists did not fit the slice pool and were repeated with a larger one -- the counterpart of the batch path's re-run slots
+ * (replaces nothing in the reference: its sort buffers are sized for the whole matrix, CL:1009-1069) */
+int ig_debug_pool_retries(ig_ctx* ctx, int64_t* n);
 int ig_debug_nuis_chain_stats(ig_ctx* ctx, int64_t out10[10]); /* chains: {calls, segments, pairs completed, ends by reason [7]} */
 int ig_debug_set_full_hist(int on); /* from-scratch pass: all-trans tiles from their count histograms (1, default) or contact by contact (0) */
 

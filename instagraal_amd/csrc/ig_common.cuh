@@ -94,6 +94,10 @@ struct Glob {
     int valid_insert[12];
     int error;
     int stamp_ctr;
+    int retry_pool; /* one-move path: the lists of a move did not fit the slice pool (k_offsets: MoveCtl.overflow) -- set by the chooser,
+                     * nothing is applied while it stands (every later one-move launch skips as well); the host grows the pool, clears it
+                     * and repeats the move (ig_move_result.pad = 1 tells it) */
+    int retry_pad;
     long long scr_cols, scr_cont; /* two-tier scoring: columns screened, columns scored exactly */
     long long scr_void_cols; /* columns whose screening bound was void */
     long long scr_terms, scr_terms_exact; /* ... and the (contact, column) terms in them */
@@ -400,6 +404,8 @@ struct ig_ctx {
     int bo_seq;
     int last_stop; /* what the last decided batch stopped at: 0 a conflict / its end, 1 the slice pool, 2 the exact kernel's grid, 3 a score of exactly 0.0 */
     bool exact_next; /* ... 3: the next scoring leaves the screening tier out (enqueue_score) */
+    int nuis_one_C; /* candidates of the move ig_nuis_begin enqueued (repeated by ig_nuis_end if its lists did not fit the pool) */
+    long long n_pool_retries; /* one-move path: moves repeated with a larger slice pool (retry_with_larger_pool; ig_debug_pool_retries) */
     /* chains (see ChainIn): per-set constants of a segment, the uploaded sets, the intervals, scratch words; statistics */
     struct ChainSet* chain_sets; /* [CHAIN_SEG] */
     ChainIn* chain_in;           /* [CHAIN_MAX] device */

@@ -121,6 +121,7 @@ __global__ void __launch_bounds__(256) k_scores(Glob* g, MoveBuf mb, int w)
     __shared__ double sc[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT];
     __shared__ int vf[12];
     if (threadIdx.x < 12) vf[threadIdx.x] = g->valid_insert[threadIdx.x];
+    if (threadIdx.x == 0 && mb.ctl[w].overflow) g->retry_pool = 1; /* (the scores below miss the lists that did not fit: nothing is applied) */
     __syncthreads();
     score_and_choose(g, mb, w, vf, sc);
     const int n = mb.ctl[w].C * IG_N_TMP_STRUCT;
@@ -131,6 +132,7 @@ __global__ void __launch_bounds__(256) k_scores(Glob* g, MoveBuf mb, int w)
 __global__ void k_force_choice(Glob* g, MoveBuf mb, int slot)
 {
     MoveCtl& mc = mb.ctl[0];
+    if (mc.overflow) g->retry_pool = 1;
     mc.ch_c = 0;
     mc.ch_slot = slot;
     mc.ch_k = mb.meta[0].kidx[slot];
@@ -223,7 +225,7 @@ __device__ void apply_winner(State st, Tables tab, Glob* g, const MoveBuf& mb, i
 
 __global__ void k_apply(State st, Tables tab, Glob* g, MoveBuf mb, int w, int forced, int* prev_touched)
 {
-    if (g->error) return;
+    if (g->error || g->retry_pool) return;
     apply_winner(st, tab, g, mb, w, forced, prev_touched, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, false);
 }
 
@@ -249,6 +251,12 @@ __device__ __forceinline__ void write_result(Glob* g, const MoveBuf& mb, int w, 
 
 __global__ void k_commit(Glob* g, MoveBuf mb, ig_move_result* res, int move, int w, int* dirty)
 {
+    if (g->retry_pool) { /* the move's lists did not fit the slice pool: nothing was applied, the host repeats it with a larger one */
+        g->credit2_acc = 0;
+        write_result(g, mb, w, res + move);
+        res[move].pad = 1;
+        return;
+    }
     /* dirty (a move of a batch finished with the one-move kernels, decided one move per call: ig_nuis_step_begin): its contigs
      * onto the batch's list of modified contigs, as k_decide_batch does for the moves it commits itself */
     if (dirty) {

@@ -1636,7 +1636,7 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     __shared__ long long red[2][SCORE_THREADS / 64];
     __shared__ int q_li[SCORE_THREADS / 64][128], q_lj[SCORE_THREADS / 64][128], q_ob[SCORE_THREADS / 64][128];
     MoveCtl& mc = mb.ctl[w];
-    if (g->error || (predicted == 1 ? mc.pred < 0 : (predicted == 0 && !mc.ch_windowed))) return;
+    if (g->error || (predicted == 0 && g->retry_pool) || (predicted == 1 ? mc.pred < 0 : (predicted == 0 && !mc.ch_windowed))) return;
     const int c = predicted == 1 ? mc.pred_c : mc.ch_c;
     const int cw = CW(w, c);
     const CandMeta& m = mb.meta[cw];

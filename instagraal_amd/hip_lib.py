@@ -480,6 +480,12 @@ class Context:
         _ck(lib().ig_debug_zero_fallbacks(self._h, C.byref(n)))
         return int(n.value)
 
+    def debug_pool_retries(self):
+        """moves of the one-move path repeated with a larger slice pool (their lists did not fit)"""
+        n = C.c_int64()
+        _ck(lib().ig_debug_pool_retries(self._h, C.byref(n)))
+        return int(n.value)
+
     def debug_nuis_hist_check(self):
         """words of the maintained histogram that differ from one built from scratch (-1: no histogram kept)"""
         n = C.c_int64()

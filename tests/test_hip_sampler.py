@@ -276,6 +276,82 @@ def test_slice_pool_overflow_reruns_the_slot(monkeypatch):
     assert outs[1][2] > outs[0][2]  # the small pool really cut batches short
 
 
+def test_slice_pool_overflow_on_the_one_move_path(monkeypatch):
+    """the same for the launches of ONE move (ig_step = step_sampler, ig_score_move, ig_step_batch at width 1, ig_step_begin /
+    ig_step_finish, ig_nuis_begin): a move whose lists do not fit the pool is not applied (the chooser raises a flag the apply kernels
+    honour), the host grows the pool and repeats it.  Until round 4 this path scored such a move without the lists that did not fit
+    (tools/fuzz_batches.py found it: nine candidates on contigs that hold a fifth of the contacts each)."""
+    from instagraal_amd import hip_lib, synth
+    from instagraal_amd.multi_gpu import ShardedRunner
+    from instagraal_amd.sampler import sampler as hip_sampler
+
+    prob = synth.make_problem(*synth.CONFIGS["small"])
+    np.random.seed(2)
+    frags = np.resize(np.random.permutation(prob.n_frags), 60).astype(np.int32)
+    cols = ["o", "dist", "op_sampled", "id_f_sampled", "n_contigs"]
+
+    class one_rank:  # (ShardedRunner's collective for a world of one)
+        class ReduceOp:
+            SUM = 0
+
+        @staticmethod
+        def all_reduce(t, op=None):
+            return None
+
+    outs = {}
+    for pool in (None, "1024"):
+        if pool:
+            monkeypatch.setenv("IG_POOL_ENTRIES", pool)
+
+        def fresh():
+            s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
+            s.set_param_simu(prob.params)
+            s.bins = np.arange(1.0, 60.0, 1.0)
+            s.eval_likelihood_init()
+            np.random.seed(3)
+            return s
+
+        got = {}
+        s = fresh()  # step_sampler, one call per move
+        got["step"] = [tuple(float(x) for x in s.step_sampler(int(f), 5)) for f in frags]
+        got["step_state"] = s.gpu_vect_frags.copy_from_gpu().soa17().tobytes()
+        got["retries_step"] = s.ctx.debug_pool_retries()
+        s.free_gpu()
+        s = fresh()  # ig_step_batch at width 1
+        hip_lib.set_batch_width(1)
+        try:
+            cands = s.draw_candidates(frags, 5)
+            got["w1"] = s.ctx.step_batch(frags, cands)[cols].tobytes()
+        finally:
+            hip_lib.set_batch_width(24)
+        got["retries_w1"] = s.ctx.debug_pool_retries()
+        s.free_gpu()
+        s = fresh()  # ig_score_move (scores only), then ig_step_begin / ig_step_finish
+        cands = s.draw_candidates(frags, 5)
+        c0 = [int(x) for x in cands[0] if x >= 0]
+        got["scores"] = s.ctx.score_move(int(frags[0]), c0).tobytes()
+        got["sharded"] = ShardedRunner(s.ctx, 0, 1, dist=one_rank, tensor_factory=lambda: None)._run(frags[:20], cands[:20])[cols].tobytes()
+        got["retries_sharded"] = s.ctx.debug_pool_retries()
+        s.free_gpu()
+        s = fresh()  # a move and the nuisance step behind it, one pair at a time (ig_nuis_begin / ig_nuis_end)
+        cands = s.draw_candidates(frags, 5)
+        p8 = np.array([float(s.param_simu[k][0]) for k in s.param_simu.dtype.names], np.float32)
+        tup = []
+        for f, cc in zip(frags[:20], cands[:20]):
+            s.ctx.nuis_begin(int(f), [int(x) for x in cc if x >= 0], p8, s.mean_kb())
+            r, nz, z = s.ctx.nuis_end()
+            tup.append((r.o, r.dist, r.op_sampled, r.id_f_sampled, r.n_contigs, nz, z))
+        got["nuis"] = repr(tup)
+        got["retries_nuis"] = s.ctx.debug_pool_retries()
+        s.free_gpu()
+        outs[pool] = got
+    a, b = outs[None], outs["1024"]
+    for k in ("step", "step_state", "w1", "scores", "sharded", "nuis"):
+        assert a[k] == b[k], k
+    assert a["retries_step"] == a["retries_w1"] == a["retries_sharded"] == 0
+    assert b["retries_step"] > 0 and b["retries_w1"] > 0 and b["retries_sharded"] > 0 and b["retries_nuis"] > 0
+
+
 def test_wide_slice_entries_equal_packed(monkeypatch):
     """slice entries are packed in 8 bytes when M < 2^20 and the counts are below 2^24, else kept as three ints: same results"""
     from instagraal_amd import synth

@@ -129,7 +129,16 @@ for k in range(n_cases):
             e, se, _ = run(prob, params, n, n_nb, seed, "E", inject=inject)
             ok = ok and e == b and se["zero_fallbacks"] > 0
             extra += " +inject(%d fallbacks)" % se["zero_fallbacks"]
-        which = "" if ok else " [A==B %s, D==B %s]" % (a == b, d == b)
+        which = ""
+        if not ok:
+            which = " [A==B %s, D==B %s, A==D %s]" % (a == b, d == b, a == d)
+            ra, rb = eval(a[0]), eval(b[0])
+            for i, (x, y) in enumerate(zip(ra, rb)):
+                if x != y:
+                    which += " first difference A / B at move %d: %r / %r" % (i, x, y)
+                    break
+            else:
+                which += " records equal; genome equal %s, generator equal %s" % (a[1] == b[1], a[2] == b[2])
         print("case %4d %s %s: batches %d (width %d: %d), one-move tails %d, columns screened / exact %s  (%.1f s%s)%s" % (
             seed, "ok  " if ok else "DIFF", desc, sa["batches"], width, sd["batches"], sa["one_move_tails"],
             (sc[2], sc[3]) if sc else None, time.time() - t0, extra, which), flush=True)
