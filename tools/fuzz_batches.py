@@ -64,7 +64,7 @@ def make_case(seed):
     width = int(r.choice([2, 3, 7, 16, 31, 40]))
     wide = int(r.randint(4) == 0)
     inject = int(r.choice([3, 11]))
-    n_nb = int(r.choice([1, 3, 5, 5, 9]))
+    n_nb = int(r.choice([1, 3, 5, 5, 9, 16]))
     return prob, params, n, width, wide, inject, n_nb, dict(n_frags=n_frags, per=per, mean_len=mean_len, scale=scale, params=kind, n=n, width=width,
                                                            wide=wide, inject=inject, neighbours=n_nb)
 
@@ -113,7 +113,11 @@ bad = 0
 t00 = time.time()
 for k in range(n_cases):
     seed = seed0 + k
-    prob, params, n, width, wide, inject, n_nb, desc = make_case(seed)
+    try:
+        prob, params, n, width, wide, inject, n_nb, desc = make_case(seed)
+    except ValueError as ex:  # (a shape the generator has no pairs for)
+        print("case %4d skipped: %s" % (seed, str(ex)[:80]), flush=True)
+        continue
     t0 = time.time()
     try:
         a, sa, sc = run(prob, params, n, n_nb, seed, "A")
@@ -144,6 +148,9 @@ for k in range(n_cases):
             (sc[2], sc[3]) if sc else None, time.time() - t0, extra, which), flush=True)
         bad += not ok
     except Exception as ex:  # a failed library call is a finding as well
+        if "needs 1.." in str(ex):  # the uniform fallback draw returned the focal bin alone: undefined in the reference (quirk Q13), refused here
+            print("case %4d skipped (a move without a candidate: quirk Q13) %s" % (seed, desc), flush=True)
+            continue
         bad += 1
         print("case %4d FAIL %s: %r" % (seed, desc, ex), flush=True)
 print("%d cases, %d bad, %.0f s" % (n_cases, bad, time.time() - t00))

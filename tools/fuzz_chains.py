@@ -121,7 +121,11 @@ t00 = time.time()
 tot_pairs = tot_chain = 0
 for k in range(n_cases):
     seed = seed0 + k
-    prob, params, scale, n, warm, temp, inject, desc = make_case(seed)
+    try:
+        prob, params, scale, n, warm, temp, inject, desc = make_case(seed)
+    except ValueError as ex:  # (a shape the generator has no pairs for)
+        print("case %4d skipped: %s" % (seed, str(ex)[:80]), flush=True)
+        continue
     t0 = time.time()
     try:
         a, sa = run(prob, params, scale, n, warm, temp, inject, seed, 1, "1", 1)
