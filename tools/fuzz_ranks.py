@@ -75,6 +75,10 @@ def make_case(seed):
     prob = synth.make_problem(n_frags, n_frags * per, 9000 + seed, mean_len, cis_frac=float(r.choice([0.3, 0.6, 0.8])))
     world = int(r.choice([2, 2, 3, 4, 8]))
     width = int(r.choice([world, 8, 10, 24, 40]))
+    if os.environ.get("FUZZ_WORLD"):  # (narrowing a finding down)
+        world = int(os.environ["FUZZ_WORLD"])
+    if os.environ.get("FUZZ_WIDTH"):
+        width = int(os.environ["FUZZ_WIDTH"])
     n_nb = int(r.choice([3, 5, 5, 9]))
     pool = int(r.choice([0, 0, 2000, 20000]))
     params = dict(prob.params) if r.randint(2) else synth.settled_params(prob.params)
