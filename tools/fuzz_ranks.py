@@ -99,7 +99,20 @@ def run_world(prob, params, world, frags, cands, make_runner):
     def work(rk):
         try:
             torch.cuda.set_device(0)
-            got[rk] = make_runner(samplers[rk].ctx, rk, InProcessDist(rk, world, barrier, parts)).run(frags, cands)
+            runner = make_runner(samplers[rk].ctx, rk, InProcessDist(rk, world, barrier, parts))
+            if os.environ.get("FUZZ_SERIAL"):  # (narrowing a finding down: one rank inside the library at a time, the device drained behind every call)
+                ctx = samplers[rk].ctx
+
+                def locked(f):
+                    def g(*a, **kw):
+                        with SERIAL:
+                            r_ = f(*a, **kw)
+                            torch.cuda.synchronize()
+                            return r_
+                    return g
+                for name in ("batch_upload", "batch_score", "batch_commit", "batch_results", "step_begin", "step_finish"):
+                    setattr(ctx, name, locked(getattr(ctx, name)))
+            got[rk] = runner.run(frags, cands)
         except Exception as e:
             errs.append(e)
             barrier.abort()
@@ -119,10 +132,11 @@ def run_world(prob, params, world, frags, cands, make_runner):
     return out
 
 
+SERIAL = threading.Lock()
 bad = 0
 t00 = time.time()
 for k in range(n_cases):
-    seed = seed0 + k
+    seed = seed0 + k // max(1, int(os.environ.get("FUZZ_REPEAT", "1")))  # (FUZZ_REPEAT=n: every case n times, for one-off failures)
     try:
         prob, params, world, width, n_nb, pool, desc = make_case(seed)
     except ValueError as ex:
