@@ -355,3 +355,19 @@ def test_synth_refuses_contact_counts_that_do_not_exist():
     with pytest.raises(ValueError, match="trans pairs exist"):
         synth.make_problem(60, 24000, 1, 20, cis_frac=0.3)
     assert synth.make_problem(60, 600, 1, 20, cis_frac=0.3).n_contacts == 600
+
+
+def test_the_librarys_fills_wait_for_themselves():
+    """hipMemset runs on the null stream and returns before the fill has happened; a caller's stream (ig_set_stream: torch's are
+    non-blocking) is not ordered behind it.  Every fill of the library's host code goes through memset_now (fill + wait) or is a
+    hipMemsetAsync on one of the library's streams -- no bare hipMemset besides the helper's own and the allocator's poison fill,
+    which waits for the device (tools/fuzz_ranks.py found the race with three and more emulated ranks on one GPU)."""
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "instagraal_amd", "csrc"))
+    bare = []
+    for name in sorted(os.listdir(root)):
+        if not name.endswith((".inc", ".hip", ".cuh", ".cpp")):
+            continue
+        for i, line in enumerate(open(os.path.join(root, name)), 1):
+            if re.search(r"=\s*hipMemset\s*\(|\(\s*hipMemset\s*\(", line):  # (a call, not the word in a message)
+                bare.append((name, i, line.strip()))
+    assert [b[0] for b in bare] == ["ig_host_core.inc", "ig_host_core.inc"], bare  # memset_now itself, and dalloc's poison fill (device synchronised)
