@@ -304,6 +304,21 @@ static void model_promote(void** a, dim3, dim3)
     }
 }
 
+/* k_commit (the one-move record writer; mangled "8k_commitP4Glob": the plain name is a substring of the batch kernels' names): a
+ * record with pad = 1 -- "the move's lists did not fit the slice pool, nothing was applied" -- as often as g_force_retry says; the
+ * host must grow the pool, clear the device's flag and repeat the move (retry_with_larger_pool) */
+static int g_force_retry = 0, g_retry_paths = 0;
+static void model_commit_one(void** a, dim3, dim3)
+{
+    ig_move_result* res = *(ig_move_result**)a[2];
+    const int move = *(int*)a[3];
+    std::memset(&res[move], 0, sizeof(ig_move_result));
+    if (g_force_retry > 0) {
+        res[move].pad = 1;
+        g_force_retry--;
+    }
+}
+
 int main()
 {
     setenv("IG_NUIS_SCREEN_NOCHECK", "1", 1); /* the models' screened and exact sums are unrelated numbers */
@@ -317,6 +332,7 @@ int main()
     fake_hip::set_model("k_hist_eval", model_hist_eval);
     fake_hip::set_model("k_full_nz_tiled", model_full_nz_tiled);
     fake_hip::set_model("k_nuis_promote", model_promote);
+    fake_hip::set_model("8k_commitP4Glob", model_commit_one);
 
     // ---- argument checks before anything is uploaded
     ig_ctx* c = nullptr;
@@ -387,6 +403,30 @@ int main()
                 if (k == 0) cands[(size_t)i * max_c] = (frags[i] + 1) % pr.N;
             }
             std::vector<ig_move_result> res(n_moves);
+            { // the one-move path's answer to a slice pool that is too small (the device's record says pad = 1): a larger pool, the
+              // move again -- while the pool is still small; at its worst case the same outcome is a legitimate error
+                int C0 = 0;
+                while (C0 < max_c && cands[C0] >= 0) C0++;
+                std::vector<double> sc0((size_t)max_c * IG_N_TMP_STRUCT);
+                int64_t r0 = 0, r1 = 0;
+                CHECK(ig_step(c, frags[0], cands.data(), C0, &one, sc0.data()) == 0); /* (allocates the move buffers) */
+                CHECK(ig_debug_pool_retries(c, &r0) == 0);
+                const bool room = (size_t)c->mb.pool_cap * 4 <= (size_t)std::max<long long>(c->Z, 1) * (size_t)std::max(c->mb.capC, 1);
+                g_force_retry = 1;
+                const int rc = ig_step(c, frags[0], cands.data(), C0, &one, sc0.data());
+                CHECK(g_force_retry == 0);
+                if (room) {
+                    g_retry_paths++;
+                    CHECK(rc == 0 && one.pad == 0);
+                    CHECK(ig_debug_pool_retries(c, &r1) == 0);
+                    CHECK(r1 == r0 + 1);
+                    g_force_retry = 1;
+                    CHECK(ig_set_batch_width(1) == 0);
+                    CHECK(ig_step_batch(c, 5, frags.data(), cands.data(), max_c, res.data()) == 0 || (size_t)c->mb.pool_cap >= (size_t)std::max<long long>(c->Z, 1) * (size_t)std::max(c->mb.capC, 1));
+                    CHECK(ig_set_batch_width(24) == 0);
+                    g_force_retry = 0;
+                }
+            }
             for (int w : {24, 1, 7, 64}) {
                 CHECK(ig_set_batch_width(w) == 0);
                 g_grow_windows = (w == 7);
@@ -599,6 +639,7 @@ int main()
                          "screened steps %.0f, rejected from the interval %.0f, void %.0f\n",
                  fake_hip::launches(), fake_hip::allocations(), g_decides, g_pendings, g_conflicts, g_overflows, g_diffs, g_exacts, st[0], st[1], st[3]);
     CHECK(g_pendings > 0 && g_conflicts > 0 && g_overflows > 0 && g_diffs > 0 && g_exacts > 0 && st[1] > 0 && st[3] > 0);
+    CHECK(g_retry_paths > 0); /* the one-move path's retry with a larger pool ran at least once */
     double hs[12];
     CHECK(ig_debug_nuis_hist_stats(c, hs) == 0);
     std::fprintf(stderr, "[harness] histogram tier: evaluations %.0f (model calls %ld), rejected there %.0f, accepted there %.0f, void %.0f, walks %.0f, builds %.0f\n",
