@@ -61,7 +61,9 @@ def make_case(seed):
     warm = int(r.choice([0, 0, 200, 900]))
     temp = int(r.randint(3))
     inject = int(r.choice([0, 0, 0, 5, 17]))
-    return prob, params, scale, n, warm, temp, inject, dict(n_frags=n_frags, per=per, mean_len=mean_len, scale=scale, params=kind, n=n,
+    global POOL
+    POOL = int(r.choice([0, 0, 0, 3000, 30000]))  # (a small slice pool: slots re-run, the pool grown, chains ended by an overflow)
+    return prob, params, scale, n, warm, temp, inject, dict(pool=POOL, n_frags=n_frags, per=per, mean_len=mean_len, scale=scale, params=kind, n=n,
                                                             warm=warm, temp=temp, inject=inject)
 
 
@@ -76,8 +78,14 @@ class cooled(hip_sampler):
         return 1.0
 
 
+POOL = 0
+
+
 def run(prob, params, scale, n, warm, temp, inject, seed, chain, async_, screen):
     os.environ["IG_NUIS_ASYNC"] = async_
+    os.environ.pop("IG_POOL_ENTRIES", None)
+    if POOL:
+        os.environ["IG_POOL_ENTRIES"] = str(POOL)
     hip_lib.set_nuis_chain(chain)
     hip_lib.set_nuis_screen(screen)
     hip_lib.set_nuis_hist(2)
@@ -114,6 +122,7 @@ def run(prob, params, scale, n, warm, temp, inject, seed, chain, async_, screen)
         hip_lib.set_nuis_hist(1)
         hip_lib.debug_set_zero_inject(0)
         os.environ.pop("IG_NUIS_ASYNC", None)
+        os.environ.pop("IG_POOL_ENTRIES", None)
 
 
 bad = 0
