@@ -45,7 +45,8 @@ typedef struct ig_move_result {
     int64_t n_evals;     /* sum over candidates of S_c * (n_uniq + 1) term evaluations */
     int64_t bytes_min;   /* compulsory-traffic model B_min of this move */
     int32_t error;       /* 0, or a device-side consistency failure code */
-    int32_t pad;
+    int32_t pad;         /* 0 in every record a caller sees (inside the library: 1 = the one-move launches found the move's lists too long
+                          * for the slice pool and applied nothing; the entry point grows the pool and repeats the move) */
 } ig_move_result;
 
 /* ---- lifetime --------------------------------------------------------- */
