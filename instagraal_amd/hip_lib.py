@@ -71,7 +71,12 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
-        _lib = C.CDLL(os.environ.get("IG_HIP_LIB", LIB_PATH))  # IG_HIP_LIB: tuning builds of the same source
+        # the product library, nothing else -- unless the caller says in so many words that this is a tuning session
+        # (IG_DEBUG_TUNING=1 IG_HIP_LIB=<a build of the same source with other -D constants>: tools/diff_pass_time.py)
+        path = LIB_PATH
+        if os.environ.get("IG_DEBUG_TUNING") == "1" and os.environ.get("IG_HIP_LIB"):
+            path = os.environ["IG_HIP_LIB"]
+        _lib = C.CDLL(path)
         _lib.ig_last_error.restype = C.c_char_p
         _lib.ig_partials_count.restype = C.c_int64
         _lib.ig_partials_device_ptr.restype = C.c_void_p

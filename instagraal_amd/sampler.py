@@ -463,6 +463,10 @@ class sampler:  # noqa: N801 - the reference's class name
           outcomes of this one; the acceptance test itself and the first launches of the next step are one library call
           (``ig_nuis_step_next``), so that no Python runs between two steps' kernels.
 
+        ``self.likelihood_nuis`` (the test likelihood of the last step: read nowhere outside the reference's method, CL:3023-3036) is
+        set by the steps that go the plain way only -- a step rejected inside a chain is decided from an interval that
+        lies below the threshold, and no value of it exists.
+
         -> (structured move results, list of the 8-tuples of step_nuisance_parameters with y_rippe = None)"""
         frags = np.ascontiguousarray(frags, np.int32)
         n = frags.size
@@ -494,7 +498,9 @@ class sampler:  # noqa: N801 - the reference's class name
         cands, id_modif, gauss, unif = self.neighbours.draw_nuisance(frags, max(1, n_neighbours))
         mean_kb = self.mean_kb()
         gauss_l, id_modif_l, unif_l = gauss.tolist(), id_modif.tolist(), unif.tolist()
-        temps = np.array([float(self.temperature(t0 + i, n_step)) for i in range(n)]) if type(self).temperature is not sampler.temperature else np.ones(n)
+        # (the base method returns 1.0: not called n times; one overridden in a subclass OR assigned on the instance is)
+        plain_T = getattr(self.temperature, "__func__", None) is sampler.temperature
+        temps = np.ones(n) if plain_T else np.array([float(self.temperature(t0 + i, n_step)) for i in range(n)])
         prof = self.nuis_profile = dict(propose=0.0, step=0.0, book=0.0, chain=0.0)
         trace = getattr(self, "nuis_step_trace", None)  # a list: (seconds, accepted) per plain step (tools/nuisance_rate.py)
         use_chain = hip_lib.nuis_chain_wanted()
@@ -681,9 +687,15 @@ class sampler:  # noqa: N801 - the reference's class name
                 prof["book"] += t3 - t2
                 if trace is not None:
                     trace.append((t3 - ta, int(success)))
-        finally:
+        except BaseException:
             if patch is not None:
-                fill_in()
+                try:  # (the run failed: whatever fetching the pending exact sum raises on the failed handle must not replace the cause)
+                    fill_in()
+                except Exception:
+                    pass
+            raise
+        if patch is not None:
+            fill_in()
         # the records of all moves at once; the 8-tuples from them
         res[:] = self.ctx.batch_results(n)
         o_col = res["o"]

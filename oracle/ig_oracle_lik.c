@@ -522,7 +522,8 @@ static inline int find_row_slot(const int32_t* block_csr, ig_int3 pb, int curr_f
     return local;
 }
 
-/* KA:4099-4233, block 64 */
+/* KA:4099-4233, block 64.  The blocks are independent (a CUDA block each): they are evaluated on g_threads cores
+ * and their results taken in block order, i.e. summed exactly as the serial loop sums them. */
 void igo_extract_sub_likelihood(const int32_t* dat, const ig_int3* info_block, const int32_t* block_csr, const int32_t* row,
                                 const int32_t* col, const ig_params* P, float mean_size_frag, const float* pos_bp,
                                 const int32_t* id_c, const float* s_tot, const int32_t* pos, const int32_t* len,
@@ -534,10 +535,14 @@ void igo_extract_sub_likelihood(const int32_t* dat, const ig_int3* info_block, c
     const ig_hot hot = ig_hot_make(p, ig_tab());
     const int B = IGO_SIZE_BLOCK_4_SUB;
     const int n_blocks = n_data / B + 1;
-    ig_acc acc = {0, 0};
-    double total = vect_likelihood[0];
-    double sdata[IGO_SIZE_BLOCK_4_SUB];
+    const int mode = g_mode;
+    double* per_block = (double*)malloc(sizeof(double) * (size_t)n_blocks);
+    int64_t hi = 0, lo = 0;
+#ifdef _OPENMP
+#pragma omp parallel for reduction(+ : hi, lo) num_threads(g_threads) schedule(static)
+#endif
     for (int b = 0; b < n_blocks; b++) {
+        double sdata[IGO_SIZE_BLOCK_4_SUB];
         ig_int3 pb = info_block[b];
         for (int t = 0; t < B; t++) {
             int g = b * B + t;
@@ -558,24 +563,34 @@ void igo_extract_sub_likelihood(const int32_t* dat, const ig_int3* info_block, c
                 float s_z = fabsf(pos_i - pos_j) * mean_size_frag;
                 float s_tot_z = (float)len[fj] * mean_size_frag;
                 v = pair_term(p, &hot, contig_i == contig_j, s, s_z, st, s_tot_z, dat[g]);
-                if (g_mode) ig_acc_add(&acc, ig_quantize(v));
+                if (mode) {
+                    int64_t q = ig_quantize(v);
+                    hi += q >> 32;
+                    lo += (int64_t)(uint32_t)q;
+                }
             }
             sdata[t] = v;
         }
-        double r = tree_reduce(sdata, B);
-        if (b * B < n_data) total += r; /* tid 0 && condition, KA:4230 */
+        per_block[b] = tree_reduce(sdata, B);
     }
-    if (g_mode) {
+    if (mode) {
+        ig_acc acc = {hi, lo};
         publish(IGO_N_TMP_STRUCT, acc);
         vect_likelihood[0] += ig_acc_to_double(acc.hi, acc.lo);
     } else {
+        double total = vect_likelihood[0];
+        for (int b = 0; b < n_blocks; b++)
+            if (b * B < n_data) total += per_block[b]; /* tid 0 && condition, KA:4230 */
         vect_likelihood[0] = total;
     }
+    free(per_block);
 }
 
 /* KA:4236-4370, block 64.  Column k of the uniq list is summed by thread k of
  * each block and only if THAT thread holds a valid entry (KA:4362): in the last,
- * partially filled block columns with k >= n_data % 64 drop the block (quirk Q5). */
+ * partially filled block columns with k >= n_data % 64 drop the block (quirk Q5).
+ * Blocks on g_threads cores, their column sums added in block order (LIBM: the serial loop's double sums;
+ * DET: integer limbs, any order). */
 void igo_eval_sub_likelihood(const int32_t* dat, const ig_int3* info_block, const int32_t* block_csr, const int32_t* row,
                              const int32_t* col, const ig_params* P, float mean_size_frag, const float* pos_bp,
                              const int32_t* id_c, const float* s_tot, const int32_t* pos, const int32_t* len,
@@ -589,60 +604,93 @@ void igo_eval_sub_likelihood(const int32_t* dat, const ig_int3* info_block, cons
     const int B = IGO_SIZE_BLOCK_4_SUB, T = IGO_N_TMP_STRUCT;
     const int n_blocks = n_data / B + 1;
     const int nu = n_uniq[0];
+    const int mode = g_mode;
     ig_acc acc[IGO_N_TMP_STRUCT];
     memset(acc, 0, sizeof acc);
-    static double loc[IGO_SIZE_BLOCK_4_SUB * IGO_N_TMP_STRUCT];
-    static int64_t locq[IGO_SIZE_BLOCK_4_SUB * IGO_N_TMP_STRUCT];
-    for (int b = 0; b < n_blocks; b++) {
-        ig_int3 pb = info_block[b];
-        for (int t = 0; t < B; t++) {
-            int g = b * B + t;
-            if (g < n_data) {
-                int curr_fi = row[g];
-                int slot = find_row_slot(block_csr, pb, curr_fi);
-                int64_t fiT = (int64_t)block_csr[pb.y + slot] * T;
-                int curr_fj = col[g];
-                for (int k = 0; k < nu; k++) {
-                    int m = list_uniq[k];
-                    int64_t fj = (int64_t)curr_fj * T + m;
-                    int contig_i = (int)floorf((float)id_c[fiT + m]);
-                    int contig_j = id_c[fj];
-                    float st = s_tot[fiT + m];
-                    float si = pos_bp[fiT + m];
-                    float pos_i = (float)pos[fiT + m];
-                    float sj = pos_bp[fj];
-                    float pos_j = (float)pos[fj];
-                    float s = fabsf(si - sj);
-                    float s_z = fabsf(pos_i - pos_j) * mean_size_frag;
-                    float s_tot_z = (float)len[fj] * mean_size_frag;
-                    double v = pair_term(p, &hot, contig_i == contig_j, s, s_z, st, s_tot_z, dat[g]);
-                    loc[t * T + m] = v;
-                    locq[t * T + m] = ig_quantize(v);
+    double* per_block = mode ? NULL : (double*)malloc(sizeof(double) * (size_t)n_blocks * T);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(g_threads)
+#endif
+    {
+        double loc[IGO_SIZE_BLOCK_4_SUB * IGO_N_TMP_STRUCT];
+        int64_t locq[IGO_SIZE_BLOCK_4_SUB * IGO_N_TMP_STRUCT];
+        ig_acc mine[IGO_N_TMP_STRUCT];
+        memset(mine, 0, sizeof mine);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int b = 0; b < n_blocks; b++) {
+            ig_int3 pb = info_block[b];
+            for (int t = 0; t < B; t++) {
+                int g = b * B + t;
+                if (g < n_data) {
+                    int curr_fi = row[g];
+                    int slot = find_row_slot(block_csr, pb, curr_fi);
+                    int64_t fiT = (int64_t)block_csr[pb.y + slot] * T;
+                    int curr_fj = col[g];
+                    for (int k = 0; k < nu; k++) {
+                        int m = list_uniq[k];
+                        int64_t fj = (int64_t)curr_fj * T + m;
+                        int contig_i = (int)floorf((float)id_c[fiT + m]);
+                        int contig_j = id_c[fj];
+                        float st = s_tot[fiT + m];
+                        float si = pos_bp[fiT + m];
+                        float pos_i = (float)pos[fiT + m];
+                        float sj = pos_bp[fj];
+                        float pos_j = (float)pos[fj];
+                        float s = fabsf(si - sj);
+                        float s_z = fabsf(pos_i - pos_j) * mean_size_frag;
+                        float s_tot_z = (float)len[fj] * mean_size_frag;
+                        double v = pair_term(p, &hot, contig_i == contig_j, s, s_z, st, s_tot_z, dat[g]);
+                        loc[t * T + m] = v;
+                        locq[t * T + m] = mode ? ig_quantize(v) : 0;
+                    }
+                } else {
+                    for (int k = 0; k < nu; k++) {
+                        int m = list_uniq[k];
+                        loc[t * T + m] = 0.0;
+                        locq[t * T + m] = 0;
+                    }
                 }
-            } else {
-                for (int m = 0; m < T; m++) {
-                    loc[t * T + m] = 0.0;
-                    locq[t * T + m] = 0;
+            }
+            for (int t = 0; t < nu && t < B; t++) {
+                int m = list_uniq[t];
+                if (b * B + t >= n_data) { /* (tid < n_uniq) && condition */
+                    if (!mode) per_block[(size_t)b * T + m] = 0.0;
+                    continue;
                 }
+                double tmp = 0.0;
+                for (int i = 0; i < B; i++) {
+                    tmp += loc[i * T + m];
+                    if (mode) ig_acc_add(&mine[m], locq[i * T + m]);
+                }
+                if (!mode) per_block[(size_t)b * T + m] = tmp;
             }
         }
-        for (int t = 0; t < nu && t < B; t++) {
-            if (b * B + t >= n_data) continue; /* (tid < n_uniq) && condition */
-            int m = list_uniq[t];
-            double tmp = 0.0;
-            for (int i = 0; i < B; i++) {
-                tmp += loc[i * T + m];
-                if (g_mode) ig_acc_add(&acc[m], locq[i * T + m]);
+        if (mode) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+            for (int m = 0; m < T; m++) {
+                acc[m].hi += mine[m].hi;
+                acc[m].lo += mine[m].lo;
             }
-            if (!g_mode) vect_likelihood[m] += tmp;
         }
     }
-    if (g_mode) {
+    if (mode) {
         for (int k = 0; k < nu; k++) {
             int m = list_uniq[k];
             publish(m, acc[m]);
             vect_likelihood[m] += ig_acc_to_double(acc[m].hi, acc[m].lo);
         }
+    } else {
+        for (int b = 0; b < n_blocks; b++)
+            for (int t = 0; t < nu && t < B; t++) {
+                if (b * B + t >= n_data) continue;
+                int m = list_uniq[t];
+                vect_likelihood[m] += per_block[(size_t)b * T + m];
+            }
+        free(per_block);
     }
 }
 

@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import weakref
 
 import numpy as np
 
@@ -47,14 +48,26 @@ def lib():
     return _lib
 
 
+_ptr_cache = {}  # id(array) -> (weak reference, address): the sampler's buffers live as long as it does
+
+
 def ptr(a):
     """address of a numpy array / FragStruct / None"""
     if a is None:
         return C.c_void_p(0)
+    e = _ptr_cache.get(id(a))
+    if e is not None and e[0]() is a:
+        return e[1]
     if isinstance(a, FragStruct):
         return C.c_void_p(a.addr)
     assert a.flags["C_CONTIGUOUS"]
-    return C.c_void_p(a.ctypes.data)
+    p = C.c_void_p(a.ctypes.data)
+    if a.base is None and a.flags["OWNDATA"]:  # (views are made per call: not worth an entry)
+        if len(_ptr_cache) > 4096:
+            for k in [k for k, v in _ptr_cache.items() if v[0]() is None]:
+                del _ptr_cache[k]
+        _ptr_cache[id(a)] = (weakref.ref(a), p)
+    return p
 
 
 class FragStruct:

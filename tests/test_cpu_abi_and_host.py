@@ -59,6 +59,10 @@ def test_rippe_fit_matches_reference_host_functions():
     fit = np.array(fit, dtype=np.float64)
     assert abs(fit[2] - float(g["fit_slope"])) < 2e-8 and fit[3] == float(g["fit_d"])
     assert np.allclose(y, g["y_est"].astype(np.float64), rtol=1e-6, atol=0)
+    # what the valley leaves fixed, in double (round 3's advisor note): the amplitude product and the fitted curve at 1e-9
+    amp = fit[4] * 0.53 * abs(fit[0]) ** -3 * (abs(fit[1]) / abs(fit[0])) ** fit[2]
+    assert abs(amp - float(g["fit_amp"])) <= 1e-9 * abs(float(g["fit_amp"])), (amp, float(g["fit_amp"]))
+    assert np.allclose(np.asarray(y, np.float64), g["y_est64"], rtol=1e-9, atol=0)
 
 
 def test_draw_unit_under_address_and_ub_sanitizers(tmp_path):

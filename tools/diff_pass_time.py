@@ -1,5 +1,5 @@
 """average duration of the screened nuisance pass's kernel (k_full_diff_tiled, hipEvents on its stream) over a run of
-nuisance steps   python tools/diff_pass_time.py [cfg3] [steps]   (IG_HIP_LIB=<tuning build> to time a variant)"""
+nuisance steps   python tools/diff_pass_time.py [cfg3] [steps]   (IG_DEBUG_TUNING=1 IG_HIP_LIB=<tuning build> to time a variant)"""
 import os
 import sys
 

@@ -155,6 +155,10 @@ def host_helper_goldens(outdir):
              # WHERE varies from run to run with the last bits of numpy's log: only what every run reproduces is stored --
              # slope (8 decimals), d, the fitted curve in float32
              fit_slope=np.float64(round(float(fit[2]), 8)), fit_d=np.float64(fit[3]), y_est=np.asarray(y_est, np.float32),
+             # ... and what the valley leaves fixed, in double: the amplitude product A 0.53 kuhn^-3 (lm / kuhn)^slope (the one
+             # identifiable combination of kuhn, lm, A) and the fitted curve itself -- compared at 1e-9 relative
+             fit_amp=np.float64(float(fit[4]) * 0.53 * abs(float(fit[0])) ** -3 * (abs(float(fit[1])) / abs(float(fit[0]))) ** float(fit[2])),
+             y_est64=np.asarray(y_est, np.float64),
              rippe_grid_s=grid, rippe_grid_peval=np.asarray(ref, np.float64),
              rippe_grid_params=np.array([rp[k] for k in ("kuhn", "lm", "c1", "slope", "d", "d_max", "fact", "v_inter")], np.float64))
     print("wrote host_helpers.npz", dmax, dmax_n, fit)
