@@ -33,6 +33,21 @@ warnings.filterwarnings("ignore", category=RuntimeWarning)
 CHECK_EVERY = 50
 
 
+def _digest(a):
+    import hashlib
+
+    return np.frombuffer(hashlib.blake2b(np.ascontiguousarray(a).tobytes(), digest_size=8).digest(), np.uint64)[0]
+
+
+def _state_equal(expect, k, arr):
+    """checkpoint k of a run: the full genome where the recording holds it (live runs; the last checkpoint of a file), else its digest"""
+    if "states" in expect and k < len(expect["states"]):
+        return np.array_equal(expect["states"][k], arr)
+    if k == len(expect["state_digests"]) - 1 and "state_last" in expect:
+        return np.array_equal(expect["state_last"], arr)
+    return expect["state_digests"][k] == _digest(arr)
+
+
 def make_case(seed):
     """-> (problem, parameters, description dict) -- deterministic in the seed, no GPU touched"""
     from instagraal_amd import synth
@@ -157,9 +172,8 @@ def run_oracle(prob, params, desc, threads=0, expect=None):
                 states.append(o.gpu_vect_frags.soa17())
                 flags.append(np.array(o.gpu_list_valid_insert, np.int32))
                 if expect is not None and diff is None:
-                    if not np.array_equal(expect["states"][k], states[-1]):
-                        bad = np.argwhere(expect["states"][k] != states[-1])
-                        diff = "genome after move %d: %d entries differ, first (field %d, bin %d)" % (t, len(bad), bad[0][0], bad[0][1])
+                    if not _state_equal(expect, k, states[-1]):
+                        diff = "genome after move %d differs" % t
                         break
                     if not np.array_equal(expect["flags"][k], flags[-1]):
                         diff = "stale insert flags after move %d: HIP %r / oracle %r" % (t, expect["flags"][k].tolist(), flags[-1].tolist())
@@ -190,8 +204,8 @@ def _check_one(args):
     path, seed, threads = args
     z = np.load(path, allow_pickle=False)
     pre = "c%d_" % seed
-    exp = dict(records=z[pre + "records"], states=z[pre + "states"], flags=z[pre + "flags"], rng_key=z[pre + "rng_key"],
-               rng_pos=int(z[pre + "rng_pos"]))
+    exp = dict(records=z[pre + "records"], state_digests=z[pre + "state_digests"], state_last=z[pre + "state_last"], flags=z[pre + "flags"],
+               rng_key=z[pre + "rng_key"], rng_pos=int(z[pre + "rng_pos"]))
     prob, params, desc = make_case(seed)
     assert desc["n"] == len(exp["records"]), "the recording was made by another generator"
     t0 = time.time()
@@ -250,8 +264,10 @@ def main(argv):
             t1 = time.time()
             if record:
                 pre = "c%d_" % seed
-                for k in ("records", "states", "flags", "rng_key"):
+                for k in ("records", "flags", "rng_key"):
                     store[pre + k] = h[k]
+                store[pre + "state_digests"] = np.array([_digest(x) for x in h["states"]], np.uint64)  # (64 MiB come back from a GPU box)
+                store[pre + "state_last"] = h["states"][-1]
                 store[pre + "rng_pos"] = np.int64(h["rng_pos"])
                 done.append(seed)
                 print("case %5d recorded %s: batches %d, pool retries %d  (%.1f s)" % (seed, desc, h["stats"]["batches"], h["stats"]["pool_retries"],
