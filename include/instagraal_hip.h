@@ -133,6 +133,11 @@ int ig_batch_records(ig_ctx* ctx, void** records, int64_t* bytes_per_slot); /* s
 int ig_batch_commit(ig_ctx* ctx, int32_t move0, int32_t W, int32_t* n_committed); /* moves move0 .. move0+n_committed-1 are done */
 int ig_batch_results(ig_ctx* ctx, int32_t n_moves, ig_move_result* results);
 int ig_set_batch_width(int w);                        /* W in 1..64 (default 24, env IG_BATCH_W); 1 = no speculation */
+/* The WINDOW rule of ig_step_batch / ig_step_batch_draw (round 5): the scored slots of the moves ahead stay scored from launch to launch
+ * while no contig they read is written; a launch re-scores the stale ones and fills the window up; decisions strictly in order, results
+ * those of one move at a time (CL:1401-1465).  w = 0: off (every launch scores a fresh batch of ig_set_batch_width slots and drops what
+ * lies behind its first conflict: rounds 1 - 4); w in 2..64: slots of the window (default 48, env IG_WINDOW). */
+int ig_set_window(int w);
 int ig_batch_stats(ig_ctx* ctx, int64_t out4[4]);     /* {batches, moves committed in-batch, one-move tails, predicted deltas used} */
 int ig_scratch_bytes(ig_ctx* ctx, int64_t out3[3]);   /* move buffers: {per-window arrays, slice pool, per-slot records and lists} */
 

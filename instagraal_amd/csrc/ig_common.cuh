@@ -101,6 +101,7 @@ struct Glob {
     long long scr_cols, scr_cont; /* two-tier scoring: columns screened, columns scored exactly */
     long long scr_void_cols; /* columns whose screening bound was void */
     long long scr_terms, scr_terms_exact; /* ... and the (contact, column) terms in them */
+    int dbg[8]; /* what raised Glob.error (diagnostics: printed with a consistency failure) */
 };
 
 /* one move slot of a batch (W = 1: the move in flight) */
@@ -218,7 +219,18 @@ struct MoveBuf {
      * largest window the genome can produce right now -- two contigs of the current maximum length, with headroom -- not
      * the whole genome; the host grows them when the maximum grows (ensure_window_buffers) */
     int sN, sM;
+    /* the WINDOW of scored slots (round 5; ig_host_batch.inc: run_moves_window).  A kernel's slot index w is a POSITION in the window
+     * (position p <-> move `done + p`); the buffers of position p live in physical slot PS(p) = (p + rot) & wmask, so that a slot keeps
+     * its buffers while the window moves on (rot = done & wmask).  keep: bit p = position p holds a slot scored by an EARLIER launch
+     * that is still valid (no contig it reads was written since): every scoring kernel leaves it alone, the decide step uses it.
+     * Everywhere else (one move per call, the nuisance runs, slots split over GPUs): rot = 0, wmask = ~0, keep = 0 -- PS is the identity. */
+    int rot, wmask;
+    unsigned long long keep;
+    int ring; /* 1: the window rule (every slot's candidate 0 is scored with all block-insert slots: its stale flags are not known yet) */
 };
+#define PS(w) (((w) + mb.rot) & mb.wmask)
+#define KEPT(w) ((int)((mb.keep >> (w)) & 1ull))
+#define LW(ps) (((ps) - mb.rot) & mb.wmask) /* the position of physical slot ps */
 /* layout of MoveBuf.part per candidate (int64 units) */
 #define P_NZ 0                 /* [NSLOT][2] slice sums per column k (k=0: current = "extract") */
 #ifndef SLICE_SEG
@@ -456,6 +468,8 @@ struct ig_ctx {
     size_t h_stage_bytes;
     int own_begin, own_end; /* slots whose candidate genomes this handle built for the batch in flight */
     int own_screened;       /* the batch in flight was scored in two tiers (1), or verified (2) */
+    unsigned long long last_stale; /* the window rule: positions the last decide launch found stale (wait_commit) */
+    long long n_window_slots;      /* ... slots scored by its launches */
     int max_L, max_SL;      /* host copies of Glob.max_L / max_SL as of the last synchronisation */
     bool full_windows;      /* window strides = the whole genome (runs of moves enqueued one at a time without a host round trip) */
     int* host_max;          /* pinned: {max_L, max_SL} copied back with every one-move call's result */
@@ -471,10 +485,11 @@ __device__ __forceinline__ SlotPre& pre_at(const MoveBuf& mb, int cw, int slot)
     return ((SlotPre*)(mb.rec + (size_t)w * mb.rec_stride))[c * IG_N_TMP_STRUCT + slot];
 }
 /* the same by (slot w, entry i = c * IG_N_TMP_STRUCT + column) / (slot w, candidate c): no division by the runtime capC */
-__device__ __forceinline__ SlotPre& pre_w(const MoveBuf& mb, int w, int i) { return ((SlotPre*)(mb.rec + (size_t)w * mb.rec_stride))[i]; }
+/* (w: a position of the window, PS(w) its physical slot; pre_at / cpre_at take the physical cw = CW(w, c)) */
+__device__ __forceinline__ SlotPre& pre_w(const MoveBuf& mb, int w, int i) { return ((SlotPre*)(mb.rec + (size_t)PS(w) * mb.rec_stride))[i]; }
 __device__ __forceinline__ CandPre& cpre_w(const MoveBuf& mb, int w, int c)
 {
-    return ((CandPre*)(mb.rec + (size_t)w * mb.rec_stride + (size_t)mb.capC * IG_N_TMP_STRUCT * sizeof(SlotPre)))[c];
+    return ((CandPre*)(mb.rec + (size_t)PS(w) * mb.rec_stride + (size_t)mb.capC * IG_N_TMP_STRUCT * sizeof(SlotPre)))[c];
 }
 __device__ __forceinline__ CandPre& cpre_at(const MoveBuf& mb, int cw)
 {

@@ -8,7 +8,7 @@
 __device__ void score_and_choose(Glob* g, const MoveBuf& mb, int w, const int* vf0, double* sc_lds /* [C*24] */)
 {
     const int tid = threadIdx.x;
-    MoveCtl& mc = mb.ctl[w];
+    MoveCtl& mc = mb.ctl[PS(w)];
     const int C = mc.C;
     const ig_params p = g->par[0];
     const double log_e = IG_LOG_E_F;
@@ -121,10 +121,10 @@ __global__ void __launch_bounds__(256) k_scores(Glob* g, MoveBuf mb, int w)
     __shared__ double sc[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT];
     __shared__ int vf[12];
     if (threadIdx.x < 12) vf[threadIdx.x] = g->valid_insert[threadIdx.x];
-    if (threadIdx.x == 0 && mb.ctl[w].overflow) g->retry_pool = 1; /* (the scores below miss the lists that did not fit: nothing is applied) */
+    if (threadIdx.x == 0 && mb.ctl[PS(w)].overflow) g->retry_pool = 1; /* (the scores below miss the lists that did not fit: nothing is applied) */
     __syncthreads();
     score_and_choose(g, mb, w, vf, sc);
-    const int n = mb.ctl[w].C * IG_N_TMP_STRUCT;
+    const int n = mb.ctl[PS(w)].C * IG_N_TMP_STRUCT;
     for (int i = threadIdx.x; i < n; i += blockDim.x) mb.scores[(size_t)CW(w, 0) * IG_N_TMP_STRUCT + i] = sc[i];
 }
 
@@ -149,7 +149,7 @@ __global__ void k_force_choice(Glob* g, MoveBuf mb, int slot)
 __device__ void apply_winner(State st, Tables tab, Glob* g, const MoveBuf& mb, int w, int forced, int* prev_touched, int tid, int nth,
                              bool single_block)
 {
-    MoveCtl& mc = mb.ctl[w];
+    MoveCtl& mc = mb.ctl[PS(w)];
     const int c = mc.ch_c, slot = mc.ch_slot, k = mc.ch_k;
     const int cw = CW(w, c);
     const CandMeta& m = mb.meta[cw];
@@ -231,7 +231,7 @@ __global__ void k_apply(State st, Tables tab, Glob* g, MoveBuf mb, int w, int fo
 
 __device__ __forceinline__ void write_result(Glob* g, const MoveBuf& mb, int w, ig_move_result* out)
 {
-    const MoveCtl& mc = mb.ctl[w];
+    const MoveCtl& mc = mb.ctl[PS(w)];
     ig_move_result r;
     const double norm = 3.0 * (double)(g->N - g->n_black);
     r.o = mc.ch_score;
@@ -260,7 +260,7 @@ __global__ void k_commit(Glob* g, MoveBuf mb, ig_move_result* res, int move, int
     /* dirty (a move of a batch finished with the one-move kernels, decided one move per call: ig_nuis_step_begin): its contigs
      * onto the batch's list of modified contigs, as k_decide_batch does for the moves it commits itself */
     if (dirty) {
-        const MoveCtl& mc = mb.ctl[w];
+        const MoveCtl& mc = mb.ctl[PS(w)];
         const CandMeta& m = mb.meta[CW(w, mc.ch_c)];
         const int n = dirty[0];
         if (n + 2 <= 2 * IG_MAX_BATCH + 2) {
@@ -423,7 +423,7 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
             for (int j = 0; j < ND; j++)
                 if (lane + 64 * j < n_dirty) dirty[j] = dirty_buf[1 + lane + 64 * j];
             if (w_start > 0 && !(resumed_plain & 1)) {
-                const MoveCtl pm = mb.ctl[w_start - 1];
+                const MoveCtl pm = mb.ctl[PS(w_start - 1)];
                 const CandMeta& m = mb.meta[CW(w_start - 1, pm.ch_c)];
 #pragma unroll
                 for (int j = 0; j < ND; j++) {
@@ -444,8 +444,8 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
             int e_r[2], e_base[2];  /* S_c mod 64, list entries before the block inserts */
         };
         /* the candidate counts of all slots up front (lane w: slot w): a prefetch must not wait for its own first load */
-        const int all_C = (lane < W) ? mb.ctl[lane].C : 0;
-        const int all_sup = (lane < W) ? mb.ctl[lane].superset0 : 0;
+        const int all_C = (lane < W) ? mb.ctl[PS(lane)].C : 0;
+        const int all_sup = (lane < W) ? mb.ctl[PS(lane)].superset0 : 0;
         /* CHAIN: the interval of step w_start + lane in lane `lane` */
         long long ct_s = 0, ct_b = 0, ct_f = 1;
         double ct_z = 0.0, ct_lnu = -IG_INF;
@@ -644,7 +644,7 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
             long long nzb_hi_w = 0, nzb_lo_w = 0;
             const unsigned vmask_w = vmask; /* the stale flags this move was scored under (vmask moves on below) */
             if (lane == 0) {
-                MoveCtl& o = mb.ctl[w];
+                MoveCtl& o = mb.ctl[PS(w)];
                 o.ch_c = bc;
                 o.ch_slot = bslot;
                 o.ch_k = br.k;
@@ -752,6 +752,35 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
             if (w + 2 >= W || !decide_one(w + 2, d2) || (CHAIN && halt_after)) break;
             d2 = load_move(clampw(w + 5));
         }
+        /* the window rule (MoveBuf.ring): which of the positions this launch did NOT commit hold a slot that is stale now -- a contig it
+         * reads (its focal bin's, its candidates') was written by a move of this chain (the list in the registers: every entry of it is
+         * younger than every slot of the window, which the host keeps clean of everything older) -- or whose lists did not fit a pool.
+         * Lane p: position p.  The host re-scores those with the next launch and keeps the rest (ig_host_batch.inc: run_moves_window). */
+        unsigned long long stale_mask = 0ull;
+        if (mb.ring) {
+            const bool mine = lane >= committed && lane < W;
+            bool st = false;
+            int maxC = all_C;
+            for (int o = 32; o > 0; o >>= 1) maxC = max(maxC, __shfl_xor(maxC, o, 64));
+            for (int cq = 0; cq < maxC; cq++) {
+                int qa = -3, qb = -3;
+                if (mine && cq < all_C) {
+                    const CandPre& cp = cpre_w(mb, lane, cq);
+                    qa = cp.ctgA;
+                    qb = cp.ctgB;
+                    st |= (cq == 0 && cp.overflow != 0);
+                }
+#pragma unroll
+                for (int j = 0; j < ND; j++) {
+                    const int nj = min(max(n_dirty - 64 * j, 0), 64);
+                    for (int q = 0; q < nj; q++) {
+                        const int id = __builtin_amdgcn_readlane(dirty[j], q);
+                        st |= (id == qa) | (id == qb);
+                    }
+                }
+            }
+            stale_mask = __ballot(mine && st);
+        }
 #pragma unroll
         for (int j = 0; j < ND; j++)
             if (lane + 64 * j < n_dirty) dirty_buf[1 + lane + 64 * j] = dirty[j];
@@ -780,6 +809,8 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
                 for (int x = 0; x < 8; x++) need = max(need, 8 * (int)mb.work[8 + x]);
             batch_out[6] = need;
             batch_out[11] = chain_changed; /* (a chain's segment: its last committed move changed the genome) */
+            batch_out[12] = (int)(unsigned)stale_mask;
+            batch_out[13] = (int)(unsigned)(stale_mask >> 32);
             /* the host polls this copy (mapped, coherent host memory): it learns the outcome while k_commit_batch is still
              * running and has the next launches queued behind it when it ends */
             if (host_out) {
@@ -794,6 +825,8 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
                 host_out[5] = n_contigs;
                 host_out[6] = need;
                 host_out[11] = chain_changed;
+                host_out[12] = (int)(unsigned)stale_mask;
+                host_out[13] = (int)(unsigned)(stale_mask >> 32);
                 __threadfence_system();
                 host_out[7] = seq;
             }
@@ -842,7 +875,7 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
     /* ---------------------------------------------------------------- 2. apply */
     const int N = mb.sN, M = mb.sM; /* strides of the window arrays */
     auto winner_loc = [&](int w) -> const int* {
-        const MoveCtl& mc = mb.ctl[w];
+        const MoveCtl& mc = mb.ctl[PS(w)];
         return mb.loc + ((size_t)(CW(w, mc.ch_c) * NSLOT + mc.ch_slot) * NDYN) * N;
     };
     /* The committed moves touch pairwise disjoint contigs: in every step below a group of COMMIT_GROUP threads takes a move
@@ -850,7 +883,7 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
      * fragment) overlap instead of being walked one move after the other by the whole workgroup.
      * 2a. ownership marks of the fragments whose state changes */
     for (int w = w_start + grp; w < committed; w += ngrp) {
-        const MoveCtl& mc = mb.ctl[w];
+        const MoveCtl& mc = mb.ctl[PS(w)];
         if (!mc.n_dirty) continue;
         const int cw = CW(w, mc.ch_c);
         const int n_loc = mb.meta[cw].n_loc;
@@ -866,7 +899,7 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
      * (CL:665-716), so move w can change the credits of its window and of the window's initial neighbours only; each is
      * evaluated on the genome as of move w-1 and as of move w (moves < t applied, read through the marks) */
     for (int w = w_start + grp; w < committed; w += ngrp) {
-        const MoveCtl& mc = mb.ctl[w];
+        const MoveCtl& mc = mb.ctl[PS(w)];
         if (!mc.n_dirty) continue;
         const int cw = CW(w, mc.ch_c);
         const int n_loc = mb.meta[cw].n_loc;
@@ -926,7 +959,7 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
     }
     __syncthreads();
     for (int w = w_start + grp; w < committed; w += ngrp) {
-        const MoveCtl& mc = mb.ctl[w];
+        const MoveCtl& mc = mb.ctl[PS(w)];
         const int cw = CW(w, mc.ch_c);
         const CandMeta& m = mb.meta[cw];
         const bool last = (w == committed - 1);
@@ -979,7 +1012,7 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
     /* 2d. the statistics columns (one thread per move), the distance column */
     if (tid >= w_start && tid < committed) {
         const int w = tid;
-        const MoveCtl& mc = mb.ctl[w];
+        const MoveCtl& mc = mb.ctl[PS(w)];
         const unsigned vmask = (unsigned)mc.pad;
         long long Sc = 0, ev = 0, by = 0;
         for (int c = 0; c < mc.C; c++) {
@@ -1009,11 +1042,11 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
         __syncthreads();
         if (tid == 0) {
             hn->res = res[move0 + committed - 1];
-            hn->nzb[0] = mb.ctl[committed - 1].nzb_hi;
-            hn->nzb[1] = mb.ctl[committed - 1].nzb_lo;
+            hn->nzb[0] = mb.ctl[PS(committed - 1)].nzb_hi;
+            hn->nzb[1] = mb.ctl[PS(committed - 1)].nzb_lo;
             hn->max_L = g->max_L;
             hn->max_SL = g->max_SL;
-            hn->changed = mb.ctl[committed - 1].n_dirty;
+            hn->changed = mb.ctl[PS(committed - 1)].n_dirty;
             __threadfence_system();
             hn->res_seq = hn_seq;
         }
@@ -1048,12 +1081,12 @@ __device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_pr
     /* the statistics columns of every slot, ahead of the decisions (k_commit_batch 2d): 16 lanes per slot */
     for (int w = w_start + (ctid >> 4); w < W; w += NCT / 16) {
         const int c = lane & 15;
-        const int C = mb.ctl[w].C;
+        const int C = mb.ctl[PS(w)].C;
         long long Sc = 0, ev = 0, by = 0;
         if (c < C) {
             const CandMeta& m = mb.meta[CW(w, c)];
             const CandPre& cp = cpre_at(mb, CW(w, c));
-            const bool apart = (c == 0) && mb.ctl[w].superset0;
+            const bool apart = (c == 0) && mb.ctl[PS(w)].superset0;
             Sc = cp.n_slice;
             if (!apart) {
                 ev = cp.n_slice * (m.n_uniq + 1);
@@ -1116,6 +1149,25 @@ __device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_pr
                 const int n_loc = mb.meta[cw].n_loc;
                 const int* gid = mb.Lloc + (size_t)cw * N;
                 const int* wl = winner_loc(w);
+                if (mb.ring & 4) { /* IG_WINDOW_CHECK=1: the slot's window (the fragments in their order) must be what the live genome says */
+                    const CandMeta& mm = mb.meta[cw];
+                    for (int x = ctid; x < n_loc; x += NCT) {
+                        const int f = gid[x];
+                        const bool inA = mm.same || x < mm.LA;
+                        const int want_c = inA ? mm.ctgA : mm.ctgB, want_p = inA ? x : x - mm.LA;
+                        if (f < 0 || f >= g->N || st.cid[f] != want_c || st.pos[f] != want_p) {
+                            g->error = 12;
+                            g->dbg[0] = w;
+                            g->dbg[1] = x;
+                            g->dbg[2] = f;
+                            g->dbg[3] = (f >= 0 && f < g->N) ? st.cid[f] : -1;
+                            g->dbg[4] = want_c;
+                            g->dbg[5] = (f >= 0 && f < g->N) ? st.pos[f] : -1;
+                            g->dbg[6] = want_p;
+                            g->dbg[7] = n_loc;
+                        }
+                    }
+                }
                 for (int x = ctid; x < n_loc; x += NCT) {
                     const int f = gid[x];
                     own_tag[f] = tag_base + w;
@@ -1176,7 +1228,7 @@ __device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_pr
             if (ctid == 0) {
                 const unsigned vmask = (unsigned)sh->vmask[w];
                 long long Sc = sh->st_sc[w], ev = sh->st_ev[w], by = sh->st_by[w];
-                if (mb.ctl[w].superset0) { /* candidate 0 as the reference would have scored it: its list under the stale flags of the decision */
+                if (mb.ctl[PS(w)].superset0) { /* candidate 0 as the reference would have scored it: its list under the stale flags of the decision */
                     const long long nu = sh->s0_base[w] + __popc(vmask);
                     ev += sh->s0_slice[w] * (nu + 1);
                     by += 12 * sh->s0_slice[w] + 20LL * sh->s0_mloc[w] * nu + 8LL * nu;
@@ -1214,7 +1266,7 @@ __device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_pr
             const uint2* col = mb.coords + (size_t)(cw * NSLOT + k) * M;
             const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
             const int* subs = mb.subs + (size_t)cw * M;
-            const int fresh = mb.ctl[w].fresh;
+            const int fresh = mb.ctl[PS(w)].fresh;
             for (int ls = gtid; ls < m.m_loc; ls += GT) {
                 const int s = subs[ls];
                 const uint2 v = col[ls];

@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(256) k_hist_build(const long long* __restrict_
 __global__ void __launch_bounds__(256) k_hist_walk(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, const Glob* g,
                                                    MoveBuf mb, int w, NuisHist h)
 {
-    const MoveCtl& mc = mb.ctl[w];
+    const MoveCtl& mc = mb.ctl[PS(w)];
     if (g->error || !mc.n_dirty) return;
     const int cw = CW(w, mc.ch_c), k = mc.ch_k;
     const CandMeta& m = mb.meta[cw];

@@ -10,7 +10,7 @@
  * modified by an earlier move of the batch.  W = 1 is the plain one-move-at-a-time path.
  * Buffers of candidate c of slot w live at index cw = w * capC + c. */
 
-#define CW(w, c) ((w) * mb.capC + (c))
+#define CW(w, c) (PS(w) * mb.capC + (c)) /* (w: a position of the window -- ig_common.cuh, MoveBuf.rot) */
 
 /* uniq-mutation list of extract_uniq_mutations (KA:4492-4553); vf == nullptr -> every insert slot (superset) */
 __device__ inline int build_uniq(int* u, bool first, int LA, int LB, const int* vf)
@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(256)
         const int sf = st.sub_first[f]; /* (with the others: not a round trip of its own for the fragments that need it) */
         bool in_window = false;
         for (int w = 0; w < W; w++) {
+            if (KEPT(w)) continue; /* (a slot of the window scored by an earlier launch and still valid: its lists stand) */
             const int cA = sh_cA[w], LA = sh_LA[w], C = sh_C[w];
             for (int c = 0; c < C; c++) {
                 int slot = -1;
@@ -106,6 +107,26 @@ __global__ void __launch_bounds__(256)
     if (w >= W) return;
     const int t = threadIdx.x;
     if (w == 0 && t < 16 && mb.work) mb.work[t] = 0; /* the exact kernel's work list: lengths and needs of the sub-lists (k_worklist) */
+    if (KEPT(w)) {
+        if ((mb.ring & 4) && t < sh_C[w]) { /* IG_WINDOW_CHECK=1: a kept slot's candidates and contigs must be what the live state says */
+            const CandMeta& m = mb.meta[CW(w, t)];
+            const int A = frags_all[move0 + w], B = cands_all[(size_t)(move0 + w) * max_c + t];
+            const bool ok = mb.ctl[PS(w)].A == A && m.B == B && st.cid[A] == m.ctgA && st.cid[B] == m.ctgB && st.L[A] == m.LA && st.L[B] == m.LB &&
+                            st.SL[A] == m.SLA && st.SL[B] == m.SLB && st.pos[A] == m.lA;
+            if (!ok) {
+                g->error = 11;
+                g->dbg[0] = w;
+                g->dbg[1] = t;
+                g->dbg[2] = st.cid[A];
+                g->dbg[3] = m.ctgA;
+                g->dbg[4] = st.cid[B];
+                g->dbg[5] = m.ctgB;
+                g->dbg[6] = st.L[A] * 1000 + m.LA;
+                g->dbg[7] = st.L[B] * 1000 + m.LB;
+            }
+        }
+        return;
+    }
     const int A = frags_all[move0 + w];
     const int* cands = cands_all + (size_t)(move0 + w) * max_c;
     const int C = sh_C[w];
@@ -120,7 +141,7 @@ __global__ void __launch_bounds__(256)
         mc.ch_score = 0.0;
         mc.n_slice_tot = mc.n_eval_tot = mc.bytes_min = 0;
         mc.d_hi = mc.d_lo = 0;
-        mc.superset0 = (w > 0 && force_slot < 0) ? 1 : 0;
+        mc.superset0 = ((w > 0 || mb.ring) && force_slot < 0) ? 1 : 0; /* (the window rule: a slot may be decided by a later launch, behind other moves) */
         mc.n_dirty = 0;
         mc.pred = -1;
         mc.pred_c = mc.pred_k = 0;
@@ -130,7 +151,7 @@ __global__ void __launch_bounds__(256)
         mc.pad = 0;
         mc.exact_chunk = 0;
         mc.pad2 = 0;
-        mb.ctl[w] = mc;
+        mb.ctl[PS(w)] = mc;
     }
     for (int i = t; i < C * P_STRIDE; i += blockDim.x) mb.part[(size_t)CW(w, 0) * P_STRIDE + i] = 0;
     for (int i = t; i < C * Q_STRIDE; i += blockDim.x) mb.qpart[(size_t)CW(w, 0) * Q_STRIDE + i] = 0;
@@ -185,7 +206,7 @@ __global__ void __launch_bounds__(256)
         if (force_slot >= 0) {
             u[n++] = force_slot;
         } else if (t == 0) {
-            n = build_uniq(u, true, m->LA, m->LB, (w == 0) ? g->valid_insert : nullptr);
+            n = build_uniq(u, true, m->LA, m->LB, (w == 0 && !mb.ring) ? g->valid_insert : nullptr);
         } else {
             n = build_uniq(u, false, m->LA, m->LB, sh_flags[t - 1]);
         }
@@ -203,7 +224,7 @@ __device__ __forceinline__ void mutate_one(const State& st, const Tables& tab, c
                                            const long long* __restrict__ rowptr, Glob* g, const MoveBuf& mb, const PzTab& pz, int slot,
                                            int c, int w)
 {
-    const MoveCtl& mc = mb.ctl[w];
+    const MoveCtl& mc = mb.ctl[PS(w)];
     if (c >= mc.C) return;
     const int cw = CW(w, c);
     const CandMeta& m = mb.meta[cw];
@@ -388,6 +409,7 @@ __device__ __forceinline__ void mutate_one(const State& st, const Tables& tab, c
 __global__ void __launch_bounds__(1024) k_mutate(State st, Tables tab, const SubTab* __restrict__ sub, const long long* __restrict__ rowptr,
                                                 Glob* g, MoveBuf mb, PzTab pz, int w_begin)
 {
+    if (KEPT(w_begin + (int)blockIdx.z)) return; /* (a slot of the window scored by an earlier launch and still valid) */
     mutate_one(st, tab, sub, rowptr, g, mb, pz, blockIdx.x, blockIdx.y, w_begin + blockIdx.z);
 }
 
@@ -402,7 +424,7 @@ __global__ void __launch_bounds__(256) k_mutate_winners(State st, Tables tab, co
     const int committed = batch_out[0], pending = batch_out[1];
     if (w >= own_begin && w < own_end) return; /* built before scoring */
     if (!((w >= w_start && w < committed) || w == pending)) return;
-    const MoveCtl& mc = mb.ctl[w];
+    const MoveCtl& mc = mb.ctl[PS(w)];
     if (blockIdx.x == 1 && mc.ch_slot == IG_N_TMP_STRUCT) return;
     mutate_one(st, tab, sub, rowptr, g, mb, pz, blockIdx.x == 0 ? IG_N_TMP_STRUCT : mc.ch_slot, mc.ch_c, w);
 }
@@ -423,18 +445,24 @@ __global__ void __launch_bounds__(OFFSETS_THREADS) k_offsets(MoveBuf mb, int W, 
     long long my_tot = 0;
     if (can_order && tid < n_idx) {
         const int w = w_begin + tid / max_c, c = tid % max_c;
-        const bool used = c < mb.ctl[w].C;
+        const bool used = c < mb.ctl[PS(w)].C && !KEPT(w);
         for (int sg = 0; sg < SLICE_SEG; sg++) {
-            const long long b = mb.slbound[(size_t)(w * mb.capC + c) * SLICE_SEG + sg]; /* (requested whether used or not: no wait in front of the scan) */
+            const long long b = mb.slbound[(size_t)CW(w, c) * SLICE_SEG + sg]; /* (requested whether used or not: no wait in front of the scan) */
             my_tot += (used && b > 0) ? b : 0;
         }
     }
     const int n = W * mb.capC * SLICE_SEG;
     const int per = (n + OFFSETS_THREADS - 1) / OFFSETS_THREADS;
+    /* entry i = (position w, candidate c, segment): its arrays live at the PHYSICAL index phys(i) (MoveBuf.rot); the pool is dealt
+     * out in the order of the positions -- the window's front first */
+    auto phys = [&](int i) -> size_t {
+        const int cwl = i / SLICE_SEG;
+        return (size_t)CW(cwl / mb.capC, cwl % mb.capC) * SLICE_SEG + (size_t)(i % SLICE_SEG);
+    };
     auto bound_of = [&](int i) -> long long {
-        const int cw = i / SLICE_SEG;
-        const int w = cw / mb.capC, c = cw % mb.capC;
-        return (w >= w_begin && w < w_end && c < mb.ctl[w].C) ? mb.slbound[i] : -1; /* -1: not an entry of this launch */
+        const int cwl = i / SLICE_SEG;
+        const int w = cwl / mb.capC, c = cwl % mb.capC;
+        return (w >= w_begin && w < w_end && !KEPT(w) && c < mb.ctl[PS(w)].C) ? mb.slbound[phys(i)] : -1; /* -1: not an entry of this launch */
     };
     long long sum = 0;
     for (int q = 0; q < per; q++) {
@@ -459,10 +487,10 @@ __global__ void __launch_bounds__(OFFSETS_THREADS) k_offsets(MoveBuf mb, int W, 
             const long long b = bound_of(i);
             if (b >= 0) {
                 if (run + b > mb.pool_cap) {
-                    mb.sloff[i] = -1;
-                    mb.ctl[i / SLICE_SEG / mb.capC].overflow = 1;
+                    mb.sloff[phys(i)] = -1;
+                    mb.ctl[PS(i / SLICE_SEG / mb.capC)].overflow = 1;
                 } else {
-                    mb.sloff[i] = run;
+                    mb.sloff[phys(i)] = run;
                 }
                 run += b;
             }
@@ -472,7 +500,7 @@ __global__ void __launch_bounds__(OFFSETS_THREADS) k_offsets(MoveBuf mb, int W, 
     __syncthreads();
     for (int q = 0; q < per; q++) {
         const int i = tid * per + q;
-        if (i < n && bound_of(i) >= 0 && mb.ctl[i / SLICE_SEG / mb.capC].overflow) mb.sloff[i] = -1;
+        if (i < n && bound_of(i) >= 0 && mb.ctl[PS(i / SLICE_SEG / mb.capC)].overflow) mb.sloff[phys(i)] = -1;
     }
     /* the (slot, candidate) pairs of this launch by falling list size: the screening kernel's workgroups are as long as their
      * candidate's lists (two grown contigs: ten times the median), and the long ones handed out last were the launch's tail
@@ -533,6 +561,7 @@ __global__ void __launch_bounds__(256, SLICE_MIN_WAVES) k_slice(const long long*
                                                                  Glob* g, MoveBuf mb, int rank, int world, int w_begin, int share_rows, int max_j)
 {
     const int w = mb.order[mb.capC * mb.capW + blockIdx.z]; /* (the slots with the longest rows first: k_offsets; w_begin + z without it) */
+    if (KEPT(w)) return;
     const bool shared_plane = (blockIdx.y == 0); /* first: its waves write every kept contact once per candidate */
     const int cand_plane = (int)blockIdx.y - 1;
     __shared__ long long seg_off[IG_MAX_CANDIDATES][SLICE_SEG];
@@ -542,7 +571,7 @@ __global__ void __launch_bounds__(256, SLICE_MIN_WAVES) k_slice(const long long*
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     /* ONE round trip for everything the prologue needs (this launch is tens of thousands of short waves: every dependent load in
      * front of the rows counts): the slot's candidate count, the few fields of every candidate's window, every list start */
-    const int C = mb.ctl[w].C;
+    const int C = mb.ctl[PS(w)].C;
     const int capC = min(mb.capC, IG_MAX_CANDIDATES);
     if ((int)threadIdx.x < capC) {
         const CandMeta& mt = mb.meta[CW(w, threadIdx.x)]; /* (entries behind the slot's last candidate: stale but in bounds, not used) */
@@ -961,7 +990,7 @@ __device__ __forceinline__ void score_workgroup(ScoreLds<CAP>& L, const ScoreCon
 {
     /* everything the early exits and the set-up need is loaded before the first branch: one round trip, not five */
     const int cw = CW(w, c);
-    const int C = mb.ctl[w].C;
+    const int C = mb.ctl[PS(w)].C;
     const int n_uniq = mb.meta[cw].n_uniq, m_loc = mb.meta[cw].m_loc;
     const long long n_seg = mb.part[(size_t)cw * P_STRIDE + P_CNT + seg];
     const long long off = mb.sloff[(size_t)cw * SLICE_SEG + seg] + first;
@@ -1028,6 +1057,7 @@ __global__ void __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per
 {
     __shared__ ScoreLds<CAP> L;
     if (!contenders_only) { /* every column: the grid is (segment, column, candidate), a workgroup streams a whole segment */
+        if (KEPT(w_begin + (int)blockIdx.z / max_c)) return;
         score_workgroup<CAP>(L, sc, mb, lgf_tab, pz, ablate, w_begin + blockIdx.z / max_c, blockIdx.z % max_c, blockIdx.y, blockIdx.x, 0,
                              0x7fffffffffffffffLL);
         return;
@@ -1037,8 +1067,8 @@ __global__ void __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per
     if ((blockIdx.x >> 3) >= mb.work[blockIdx.x & 7]) return;
     const unsigned long long e = mb.work[16 + blockIdx.x];
     const int cw = (int)((e >> 12) & 0xfffffu), k = (int)((e >> 4) & 0xffu), seg = (int)(e & 0xfu);
-    const int w = cw / mb.capC;
-    const long long ch = mb.ctl[w].exact_chunk;
+    const int w = LW(cw / mb.capC); /* (the items carry the physical cw) */
+    const long long ch = mb.ctl[PS(w)].exact_chunk;
     score_workgroup<CAP>(L, sc, mb, lgf_tab, pz, ablate, w, cw % mb.capC, k, seg, (long long)(e >> 32) * ch, ch);
 }
 
@@ -1622,7 +1652,10 @@ __global__ void __launch_bounds__(SCORE_THREADS)
      * 2: the winner of slot w AFTER it was applied, under parameter set `which` (an accepted nuisance step: the maintained
      * sum under the new parameters = their full pass on the state before the move + this delta); the caller passes the
      * tables of the state before the move as `tab` */
-    if (predicted == 1) w += blockIdx.z;
+    if (predicted == 1) {
+        w += blockIdx.z;
+        if (KEPT(w)) return;
+    }
     /* tab_prev catches up with the last applied move before k_apply replaces the touched list (quirk Q12) */
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < (predicted ? 0 : g->n_prev_touched);
          i += gridDim.x * gridDim.y * blockDim.x) {
@@ -1635,7 +1668,7 @@ __global__ void __launch_bounds__(SCORE_THREADS)
     __shared__ uint2 lcol[LDS_COL_CAP];
     __shared__ long long red[2][SCORE_THREADS / 64];
     __shared__ int q_li[SCORE_THREADS / 64][128], q_lj[SCORE_THREADS / 64][128], q_ob[SCORE_THREADS / 64][128];
-    MoveCtl& mc = mb.ctl[w];
+    MoveCtl& mc = mb.ctl[PS(w)];
     if (g->error || (predicted == 0 && g->retry_pool) || (predicted == 1 ? mc.pred < 0 : (predicted == 0 && !mc.ch_windowed))) return;
     const int c = predicted == 1 ? mc.pred_c : mc.ch_c;
     const int cw = CW(w, c);
@@ -1750,7 +1783,8 @@ __global__ void __launch_bounds__(256) k_predict(Glob* g, MoveBuf mb, int w_begi
 {
     __shared__ double sc[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT];
     const int w = w_begin + blockIdx.x, tid = threadIdx.x;
-    MoveCtl& mc = mb.ctl[w];
+    if (KEPT(w)) return;
+    MoveCtl& mc = mb.ctl[PS(w)];
     const int C = mc.C, n = C * IG_N_TMP_STRUCT;
     if (cpre_at(mb, CW(w, 0)).overflow) return;
     /* the flags candidate 0 most likely sees: the live ones for the first slot, else those of the previous slot's last candidate */
@@ -1760,7 +1794,7 @@ __global__ void __launch_bounds__(256) k_predict(Glob* g, MoveBuf mb, int w_begi
     } else {
         /* pass 0: the previous slot's last candidate; pass 1: the family the previous slot's predicted winner (pass 0) would
          * leave the flags to (CL:2125-2126: a block-insert winner re-ran get_bounds for its own candidate) */
-        const MoveCtl& pc = mb.ctl[w - 1];
+        const MoveCtl& pc = mb.ctl[PS(w - 1)];
         int sel = pc.C - 1;
         if (pass == 1 && pc.pred_pad >= 0 && (pc.pred_pad % IG_N_TMP_STRUCT) >= 12) sel = pc.pred_pad / IG_N_TMP_STRUCT;
         const CandMeta& pm = mb.meta[CW(w - 1, sel)];
@@ -1839,7 +1873,7 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
                               const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int w_begin, int c, int w_rel, TailLds& TL)
 {
     const int w = w_begin + w_rel;
-    if (c >= mb.ctl[w].C) return;
+    if (KEPT(w) || c >= mb.ctl[PS(w)].C) return;
     const int cw = CW(w, c);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int M = mb.sM; /* stride; the bisection below runs over the global sub-fragment ids [0, mb.M) */
@@ -1978,7 +2012,17 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
     }
     __syncthreads();
     n_tail = min(TL.sh_n_tail, 64);
-    if (tid == 0 && n_tail != r) g->error = 5; /* the walk must find exactly r contacts */
+    if (tid == 0 && n_tail != r) { /* the walk must find exactly r contacts */
+        g->error = 5;
+        g->dbg[0] = w;
+        g->dbg[1] = c;
+        g->dbg[2] = r;
+        g->dbg[3] = n_tail;
+        g->dbg[4] = (int)Sc;
+        g->dbg[5] = KEPT(w);
+        g->dbg[6] = mb.rot;
+        g->dbg[7] = m.m_loc;
+    }
     if (tid < n_tail) {
         mb.tail_ent[(size_t)cw * 192 + tid] = TL.t_li[tid];
         mb.tail_ent[(size_t)cw * 192 + 64 + tid] = TL.t_lj[tid];
@@ -2018,7 +2062,7 @@ __global__ void __launch_bounds__(256) k_tail(const long long* __restrict__ rowp
 __global__ void __launch_bounds__(64) k_records(MoveBuf mb, int w_begin, int contenders_only)
 {
     const int c = blockIdx.x, w = w_begin + blockIdx.y;
-    if (c >= mb.ctl[w].C) return;
+    if (KEPT(w) || c >= mb.ctl[PS(w)].C) return;
     const int cw = CW(w, c);
     const CandMeta& m = mb.meta[cw];
     long long* qp = mb.qpart + (size_t)cw * Q_STRIDE;
@@ -2074,7 +2118,7 @@ __global__ void __launch_bounds__(64) k_records(MoveBuf mb, int w_begin, int con
         unsigned fm = 0;
         for (int q = 0; q < 12; q++) fm |= (m.flags[q] != -1) ? (1u << q) : 0u;
         cp.flag_mask = fm;
-        cp.overflow = mb.ctl[w].overflow; /* travels with the records: the slot must be re-run */
+        cp.overflow = mb.ctl[PS(w)].overflow; /* travels with the records: the slot must be re-run */
         cp.pred = -1; /* k_predict, k_delta */
         cp.pd_hi = cp.pd_lo = 0;
         cpre_at(mb, cw) = cp;

@@ -293,7 +293,7 @@ __device__ __forceinline__ void screen_column(ScreenLds& L, const ScreenConst* _
                                               int Q = 1)
 {
     const int cw = CW(w, c);
-    const int C = mb.ctl[w].C;
+    const int C = mb.ctl[PS(w)].C;
     const int n_uniq = mb.meta[cw].n_uniq, m_loc = mb.meta[cw].m_loc;
     long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + seg];
     long long off = mb.sloff[(size_t)cw * SLICE_SEG + seg];
@@ -509,6 +509,7 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
     /* (use_order: the launch covers the slots k_offsets ordered -- the long lists first) */
     const int oc = use_order ? mb.order[zc] : (((w_begin + zc / max_c) << 8) | (zc % max_c));
     const int w = oc >> 8, c = oc & 255;
+    if (KEPT(w)) return; /* (a slot of the window scored by an earlier launch and still valid) */
     const int cw = CW(w, c);
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned step = 64 * SCREEN_BATCH, stride = step * (SCORE_THREADS / 64);
@@ -520,7 +521,7 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
      * five had one such column and took the one-column routine -- 80 of the launch's 209 us (tools/screen_probe.py).  Pair y is the
      * (2 y)-th and (2 y + 1)-th live column instead: only a candidate's last, odd column is left alone. */
     const CandMeta* mp = &mb.meta[cw];
-    const int C = mb.ctl[w].C;
+    const int C = mb.ctl[PS(w)].C;
     const int n_uniq = mp->n_uniq, m_loc = mp->m_loc;
     const unsigned livecol = mb.livecol[cw]; /* bit k: column k's genome differs from the current one (k_mutate) */
     long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + seg];
@@ -946,7 +947,7 @@ __device__ __forceinline__ void screen_block_multi(const ScreenConst* __restrict
     const int cw = CW(w, c);
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const CandMeta* mp = &mb.meta[cw];
-    const int C = mb.ctl[w].C;
+    const int C = mb.ctl[PS(w)].C;
     const int n_uniq = mp->n_uniq, m_loc = mp->m_loc;
     const unsigned livecol = mb.livecol[cw];
     long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + seg];
@@ -1198,7 +1199,11 @@ __global__ void __launch_bounds__(256) k_contend(Glob* g, MoveBuf mb, const Scre
     __shared__ double s_best[4];
     __shared__ unsigned s_mask[IG_MAX_CANDIDATES], s_ident[IG_MAX_CANDIDATES];
     const int w = w_begin + blockIdx.x, tid = threadIdx.x;
-    const MoveCtl& mc = mb.ctl[w];
+    if (KEPT(w)) { /* (nothing of this slot on the exact kernel's work list: k_worklist adds up the slots in front of a slot) */
+        if (tid < 8) mb.slot_items[w * 8 + tid] = 0;
+        return;
+    }
+    const MoveCtl& mc = mb.ctl[PS(w)];
     const int C = mc.C, n = C * IG_N_TMP_STRUCT;
     const ig_params p = g->par[0];
     const double log_e = IG_LOG_E_F, n_tot_pxl = g->n_tot_pxl;
@@ -1293,7 +1298,7 @@ __global__ void __launch_bounds__(256) k_contend(Glob* g, MoveBuf mb, const Scre
          * whole segments, k_worklist flags the slot (overflow 2) and the host enlarges the grid) */
         long long ch = chunk0 > 0 ? chunk0 : EXACT_CHUNK;
         while (ch < (1LL << 40) && tot / ch + (long long)C * NSLOT * mb.nseg > grid_cap / 2) ch *= 2;
-        mb.ctl[w].exact_chunk = (int)ch;
+        mb.ctl[PS(w)].exact_chunk = (int)ch;
         s_kind[0] = (int)ch; /* (the intervals are done with) */
     }
     /* ... and how many items that is per sub-list (segment s -> sub-list s % 8): k_worklist places the slots in order from these */
@@ -1342,6 +1347,7 @@ __global__ void __launch_bounds__(256) k_worklist(MoveBuf mb, const unsigned* __
 {
     __shared__ int s_base[8], s_cnt[8], s_fit;
     const int w = w_begin + blockIdx.x, tid = threadIdx.x;
+    if (KEPT(w)) return;
     /* the items of the slots before this one, per sub-list (k_contend counted them) */
     if (tid < 8) {
         int base = 0;
@@ -1354,7 +1360,7 @@ __global__ void __launch_bounds__(256) k_worklist(MoveBuf mb, const unsigned* __
         bool fit = true;
         for (int x = 0; x < 8; x++) fit &= 8LL * (s_base[x] + s_cnt[x]) <= (long long)grid_cap;
         s_fit = fit;
-        if (!fit) mb.ctl[w].overflow = 2; /* 2: the exact kernel's grid (1: the slice pool, k_offsets) */
+        if (!fit) mb.ctl[PS(w)].overflow = 2; /* 2: the exact kernel's grid (1: the slice pool, k_offsets) */
         for (int x = 0; x < 8; x++) {
             if (fit) atomicMax(&mb.work[x], (unsigned long long)(s_base[x] + s_cnt[x])); /* the sub-lists end behind the last slot that fits */
             atomicMax(&mb.work[8 + x], (unsigned long long)(s_base[x] + s_cnt[x])); /* what the grid would have to cover (the host sizes the next one) */
@@ -1363,8 +1369,8 @@ __global__ void __launch_bounds__(256) k_worklist(MoveBuf mb, const unsigned* __
     if (tid < 8) s_cnt[tid] = 0; /* now: the slot's append cursors */
     __syncthreads();
     if (!s_fit) return;
-    const int C = mb.ctl[w].C;
-    const long long ch = mb.ctl[w].exact_chunk;
+    const int C = mb.ctl[PS(w)].C;
+    const long long ch = mb.ctl[PS(w)].exact_chunk;
     for (int u = tid; u < C * SLICE_SEG; u += blockDim.x) {
         const int c = u / SLICE_SEG, seg = u % SLICE_SEG;
         const int cw = CW(w, c);
@@ -1391,7 +1397,8 @@ __global__ void k_screen_verify(Glob* g, MoveBuf mb, const ScreenSum* __restrict
                                 const unsigned* __restrict__ scr_ub, int w_begin, double* worst)
 {
     const int w = w_begin + blockIdx.x;
-    const MoveCtl& mc = mb.ctl[w];
+    if (KEPT(w)) return;
+    const MoveCtl& mc = mb.ctl[PS(w)];
     for (int i = threadIdx.x; i < mc.C * NSLOT; i += blockDim.x) {
         const int c = i / NSLOT, k = i % NSLOT;
         const int cw = CW(w, c);

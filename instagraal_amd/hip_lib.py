@@ -132,11 +132,38 @@ class Neighbours:
     def put_numpy_state(key, pos, rest):
         np.random.set_state(("MT19937", key, int(pos)) + tuple(rest))
 
+    _mt_cache = [None, 0]
+
+    @staticmethod
+    def numpy_mt_address():
+        """address of numpy's GLOBAL legacy generator's mt19937_state {uint32 key[624]; int pos} (numpy/random/src/mt19937/mt19937.h),
+        through the bit generator's own ctypes interface -- or 0 where the layout check fails.  np.random.get_state() +
+        set_state() cost 50 - 130 us per pair (a tuple and a 2.5 KB copy each way): more than the draw of one move's candidates
+        through numpy itself; on the state in place a draw is a few microseconds.  (np.random.seed / set_state work in place.)"""
+        bg = np.random.mtrand._rand._bit_generator
+        if Neighbours._mt_cache[0] is not bg:
+            addr = 0
+            try:
+                a = int(bg.ctypes.state_address)
+                st = np.random.get_state()
+                key = np.frombuffer((C.c_uint32 * 624).from_address(a), np.uint32)
+                if st[0] == "MT19937" and np.array_equal(key, st[1]) and C.c_int32.from_address(a + 624 * 4).value == int(st[2]):
+                    addr = a
+            except Exception:
+                addr = 0
+            Neighbours._mt_cache = [bg, addr]
+        return Neighbours._mt_cache[1]
+
     def draw(self, frags, n_neighbours):
         """candidate lists of consecutive moves, consuming numpy's global generator exactly as successive
         return_neighbours calls would -> (n, n_neighbours) int32, sorted, -1 padded"""
         f = np.ascontiguousarray(frags, np.int32)
         out = np.full((f.size, int(n_neighbours)), -1, np.int32)
+        addr = self.numpy_mt_address()
+        if addr:  # on numpy's state in place
+            _ck(lib().ig_neighbours_draw(self._h, C.c_void_p(addr), C.c_void_p(addr + 624 * 4), _p(f), C.c_int32(f.size), C.c_int32(int(n_neighbours)),
+                                         _p(out)))
+            return out
         key, pos, rest = self.take_numpy_state()
         cpos = C.c_int32(pos)
         rc = lib().ig_neighbours_draw(self._h, _p(key), C.byref(cpos), _p(f), C.c_int32(f.size), C.c_int32(int(n_neighbours)), _p(out))
@@ -170,6 +197,11 @@ Neighbours.draw_nuisance = _neighbours_draw_nuisance
 def set_batch_width(w):
     """moves scored per launch by ``Context.step_batch`` (1 = one move at a time; results do not depend on it)"""
     _ck(lib().ig_set_batch_width(C.c_int(int(w))))
+
+
+def set_window(w):
+    """slots of the window of scored moves ig_step_batch keeps from launch to launch (0: off -- the batches of rounds 1 - 4)"""
+    _ck(lib().ig_set_window(C.c_int(int(w))))
 
 
 def set_nuis_width(w):

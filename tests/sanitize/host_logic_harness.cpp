@@ -143,10 +143,19 @@ static void model_decide(void** a, dim3, dim3)
         committed = w_start;
         g_conflicts++;
     }
-    int vals[12] = {0};
+    int vals[16] = {0};
     vals[0] = committed;
     vals[1] = pending;
     vals[2] = (committed == w_start && pending < 0) ? first : 0;
+    { /* the window rule (run_moves_window): some of the positions this launch did not commit hold slots that went stale -- the slot it
+       * stopped in front of at any rate, now and then a few behind it */
+        unsigned long long stale = 0ull;
+        if (committed < W && pending < 0) stale |= 1ull << committed;
+        for (int p2 = committed + 1; p2 < W && p2 < 64; p2++)
+            if (rnd() % 6 == 0) stale |= 1ull << p2;
+        vals[12] = (int)(unsigned)stale;
+        vals[13] = (int)(unsigned)(stale >> 32);
+    }
     vals[3] = 5 * (committed - w_start);
     vals[4] = 0;
     vals[5] = 1 + (int)(rnd() % 1000);
@@ -154,10 +163,10 @@ static void model_decide(void** a, dim3, dim3)
     vals[8] = g_grow_windows ? std::min(g_N / 2, 40 + (int)(rnd() % 200)) : 0;
     vals[9] = g_grow_windows ? std::min(g_M / 2, 100 + (int)(rnd() % 600)) : 0;
     vals[10] = stop;
-    for (int i = 0; i < 12; i++)
+    for (int i = 0; i < 16; i++)
         if (i != 7) bo[i] = vals[i];
     if (ho) {
-        for (int i = 0; i < 12; i++)
+        for (int i = 0; i < 16; i++)
             if (i != 7) ho[i] = vals[i];
         ho[7] = seq;
     }
@@ -427,13 +436,20 @@ int main()
                     g_force_retry = 0;
                 }
             }
-            for (int w : {24, 1, 7, 64}) {
+            for (int w : {24, 1, 7, 64}) { /* the batches of rounds 1 - 4 (no window) */
+                CHECK(ig_set_window(0) == 0);
                 CHECK(ig_set_batch_width(w) == 0);
                 g_grow_windows = (w == 7);
                 CHECK(ig_step_batch(c, n_moves, frags.data(), cands.data(), max_c, res.data()) == 0);
             }
-            g_grow_windows = 0;
             CHECK(ig_set_batch_width(24) == 0);
+            for (int w : {48, 2, 7, 64}) { /* the window rule (run_moves_window): kept slots, stale masks, regrown window buffers */
+                CHECK(ig_set_window(w) == 0);
+                g_grow_windows = (w == 7);
+                CHECK(ig_step_batch(c, n_moves, frags.data(), cands.data(), max_c, res.data()) == 0);
+            }
+            g_grow_windows = 0;
+            CHECK(ig_set_window(48) == 0);
             // the first slot of a batch does not fit the slice pool / the exact kernel's grid: more room, the batch again
             if ((size_t)c->mb.pool_cap < (size_t)std::max<long long>(c->Z, 1) * (size_t)std::max(c->mb.capC, 1)) { /* (a pool at its worst case cannot: a legitimate error) */
                 g_force_first_overflow = 1;

@@ -19,9 +19,12 @@ A slot scored when `t0` moves were committed is STALE at its turn iff a move in 
           slot known to be stale, and fills the window up with fresh slots; decisions strictly in order up to the first stale slot
           (all the live scalars, the stale insert flags and the zero-score rule stay exactly what they are today).
 
-For each: slots scored per committed move, moves per launch chain, and moves/s under the cost model of a chain measured in round 4
-(a + b * slots scored + c * moves decided; a = 280 us of latency-bound launches, b = 8 us per slot scored -- screen 4.6,
-slice 2.5, the rest --, c = 2.3 us per decision of the one deciding wave).
+For each: slots scored per committed move, moves per launch chain, and moves/s under the cost model of a chain RE-MEASURED in round 5 on
+today's code (bench.py at IG_BATCH_W = 24 / 32 / 48 / 64: 45.4 / 44.8 / 42.2 / 38.4 k moves/s, i.e. 521 / 900 / 1 172 us per batch of 24 / 48 / 64
+slots; profiles/r05b_cfg3_W24_kernel_stats.csv, r05b_cfg3_W48_kernel_stats.csv: every kernel of a batch grows 1.4 - 1.8 x from 24 to 48
+slots): a + b * slots scored + c * moves decided with a = 142 us, b = 15 us per slot scored, c = 1 us per decision.  (Round 4's DESIGN
+took 360 of a batch's 521 us for latency chains that "do not grow with W": they do.)  The model reproduces the recorded run -- rule (i) at
+W = 24 gives the recording's own number of batches and its rate to 1 %.
 
     python tools/commit_sim.py RECORDING.npz [...] [--out TABLE.txt]
 """
@@ -32,7 +35,7 @@ import time
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import numpy as np
 
-A_US, B_US, C_US = 280.0, 8.0, 2.3
+A_US, B_US, C_US = 142.0, 15.0, 1.0
 
 
 def replay(path, cache=True):
@@ -194,7 +197,8 @@ def main(argv):
         else:
             paths.append(a)
     lines = ["# tools/commit_sim.py: commit rules replayed on recorded trajectories of the HIP batch path (tools/record_moves.py, one MI355X);",
-             "# cost of a launch chain: %.0f us + %.1f us per slot scored + %.1f us per move decided (round 4's launches, DESIGN 4.2)" % (A_US, B_US, C_US),
+             "# cost of a launch chain: %.0f us + %.1f us per slot scored + %.1f us per move decided (re-measured in round 5: bench.py at" % (A_US, B_US, C_US),
+             "# IG_BATCH_W = 24 / 48 / 64 takes 521 / 900 / 1 172 us per batch -- every kernel of a batch grows with its slots, profiles/r05b_*)",
              "# rule (i) today: in-order, stop at the first stale slot, batch re-scored behind it; (ii) out of order: a slot commits unless a",
              "# contig it reads was written or may be written (read set of a blocked predecessor) earlier in the batch; (iii) in order over a",
              "# window of scored slots: stale slots re-scored, the window filled up, decisions strictly in order"]

@@ -3,10 +3,11 @@
 For a stream of seeded random problems (bins, contacts per bin, contig lengths, cis share, count scale, neighbours per move) and P(s)
 parameters (the synthetic defaults, a settled chain's, random slopes / d_max) the same run of moves goes
 
-    A  through speculative batches of 24 slots, two-tier scoring, the fused decide + apply launch      (the default)
+    A  through a window of 48 scored slots, two-tier scoring, the fused decide + apply launch          (the default)
     B  one move per call through the exact kernel on every column                                      (step_sampler)
     C  batches with every column through the exact kernel                                              (IG_SCREEN=0)
-    D  batches of another width (2 .. 40 slots), 12-byte list entries now and then                     (ig_set_batch_width, IG_WIDE_LISTS)
+    D  a window of another width (2 .. 40 slots), 12-byte list entries now and then                    (ig_set_window, IG_WIDE_LISTS)
+    F  no window: batches of that width, dropped behind their first conflict (rounds 1 - 4)             (ig_set_window(0), ig_set_batch_width)
     E  batches with the zero-score fault injection                                                     (ig_debug_set_zero_inject)
 
 and must return the same move records and genome; the maintained exact sums must equal a from-scratch pass in every run.
@@ -76,7 +77,10 @@ def run(prob, params, n, n_nb, seed, mode, width=0, wide=0, inject=0):
         os.environ["IG_SCREEN"] = "0"
     if wide:
         os.environ["IG_WIDE_LISTS"] = "1"
-    hip_lib.set_batch_width(width if width else 24)
+    # D: a window of `width` slots (round 5: the scored slots of the moves ahead stay scored from launch to launch); F: no window -- batches
+    # of `width` slots dropped behind their first conflict (rounds 1 - 4)
+    hip_lib.set_window(0 if mode == "F" else (width if width else 48))
+    hip_lib.set_batch_width(width if (width and mode == "F") else 24)
     hip_lib.debug_set_zero_inject(inject)
     try:
         np.random.seed(seed)
@@ -106,6 +110,7 @@ def run(prob, params, n, n_nb, seed, mode, width=0, wide=0, inject=0):
         os.environ.pop("IG_SCREEN", None)
         os.environ.pop("IG_WIDE_LISTS", None)
         hip_lib.set_batch_width(24)
+        hip_lib.set_window(48)
         hip_lib.debug_set_zero_inject(0)
 
 
@@ -123,7 +128,8 @@ for k in range(n_cases):
         a, sa, sc = run(prob, params, n, n_nb, seed, "A")
         b, _, _ = run(prob, params, n, n_nb, seed, "B")
         d, sd, _ = run(prob, params, n, n_nb, seed, "D", width=width, wide=wide)
-        ok = a == b and d == b
+        f, _, _ = run(prob, params, n, n_nb, seed, "F", width=width)
+        ok = a == b and d == b and f == b
         extra = ""
         if k % 2 == 0:
             c, _, _ = run(prob, params, n, n_nb, seed, "C")
@@ -135,7 +141,7 @@ for k in range(n_cases):
             extra += " +inject(%d fallbacks)" % se["zero_fallbacks"]
         which = ""
         if not ok:
-            which = " [A==B %s, D==B %s, A==D %s]" % (a == b, d == b, a == d)
+            which = " [A==B %s, D==B %s, F==B %s, A==D %s]" % (a == b, d == b, f == b, a == d)
             ra, rb = eval(a[0]), eval(b[0])
             for i, (x, y) in enumerate(zip(ra, rb)):
                 if x != y:
