@@ -359,6 +359,11 @@ class Context:
         f = np.ascontiguousarray(frags, np.int32)
         res = np.zeros(f.size, MOVE_RESULT_DTYPE)
         cands = np.full((f.size, int(n_neighbours)), -1, np.int32)
+        addr = Neighbours.numpy_mt_address()
+        if addr:  # on numpy's generator state in place (this thread waits inside the call while the library's thread draws)
+            _ck(lib().ig_step_batch_draw(self._h, neighbours._h, C.c_void_p(addr), C.c_void_p(addr + 624 * 4), C.c_int32(f.size), _p(f),
+                                         C.c_int32(int(n_neighbours)), _p(cands), _p(res)))
+            return res, cands
         key, pos, rest = Neighbours.take_numpy_state()
         cpos = C.c_int32(pos)
         rc = lib().ig_step_batch_draw(self._h, neighbours._h, _p(key), C.byref(cpos), C.c_int32(f.size), _p(f),
