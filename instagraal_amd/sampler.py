@@ -487,7 +487,14 @@ class sampler:  # noqa: N801 - the reference's class name
                 tuples.append(self.step_nuisance_parameters(dt, t0 + i, n_step))
             return res, tuples
         with opti.quiet_runs():
-            return self._nuisance_run(frags, n_neighbours, t0, n_step, res)
+            tuples, n_done = self._nuisance_run(frags, n_neighbours, t0, n_step, res)
+        if n_done < n:
+            # an accepted step took d_nuc to 0 (sigma_d_nuc with it: CL:2973): from the next step on the reference draws no normal for
+            # id_modif == 3 (CL:3007-3010) and the stream drawn up front is not the reference's any more -- the rest one step at a time
+            rest, more = self.step_sampler_nuisance_batch(frags[n_done:], n_neighbours, dt, t0 + n_done, n_step)
+            res[n_done:] = rest
+            tuples += more
+        return res, tuples
 
     def _nuisance_run(self, frags, n_neighbours, t0, n_step, res):
         """the run of (move, nuisance step) pairs.  Two kinds of library calls: a CHAIN (``ig_nuis_chain_begin``: the pairs ahead as far
@@ -499,6 +506,7 @@ class sampler:  # noqa: N801 - the reference's class name
         import time as _t
 
         n = frags.size
+        stream0 = np.random.get_state()  # (a run that ends early rewinds to its last step: `stop`)
         cands, id_modif, gauss, unif = self.neighbours.draw_nuisance(frags, max(1, n_neighbours))
         mean_kb = self.mean_kb()
         gauss_l, id_modif_l, unif_l = gauss.tolist(), id_modif.tolist(), unif.tolist()
@@ -536,6 +544,7 @@ class sampler:  # noqa: N801 - the reference's class name
         success_of = np.zeros(n, np.int8)
         lik_acc = {}
         patch = None  # (step, z)
+        stop = [None]  # the run ends behind this many pairs: an accepted step left sigma_d_nuc <= 0 (step_sampler_nuisance_batch)
 
         def fill_in():
             j, zj = patch
@@ -553,6 +562,8 @@ class sampler:  # noqa: N801 - the reference's class name
             lik_acc[i] = lik_nuis
             if deferred:
                 patch = (i, z)
+            if self.sigma_d_nuc <= 0:
+                stop[0] = i + 1
 
         def pairs_pipelined(i0, i1):
             """steps i0 .. i1 - 1, one pair per library call with the next step begun inside the call that ends this one (the loop of
@@ -586,6 +597,7 @@ class sampler:  # noqa: N801 - the reference's class name
                         self.ctx.nuis_accept()
                 if success:
                     accepted(i, p8, lik_nuis, deferred, z)
+                    has_next = has_next and stop[0] is None
                     nxt = prop(i + 1) if has_next else None  # (under the promoted parameters)
                 ep_of[i] = len(epochs) - 1
                 success_of[i] = success
@@ -602,6 +614,8 @@ class sampler:  # noqa: N801 - the reference's class name
                 prof["book"] += t3 - t2
                 if trace is not None:
                     trace.append((t3 - ta, int(success)))
+                if stop[0] is not None:
+                    return
 
         self.ctx.nuis_run_begin(frags, cands)
         i = 0
@@ -613,7 +627,7 @@ class sampler:  # noqa: N801 - the reference's class name
             if not use_chain:
                 pairs_pipelined(0, n)
                 i = n
-            while i < n:
+            while i < n and stop[0] is None:
                 if self._nuis_acc_ema > 0.3 or empty >= 4:
                     # (the first steps of a run's first nuisance cycle: a third of the proposals accepted; or chains that get nowhere:
                     # a chain only ever rejects, and only from a certain interval -- one pair per call for a while, then another try)
@@ -701,10 +715,14 @@ class sampler:  # noqa: N801 - the reference's class name
         if patch is not None:
             fill_in()
         # the records of all moves at once; the 8-tuples from them
-        res[:] = self.ctx.batch_results(n)
+        n_done = n if stop[0] is None else stop[0]
+        if n_done < n:  # the generator where the reference's is behind pair n_done - 1 (the same draws again: their number per pair is fixed while sigma_d_nuc > 0)
+            np.random.set_state(stream0)
+            self.neighbours.draw_nuisance(frags[:n_done], max(1, n_neighbours))
+        res[:n_done] = self.ctx.batch_results(n_done)
         o_col = res["o"]
         tuples = []
-        for k in range(n):
+        for k in range(n_done):
             kuhn, lm, c1, slope, d, d_max, fact, d_nuc = epochs[ep_of[k]][0]
             lik = lik_acc[k] if success_of[k] else o_col[k]
             tuples.append((fact, d, d_max, d_nuc, slope, lik, int(success_of[k]), None))
@@ -712,12 +730,12 @@ class sampler:  # noqa: N801 - the reference's class name
         if last_test[0] is not None:
             self.param_simu_test = as_array(last_test[0])
         self.likelihood_t = tuples[-1][5]
-        last = res[-1]
+        last = res[n_done - 1]
         self.o = float(last["o"])
         self.n_contigs = np.int32(last["n_contigs"])
         self.mean_length_contigs = np.float32(last["mean_len"])
-        self.candidates = [int(x) for x in cands[-1] if x >= 0]
-        return res, tuples
+        self.candidates = [int(x) for x in cands[n_done - 1] if x >= 0]
+        return tuples, n_done
 
     def free_gpu(self):  # CL:3167-3177
         self.ctx.close()

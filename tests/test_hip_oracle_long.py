@@ -6,6 +6,8 @@ HIP-against-HIP: a three-round-old wrong-result bug (the one-move path ignoring 
 * ``test_fuzz_cases_against_the_oracle`` -- tools/fuzz_oracle.py's generator (60 - 2 000 bins, contigs of 2 - 1 000 bins, 1 - 16
   neighbours, counts x 9 / x 60, --bomb'ed starts, small slice pools, synthetic / settled / random parameters; batches of 24, other
   widths, one step_sampler call per move): 40 seeded cases, 6-tuples, 17 x N state, stale flags, generator state.
+* ``test_nuisance_run_whose_d_nuc_reaches_zero`` -- the two cases of that generator that found the round's one difference on the
+  nuisance path (the generator's consumption after d_nuc rounds to 0 inside a call).
 * ``test_long_trajectory_live_oracle`` -- whole cycles of the reference's loop (IG:196-262) through ``step_sampler_batch`` against
   ``OracleSampler(DET).step_sampler`` (CL:1401-1465; KA:485-607, 612-3693), state compared every 250 moves: `small` for 5 full cycles
   from the assembled and from the --bomb'ed genome, `bigctg` (windows of 3 000 - 9 000 sub-fragments) and `bigctg --bomb`.
@@ -52,6 +54,24 @@ def test_fuzz_cases_against_the_oracle():
     print("fuzz against the oracle: %d moves, %d kinds of runs" % (n_moves, len(kinds)))
     assert not bad, bad
     assert n_moves >= 4000 and len(kinds) >= 6, (n_moves, kinds)
+
+
+@pytest.mark.parametrize("seed", [5072, 5123])
+def test_nuisance_run_whose_d_nuc_reaches_zero(seed):
+    """tools/fuzz_oracle.py's first finding on the nuisance path (round 5): 60 bins under parameters that run away (d_max 1e30, d_nuc a
+    float32 denormal) -- an accepted step rounds d_nuc to 0, sigma_d_nuc with it, and from the next step on the reference draws no normal
+    for id_modif == 3 (CL:2973, 3007-3010): the one case where the stream's consumption depends on the parameters.  Until round 5 the
+    host looked at sigma_d_nuc at the start of a call only and went on with the stream it had drawn up front: other candidates from the
+    first such step on.  Now a run ends behind the accepted step, rewinds the generator and takes the rest one step at a time."""
+    fo = _tool("fuzz_oracle")
+    prob, params, desc = fo.make_case(seed)
+    assert desc["how"] == "nuis"
+    h = fo.run_hip(prob, params, desc)
+    d_nuc = h["nuis"][:, 3]
+    first = int(np.nonzero(d_nuc == 0.0)[0][0])
+    assert 0 < first < desc["n"] - 20 and first % fo.CHECK_EVERY not in (0, fo.CHECK_EVERY - 1), first  # inside a call, moves behind it
+    _, diff = fo.run_oracle(prob, params, desc, 0, expect=h)
+    assert diff is None, diff
 
 
 @pytest.mark.parametrize("cfg,moves,bomb", [("small", 5000, False), ("small", 5000, True), ("bigctg", 2000, False), ("bigctg", 4000, True)])

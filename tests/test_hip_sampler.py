@@ -153,16 +153,22 @@ def test_batch_equals_step_by_step():
 
 @pytest.mark.parametrize("cfg,n_moves", [("tiny", 150), ("small", 400)])
 def test_speculative_batches_equal_one_move_at_a_time(cfg, n_moves):
-    """ig_step_batch scores W moves against one state and commits them in order on the device; every result
-    record, the final genome, the maintained exact sums and the pre-move tables (quirk Q12) must not depend on W."""
+    """ig_step_batch scores W moves against one state and commits them in order on the device -- as fresh batches (rounds 1 - 4) or over
+    a window of slots that stay scored from launch to launch (round 5); every result record, the final genome, the
+    maintained exact sums and the pre-move tables (quirk Q12) must not depend on the rule or its width."""
     from instagraal_amd import hip_lib, synth
     from instagraal_amd.sampler import sampler as hip_sampler
 
     prob = synth.make_problem(*synth.CONFIGS[cfg])
     outs = []
     try:
-        for W in (1, 2, 5, 16, 32):
+        # one move at a time; round 4's batches (no window) of 2 .. 32 slots; round 5's window of scored slots, 2 .. 64 wide (kept slots
+        # validated on the device against the live genome: IG_WINDOW_CHECK)
+        os.environ["IG_WINDOW_CHECK"] = "1"
+        modes = [(1, 0), (2, 0), (5, 0), (16, 0), (32, 0), (24, 2), (24, 7), (24, 48), (24, 64)]
+        for W, win in modes:
             hip_lib.set_batch_width(W)
+            hip_lib.set_window(win)
             np.random.seed(9)
             s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
             s.set_param_simu(prob.params)
@@ -178,11 +184,14 @@ def test_speculative_batches_equal_one_move_at_a_time(cfg, n_moves):
                          [int(x) for x in prev[2]], [int(x) for x in s.ctx.valid_insert()], s.ctx.batch_stats()))
     finally:
         hip_lib.set_batch_width(24)
-    for W, o in zip((2, 5, 16, 32), outs[1:]):
+        hip_lib.set_window(48)
+        os.environ.pop("IG_WINDOW_CHECK", None)
+    for W, o in zip(modes[1:], outs[1:]):
         assert o[0] == outs[0][0], W
         assert np.array_equal(o[1], outs[0][1]), W
         assert o[2:6] == outs[0][2:6], W
     assert outs[3][6]["batches"] < n_moves  # speculation actually happened
+    assert outs[7][6]["batches"] < outs[3][6]["batches"]  # ... and a window of 48 needs fewer launch chains than batches of 16
 
 
 def test_large_windows_match_oracle():

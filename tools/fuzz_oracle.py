@@ -3,8 +3,9 @@
 tools/fuzz_batches.py / fuzz_chains.py / fuzz_ranks.py compare the library with itself -- they catch a path that disagrees with its
 siblings, not a mistake the paths share.  Here every case is one run of moves through
 
-    HIP     sampler.step_sampler_batch (speculative batches, two-tier scoring, the candidate draw inside the call: the path bench.py
-            times; some cases at another batch width, with a small slice pool, or one reference-shaped step_sampler call per move)
+    HIP     sampler.step_sampler_batch (the window of scored slots, two-tier scoring, the candidate draw inside the call: the path bench.py
+            times; some cases at another window width, without the window, with a small slice pool, one reference-shaped step_sampler call
+            per move, or with a nuisance step behind every move: step_sampler_nuisance_batch)
     ORACLE  OracleSampler(DET).step_sampler, one move at a time, on numpy's generator (CL:1401-1465, 3103-3141; KA:485-607, 612-3693)
 
 from the same seeded state and the two must agree on: the 6-tuple of every move (score, genome distance, winner, partner, mean contig
@@ -84,13 +85,17 @@ def make_case(seed):
     n_nb = int(r.choice([1, 3, 5, 5, 9, 16]))
     bomb = int(r.randint(4) == 0)
     pool = int(r.choice([0, 0, 0, 3000, 30000]))
-    how = str(r.choice(["batch", "batch", "batch", "width", "one"]))  # default batches / another width / one step_sampler call per move
-    width = int(r.choice([2, 3, 7, 16, 31, 40])) if how == "width" else 24
+    # the default window / another width / no window (round 4's batches) / one step_sampler call per move / a nuisance step behind every
+    # move (step_sampler_nuisance_batch: chains, screened tiers -- against o.step_sampler + o.step_nuisance_parameters, CL:2961-3051)
+    how = str(r.choice(["batch", "batch", "width", "nowindow", "one", "nuis"]))
+    width = int(r.choice([2, 3, 7, 16, 31, 40, 64])) if how in ("width", "nowindow") else 0
     # the oracle's cost per move: (1 + C) passes over all contacts, C x 24 columns over the slice (about 2 Z / contigs entries, all of
     # them late in an assembly), ~250 rewrites of the genome per candidate; moves so that a case stays within ~10 core-seconds
     Z, C = prob.n_contacts, min(n_nb, 16)
     n_ctg = max(1, n_frags // mean_len) if not bomb else n_frags
     per_move = 8e-9 * Z * (1 + C) + 45e-9 * 21 * C * min(Z, 3.0 * Z / n_ctg) + 1.5e-6 * n_frags * C + 3e-3
+    if how == "nuis":
+        per_move += 8e-9 * Z
     n = int(min(int(r.choice([100, 250, 500])), max(40, 10.0 / per_move)))
     desc = dict(seed=int(seed), n_frags=n_frags, per=per, mean_len=mean_len, scale=scale, params=kind, n=n, neighbours=n_nb, bomb=bomb,
                 pool=pool, how=how, width=width)
@@ -109,7 +114,13 @@ def run_hip(prob, params, desc):
     os.environ.pop("IG_POOL_ENTRIES", None)
     if desc["pool"]:
         os.environ["IG_POOL_ENTRIES"] = str(desc["pool"])
-    hip_lib.set_batch_width(desc["width"])
+    try:
+        hip_lib.set_window(0 if desc["how"] == "nowindow" else (desc["width"] if desc["how"] == "width" else 48))
+    except AttributeError:  # (an older build of the library under IG_DEBUG_TUNING=1 IG_HIP_LIB=...: no window rule)
+        pass
+    hip_lib.set_batch_width(min(desc["width"], 64) if desc["how"] == "nowindow" else 24)
+    if desc["how"] == "nuis":
+        hip_lib.set_nuis_hist(2)  # (the histogram tier whatever its cost model says: chains need it)
     try:
         np.random.seed(desc["seed"])
         s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
@@ -118,10 +129,15 @@ def run_hip(prob, params, desc):
         if desc["bomb"]:
             s.bomb_the_genome()
         frags = _frags(prob, desc["n"])
-        rec, states, flags = [], [], []
+        rec, states, flags, nrec = [], [], [], []
         for i0 in range(0, len(frags), CHECK_EVERY):
             part = frags[i0:i0 + CHECK_EVERY]
-            if desc["how"] == "one":
+            if desc["how"] == "nuis":
+                res, tuples = s.step_sampler_nuisance_batch(part, desc["neighbours"], s.dt, i0, len(frags))
+                rec += [(float(q["o"]), float(q["dist"]), int(q["op_sampled"]), int(q["id_f_sampled"]), float(np.float32(q["mean_len"])),
+                         int(q["n_contigs"])) for q in res]
+                nrec += [tuple(float(np.ravel(x)[0]) for x in q[:7]) for q in tuples]
+            elif desc["how"] == "one":
                 for f in part:
                     o, dist, op, idf, ml, nc = s.step_sampler(int(f), desc["neighbours"])
                     rec.append((float(o), float(dist), int(op), int(idf), float(ml), int(nc)))
@@ -133,12 +149,19 @@ def run_hip(prob, params, desc):
             flags.append(np.array(s.ctx.valid_insert(), np.int32))
         st = np.random.get_state()
         stats = dict(s.ctx.batch_stats(), pool_retries=s.ctx.debug_pool_retries())
+        if desc["how"] == "nuis":
+            stats["chain_pairs"] = s.ctx.debug_nuis_chain_stats()["pairs"]
         s.free_gpu()
         return dict(records=np.array(rec, np.float64).reshape(-1, 6), states=np.array(states, np.int32), flags=np.array(flags, np.int32),
-                    rng_key=np.array(st[1], np.uint32), rng_pos=int(st[2]), stats=stats)
+                    nuis=np.array(nrec, np.float64).reshape(-1, 7), rng_key=np.array(st[1], np.uint32), rng_pos=int(st[2]), stats=stats)
     finally:
         os.environ.pop("IG_POOL_ENTRIES", None)
         hip_lib.set_batch_width(24)
+        try:
+            hip_lib.set_window(48)
+        except AttributeError:
+            pass
+        hip_lib.set_nuis_hist(1)
 
 
 def run_oracle(prob, params, desc, threads=0, expect=None):
@@ -167,6 +190,11 @@ def run_oracle(prob, params, desc, threads=0, expect=None):
             if expect is not None and diff is None and tuple(expect["records"][t]) != row:
                 diff = "move %d (bin %d): HIP %r / oracle %r" % (t, int(f), tuple(expect["records"][t]), row)
                 break
+            if desc["how"] == "nuis":
+                q = tuple(float(np.ravel(x)[0]) for x in o.step_nuisance_parameters(o.dt, t, len(frags))[:7])
+                if expect is not None and diff is None and tuple(expect["nuis"][t]) != q:
+                    diff = "nuisance step %d: HIP %r / oracle %r" % (t, tuple(expect["nuis"][t]), q)
+                    break
             if (t + 1) % CHECK_EVERY == 0 or t + 1 == len(frags):
                 k = len(states)
                 states.append(o.gpu_vect_frags.soa17())
@@ -205,7 +233,7 @@ def _check_one(args):
     z = np.load(path, allow_pickle=False)
     pre = "c%d_" % seed
     exp = dict(records=z[pre + "records"], state_digests=z[pre + "state_digests"], state_last=z[pre + "state_last"], flags=z[pre + "flags"],
-               rng_key=z[pre + "rng_key"], rng_pos=int(z[pre + "rng_pos"]))
+               nuis=z[pre + "nuis"] if pre + "nuis" in z.files else np.zeros((0, 7)), rng_key=z[pre + "rng_key"], rng_pos=int(z[pre + "rng_pos"]))
     prob, params, desc = make_case(seed)
     assert desc["n"] == len(exp["records"]), "the recording was made by another generator"
     t0 = time.time()
@@ -264,7 +292,7 @@ def main(argv):
             t1 = time.time()
             if record:
                 pre = "c%d_" % seed
-                for k in ("records", "flags", "rng_key"):
+                for k in ("records", "flags", "rng_key", "nuis"):
                     store[pre + k] = h[k]
                 store[pre + "state_digests"] = np.array([_digest(x) for x in h["states"]], np.uint64)  # (64 MiB come back from a GPU box)
                 store[pre + "state_last"] = h["states"][-1]
