@@ -20,6 +20,7 @@ The two halves need different machines' strengths (one MI355X for seconds, host 
     python tools/fuzz_oracle.py CASES [FIRST_SEED]                      both, live (a GPU box)
     python tools/fuzz_oracle.py CASES [FIRST_SEED] --record FILE.npz    HIP only: what it returned, per case      (a GPU box)
     python tools/fuzz_oracle.py --check FILE.npz [--jobs J]             the oracle against a recording            (no GPU needed)
+    ... --how nuis | batch | width | nowindow | one                      every case in that mode (with --check: as recorded)
 """
 import os
 import sys
@@ -47,6 +48,9 @@ def _state_equal(expect, k, arr):
     if k == len(expect["state_digests"]) - 1 and "state_last" in expect:
         return np.array_equal(expect["state_last"], arr)
     return expect["state_digests"][k] == _digest(arr)
+
+
+FORCE_HOW = None  # (--how: every case of a run in one mode)
 
 
 def make_case(seed):
@@ -88,6 +92,8 @@ def make_case(seed):
     # the default window / another width / no window (round 4's batches) / one step_sampler call per move / a nuisance step behind every
     # move (step_sampler_nuisance_batch: chains, screened tiers -- against o.step_sampler + o.step_nuisance_parameters, CL:2961-3051)
     how = str(r.choice(["batch", "batch", "width", "nowindow", "one", "nuis"]))
+    if FORCE_HOW:
+        how = FORCE_HOW
     width = int(r.choice([2, 3, 7, 16, 31, 40, 64])) if how in ("width", "nowindow") else 0
     # the oracle's cost per move: (1 + C) passes over all contacts, C x 24 columns over the slice (about 2 Z / contigs entries, all of
     # them late in an assembly), ~250 rewrites of the genome per candidate; moves so that a case stays within ~10 core-seconds
@@ -97,8 +103,15 @@ def make_case(seed):
     if how == "nuis":
         per_move += 8e-9 * Z
     n = int(min(int(r.choice([100, 250, 500])), max(40, 10.0 / per_move)))
+    # the nuisance runs' own knobs: the histogram tier always / where its cost model says / never, chains on / off, the moves per call
+    # (drawn behind everything else: the shapes of the seeds of earlier rounds stay what they were)
+    hist = int(r.choice([2, 2, 1, 0]))
+    chain = int(r.randint(4) != 0)
+    chunk = int(r.choice([50, 50, 17, 1000])) if how == "nuis" else CHECK_EVERY
     desc = dict(seed=int(seed), n_frags=n_frags, per=per, mean_len=mean_len, scale=scale, params=kind, n=n, neighbours=n_nb, bomb=bomb,
                 pool=pool, how=how, width=width)
+    if how == "nuis":
+        desc.update(hist=hist, chain=chain, chunk=chunk)
     return prob, params, desc
 
 
@@ -119,8 +132,10 @@ def run_hip(prob, params, desc):
     except AttributeError:  # (an older build of the library under IG_DEBUG_TUNING=1 IG_HIP_LIB=...: no window rule)
         pass
     hip_lib.set_batch_width(min(desc["width"], 64) if desc["how"] == "nowindow" else 24)
+    every = desc.get("chunk", CHECK_EVERY)
     if desc["how"] == "nuis":
-        hip_lib.set_nuis_hist(2)  # (the histogram tier whatever its cost model says: chains need it)
+        hip_lib.set_nuis_hist(desc.get("hist", 2))  # (2: the histogram tier whatever its cost model says -- chains need it)
+        hip_lib.set_nuis_chain(desc.get("chain", 1))
     try:
         np.random.seed(desc["seed"])
         s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
@@ -130,8 +145,8 @@ def run_hip(prob, params, desc):
             s.bomb_the_genome()
         frags = _frags(prob, desc["n"])
         rec, states, flags, nrec = [], [], [], []
-        for i0 in range(0, len(frags), CHECK_EVERY):
-            part = frags[i0:i0 + CHECK_EVERY]
+        for i0 in range(0, len(frags), every):
+            part = frags[i0:i0 + every]
             if desc["how"] == "nuis":
                 res, tuples = s.step_sampler_nuisance_batch(part, desc["neighbours"], s.dt, i0, len(frags))
                 rec += [(float(q["o"]), float(q["dist"]), int(q["op_sampled"]), int(q["id_f_sampled"]), float(np.float32(q["mean_len"])),
@@ -162,6 +177,7 @@ def run_hip(prob, params, desc):
         except AttributeError:
             pass
         hip_lib.set_nuis_hist(1)
+        hip_lib.set_nuis_chain(1)
 
 
 def run_oracle(prob, params, desc, threads=0, expect=None):
@@ -195,7 +211,7 @@ def run_oracle(prob, params, desc, threads=0, expect=None):
                 if expect is not None and diff is None and tuple(expect["nuis"][t]) != q:
                     diff = "nuisance step %d: HIP %r / oracle %r" % (t, tuple(expect["nuis"][t]), q)
                     break
-            if (t + 1) % CHECK_EVERY == 0 or t + 1 == len(frags):
+            if (t + 1) % desc.get("chunk", CHECK_EVERY) == 0 or t + 1 == len(frags):
                 k = len(states)
                 states.append(o.gpu_vect_frags.soa17())
                 flags.append(np.array(o.gpu_list_valid_insert, np.int32))
@@ -229,8 +245,10 @@ def live_case(seed, threads=0):
 
 
 def _check_one(args):
+    global FORCE_HOW
     path, seed, threads = args
     z = np.load(path, allow_pickle=False)
+    FORCE_HOW = (str(z["how"]) or None) if "how" in z.files else None
     pre = "c%d_" % seed
     exp = dict(records=z[pre + "records"], state_digests=z[pre + "state_digests"], state_last=z[pre + "state_last"], flags=z[pre + "flags"],
                nuis=z[pre + "nuis"] if pre + "nuis" in z.files else np.zeros((0, 7)), rng_key=z[pre + "rng_key"], rng_pos=int(z[pre + "rng_pos"]))
@@ -253,6 +271,9 @@ def main(argv):
             check = next(it)
         elif a == "--jobs":
             jobs = int(next(it))
+        elif a == "--how":
+            global FORCE_HOW
+            FORCE_HOW = next(it)
         else:
             pos.append(a)
     t00 = time.time()
@@ -314,6 +335,7 @@ def main(argv):
             print("case %5d FAIL %s: %r" % (seed, desc, ex), flush=True)
     if record:
         store["seeds"] = np.array(done, np.int64)
+        store["how"] = np.array(FORCE_HOW or "")
         np.savez_compressed(record, **store)
         print("%d cases recorded in %s (%.1f MB), %d failed, %.0f s" % (len(done), record, os.path.getsize(record) / 1e6, bad, time.time() - t00))
     else:
