@@ -51,6 +51,7 @@ def _state_equal(expect, k, arr):
 
 
 FORCE_HOW = None  # (--how: every case of a run in one mode)
+LONG = 1  # (--long K: K times the moves per case, and K times the oracle's budget -- runaway parameters take hundreds of accepted steps)
 
 
 def make_case(seed):
@@ -102,7 +103,7 @@ def make_case(seed):
     per_move = 8e-9 * Z * (1 + C) + 45e-9 * 21 * C * min(Z, 3.0 * Z / n_ctg) + 1.5e-6 * n_frags * C + 3e-3
     if how == "nuis":
         per_move += 8e-9 * Z
-    n = int(min(int(r.choice([100, 250, 500])), max(40, 10.0 / per_move)))
+    n = int(min(int(r.choice([100, 250, 500])) * LONG, max(40, 10.0 * LONG / per_move)))
     # the nuisance runs' own knobs: the histogram tier always / where its cost model says / never, chains on / off, the moves per call
     # (drawn behind everything else: the shapes of the seeds of earlier rounds stay what they were)
     hist = int(r.choice([2, 2, 1, 0]))
@@ -245,10 +246,11 @@ def live_case(seed, threads=0):
 
 
 def _check_one(args):
-    global FORCE_HOW
+    global FORCE_HOW, LONG
     path, seed, threads = args
     z = np.load(path, allow_pickle=False)
     FORCE_HOW = (str(z["how"]) or None) if "how" in z.files else None
+    LONG = int(z["long"]) if "long" in z.files else 1
     pre = "c%d_" % seed
     exp = dict(records=z[pre + "records"], state_digests=z[pre + "state_digests"], state_last=z[pre + "state_last"], flags=z[pre + "flags"],
                nuis=z[pre + "nuis"] if pre + "nuis" in z.files else np.zeros((0, 7)), rng_key=z[pre + "rng_key"], rng_pos=int(z[pre + "rng_pos"]))
@@ -274,6 +276,9 @@ def main(argv):
         elif a == "--how":
             global FORCE_HOW
             FORCE_HOW = next(it)
+        elif a == "--long":
+            global LONG
+            LONG = int(next(it))
         else:
             pos.append(a)
     t00 = time.time()
@@ -336,6 +341,7 @@ def main(argv):
     if record:
         store["seeds"] = np.array(done, np.int64)
         store["how"] = np.array(FORCE_HOW or "")
+        store["long"] = np.int64(LONG)
         np.savez_compressed(record, **store)
         print("%d cases recorded in %s (%.1f MB), %d failed, %.0f s" % (len(done), record, os.path.getsize(record) / 1e6, bad, time.time() - t00))
     else:
