@@ -117,6 +117,14 @@ int ig_neighbours_draw(ig_neighbours* nb, uint32_t* mt_key624, int32_t* mt_pos, 
 int ig_neighbours_draw_nuisance(ig_neighbours* nb, uint32_t* mt_key624, int32_t* mt_pos, int32_t* has_gauss, double* gauss,
                                 const int32_t* frags, int32_t n_moves, int32_t n_neighbours, int32_t skip_normal_3, int32_t* cands_out,
                                 int32_t* id_modif_out, double* normal_out, double* uniform_out);
+/* ONE complete step_sampler call (CL:1401-1465) as the reference's loop makes it (instagraal.py:221-228), candidate draw of
+ * return_neighbours (CL:3103-3141) included: nb != NULL draws cands[0 .. n_neighbours) (-1 padded, *n_cands = the list's length) on
+ * numpy's MT19937 state as ig_neighbours_draw does; nb == NULL scores the caller's cands[0 .. *n_cands).  Same results as ig_step,
+ * less around them: the lists and the results travel through mapped host memory instead of five copies, and the move is decided
+ * and applied by the batch path's fused commit kernel (a batch of one) instead of the five kernels of the one-move tail.
+ * IG_STEP_DRAW_FAST=0: ig_step's way. */
+int ig_step_draw(ig_ctx* ctx, ig_neighbours* nb, uint32_t* mt_key624, int32_t* mt_pos, int32_t frag_a, int32_t n_neighbours,
+                 int32_t* cands, int32_t* n_cands, ig_move_result* out, double* scores_or_null);
 /* n_moves complete step_sampler calls: draw (on a host thread, ahead of the launches) + ig_step_batch.  cands_out
  * [n_moves x n_neighbours] receives the drawn lists; the generator state is advanced past all n_moves draws. */
 int ig_step_batch_draw(ig_ctx* ctx, ig_neighbours* nb, uint32_t* mt_key624, int32_t* mt_pos, int32_t n_moves, const int32_t* frags,
@@ -270,6 +278,7 @@ int ig_debug_zero_fallbacks(ig_ctx* ctx, int64_t* fallbacks);
  * lists did not fit the slice pool and were repeated with a larger one -- the counterpart of the batch path's re-run slots
  * (replaces nothing in the reference: its sort buffers are sized for the whole matrix, CL:1009-1069) */
 int ig_debug_pool_retries(ig_ctx* ctx, int64_t* n);
+int ig_debug_step_stats(ig_ctx* ctx, int64_t out2[2]); /* ig_step_draw: {calls that went through mapped memory, of them finished by the one-move tail} */
 int ig_debug_nuis_chain_stats(ig_ctx* ctx, int64_t out10[10]); /* chains: {calls, segments, pairs completed, ends by reason [7]} */
 int ig_debug_set_full_hist(int on); /* from-scratch pass: all-trans tiles from their count histograms (1, default) or contact by contact (0) */
 

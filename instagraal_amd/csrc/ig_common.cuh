@@ -266,6 +266,18 @@ struct NuisHost {
     int changed; /* the record's move changed the genome (k_commit_batch, with the record) */
 };
 
+/* ig_step_draw (one reference-shaped step_sampler call, CL:1401-1465): mapped, coherent host memory the call's kernels read the
+ * move's lists from and write its scores to -- no copy in either direction, no stream synchronisation.  The record comes back the
+ * same way: through NuisHost.res from the batch commit kernels, through `fin` from k_commit when the move was finished by the one-move
+ * tail (a windowed winner that changes the genome). */
+struct StepHost {
+    int in[1 + IG_MAX_CANDIDATES]; /* focal bin, candidates */
+    ig_move_result fin;
+    int max_L, max_SL;             /* with `fin`: Glob.max_L / max_SL behind the move */
+    volatile int fin_seq;          /* written last, behind a system-scope fence */
+    double scores[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT];
+};
+
 /* The cis contacts of the state BEFORE the last move as a histogram over log2 of their distance (ig_kernels_nuis.cuh, tier 0 of
  * the screened nuisance pass): bin = floor(x 2^NH_OCT_BITS), x = log2 s in units of 2^-NH_FRAC_BITS; per bin
  * {contacts, sum of the offsets inside the bin, sum of the counts, sum of count x offset} -- integers, maintained with atomics by
@@ -473,6 +485,11 @@ struct ig_ctx {
     int max_L, max_SL;      /* host copies of Glob.max_L / max_SL as of the last synchronisation */
     bool full_windows;      /* window strides = the whole genome (runs of moves enqueued one at a time without a host round trip) */
     int* host_max;          /* pinned: {max_L, max_SL} copied back with every one-move call's result */
+    struct StepHost *host_step, *host_step_dev; /* ig_step_draw: mapped host memory and its device address (null: not available) */
+    int step_seq;
+    struct StepHost* pub_step; /* set while ig_step_draw enqueues: k_commit publishes there */
+    double* pub_scores;        /* ... and the decide step of its one-move batch writes the move's scores there */
+    long long n_step_tail;     /* ig_step_draw calls finished by the one-move tail */
     int exact_grid;         /* two-tier scoring: blocks of the exact kernel's launch (follows what the last batches needed) */
     bool have_contacts, have_sub, have_state, have_init, have_params;
     bool init_links_inverse; /* initial prev / next are mutually inverse (k_commit_batch's de-duplication relies on it; else W = 1) */

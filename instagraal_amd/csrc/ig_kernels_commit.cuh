@@ -249,12 +249,23 @@ __device__ __forceinline__ void write_result(Glob* g, const MoveBuf& mb, int w, 
     *out = r;
 }
 
-__global__ void k_commit(Glob* g, MoveBuf mb, ig_move_result* res, int move, int w, int* dirty)
+__device__ __forceinline__ void publish_final(const Glob* g, StepHost* hs, int seq, const ig_move_result* r)
+{
+    if (!hs) return;
+    hs->fin = *r;
+    hs->max_L = g->max_L;
+    hs->max_SL = g->max_SL;
+    __threadfence_system();
+    hs->fin_seq = seq;
+}
+
+__global__ void k_commit(Glob* g, MoveBuf mb, ig_move_result* res, int move, int w, int* dirty, StepHost* hs, int seq)
 {
     if (g->retry_pool) { /* the move's lists did not fit the slice pool: nothing was applied, the host repeats it with a larger one */
         g->credit2_acc = 0;
         write_result(g, mb, w, res + move);
         res[move].pad = 1;
+        publish_final(g, hs, seq, res + move);
         return;
     }
     /* dirty (a move of a batch finished with the one-move kernels, decided one move per call: ig_nuis_step_begin): its contigs
@@ -273,6 +284,7 @@ __global__ void k_commit(Glob* g, MoveBuf mb, ig_move_result* res, int move, int
     g->credit2 = g->credit2_acc;
     g->credit2_acc = 0;
     write_result(g, mb, w, res + move);
+    publish_final(g, hs, seq, res + move);
 }
 
 /* credit of fragment f (dist_inter_genome, CL:665-716) when the genome is read through an accessor: V(x) returns
@@ -380,8 +392,10 @@ struct ChainArgs {
 template <bool FUSED, bool CHAIN = false>
 __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out,
                                             volatile int* host_out, int seq, int resumed_plain, FusedLds* sh, int zcheck,
-                                            const ChainArgs ca = ChainArgs{nullptr, nullptr, 0, 1.0})
+                                            const ChainArgs ca = ChainArgs{nullptr, nullptr, 0, 1.0}, double* host_scores = nullptr)
 {
+    /* host_scores (ig_step_draw: a launch that decides ONE move): the move's C x 24 scores as all_scores holds them (CL:1414, 1431),
+     * into mapped host memory */
     /* zcheck bit 0: the records hold the CONTENDER columns only (two-tier scoring).  k_contend ruled the others out against lower
      * bounds of columns it took for scored -- under the batch-start scalars; a column whose score comes out as exactly 0.0 under the
      * LIVE ones counts as "not scored" in the reference's argmax (CL:1435-1440) and bounds nothing: the batch stops in front of such
@@ -553,6 +567,12 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
                         best = i;
                     }
                 }
+            }
+            if (host_scores) {
+#pragma unroll
+                for (int j = 0; j < NJ; j++)
+                    if (lane + 64 * j < n) host_scores[lane + 64 * j] = sc[j];
+                __threadfence_system(); /* (the record that says they are there is published by another wave, behind this wave's progress word) */
             }
             if (zcheck & 1) {
                 const int inj = zcheck >> 8;
@@ -844,9 +864,10 @@ __device__ __forceinline__ void decide_body(Glob* g, MoveBuf mb, ig_move_result*
 }
 __global__ void __launch_bounds__(64)
     k_decide_batch(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out,
-                   volatile int* host_out, int seq, int resumed_plain, int zcheck)
+                   volatile int* host_out, int seq, int resumed_plain, int zcheck, double* host_scores)
 {
-    decide_body<false>(g, mb, res, move0, W, w_start, dirty_buf, batch_out, host_out, seq, resumed_plain, nullptr, zcheck);
+    decide_body<false>(g, mb, res, move0, W, w_start, dirty_buf, batch_out, host_out, seq, resumed_plain, nullptr, zcheck,
+                       ChainArgs{nullptr, nullptr, 0, 1.0}, host_scores);
 }
 
 __global__ void __launch_bounds__(64)
@@ -1315,7 +1336,7 @@ __global__ void __launch_bounds__(64 + FUSED_CW * 64)
     k_decide_commit(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out, volatile int* host_out,
                     int seq, int resumed_plain, State st, Tables tab, Tables tab_prev, const int* __restrict__ ip, const int* __restrict__ in,
                     const int* __restrict__ orientable, const unsigned char* __restrict__ black, int* own_tag, int* own_idx, int* prev_touched,
-                    NuisHost* hn, int hn_seq, int zcheck)
+                    NuisHost* hn, int hn_seq, int zcheck, double* host_scores)
 {
     __shared__ FusedLds sh;
     for (int i = threadIdx.x; i < 3 * IG_MAX_BATCH + 2; i += blockDim.x) sh.bar[i] = 0;
@@ -1325,7 +1346,9 @@ __global__ void __launch_bounds__(64 + FUSED_CW * 64)
         sh.prog[1] = 0;
     }
     __syncthreads();
-    if (threadIdx.x < 64) decide_body<true>(g, mb, res, move0, W, w_start, dirty_buf, batch_out, host_out, seq, resumed_plain, &sh, zcheck);
+    if (threadIdx.x < 64)
+        decide_body<true>(g, mb, res, move0, W, w_start, dirty_buf, batch_out, host_out, seq, resumed_plain, &sh, zcheck, ChainArgs{nullptr, nullptr, 0, 1.0},
+                          host_scores);
     else commit_waves(st, tab, tab_prev, g, mb, ip, in, orientable, black, own_tag, own_idx, prev_touched, res, move0, W, w_start, hn, hn_seq, &sh);
 }
 

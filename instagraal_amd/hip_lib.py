@@ -344,6 +344,45 @@ class Context:
         _ck(lib().ig_step(self._h, C.c_int32(int(frag_a)), _p(c), C.c_int32(c.size), C.byref(res), _p(sc)))
         return res, sc
 
+    def step_draw(self, neighbours, frag_a, n_neighbours, cands=None):
+        """ONE complete step_sampler call in one library call (ig_step_draw): the candidate draw on numpy's generator state in
+        place (``cands`` given: the caller's list), lists and results through mapped host memory, the move decided and applied as a
+        batch of one -> (MoveResult, scores [C x 24], candidate list)"""
+        fn = lib().ig_step_draw
+        if fn.argtypes is None:
+            fn.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_int32] + [C.c_void_p] * 4
+        io = self.__dict__.get("_step_io")
+        if io is None:
+            sc = np.zeros(MAX_CANDIDATES * N_TMP_STRUCT, np.float64)
+            io = self._step_io = (sc, sc.ctypes.data, (C.c_int32 * MAX_CANDIDATES)(), C.c_int32(0))
+        sc, sc_addr, cbuf, ncand = io
+        res = MoveResult()
+        if cands is None:
+            addr = Neighbours.numpy_mt_address()
+            if not addr:  # (a numpy whose generator state cannot be reached in place: two calls)
+                row = neighbours.draw(np.array([frag_a], np.int32), int(n_neighbours))[0]
+                lst = [int(x) for x in row if x >= 0]
+                r, s2 = self.step(int(frag_a), lst, want_scores=True)
+                return r, s2, lst
+            rc = fn(self._h, neighbours._h, addr, addr + 624 * 4, int(frag_a), int(n_neighbours), cbuf, C.byref(ncand), C.byref(res), sc_addr)
+        else:
+            n = len(cands)
+            if n > MAX_CANDIDATES:
+                raise HipError("a move needs 1..%d candidates (got %d)" % (MAX_CANDIDATES, n))
+            cbuf[:n] = [int(x) for x in cands]
+            ncand.value = n
+            rc = fn(self._h, None, None, None, int(frag_a), 0, cbuf, C.byref(ncand), C.byref(res), sc_addr)
+        if rc != 0:
+            _ck(rc)
+        n = ncand.value
+        return res, sc[:n * N_TMP_STRUCT].copy(), cbuf[:n]
+
+    def debug_step_stats(self):
+        """ig_step_draw: calls that went through mapped memory, and how many of them the one-move tail finished"""
+        o = np.zeros(2, np.int64)
+        _ck(lib().ig_debug_step_stats(self._h, _p(o)))
+        return dict(calls=int(o[0]), tails=int(o[1]))
+
     def step_batch(self, frags, cands):
         """frags: (n,), cands: (n, max_c) -1 padded -> structured array of MOVE_RESULT_DTYPE"""
         f = np.ascontiguousarray(frags, np.int32)

@@ -296,14 +296,10 @@ class sampler:  # noqa: N801 - the reference's class name
         return c
 
     def step_sampler(self, id_frag, n_neighbours, dt=None, candidates=None):  # CL:1401-1465
-        if candidates is None:
-            # the draw of return_neighbours (CL:3103-3141) in the library, on numpy's generator state: the same list and the same
-            # state afterwards (tests/test_cpu_abi_and_host.py) for a fifth of np.random.choice's 34 - 49 us per call
-            row = self.neighbours.draw(np.array([id_frag], np.int32), max(1, int(n_neighbours)))[0]
-            self.candidates = [int(x) for x in row if x >= 0]
-        else:
-            self.candidates = self._clean(id_frag, candidates)
-        res, sc = self.ctx.step(int(id_frag), self.candidates, want_scores=True)
+        # one library call (ig_step_draw): the draw of return_neighbours (CL:3103-3141) on numpy's generator state in place -- the same
+        # list and the same state afterwards (tests/test_cpu_abi_and_host.py) -- the move, and the record as soon as it is complete
+        res, sc, self.candidates = self.ctx.step_draw(self.neighbours, id_frag, max(1, int(n_neighbours)),
+                                                      None if candidates is None else self._clean(id_frag, candidates))
         self.all_scores = sc
         self.o = res.o
         self.likelihood_t = res.o

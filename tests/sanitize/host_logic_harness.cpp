@@ -326,6 +326,12 @@ static void model_commit_one(void** a, dim3, dim3)
         res[move].pad = 1;
         g_force_retry--;
     }
+    StepHost* hs = *(StepHost**)a[6]; /* ig_step_draw: the record of a move the one-move tail finished, into mapped host memory */
+    if (hs) {
+        hs->fin = res[move];
+        hs->max_L = hs->max_SL = 0;
+        hs->fin_seq = *(int*)a[7];
+    }
 }
 
 int main()
@@ -463,6 +469,27 @@ int main()
             while (C0 < max_c && cands[C0] >= 0) C0++;
             CHECK(ig_step(c, frags[0], cands.data(), C0, &one, sc.data()) == 0);
             CHECK(ig_score_move(c, frags[0], cands.data(), C0, sc.data()) == 0);
+            { /* ig_step_draw with the caller's candidates: a batch of one through the mapped block -- committed by the batch kernels, handed
+               * to the one-move tail (the decide model's pending winners), a first slot that does not fit the pool / the exact grid */
+                const long tails0 = g_pendings;
+                for (int rep = 0; rep < 60; rep++) {
+                    std::vector<int32_t> cl(cands.begin(), cands.begin() + max_c);
+                    int32_t nc = C0;
+                    const bool forced = rep % 9 == 4;
+                    if (forced) g_force_first_overflow = 1 + (rep % 2);
+                    const int rc = ig_step_draw(c, nullptr, nullptr, nullptr, frags[0], 0, cl.data(), &nc, &one, (rep & 1) ? sc.data() : nullptr);
+                    g_force_first_overflow = 0;
+                    /* (a forced "does not fit" with the pool / the work list at their largest fails, as it must) */
+                    CHECK(rc == 0 || (forced && (std::strstr(ig_last_error(), "worst case") || std::strstr(ig_last_error(), "work list"))));
+                    CHECK(rc != 0 || (nc == C0 && one.pad == 0));
+                }
+                CHECK(g_pendings > tails0); /* (one decision in sixteen) */
+                int32_t nc = 0;
+                CHECK(ig_step_draw(c, nullptr, nullptr, nullptr, frags[0], 0, cands.data(), &nc, &one, nullptr) != 0); // no candidates
+                nc = C0;
+                CHECK(ig_step_draw(c, nullptr, nullptr, nullptr, frags[0], 0, cands.data(), &nc, nullptr, nullptr) != 0);
+                CHECK(ig_step_draw(c, nullptr, nullptr, nullptr, -1, 0, cands.data(), &nc, &one, nullptr) != 0);
+            }
             CHECK(ig_apply(c, frags[0], cands[0], 3) == 0);
             CHECK(ig_apply(c, frags[0], cands[0], 24) != 0);
             // argument checks of the move entry points
@@ -513,6 +540,21 @@ int main()
                 std::vector<int32_t> cout_((size_t)n_moves * nn, -1);
                 if (pr.N > nn + 1) {
                     CHECK(ig_step_batch_draw(c, nb, key.data(), &pos, n_moves, frags.data(), nn, cout_.data(), res.data()) == 0);
+                    for (int rep = 0; rep < 20; rep++) { /* one call per move, the draw inside it */
+                        int32_t nc = 0;
+                        std::vector<int32_t> cl(nn, -7);
+                        ig_move_result one2;
+                        CHECK(ig_step_draw(c, nb, key.data(), &pos, frags[rep], nn, cl.data(), &nc, &one2, nullptr) == 0);
+                        CHECK(nc >= 1 && nc <= nn);
+                        for (int q = 0; q < nn; q++) CHECK(q < nc ? (cl[q] >= 0 && cl[q] < pr.N && cl[q] != frags[rep]) : cl[q] == -1);
+                    }
+                    {
+                        int32_t nc = 0;
+                        std::vector<int32_t> cl(nn, -7);
+                        ig_move_result one2;
+                        CHECK(ig_step_draw(c, nb, key.data(), &pos, pr.N + 5, nn, cl.data(), &nc, &one2, nullptr) != 0);
+                        CHECK(ig_step_draw(c, nb, key.data(), &pos, frags[0], IG_MAX_CANDIDATES + 1, cl.data(), &nc, &one2, nullptr) != 0);
+                    }
                     std::vector<int32_t> badf(frags.begin(), frags.begin() + 40);
                     badf[37] = pr.N + 5;
                     CHECK(ig_step_batch_draw(c, nb, key.data(), &pos, 40, badf.data(), nn, cout_.data(), res.data()) != 0);

@@ -194,6 +194,51 @@ def test_speculative_batches_equal_one_move_at_a_time(cfg, n_moves):
     assert outs[7][6]["batches"] < outs[3][6]["batches"]  # ... and a window of 48 needs fewer launch chains than batches of 16
 
 
+@pytest.mark.parametrize("cfg,n_moves", [("tiny", 200), ("small", 300), ("bigctg", 60)])
+def test_step_draw_equals_step(cfg, n_moves):
+    """``step_sampler`` goes through ig_step_draw (round 5: the draw inside the call, lists and results through mapped host memory,
+    the move scored and committed as a batch of one by the fused commit kernel): every 6-tuple, every score of all_scores
+    (CL:1414-1431), the candidate lists, numpy's generator state and the final genome must be those of ig_step's way (the one-move
+    kernels: IG_STEP_DRAW_FAST=0) -- with the draw inside the call and with the caller's candidates; bigctg: windowed winners, which
+    the one-move tail finishes."""
+    from instagraal_amd import synth
+    from instagraal_amd.sampler import sampler as hip_sampler
+
+    prob = synth.make_problem(*synth.CONFIGS[cfg])
+    outs = []
+    try:
+        for fast in (0, 1):
+            os.environ["IG_STEP_DRAW_FAST"] = str(fast)
+            np.random.seed(21)
+            s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
+            s.set_param_simu(prob.params)
+            s.eval_likelihood_init()
+            frags = np.resize(np.random.permutation(prob.n_frags), n_moves)
+            rows, scores, cands = [], [], []
+            for i, f in enumerate(frags):
+                if i % 3 == 2:  # the caller's own list (the reference's way to the same draw)
+                    a = s.step_sampler(int(f), 5, candidates=s.return_neighbours(int(f), 5))
+                else:
+                    a = s.step_sampler(int(f), 5)
+                rows.append((a[0], a[1], int(a[2]), int(a[3]), float(a[4]), int(a[5])))
+                scores.append(np.array(s.all_scores))
+                cands.append(list(s.candidates))
+            st = np.random.get_state()
+            outs.append((rows, scores, cands, st[1].tobytes(), st[2], s.gpu_vect_frags.copy_from_gpu().soa17(),
+                         [int(x) for x in s.ctx.valid_insert()], s.ctx.debug_step_stats()))
+            s.free_gpu()
+    finally:
+        os.environ.pop("IG_STEP_DRAW_FAST", None)
+    a, b = outs
+    assert a[0] == b[0]
+    assert all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
+    assert a[2] == b[2] and a[3] == b[3] and a[4] == b[4]
+    assert np.array_equal(a[5], b[5]) and a[6] == b[6]
+    assert a[7]["calls"] == 0 and b[7]["calls"] >= n_moves
+    if cfg == "bigctg":
+        assert b[7]["tails"] > 0  # windowed winners that change the genome: finished by the one-move tail
+
+
 def test_large_windows_match_oracle():
     """Contigs of thousands of sub-fragments: the 32 KB column stage of k_score_list<4096> and, above 4096 sub-fragments,
     the unstaged path (8-byte gathers from L2), against the oracle move by move; then a batch."""

@@ -19,7 +19,7 @@ np.random.seed(0)
 frags = np.random.permutation(prob.n_frags).astype(np.int32)
 for f in frags[:10]:
     s.step_sampler(int(f), 5, s.dt)
-for name, fn in (("step_sampler (one-move kernels)", lambda f: s.step_sampler(int(f), 5, s.dt)),
+for name, fn in (("step_sampler (ig_step_draw)", lambda f: s.step_sampler(int(f), 5, s.dt)),
                  ("step_sampler_batch of one move", lambda f: s.step_sampler_batch(np.array([f], dtype=np.int32), 5))):
     ts = []
     for f in frags[10:10 + n]:
@@ -29,3 +29,4 @@ for name, fn in (("step_sampler (one-move kernels)", lambda f: s.step_sampler(in
     ts = np.array(ts) * 1e6
     print("%-34s median %.0f us, p10 %.0f, p90 %.0f per move (%.0f moves/s)" % (name, np.median(ts), np.percentile(ts, 10), np.percentile(ts, 90), 1e6 / ts.mean()))
     frags = frags[n:]
+print("ig_step_draw: %s, batch stats %s" % (s.ctx.debug_step_stats(), s.ctx.batch_stats()))
