@@ -170,6 +170,7 @@ def main():
                     help="P(s) parameters of the timed moves: the synthetic set of BASELINE.md section 3 (slope -1.5: the headline), or the set a "
                          "nuisance chain settles into on this data (slope -0.53, d_max 2.9e6 kb: synth.settled_params)")
     ap.add_argument("--settled-batches", type=int, default=40, help="batches of the default line's config.settled_parameters sample (0: skip)")
+    ap.add_argument("--reference-loop-moves", type=int, default=200, help="step_sampler calls of config.reference_loop, one per move (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=45.0, help="seconds of the oracle's timed sample (a fifth on one thread, the rest on 16)")
     ap.add_argument("--nuisance-moves", type=int, default=150, help="moves of the nuisance-on loop timed after the run (0: skip)")
@@ -298,6 +299,27 @@ def main():
         _, _, limbs = s.ctx.full_likelihood(0)
         exact_ok = bool(int(sums[0]) == int(limbs[0]) and int(sums[1]) == int(limbs[1]))
 
+    # the reference's own loop shape (instagraal.py:221-228): ONE step_sampler call per bin, the result read before the next -- what a
+    # caller that keeps that loop gets (sampler.step_sampler -> ig_step_draw), behind the timed moves on the same genome
+    ref_loop = None
+    if rank == 0 and world == 1 and a.reference_loop_moves > 0:
+        try:
+            fr = np.random.permutation(prob.n_frags)[: 2 * a.reference_loop_moves]
+            ref_loop = {"what": "one sampler.step_sampler call per move, its 6-tuple read before the next call (median of %d calls each)" % a.reference_loop_moves}
+            keep0 = s.keep_all_scores
+            for key, keep in (("us_per_call", False), ("us_per_call_with_all_scores", True)):
+                s.keep_all_scores = keep
+                ts = []
+                for f in fr[:a.reference_loop_moves] if not keep else fr[a.reference_loop_moves:]:
+                    t0 = time.perf_counter()
+                    s.step_sampler(int(f), a.neighbours, s.dt)
+                    ts.append(time.perf_counter() - t0)
+                ref_loop[key] = 1e6 * float(np.median(ts))
+                ref_loop[key.replace("us_per_call", "moves_per_s")] = len(ts) / float(np.sum(ts))
+            s.keep_all_scores = keep0
+        except Exception as e:  # a diagnostic next to the headline, never instead of it
+            ref_loop = {"us_per_call": None, "error": repr(e)}
+
     nuis = None
     if rank == 0 and world == 1 and a.nuisance_moves > 0:
         try:
@@ -422,6 +444,7 @@ def main():
                 "columns_scored_exactly_per_s": None if not screened else screened[3] / max(screened[2], 1) * float(res["n_candidates"].sum()) * 24 / elapsed,
                 "term_evals_per_move": float(res["n_evals"].mean()), "moves_per_launch": n_moves / n_launch,
                 "batches": bstats, "maintained_likelihood_exact": exact_ok,
+                "reference_loop": ref_loop,
                 "nuisance_on": nuis,
                 "settled_parameters": settled,
                 "parameters": a.params,

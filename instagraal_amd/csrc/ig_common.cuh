@@ -489,6 +489,7 @@ struct ig_ctx {
     int step_seq;
     struct StepHost* pub_step; /* set while ig_step_draw enqueues: k_commit publishes there */
     double* pub_scores;        /* ... and the decide step of its one-move batch writes the move's scores there */
+    bool screen_w1;            /* ... whose caller asked for no scores: two-tier scoring at width one (enqueue_score) */
     long long n_step_tail;     /* ig_step_draw calls finished by the one-move tail */
     int exact_grid;         /* two-tier scoring: blocks of the exact kernel's launch (follows what the last batches needed) */
     bool have_contacts, have_sub, have_state, have_init, have_params;

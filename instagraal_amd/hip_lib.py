@@ -344,10 +344,11 @@ class Context:
         _ck(lib().ig_step(self._h, C.c_int32(int(frag_a)), _p(c), C.c_int32(c.size), C.byref(res), _p(sc)))
         return res, sc
 
-    def step_draw(self, neighbours, frag_a, n_neighbours, cands=None):
+    def step_draw(self, neighbours, frag_a, n_neighbours, cands=None, want_scores=True):
         """ONE complete step_sampler call in one library call (ig_step_draw): the candidate draw on numpy's generator state in
         place (``cands`` given: the caller's list), lists and results through mapped host memory, the move decided and applied as a
-        batch of one -> (MoveResult, scores [C x 24], candidate list)"""
+        batch of one -> (MoveResult, scores [C x 24], candidate list).  ``want_scores=False`` -> scores None, and the library is free to
+        score the move in two tiers (the exact kernel for the columns that can still win only)"""
         fn = lib().ig_step_draw
         if fn.argtypes is None:
             fn.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_int32] + [C.c_void_p] * 4
@@ -362,20 +363,21 @@ class Context:
             if not addr:  # (a numpy whose generator state cannot be reached in place: two calls)
                 row = neighbours.draw(np.array([frag_a], np.int32), int(n_neighbours))[0]
                 lst = [int(x) for x in row if x >= 0]
-                r, s2 = self.step(int(frag_a), lst, want_scores=True)
+                r, s2 = self.step(int(frag_a), lst, want_scores=want_scores)
                 return r, s2, lst
-            rc = fn(self._h, neighbours._h, addr, addr + 624 * 4, int(frag_a), int(n_neighbours), cbuf, C.byref(ncand), C.byref(res), sc_addr)
+            rc = fn(self._h, neighbours._h, addr, addr + 624 * 4, int(frag_a), int(n_neighbours), cbuf, C.byref(ncand), C.byref(res),
+                    sc_addr if want_scores else None)
         else:
             n = len(cands)
             if n > MAX_CANDIDATES:
                 raise HipError("a move needs 1..%d candidates (got %d)" % (MAX_CANDIDATES, n))
             cbuf[:n] = [int(x) for x in cands]
             ncand.value = n
-            rc = fn(self._h, None, None, None, int(frag_a), 0, cbuf, C.byref(ncand), C.byref(res), sc_addr)
+            rc = fn(self._h, None, None, None, int(frag_a), 0, cbuf, C.byref(ncand), C.byref(res), sc_addr if want_scores else None)
         if rc != 0:
             _ck(rc)
         n = ncand.value
-        return res, sc[:n * N_TMP_STRUCT].copy(), cbuf[:n]
+        return res, (sc[:n * N_TMP_STRUCT].copy() if want_scores else None), cbuf[:n]
 
     def debug_step_stats(self):
         """ig_step_draw: calls that went through mapped memory, and how many of them the one-move tail finished"""

@@ -117,7 +117,7 @@ class sampler:  # noqa: N801 - the reference's class name
                  sub_sampled_sparse_matrix, np_sub_frags_len_bp, np_sub_frags_id, np_sub_frags_accu, np_sub_frags_2_frags,
                  mean_squared_frags_per_bin, norm_vect_accu, sub_candidates_dup, sub_candidates_output_data,
                  S_o_A_sub_frags, sub_collector_id_repeats, sub_frag_dispatcher, sparse_matrix, mean_value_trans,
-                 n_iterations, is_simu, vel=None, pos=None, device_id=0, coo=None):
+                 n_iterations, is_simu, vel=None, pos=None, device_id=0, coo=None, keep_all_scores=True):
         if not use_rippe:
             raise NotImplementedError("use_rippe=False is unreachable from the reference CLI (instagraal.py:564)")
         if len(sub_candidates_dup) or len(id_frag_duplicated):
@@ -178,6 +178,10 @@ class sampler:  # noqa: N801 - the reference's class name
         self.n_contigs, self.mean_length_contigs = n, m
         self.candidates = []
         self.all_scores = np.zeros(0)
+        # step_sampler leaves the 24 x C scores of its move in ``all_scores`` as the reference does (CL:1414-1431) -- which nothing
+        # outside step_sampler ever reads (CL:1435-1454).  False (what ``simulation`` constructs: the reference's loop, IG:221-228):
+        # ``all_scores`` stays None and the move is scored in two tiers, the exact kernel for the columns that can still win only.
+        self.keep_all_scores = bool(keep_all_scores)
 
     # ------------------------------------------------------------ parameters
     def mean_kb(self):
@@ -299,7 +303,7 @@ class sampler:  # noqa: N801 - the reference's class name
         # one library call (ig_step_draw): the draw of return_neighbours (CL:3103-3141) on numpy's generator state in place -- the same
         # list and the same state afterwards (tests/test_cpu_abi_and_host.py) -- the move, and the record as soon as it is complete
         res, sc, self.candidates = self.ctx.step_draw(self.neighbours, id_frag, max(1, int(n_neighbours)),
-                                                      None if candidates is None else self._clean(id_frag, candidates))
+                                                      None if candidates is None else self._clean(id_frag, candidates), self.keep_all_scores)
         self.all_scores = sc
         self.o = res.o
         self.likelihood_t = res.o

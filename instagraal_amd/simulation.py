@@ -133,7 +133,7 @@ class simulation:
         self.level.build_seq_per_bin(genome_fasta=self.fasta)
         self.n_frags = args["n_new_frags"]
         self.new_S_o_A_frags, self.new_sub_S_o_A_frags = args["S_o_A_frags"], args["S_o_A_sub_frags"]
-        self.sampler = sampler_lib(**args, device_id=device_id)
+        self.sampler = sampler_lib(**args, device_id=device_id, keep_all_scores=False)  # (nobody reads them: CL:1414-1454)
         # SS:157-171
         g = self.sampler.gpu_vect_frags
         g.copy_from_gpu()

@@ -200,17 +200,17 @@ def test_step_draw_equals_step(cfg, n_moves):
     the move scored and committed as a batch of one by the fused commit kernel): every 6-tuple, every score of all_scores
     (CL:1414-1431), the candidate lists, numpy's generator state and the final genome must be those of ig_step's way (the one-move
     kernels: IG_STEP_DRAW_FAST=0) -- with the draw inside the call and with the caller's candidates; bigctg: windowed winners, which
-    the one-move tail finishes."""
+    the one-move tail finishes.  A third run without all_scores (``keep_all_scores=False``: the batch of one scored in two tiers)."""
     from instagraal_amd import synth
     from instagraal_amd.sampler import sampler as hip_sampler
 
     prob = synth.make_problem(*synth.CONFIGS[cfg])
     outs = []
     try:
-        for fast in (0, 1):
+        for fast, keep in ((0, True), (1, True), (1, False)):
             os.environ["IG_STEP_DRAW_FAST"] = str(fast)
             np.random.seed(21)
-            s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
+            s = hip_sampler(**prob.sampler_kwargs(), device_id=0, keep_all_scores=keep)
             s.set_param_simu(prob.params)
             s.eval_likelihood_init()
             frags = np.resize(np.random.permutation(prob.n_frags), n_moves)
@@ -221,22 +221,24 @@ def test_step_draw_equals_step(cfg, n_moves):
                 else:
                     a = s.step_sampler(int(f), 5)
                 rows.append((a[0], a[1], int(a[2]), int(a[3]), float(a[4]), int(a[5])))
-                scores.append(np.array(s.all_scores))
+                scores.append(np.array(s.all_scores) if keep else s.all_scores)
                 cands.append(list(s.candidates))
             st = np.random.get_state()
             outs.append((rows, scores, cands, st[1].tobytes(), st[2], s.gpu_vect_frags.copy_from_gpu().soa17(),
-                         [int(x) for x in s.ctx.valid_insert()], s.ctx.debug_step_stats()))
+                         [int(x) for x in s.ctx.valid_insert()], s.ctx.debug_step_stats(), s.ctx.debug_screen_stats()))
             s.free_gpu()
     finally:
         os.environ.pop("IG_STEP_DRAW_FAST", None)
-    a, b = outs
-    assert a[0] == b[0]
+    a, b, c = outs
+    assert a[0] == b[0] == c[0]
     assert all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
-    assert a[2] == b[2] and a[3] == b[3] and a[4] == b[4]
-    assert np.array_equal(a[5], b[5]) and a[6] == b[6]
-    assert a[7]["calls"] == 0 and b[7]["calls"] >= n_moves
+    assert all(x is None for x in c[1])  # keep_all_scores=False (what ``simulation`` constructs): no scores, two-tier scoring
+    assert a[2] == b[2] == c[2] and a[3] == b[3] == c[3] and a[4] == b[4] == c[4]
+    assert np.array_equal(a[5], b[5]) and np.array_equal(a[5], c[5]) and a[6] == b[6] == c[6]
+    assert a[7]["calls"] == 0 and b[7]["calls"] >= n_moves and c[7]["calls"] >= n_moves
+    assert b[8][2] == 0 and c[8][2] > 5 * c[8][3] > 0, (b[8], c[8])  # columns screened / scored exactly: the second tier is a small share
     if cfg == "bigctg":
-        assert b[7]["tails"] > 0  # windowed winners that change the genome: finished by the one-move tail
+        assert b[7]["tails"] > 0 and c[7]["tails"] > 0  # windowed winners that change the genome: finished by the one-move tail
 
 
 def test_large_windows_match_oracle():

@@ -139,7 +139,8 @@ def run_hip(prob, params, desc):
         hip_lib.set_nuis_chain(desc.get("chain", 1))
     try:
         np.random.seed(desc["seed"])
-        s = hip_sampler(**prob.sampler_kwargs(), device_id=0)
+        # (one call per move: every other case the way ``simulation`` constructs the sampler -- no all_scores, the batch of one in two tiers)
+        s = hip_sampler(**prob.sampler_kwargs(), device_id=0, keep_all_scores=bool(desc["seed"] & 1))
         s.set_param_simu(params)
         s.eval_likelihood_init()
         if desc["bomb"]:

@@ -19,7 +19,16 @@ np.random.seed(0)
 frags = np.random.permutation(prob.n_frags).astype(np.int32)
 for f in frags[:10]:
     s.step_sampler(int(f), 5, s.dt)
-for name, fn in (("step_sampler (ig_step_draw)", lambda f: s.step_sampler(int(f), 5, s.dt)),
+def _no_scores(f):
+    s.keep_all_scores = False
+    try:
+        return s.step_sampler(int(f), 5, s.dt)
+    finally:
+        s.keep_all_scores = True
+
+
+for name, fn in (("step_sampler, all_scores kept", lambda f: s.step_sampler(int(f), 5, s.dt)),
+                 ("step_sampler, no all_scores", _no_scores),
                  ("step_sampler_batch of one move", lambda f: s.step_sampler_batch(np.array([f], dtype=np.int32), 5))):
     ts = []
     for f in frags[10:10 + n]:
