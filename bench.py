@@ -170,6 +170,7 @@ def main():
                     help="P(s) parameters of the timed moves: the synthetic set of BASELINE.md section 3 (slope -1.5: the headline), or the set a "
                          "nuisance chain settles into on this data (slope -0.53, d_max 2.9e6 kb: synth.settled_params)")
     ap.add_argument("--settled-batches", type=int, default=40, help="batches of the default line's config.settled_parameters sample (0: skip)")
+    ap.add_argument("--timer-sampling", type=int, default=0, help="hipEvent pairs around every N-th launch of the scoring kernels (0: every launch of a short run, every 4th of a long one)")
     ap.add_argument("--reference-loop-moves", type=int, default=200, help="step_sampler calls of config.reference_loop, one per move (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=45.0, help="seconds of the oracle's timed sample (a fifth on one thread, the rest on 16)")
@@ -255,7 +256,10 @@ def main():
         first_res, first_cands = first_res[:96].copy(), np.array(first_cands[:96])
     # hipEvent pairs around the two scoring kernels (k_screen, k_score_list) on the library's stream, every 4th launch: an event
     # record between two kernels of a stream costs ~6 us of idle queue, four of them per batch were 4 % of the timed region
-    s.ctx.set_timer_sampling(4)
+    # (a short call -- the driver's 480 moves are ~15 launches of the dominant kernel, of 9 to 48 slots each since round 5's window rule --
+    # times every launch: four samples of launches that different read 0.093 - 0.114 for the same kernel; --timer-sampling N fixes it)
+    t_every = a.timer_sampling if a.timer_sampling > 0 else (1 if n_moves <= 1200 else 4)
+    s.ctx.set_timer_sampling(t_every)
     s.ctx.reset_timers(1 | (((1 << 2) | (1 << 10)) << 1))
     batches_before = s.ctx.batch_stats()["batches"] if (world == 1 or replicas) else 0
     if dist is not None:
@@ -283,7 +287,7 @@ def main():
         n_launch = n_screen
     bstats = s.ctx.batch_stats() if (world == 1 or replicas) else None
     # launches of the dominant kernel in the timed region: one per scored batch (the timed ones are a sample of them)
-    n_launch = (bstats["batches"] - batches_before) if (bstats is not None and bstats["batches"] > batches_before) else 4 * int(n_launch)
+    n_launch = (bstats["batches"] - batches_before) if (bstats is not None and bstats["batches"] > batches_before) else t_every * int(n_launch)
 
     # the draw alone, for the record (it ran on a host thread next to the launches above)
     st = np.random.get_state()

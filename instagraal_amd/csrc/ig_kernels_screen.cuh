@@ -1360,7 +1360,12 @@ __global__ void __launch_bounds__(256) k_worklist(MoveBuf mb, const unsigned* __
         bool fit = true;
         for (int x = 0; x < 8; x++) fit &= 8LL * (s_base[x] + s_cnt[x]) <= (long long)grid_cap;
         s_fit = fit;
-        if (!fit) mb.ctl[PS(w)].overflow = 2; /* 2: the exact kernel's grid (1: the slice pool, k_offsets) */
+        /* 2: the exact kernel's grid (1: the slice pool, k_offsets).  NEVER over a 1: the grid is dealt out again whenever the
+         * parameter half of a slot is re-scored (k_rescore_prepare takes a 2 back), the pool is not -- a slot without lists whose 1
+         * had become a 2 here (every slot behind the first one that does not fit the grid is flagged) came back from the next
+         * re-scoring as "fits", with empty lists and sums of zero, and was decided from them (found by tools/fuzz_chains.py in
+         * round 5: a nuisance run on a small pool AND a small grid) */
+        if (!fit && mb.ctl[PS(w)].overflow == 0) mb.ctl[PS(w)].overflow = 2;
         for (int x = 0; x < 8; x++) {
             if (fit) atomicMax(&mb.work[x], (unsigned long long)(s_base[x] + s_cnt[x])); /* the sub-lists end behind the last slot that fits */
             atomicMax(&mb.work[8 + x], (unsigned long long)(s_base[x] + s_cnt[x])); /* what the grid would have to cover (the host sizes the next one) */

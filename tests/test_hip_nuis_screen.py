@@ -192,3 +192,49 @@ def test_chains_under_a_temperature_and_without_the_helper_thread(monkeypatch):
         hip_lib.set_nuis_hist(1)
     assert outs[(1, "1")] == outs[(0, "1")] and outs[(1, "0")] == outs[(0, "1")]
     assert 0 < sum(q[6] for q in outs[(0, "1")][1]) < 500
+
+
+def test_a_slot_without_lists_stays_flagged_through_a_rescoring(monkeypatch):
+    """tools/fuzz_chains.py, round 5 (cases 50023 / 50596): a nuisance run on a SMALL slice pool and a SMALL exact grid at once.  A
+    slot whose lists did not fit the pool (overflow 1, k_offsets) and that also lay behind the first slot that did not fit the exact
+    kernel's work list was re-flagged 2 by k_worklist; the next re-scoring of the batch's parameter half (an accepted step) takes every
+    2 back -- the grid is dealt out again --, and the slot came back as "fits": no lists, sums of zero, decided from them (a winner
+    9 668 log units worse than the best at pair 18 of this run; the maintained sum off from there on).  Present since the parameter
+    half is re-scored in pieces (round 3); rounds 3 - 4 never had both overflows in one batch.  The run on the small pool must return
+    what the run on the default pool returns, and the maintained sums must equal a from-scratch pass."""
+    from instagraal_amd import hip_lib, synth
+    from instagraal_amd.sampler import sampler as hip_sampler
+
+    class cooled(hip_sampler):
+        def temperature(self, t, n_step):
+            return 0.5 + 0.25 * (t % 3)
+
+    prob = synth.make_problem(20000, 20000 * 75, 51023, 15)
+    params = synth.settled_params(prob.params)
+    outs = []
+    try:
+        hip_lib.set_nuis_width(16)
+        hip_lib.set_nuis_chain(0)
+        hip_lib.set_nuis_hist(2)
+        for pool in ("3000", None):
+            monkeypatch.delenv("IG_POOL_ENTRIES", raising=False)
+            if pool:
+                monkeypatch.setenv("IG_POOL_ENTRIES", pool)
+            np.random.seed(50023)
+            s = cooled(**prob.sampler_kwargs(), device_id=0)
+            s.set_param_simu(params)
+            s.bins = np.arange(1.0, 60.0, 1.0)
+            s.eval_likelihood_init()
+            frags = np.resize(np.random.permutation(prob.n_frags), 100)
+            res, tuples = s.step_sampler_nuisance_batch(frags, 5, s.dt, 0, 1020)
+            sums, _ = s.ctx.debug_globals()
+            _, _, limbs = s.ctx.full_likelihood(0)
+            assert [int(x) for x in sums[:5]] == [int(x) for x in limbs[:5]], pool
+            outs.append((res[["o", "dist", "op_sampled", "id_f_sampled", "n_contigs"]].tobytes(),
+                         [tuple(float(np.ravel(x)[0]) for x in q[:7]) for q in tuples], s.gpu_vect_frags.copy_from_gpu().soa17().tobytes()))
+            s.free_gpu()
+    finally:
+        hip_lib.set_nuis_width(0)
+        hip_lib.set_nuis_chain(1)
+        hip_lib.set_nuis_hist(1)
+    assert outs[0] == outs[1]
