@@ -472,7 +472,7 @@ int main()
             { /* ig_step_draw with the caller's candidates: a batch of one through the mapped block -- committed by the batch kernels, handed
                * to the one-move tail (the decide model's pending winners), a first slot that does not fit the pool / the exact grid */
                 const long tails0 = g_pendings;
-                for (int rep = 0; rep < 60; rep++) {
+                for (int rep = 0; rep < 60 || (g_pendings == tails0 && rep < 2000); rep++) { /* (until the decide model has handed one to the tail) */
                     std::vector<int32_t> cl(cands.begin(), cands.begin() + max_c);
                     int32_t nc = C0;
                     const bool forced = rep % 9 == 4;
