@@ -122,6 +122,8 @@ int ig_neighbours_draw_nuisance(ig_neighbours* nb, uint32_t* mt_key624, int32_t*
  * numpy's MT19937 state as ig_neighbours_draw does; nb == NULL scores the caller's cands[0 .. *n_cands).  Same results as ig_step,
  * less around them: the lists and the results travel through mapped host memory instead of five copies, and the move is decided
  * and applied by the batch path's fused commit kernel (a batch of one) instead of the five kernels of the one-move tail.
+ * scores_or_null == NULL (the reference's loop reads all_scores nowhere outside step_sampler, CL:1414-1454): the move may be scored
+ * in two tiers like a wider batch -- every column through the float screen, the exact kernel for the columns that can still win.
  * IG_STEP_DRAW_FAST=0: ig_step's way. */
 int ig_step_draw(ig_ctx* ctx, ig_neighbours* nb, uint32_t* mt_key624, int32_t* mt_pos, int32_t frag_a, int32_t n_neighbours,
                  int32_t* cands, int32_t* n_cands, ig_move_result* out, double* scores_or_null);
