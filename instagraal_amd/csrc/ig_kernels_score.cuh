@@ -1779,80 +1779,101 @@ __global__ void __launch_bounds__(SCORE_THREADS)
  * predicted from the batch-start state: if it is a windowed candidate that changes the genome, its exact full-contig delta
  * is computed NOW (k_delta, predicted) and the decide step does not have to pause the batch for it.  A wrong prediction
  * costs nothing but the pause it failed to avoid. */
-__global__ void __launch_bounds__(256) k_predict(Glob* g, MoveBuf mb, int w_begin, int pass)
+/* (until round 5 two launches: pass 0 left every slot's winner under the flags of its predecessor's last candidate, pass 1 read the
+ * predecessor's.  A block now redoes its predecessor's first pass itself -- one argmax more per block, one launch and one dependent
+ * dispatch less per chain) */
+__global__ void __launch_bounds__(256) k_predict(Glob* g, MoveBuf mb, int w_begin)
 {
     __shared__ double sc[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT];
+    __shared__ int s_best;
     const int w = w_begin + blockIdx.x, tid = threadIdx.x;
     if (KEPT(w)) return;
     MoveCtl& mc = mb.ctl[PS(w)];
-    const int C = mc.C, n = C * IG_N_TMP_STRUCT;
     if (cpre_at(mb, CW(w, 0)).overflow) return;
-    /* the flags candidate 0 most likely sees: the live ones for the first slot, else those of the previous slot's last candidate */
-    unsigned vmask = 0;
-    if (w == 0) {
-        for (int q = 0; q < 12; q++) vmask |= (g->valid_insert[q] != -1) ? (1u << q) : 0u;
-    } else {
-        /* pass 0: the previous slot's last candidate; pass 1: the family the previous slot's predicted winner (pass 0) would
-         * leave the flags to (CL:2125-2126: a block-insert winner re-ran get_bounds for its own candidate) */
-        const MoveCtl& pc = mb.ctl[PS(w - 1)];
-        int sel = pc.C - 1;
-        if (pass == 1 && pc.pred_pad >= 0 && (pc.pred_pad % IG_N_TMP_STRUCT) >= 12) sel = pc.pred_pad / IG_N_TMP_STRUCT;
-        const CandMeta& pm = mb.meta[CW(w - 1, sel)];
-        for (int q = 0; q < 12; q++) vmask |= (pm.flags[q] != -1) ? (1u << q) : 0u;
-    }
     const ig_params p = g->par[0];
     const double log_e = IG_LOG_E_F, n_tot_pxl = g->n_tot_pxl;
     const long long z_hi = g->z_hi, z_lo = g->z_lo, n_intra = g->n_intra;
     const double cur_nz = ig_acc_to_double(g->nz_hi, g->nz_lo);
-    for (int i = tid; i < n; i += blockDim.x) {
-        const int c = i / IG_N_TMP_STRUCT, slot = i % IG_N_TMP_STRUCT;
-        const SlotPre r = pre_at(mb, CW(w, c), slot);
-        const CandPre& cp = cpre_at(mb, CW(w, c));
-        const bool sup = (c == 0) && mc.superset0 && (slot >= 12);
-        double v = 0.0;
-        if ((r.k > 0) && !(sup && !((vmask >> (slot - 12)) & 1u))) {
-            const int pos = sup ? cp.base_cnt + __popc(vmask & ((1u << (slot - 12)) - 1u)) : r.k - 1;
-            const double nzd = (cp.r > 0 && pos >= cp.r) ? r.nz_cut_d : r.nz_d;
-            const double val_inter = -1.0 * log_e * (n_tot_pxl - (double)(n_intra + r.dni)) * p.v_inter;
-            const double val_intra = ig_acc_to_double(z_hi + r.dz_hi, z_lo + r.dz_lo) * log_e;
-            v = nzd + (val_intra + val_inter) + cur_nz - cp.ext_d;
+    auto live_flags = [&]() -> unsigned {
+        unsigned v = 0;
+        for (int q = 0; q < 12; q++) v |= (g->valid_insert[q] != -1) ? (1u << q) : 0u;
+        return v;
+    };
+    auto flags_of = [&](int ws, int sel) -> unsigned {
+        const CandMeta& pm = mb.meta[CW(ws, sel)];
+        unsigned v = 0;
+        for (int q = 0; q < 12; q++) v |= (pm.flags[q] != -1) ? (1u << q) : 0u;
+        return v;
+    };
+    /* the winner of slot ws under the batch-start scalars and the stale insert flags `vmask` (the whole workgroup; -> every thread) */
+    auto argmax_of = [&](int ws, unsigned vmask) -> int {
+        const MoveCtl& wc = mb.ctl[PS(ws)];
+        const int n = min(wc.C, IG_MAX_CANDIDATES) * IG_N_TMP_STRUCT;
+        for (int i = tid; i < n; i += blockDim.x) {
+            const int c = i / IG_N_TMP_STRUCT, slot = i % IG_N_TMP_STRUCT;
+            const SlotPre r = pre_at(mb, CW(ws, c), slot);
+            const CandPre& cp = cpre_at(mb, CW(ws, c));
+            const bool sup = (c == 0) && wc.superset0 && (slot >= 12);
+            double v = 0.0;
+            if ((r.k > 0) && !(sup && !((vmask >> (slot - 12)) & 1u))) {
+                const int pos = sup ? cp.base_cnt + __popc(vmask & ((1u << (slot - 12)) - 1u)) : r.k - 1;
+                const double nzd = (cp.r > 0 && pos >= cp.r) ? r.nz_cut_d : r.nz_d;
+                const double val_inter = -1.0 * log_e * (n_tot_pxl - (double)(n_intra + r.dni)) * p.v_inter;
+                const double val_intra = ig_acc_to_double(z_hi + r.dz_hi, z_lo + r.dz_lo) * log_e;
+                v = nzd + (val_intra + val_inter) + cur_nz - cp.ext_d;
+            }
+            sc[i] = v;
         }
-        sc[i] = v;
+        __syncthreads();
+        if (tid < 64) {
+            double bestv = -IG_INF;
+            int best = 0x7fffffff;
+            for (int i = tid; i < n; i += 64) {
+                const double ok = (sc[i] == 0.0) ? -IG_INF : sc[i];
+                if (ok > bestv) {
+                    bestv = ok;
+                    best = i;
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ov = __shfl_xor(bestv, off, 64);
+                const int oi = __shfl_xor(best, off, 64);
+                if (ov > bestv || (ov == bestv && oi < best)) {
+                    bestv = ov;
+                    best = oi;
+                }
+            }
+            if (tid == 0) s_best = best >= n ? 0 : best;
+        }
+        __syncthreads();
+        const int b = s_best;
+        __syncthreads(); /* (sc and s_best are used again) */
+        return b;
+    };
+    /* the flags candidate 0 most likely sees: the live ones for the first slot; else those of the previous slot's last candidate, or of
+     * the family the previous slot's own likely winner would leave the flags to (CL:2125-2126: a block-insert winner re-ran get_bounds
+     * for its own candidate) -- that winner under the flags ITS predecessor's last candidate leaves */
+    unsigned vmask;
+    if (w == 0) {
+        vmask = live_flags();
+    } else {
+        const MoveCtl& pc = mb.ctl[PS(w - 1)];
+        int sel = max(pc.C - 1, 0);
+        const unsigned vprev = (w == 1) ? live_flags() : flags_of(w - 2, max(mb.ctl[PS(w - 2)].C - 1, 0));
+        const int bp = argmax_of(w - 1, vprev);
+        if ((bp % IG_N_TMP_STRUCT) >= 12 && bp / IG_N_TMP_STRUCT < pc.C) sel = bp / IG_N_TMP_STRUCT;
+        vmask = flags_of(w - 1, sel);
     }
-    __syncthreads();
-    if (tid < 64) {
-        double bestv = -IG_INF;
-        int best = 0x7fffffff;
-        for (int i = tid; i < n; i += 64) {
-            const double ok = (sc[i] == 0.0) ? -IG_INF : sc[i];
-            if (ok > bestv) {
-                bestv = ok;
-                best = i;
-            }
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ov = __shfl_xor(bestv, off, 64);
-            const int oi = __shfl_xor(best, off, 64);
-            if (ov > bestv || (ov == bestv && oi < best)) {
-                bestv = ov;
-                best = oi;
-            }
-        }
-        if (tid == 0) {
-            if (best >= n) best = 0;
-            if (pass == 0) {
-                mc.pred_pad = best; /* read by the next slot's second pass */
-                return;
-            }
-            const int c = best / IG_N_TMP_STRUCT, slot = best % IG_N_TMP_STRUCT;
-            const SlotPre r = pre_at(mb, CW(w, c), slot);
-            const bool windowed = (cpre_at(mb, CW(w, c)).same_windowed >> 1) & 1;
-            if (windowed && (r.info & 1u) && r.k > 0) {
-                mc.pred = best;
-                cpre_at(mb, CW(w, 0)).pred = best; /* travels with the records; pd_hi / pd_lo (zeroed by k_records) are k_delta's */
-                mc.pred_c = c;
-                mc.pred_k = r.k;
-            }
+    const int best = argmax_of(w, vmask);
+    if (tid == 0) {
+        const int c = best / IG_N_TMP_STRUCT, slot = best % IG_N_TMP_STRUCT;
+        const SlotPre r = pre_at(mb, CW(w, c), slot);
+        const bool windowed = (cpre_at(mb, CW(w, c)).same_windowed >> 1) & 1;
+        if (windowed && (r.info & 1u) && r.k > 0) {
+            mc.pred = best;
+            cpre_at(mb, CW(w, 0)).pred = best; /* travels with the records; pd_hi / pd_lo (zeroed by k_records) are k_delta's */
+            mc.pred_c = c;
+            mc.pred_k = r.k;
         }
     }
 }
