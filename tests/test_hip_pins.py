@@ -173,17 +173,25 @@ def test_zero_score_rule_fallback_changes_nothing():
             n_fb = s.ctx.debug_zero_fallbacks()
             res2, tuples = s.step_sampler_nuisance_batch(frags[300:], 5, s.dt, 0, 100)
             n_fb2 = s.ctx.debug_zero_fallbacks() - n_fb
+            # ... and the reference-shaped call without all_scores (ig_step_draw: a batch of ONE in two tiers, round 5)
+            # (every call is move 0 of its own batch: "every move" is the one injection period that reaches it)
+            hip_lib.debug_set_zero_inject(1 if inject else 0)
+            s.keep_all_scores = False
+            rows3 = [tuple(s.step_sampler(int(f), 5, s.dt)) for f in np.random.permutation(prob.n_frags)[:60]]
+            s.keep_all_scores = True
+            hip_lib.debug_set_zero_inject(inject)
+            n_fb3 = s.ctx.debug_zero_fallbacks() - n_fb - n_fb2
             sums, _ = s.ctx.debug_globals()
             _, _, limbs = s.ctx.full_likelihood(0)
             assert [int(x) for x in sums[:5]] == [int(x) for x in limbs[:5]]
             cols = ["o", "dist", "op_sampled", "id_f_sampled", "n_contigs"]
-            outs.append((res[cols].tobytes(), res2[cols].tobytes(), [tuple(float(np.ravel(x)[0]) for x in q[:7]) for q in tuples],
+            outs.append((res[cols].tobytes(), res2[cols].tobytes(), rows3, [tuple(float(np.ravel(x)[0]) for x in q[:7]) for q in tuples],
                          s.gpu_vect_frags.copy_from_gpu().soa17().tobytes(), [int(x) for x in s.ctx.valid_insert()],
                          np.random.get_state()[1][:8].tobytes()))
             if inject:
-                assert n_fb >= 20 and n_fb2 >= 5, (n_fb, n_fb2)
+                assert n_fb >= 20 and n_fb2 >= 5 and n_fb3 >= 5, (n_fb, n_fb2, n_fb3)
             else:
-                assert n_fb == 0 and n_fb2 == 0
+                assert n_fb == 0 and n_fb2 == 0 and n_fb3 == 0
             s.free_gpu()
     finally:
         hip_lib.debug_set_zero_inject(0)
