@@ -21,6 +21,9 @@ The two halves need different machines' strengths (one MI355X for seconds, host 
     python tools/fuzz_oracle.py CASES [FIRST_SEED] --record FILE.npz    HIP only: what it returned, per case      (a GPU box)
     python tools/fuzz_oracle.py --check FILE.npz [--jobs J]             the oracle against a recording            (no GPU needed)
     ... --how nuis | batch | width | nowindow | one                      every case in that mode (with --check: as recorded)
+    ... --long K                                                         K times the moves (and the oracle's budget) per case
+    ... --big                                                            5 000 - 20 000 bins, up to 1.5 M contacts, mostly small pools (record
+                                                                         on a GPU box, check on host cores: an oracle move takes 0.1 - 0.3 s)
 """
 import os
 import sys
@@ -51,6 +54,7 @@ def _state_equal(expect, k, arr):
 
 
 FORCE_HOW = None  # (--how: every case of a run in one mode)
+BIG = 0   # (--big: problems of 5 000 - 20 000 bins; the oracle half is meant for --check on host cores)
 LONG = 1  # (--long K: K times the moves per case, and K times the oracle's budget -- runaway parameters take hundreds of accepted steps)
 
 
@@ -62,6 +66,9 @@ def make_case(seed):
     n_frags = int(r.choice([60, 150, 300, 700, 1200, 2000]))
     per = int(r.choice([8, 30, 100, 400]))
     per = max(8, min(per, 600000 // n_frags, n_frags))
+    if BIG:  # (--big: 5 000 - 20 000 bins, up to 1.5 M contacts -- lists that overflow small pools and the exact kernel's first grid)
+        n_frags = int(r.choice([5000, 10000, 20000]))
+        per = max(15, min(int(r.choice([30, 75, 150])), 1500000 // n_frags))
     mean_len = int(r.choice([2, 4, 15, 50, 200, 1000]))
     mean_len = min(mean_len, max(2, n_frags // 3))
     prob = synth.make_problem(n_frags, n_frags * per, 7000 + seed, mean_len, cis_frac=float(r.choice([0.3, 0.6, 0.8, 0.95])))
@@ -89,7 +96,7 @@ def make_case(seed):
                       v_inter=float(prob.params["v_inter"]) * float(r.choice([0.1, 1.0, 10.0])))
     n_nb = int(r.choice([1, 3, 5, 5, 9, 16]))
     bomb = int(r.randint(4) == 0)
-    pool = int(r.choice([0, 0, 0, 3000, 30000]))
+    pool = int(r.choice([0, 0, 0, 3000, 30000])) if not BIG else int(r.choice([0, 3000, 3000, 30000]))
     # the default window / another width / no window (round 4's batches) / one step_sampler call per move / a nuisance step behind every
     # move (step_sampler_nuisance_batch: chains, screened tiers -- against o.step_sampler + o.step_nuisance_parameters, CL:2961-3051)
     how = str(r.choice(["batch", "batch", "width", "nowindow", "one", "nuis"]))
@@ -247,11 +254,12 @@ def live_case(seed, threads=0):
 
 
 def _check_one(args):
-    global FORCE_HOW, LONG
+    global FORCE_HOW, LONG, BIG
     path, seed, threads = args
     z = np.load(path, allow_pickle=False)
     FORCE_HOW = (str(z["how"]) or None) if "how" in z.files else None
     LONG = int(z["long"]) if "long" in z.files else 1
+    BIG = int(z["big"]) if "big" in z.files else 0
     pre = "c%d_" % seed
     exp = dict(records=z[pre + "records"], state_digests=z[pre + "state_digests"], state_last=z[pre + "state_last"], flags=z[pre + "flags"],
                nuis=z[pre + "nuis"] if pre + "nuis" in z.files else np.zeros((0, 7)), rng_key=z[pre + "rng_key"], rng_pos=int(z[pre + "rng_pos"]))
@@ -280,6 +288,9 @@ def main(argv):
         elif a == "--long":
             global LONG
             LONG = int(next(it))
+        elif a == "--big":
+            global BIG
+            BIG = 1
         else:
             pos.append(a)
     t00 = time.time()
@@ -343,6 +354,7 @@ def main(argv):
         store["seeds"] = np.array(done, np.int64)
         store["how"] = np.array(FORCE_HOW or "")
         store["long"] = np.int64(LONG)
+        store["big"] = np.int64(BIG)
         np.savez_compressed(record, **store)
         print("%d cases recorded in %s (%.1f MB), %d failed, %.0f s" % (len(done), record, os.path.getsize(record) / 1e6, bad, time.time() - t00))
     else:
