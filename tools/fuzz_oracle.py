@@ -118,8 +118,11 @@ def make_case(seed):
     chunk = int(r.choice([50, 50, 17, 1000])) if how == "nuis" else CHECK_EVERY
     desc = dict(seed=int(seed), n_frags=n_frags, per=per, mean_len=mean_len, scale=scale, params=kind, n=n, neighbours=n_nb, bomb=bomb,
                 pool=pool, how=how, width=width)
+    nwidth = int(r.choice([0, 0, 16, 24]))  # (a fixed width of a run's batches: both halves scored W slots at a time -- more overflows per batch)
     if how == "nuis":
         desc.update(hist=hist, chain=chain, chunk=chunk)
+        if BIG:
+            desc.update(nwidth=nwidth)
     return prob, params, desc
 
 
@@ -144,6 +147,7 @@ def run_hip(prob, params, desc):
     if desc["how"] == "nuis":
         hip_lib.set_nuis_hist(desc.get("hist", 2))  # (2: the histogram tier whatever its cost model says -- chains need it)
         hip_lib.set_nuis_chain(desc.get("chain", 1))
+        hip_lib.set_nuis_width(desc.get("nwidth", 0))
     try:
         np.random.seed(desc["seed"])
         # (one call per move: every other case the way ``simulation`` constructs the sampler -- no all_scores, the batch of one in two tiers)
@@ -187,6 +191,7 @@ def run_hip(prob, params, desc):
             pass
         hip_lib.set_nuis_hist(1)
         hip_lib.set_nuis_chain(1)
+        hip_lib.set_nuis_width(0)
 
 
 def run_oracle(prob, params, desc, threads=0, expect=None):
