@@ -3,8 +3,10 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the path over one BATCH of moves: ``--moves-per-step`` (default 24, the speculative batch width
-the library scores per launch of its kernels) consecutive ``step_sampler`` calls (CL:1401-1465), each one the candidate
+A "step" is one pass of the path over one BATCH of moves: ``--moves-per-step`` (default 128; until round 5 it was 24, the
+speculative batch width of rounds 1 - 4 -- since the window rule a launch chain covers ~35 moves and the driver's
+``--steps 20 --warmup 5`` timed 480 moves in 10 ms, a quarter of BASELINE.md section 3's protocol of >= 2 000 moves behind
+>= 200) consecutive ``step_sampler`` calls (CL:1401-1465), each one the candidate
 draw (return_neighbours, CL:3103-3141, on numpy's generator stream), one focal bin, <= 5 partner bins, up to 5 x 24
 candidate genomes scored, argmax applied.  ``value`` is MOVES per second (BASELINE.json's metric) = K x moves-per-step /
 elapsed; ``ms_per_step`` is per batch; ``config.moves_timed`` says how many moves the timed region held.  (Rounds 1 and
@@ -157,9 +159,11 @@ def spawn_workers(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=84, help="timed batches of --moves-per-step moves")
-    ap.add_argument("--warmup", type=int, default=8, help="untimed batches before them")
-    ap.add_argument("--moves-per-step", type=int, default=24, help="moves (step_sampler calls) per step")
+    ap.add_argument("--steps", type=int, default=20, help="timed steps of --moves-per-step moves")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed steps before them")
+    ap.add_argument("--moves-per-step", type=int, default=128,
+                    help="moves (step_sampler calls) per step: 128, so that the driver's --steps 20 --warmup 5 times 2 560 moves behind 640 "
+                         "(BASELINE.md section 3: >= 2 000 timed after >= 200)")
     ap.add_argument("--config", default="cfg3", help="synthetic shape: cfg2 | cfg3 | cfg5 | small | tiny")
     ap.add_argument("--neighbours", type=int, default=5)
     ap.add_argument("--seed", type=int, default=0)
@@ -397,7 +401,8 @@ def main():
         # HBM bytes per launch of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
         # separate passes) of THIS workload, committed under profiles/ -- replayed from the file named below, not measured
         # in this run (the counters need the profiler around the process)
-        traffic = valu_busy = traffic_src = batch_traffic = None
+        traffic = valu_busy = traffic_src = batch_traffic = prof_mpl = None
+        traffic_scale = 1.0
         try:
             import glob
 
@@ -405,13 +410,17 @@ def main():
             if pmc and world == 1:
                 allk = json.load(open(pmc[-1]))
                 prof = allk[dom_key]
-                traffic = float(prof["traffic_bytes_per_launch"])
+                # REPLAYED, not measured here: per launch of the profiled run, scaled to this run's moves per launch chain where the
+                # summary says how many moves its launches covered (a launch's traffic follows the slots it scores)
+                prof_mpl = allk.get("moves_per_launch")
+                traffic_scale = (n_moves / max(int(n_launch), 1)) / float(prof_mpl) if prof_mpl else 1.0
+                traffic = float(prof["traffic_bytes_per_launch"]) * traffic_scale
                 valu_busy = float(prof["VALUBusy_pct"]) / 100.0  # fraction of cycles the VALUs issue
                 traffic_src = "profiles/" + os.path.basename(pmc[-1])
                 # the whole batch: every kernel of it that was counted (the slice lists' round trip -- written by k_slice, read
                 # by the scoring kernels -- is in neither B_min nor the dominant kernel's figure)
                 # every kernel of a batch that was counted (k_predict runs twice per batch; k_full_nz_tiled and k_tail are not part of one)
-                per_k = {k: float(v["traffic_bytes_per_launch"]) * (2.0 if k == "k_predict" else 1.0) for k, v in allk.items()
+                per_k = {k: float(v["traffic_bytes_per_launch"]) * traffic_scale * float(v.get("launches_per_chain", 1.0)) for k, v in allk.items()
                          if isinstance(v, dict) and "traffic_bytes_per_launch" in v and k not in ("k_full_nz_tiled", "k_tail", "k_commit_batch")}
                 batch_traffic = {"bytes_per_batch": sum(per_k.values()), "by_kernel": per_k}
         except Exception:
@@ -433,6 +442,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak" if replicas else "strong",
             "vs_baseline": None,
+            # BASELINE.md section 3's protocol read literally -- "wall-clock around step_sampler", ONE call per move, the reference's loop
+            # (IG:221-228) unchanged but for the import: what a drop-in-by-import caller gets; `value` needs the caller to hand a cycle's
+            # bins to step_sampler_batch, results identical
+            "value_unchanged_caller": None if not ref_loop else ref_loop.get("moves_per_s"),
+            "value_unchanged_caller_unit": "moves/s, one sampler.step_sampler call per move (median %s us per call)" % (
+                "%.0f" % ref_loop["us_per_call"] if ref_loop and ref_loop.get("us_per_call") else "?"),
             "dtype": "f32 screening tier with a rigorous bound (every column) + f64 terms (f32 inputs) for the contenders / exact i64 fixed-point sums",
             "data": "synthetic",
             "config": {"workload": "synthetic Hi-C %s (%d sub-frags), level 4, %d neighbours, nuisance sampling off%s" % (
@@ -457,6 +472,11 @@ def main():
                 "B_ref_bytes_per_move": b_ref},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": traffic_src, "valu_busy_profiled": valu_busy, "kernel": dom_name,
+                         "traffic_replayed": None if traffic is None else {
+                             "replayed": True, "profiled_moves_per_launch": prof_mpl, "this_run_moves_per_launch": n_moves / n_launch,
+                             "scale_applied": traffic_scale,
+                             "note": "HBM bytes come from separate rocprofv3 --pmc passes of this workload (the file in traffic_source), per launch "
+                                     "of that run, scaled by this run's moves per launch chain / the profiled run's; not counted in this process"},
                          "traffic_over_algorithmic": None if not traffic else traffic / max(bytes_min, 1.0),
                          "batch_traffic": batch_traffic,
                          "batch": {"bytes": bytes_min, "ms": 1e3 * elapsed / n_launch, "frac": bytes_min / (elapsed / n_launch) / 8e12,

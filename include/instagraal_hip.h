@@ -136,7 +136,7 @@ int ig_step_batch_draw(ig_ctx* ctx, ig_neighbours* nb, uint32_t* mt_key624, int3
  * scores only slots [slot_begin, slot_end); the slot-major score records (ig_batch_records: one device buffer, a fixed
  * number of bytes per slot) are all-gathered by the caller; then every rank commits the batch -- identical integer
  * inputs, identical decisions, no further communication.  W <= max_w <= 64. */
-int ig_batch_max_width(ig_ctx* ctx, int32_t max_c); /* largest W whose work buffers fit (<= 64; ~0.84 GB per slot at 50 k bins) */
+int ig_batch_max_width(ig_ctx* ctx, int32_t max_c); /* largest W whose work buffers fit (<= 64; the per-slot window arrays are strided by 3 x the longest contig: ~12 MB per slot at 50 k bins in 1 000 contigs, gigabytes late in an assembly) */
 int ig_batch_upload(ig_ctx* ctx, int32_t n_moves, const int32_t* frags, const int32_t* cands, int32_t max_c, int32_t max_w);
 int ig_batch_score(ig_ctx* ctx, int32_t move0, int32_t W, int32_t slot_begin, int32_t slot_end); /* asynchronous */
 int ig_batch_records(ig_ctx* ctx, void** records, int64_t* bytes_per_slot); /* slot w: records + w * bytes_per_slot */

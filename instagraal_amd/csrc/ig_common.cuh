@@ -483,6 +483,7 @@ struct ig_ctx {
     unsigned long long last_stale; /* the window rule: positions the last decide launch found stale (wait_commit) */
     long long n_window_slots;      /* ... slots scored by its launches */
     int max_L, max_SL;      /* host copies of Glob.max_L / max_SL as of the last synchronisation */
+    int win_slots = 0;      /* physical slots the per-window arrays hold (ensure_window_buffers; <= mb.capW) */
     bool full_windows;      /* window strides = the whole genome (runs of moves enqueued one at a time without a host round trip) */
     int* host_max;          /* pinned: {max_L, max_SL} copied back with every one-move call's result */
     struct StepHost *host_step, *host_step_dev; /* ig_step_draw: mapped host memory and its device address (null: not available) */

@@ -25,14 +25,11 @@
  * from-scratch pass over all contacts: k_pack_tab_sig / k_nuis_prepare, k_tile_trans, k_full_nz_tiled; the
  * nuisance step's screened pass: k_hist_build / k_hist_walk / k_hist_eval (tier 0), k_full_diff_tiled (tier 1).
  *
- * Environment knobs (tuning and tests only): IG_BATCH_W (moves per batch, default 24), IG_POOL_ENTRIES (slice pool size: a small
- * one forces the overflow / re-run path), IG_WIDE_LISTS=1 (12-byte slice entries even where the packed 8-byte form fits),
- * IG_NO_HOST_FLAG=1 (outcomes by copy + synchronise instead of the polled mapped copies), IG_SCREEN=0 / IG_SCREEN_VERIFY=1 (every
- * column exact / exact and screened, bounds checked), IG_FUSE_TAIL=0, IG_SLICE_SHARE=0, IG_FULL_TILED=0, IG_FULL_HIST=0 (the
- * earlier forms of those kernels), IG_FULL_GRID / IG_FULL_GRID_SIDE (persistent grid of the from-scratch pass), IG_NUIS_W /
- * IG_NUIS_WMAX (moves scored ahead in the nuisance-on loop), IG_NUIS_SCREEN / IG_NUIS_HIST / IG_NUIS_SCREEN_VERIFY (the screened
- * nuisance pass and its tiers), IG_NUIS_ASYNC=0 (no helper thread), IG_NUIS_BG=1 (the next batch in the background), IG_ABLATE
- * (bit 1: every column of k_score_list through the checked path).
+ * Environment knobs (tests, fault injection and tuning only; the table in INTEGRATION.md section 4 is the reference): IG_BATCH_W, IG_WINDOW
+ * (widths), IG_POOL_ENTRIES, IG_WIDE_LISTS, IG_NO_HOST_FLAG, IG_POISON_ALLOC / IG_POISON_ONLY (force the rare paths), IG_SCREEN,
+ * IG_SCREEN_VERIFY, IG_ABLATE, IG_WINDOW_CHECK, IG_FUSED_COMMIT, IG_STEP_DRAW_FAST (the same results another way: what the
+ * path-against-path tests and fuzzers toggle), IG_NUIS_W, IG_NUIS_SCREEN, IG_NUIS_HIST, IG_NUIS_SCREEN_VERIFY, IG_NUIS_SCREEN_NOCHECK,
+ * IG_NUIS_HIST_TRACE, IG_NUIS_CHAIN, IG_NUIS_ASYNC (the nuisance step's tiers and its helper thread).
  */
 #include <chrono>
 #include <condition_variable>

@@ -740,415 +740,9 @@ __device__ __forceinline__ void screen_block(const ScreenConst* __restrict__ sc,
         screen_publish(sc, scr, scr_void, cw, isB ? kB : kA, n, S, E, O, Y, B);
     }
 }
-/* ---- round 5: the MULTI-COLUMN pass -- MEASURED AND DROPPED (profiles/r05e_screen_multi_probe.txt); compiled only with
- * -DIG_SCREEN_MULTI_PROBE, as the probe behind that table (IG_SCREEN_MPROBE=mode[,groups[,workgroups]], tools/screen_probe.py).
- * At the headline shape the launch takes 250 - 310 us against the pair pass's 170: its workgroups' fixed part alone (first round of loads
- * 26 - 52 us, staging + barrier + 50, reduction and publication of 8 columns + 70: long straight-line code run once per workgroup) is what
- * the whole pair launch costs, and the pass itself (110 - 130 us) is slower than the pair pass's 85 at four waves per SIMD. */
-#ifdef IG_SCREEN_MULTI_PROBE
-/* A workgroup = (segment of the slice list, a GROUP of up to 8 live columns, candidate): the
- * group's columns are staged side by side in a pool of SCREEN_POOL records (32 KB: 8 columns of windows up to 512 sub-fragments, 4 of
- * up to 1 024, 2 of up to 2 048) and the segment is walked ONCE -- an entry is loaded and unpacked once for all of them, and the fixed
- * part of a workgroup (three dependent rounds of loads, staging, reduction, publication: 57 us of the pair launch's 166 at the headline
- * shape, tools/screen_probe.py) is paid by a quarter of the workgroups.  The term, the ring pairs' upper bound and the error sums are
- * screen_pair_col's, column by column; the groups are balanced (14 live columns: 7 + 7).  What the pass cannot take -- parameters
- * outside the one-log domain, a ring without an upper bound or on the current genome's own column, windows above 2 048
- * sub-fragments -- goes column by column through screen_column, as it always did. */
-#ifndef SCREEN_POOL
-#define SCREEN_POOL 4096
-#endif
-#define SCREEN_GMAX 8
-#ifndef SCREEN_GCAP_MAX
-#define SCREEN_GCAP_MAX 8 /* most columns of a group (8, or 4 where the register budget of more waves per SIMD is wanted) */
-#endif
-#ifndef SCREEN_MB
-#define SCREEN_MB 4 /* list entries a lane of the multi-column pass has in flight */
-#endif
-struct alignas(16) ScreenLdsM {
-    float pzc[LDS_PZ + 2];
-    unsigned pad_[2];
-    double red_s[SCORE_THREADS / 64][SCREEN_GMAX];
-    float red_e[SCORE_THREADS / 64][SCREEN_GMAX], red_y[SCORE_THREADS / 64][SCREEN_GMAX];
-    float red_o[SCORE_THREADS / 64];
-    unsigned red_bad[SCORE_THREADS / 64], red_void[SCORE_THREADS / 64];
-    unsigned pad2_[4];
-    uint2 cols[SCREEN_POOL];
-};
-union alignas(16) ScreenLdsU {
-    ScreenLds2 pair; /* the one-column routine's view (fallback columns) */
-    ScreenLdsM multi;
-};
-
-/* the terms of ONE entry under TWO columns (A at cbA, B at cbB) -- screen_pair_col's arithmetic with the packed lanes holding the two
- * columns instead of two entries: t.x is column A's term, t.y column B's.  The gathers come in from the caller (all columns' records
- * are requested before the first term is computed: one wave in four per SIMD cannot hide an LDS round trip per column). */
-template <bool CIRC>
-__device__ __forceinline__ void screen_cols2(const uint2 a0, const uint2 b0, const uint2 a1, const uint2 b1, const float pz0, const float pz1, float obf,
-                                             float slope, float la, float lv, float d_max, float c10, double& accA, double& accB, f32x2& exs2,
-                                             float& ymax, unsigned maskA = 0u, unsigned maskB = 0u, float ru_k1 = 0.0f, float ru_k0 = 0.0f,
-                                             float ru_ob = 0.0f, unsigned* badA = nullptr, unsigned* badB = nullptr)
-{
-    const unsigned d0 = abs_diff_u32(a0.y, b0.y), d1 = abs_diff_u32(a1.y, b1.y);
-    f32x2 sv;
-    __asm__("v_sub_f32 %0, %1, %2" : "=v"(sv.x) : "v"(__uint_as_float(a0.x)), "v"(__uint_as_float(b0.x)));
-    __asm__("v_sub_f32 %0, %1, %2" : "=v"(sv.y) : "v"(__uint_as_float(a1.x)), "v"(__uint_as_float(b1.x)));
-    const bool in0 = (d0 < (1u << 27)) && (sv.x != 0.0f) && (fabsf(sv.x) < d_max);
-    const bool in1 = (d1 < (1u << 27)) && (sv.y != 0.0f) && (fabsf(sv.y) < d_max);
-    const f32x2 pzc = {pz0, pz1};
-    const f32x2 lg2 = {__builtin_amdgcn_logf(fabsf(sv.x)), __builtin_amdgcn_logf(fabsf(sv.y))};
-    const f32x2 y = __builtin_elementwise_fma(f32x2{slope, slope}, lg2, f32x2{la, la});
-    float m0, m1;
-    __asm__("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(y.x), "v"(lv));
-    __asm__("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(y.y), "v"(lv));
-    const f32x2 yy = {in0 ? m0 : lv, in1 ? m1 : lv};
-    const f32x2 ex = {__builtin_amdgcn_exp2f(yy.x), __builtin_amdgcn_exp2f(yy.y)};
-    const f32x2 m = f32x2{obf, obf} * yy;
-    f32x2 t = __builtin_elementwise_fma(m, f32x2{c10, c10}, -ex) + pzc;
-    if (CIRC) {
-        const bool r0 = (d0 < (1u << 27)) && ((maskA >> (a0.y >> 28)) & 1u), r1 = (d1 < (1u << 27)) && ((maskB >> (a1.y >> 28)) & 1u);
-        const float u = fmaxf(__builtin_fmaf(obf, ru_k1, ru_k0), __builtin_fmaf(obf, 4.2145f, -1048575.9f));
-        t.x = r0 ? u : t.x;
-        t.y = r1 ? u : t.y;
-        *badA |= (r0 && obf > ru_ob) ? 0x80000000u : 0u;
-        *badB |= (r1 && obf > ru_ob) ? 0x80000000u : 0u;
-    }
-    accA += (double)t.x;
-    accB += (double)t.y;
-    exs2 += ex;
-    __asm__("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(ymax) : "v"(yy.x), "v"(yy.y));
-}
-
-/* the pass of one group: 2 P columns (an odd group's last column staged twice) at compile-time stride STRIDE (records) in L.cols;
- * ANYRING: some column of the group has a ring on its window (circ[k] != 0: that column's ring pairs take their upper bound) */
-template <int P, int STRIDE, bool ANYRING>
-__device__ __forceinline__ void screen_multi_pass(ScreenLdsM& L, const unsigned long long* __restrict__ slp, unsigned nn, float slope, float la_s,
-                                                  float lv_s, float d_max, float zc_ub_s, const unsigned (&circ)[SCREEN_GMAX], double (&acc)[SCREEN_GMAX],
-                                                  float (&exo)[SCREEN_GMAX], float (&ymax)[SCREEN_GMAX], unsigned (&badk)[SCREEN_GMAX], float& obs,
-                                                  unsigned& bad, const unsigned long long (&nx0)[SCREEN_MB])
-{
-    /* a wave takes 64 x SCREEN_MB consecutive entries per step (steps wave, wave + 4, ...); a lane works through its SCREEN_MB entries
-     * ONE at a time (2 P terms each: all their gathers requested up front), each entry's successor -- the next step's -- requested as
-     * soon as it is unpacked: SCREEN_MB global loads in flight per lane (one was not enough: a step's terms are shorter than a load) */
-    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned step = 64 * SCREEN_MB, stride = step * (SCORE_THREADS / 64);
-    const float c10 = (float)IG_LOG2_10_INV;
-    float la, lv;
-    __asm__ volatile("v_mov_b32 %0, %1" : "=v"(la) : "s"(la_s));
-    __asm__ volatile("v_mov_b32 %0, %1" : "=v"(lv) : "s"(lv_s));
-    const char* colb = (const char*)L.cols;
-    const char* pzb = (const char*)L.pzc;
-    const unsigned long long* ptr = slp + wave * step + lane;
-    unsigned long long nx[SCREEN_MB];
-#pragma unroll
-    for (int u = 0; u < SCREEN_MB; u++) nx[u] = nx0[u]; /* (requested by the caller, in front of the staging) */
-    f32x2 exs[P];
-    float ymx[P];
-#pragma unroll
-    for (int k = 0; k < P; k++) {
-        exs[k] = f32x2{0.0f, 0.0f};
-        ymx[k] = 0.0f;
-    }
-    const float lem_s = __builtin_amdgcn_logf(fmaxf(d_max, 1e-30f)) * c10;
-    const float ru_k1 = lem_s + 1e-5f * fabsf(lem_s), ru_k0 = zc_ub_s - d_max + 1e-5f * d_max, ru_ob = d_max * 2.3f;
-    unsigned s0 = wave * step;
-    for (; s0 + step <= nn; s0 += stride) { /* full steps: all columns of the group from one pass over the entries */
-        ptr += stride;
-#pragma unroll
-        for (int u = 0; u < SCREEN_MB; u++) {
-            const unsigned lo = (unsigned)nx[u], hi = (unsigned)(nx[u] >> 32);
-            bad |= hi;
-            const unsigned oi = (lo << 3) & 0x7ffff8u, oj = __builtin_amdgcn_alignbit(hi, lo, 17) & 0x7ffff8u;
-            const float obf = (float)(hi >> 8);
-            nx[u] = ptr[u * 64];
-            obs += obf;
-            uint2 ra[2 * P], rb[2 * P];
-#pragma unroll
-            for (int k = 0; k < 2 * P; k++) { /* every column's two records first ... */
-                const char* cb = colb + (size_t)k * STRIDE * sizeof(uint2);
-                ra[k] = *(const uint2*)(cb + oi);
-                rb[k] = *(const uint2*)(cb + oj);
-            }
-            float pz[2 * P];
-#pragma unroll
-            for (int k = 0; k < 2 * P; k++) /* ... then their P_z entries ... */
-                pz[k] = *(const float*)(pzb + min(abs_diff_u32(ra[k].y, rb[k].y), 4u * LDS_PZ));
-#pragma unroll
-            for (int k = 0; k < P; k++) { /* ... then the terms, two columns at a time */
-                if (ANYRING && (circ[2 * k] | circ[2 * k + 1]))
-                    screen_cols2<true>(ra[2 * k], rb[2 * k], ra[2 * k + 1], rb[2 * k + 1], pz[2 * k], pz[2 * k + 1], obf, slope, la, lv, d_max, c10,
-                                       acc[2 * k], acc[2 * k + 1], exs[k], ymx[k], circ[2 * k], circ[2 * k + 1], ru_k1, ru_k0, ru_ob, &badk[2 * k],
-                                       &badk[2 * k + 1]);
-                else
-                    screen_cols2<false>(ra[2 * k], rb[2 * k], ra[2 * k + 1], rb[2 * k + 1], pz[2 * k], pz[2 * k + 1], obf, slope, la, lv, d_max, c10,
-                                        acc[2 * k], acc[2 * k + 1], exs[k], ymx[k]);
-            }
-            __builtin_amdgcn_sched_barrier(0); /* (two entries' gathers side by side do not fit the registers of four waves per SIMD) */
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < P; k++) {
-        exo[2 * k] += exs[k].x;
-        exo[2 * k + 1] += exs[k].y;
-        ymax[2 * k] = fmaxf(ymax[2 * k], ymx[k]); /* (the larger of the pair's two: a bound may be too large) */
-        ymax[2 * k + 1] = fmaxf(ymax[2 * k + 1], ymx[k]);
-    }
-#pragma unroll
-    for (int u = 0; u < SCREEN_MB; u++) { /* the partly filled step: masked, sub-step by sub-step */
-        if (s0 + u * 64 >= nn) break;
-        const bool live = s0 + u * 64 + lane < nn;
-        const unsigned long long e = live ? nx[u] : slp[0];
-        const unsigned lo = (unsigned)e, hi = (unsigned)(e >> 32);
-        bad |= live ? hi : 0u;
-        const unsigned oi = (lo << 3) & 0x7ffff8u, oj = __builtin_amdgcn_alignbit(hi, lo, 17) & 0x7ffff8u;
-        const float obf1 = (float)(hi >> 8);
-        obs += live ? obf1 : 0.0f;
-#pragma unroll
-        for (int k = 0; k < 2 * P; k++) {
-            const char* cb = colb + (size_t)k * STRIDE * sizeof(uint2);
-            const uint2 ai = *(const uint2*)(cb + oi), bj = *(const uint2*)(cb + oj);
-            const unsigned dq = abs_diff_u32(ai.y, bj.y);
-            const bool cis = dq < (1u << 27);
-            const float sv = fabsf(__uint_as_float(ai.x) - __uint_as_float(bj.x));
-            const bool in = cis && (sv > 0.0f) && (sv < d_max);
-            const float pzc = *(const float*)(pzb + min(dq, 4u * LDS_PZ));
-            const float y = __builtin_fmaf(slope, __builtin_amdgcn_logf(sv), la);
-            float ymx1;
-            __asm__("v_max_f32 %0, %1, %2" : "=v"(ymx1) : "v"(y), "v"(lv));
-            const float yy = in ? ymx1 : lv;
-            const float ex = __builtin_amdgcn_exp2f(yy);
-            float t = __builtin_fmaf(obf1 * yy, c10, -ex) + pzc;
-            bool ring = false;
-            if (ANYRING && cis && ((circ[k] >> (ai.y >> 28)) & 1u)) { /* (screen_term's bound, as the pair pass's masked step takes it) */
-                const float em = fmaxf(d_max, 0.43429448f * obf1);
-                const float lem = __builtin_amdgcn_logf(em) * c10;
-                const float ub0 = __builtin_fmaf(obf1, lem, -em) + zc_ub_s + 1e-5f * (obf1 * fabsf(lem) + em);
-                const float lgf_ub = obf1 * __builtin_amdgcn_logf(fmaxf(obf1, 1.0f)) * c10 * 1.00001f + 1e-3f;
-                t = fmaxf(ub0, -1048576.0f + lgf_ub);
-                ring = true;
-            }
-            acc[k] += (double)(live ? t : 0.0f);
-            exo[k] += (live && !ring) ? ex : 0.0f;
-            const float yya = (live && !ring) ? yy : 0.0f;
-            __asm__("v_max_f32 %0, %0, |%1|" : "+v"(ymax[k]) : "v"(yya));
-        }
-    }
-}
-
-/* one workgroup of the multi-column pass: segment `seg` (part q of Q) of candidate zc's slice list, group `grp` of its live columns */
-__device__ __forceinline__ void screen_block_multi(const ScreenConst* __restrict__ sc, const MoveBuf& mb, ScreenSum* __restrict__ scr,
-                                                   unsigned* __restrict__ scr_void, unsigned* __restrict__ scr_ub, int max_c, int w_begin, int seg,
-                                                   int grp, int zc, ScreenLdsU& LU, int use_order, int q, int Q, int dbg = 0)
-{
-    /* dbg (IG_SCREEN_MPROBE: probe launches into scratch sums, tools/screen_probe.py): 1 leave behind the first round of loads, 2 behind the
-     * staging's barrier, 4 no entries (staging, reduction, publication), 8 no staging of the columns */
-    ScreenLdsM& L = LU.multi;
-    const int oc = use_order ? mb.order[zc] : (((w_begin + zc / max_c) << 8) | (zc % max_c));
-    const int w = oc >> 8, c = oc & 255;
-    const int cw = CW(w, c);
-    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const CandMeta* mp = &mb.meta[cw];
-    const int C = mb.ctl[PS(w)].C;
-    const int n_uniq = mp->n_uniq, m_loc = mp->m_loc;
-    const unsigned livecol = mb.livecol[cw];
-    long long n = mb.part[(size_t)cw * P_STRIDE + P_CNT + seg];
-    long long off = mb.sloff[(size_t)cw * SLICE_SEG + seg];
-    /* (the grid holds the most groups a candidate can have; most workgroups of it leave here, on their first round of loads) */
-    if (c >= C) return;
-    const unsigned live = 1u | (livecol & (n_uniq >= 31 ? 0xfffffffeu : ((2u << n_uniq) - 2u)));
-    const int n_live = __popc(live);
-    /* columns per group: what the pool holds at this window's size, the groups balanced */
-    const int gcap = (m_loc <= SCREEN_POOL / 8 && SCREEN_GCAP_MAX >= 8) ? 8 : ((m_loc <= SCREEN_POOL / 4 && SCREEN_GCAP_MAX >= 4) ? 4 : 2);
-    const int n_groups = (n_live + gcap - 1) / gcap;
-    if (grp >= n_groups) return;
-    if (off >= 0) screen_chunk(n, off, q, Q);
-    if (n == 0 || off < 0) return;
-    if (dbg & 1) return;
-    const float slope = sc->slope, la_s = sc->la, lv_s = sc->lv, d_max = sc->d_max, zc_ub_s = sc->zc_ub;
-    const int fast = sc->fast;
-    const float4 pz_v = ((const float4*)sc->pzc)[threadIdx.x]; /* (LDS_PZ + 2) / 4 = 256 vectors and two more words */
-    const float pz_t = sc->pzc[(LDS_PZ + 2) / 4 * 4 + (threadIdx.x & 1)];
-    const int per = (n_live + n_groups - 1) / n_groups;
-    const int first = grp * per;
-    const int ncol = min(per, n_live - first);
-    if (ncol <= 0) return;
-    int kcol[SCREEN_GMAX];
-    {
-        unsigned rest = live;
-        for (int x = 0; x < first; x++) rest &= rest - 1;
-#pragma unroll
-        for (int j = 0; j < SCREEN_GMAX; j++) {
-            kcol[j] = (j < ncol && rest) ? __ffs(rest) - 1 : -1;
-            if (j < ncol) rest &= rest - 1;
-        }
-    }
-    /* rings: lane 8 j + code asks column j's contig code */
-    unsigned circ[SCREEN_GMAX];
-    {
-        const int j = lane >> 3, code = lane & 7;
-        int kj = -1;
-#pragma unroll
-        for (int x = 0; x < SCREEN_GMAX; x++) kj = (x == j) ? kcol[x] : kj;
-        const float st = (kj >= 0 && code < NCODE) ? mb.cmeta[(size_t)(cw * NSLOT + kj) * NCODE + code].stot : 0.0f;
-        const unsigned long long bal = __ballot(st != 0.0f);
-#pragma unroll
-        for (int x = 0; x < SCREEN_GMAX; x++) circ[x] = (unsigned)((bal >> (8 * x)) & 0xffull);
-    }
-    const unsigned long long* slp = mb.sl_pk + off;
-    unsigned long long nx0[SCREEN_MB]; /* the wave's first entries: on their way while the columns are staged (the pool has slack behind its last entry) */
-#pragma unroll
-    for (int u = 0; u < SCREEN_MB; u++) nx0[u] = slp[wave * 64 * SCREEN_MB + u * 64 + lane];
-    /* (windows beyond the staged P_z table's length under a table longer than its staged copy: the far pairs' entries come from the
-     * table itself -- the one-column routine's business) */
-    bool anyring = false, ok = fast && m_loc <= SCREEN_POOL / 2 && (m_loc <= LDS_PZ || sc->pz_n <= LDS_PZ);
-#pragma unroll
-    for (int j = 0; j < SCREEN_GMAX; j++) {
-        anyring |= circ[j] != 0u;
-        if (circ[j] && (zc_ub_s < 0.0f || kcol[j] == 0)) ok = false; /* a ring without an upper bound / on the current genome's own column */
-    }
-    if (!ok) { /* column by column, as ever (barriers inside; every thread of the workgroup takes the same way) */
-        for (int j = 0; j < ncol; j++) {
-            int kj = -1;
-#pragma unroll
-            for (int x = 0; x < SCREEN_GMAX; x++) kj = (x == j) ? kcol[x] : kj;
-            __syncthreads();
-            screen_column(LU.pair.one, sc, mb, scr, scr_void, scr_ub, w, c, kj, seg, q, Q);
-        }
-        return;
-    }
-    /* staging: ranks x 4 (screen_pair), column j at j * stride; an odd group's last column twice (the pass takes the columns in pairs) */
-    const int stride = SCREEN_POOL / gcap;
-    const int npair = (ncol + 1) / 2;
-    {
-        /* record r of the pool: column r / stride, local sub-fragment r % stride -- SCREEN_POOL / SCORE_THREADS = 16 records per thread,
-         * all requested before the first is stored (column by column they were 8 dependent round trips per workgroup) */
-        constexpr int RPT = SCREEN_POOL / SCORE_THREADS;
-        uint2 v[RPT];
-        const int sh = __ffs(stride) - 1; /* log2(stride) */
-#pragma unroll
-        for (int r = 0; r < RPT; r++) {
-            const int rec = r * SCORE_THREADS + threadIdx.x;
-            const int j = rec >> sh, i = rec & (stride - 1);
-            int kj = -1;
-#pragma unroll
-            for (int x = 0; x < SCREEN_GMAX; x++) kj = (x == j) ? ((x == 0 || x < ncol) ? kcol[x] : kcol[x > 0 ? x - 1 : 0]) : kj;
-            const bool on = j < 2 * npair && i < m_loc && !(dbg & 8);
-            const uint2* gc = mb.coords + (size_t)(cw * NSLOT + max(kj, 0)) * mb.sM;
-            v[r] = on ? gc[i] : make_uint2(0u, 0u);
-        }
-#pragma unroll
-        for (int r = 0; r < RPT; r++) {
-            const int rec = r * SCORE_THREADS + threadIdx.x;
-            uint2 w2 = v[r];
-            w2.y = (w2.y & 0xf0000000u) | ((w2.y & 0x0fffffffu) << 2);
-            L.cols[rec] = w2;
-        }
-    }
-#pragma unroll
-    for (int x = SCREEN_GMAX - 1; x > 0; x--) circ[x] = ((ncol & 1) && x == ncol) ? circ[x - 1] : circ[x];
-    ((float4*)L.pzc)[threadIdx.x] = pz_v;
-    if (threadIdx.x < (LDS_PZ + 2) % 4) L.pzc[(LDS_PZ + 2) / 4 * 4 + threadIdx.x] = pz_t;
-    if (anyring && threadIdx.x == 0) { /* (every segment's workgroup: an empty one left before) */
-#pragma unroll
-        for (int j = 0; j < SCREEN_GMAX; j++)
-            if (j < ncol && circ[j]) atomicOr(&scr_ub[cw], 1u << kcol[j]);
-    }
-    __syncthreads();
-    double acc[SCREEN_GMAX];
-    float exo[SCREEN_GMAX], ymax[SCREEN_GMAX];
-    unsigned badk[SCREEN_GMAX];
-#pragma unroll
-    for (int j = 0; j < SCREEN_GMAX; j++) {
-        acc[j] = 0.0;
-        exo[j] = 0.0f;
-        ymax[j] = 0.0f;
-        badk[j] = 0u;
-    }
-    float obs = 0.0f;
-    unsigned bad = 0;
-    if (dbg & 2) return;
-    const unsigned nn = (dbg & 4) ? 0u : (unsigned)n;
-#define IG_MP(P, S)                                                                                                                          \
-    case P:                                                                                                                                  \
-        if (anyring) screen_multi_pass<P, S, true>(L, slp, nn, slope, la_s, lv_s, d_max, zc_ub_s, circ, acc, exo, ymax, badk, obs, bad, nx0);      \
-        else screen_multi_pass<P, S, false>(L, slp, nn, slope, la_s, lv_s, d_max, zc_ub_s, circ, acc, exo, ymax, badk, obs, bad, nx0);             \
-        break;
-#if SCREEN_GCAP_MAX >= 8
-    if (gcap == 8) {
-        switch (npair) { IG_MP(1, SCREEN_POOL / 8) IG_MP(2, SCREEN_POOL / 8) IG_MP(3, SCREEN_POOL / 8) IG_MP(4, SCREEN_POOL / 8) }
-    } else
-#endif
-    if (gcap == 4) {
-        switch (npair) { IG_MP(1, SCREEN_POOL / 4) IG_MP(2, SCREEN_POOL / 4) }
-    } else {
-        switch (npair) { IG_MP(1, SCREEN_POOL / 2) }
-    }
-#undef IG_MP
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-        for (int j = 0; j < SCREEN_GMAX; j++) {
-            acc[j] += __shfl_down(acc[j], o, 64);
-            exo[j] += __shfl_down(exo[j], o, 64);
-            ymax[j] = fmaxf(ymax[j], __shfl_down(ymax[j], o, 64));
-            badk[j] |= __shfl_down(badk[j], o, 64);
-        }
-        obs += __shfl_down(obs, o, 64);
-        bad |= __shfl_down(bad, o, 64);
-    }
-    if (lane == 0) {
-        unsigned vd = 0;
-#pragma unroll
-        for (int j = 0; j < SCREEN_GMAX; j++) {
-            L.red_s[wave][j] = acc[j];
-            L.red_e[wave][j] = exo[j];
-            L.red_y[wave][j] = ymax[j];
-            vd |= (badk[j] >> 31) << j;
-        }
-        L.red_o[wave] = obs;
-        L.red_bad[wave] = bad;
-        L.red_void[wave] = vd;
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < ncol) {
-        const int j = threadIdx.x;
-        int kj = -1;
-#pragma unroll
-        for (int x = 0; x < SCREEN_GMAX; x++) kj = (x == j) ? kcol[x] : kj;
-        double S = 0.0, E = 0.0, O = 0.0, Y = 0.0;
-        unsigned B = 0;
-        for (int v = 0; v < SCORE_THREADS / 64; v++) {
-            S += L.red_s[v][j];
-            E += (double)L.red_e[v][j];
-            O += (double)L.red_o[v];
-            Y = __builtin_fmax(Y, (double)L.red_y[v][j]);
-            B |= L.red_bad[v];
-            B |= ((L.red_void[v] >> j) & 1u) ? 0x80000000u : 0u;
-        }
-        screen_publish(sc, scr, scr_void, cw, kj, n, S, E, O, Y, B);
-    }
-}
-/* the launch: the Q5 tail walks first (k_screen_tail's reasons), then the (segment part, group, candidate) workgroups -- segment
- * fastest (block -> XCD: an XCD reads an eighth of every list for all groups) */
-#ifndef SCREEN_MULTI_WAVES
-#define SCREEN_MULTI_WAVES 4 /* four workgroups per CU: what 37 KB of LDS admit */
-#endif
-__global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MULTI_WAVES)
-    k_screen_multi_tail(const ScreenConst* __restrict__ sc, MoveBuf mb, ScreenSum* __restrict__ scr, unsigned* __restrict__ scr_void,
-                        unsigned* __restrict__ scr_ub, int max_c, int w_begin, int n_tail, const long long* __restrict__ rowptr,
-                        const int2* __restrict__ cc, Tables tab, Glob* g, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int use_order, int Q,
-                        int n_grp, int dbg)
-{
-    __shared__ __align__(16) unsigned char lds_raw[sizeof(ScreenLdsU) > sizeof(TailLds) ? sizeof(ScreenLdsU) : sizeof(TailLds)];
-    const int b = (int)blockIdx.x;
-    if (b < n_tail) {
-        prefinal_tail(rowptr, cc, tab, g, mb, lgf_tab, tail_quirk, pz, w_begin, b % max_c, b / max_c, *(TailLds*)lds_raw);
-        return;
-    }
-    const int s = b - n_tail, nseg = mb.nseg, nxq = nseg * Q;
-    screen_block_multi(sc, mb, scr, scr_void, scr_ub, max_c, w_begin, s % nseg, (s / nxq) % n_grp, s / (nxq * n_grp), *(ScreenLdsU*)lds_raw, use_order,
-                       (s % nxq) / nseg, Q, dbg);
-}
-
-#endif /* IG_SCREEN_MULTI_PROBE */
+/* (round 5's MULTI-COLUMN pass -- a workgroup = (segment, a group of up to 8 live columns staged side by side, candidate) -- was built, measured
+ * at 250 - 310 us against this pair pass's 170 and dropped; the numbers are in DESIGN 4.3 and profiles/r05e_screen_multi_probe.txt, the code
+ * in the history before round 6.) */
 
 #ifndef SCREEN_MIN_WAVES
 #define SCREEN_MIN_WAVES 7 /* seven workgroups per CU (what the LDS admits) need <= 96 SGPRs (106 admit six) */

@@ -74,8 +74,14 @@ def lib():
         # the product library, nothing else -- unless the caller says in so many words that this is a tuning session
         # (IG_DEBUG_TUNING=1 IG_HIP_LIB=<a build of the same source with other -D constants>: tools/diff_pass_time.py)
         path = LIB_PATH
-        if os.environ.get("IG_DEBUG_TUNING") == "1" and os.environ.get("IG_HIP_LIB"):
-            path = os.environ["IG_HIP_LIB"]
+        if os.environ.get("IG_HIP_LIB"):
+            if os.environ.get("IG_DEBUG_TUNING") == "1":
+                path = os.environ["IG_HIP_LIB"]
+            else:  # (said out loud: a deployment that used to point IG_HIP_LIB somewhere else would load another build silently)
+                import warnings
+
+                warnings.warn("IG_HIP_LIB=%s is ignored without IG_DEBUG_TUNING=1: loading the product library %s"
+                              % (os.environ["IG_HIP_LIB"], LIB_PATH), RuntimeWarning, stacklevel=2)
         _lib = C.CDLL(path)
         _lib.ig_last_error.restype = C.c_char_p
         _lib.ig_partials_count.restype = C.c_int64
@@ -96,6 +102,17 @@ def _ck(rc):
 
 def _p(a):
     return C.c_void_p(0) if a is None else C.c_void_p(a.ctypes.data)
+
+
+class _NoLock:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_LOCK = _NoLock()
 
 
 class Neighbours:
@@ -132,7 +149,7 @@ class Neighbours:
     def put_numpy_state(key, pos, rest):
         np.random.set_state(("MT19937", key, int(pos)) + tuple(rest))
 
-    _mt_cache = [None, 0]
+    _mt_cache = [None, 0, None]
 
     @staticmethod
     def numpy_mt_address():
@@ -151,8 +168,18 @@ class Neighbours:
                     addr = a
             except Exception:
                 addr = 0
-            Neighbours._mt_cache = [bg, addr]
+            Neighbours._mt_cache = [bg, addr, getattr(bg, "lock", None)]
         return Neighbours._mt_cache[1]
+
+    @staticmethod
+    def numpy_mt_lock():
+        """the bit generator's own lock (numpy's legacy functions take it around every draw): held around the library calls that
+        work on the state in place -- they run with the GIL released, and ig_step_batch_draw's drawing thread writes key / pos for
+        the whole call, so another Python thread's np.random.* would race with it.  (Where the layout probe of numpy_mt_address
+        fails the callers fall back to get_state / set_state copies, which need no lock.)"""
+        Neighbours.numpy_mt_address()
+        lk = Neighbours._mt_cache[2]
+        return lk if lk is not None else _NO_LOCK
 
     def draw(self, frags, n_neighbours):
         """candidate lists of consecutive moves, consuming numpy's global generator exactly as successive
@@ -161,8 +188,10 @@ class Neighbours:
         out = np.full((f.size, int(n_neighbours)), -1, np.int32)
         addr = self.numpy_mt_address()
         if addr:  # on numpy's state in place
-            _ck(lib().ig_neighbours_draw(self._h, C.c_void_p(addr), C.c_void_p(addr + 624 * 4), _p(f), C.c_int32(f.size), C.c_int32(int(n_neighbours)),
-                                         _p(out)))
+            with self.numpy_mt_lock():
+                rc = lib().ig_neighbours_draw(self._h, C.c_void_p(addr), C.c_void_p(addr + 624 * 4), _p(f), C.c_int32(f.size),
+                                              C.c_int32(int(n_neighbours)), _p(out))
+            _ck(rc)
             return out
         key, pos, rest = self.take_numpy_state()
         cpos = C.c_int32(pos)
@@ -365,8 +394,9 @@ class Context:
                 lst = [int(x) for x in row if x >= 0]
                 r, s2 = self.step(int(frag_a), lst, want_scores=want_scores)
                 return r, s2, lst
-            rc = fn(self._h, neighbours._h, addr, addr + 624 * 4, int(frag_a), int(n_neighbours), cbuf, C.byref(ncand), C.byref(res),
-                    sc_addr if want_scores else None)
+            with Neighbours.numpy_mt_lock():
+                rc = fn(self._h, neighbours._h, addr, addr + 624 * 4, int(frag_a), int(n_neighbours), cbuf, C.byref(ncand), C.byref(res),
+                        sc_addr if want_scores else None)
         else:
             n = len(cands)
             if n > MAX_CANDIDATES:
@@ -402,8 +432,10 @@ class Context:
         cands = np.full((f.size, int(n_neighbours)), -1, np.int32)
         addr = Neighbours.numpy_mt_address()
         if addr:  # on numpy's generator state in place (this thread waits inside the call while the library's thread draws)
-            _ck(lib().ig_step_batch_draw(self._h, neighbours._h, C.c_void_p(addr), C.c_void_p(addr + 624 * 4), C.c_int32(f.size), _p(f),
-                                         C.c_int32(int(n_neighbours)), _p(cands), _p(res)))
+            with Neighbours.numpy_mt_lock():
+                rc = lib().ig_step_batch_draw(self._h, neighbours._h, C.c_void_p(addr), C.c_void_p(addr + 624 * 4), C.c_int32(f.size), _p(f),
+                                              C.c_int32(int(n_neighbours)), _p(cands), _p(res))
+            _ck(rc)
             return res, cands
         key, pos, rest = Neighbours.take_numpy_state()
         cpos = C.c_int32(pos)

@@ -230,12 +230,13 @@ def make_problem(n_frags, n_contacts, seed=DEFAULT_SEED, mean_contig_len=50, cis
     for k in range(1, max_k + 1):
         i = np.nonzero(sub_contig[:-k] == sub_contig[k:])[0]
         if i.size == 0:
-            continue
+            break  # (no pair k apart inside a contig: none further apart either)
         s = centre_kb[i + k] - centre_kb[i]
         i = i[s <= max_cis_kb]
-        if i.size:
-            ci.append(i)
-            cj.append(i + k)
+        if i.size == 0:
+            break  # (s(i, i + k) grows with k: the same lists as without the break, minus thousands of empty passes on long contigs)
+        ci.append(i)
+        cj.append(i + k)
     ci = np.concatenate(ci) if ci else np.zeros(0, np.int64)
     cj = np.concatenate(cj) if cj else np.zeros(0, np.int64)
     n_avail = ci.size
@@ -312,6 +313,10 @@ CONFIGS = {
     "cfg5": (200_000, 500_000_000),
     # few long contigs: windows of 1 000 .. 7 000 sub-fragments (the 32 KB LDS stage and the unstaged path of k_score_list)
     "bigctg": (4_000, 400_000, DEFAULT_SEED, 1_000),
+    # the headline's size where an assembly ENDS: the reference merges contigs (paste_contigs KA:3367-3693, insert_block KA:2724-2975; its own
+    # GPU test asserts 15 - 45 contigs at the end, tests/test_instagraal_gpu.py:126-340) -- 50 k bins / 50 M contacts in ~20 contigs of
+    # ~2 500 bins (7 500 sub-fragments; windows of two contigs: 5 000 - 30 000 sub-fragments, far beyond every LDS stage)
+    "cfg3_late": (50_000, 50_000_000, DEFAULT_SEED, 2_500),
 }
 
 

@@ -151,3 +151,16 @@ def test_rippe_against_reference_peval(oracle_lib):
         rel = np.abs(ex.astype(np.float64) - want) / want
         assert rel.max() < 1e-6, (mode, rel.max())
     ol.set_mode(ol.MODE_DET)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/instagraal"), reason="needs the reference checkout (authoring container only)")
+def test_goldens_regenerate_from_the_reference():
+    """tools/gen_golden.py --check: the reference's unmodified sampler class over the functional fake pycuda regenerates every committed
+    golden array for array (host_helpers.npz:y_est64 / fit_amp to 1e-9: the fit's last ulp follows numpy's log path -- documented)"""
+    import subprocess
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_golden.py"), "--check"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "0 differences" in p.stdout
