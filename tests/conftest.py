@@ -12,6 +12,38 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: tens of seconds each (long oracle trajectories, the human-scale shape): collected LAST, so that a "
+                                       "slow box's step limit under `pytest -x` leaves the quick parity tests tested (VERDICT r5 item 6d)")
+    _cache_big_problems()
+
+
+def pytest_collection_modifyitems(config, items):
+    """the `slow` tests run behind everything else, in their file order (`-m gpu` and `-m "not gpu"` select them as before)"""
+    items.sort(key=lambda it: 1 if it.get_closest_marker("slow") else 0)  # (stable)
+
+
+def _cache_big_problems():
+    """synth.make_problem is seeded and pure: seven GPU tests generate the headline shape (8 - 10 s each); the arrays of a problem are
+    never written by a sampler (tests that build two samplers from one problem and compare them rely on that already).  Cached per
+    argument list for shapes of 10 M - 60 M contacts (cfg3, cfg3_late), the two most recent ones."""
+    from instagraal_amd import synth
+
+    if getattr(synth.make_problem, "_cached", False):
+        return
+    raw, cache = synth.make_problem, {}
+
+    def make_problem(*a, **kw):
+        if kw or len(a) < 2 or not (10_000_000 <= int(a[1]) <= 60_000_000):
+            return raw(*a, **kw)
+        if a not in cache:
+            while len(cache) >= 2:
+                cache.pop(next(iter(cache)))
+            cache[a] = raw(*a)
+        return cache[a]
+
+    make_problem._cached = True
+    make_problem.__doc__ = raw.__doc__
+    synth.make_problem = make_problem
 
 
 @pytest.fixture(scope="session")

@@ -124,6 +124,7 @@ def test_cfg2_live_oracle_then_properties():
     _valid_linear_contigs(outs[0][1])
 
 
+@pytest.mark.slow
 def test_cfg5_properties():
     """BASELINE.json configs[4] on one GPU: 200 k fragments / 500 M contacts (human scale).  The oracle needs minutes per
     move here; what is checked are the size-independent properties: the incrementally maintained exact likelihood limbs

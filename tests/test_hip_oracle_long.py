@@ -9,7 +9,7 @@ HIP-against-HIP: a three-round-old wrong-result bug (the one-move path ignoring 
 * ``test_nuisance_run_whose_d_nuc_reaches_zero`` -- the two cases of that generator that found the round's one difference on the
   nuisance path (the generator's consumption after d_nuc rounds to 0 inside a call).
 * ``test_long_trajectory_live_oracle`` -- whole cycles of the reference's loop (IG:196-262) through ``step_sampler_batch`` against
-  ``OracleSampler(DET).step_sampler`` (CL:1401-1465; KA:485-607, 612-3693), state compared every 250 moves: `small` for 5 full cycles
+  ``OracleSampler(DET).step_sampler`` (CL:1401-1465; KA:485-607, 612-3693), state compared every 250 moves: `small` for 3 full cycles
   from the assembled and from the --bomb'ed genome, `bigctg` (windows of 3 000 - 9 000 sub-fragments) and `bigctg --bomb`.
 * ``test_long_nuisance_trajectory_live_oracle`` -- the same with a nuisance step behind every move from the first cycle on
   (``step_sampler_nuisance_batch`` against ``o.step_sampler`` + ``o.step_nuisance_parameters``, CL:2961-3051), chains
@@ -35,6 +35,7 @@ def _tool(name):
     return mod
 
 
+@pytest.mark.slow
 def test_fuzz_cases_against_the_oracle():
     fo = _tool("fuzz_oracle")
     bad, n_moves, kinds = [], 0, set()
@@ -74,7 +75,10 @@ def test_nuisance_run_whose_d_nuc_reaches_zero(seed):
     assert diff is None, diff
 
 
-@pytest.mark.parametrize("cfg,moves,bomb", [("small", 5000, False), ("small", 5000, True), ("bigctg", 2000, False), ("bigctg", 4000, True)])
+# (round 6: 3 cycles of `small` instead of 5, bigctg 1 200 / 2 000 instead of 2 000 / 4 000 -- the full lengths were run and recorded with
+# tools/long_oracle.py, profiles/r05a_long_oracle.txt; the GPU suite's budget)
+@pytest.mark.slow
+@pytest.mark.parametrize("cfg,moves,bomb", [("small", 3000, False), ("small", 3000, True), ("bigctg", 1200, False), ("bigctg", 2000, True)])
 def test_long_trajectory_live_oracle(cfg, moves, bomb):
     lo = _tool("long_oracle")
     h = lo.run_hip(cfg, moves, bomb=bomb, seed=41)
@@ -88,6 +92,7 @@ def test_long_trajectory_live_oracle(cfg, moves, bomb):
         assert sm["n_contigs_end"] < 0.75 * h["records"][0][5], sm  # the genome was being re-assembled on the way
 
 
+@pytest.mark.slow
 def test_long_nuisance_trajectory_live_oracle():
     lo = _tool("long_oracle")
     moves = 3000

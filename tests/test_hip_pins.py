@@ -73,6 +73,54 @@ def test_cfg3_live_oracle_batch_path():
     s.free_gpu()
 
 
+@pytest.mark.slow
+def test_cfg3_late_live_oracle():
+    """The headline's size where an assembly ENDS (synth cfg3_late: 50 k bins / 50 M contacts in 20 contigs; windows of 5 000 - 45 000
+    sub-fragments: past every LDS stage, the fused commit's 4 096 and the one-column screening routine) against OracleSampler(DET):
+    14 moves through the batch path (window rule, two-tier scoring, draw inside the call) and 4 more one step_sampler call at a time --
+    6-tuples, genome, generator state (the reference's own GPU test ends with 15 - 45 contigs,
+    /root/reference/tests/test_instagraal_gpu.py:126-340, via paste_contigs KA:3367-3693 / insert_block KA:2724-2975)."""
+    import os
+
+    from instagraal_amd import synth
+    from oracle import oracle_lib as ol
+
+    ol.build()
+    prob = synth.make_problem(*synth.CONFIGS["cfg3_late"])
+    assert (prob.n_frags, prob.n_contacts) == (50_000, 50_000_000)
+    n_ctg = np.unique(prob.S_o_A_frags["id_c"]).size
+    assert n_ctg <= 25 and int(prob.S_o_A_frags["sub_l_cont"].max()) >= 5000
+    s = _hip(prob)
+    ol.set_threads(min(16, os.cpu_count() or 1))
+    try:
+        o = _oracle(prob, ol.MODE_DET)
+        assert float(s.curr_likelihood_on_nz[0]) == float(o.gpu_curr_likelihood_nz[0])
+        np.random.seed(23)
+        frags = np.random.permutation(prob.n_frags)[:18].astype(np.int32)
+        st = np.random.get_state()
+        res = s.step_sampler_batch(frags[:14], 5)
+        tuples = [(float(r["o"]), float(r["dist"]), int(r["op_sampled"]), int(r["id_f_sampled"]), float(np.float32(r["mean_len"])), int(r["n_contigs"]))
+                  for r in res]
+        for f in frags[14:]:
+            a = s.step_sampler(int(f), 5, s.dt)
+            tuples.append((float(a[0]), float(a[1]), int(a[2]), int(a[3]), float(a[4]), int(a[5])))
+        after = np.random.get_state()
+        np.random.set_state(st)
+        n_changed = 0
+        d_prev = None
+        for f, got in zip(frags, tuples):
+            b = o.step_sampler(int(f), 5, o.dt)
+            assert got == (b[0], b[1], b[2], b[3], float(b[4]), int(b[5])), (int(f), got, b)
+            n_changed += int(d_prev is not None and b[1] != d_prev)
+            d_prev = b[1]
+        assert np.array_equal(np.random.get_state()[1], after[1]) and np.random.get_state()[2] == after[2], "generator state differs"
+        assert np.array_equal(s.gpu_vect_frags.copy_from_gpu().soa17(), o.gpu_vect_frags.soa17())
+        assert n_changed >= 2  # (the genome moved: the late regime's conflicts and long windows were exercised)
+    finally:
+        ol.set_threads(1)
+    s.free_gpu()
+
+
 def _libm_walk(prob, seed, n_moves):
     """HIP (the deterministic contract) and the oracle in LIBM mode, each on its own genome, fed the same candidate lists: scores
     within REL, same flags / winners / distances, until the first move where the winners differ -- a near-tie by both
