@@ -250,6 +250,7 @@ int ig_debug_last_sums(ig_ctx* ctx, int64_t* nz_hi, int64_t* nz_lo, int64_t* z_h
 int ig_debug_tables(ig_ctx* ctx, float* dist, int32_t* id_c, float* s_tot, int32_t* pos, int32_t* len);
 /* maintained exact sums {nz_hi, nz_lo, z_hi, z_lo, n_intra}; {n_contigs, next_cid, chosen c, k, slot, windowed} */
 int ig_debug_globals(ig_ctx* ctx, int64_t* sums5, int32_t* ints6);
+int ig_debug_dbg(ig_ctx* ctx, int32_t* out8, int32_t clear); /* Glob.dbg: the eight words a device-side consistency failure leaves (tuning builds: tick counters) */
 /* two-tier scoring of the batches (csrc/ig_kernels_screen.cuh): the hardware log2 / exp2 the screening bound leans on, measured
  * over their whole domain {max |v_log_f32(s) - log2 s| / (2^-23 (|result| + 1)), max |v_exp_f32(y) - 2^y| / (2^-23 2^y)};
  * and {largest |screened - exact| / bound, largest bound} of the runs under IG_SCREEN_VERIFY=1, {columns screened, columns

@@ -362,6 +362,7 @@ __device__ __forceinline__ void wave_argmax_step(double& v, int& i)
  * through.  LDS operations of a wave complete in order: no fence (a release would wait for the prefetches of the next three
  * moves, i.e. one memory round trip per decision: measured 38 k instead of 43 k moves/s).  The record goes to memory from the
  * commit wave alone (two waves storing to the same words without a fence between them land in either order). */
+#define FUSED_CHG_CAP 512
 struct FusedLds {
     volatile int prog[2];
     volatile int bar[3 * IG_MAX_BATCH + 2]; /* arrivals at the commit waves' barriers (three per move, one behind their prologue) */
@@ -375,6 +376,8 @@ struct FusedLds {
     long long st_sc[IG_MAX_BATCH], st_ev[IG_MAX_BATCH], st_by[IG_MAX_BATCH];
     long long s0_slice[IG_MAX_BATCH];
     int s0_mloc[IG_MAX_BATCH], s0_base[IG_MAX_BATCH];
+    int n_chg[IG_MAX_BATCH]; /* per move: fragments whose prev / next / ori change, */
+    int chg[FUSED_CHG_CAP];  /* ... and the local indices of the move being applied */
 };
 /* CHAIN (k_decide_chain): a segment of a chain of (move, nuisance step) pairs -- ig_common.cuh, ChainIn.  Behind every decision
  * the step's Metropolis test (CL:3026-3036: exp((L_test - L_move) / T) >= u) against the interval k_chain_hist_eval left for its
@@ -1085,20 +1088,28 @@ __global__ void __launch_bounds__(COMMIT_THREADS)
 #define FUSED_CW 7 /* commit waves of k_decide_commit (a move is applied by all of them: its loops are k_commit_batch's, 448 threads wide; 3 / 5 / 7 waves: 44.7 / 45.4 / 45.5 k moves/s) */
 #endif
 /* a barrier of the commit waves alone (the decide wave never waits): arrivals counted in LDS, one word per use */
+template <int CW = FUSED_CW>
 __device__ __forceinline__ void cw_barrier(FusedLds* sh, int id)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if ((threadIdx.x & 63) == 0) atomicAdd((int*)&sh->bar[id], 1);
-    while (sh->bar[id] < FUSED_CW) __builtin_amdgcn_s_sleep(1);
+    while (sh->bar[id] < CW) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+/* NDW: decide waves in front of the commit waves (1: decide_body's one wave; DPAR: the decide waves of decide_rounds), CW: commit waves */
+template <int NDW = 1, int CW = FUSED_CW>
 __device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_prev, Glob* g, MoveBuf mb, const int* __restrict__ ip,
                                              const int* __restrict__ in, const int* __restrict__ orientable, const unsigned char* __restrict__ black,
                                              int* own_tag, int* own_idx, int* prev_touched, ig_move_result* res, int move0, int W, int w_start,
                                              NuisHost* hn, int hn_seq, FusedLds* sh)
 {
-    const int lane = threadIdx.x & 63, ctid = (int)threadIdx.x - 64, cwv = ctid >> 6;
-    constexpr int NCT = FUSED_CW * 64;
+    const int lane = threadIdx.x & 63, ctid = (int)threadIdx.x - 64 * NDW, cwv = ctid >> 6;
+    constexpr int NCT = CW * 64;
+#if defined(IG_PAR_TRACE) && IG_PAR_TRACE == 2
+    const long long ct0 = wall_clock64();
+    long long ct_spin = 0, ct_fin = 0;
+#endif
+    for (int i = ctid; i < IG_MAX_BATCH; i += NCT) sh->n_chg[i] = 0; /* (up before the statistics' barrier below) */
     /* the statistics columns of every slot, ahead of the decisions (k_commit_batch 2d): 16 lanes per slot */
     for (int w = w_start + (ctid >> 4); w < W; w += NCT / 16) {
         const int c = lane & 15;
@@ -1116,7 +1127,10 @@ __device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_pr
             if (c == 0) {
                 sh->s0_slice[w] = cp.n_slice;
                 sh->s0_mloc[w] = m.m_loc;
-                sh->s0_base[w] = cp.base_cnt;
+                /* (-1: candidate 0 was scored with its own list.  The per-move section below read MoveCtl.superset0 from memory: one
+                 * round trip per move in the commit waves' serial part -- hidden while one wave decided a move in 2.3 us, 50 us of a
+                 * chain behind decide_rounds, tools/par_trace.py) */
+                sh->s0_base[w] = apart ? cp.base_cnt : -1;
             }
         }
         for (int o = 8; o > 0; o >>= 1) { /* over the 16 lanes of the slot */
@@ -1130,25 +1144,67 @@ __device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_pr
             sh->st_by[w] = by;
         }
     }
+    /* the coordinate tables of a move that changed the genome (k_commit_batch 2c); tab_prev receives every move but the last committed one */
+    auto write_tables = [&](int w, bool last, int gtid, int GT) {
+        const int cw = CW(w, sh->ch_c[w]);
+        const CandMeta& m = mb.meta[cw];
+        const int k = sh->ch_k[w];
+        const uint2* col = mb.coords + (size_t)(cw * NSLOT + k) * mb.sM;
+        const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
+        const int* subs = mb.subs + (size_t)cw * mb.sM;
+        const int fresh = mb.ctl[PS(w)].fresh;
+        for (int ls = gtid; ls < m.m_loc; ls += GT) {
+            const int s = subs[ls];
+            const uint2 v = col[ls];
+            const int code = (int)(v.y >> 28);
+            const float dist = __uint_as_float(v.x);
+            const int2 cp = make_int2(code == 0 ? m.ctgA : (code == 1 ? m.ctgB : fresh + (code - 2)), (int)(v.y & 0x0fffffffu));
+            const float stot = cm[code].stot;
+            const int len = cm[code].len;
+            tab.dist[s] = dist;
+            tab.cp[s] = cp;
+            tab.stot[s] = stot;
+            tab.len[s] = len;
+            if (last) {
+                prev_touched[ls] = s;
+            } else {
+                tab_prev.dist[s] = dist;
+                tab_prev.cp[s] = cp;
+                tab_prev.stot[s] = stot;
+                tab_prev.len[s] = len;
+            }
+        }
+    };
+    int pend_tab = -1; /* NDW > 1: a move whose tables are still to be written -- as soon as a later decision says it is not the last one */
     const int tag_base = g->stamp_ctr;
     long long c2 = g->credit2; /* (used by the first commit wave's lane 0) */
     const double norm = 3.0 * (double)(g->N - g->n_black);
     const int N = mb.sN, M = mb.sM;
     int processed = w_start;
     long long hn_last_sc = 0, hn_last_ev = 0, hn_last_by = 0; /* (lane 0 of the first commit wave: the last applied move's statistics) */
-    cw_barrier(sh, 3 * IG_MAX_BATCH); /* (the statistics are in LDS) */
+    cw_barrier<CW>(sh, 3 * IG_MAX_BATCH); /* (the statistics are in LDS) */
+#if defined(IG_PAR_TRACE) && IG_PAR_TRACE == 2
+    if (NDW > 1 && ctid == 0) atomicAdd(&g->dbg[2], (int)(wall_clock64() - ct0));
+#endif
     auto winner_loc = [&](int w) -> const int* { return mb.loc + ((size_t)(CW(w, sh->ch_c[w]) * NSLOT + sh->ch_slot[w]) * NDYN) * N; };
     /* While the decisions come in: a move that changes the genome gets its ownership marks and its credits -- evaluated through the
      * marks on the state as of the batch's start, as k_commit_batch does (nothing is applied yet: a later move's marks, written
      * while an earlier one's credits are still being read, say "later" to them either way) -- and every move its record. */
     for (;;) {
         int upto, fin;
+#if defined(IG_PAR_TRACE) && IG_PAR_TRACE == 2
+        const long long cs0 = wall_clock64();
+#endif
         for (;;) {
             fin = sh->prog[1]; /* (first: a final count read before the last progress word misses nothing, the other way round could) */
             upto = sh->prog[0];
             if (upto > processed || fin) break;
             __builtin_amdgcn_s_sleep(4);
         }
+#if defined(IG_PAR_TRACE) && IG_PAR_TRACE == 2
+        ct_spin += wall_clock64() - cs0;
+        if (fin && !ct_fin) ct_fin = wall_clock64();
+#endif
         __asm__ volatile("" ::: "memory");
         if (fin) upto = fin - 1;
         if (processed == w_start && upto > w_start) { /* a move will be committed: tab_prev catches up with the move applied last before
@@ -1162,10 +1218,16 @@ __device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_pr
                 tab_prev.cp[s2] = tab.cp[s2];
                 tab_prev.len[s2] = tab.len[s2];
             }
-            cw_barrier(sh, 3 * IG_MAX_BATCH + 1);
+            cw_barrier<CW>(sh, 3 * IG_MAX_BATCH + 1);
         }
         for (int w = processed; w < upto; w++) {
+            if (NDW > 1 && pend_tab >= 0) { /* (behind decide_rounds the decisions are in long before the commit waves are through: what used
+                                             * to wait for the last decision -- 18 us behind it, tools/par_trace.py -- runs as the moves go by) */
+                write_tables(pend_tab, false, ctid, NCT);
+                pend_tab = -1;
+            }
             if (sh->n_dirty[w]) {
+                if (NDW > 1) pend_tab = w;
                 const int cw = CW(w, sh->ch_c[w]);
                 const int n_loc = mb.meta[cw].n_loc;
                 const int* gid = mb.Lloc + (size_t)cw * N;
@@ -1189,22 +1251,32 @@ __device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_pr
                         }
                     }
                 }
+                /* ... and, on the way, which fragments change one of the three fields a credit reads (a handful: the cut points, a flipped
+                 * block): the credits below are evaluated for them alone, all at once -- walking all 3 n_loc items took the chain of a dozen
+                 * dependent loads once per pass of the threads over the window (round 6: behind decide_rounds the apply step is what a
+                 * chain's serial part waits for, ~17 us per genome-changing move; tools/par_trace.py) */
                 for (int x = ctid; x < n_loc; x += NCT) {
                     const int f = gid[x];
                     own_tag[f] = tag_base + w;
                     own_idx[f] = x;
+                    if (wl[(size_t)5 * N + x] != st.prev[f] || wl[(size_t)6 * N + x] != st.next[f] || wl[(size_t)10 * N + x] != st.ori[f]) {
+                        const int at = atomicAdd(&sh->n_chg[w], 1);
+                        if (at < FUSED_CHG_CAP) sh->chg[at] = x;
+                    }
                 }
-                cw_barrier(sh, 3 * w);
+                cw_barrier<CW>(sh, 3 * w);
                 auto changed_member = [&](int y) -> bool {
                     if (y < 0 || own_tag[y] != tag_base + w) return false;
                     const int xi = own_idx[y];
                     return wl[(size_t)5 * N + xi] != st.prev[y] || wl[(size_t)6 * N + xi] != st.next[y] || wl[(size_t)10 * N + xi] != st.ori[y];
                 };
                 long long d = 0;
-                for (int item = ctid; item < 3 * n_loc; item += NCT) {
-                    const int x0 = item / 3;
+                const int n_chg = sh->n_chg[w];
+                const bool listed = n_chg <= FUSED_CHG_CAP; /* (more than the list holds: the walk over every fragment, as before) */
+                for (int item = ctid; item < 3 * (listed ? n_chg : n_loc); item += NCT) {
+                    const int x0 = listed ? sh->chg[item / 3] : item / 3;
                     const int f0 = gid[x0];
-                    if (wl[(size_t)5 * N + x0] == st.prev[f0] && wl[(size_t)6 * N + x0] == st.next[f0] && wl[(size_t)10 * N + x0] == st.ori[f0])
+                    if (!listed && wl[(size_t)5 * N + x0] == st.prev[f0] && wl[(size_t)6 * N + x0] == st.next[f0] && wl[(size_t)10 * N + x0] == st.ori[f0])
                         continue;
                     const int q = item % 3;
                     const int f = (q == 0) ? f0 : ((q == 1) ? ip[f0] : in[f0]);
@@ -1228,7 +1300,7 @@ __device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_pr
                 }
                 d = wave_sum_ll(d);
                 if (lane == 0 && d) atomicAdd((unsigned long long*)&sh->delta[w], (unsigned long long)d);
-                cw_barrier(sh, 3 * w + 1); /* (the move's sum is complete, its credits are read) */
+                cw_barrier<CW>(sh, 3 * w + 1); /* (the move's sum is complete, its credits are read) */
                 /* the winner becomes the live genome: nothing reads these fragments' state any more -- a later move's credits take
                  * them from the winner's buffers, through the marks */
                 for (int x = ctid; x < n_loc; x += NCT) {
@@ -1249,7 +1321,7 @@ __device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_pr
             if (ctid == 0) {
                 const unsigned vmask = (unsigned)sh->vmask[w];
                 long long Sc = sh->st_sc[w], ev = sh->st_ev[w], by = sh->st_by[w];
-                if (mb.ctl[PS(w)].superset0) { /* candidate 0 as the reference would have scored it: its list under the stale flags of the decision */
+                if (sh->s0_base[w] >= 0) { /* candidate 0 as the reference would have scored it: its list under the stale flags of the decision */
                     const long long nu = sh->s0_base[w] + __popc(vmask);
                     ev += sh->s0_slice[w] * (nu + 1);
                     by += 12 * sh->s0_slice[w] + 20LL * sh->s0_mloc[w] * nu + 8LL * nu;
@@ -1273,44 +1345,24 @@ __device__ __forceinline__ void commit_waves(State st, Tables tab, Tables tab_pr
     if (committed == w_start) return; /* nothing was committed: as k_commit_batch, nothing is touched */
     /* The decisions are in: the coordinate tables of the moves that changed the genome -- disjoint contigs, two at a time --; tab_prev
      * receives every move but the last one (k_commit_batch 2c; its catch-up ran when the first decision came) */
-    {
+    if (NDW > 1) {
+        if (pend_tab >= 0) write_tables(pend_tab, pend_tab == committed - 1, ctid, NCT);
+    } else {
         constexpr int GT = NCT / 2; /* two groups of four waves, a move each */
         const int grp = ctid / GT, gtid = ctid % GT;
         int nth = 0; /* the moves that change the genome, dealt out in turn */
         for (int w = w_start; w < committed; w++) {
             if (!sh->n_dirty[w]) continue;
             if ((nth++ & 1) != grp) continue;
-            const int cw = CW(w, sh->ch_c[w]);
-            const CandMeta& m = mb.meta[cw];
-            const bool last = (w == committed - 1);
-            const int k = sh->ch_k[w];
-            const uint2* col = mb.coords + (size_t)(cw * NSLOT + k) * M;
-            const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
-            const int* subs = mb.subs + (size_t)cw * M;
-            const int fresh = mb.ctl[PS(w)].fresh;
-            for (int ls = gtid; ls < m.m_loc; ls += GT) {
-                const int s = subs[ls];
-                const uint2 v = col[ls];
-                const int code = (int)(v.y >> 28);
-                const float dist = __uint_as_float(v.x);
-                const int2 cp = make_int2(code == 0 ? m.ctgA : (code == 1 ? m.ctgB : fresh + (code - 2)), (int)(v.y & 0x0fffffffu));
-                const float stot = cm[code].stot;
-                const int len = cm[code].len;
-                tab.dist[s] = dist;
-                tab.cp[s] = cp;
-                tab.stot[s] = stot;
-                tab.len[s] = len;
-                if (last) {
-                    prev_touched[ls] = s;
-                } else {
-                    tab_prev.dist[s] = dist;
-                    tab_prev.cp[s] = cp;
-                    tab_prev.stot[s] = stot;
-                    tab_prev.len[s] = len;
-                }
-            }
+            write_tables(w, w == committed - 1, gtid, GT);
         }
     }
+#if defined(IG_PAR_TRACE) && IG_PAR_TRACE == 2
+    if (NDW > 1 && ctid == 0) {
+        atomicAdd(&g->dbg[3], (int)ct_spin);
+        atomicAdd(&g->dbg[4], (int)(wall_clock64() - ct_fin));
+    }
+#endif
     if (ctid == 0) {
         g->credit2 = c2;
         g->stamp_ctr = tag_base + W + 2;
@@ -1350,6 +1402,593 @@ __global__ void __launch_bounds__(64 + FUSED_CW * 64)
         decide_body<true>(g, mb, res, move0, W, w_start, dirty_buf, batch_out, host_out, seq, resumed_plain, &sh, zcheck, ChainArgs{nullptr, nullptr, 0, 1.0},
                           host_scores);
     else commit_waves(st, tab, tab_prev, g, mb, ip, in, orientable, black, own_tag, own_idx, prev_touched, res, move0, W, w_start, hn, hn_seq, &sh);
+}
+
+
+/* ---- round 6: the decisions of a launch chain in ROUNDS (k_decide_commit was 105 us per chain of ~35 decisions,
+ * one wave at ~3 us per decision next to an idle machine).
+ *
+ * decide_body walks the moves one after the other because each decision reads what its predecessor left: the live scalars (maintained
+ * sums, pair count, contig count), the list of contigs written so far, the stale insert flags (quirk Q4).  But 85 % of the moves leave
+ * all of that alone but for the flags -- their winner is a column whose genome IS the current genome -- and the flags a move leaves are
+ * one of its candidates' precomputed masks, nearly always the last candidate's (CL:2125-2126: the family that re-ran get_bounds; a
+ * block-insert winner's own otherwise).  So DPAR waves decide the next DPAR moves SIDE BY SIDE, each under the shared state as it
+ * stands and under the flags its predecessor is expected to leave; then every wave reads the DPAR outcomes in order and finds the
+ * prefix that is what decide_body would have decided: move l holds if every move before it held, left the state alone, and left the
+ * flags move l assumed.  The prefix ends behind the first move that changes the state (its owner applies decide_body's update, word
+ * for word), in front of the first move that assumed other flags (decided again next round, now under the right ones) and in front
+ * of whatever stops a chain (a conflict, a pool, a score of exactly 0.0, a pending windowed winner).  The first move of a round
+ * always holds -- its inputs are exact -- so a round decides 1 .. DPAR moves; at 15 % state-changing moves ~3 of 4.
+ * One move's decision is decide_one's arithmetic on the same records in the same order of operations: same bits (the fused / unfused
+ * comparison of tests/test_hip_fused_commit.py runs this against decide_body, the oracle suites against the reference's argmax).
+ * Moves with more than 5 candidates, launches that publish their scores (ig_step_draw) and the nuisance chains keep decide_body. */
+#ifndef DPAR
+#define DPAR 4 /* decide waves */
+#endif
+#ifndef DPAR_CW
+#define DPAR_CW 4 /* commit waves behind them (8 waves: two per SIMD, 256 registers each -- a decide wave holds two moves' records) */
+#endif
+struct ParLds {
+    long long nz_hi, nz_lo, z_hi, z_lo, n_intra;
+    int n_contigs, next_cid, max_L, max_SL;
+    unsigned vmask;
+    int n_dirty;
+    int committed, pending, stop_overflow, n_cand, n_predicted;
+    volatile int bar; /* arrivals at the decide waves' barriers (monotonic) */
+    int dirty[2 * IG_MAX_BATCH + 4];
+    unsigned vm_in[IG_MAX_BATCH], vm_out[IG_MAX_BATCH], vm_def[IG_MAX_BATCH];
+    unsigned sens[IG_MAX_BATCH]; /* the flags a move's decision depends on (decide_rounds) */
+    int kind[IG_MAX_BATCH]; /* 0 decided, 1 stops in front (conflict / pool / error: whatever the flags), 2 pending windowed winner, 3 a score of 0.0 */
+    int changes[IG_MAX_BATCH], scode[IG_MAX_BATCH];
+};
+/* LDS operations of a wave complete in order: when a wave's arrival is visible, so is everything it wrote to LDS before it (no fence:
+ * a release would wait for the wave's prefetch of its next move, decide_body's note) */
+__device__ __forceinline__ void dw_barrier(ParLds* ps, int& phase)
+{
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    phase += DPAR;
+    if ((threadIdx.x & 63) == 0) atomicAdd((int*)&ps->bar, 1);
+    while (ps->bar < phase) __builtin_amdgcn_s_sleep(1);
+    __asm__ volatile("" ::: "memory");
+}
+__device__ __forceinline__ void decide_rounds(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out,
+                                              volatile int* host_out, int seq, int resumed_plain, FusedLds* sh, ParLds* ps, int zcheck)
+{
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int ND = (IG_MAX_BATCH * 2 + 2 + 63) / 64;
+    const int lane = threadIdx.x & 63, dwv = threadIdx.x >> 6; /* decide wave 0 .. DPAR - 1 */
+    int phase = 0;
+    const int err0 = g->error;
+    const ig_params p = g->par[0];
+    const double log_e = IG_LOG_E_F;
+    const double n_tot_pxl = g->n_tot_pxl;
+    const float n_frags_f = (float)g->N;
+    if (dwv == 0) { /* the shared state: decide_body's registers */
+        int n_dirty = 0;
+        if (w_start > 0) {
+            n_dirty = dirty_buf[0];
+            for (int j = 0; j < ND; j++)
+                if (lane + 64 * j < n_dirty) ps->dirty[lane + 64 * j] = dirty_buf[1 + lane + 64 * j];
+            if (!(resumed_plain & 1)) {
+                const MoveCtl pm = mb.ctl[PS(w_start - 1)];
+                const CandMeta& m = mb.meta[CW(w_start - 1, pm.ch_c)];
+                if (lane == 0) {
+                    ps->dirty[n_dirty] = m.ctgA;
+                    ps->dirty[n_dirty + 1] = m.ctgB;
+                }
+                n_dirty += 2;
+            }
+        }
+        const int v = (lane < 12) ? g->valid_insert[lane] : -1;
+        const unsigned vmask0 = (unsigned)__ballot(lane < 12 && v != -1);
+        if (lane == 0) {
+            ps->nz_hi = g->nz_hi;
+            ps->nz_lo = g->nz_lo;
+            ps->z_hi = g->z_hi;
+            ps->z_lo = g->z_lo;
+            ps->n_intra = g->n_intra;
+            ps->n_contigs = g->n_contigs;
+            ps->next_cid = g->next_cid;
+            ps->max_L = g->max_L;
+            ps->max_SL = g->max_SL;
+            ps->vmask = vmask0;
+            ps->n_dirty = n_dirty;
+            ps->committed = w_start;
+            ps->pending = -1;
+            ps->stop_overflow = 0;
+            ps->n_cand = 0;
+            ps->n_predicted = 0;
+        }
+    }
+    struct MoveData {
+        int C, superset0;
+        CandPre cand;
+        SlotPre rec[2];
+        double e_ext_d[2];
+        int e_r[2], e_base[2];
+    };
+    const int all_C = (lane < W) ? mb.ctl[PS(lane)].C : 0;
+    const int all_sup = (lane < W) ? mb.ctl[PS(lane)].superset0 : 0;
+    auto load_move = [&](int w) { /* (decide_body's: nothing here touches a loaded value) */
+        MoveData d;
+        d.C = __builtin_amdgcn_readlane(all_C, w);
+        d.superset0 = __builtin_amdgcn_readlane(all_sup, w);
+        d.cand = cpre_w(mb, w, lane < d.C ? lane : 0);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int i = max(min(lane + 64 * j, d.C * IG_N_TMP_STRUCT - 1), 0);
+            d.rec[j] = pre_w(mb, w, i);
+            const CandPre& cp = cpre_w(mb, w, i / IG_N_TMP_STRUCT);
+            d.e_ext_d[j] = cp.ext_d;
+            d.e_r[j] = cp.r;
+            d.e_base[j] = cp.base_cnt;
+        }
+        return d;
+    };
+    auto rl = [](int v, int src) { return __builtin_amdgcn_readlane(v, src); };
+    auto rl64 = [](long long v, int src) {
+        const int lo = __builtin_amdgcn_readlane((int)(unsigned)v, src), hi = __builtin_amdgcn_readlane((int)(v >> 32), src);
+        return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+    };
+    auto rld = [&](double v, int src) { return __longlong_as_double(rl64(__double_as_longlong(v), src)); };
+    auto clampw = [&](int w) { return w < W ? w : W - 1; };
+    bool fin = false;
+    /* the rounds a wave spends on ONE move (its own registers: d), until the move is committed or the chain is over */
+    auto rounds_for = [&](const int w, const MoveData& d, const MoveData& dn) {
+        const bool have = w < W;
+        const int C = d.C;
+        unsigned my_out = 0; /* the flags this move left when it was last decided */
+        for (;;) {
+            /* (behind the barrier that closed the previous round, or the one in front of the first: the state of this round stands) */
+#if defined(IG_PAR_TRACE) && IG_PAR_TRACE == 3
+            const long long q0 = wall_clock64();
+#endif
+            const int base = ps->committed;
+            const bool active = have && w >= base && w < base + DPAR;
+            /* what the decision is a function of */
+            const long long nz_hi = ps->nz_hi, nz_lo = ps->nz_lo, z_hi = ps->z_hi, z_lo = ps->z_lo, n_intra = ps->n_intra;
+            const int n_contigs = ps->n_contigs, n_dirty = ps->n_dirty;
+            const unsigned vm0 = ps->vmask; /* (read here: the owner of the prefix's last move overwrites it while the others still scan) */
+            unsigned vm = vm0;
+            if (active && w > base) vm = ps->kind[w - 1] == 0 && ps->vm_in[w - 1] != 0xffffffffu ? ps->vm_out[w - 1] : ps->vm_def[w - 1];
+            /* (vm_in = ~0: that move has not been decided yet -- its default) */
+            /* this move's outcome, uniform */
+            int kind = 0, scode = 0, changes = 0;
+            unsigned vm_out = 0, sens = 0;
+            int bc = 0, bslot = 0, br_k = 0, br_changed = 0, br_heads = 0, b_same = 0, b_nloc = 0, b_mloc = 0, b_cA = 0, b_cB = 0, windowed = 0;
+            long long d_nz_hi = 0, d_nz_lo = 0, br_dz_hi = 0, br_dz_lo = 0, br_dni = 0;
+            bool have_delta = false;
+            double bests = 0.0;
+            long long Sc = 0, ev = 0, by = 0;
+            if (active) {
+                int dirty[ND];
+#pragma unroll
+                for (int j = 0; j < ND; j++) dirty[j] = (lane + 64 * j < n_dirty) ? ps->dirty[lane + 64 * j] : -2;
+                bool hitd = false;
+                for (int cq = 0; cq < C; cq++) {
+                    const int qa = rl(d.cand.ctgA, cq), qb = rl(d.cand.ctgB, cq);
+#pragma unroll
+                    for (int j = 0; j < ND; j++) hitd |= (dirty[j] == qa) | (dirty[j] == qb);
+                }
+                if (err0 || rl(d.cand.overflow, 0) || __any(hitd)) {
+                    kind = 1;
+                    scode = err0 ? 0 : rl(d.cand.overflow, 0);
+                } else {
+                    const double cur_nz = ig_acc_to_double(nz_hi, nz_lo);
+                    const int n = C * IG_N_TMP_STRUCT;
+                    double sc[2];
+                    double bestv = -IG_INF;
+                    int best = 0x7fffffff;
+                    bool zhit = false;
+                    auto score_of = [&](int i, const SlotPre& r, double ext, int cr, int cbase) -> double { /* decide_one's, with vm for the live flags */
+                        const int c = i / IG_N_TMP_STRUCT, slot = i % IG_N_TMP_STRUCT;
+                        const bool sup = (c == 0) && d.superset0 && (slot >= 12);
+                        const bool scored = (i < n) && (r.k > 0) && !(sup && !((vm >> (slot - 12)) & 1u));
+                        if (!scored) return 0.0;
+                        const int pos = sup ? cbase + __popc(vm & ((1u << (slot - 12)) - 1u)) : r.k - 1;
+                        const double nzd = (cr > 0 && pos >= cr) ? r.nz_cut_d : r.nz_d; /* quirk Q5 */
+                        const double val_inter = -1.0 * log_e * (n_tot_pxl - (double)(n_intra + r.dni)) * p.v_inter;
+                        const double val_intra = ig_acc_to_double(z_hi + r.dz_hi, z_lo + r.dz_lo) * log_e;
+                        const double z = val_intra + val_inter;
+                        const double v = nzd + z + cur_nz - ext;
+                        zhit |= (v == 0.0);
+                        return v;
+                    };
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        const int i = lane + 64 * j;
+                        const double v = score_of(i, d.rec[j], d.e_ext_d[j], d.e_r[j], d.e_base[j]);
+                        sc[j] = v;
+                        const double ok = (v == 0.0) ? -IG_INF : v;
+                        if (i < n && ok > bestv) {
+                            bestv = ok;
+                            best = i;
+                        }
+                    }
+                    /* which of the flags this decision is a function of: candidate 0's block-insert columns that hold a score (scored or
+                     * not by their flag); and, where the Q5 tail applies to candidate 0 (r > 0), every flag below the highest of them --
+                     * a column's list position counts the flags below it.  Under flags that differ elsewhere the decision is the same
+                     * decision (the scan below holds a move to exactly that) */
+                    {
+                        const bool supk = d.superset0 && lane >= 12 && lane < IG_N_TMP_STRUCT && lane < n && d.rec[0].k > 0;
+                        sens = ((unsigned)(__ballot(supk) >> 12)) & 0xfffu;
+                        const int cr0 = rl(d.e_r[0], 0);
+                        if (cr0 > 0 && sens) sens |= (1u << (31 - __clz((int)sens))) - 1u;
+                    }
+                    const int inj = zcheck >> 8;
+                    if ((zcheck & 1) && (__any(zhit) || (inj > 0 && (move0 + w) % inj == inj - 1))) {
+                        kind = 3;
+                        scode = 3;
+                    } else {
+                        wave_argmax_step<0x111, 0xf>(bestv, best);
+                        wave_argmax_step<0x112, 0xf>(bestv, best);
+                        wave_argmax_step<0x114, 0xf>(bestv, best);
+                        wave_argmax_step<0x118, 0xf>(bestv, best);
+                        wave_argmax_step<0x142, 0xa>(bestv, best);
+                        wave_argmax_step<0x143, 0xc>(bestv, best);
+                        best = rl(best, 63);
+                        if (best >= n) best = 0;
+                        bc = best / IG_N_TMP_STRUCT;
+                        bslot = best % IG_N_TMP_STRUCT;
+                        const int owner = best & 63, bj = best >> 6;
+                        const SlotPre mine = (bj == 0) ? d.rec[0] : d.rec[1];
+                        const long long br_nz_hi = rl64(mine.nz_hi, owner), br_nz_lo = rl64(mine.nz_lo, owner);
+                        br_dz_hi = rl64(mine.dz_hi, owner);
+                        br_dz_lo = rl64(mine.dz_lo, owner);
+                        br_dni = rl64(mine.dni, owner);
+                        br_k = rl(mine.k, owner);
+                        const unsigned br_info = (unsigned)rl((int)mine.info, owner);
+                        bests = rld((bj == 0) ? sc[0] : sc[1], owner);
+                        if (n == 0) br_k = 0;
+                        const int b_sw = rl(d.cand.same_windowed, bc), b_B = rl(d.cand.B, bc);
+                        b_nloc = rl(d.cand.n_loc, bc);
+                        b_mloc = rl(d.cand.m_loc, bc);
+                        windowed = (b_sw >> 1) & 1;
+                        b_same = b_sw & 1;
+                        b_cA = rl(d.cand.ctgA, bc);
+                        b_cB = rl(d.cand.ctgB, bc);
+                        const long long b_ext_hi = rl64(d.cand.ext_hi, bc), b_ext_lo = rl64(d.cand.ext_lo, bc);
+                        br_changed = (int)(br_info & 1u);
+                        br_heads = (int)(br_info >> 1);
+                        const int pred = rl(d.cand.pred, 0);
+                        have_delta = windowed && br_changed && (best == pred);
+                        const bool is_pending = windowed && br_changed && !have_delta;
+                        if (is_pending) {
+                            kind = 2;
+                            sens = 0xfffu; /* (its record's statistics count the flags: decided under the very flags, or again) */
+                            if (lane < C) {
+                                int nu = d.cand.n_uniq;
+                                if (lane == 0 && d.superset0) nu = d.cand.base_cnt + __popc(vm);
+                                Sc = d.cand.n_slice;
+                                ev = Sc * (nu + 1);
+                                by = 12 * Sc + 20LL * d.cand.m_loc * nu + 8LL * nu;
+                            }
+                            Sc = rl64(wave_sum_ll(Sc), 0);
+                            ev = rl64(wave_sum_ll(ev), 0);
+                            by = rl64(wave_sum_ll(by), 0);
+                        }
+                        if (have_delta) {
+                            d_nz_hi = rl64(d.cand.pd_hi, 0);
+                            d_nz_lo = rl64(d.cand.pd_lo, 0);
+                        } else {
+                            d_nz_hi = br_nz_hi - b_ext_hi;
+                            d_nz_lo = br_nz_lo - b_ext_lo;
+                        }
+                        {
+                            const int sel = (bslot >= 12) ? bc : C - 1; /* the family of the winner re-ran get_bounds (CL:2125-2126) */
+                            vm_out = (unsigned)rl((int)d.cand.flag_mask, sel);
+                        }
+                        /* does committing this move change anything a later decision reads besides the flags? */
+                        const int dheads = br_heads - (b_same ? 1 : 2);
+                        changes = (br_changed || have_delta || d_nz_hi != 0 || d_nz_lo != 0 || br_dz_hi != 0 || br_dz_lo != 0 || br_dni != 0 || dheads != 0) ? 1 : 0;
+                        if (kind == 0 && lane == 0) { /* the record, as decide_one leaves it for the commit waves: read by them once the move is committed */
+                            ig_move_result r;
+                            r.o = bests;
+                            r.dist = 0.0;
+                            r.mean_len = (double)(n_frags_f / (float)(n_contigs + dheads));
+                            r.op_sampled = bslot;
+                            r.id_f_sampled = b_B;
+                            r.n_contigs = n_contigs + dheads;
+                            r.n_candidates = C;
+                            r.n_slice = 0;
+                            r.n_evals = 0;
+                            r.bytes_min = 68LL * b_nloc;
+                            r.error = err0;
+                            r.pad = 0;
+                            sh->rec[w] = r;
+                            sh->ch_c[w] = bc;
+                            sh->ch_slot[w] = bslot;
+                            sh->ch_k[w] = br_k;
+                            sh->n_dirty[w] = br_changed;
+                            sh->vmask[w] = (int)vm;
+                            sh->nzb_hi[w] = nz_hi;
+                            sh->nzb_lo[w] = nz_lo;
+                        }
+                    }
+                }
+                if (lane == 0) {
+                    ps->kind[w] = kind;
+                    ps->scode[w] = scode;
+                    ps->changes[w] = changes;
+                    ps->vm_in[w] = vm;
+                    ps->vm_out[w] = vm_out;
+                    ps->sens[w] = sens;
+                }
+                my_out = vm_out;
+            }
+#if defined(IG_PAR_TRACE) && IG_PAR_TRACE == 3
+            const long long q1 = wall_clock64();
+#endif
+            dw_barrier(ps, phase); /* the outcomes of this round are up */
+#if defined(IG_PAR_TRACE) && IG_PAR_TRACE == 3
+            const long long q2 = wall_clock64();
+#endif
+            /* the prefix decide_body would have decided: the same scan in every wave */
+            const int cnt = min(DPAR, W - base);
+            int np = 0, stop_at = -1, f_code = 0, f_pend = -1;
+            bool f = false;
+            unsigned vm_act = vm; /* the flags this wave's move is decided under when it holds: what its predecessor left */
+            {
+                unsigned vm_prev = vm0;
+                for (int l = 0; l < cnt; l++) {
+                    const int wl = base + l, k = ps->kind[wl];
+                    if (k == 1) { /* (a conflict, a pool, an error: whatever flags it assumed) */
+                        f = true;
+                        stop_at = wl;
+                        f_code = ps->scode[wl];
+                        break;
+                    }
+                    if ((ps->vm_in[wl] ^ vm_prev) & ps->sens[wl]) break; /* decided under flags that differ where it looks: again, next round */
+                    if (wl == w) vm_act = vm_prev;
+                    if (k == 3) {
+                        f = true;
+                        stop_at = wl;
+                        f_code = 3;
+                        break;
+                    }
+                    if (k == 2) {
+                        f = true;
+                        stop_at = wl;
+                        f_pend = wl;
+                        break;
+                    }
+                    np = l + 1;
+                    vm_prev = ps->vm_out[wl];
+                    if (ps->changes[wl]) break;
+                }
+                if (!f && base + np >= W) f = true;
+            }
+            const bool mine_committed = active && w < base + np;
+            if (mine_committed) { /* this wave's NEXT move enters the window: the flags it leaves by default -- unless a block insert of another
+                                   * candidate wins, its last candidate's (CL:2125-2126) -- for its successor's first decision (its records were
+                                   * requested a move ago; up before the barrier that ends this round) */
+                const unsigned vdef = (unsigned)rl((int)dn.cand.flag_mask, max(dn.C - 1, 0));
+                if (w + DPAR < W && lane == 0) ps->vm_def[w + DPAR] = vdef;
+            }
+            if ((mine_committed || (active && w == f_pend)) && lane == 0) { /* decide_one's control block (a pending move's too: the one-move tail reads it) */
+                MoveCtl& o = mb.ctl[PS(w)];
+                o.ch_c = bc;
+                o.ch_slot = bslot;
+                o.ch_k = br_k;
+                o.ch_windowed = windowed;
+                o.ch_score = bests;
+                o.n_slice_tot = Sc;
+                o.n_eval_tot = ev;
+                o.bytes_min = by;
+                o.d_hi = 0;
+                o.d_lo = 0;
+                o.nzb_hi = nz_hi;
+                o.nzb_lo = nz_lo;
+                o.n_dirty = br_changed;
+                o.pad = (int)vm_act;
+                sh->vmask[w] = (int)vm_act; /* (the statistics columns count them: k_commit_batch 2d) */
+                if (br_k <= 0) g->error = 3;
+                atomicAdd(&ps->n_cand, C);
+                if (mine_committed && have_delta) atomicAdd(&ps->n_predicted, 1);
+            }
+            if (mine_committed && w == base + np - 1 && lane == 0) { /* the last move of the prefix: the state behind it (decide_one's commit, the same operations) */
+                if (changes) {
+                    long long a = nz_hi + d_nz_hi, b = nz_lo + d_nz_lo;
+                    ig_acc_normalize((int64_t*)&a, (int64_t*)&b);
+                    ps->nz_hi = a;
+                    ps->nz_lo = b;
+                    a = z_hi + br_dz_hi;
+                    b = z_lo + br_dz_lo;
+                    ig_acc_normalize((int64_t*)&a, (int64_t*)&b);
+                    ps->z_hi = a;
+                    ps->z_lo = b;
+                    ps->n_intra = n_intra + br_dni;
+                    ps->n_contigs = n_contigs + (br_heads - (b_same ? 1 : 2));
+                    if (br_changed) {
+                        ps->max_L = max(ps->max_L, b_nloc);
+                        ps->max_SL = max(ps->max_SL, b_mloc);
+                        ps->dirty[n_dirty] = b_cA;
+                        ps->dirty[n_dirty + 1] = b_cB;
+                        ps->n_dirty = n_dirty + 2;
+                    }
+                }
+                ps->next_cid += NFRESH * np;
+                ps->vmask = my_out;
+                ps->committed = base + np;
+            }
+            if (f && active && w == stop_at && lane == 0) {
+                ps->stop_overflow = f_code;
+                ps->pending = f_pend;
+            }
+#if defined(IG_PAR_TRACE) && IG_PAR_TRACE == 3
+            const long long q3 = wall_clock64();
+#endif
+            dw_barrier(ps, phase); /* the state behind this round is up (the last one's: the epilogue reads it) */
+#if defined(IG_PAR_TRACE) && IG_PAR_TRACE == 3
+            if (dwv == 0 && lane == 0) {
+                atomicAdd(&g->dbg[2], (int)(q1 - q0));
+                atomicAdd(&g->dbg[3], (int)(q2 - q1));
+                atomicAdd(&g->dbg[4], (int)(q3 - q2));
+                atomicAdd(&g->dbg[6], (int)(wall_clock64() - q3));
+            }
+#endif
+            if (dwv == 0 && lane == 0 && np > 0) sh->prog[0] = base + np; /* the prefix goes to the commit waves (their records were in LDS before the barrier);
+                                                                           * the last one too: the epilogue's scan runs next to their work on it */
+            if (f) {
+                fin = true;
+                return;
+            }
+            if (mine_committed) return; /* on to this wave's next move */
+        }
+    };
+    /* vm_in = ~0 marks "not decided yet" for the moves ahead of the window */
+    for (int i = threadIdx.x; i < IG_MAX_BATCH; i += DPAR * 64) {
+        ps->vm_in[i] = 0xffffffffu;
+        ps->kind[i] = 0;
+        ps->changes[i] = 0;
+    }
+    /* a wave's moves: w_start + dwv, + DPAR, ...; two of them in registers (the next one is loaded while this one is decided) */
+    int w = w_start + dwv;
+#ifdef IG_PAR_TRACE
+    const long long tr0 = wall_clock64();
+    int tr_rounds = 0;
+#endif
+    MoveData d0 = load_move(clampw(w)), d1 = load_move(clampw(w + DPAR));
+    {
+        const unsigned vdef = (unsigned)rl((int)d0.cand.flag_mask, max(d0.C - 1, 0));
+        if (w < W && lane == 0) ps->vm_def[w] = vdef;
+    }
+    dw_barrier(ps, phase); /* the shared state, the marks above and the first moves' default flags are up */
+#ifdef IG_PAR_TRACE
+    const long long tr1 = wall_clock64();
+#endif
+    for (;;) {
+        rounds_for(w, d0, d1);
+        if (fin) break;
+        w += DPAR;
+        d0 = load_move(clampw(w + DPAR));
+        rounds_for(w, d1, d0);
+        if (fin) break;
+        w += DPAR;
+        d1 = load_move(clampw(w + DPAR));
+    }
+    if (dwv != 0) return;
+#ifdef IG_PAR_TRACE
+    const long long tr2 = wall_clock64();
+#endif
+    /* ---- the epilogue of decide_body, from the shared state */
+    const int committed = ps->committed, n_dirty = ps->n_dirty;
+    unsigned long long stale_mask = 0ull;
+    if (mb.ring) { /* the window rule: which of the positions this launch did not commit hold a slot that is stale now (decide_body) */
+        const bool mine = lane >= committed && lane < W;
+        bool st = false;
+        int maxC = all_C;
+        for (int o = 32; o > 0; o >>= 1) maxC = max(maxC, __shfl_xor(maxC, o, 64));
+        for (int cq = 0; cq < maxC; cq++) {
+            int qa = -3, qb = -3;
+            if (mine && cq < all_C) {
+                const CandPre& cp = cpre_w(mb, lane, cq);
+                qa = cp.ctgA;
+                qb = cp.ctgB;
+                st |= (cq == 0 && cp.overflow != 0);
+            }
+            for (int q = 0; q < n_dirty; q++) {
+                const int id = ps->dirty[q];
+                st |= (id == qa) | (id == qb);
+            }
+        }
+        stale_mask = __ballot(mine && st);
+    }
+    for (int j = 0; j < ND; j++)
+        if (lane + 64 * j < n_dirty) dirty_buf[1 + lane + 64 * j] = ps->dirty[lane + 64 * j];
+    const unsigned vmask = ps->vmask;
+    if (lane == 0) {
+        const int pending = ps->pending, stop_overflow = ps->stop_overflow, max_L = ps->max_L, max_SL = ps->max_SL, n_contigs = ps->n_contigs;
+        g->nz_hi = ps->nz_hi;
+        g->nz_lo = ps->nz_lo;
+        g->z_hi = ps->z_hi;
+        g->z_lo = ps->z_lo;
+        g->n_intra = ps->n_intra;
+        g->n_contigs = n_contigs;
+        g->next_cid = ps->next_cid;
+        g->max_L = max_L;
+        g->max_SL = max_SL;
+        dirty_buf[0] = n_dirty;
+        int need = 0;
+        if (mb.work)
+            for (int x = 0; x < 8; x++) need = max(need, 8 * (int)mb.work[8 + x]);
+        const int first_none = (committed == w_start && pending < 0) ? stop_overflow : 0;
+        batch_out[0] = committed;
+        batch_out[1] = pending;
+        batch_out[2] = first_none;
+        batch_out[8] = max_L;
+        batch_out[9] = max_SL;
+        batch_out[10] = stop_overflow;
+        batch_out[3] = ps->n_cand;
+        batch_out[4] = ps->n_predicted;
+        batch_out[5] = n_contigs;
+        batch_out[6] = need;
+        batch_out[11] = 0;
+        batch_out[12] = (int)(unsigned)stale_mask;
+        batch_out[13] = (int)(unsigned)(stale_mask >> 32);
+        if (host_out) {
+            host_out[0] = committed;
+            host_out[1] = pending;
+            host_out[2] = first_none;
+            host_out[8] = max_L;
+            host_out[9] = max_SL;
+            host_out[10] = stop_overflow;
+            host_out[3] = ps->n_cand;
+            host_out[4] = ps->n_predicted;
+            host_out[5] = n_contigs;
+            host_out[6] = need;
+            host_out[11] = 0;
+            host_out[12] = (int)(unsigned)stale_mask;
+            host_out[13] = (int)(unsigned)(stale_mask >> 32);
+            __threadfence_system();
+            host_out[7] = seq;
+        }
+        sh->fin_max_L = max_L;
+        sh->fin_max_SL = max_SL;
+    }
+    if (lane < 12) g->valid_insert[lane] = ((vmask >> lane) & 1u) ? 1 : -1;
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) sh->prog[1] = committed + 1;
+#ifdef IG_PAR_TRACE
+    if (lane == 0) { /* (tuning builds: 10 ns ticks, summed over the launches -- ig_debug_dbg) */
+        atomicAdd(&g->dbg[0], 1);
+        atomicAdd(&g->dbg[1], ps->bar / (2 * DPAR));
+#if IG_PAR_TRACE == 1
+        atomicAdd(&g->dbg[2], (int)(tr1 - tr0));
+        atomicAdd(&g->dbg[3], (int)(tr2 - tr1));
+        atomicAdd(&g->dbg[4], (int)(wall_clock64() - tr2));
+#endif
+        atomicAdd(&g->dbg[5], committed - w_start);
+    }
+#endif
+}
+__global__ void __launch_bounds__(DPAR * 64 + DPAR_CW * 64)
+    k_decide_commit_par(Glob* g, MoveBuf mb, ig_move_result* res, int move0, int W, int w_start, int* dirty_buf, int* batch_out, volatile int* host_out,
+                        int seq, int resumed_plain, State st, Tables tab, Tables tab_prev, const int* __restrict__ ip, const int* __restrict__ in,
+                        const int* __restrict__ orientable, const unsigned char* __restrict__ black, int* own_tag, int* own_idx, int* prev_touched,
+                        int zcheck)
+{
+    __shared__ FusedLds sh;
+    __shared__ ParLds ps;
+    for (int i = threadIdx.x; i < 3 * IG_MAX_BATCH + 2; i += blockDim.x) sh.bar[i] = 0;
+    for (int i = threadIdx.x; i < IG_MAX_BATCH; i += blockDim.x) sh.delta[i] = 0;
+    if (threadIdx.x == 0) {
+        sh.prog[0] = w_start;
+        sh.prog[1] = 0;
+        ps.bar = 0;
+    }
+    __syncthreads();
+#ifdef IG_PAR_TRACE
+    const long long tk0 = wall_clock64();
+#endif
+    if (threadIdx.x < DPAR * 64) decide_rounds(g, mb, res, move0, W, w_start, dirty_buf, batch_out, host_out, seq, resumed_plain, &sh, &ps, zcheck);
+    else commit_waves<DPAR, DPAR_CW>(st, tab, tab_prev, g, mb, ip, in, orientable, black, own_tag, own_idx, prev_touched, res, move0, W, w_start, nullptr, 0, &sh);
+#ifdef IG_PAR_TRACE
+#if IG_PAR_TRACE != 3
+    if (threadIdx.x == DPAR * 64) atomicAdd(&g->dbg[6], (int)(wall_clock64() - tk0)); /* the commit waves' end */
+#endif
+    if (threadIdx.x == 0) atomicAdd(&g->dbg[7], (int)(wall_clock64() - tk0));        /* the first decide wave's */
+#endif
 }
 
 __global__ void k_debug_terms(const float* s, const float* stot, const int* ob, long long n, const Glob* g,

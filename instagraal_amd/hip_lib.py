@@ -725,6 +725,12 @@ class Context:
         _ck(lib().ig_debug_globals(self._h, _p(sums), _p(ints)))
         return sums, ints
 
+    def debug_dbg(self, clear=False):
+        """Glob.dbg (what raised a device-side consistency failure; in a tuning build a kernel's tick counters)"""
+        o = np.zeros(8, np.int32)
+        _ck(lib().ig_debug_dbg(self._h, _p(o), C.c_int32(int(bool(clear)))))
+        return o
+
     def debug_tables(self):
         M = self.M
         d = np.zeros(M, np.float32)

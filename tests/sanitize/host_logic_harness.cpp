@@ -267,6 +267,8 @@ static void model_decide_commit(void** a, dim3 g, dim3 b)
     shifted[18] = a[22];
     model_commit_batch(shifted, g, b);
 }
+/* k_decide_commit_par (round 6: the decisions in rounds, decide_rounds): the same outcome block; it never publishes to the host */
+static void model_decide_commit_par(void** a, dim3 g, dim3 b) { model_decide(a, g, b); }
 static int g_diff_mode = 0; // 0 random, 1 always decisive reject, 2 always undecided, 3 always void
 static long g_diffs = 0, g_exacts = 0;
 static void model_diff(void** a, dim3, dim3)
@@ -340,7 +342,8 @@ int main()
     setenv("IG_POOL_ENTRIES", "4096", 1);      /* a small slice pool: the growth paths are taken */
     fake_hip::set_model("k_decide_batch", model_decide);
     fake_hip::set_model("k_commit_batch", model_commit_batch);
-    fake_hip::set_model("k_decide_commit", model_decide_commit);
+    fake_hip::set_model("15k_decide_commitP", model_decide_commit); /* (mangled: the models are matched by substring, in the map's order) */
+    fake_hip::set_model("19k_decide_commit_par", model_decide_commit_par);
     fake_hip::set_model("k_decide_chain", model_decide_chain);
     fake_hip::set_model("k_chain_decide_commit", model_decide_chain);
     fake_hip::set_model("k_full_diff_tiled", model_diff);

@@ -1,6 +1,7 @@
 """GPU test of k_decide_commit (csrc/ig_kernels_commit.cuh): the decide step and the apply step of a batch in one launch, seven waves
-applying the moves behind the decide wave.  The library picks it for plain batches on small windows; IG_FUSED_COMMIT=0 / 2 (read once
-per process) force the two kernels / the fused one everywhere -- also for a run's one-move launches (the record the host waits for) and
+applying the moves behind the decide wave, and of k_decide_commit_par (round 6: the decisions in rounds of DPAR moves decided side by side
+by DPAR waves, decide_rounds), which the library picks for plain chains on small windows by default (IG_FUSED_COMMIT=1); IG_FUSED_COMMIT=0 / 2
+(read once per process) force the two kernels / the one-wave fused one everywhere -- also for a run's one-move launches (the record the host waits for) and
 for windows of thousands of sub-fragments.  Both must leave the same words: move records (score, genome distance, statistics columns),
 genome, tables behind the last move (the nuisance steps read them), generator state, maintained sums."""
 import hashlib
@@ -58,7 +59,8 @@ def _run(cfg, n_plain, n_nuis, fused):
 def test_fused_decide_commit_leaves_the_same_words(cfg, n_plain, n_nuis):
     two = _run(cfg, n_plain, n_nuis, 0)
     one = _run(cfg, n_plain, n_nuis, 2)
-    print(cfg, two, one)
-    assert one["digest"] == two["digest"]
-    assert one["batches"] == two["batches"] and one["batches"]["committed_in_batch"] > 0
+    par = _run(cfg, n_plain, n_nuis, 1)  # the default: decide_rounds (round 6: DPAR moves decided side by side) wherever a chain is eligible
+    print(cfg, two, one, par)
+    assert one["digest"] == two["digest"] == par["digest"]
+    assert one["batches"] == two["batches"] == par["batches"] and one["batches"]["committed_in_batch"] > 0
     assert one["changed"] > 0  # moves that changed the genome went through it
