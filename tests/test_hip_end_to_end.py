@@ -139,8 +139,8 @@ def test_bench_starts_its_own_ranks(runner):
 
 
 def test_bench_line_contract_one_gpu():
-    """`python bench.py --steps K --warmup W` on one GPU: one JSON line, a step is one batch of 24 moves (value in moves/s over
-    24 K moves), the roofline and CPU-baseline objects present, the maintained likelihood exact after the run"""
+    """`python bench.py --steps K --warmup W` on one GPU: one JSON line, a step is 128 consecutive moves (value in moves/s over
+    128 K moves), the roofline and CPU-baseline objects present, the maintained likelihood exact after the run"""
     import json
     import subprocess
     import sys
@@ -155,8 +155,11 @@ def test_bench_line_contract_one_gpu():
     assert len(lines) == 1, p.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["steps"] == 4 and out["warmup"] == 1 and out["unit"] == "moves/s" and out["higher_is_better"] is True
-    assert out["config"]["moves_per_step"] == 24 and out["config"]["moves_timed"] == 96
-    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 24.0) < 1e-6 * 24.0  # value = moves / s, ms_per_step per batch
+    assert out["config"]["moves_per_step"] == 128 and out["config"]["moves_timed"] == 512 and out["config"]["moves_warmup"] == 128
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 128.0) < 1e-6 * 128.0  # value = moves / s, ms_per_step per step of 128 moves
+    # BASELINE.md section 3 read literally: one step_sampler call per move (round 6: a top-level field)
+    assert out["value_unchanged_caller"] > 0 and out["value_unchanged_caller"] < out["value"]
+    assert out["roofline"]["traffic_replayed"] is None or out["roofline"]["traffic_replayed"]["replayed"] is True
     assert out["vs_baseline"] is None and out["config"]["maintained_likelihood_exact"] is True
     r = out["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["launches"] >= 4 and 0.0 < r["frac"] < 1.0

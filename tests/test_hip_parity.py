@@ -57,6 +57,52 @@ def test_terms_bit_exact(tiny, oracle_lib):
     assert np.array_equal(q, gq)
 
 
+def test_the_clamps_reach_against_the_reference_shaped_arithmetic(tiny, oracle_lib):
+    """The contract clamps a term at +-2^20 before it is quantised (include/ig_detmath.h: ig_quantize; what keeps 50 M-term sums inside two
+    int64 limbs); the reference adds the unclamped double (KA:251-270, 4486).  Where the two part is a TESTED statement:
+    counts from 10 to 10^7 (packed lists hold counts below 2^24) against expectations from the trans level to P(s) = 200 --
+    * HIP == oracle DET bit for bit on every term, clamped or not;
+    * wherever the reference-shaped term (oracle LIBM mode: powf / expf / log10 of glibc, float factorial below 15, Stirling above) lies
+      inside +-2^20 the contract's term agrees with it to 1e-6 of its parts: that covers every count up to 1.5e5 whatever the
+      expectation, and counts of 10^6 .. 10^7 only where the expectation is of the count's order (P(s) at a few base pairs);
+    * beyond (a count of 10^6 against an expectation of a few: a term of -5e6) the contract's term IS the clamp, -2^20 exactly, and the
+      reference's is not: a level-(L-1) pixel that deep is outside what the two arithmetics can be compared on."""
+    ol = oracle_lib
+    ctx = make_ctx(tiny)
+    counts = np.array([10, 100, 1000, 10_000, 75_000, 150_000, 300_000, 1_000_000, 3_000_000, 10_000_000], np.int64)
+    s_grid = np.exp(np.linspace(np.log(1e-4), np.log(2.0e3), 96)).astype(np.float32)  # kb: P(s) from 10^7 contacts per pixel down to the trans level
+    s = np.tile(s_grid, counts.size).astype(np.float32)
+    ob = np.repeat(counts, s_grid.size).astype(np.int32)
+    st = np.zeros_like(s)
+    p = np.zeros(1, ol.PARAM_DTYPE)
+    for k in p.dtype.names:
+        p[k] = np.float32(tiny.params[k])
+    ol.set_mode(ol.MODE_DET)
+    ex, exc, term_det, q_det = ol.eval_terms(s, st, ob, p)
+    gex, gexc, gterm, gq = ctx.debug_eval_terms(s, st, ob)
+    assert np.array_equal(term_det.view(np.uint64), gterm.view(np.uint64)) and np.array_equal(q_det, gq)
+    ol.set_mode(ol.MODE_LIBM)
+    try:
+        _, _, term_libm, _ = ol.eval_terms(s, st, ob, p)
+    finally:
+        ol.set_mode(ol.MODE_DET)
+    clamp = 1048576.0
+    val_det = q_det.astype(np.float64) / 4294967296.0  # what joins the sums
+    inside = np.abs(term_libm) < clamp * (1 - 1e-6)
+    phys = s >= 0.05  # P(s) <= 4.3e3 contacts per pixel: distances a sub-fragment pair can have (below: the count's order for 10^6 .. 10^7)
+    assert inside[(ob <= 150_000) & phys].all()  # every count the golden / live LIBM comparisons reach, and twice beyond
+    # (1e-6 of what the term is made of -- ob log10 P, P, log10 ob! -- : near its zero crossing a term is the small difference of those)
+    scale = np.abs(ob * np.log10(np.maximum(ex.astype(np.float64), 1e-300))) + ex + ob * np.log10(np.maximum(ob, 2).astype(np.float64))
+    assert np.all(np.abs(val_det[inside] - term_libm[inside]) <= 1e-6 * scale[inside] + 1e-9)
+    beyond = ~inside
+    assert beyond.any() and (ob[beyond & phys] >= 300_000).all()
+    assert np.all(np.abs(val_det[beyond]) == clamp)  # the clamp, exactly
+    assert np.all(np.abs(term_libm[beyond]) >= clamp * (1 - 1e-6))
+    big = ob >= 1_000_000
+    print("counts >= 1e6: %d of %d terms inside the clamp (expectation of the count's order), the rest at -2^20; largest reference-shaped term %.3g"
+          % (int((inside & big).sum()), int(big.sum()), float(np.abs(term_libm).max())))
+
+
 def test_full_likelihood_matches_oracle(tiny, oracle_lib):
     from oracle.sampler_oracle import OracleSampler
 

@@ -15,7 +15,7 @@ if os.environ.get("PARAMS", "synthetic") == "settled":
     cfg += "settled"
 outdir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
 KERNELS = {"k_screen": ("_Z13k_screen_tail", "_Z8k_screen"), "k_score_list": "_Z12k_score_list", "k_slice": "_Z7k_slice", "k_tail": "_Z6k_tail",
-           "k_full_nz_tiled": "_Z15k_full_nz_tiled", "k_decide_batch": ("_Z14k_decide_batch", "_Z15k_decide_commit"), "k_mutate": "_Z8k_mutate",
+           "k_full_nz_tiled": "_Z15k_full_nz_tiled", "k_decide_batch": ("_Z14k_decide_batch", "_Z15k_decide_commit", "_Z19k_decide_commit_par"), "k_mutate": "_Z8k_mutate",
            "k_gather": "_Z8k_gather", "k_delta": "_Z7k_delta", "k_offsets": "_Z9k_offsets", "k_contend": "_Z9k_contend", "k_worklist": "_Z10k_worklist",
            "k_records": "_Z9k_records", "k_predict": "_Z9k_predict", "k_commit_batch": "_Z14k_commit_batch"}
 merged = {}
@@ -28,9 +28,19 @@ for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "%s_%s_pmc_pass*.json
                 for c, v in ctrs.items():
                     e[c] = v["avg"]
                     e.setdefault("launches", v["launches"])
+# the bench line of the first counter pass (tools/profile_round.sh keeps it): how many moves a launch chain of the PROFILED run covered --
+# bench.py scales the replayed per-launch traffic to its own run's moves per launch with it
+mpl = None
+try:
+    line = json.load(open(os.path.join(ROOT, "gpurun_out", "%s_%s_pmc_bench_line.json" % (tag, cfg))))
+    mpl = float(line["config"]["moves_per_launch"])
+except Exception:
+    pass
 out = {"command": "tools/profile_round.sh %s: rocprofv3 --pmc <one group per pass> -- python3 bench.py --no-cpu-baseline --nuisance-moves 0 "
-                  "--config %s%s --settled-batches 0 --steps 12 --warmup 2 (12 batches of 24 moves; one MI355X, W = 24 moves per launch)" % (
-                      tag, cfg.replace("settled", ""), " --params settled" if cfg.endswith("settled") else ""),
+                  "--reference-loop-moves 0 --late-moves 0 --config %s%s --settled-batches 0 --steps 8 --warmup 2 (8 steps of 128 moves; one MI355X; "
+                  "%s moves per launch chain)" % (tag, cfg.replace("settled", ""), " --params settled" if cfg.endswith("settled") else "",
+                                                   "%.1f" % mpl if mpl else "?"),
+       "moves_per_launch": mpl,
        "note": "FETCH_SIZE / WRITE_SIZE are KB per dispatch (separate passes). traffic_bytes_per_launch = 2 x FETCH_SIZE (gfx950 "
                "correction of MI355X_MICROARCH.md, calibrated in round 1 on k_full_nz) + WRITE_SIZE.  Instruction counts are per "
                "dispatch and per counter instance as rocprofv3 reports them."}

@@ -8,9 +8,9 @@ NAME=$CFG; [ "$PAR" = "settled" ] && NAME=${CFG}settled
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_kt
-timeout 600 rocprofv3 --kernel-trace -d /tmp/prof_kt -o run -- python3 $R/bench.py --config $CFG --params $PAR --settled-batches 0 --no-cpu-baseline --nuisance-moves 0 --reference-loop-moves 0 --steps 42 --warmup 4 > /tmp/kt.log 2>&1
+timeout 600 rocprofv3 --kernel-trace -d /tmp/prof_kt -o run -- python3 $R/bench.py --config $CFG --params $PAR --settled-batches 0 --no-cpu-baseline --nuisance-moves 0 --reference-loop-moves 0 --late-moves 0 --steps 20 --warmup 5 > /tmp/kt.log 2>&1
 python3 $R/tools/rocprof_stats.py $(find /tmp/prof_kt -name "*.db" | head -1) $R/gpurun_out/${TAG}_${NAME}_kernel_stats.csv \
-  "rocprofv3 --kernel-trace -- python3 bench.py --config $CFG --params $PAR --settled-batches 0 --no-cpu-baseline --nuisance-moves 0 --reference-loop-moves 0 --steps 42 --warmup 4 (one MI355X); aggregated by tools/rocprof_stats.py"
+  "rocprofv3 --kernel-trace -- python3 bench.py --config $CFG --params $PAR --settled-batches 0 --no-cpu-baseline --nuisance-moves 0 --reference-loop-moves 0 --late-moves 0 --steps 20 --warmup 5 (2 560 timed moves; one MI355X); aggregated by tools/rocprof_stats.py"
 tail -1 /tmp/kt.log | cut -c1-400
 [ -n "$SKIP_PMC" ] && exit 0
 i=0
@@ -18,6 +18,7 @@ for CT in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ
   i=$((i+1))
   [ -n "$TRAFFIC_ONLY" ] && [ $i -gt 2 ] && [ $i -ne 4 ] && continue   # FETCH_SIZE, WRITE_SIZE, VALUBusy only
   rm -rf /tmp/pmc$i
-  timeout 600 rocprofv3 --pmc $CT -d /tmp/pmc$i -o run -- python3 $R/bench.py --config $CFG --params $PAR --settled-batches 0 --no-cpu-baseline --nuisance-moves 0 --reference-loop-moves 0 --steps 12 --warmup 2 > /tmp/pmc$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $CT -d /tmp/pmc$i -o run -- python3 $R/bench.py --config $CFG --params $PAR --settled-batches 0 --no-cpu-baseline --nuisance-moves 0 --reference-loop-moves 0 --late-moves 0 --steps 8 --warmup 2 > /tmp/pmc$i.log 2>&1
+  [ $i -eq 1 ] && tail -1 /tmp/pmc1.log > $R/gpurun_out/${TAG}_${NAME}_pmc_bench_line.json
   python3 $R/tools/rocprof_pmc.py $(find /tmp/pmc$i -name "*.db" | head -1) $R/gpurun_out/${TAG}_${NAME}_pmc_pass$i.json | grep -i "score_list\|k_screen\|k_slice" | cut -c1-300
 done
