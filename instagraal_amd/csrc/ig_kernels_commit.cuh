@@ -378,9 +378,6 @@ struct FusedLds {
     int s0_mloc[IG_MAX_BATCH], s0_base[IG_MAX_BATCH];
     int n_chg[IG_MAX_BATCH]; /* per move: fragments whose prev / next / ori change, */
     int chg[FUSED_CHG_CAP];  /* ... and the local indices of the move being applied */
-    /* commit_waves_par (one wave per genome-changing move): a move's marks are up / its credits are read */
-    volatile int mk_done[IG_MAX_BATCH], cr_done[IG_MAX_BATCH];
-    int chgp[3][FUSED_CHG_CAP];
 };
 /* CHAIN (k_decide_chain): a segment of a chain of (move, nuisance step) pairs -- ig_common.cuh, ChainIn.  Behind every decision
  * the step's Metropolis test (CL:3026-3036: exp((L_test - L_move) / T) >= u) against the interval k_chain_hist_eval left for its
@@ -1408,287 +1405,6 @@ __global__ void __launch_bounds__(64 + FUSED_CW * 64)
 }
 
 
-/* ---- round 6: the apply step behind decide_rounds, ONE WAVE PER GENOME-CHANGING MOVE.  commit_waves applies the moves one after the
- * other with all its waves: ~15 us each (marks -> fence -> the credits' dozen dependent loads -> copy -> tables), 2.9 of them per chain at
- * cfg3 -- a backlog of 35 us behind decisions that arrive in bursts (tools/par_trace.py).  The moves of a chain touch disjoint contigs,
- * so here they are applied SIDE BY SIDE: commit wave 0 writes the records (in order: the genome distance is a running sum), waves
- * 1 .. CW - 1 take the genome-changing moves in turn, one wave per move.  What orders them is what k_commit_batch's steps order:
- *   credits(w) read the genome as of moves < w through the marks  -> wait for the marks of every earlier genome-changing move;
- *   copy(w) overwrites state that credits(t < w) read as "not yet applied"  -> wait for the credits of every earlier one;
- *   tables(w): tab_prev takes every move but the last committed one  -> wait for a later decision, or the end.
- * Same words in memory as commit_waves leaves (the credits are integers: any order of summation). */
-template <int NDW, int CW>
-__device__ __forceinline__ void commit_waves_par(State st, Tables tab, Tables tab_prev, Glob* g, MoveBuf mb, const int* __restrict__ ip,
-                                                 const int* __restrict__ in, const int* __restrict__ orientable, const unsigned char* __restrict__ black,
-                                                 int* own_tag, int* own_idx, int* prev_touched, ig_move_result* res, int move0, int W, int w_start,
-                                                 FusedLds* sh)
-{
-    static_assert(CW >= 2 && CW <= 4, "one recorder, 1 .. 3 appliers (FusedLds.chgp)");
-    const int lane = threadIdx.x & 63, ctid = (int)threadIdx.x - 64 * NDW, cwv = ctid >> 6;
-    constexpr int NCT = CW * 64, NA = CW - 1;
-    for (int i = ctid; i < IG_MAX_BATCH; i += NCT) {
-        sh->n_chg[i] = 0;
-        sh->mk_done[i] = 0;
-        sh->cr_done[i] = 0;
-    }
-    for (int w = w_start + (ctid >> 4); w < W; w += NCT / 16) { /* the statistics columns of every slot (commit_waves) */
-        const int c = lane & 15;
-        const int C = mb.ctl[PS(w)].C;
-        long long Sc = 0, ev = 0, by = 0;
-        if (c < C) {
-            const CandMeta& m = mb.meta[CW(w, c)];
-            const CandPre& cp = cpre_at(mb, CW(w, c));
-            const bool apart = (c == 0) && mb.ctl[PS(w)].superset0;
-            Sc = cp.n_slice;
-            if (!apart) {
-                ev = cp.n_slice * (m.n_uniq + 1);
-                by = 12 * cp.n_slice + 20LL * m.m_loc * m.n_uniq + 8LL * m.n_uniq;
-            }
-            if (c == 0) {
-                sh->s0_slice[w] = cp.n_slice;
-                sh->s0_mloc[w] = m.m_loc;
-                sh->s0_base[w] = apart ? cp.base_cnt : -1;
-            }
-        }
-        for (int o = 8; o > 0; o >>= 1) {
-            Sc += __shfl_xor(Sc, o, 64);
-            ev += __shfl_xor(ev, o, 64);
-            by += __shfl_xor(by, o, 64);
-        }
-        if (c == 0) {
-            sh->st_sc[w] = Sc;
-            sh->st_ev[w] = ev;
-            sh->st_by[w] = by;
-        }
-    }
-    const int tag_base = g->stamp_ctr;
-    const int N = mb.sN, M = mb.sM;
-    cw_barrier<CW>(sh, 3 * IG_MAX_BATCH);
-    auto winner_loc = [&](int w) -> const int* { return mb.loc + ((size_t)(CW(w, sh->ch_c[w]) * NSLOT + sh->ch_slot[w]) * NDYN) * N; };
-    auto wait_decisions = [&](int processed, int& upto, int& fin) {
-        for (;;) {
-            fin = sh->prog[1];
-            upto = sh->prog[0];
-            if (upto > processed || fin) break;
-            __builtin_amdgcn_s_sleep(4);
-        }
-        __asm__ volatile("" ::: "memory");
-        if (fin) upto = fin - 1;
-    };
-    int upto, fin;
-    wait_decisions(w_start, upto, fin);
-    if (upto == w_start) return; /* nothing was committed: nothing is touched */
-    { /* tab_prev catches up with the move applied last before this call (k_commit_batch 2c), before any table is written */
-        const int n_prev0 = g->n_prev_touched;
-        for (int i = ctid; i < n_prev0; i += NCT) {
-            const int s2 = prev_touched[i];
-            tab_prev.dist[s2] = tab.dist[s2];
-            tab_prev.stot[s2] = tab.stot[s2];
-            tab_prev.cp[s2] = tab.cp[s2];
-            tab_prev.len[s2] = tab.len[s2];
-        }
-        cw_barrier<CW>(sh, 3 * IG_MAX_BATCH + 1);
-    }
-    if (cwv == 0) { /* ---- the recorder: every move's record, in order */
-        long long c2 = g->credit2;
-        const double norm = 3.0 * (double)(g->N - g->n_black);
-        int processed = w_start;
-        for (;;) {
-            for (int w = processed; w < upto; w++) {
-                if (sh->n_dirty[w]) {
-                    while (!sh->cr_done[w]) __builtin_amdgcn_s_sleep(2);
-                    __asm__ volatile("" ::: "memory");
-                }
-                if (lane == 0) {
-                    const unsigned vmask = (unsigned)sh->vmask[w];
-                    long long Sc = sh->st_sc[w], ev = sh->st_ev[w], by = sh->st_by[w];
-                    if (sh->s0_base[w] >= 0) {
-                        const long long nu = sh->s0_base[w] + __popc(vmask);
-                        ev += sh->s0_slice[w] * (nu + 1);
-                        by += 12 * sh->s0_slice[w] + 20LL * sh->s0_mloc[w] * nu + 8LL * nu;
-                    }
-                    c2 += sh->delta[w];
-                    ig_move_result r = sh->rec[w];
-                    r.n_slice = Sc;
-                    r.n_evals = ev;
-                    r.bytes_min += by;
-                    r.dist = (norm - 0.5 * (double)c2) / norm;
-                    res[move0 + w] = r;
-                }
-            }
-            processed = upto;
-            if (fin) break;
-            wait_decisions(processed, upto, fin);
-        }
-        if (lane == 0) {
-            const int committed = processed;
-            g->credit2 = c2;
-            g->stamp_ctr = tag_base + W + 2;
-            g->n_prev_touched = sh->n_dirty[committed - 1] ? mb.meta[CW(committed - 1, sh->ch_c[committed - 1])].m_loc : 0;
-        }
-        return;
-    }
-    /* ---- an applier: the genome-changing moves number a, a + NA, ... of the launch, each by this one wave */
-    const int a = cwv - 1;
-    /* every earlier genome-changing move has its flag up (lane l looks at move w_start + l: IG_MAX_BATCH = 64 moves, one lane each) */
-    auto earlier_done = [&](int w, volatile int* flags) {
-        for (;;) {
-            const int mv = w_start + lane;
-            const bool ok = mv >= w || !sh->n_dirty[mv] || flags[mv];
-            if (__all(ok)) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    };
-    auto apply_move = [&](int w) {
-        const int cw = CW(w, sh->ch_c[w]);
-        const CandMeta& mm = mb.meta[cw];
-        const int n_loc = mm.n_loc;
-        const int* gid = mb.Lloc + (size_t)cw * N;
-        const int* wl = winner_loc(w);
-        int* chg = sh->chgp[a];
-        if (mb.ring & 4) { /* IG_WINDOW_CHECK=1 (commit_waves) */
-            for (int x = lane; x < n_loc; x += 64) {
-                const int f = gid[x];
-                const bool inA = mm.same || x < mm.LA;
-                const int want_c = inA ? mm.ctgA : mm.ctgB, want_p = inA ? x : x - mm.LA;
-                if (f < 0 || f >= g->N || st.cid[f] != want_c || st.pos[f] != want_p) {
-                    g->error = 12;
-                    g->dbg[0] = w;
-                    g->dbg[1] = x;
-                    g->dbg[2] = f;
-                    g->dbg[7] = n_loc;
-                }
-            }
-        }
-        /* marks, and the fragments whose prev / next / ori change */
-#pragma unroll 2
-        for (int x = lane; x < n_loc; x += 64) {
-            const int f = gid[x];
-            own_tag[f] = tag_base + w;
-            own_idx[f] = x;
-            if (wl[(size_t)5 * N + x] != st.prev[f] || wl[(size_t)6 * N + x] != st.next[f] || wl[(size_t)10 * N + x] != st.ori[f]) {
-                const int at = atomicAdd(&sh->n_chg[w], 1);
-                if (at < FUSED_CHG_CAP) chg[at] = x;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) sh->mk_done[w] = 1;
-        earlier_done(w, sh->mk_done);
-        auto changed_member = [&](int y) -> bool {
-            if (y < 0 || own_tag[y] != tag_base + w) return false;
-            const int xi = own_idx[y];
-            return wl[(size_t)5 * N + xi] != st.prev[y] || wl[(size_t)6 * N + xi] != st.next[y] || wl[(size_t)10 * N + xi] != st.ori[y];
-        };
-        long long d = 0;
-        const int n_chg = sh->n_chg[w];
-        const bool listed = n_chg <= FUSED_CHG_CAP;
-        for (int item = lane; item < 3 * (listed ? n_chg : n_loc); item += 64) {
-            const int x0 = listed ? chg[item / 3] : item / 3;
-            const int f0 = gid[x0];
-            if (!listed && wl[(size_t)5 * N + x0] == st.prev[f0] && wl[(size_t)6 * N + x0] == st.next[f0] && wl[(size_t)10 * N + x0] == st.ori[f0])
-                continue;
-            const int q = item % 3;
-            const int f = (q == 0) ? f0 : ((q == 1) ? ip[f0] : in[f0]);
-            if (f < 0 || black[f]) continue;
-            if (q > 0) {
-                if (changed_member(f)) continue;
-                if (q == 2 && (ip[f0] == f || changed_member(in[f]))) continue;
-            }
-            auto view_at = [&](int t) {
-                return [=](int x) -> int3 {
-                    const int tg = own_tag[x] - tag_base;
-                    if (tg >= 0 && tg <= t) {
-                        const int* b = winner_loc(tg);
-                        const int xi = own_idx[x];
-                        return make_int3(b[(size_t)5 * N + xi], b[(size_t)6 * N + xi], b[(size_t)10 * N + xi]);
-                    }
-                    return make_int3(st.prev[x], st.next[x], st.ori[x]);
-                };
-            };
-            d += credit2_view(view_at(w), ip, in, orientable, f) - credit2_view(view_at(w - 1), ip, in, orientable, f);
-        }
-        d = wave_sum_ll(d);
-        if (lane == 0) {
-            sh->delta[w] = d; /* (zero at the kernel's start; this wave alone adds to it) */
-            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            sh->cr_done[w] = 1;
-        }
-        earlier_done(w, sh->cr_done);
-        /* the winner becomes the live genome */
-#pragma unroll 2
-        for (int x = lane; x < n_loc; x += 64) {
-            const int f = gid[x];
-            st.pos[f] = wl[x];
-            st.spos[f] = wl[(size_t)N + x];
-            st.cid[f] = wl[(size_t)2 * N + x];
-            st.sbp[f] = wl[(size_t)3 * N + x];
-            st.circ[f] = wl[(size_t)4 * N + x];
-            st.prev[f] = wl[(size_t)5 * N + x];
-            st.next[f] = wl[(size_t)6 * N + x];
-            st.L[f] = wl[(size_t)7 * N + x];
-            st.SL[f] = wl[(size_t)8 * N + x];
-            st.LB[f] = wl[(size_t)9 * N + x];
-            st.ori[f] = wl[(size_t)10 * N + x];
-        }
-        /* the coordinate tables: is this the last committed move?  (a later decision, or the end, says) */
-        bool last;
-        for (;;) {
-            const int f2 = sh->prog[1], u2 = sh->prog[0];
-            if (u2 > w + 1) {
-                last = false;
-                break;
-            }
-            if (f2) {
-                last = (w == f2 - 2);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        {
-            const int k = sh->ch_k[w];
-            const uint2* col = mb.coords + (size_t)(cw * NSLOT + k) * M;
-            const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
-            const int* subs = mb.subs + (size_t)cw * M;
-            const int fresh = mb.ctl[PS(w)].fresh;
-            const int m_loc = mm.m_loc, cA = mm.ctgA, cB = mm.ctgB;
-#pragma unroll 4
-            for (int ls = lane; ls < m_loc; ls += 64) {
-                const int s = subs[ls];
-                const uint2 v = col[ls];
-                const int code = (int)(v.y >> 28);
-                const float dist = __uint_as_float(v.x);
-                const int2 cp = make_int2(code == 0 ? cA : (code == 1 ? cB : fresh + (code - 2)), (int)(v.y & 0x0fffffffu));
-                const float stot = cm[code].stot;
-                const int len = cm[code].len;
-                tab.dist[s] = dist;
-                tab.cp[s] = cp;
-                tab.stot[s] = stot;
-                tab.len[s] = len;
-                if (last) {
-                    prev_touched[ls] = s;
-                } else {
-                    tab_prev.dist[s] = dist;
-                    tab_prev.cp[s] = cp;
-                    tab_prev.stot[s] = stot;
-                    tab_prev.len[s] = len;
-                }
-            }
-        }
-    };
-    int processed = w_start, n_seen = 0;
-    for (;;) {
-        for (int w = processed; w < upto; w++) {
-            if (!sh->n_dirty[w]) continue;
-            if ((n_seen++ % NA) != a) continue;
-            apply_move(w);
-        }
-        processed = upto;
-        if (fin) break;
-        wait_decisions(processed, upto, fin);
-    }
-}
-
 /* ---- round 6: the decisions of a launch chain in ROUNDS (k_decide_commit was 105 us per chain of ~35 decisions,
  * one wave at ~3 us per decision next to an idle machine).
  *
@@ -2111,8 +1827,15 @@ __device__ __forceinline__ void decide_rounds(Glob* g, MoveBuf mb, ig_move_resul
                 atomicAdd(&g->dbg[6], (int)(wall_clock64() - q3));
             }
 #endif
-            if (dwv == 0 && lane == 0 && np > 0) sh->prog[0] = base + np; /* the prefix goes to the commit waves (their records were in LDS before the barrier);
-                                                                           * the last one too: the epilogue's scan runs next to their work on it */
+            if (dwv == 0 && lane == 0) { /* the prefix goes to the commit waves (their records were in LDS before the barrier) */
+                if (np > 0) sh->prog[0] = base + np;
+                /* ... and, with the last one, the final count: the epilogue's scan (13 us) runs next to their work, and the last
+                 * genome-changing move's tables -- which wait to hear whether it is the last committed one -- do not wait for it */
+                if (f) {
+                    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    sh->prog[1] = ps->committed + 1;
+                }
+            }
             if (f) {
                 fin = true;
                 return;
@@ -2231,8 +1954,6 @@ __device__ __forceinline__ void decide_rounds(Glob* g, MoveBuf mb, ig_move_resul
         sh->fin_max_SL = max_SL;
     }
     if (lane < 12) g->valid_insert[lane] = ((vmask >> lane) & 1u) ? 1 : -1;
-    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) sh->prog[1] = committed + 1;
 #ifdef IG_PAR_TRACE
     if (lane == 0) { /* (tuning builds: 10 ns ticks, summed over the launches -- ig_debug_dbg) */
         atomicAdd(&g->dbg[0], 1);
@@ -2266,7 +1987,7 @@ __global__ void __launch_bounds__(DPAR * 64 + DPAR_CW * 64)
     const long long tk0 = wall_clock64();
 #endif
     if (threadIdx.x < DPAR * 64) decide_rounds(g, mb, res, move0, W, w_start, dirty_buf, batch_out, host_out, seq, resumed_plain, &sh, &ps, zcheck);
-    else commit_waves_par<DPAR, DPAR_CW>(st, tab, tab_prev, g, mb, ip, in, orientable, black, own_tag, own_idx, prev_touched, res, move0, W, w_start, &sh);
+    else commit_waves<DPAR, DPAR_CW>(st, tab, tab_prev, g, mb, ip, in, orientable, black, own_tag, own_idx, prev_touched, res, move0, W, w_start, nullptr, 0, &sh);
 #ifdef IG_PAR_TRACE
 #if IG_PAR_TRACE != 3
     if (threadIdx.x == DPAR * 64) atomicAdd(&g->dbg[6], (int)(wall_clock64() - tk0)); /* the commit waves' end */
