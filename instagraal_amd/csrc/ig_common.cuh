@@ -199,6 +199,8 @@ struct MoveBuf {
     unsigned long long* work;
     int work_cap;
     int* slot_items; /* [capW][8] work items a slot puts on each of the eight sub-lists (k_contend -> k_worklist) */
+    int* pred_list;  /* [1 + capW] k_predict -> k_delta: how many positions have a predicted windowed winner, and which (round 6: k_delta's grid
+                      * covers those -- one or two of a chain's 36 slots -- instead of every slot: 9 216 workgroups that left on their first load) */
     int* order;      /* [capW * capC] the (slot, candidate) pairs of the batch by falling size of their slice lists (w << 8 | c; k_offsets):
                       * the screening launch hands out the long ones first */
     /* set while the parameter-dependent half of slots scored EARLIER is redone (enqueue_score, par_only): {n, contig ids modified by

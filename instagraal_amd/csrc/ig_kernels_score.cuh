@@ -464,13 +464,18 @@ __global__ void __launch_bounds__(OFFSETS_THREADS) k_offsets(MoveBuf mb, int W, 
         const int w = cwl / mb.capC, c = cwl % mb.capC;
         return (w >= w_begin && w < w_end && !KEPT(w) && c < mb.ctl[PS(w)].C) ? mb.slbound[phys(i)] : -1; /* -1: not an entry of this launch */
     };
+    /* a thread's entries stay in registers over the three passes (round 6: each pass used to load them again -- control block, then
+     * bound: two dependent round trips per entry and pass, a dozen of the kernel's 20 us); n <= 64 x 16 x 16: at most 16 per thread */
+    constexpr int PER_MAX = (IG_MAX_BATCH * IG_MAX_CANDIDATES * SLICE_SEG + OFFSETS_THREADS - 1) / OFFSETS_THREADS;
+    long long bq[PER_MAX];
+    __shared__ int s_over[IG_MAX_BATCH]; /* slot (position) w has a list that does not fit the pool */
+    if (tid < IG_MAX_BATCH) s_over[tid] = 0;
     long long sum = 0;
-    for (int q = 0; q < per; q++) {
+#pragma unroll
+    for (int q = 0; q < PER_MAX; q++) {
         const int i = tid * per + q;
-        if (i < n) {
-            const long long b = bound_of(i);
-            sum += b > 0 ? b : 0;
-        }
+        bq[q] = (q < per && i < n) ? bound_of(i) : -1;
+        sum += bq[q] > 0 ? bq[q] : 0;
     }
     long long incl = sum;
     for (int off = 1; off < 64; off <<= 1) {
@@ -481,26 +486,27 @@ __global__ void __launch_bounds__(OFFSETS_THREADS) k_offsets(MoveBuf mb, int W, 
     __syncthreads();
     long long run = incl - sum;
     for (int q = 0; q < wv; q++) run += wave_tot[q];
-    for (int q = 0; q < per; q++) {
+#pragma unroll
+    for (int q = 0; q < PER_MAX; q++) {
         const int i = tid * per + q;
-        if (i < n) {
-            const long long b = bound_of(i);
-            if (b >= 0) {
-                if (run + b > mb.pool_cap) {
-                    mb.sloff[phys(i)] = -1;
-                    mb.ctl[PS(i / SLICE_SEG / mb.capC)].overflow = 1;
-                } else {
-                    mb.sloff[phys(i)] = run;
-                }
-                run += b;
+        const long long b = bq[q];
+        if (b >= 0) {
+            if (run + b > mb.pool_cap) {
+                mb.sloff[phys(i)] = -1;
+                mb.ctl[PS(i / SLICE_SEG / mb.capC)].overflow = 1;
+                s_over[i / SLICE_SEG / mb.capC] = 1;
+            } else {
+                mb.sloff[phys(i)] = run;
             }
+            run += b;
         }
     }
     /* a slot that does not fit is re-run as a whole: all its segments are marked */
     __syncthreads();
-    for (int q = 0; q < per; q++) {
+#pragma unroll
+    for (int q = 0; q < PER_MAX; q++) {
         const int i = tid * per + q;
-        if (i < n && bound_of(i) >= 0 && mb.ctl[PS(i / SLICE_SEG / mb.capC)].overflow) mb.sloff[phys(i)] = -1;
+        if (bq[q] >= 0 && s_over[i / SLICE_SEG / mb.capC]) mb.sloff[phys(i)] = -1;
     }
     /* the (slot, candidate) pairs of this launch by falling list size: the screening kernel's workgroups are as long as their
      * candidate's lists (two grown contigs: ten times the median), and the long ones handed out last were the launch's tail
@@ -1653,7 +1659,12 @@ __global__ void __launch_bounds__(SCORE_THREADS)
      * sum under the new parameters = their full pass on the state before the move + this delta); the caller passes the
      * tables of the state before the move as `tab` */
     if (predicted == 1) {
-        w += blockIdx.z;
+        if (mb.pred_list) { /* the positions k_predict listed (at most gridDim.z of them: it listed no more) */
+            if ((int)blockIdx.z >= min(mb.pred_list[0], (int)gridDim.z)) return;
+            w = mb.pred_list[1 + blockIdx.z];
+        } else {
+            w += blockIdx.z;
+        }
         if (KEPT(w)) return;
     }
     /* tab_prev catches up with the last applied move before k_apply replaces the touched list (quirk Q12) */
@@ -1782,7 +1793,7 @@ __global__ void __launch_bounds__(SCORE_THREADS)
 /* (until round 5 two launches: pass 0 left every slot's winner under the flags of its predecessor's last candidate, pass 1 read the
  * predecessor's.  A block now redoes its predecessor's first pass itself -- one argmax more per block, one launch and one dependent
  * dispatch less per chain) */
-__global__ void __launch_bounds__(256) k_predict(Glob* g, MoveBuf mb, int w_begin)
+__global__ void __launch_bounds__(256) k_predict(Glob* g, MoveBuf mb, int w_begin, int zcap)
 {
     __shared__ double sc[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT];
     __shared__ int s_best;
@@ -1870,10 +1881,16 @@ __global__ void __launch_bounds__(256) k_predict(Glob* g, MoveBuf mb, int w_begi
         const SlotPre r = pre_at(mb, CW(w, c), slot);
         const bool windowed = (cpre_at(mb, CW(w, c)).same_windowed >> 1) & 1;
         if (windowed && (r.info & 1u) && r.k > 0) {
-            mc.pred = best;
-            cpre_at(mb, CW(w, 0)).pred = best; /* travels with the records; pd_hi / pd_lo (zeroed by k_records) are k_delta's */
-            mc.pred_c = c;
-            mc.pred_k = r.k;
+            /* onto k_delta's list -- the launch behind this one covers zcap positions; one more than that stays unpredicted (the decide
+             * step then pauses for it as for any wrong prediction: the one-move tail) */
+            const int at = mb.pred_list ? atomicAdd(&mb.pred_list[0], 1) : 0;
+            if (at < zcap) {
+                if (mb.pred_list) mb.pred_list[1 + at] = w;
+                mc.pred = best;
+                cpre_at(mb, CW(w, 0)).pred = best; /* travels with the records; pd_hi / pd_lo (zeroed by k_records) are k_delta's */
+                mc.pred_c = c;
+                mc.pred_k = r.k;
+            }
         }
     }
 }
@@ -2083,6 +2100,7 @@ __global__ void __launch_bounds__(256) k_tail(const long long* __restrict__ rowp
 __global__ void __launch_bounds__(64) k_records(MoveBuf mb, int w_begin, int contenders_only)
 {
     const int c = blockIdx.x, w = w_begin + blockIdx.y;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && mb.pred_list) mb.pred_list[0] = 0; /* k_predict, the next launch, lists afresh */
     if (KEPT(w) || c >= mb.ctl[PS(w)].C) return;
     const int cw = CW(w, c);
     const CandMeta& m = mb.meta[cw];

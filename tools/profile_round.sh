@@ -19,6 +19,6 @@ for CT in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ
   [ -n "$TRAFFIC_ONLY" ] && [ $i -gt 2 ] && [ $i -ne 4 ] && continue   # FETCH_SIZE, WRITE_SIZE, VALUBusy only
   rm -rf /tmp/pmc$i
   timeout 600 rocprofv3 --pmc $CT -d /tmp/pmc$i -o run -- python3 $R/bench.py --config $CFG --params $PAR --settled-batches 0 --no-cpu-baseline --nuisance-moves 0 --reference-loop-moves 0 --late-moves 0 --steps 8 --warmup 2 > /tmp/pmc$i.log 2>&1
-  [ $i -eq 1 ] && tail -1 /tmp/pmc1.log > $R/gpurun_out/${TAG}_${NAME}_pmc_bench_line.json
+  [ $i -eq 1 ] && grep '^{' /tmp/pmc1.log | tail -1 > $R/gpurun_out/${TAG}_${NAME}_pmc_bench_line.json
   python3 $R/tools/rocprof_pmc.py $(find /tmp/pmc$i -name "*.db" | head -1) $R/gpurun_out/${TAG}_${NAME}_pmc_pass$i.json | grep -i "score_list\|k_screen\|k_slice" | cut -c1-300
 done
