@@ -70,6 +70,36 @@ __global__ void __launch_bounds__(256)
         const int b = cands_all[(size_t)move0 * max_c + i];
         sh_cB[(i / max_c) * IG_MAX_CANDIDATES + (i % max_c)] = b >= 0 ? st.cid[b] : -1;
     }
+    /* which windows hold a contig: a hash of the launch's contig ids -> its entries (position w; candidate c, or "the focal contig of every
+     * candidate of w").  Until round 6 every fragment walked all W x C windows for its contig id -- wave-uniform LDS loads, 8 per window,
+     * one after the other: 1 400 dependent LDS round trips per wave for a launch of 36 slots, most of the kernel's 41 us, to find that 99 %
+     * of the fragments are in none (tools note in DESIGN 4.2).  Every block builds the same table (300 inserts). */
+    constexpr int GH = 1024, GE = IG_MAX_BATCH * (IG_MAX_CANDIDATES + 1);
+    __shared__ int gh_head[GH];
+    __shared__ int gh_cid[GE], gh_code[GE], gh_next[GE];
+    __shared__ int gh_n;
+    for (int i = threadIdx.x; i < GH; i += blockDim.x) gh_head[i] = -1;
+    if (threadIdx.x == 0) gh_n = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < W * (max_c + 1); i += blockDim.x) {
+        const int w = i / (max_c + 1), q = i % (max_c + 1); /* q == 0: the focal contig; q > 0: candidate q - 1's */
+        if (KEPT(w)) continue; /* (a slot of the window scored by an earlier launch and still valid: its lists stand) */
+        const int cA = sh_cA[w];
+        int cid, code;
+        if (q == 0) {
+            cid = cA;
+            code = (w << 8) | 0xff;
+        } else {
+            if (q - 1 >= sh_C[w]) continue;
+            cid = sh_cB[w * IG_MAX_CANDIDATES + q - 1];
+            if (cid == cA) continue; /* (a candidate in the focal contig: that contig's entry fills its window) */
+            code = (w << 8) | (q - 1);
+        }
+        const int e = atomicAdd(&gh_n, 1);
+        gh_cid[e] = cid;
+        gh_code[e] = code;
+        gh_next[e] = atomicExch(&gh_head[(unsigned)cid * 2654435761u >> 22], e);
+    }
     __syncthreads();
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f < N) {
@@ -77,15 +107,15 @@ __global__ void __launch_bounds__(256)
         const int lb = st.lb[f], sl = st.sl[f];
         const int sf = st.sub_first[f]; /* (with the others: not a round trip of its own for the fragments that need it) */
         bool in_window = false;
-        for (int w = 0; w < W; w++) {
-            if (KEPT(w)) continue; /* (a slot of the window scored by an earlier launch and still valid: its lists stand) */
-            const int cA = sh_cA[w], LA = sh_LA[w], C = sh_C[w];
-            for (int c = 0; c < C; c++) {
-                int slot = -1;
-                if (cf == cA) slot = pf;
-                else if (cf == sh_cB[w * IG_MAX_CANDIDATES + c]) slot = LA + pf;
+        for (int e = gh_head[(unsigned)cf * 2654435761u >> 22]; e >= 0; e = gh_next[e]) {
+            if (gh_cid[e] != cf) continue;
+            const int code = gh_code[e], w = code >> 8, cq = code & 0xff;
+            const bool focal = cq == 0xff;
+            const int slot = focal ? pf : sh_LA[w] + pf;
+            const int c_lo = focal ? 0 : cq, c_hi = focal ? sh_C[w] : cq + 1;
+            for (int c = c_lo; c < c_hi; c++) {
                 if (slot >= sN) g->error = 9; /* a window beyond the buffers' stride: the host's bound on the contig lengths failed */
-                else if (slot >= 0) {
+                else {
                     const size_t o = (size_t)CW(w, c) * sN + slot;
                     mb.Lloc[o] = f;
                     mb.lbloc[o] = lb;
