@@ -310,7 +310,9 @@ struct NuisHist {
  * batch's score records in order, tests each step against its interval with the live likelihood in registers, and stops in
  * front of the first pair that needs the host -- a test that is not a certain rejection, a conflict, a pending windowed winner,
  * an overflow -- or behind the first move that changes the genome (the histogram has to follow it before the next segment). */
+#ifndef CHAIN_SEG
 #define CHAIN_SEG 8    /* test parameter sets evaluated per segment */
+#endif
 #define CHAIN_MAX 64   /* ... uploaded per call */
 #define DIFF_FIX 1048576.0 /* 2^20: the screened nuisance passes publish sums and bounds as integers (deterministic totals) */
 struct ChainIn {       /* host -> device, per step: the test parameters (KA:91-100 order) and ln of the acceptance uniform */
