@@ -786,7 +786,8 @@ __global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
  * out to be (candidate 0 of a slot w > 0 is screened with ALL block-insert slots, quirk Q4).  cont[cw]: bit k = column k
  * goes through the exact kernel (bit 0, the current genome's column, with any other bit). */
 __global__ void __launch_bounds__(256) k_contend(Glob* g, MoveBuf mb, const ScreenSum* __restrict__ scr, const unsigned* __restrict__ scr_void,
-                                                 const unsigned* __restrict__ scr_ub, unsigned* __restrict__ cont, int w_begin, int force_all, int grid_cap, int chunk0)
+                                                 const unsigned* __restrict__ scr_ub, unsigned* __restrict__ cont, int w_begin, int force_all, int grid_cap, int chunk0,
+                                                 int inline_worklist)
 {
     __shared__ double s_lo[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT], s_hi[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT];
     __shared__ int s_kind[IG_MAX_CANDIDATES * IG_N_TMP_STRUCT]; /* 0 not scored, 1 always scored, 2 depends on the flags, 3 void bound */
@@ -924,6 +925,44 @@ __global__ void __launch_bounds__(256) k_contend(Glob* g, MoveBuf mb, const Scre
         atomic_add_ll(&g->scr_cont, cnt);
         atomic_add_ll(&g->scr_terms, tcols);
         atomic_add_ll(&g->scr_terms_exact, tcnt);
+    }
+    /* a launch of ONE slot (ig_step_draw: one move per call): the slot's part of the work list right here, from the masks and counts
+     * in LDS -- k_worklist's arithmetic with nothing in front of the slot; its launch (5 us of a 143 us call) is left out (round 6) */
+    if (inline_worklist) {
+        __shared__ int wl_cnt[8], wl_fit;
+        if (tid == 0) {
+            bool fit = true;
+            for (int x = 0; x < 8; x++) fit &= 8LL * s_items[x] <= (long long)grid_cap;
+            wl_fit = fit;
+            if (!fit && mb.ctl[PS(w)].overflow == 0) mb.ctl[PS(w)].overflow = 2; /* (never over a 1: k_worklist) */
+            for (int x = 0; x < 8; x++) {
+                if (fit) atomicMax(&mb.work[x], (unsigned long long)s_items[x]);
+                atomicMax(&mb.work[8 + x], (unsigned long long)s_items[x]);
+            }
+        }
+        if (tid < 8) wl_cnt[tid] = 0;
+        __syncthreads();
+        if (!wl_fit) return;
+        const long long ch = s_kind[0];
+        for (int u = tid; u < C * SLICE_SEG; u += blockDim.x) {
+            const int c = u / SLICE_SEG, seg = u % SLICE_SEG;
+            const int cw = CW(w, c);
+            const long long n_seg = mb.part[(size_t)cw * P_STRIDE + P_CNT + seg];
+            const int nch = (int)((n_seg + ch - 1) / ch);
+            const unsigned mask = s_mask[c] & ~s_ident[c];
+            if (!nch || !mask) continue;
+            const int x = seg & 7;
+            int j = atomicAdd(&wl_cnt[x], nch * __popc(mask));
+            for (int q = 0; q < nch; q++) {
+                unsigned m = mask;
+                while (m) {
+                    const int k = __ffs(m) - 1;
+                    m &= m - 1;
+                    mb.work[16 + 8 * (size_t)(j++) + x] =
+                        ((unsigned long long)q << 32) | ((unsigned long long)cw << 12) | ((unsigned long long)k << 4) | (unsigned)seg;
+                }
+            }
+        }
     }
 }
 
