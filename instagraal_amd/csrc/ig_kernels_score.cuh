@@ -1938,8 +1938,12 @@ struct TailLds {
     int hist[256];
 };
 __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* __restrict__ cc, Tables tab, Glob* g, MoveBuf mb,
-                              const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int w_begin, int c, int w_rel, TailLds& TL)
+                              const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int w_begin, int c, int w_rel, TailLds& TL, int tpart = 0,
+                              int tparts = 1)
 {
+    /* tpart / tparts (round 6): a launch of ONE slot deals a candidate's columns to several workgroups -- each finds the same tail entries
+     * (the same words into the slot's cache) and evaluates the columns k = tpart (mod tparts): the walk's six serial column passes per
+     * wave, three or four dependent round trips each, were the longest chain of a one-move call */
     const int w = w_begin + w_rel;
     if (KEPT(w) || c >= mb.ctl[PS(w)].C) return;
     const int cw = CW(w, c);
@@ -1955,6 +1959,7 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
     const int* rowcnt = mb.rowcnt + (size_t)cw * M;
     const int ncol = m.n_uniq + 1;
     for (int k = tid; k < ncol; k += blockDim.x) {
+        if (k % tparts != tpart) continue; /* (its own columns only: another part may be through with its own already) */
         qp[Q_TAIL + 2 * k] = 0;
         qp[Q_TAIL + 2 * k + 1] = 0;
     }
@@ -1969,7 +1974,8 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
     const int r = (int)(Sc % 64);
     if (!(tail_quirk && r > 0)) return;
     int n_tail;
-    const int cached = mb.tail_n[cw];
+    /* (several parts: a fresh slot, every part walks -- part 0's words for the cache may be on their way while another part looks) */
+    const int cached = tparts > 1 ? -1 : mb.tail_n[cw];
     if (cached >= 0) { /* found when this slot was scored before (under other parameters): only the terms are new */
         n_tail = min(cached, 64);
         if (tid < n_tail) {
@@ -2091,14 +2097,14 @@ __device__ void prefinal_tail(const long long* __restrict__ rowptr, const int2* 
         g->dbg[6] = mb.rot;
         g->dbg[7] = m.m_loc;
     }
-    if (tid < n_tail) {
+    if (tid < n_tail && tpart == 0) {
         mb.tail_ent[(size_t)cw * 192 + tid] = TL.t_li[tid];
         mb.tail_ent[(size_t)cw * 192 + 64 + tid] = TL.t_lj[tid];
         mb.tail_ent[(size_t)cw * 192 + 128 + tid] = TL.t_ob[tid];
     }
-    if (tid == 0) mb.tail_n[cw] = n_tail;
+    if (tid == 0 && tpart == 0) mb.tail_n[cw] = n_tail;
     }
-    for (int k = 1 + wv; k < ncol; k += 4) {
+    for (int k = (tpart == 0 ? tparts : tpart) + tparts * wv; k < ncol; k += 4 * tparts) { /* (tparts = 1: k = 1 + wv, 5 + wv, ...) */
         const uint2* col = mb.coords + (size_t)(cw * NSLOT + k) * M;
         const ColMeta* cm = mb.cmeta + (size_t)(cw * NSLOT + k) * NCODE;
         long long hi = 0, lo = 0;

@@ -765,14 +765,16 @@ __global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
 __global__ void __launch_bounds__(SCORE_THREADS, SCREEN_MIN_WAVES)
     k_screen_tail(const ScreenConst* __restrict__ sc, MoveBuf mb, ScreenSum* __restrict__ scr, unsigned* __restrict__ scr_void,
                   unsigned* __restrict__ scr_ub, int max_c, int w_begin, int n_tail, const long long* __restrict__ rowptr,
-                  const int2* __restrict__ cc, Tables tab, Glob* g, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int use_order, int Q)
+                  const int2* __restrict__ cc, Tables tab, Glob* g, const double* __restrict__ lgf_tab, int tail_quirk, PzTab pz, int use_order, int Q,
+                  int tsplit)
 {
     /* one block of LDS for either kind of workgroup (the tail walk's 2.3 KB on top of the screening block's 20.2 KB cost the eighth
      * workgroup per CU) */
     __shared__ __align__(16) unsigned char lds_raw[sizeof(ScreenLds2) > sizeof(TailLds) ? sizeof(ScreenLds2) : sizeof(TailLds)];
     const int b = (int)blockIdx.x;
     if (b < n_tail) {
-        prefinal_tail(rowptr, cc, tab, g, mb, lgf_tab, tail_quirk, pz, w_begin, b % max_c, b / max_c, *(TailLds*)lds_raw);
+        const int bb = b / tsplit; /* tsplit workgroups per (candidate, slot): the columns dealt out among them (prefinal_tail) */
+        prefinal_tail(rowptr, cc, tab, g, mb, lgf_tab, tail_quirk, pz, w_begin, bb % max_c, bb / max_c, *(TailLds*)lds_raw, b % tsplit, tsplit);
         return;
     }
     const int s = b - n_tail, ny = (NSLOT + 1) / 2, nseg = mb.nseg, nxq = nseg * Q; /* x: segment fastest (block -> XCD), then the part of it */
